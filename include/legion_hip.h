@@ -1,0 +1,198 @@
+/*
+ * legion_hip.h -- C ABI of liblegion_hip.so, the MI355X-native (gfx950) drop-in for the hot path
+ * of RC4ML/Legion's sampling server: seed batch -> multi-hop CSR neighbour sampling -> node
+ * de-duplication -> feature-cache lookup + gather, plus the one-time hotness -> cache-partition ->
+ * fill set-up that feeds it.
+ *
+ * Every entry point cites the reference interface it replaces (paths relative to the reference
+ * repository; SS = sampling_server/src).  Signatures carry plain pointers and sizes only: no
+ * torch types, no C++ types.  Object arguments are opaque handles to the library's own
+ * GraphStorage / FeatureStorage / UnifiedCache / MemoryPool / IPCEnv objects (the reference passes
+ * pointers to its C++ classes of the same names through the same positions).
+ *
+ * Error convention (SS/engine/operator_impl.cu:16-24,141-148): functions return void; a null
+ * object prints a message and returns; any HIP error prints "HIP failure file:line: 'msg'" and
+ * exits the process.  There is NO CPU fallback anywhere in this library.
+ */
+#ifndef LEGION_HIP_H
+#define LEGION_HIP_H
+
+#include <stdbool.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* SS/include/system_config.cuh:47-57 -- part of the wire contract */
+#define LEGION_INTERBATCH_CON 2
+#define LEGION_INTRABATCH_CON 3
+#define LEGION_MAX_DEVICE 8
+#define LEGION_MEMORY_USAGE 7
+#define LEGION_TRAINMODE 0
+#define LEGION_VALIDMODE 1
+#define LEGION_TESTMODE 2
+#define LEGION_CACHEMISS_FLAG (-2)
+
+typedef void* legion_stream_t;            /* hipStream_t in the position of cudaStream_t */
+typedef struct LegionGraphStorage   LegionGraphStorage;    /* SS/storage/graph_storage.cuh:7-24  */
+typedef struct LegionFeatureStorage LegionFeatureStorage;  /* SS/storage/feature_storage.cuh:6-34 */
+typedef struct LegionUnifiedCache   LegionUnifiedCache;    /* SS/cache/cache.cuh:66-177 */
+typedef struct LegionMemoryPool     LegionMemoryPool;      /* SS/engine/memorypool.cuh:20-221 */
+typedef struct LegionIPCEnv         LegionIPCEnv;          /* SS/engine/ipc_service.h:6-33 */
+typedef struct LegionServer         LegionServer;          /* SS/engine/server.h:16-23 */
+
+/* =====================================================================================
+ * 1. The five operator entry points -- SS/engine/operator_impl.cuh:11-63, same names, same
+ *    argument order and meaning.  All work is enqueued on `strm_hdl`; nothing synchronises
+ *    with the host (the reference's blocking 64-byte counter read-backs are gone: frontier and
+ *    node counts stay on the device and every kernel reads them there).
+ * ===================================================================================== */
+void BatchGenerate(legion_stream_t strm_hdl, LegionFeatureStorage* feature, LegionUnifiedCache* cache,
+                   LegionMemoryPool* memorypool, int32_t batch_size, int32_t counter, int32_t part_id,
+                   int32_t dev_id, int32_t mode, bool is_presc, int32_t hop_num);
+void RandomSample(legion_stream_t strm_hdl, LegionGraphStorage* graph, LegionUnifiedCache* cache,
+                  LegionMemoryPool* memorypool, int32_t count, int32_t dev_id, int32_t op_id,
+                  bool is_presc);
+void FeatureCacheLookup(legion_stream_t strm_hdl, LegionUnifiedCache* cache, LegionMemoryPool* memorypool,
+                        int32_t op_id, int32_t dev_id);
+void IOSubmit(legion_stream_t strm_hdl, LegionFeatureStorage* feature, LegionMemoryPool* memorypool,
+              int32_t op_id, int32_t dev_id);
+void IOComplete(legion_stream_t strm_hdl, LegionUnifiedCache* cache, LegionMemoryPool* memorypool,
+                int32_t dev_id, int32_t mode);
+
+/* One whole mini-batch in the op order of GPURunner::RunOnce / RunPreSc (SS/engine/server.cu:285-332)
+ * without the IPC hand-off.  In PreSC mode only ops 0,3,6,...,last run (server.cu:290). */
+void legion_enqueue_batch(legion_stream_t strm_hdl, LegionGraphStorage* graph, LegionFeatureStorage* feature,
+                          LegionUnifiedCache* cache, LegionMemoryPool* memorypool, int32_t batch_size,
+                          int32_t counter, int32_t dev_id, int32_t mode, bool is_presc,
+                          const int32_t* fanout, int32_t hop_num);
+
+/* =====================================================================================
+ * 2. Object construction from plain buffers (replaces StorageManagement::Initialze's wiring,
+ *    SS/storage/storage_management.cu:234-269, for callers that already hold the arrays).
+ *    "devptr" = a pointer the GPU can dereference: HBM (hipMalloc / a torch CUDA tensor) or
+ *    mapped pinned host memory.  On MI355X the full CSR and, when it fits, the full feature
+ *    table live in HBM; the pinned-host tier is the spill-over.
+ * ===================================================================================== */
+
+/* GraphStorage: SS/storage/graph_storage.cu:12-73.  Slot `partition_count` of the pointer
+ * tables is the full CSR (int64 indptr[N+1], int32 col[E]). */
+LegionGraphStorage* legion_graph_create(int32_t partition_count, int32_t node_num, int64_t edge_num,
+                                        const int64_t* csr_node_index_devptr,
+                                        const int32_t* csr_dst_node_ids_devptr);
+void legion_graph_destroy(LegionGraphStorage* g);
+
+/* FeatureStorage: SS/storage/feature_storage.cu:18-90.  ids/labels are HOST arrays copied to
+ * device `dev_id`; mode selects the training / validation / testing set. */
+LegionFeatureStorage* legion_feature_create(int32_t partition_count, int32_t total_num_nodes,
+                                            int32_t float_feature_len,
+                                            const float* all_float_feature_devptr);
+void legion_feature_set_ids(LegionFeatureStorage* f, int32_t dev_id, int32_t mode,
+                            const int32_t* host_ids, const int32_t* host_labels, int32_t count);
+void legion_feature_destroy(LegionFeatureStorage* f);
+
+/* MemoryPool + its buffers: SS/engine/server.cu:172-273 (GPURunner::Initialize buffer
+ * allocation) and SS/engine/ipc_service.cu:134-211 (the 7 IPC-shared outputs per pipe slot).
+ * fanout/hop_num size num_ids = B(1 + f1 + f1 f2 + ...) (SS/engine/server.cu:187-199). */
+LegionMemoryPool* legion_pool_create(int32_t dev_id, int32_t total_num_nodes, int32_t batch_size,
+                                     const int32_t* fanout, int32_t hop_num, int32_t float_feature_len,
+                                     int32_t pipeline_depth);
+/* SS/engine/server.cu:275-283: rows = int(1.2 * MaxIdNum) in the reference; caller passes rows. */
+void legion_pool_alloc_features(LegionMemoryPool* p, int64_t rows);
+void legion_pool_set_current_pipe(LegionMemoryPool* p, int32_t pipe);
+void legion_pool_set_mode_iter(LegionMemoryPool* p, int32_t mode, int32_t iter);
+int32_t legion_pool_num_ids(const LegionMemoryPool* p);
+/* which: 0 sampled_ids 1 float_features 2 labels 3 agg_src_off 4 agg_dst_off 5 node_counter
+ *        6 edge_counter (the IPC slot order, SS/engine/ipc_service.cu:163-169,203);
+ *        7 agg_src_ids 8 agg_dst_ids 9 cache_search_buffer 10 tmp_part_ind 11 tmp_part_off
+ *        12 position_map.  Returns the device pointer of the CURRENT pipe slot. */
+void* legion_pool_buffer(LegionMemoryPool* p, int32_t which);
+void legion_pool_destroy(LegionMemoryPool* p);
+
+/* UnifiedCache: SS/cache/cache.cu:295-321 (Initialize), :323-328 (InitializeCacheController). */
+LegionUnifiedCache* legion_cache_create(int64_t cache_memory, int32_t float_feature_len,
+                                        int32_t train_step, int32_t device_count,
+                                        int32_t total_num_nodes);
+void legion_cache_init_controller(LegionUnifiedCache* c, int32_t dev_id);
+/* SS/cache/cache.cu:360-443.  Hotness is summed over the clique on the clique leader through
+ * peer pointers (one process, several GPUs); when `world_reduced` is non-zero the caller has
+ * already all-reduced the counters across processes with RCCL and they are used as they are. */
+void legion_cache_candidate_selection(LegionUnifiedCache* c, int32_t cache_agg_mode,
+                                      LegionGraphStorage* graph, int32_t world_reduced);
+/* SS/cache/cache.cu:445-551; counters[2] = PCIe/xGMI transaction counts (zeros reproduce v2). */
+void legion_cache_cost_model(LegionUnifiedCache* c, LegionFeatureStorage* feature,
+                             LegionGraphStorage* graph, const uint64_t* counters, int32_t train_step);
+/* Bypass for the all-resident configuration: fix the capacities instead of solving for them. */
+void legion_cache_set_capacity(LegionUnifiedCache* c, int32_t node_capacity, int32_t edge_capacity);
+/* SS/cache/cache.cu:553-611 */
+void legion_cache_fill_up(LegionUnifiedCache* c, LegionFeatureStorage* feature, LegionGraphStorage* graph);
+void legion_cache_destroy(LegionUnifiedCache* c);
+/* introspection for the parity tests; arrays are device pointers on the clique leader */
+int32_t legion_cache_node_capacity(const LegionUnifiedCache* c, int32_t dev_id);
+int32_t legion_cache_edge_capacity(const LegionUnifiedCache* c, int32_t dev_id);
+int32_t legion_cache_max_id_num(const LegionUnifiedCache* c, int32_t dev_id);
+/* which: 0 QF 1 QT (int32[N]) 2 AF 3 AT (uint64[N]) 4 node_access_time 5 edge_access_time
+ *        (uint64[N], per device) 6 node_map 8 edge_offset_map (int32[N]) 7 edge_index_map (int8[N]) */
+void* legion_cache_array(LegionUnifiedCache* c, int32_t dev_id, int32_t which);
+
+/* =====================================================================================
+ * 3. Runner / Server / IPC -- SS/engine/server.h:5-33, SS/engine/ipc_service.h:6-35,
+ *    sampling_server/sampling_server.cpp:7 (Run(fanout, gpu_number, in_memory_mode, cache_mode)).
+ * ===================================================================================== */
+LegionServer* NewGPUServer(void);
+void legion_server_initialize(LegionServer* s, int32_t global_shard_count, const int32_t* fanout,
+                              int32_t hop_num, int32_t in_memory_mode);
+void legion_server_presc(LegionServer* s, int32_t cache_agg_mode);
+void legion_server_run(LegionServer* s);
+void legion_server_finalize(LegionServer* s);
+/* pybind `sampling_server.Run` equivalent; reads ./meta_config from the cwd */
+int32_t legion_run(const int32_t* fanout, int32_t hop_num, int32_t gpu_number, int32_t in_memory_mode,
+                   int32_t cache_mode);
+
+LegionIPCEnv* NewIPCEnv(int32_t device_count);
+/* step arithmetic, SS/engine/ipc_service.cu:60-132,213-253 (host only, no GPU needed) */
+void legion_ipc_coordinate(LegionIPCEnv* e, int32_t partition_count, const int32_t* train_num,
+                           const int32_t* valid_num, const int32_t* test_num, int32_t raw_batch_size,
+                           int32_t epoch);
+int32_t legion_ipc_train_step(LegionIPCEnv* e);
+int32_t legion_ipc_max_step(LegionIPCEnv* e);
+int32_t legion_ipc_current_mode(LegionIPCEnv* e, int32_t global_batch_id);
+int32_t legion_ipc_local_batch_id(LegionIPCEnv* e, int32_t global_batch_id);
+int32_t legion_ipc_current_batchsize(LegionIPCEnv* e, int32_t dev_id, int32_t mode);
+void legion_ipc_finalize(LegionIPCEnv* e);
+
+/* =====================================================================================
+ * 4. Kernel-level launchers (what the operators call), exported so the hot kernels can be
+ *    measured and tested alone.
+ * ===================================================================================== */
+/* The gather of SS/cache/cache_impl.cuh:239-272 with the id->slot lookup of
+ * SS/cache/cache.cu:180-215 fused in.  range[0..1] = {row offset, row count} is read on the
+ * device (node_counter layout).  node_map may be NULL (every row is a miss). */
+void legion_gather_rows(legion_stream_t stream, const float* full_table, const float* const* cache_tables,
+                        const int32_t* node_map, int32_t node_capacity, int32_t float_feature_len,
+                        int32_t total_num_nodes, const int32_t* sampled_ids, int32_t* cache_index_out,
+                        const int32_t* range_devptr, float* dst, int32_t max_rows);
+/* the draw of SS/engine/operator_impl.cu:235-238 evaluated on the GPU for n (idx, deg) pairs */
+void legion_draw_batch(legion_stream_t stream, const int32_t* idx, const int32_t* deg, int32_t* out,
+                       int32_t n);
+
+/* =====================================================================================
+ * 5. Synthetic workload generators (RMAT + counter-hash features); device side.
+ * ===================================================================================== */
+void legion_synth_rmat_edges(legion_stream_t stream, int32_t scale, int64_t num_edges, uint64_t seed,
+                             int32_t* src_out, int32_t* dst_out);
+void legion_synth_features(legion_stream_t stream, float* out, int64_t first_row, int64_t num_rows,
+                           int32_t dim, uint64_t seed);
+void legion_synth_feature_check(legion_stream_t stream, const float* rows, const int32_t* ids,
+                                int64_t num_rows, int32_t dim, uint64_t seed,
+                                unsigned long long* mismatch_count_devptr);
+
+/* library / device info */
+const char* legion_version(void);
+int32_t legion_device_count(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LEGION_HIP_H */

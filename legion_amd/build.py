@@ -1,0 +1,78 @@
+"""Builds the in-tree native artefacts for gfx950 with hipcc.
+
+    python -m legion_amd.build            # liblegion_hip.so + bin/sampling_server
+    python -m legion_amd.build --trainer  # also the `ipc_service` torch extension
+
+hipcc cross-compiles without a GPU.  Outputs stay inside the package directory (git-ignored,
+shipped to the GPU box by gpurun).
+"""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(HERE, "liblegion_hip.so")
+BIN = os.path.join(HERE, "bin", "sampling_server")
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+ARCH = "gfx950"
+
+SOURCES = ["kernels_sample.hip", "kernels_gather.hip", "kernels_cache.hip", "kernels_synth.hip",
+           "storage.hip", "cache.hip", "operators.hip", "ipc_env.hip", "server.hip"]
+FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-fno-fast-math", "-Wall",
+         "-Wno-unused-result", "-Wno-unused-function"]
+
+
+def _newer(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build_lib(force=False, verbose=True):
+    objdir = os.path.join(HERE, "_obj")
+    os.makedirs(objdir, exist_ok=True)
+    headers = [os.path.join(CSRC, "legion_core.h"), os.path.join(HERE, "..", "include", "legion_hip.h")]
+    objs, procs = [], []
+    for src in SOURCES:
+        s = os.path.join(CSRC, src)
+        o = os.path.join(objdir, src + ".o")
+        objs.append(o)
+        if force or _newer(o, [s] + headers):
+            cmd = [HIPCC] + FLAGS + ["-c", s, "-o", o]
+            if verbose:
+                print(" ".join(cmd), flush=True)
+            procs.append((src, subprocess.Popen(cmd)))
+    failed = [src for src, p in procs if p.wait() != 0]
+    if failed:
+        raise RuntimeError(f"hipcc failed for {failed}")
+    if force or procs or not os.path.exists(LIB):
+        cmd = [HIPCC, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", LIB] + objs + ["-lpthread", "-lrt"]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+    main_src = os.path.join(CSRC, "main.cpp")
+    if force or _newer(BIN, [main_src, LIB]):
+        os.makedirs(os.path.dirname(BIN), exist_ok=True)
+        cmd = [HIPCC, "-O2", "-std=c++17", main_src, "-o", BIN, f"-L{HERE}", "-llegion_hip",
+               "-Wl,-rpath,$ORIGIN/.."]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+    return LIB
+
+
+def build_trainer(verbose=True):
+    tdir = os.path.join(HERE, "trainer")
+    env = dict(os.environ, PYTORCH_ROCM_ARCH=ARCH)
+    cmd = [sys.executable, "setup.py", "build_ext", "--inplace"]
+    if verbose:
+        print("(cd trainer &&", " ".join(cmd) + ")", flush=True)
+    subprocess.check_call(cmd, cwd=tdir, env=env)
+
+
+if __name__ == "__main__":
+    build_lib(force="--force" in sys.argv)
+    if "--trainer" in sys.argv:
+        build_trainer()

@@ -1,0 +1,540 @@
+// cache.hip -- PreSCCacheController + UnifiedCache for the MI355X build.
+//
+// Reference: SS/cache/cache.cu (controller :4-291, UnifiedCache :295-748), SS/cache/cache.cuh.
+// Same roles, same call order (Initialize -> InitializeCacheController -> [PreSC epoch:
+// CacheProfiling] -> CandidateSelection -> CostModel -> FillUp -> Find*/FeatCacheLookup).
+// What changed:
+//   * the three BGHT cuckoo maps per GPU (cache.cu:80-86) are direct-mapped tables indexed by
+//     vertex id (int32[N], int8[N], int32[N]) -- the find() contract (value or -2) is identical,
+//     a lookup is one 4-byte read instead of up to three 128-byte bucket probes;
+//   * hotness is reduced on the clique leader through peer pointers over xGMI exactly like
+//     aggregate_access, or skipped when the caller already all-reduced it with RCCL
+//     (one-process-per-GPU deployment);
+//   * the hotness sort is rocPRIM's stable LSD radix sort (ties keep ascending vertex id, as the
+//     reference's Thrust->CUB path does);
+//   * MaxIdNum is tracked on the device (no blocking read-back per PreSC batch, cache.cu:55-61).
+#include "legion_core.h"
+
+#include <algorithm>
+#include <iostream>
+
+#define MIN_INTERVAL 0.01   // SS/cache/cache_impl.cuh:30
+#define CLS 64              // SS/cache/cache_impl.cuh:31
+
+namespace lg {
+__global__ void find_range_kernel(const int32_t* __restrict__ sampled_ids,
+                                  const int32_t* __restrict__ range, const int32_t* __restrict__ map,
+                                  int32_t* __restrict__ out)
+{
+    const int32_t off = range[0], n = range[1];
+    for (int32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const int32_t k = sampled_ids[off + i];
+        out[i] = (k >= 0 && map) ? map[k] : CACHEMISS_FLAG;
+    }
+}
+
+__global__ void track_max_kernel(const int32_t* __restrict__ nc, int32_t* __restrict__ max_ids)
+{
+    atomicMax(max_ids, nc[INTRABATCH_CON * 2 + 1]);
+}
+}  // namespace lg
+
+class PreSCCacheController : public CacheController {
+public:
+    PreSCCacheController(int32_t train_step, int32_t device_count)
+        : device_count_(device_count), train_step_(train_step) {}
+    ~PreSCCacheController() override {}
+
+    void Initialize(int32_t dev_id, int32_t total_num_nodes) override
+    {
+        device_idx_ = dev_id;
+        total_num_nodes_ = total_num_nodes;
+        SetGPUDevice(dev_id);
+        const int64_t bytes = (int64_t)total_num_nodes * sizeof(unsigned long long);
+        node_access_time_ = (unsigned long long*)d_alloc_space(bytes);
+        edge_access_time_ = (unsigned long long*)d_alloc_space(bytes);
+        HIP_CALL(hipMemset(node_access_time_, 0, (size_t)bytes));
+        HIP_CALL(hipMemset(edge_access_time_, 0, (size_t)bytes));
+        d_max_ids_ = (int32_t*)d_alloc_space(4);
+        HIP_CALL(hipMemset(d_max_ids_, 0, 4));
+        iter_ = 0;
+    }
+
+    void Finalize() override
+    {
+        SetGPUDevice(device_idx_);
+        d_free_space(node_access_time_);
+        d_free_space(edge_access_time_);
+        d_free_space(d_max_ids_);
+        d_free_space(node_map_);
+        d_free_space(edge_index_map_);
+        d_free_space(edge_offset_map_);
+        node_access_time_ = edge_access_time_ = nullptr;
+        d_max_ids_ = node_map_ = edge_offset_map_ = nullptr;
+        edge_index_map_ = nullptr;
+    }
+
+    // SS/cache/cache.cu:40-68
+    void CacheProfiling(int32_t* sampled_ids, int32_t*, int32_t*, int32_t*, int32_t*,
+                        int32_t* node_counter, int32_t*, bool is_presc, void* stream) override
+    {
+        if (is_presc) {
+            hipStream_t s = static_cast<hipStream_t>(stream);
+            lg::launch_hotness_measure(s, sampled_ids, node_counter, node_access_time_);
+            lg::track_max_kernel<<<1, 1, 0, s>>>(node_counter, d_max_ids_);
+            hipCheckError();
+            if (iter_ == (train_step_ - 1)) iter_ = 0;
+        }
+        iter_++;
+    }
+
+    // SS/cache/cache.cu:71-88: sentinel-filled tables instead of three hash maps
+    void InitializeMap(int node_capacity, int edge_capacity) override
+    {
+        SetGPUDevice(device_idx_);
+        node_capacity_ = node_capacity;
+        edge_capacity_ = edge_capacity;
+        d_free_space(node_map_);
+        d_free_space(edge_index_map_);
+        d_free_space(edge_offset_map_);
+        node_map_ = (int32_t*)d_alloc_space((int64_t)total_num_nodes_ * 4);
+        edge_index_map_ = (char*)d_alloc_space((int64_t)total_num_nodes_);
+        edge_offset_map_ = (int32_t*)d_alloc_space((int64_t)total_num_nodes_ * 4);
+        lg::fill_value_i32(nullptr, node_map_, CACHEMISS_FLAG, total_num_nodes_);
+        lg::fill_value_i8(nullptr, edge_index_map_, (char)CACHEMISS_FLAG, total_num_nodes_);
+        lg::fill_value_i32(nullptr, edge_offset_map_, CACHEMISS_FLAG, total_num_nodes_);
+        HIP_CALL(hipDeviceSynchronize());
+    }
+
+    // SS/cache/cache.cu:90-136 (InitPair / InitIndexPair / InitOffsetPair + insert)
+    void Insert(int32_t* QT, int32_t* QF, int32_t cache_expand, int32_t Kg) override
+    {
+        SetGPUDevice(device_idx_);
+        (void)cache_expand;   // == Kg in every mode (cache.cu:555-564)
+        lg::init_node_map(nullptr, node_map_, QF, node_capacity_, Kg, total_num_nodes_);
+        lg::init_edge_maps(nullptr, edge_index_map_, edge_offset_map_, QT, edge_capacity_, Kg,
+                           device_idx_ / Kg, total_num_nodes_);
+        HIP_CALL(hipDeviceSynchronize());
+    }
+
+    void HybridInsert(int32_t*, int32_t, int32_t) override
+    {
+        // Legion-SSD hybrid CPU/GPU cache: unreleased upstream (README.md:100-101), out of scope
+        printf("HybridInsert: SSD tier is not part of this build\n");
+    }
+
+    void AccessCount(int32_t*, int32_t, void*) override {}
+    unsigned long long int* GetNodeAccessedMap() override { return node_access_time_; }
+    unsigned long long int* GetEdgeAccessedMap() override { return edge_access_time_; }
+
+    // SS/cache/cache.cu:180-215 -- range taken from the device counters, no read-back
+    void FindFeat(int32_t* sampled_ids, int32_t* cache_offset, int32_t* node_counter, int32_t op_id,
+                  void* stream) override
+    {
+        lg::find_range_kernel<<<1024, 256, 0, static_cast<hipStream_t>(stream)>>>(
+            sampled_ids, node_counter + (op_id % INTRABATCH_CON) * 2, node_map_, cache_offset);
+        hipCheckError();
+    }
+
+    // SS/cache/cache.cu:217-225
+    void FindTopo(int32_t* input_ids, char* partition_index, int32_t* partition_offset,
+                  int32_t batch_size, int32_t, void* strm_hdl, int32_t) override
+    {
+        lg::launch_find(static_cast<hipStream_t>(strm_hdl), input_ids, batch_size, edge_offset_map_,
+                        edge_index_map_, partition_offset, partition_index);
+    }
+
+    int32_t MaxIdNum() override
+    {
+        SetGPUDevice(device_idx_);
+        int32_t v = 0;
+        HIP_CALL(hipMemcpy(&v, d_max_ids_, 4, hipMemcpyDeviceToHost));
+        return v;
+    }
+
+    const int32_t* NodeMap() const override { return node_map_; }
+    const char* EdgeIndexMap() const override { return edge_index_map_; }
+    const int32_t* EdgeOffsetMap() const override { return edge_offset_map_; }
+
+private:
+    int32_t device_idx_ = 0;
+    int32_t device_count_ = 0;
+    int32_t total_num_nodes_ = 0;
+    unsigned long long* node_access_time_ = nullptr;
+    unsigned long long* edge_access_time_ = nullptr;
+    int32_t train_step_ = 0;
+    int32_t iter_ = 0;
+    int32_t* d_max_ids_ = nullptr;
+    int32_t* node_map_ = nullptr;
+    char* edge_index_map_ = nullptr;
+    int32_t* edge_offset_map_ = nullptr;
+    int32_t node_capacity_ = 0, edge_capacity_ = 0;
+};
+
+CacheController* NewPreSCCacheController(int32_t train_step, int32_t device_count)
+{
+    return new PreSCCacheController(train_step, device_count);
+}
+
+// =============================================================================================
+void UnifiedCache::Initialize(int64_t cache_memory, int32_t float_feature_len, int32_t train_step,
+                              int32_t device_count, int32_t cpu_cache_capacity, int32_t gpu_cache_capacity)
+{
+    device_count_ = device_count;
+    cache_controller_.resize(device_count_);
+    for (int32_t i = 0; i < device_count_; i++)
+        cache_controller_[i] = NewPreSCCacheController(train_step, device_count_);
+    float_feature_cache_.assign(device_count_, nullptr);
+    d_float_feature_cache_ptr_.assign(device_count_, nullptr);
+    cache_memory_ = cache_memory;
+    float_feature_len_ = float_feature_len;
+    cpu_cache_capacity_ = cpu_cache_capacity;
+    gpu_cache_capacity_ = gpu_cache_capacity;
+    is_presc_ = true;
+}
+
+void UnifiedCache::InitializeCacheController(int32_t dev_id, int32_t total_num_nodes)
+{
+    total_num_nodes_ = total_num_nodes;
+    cache_controller_[dev_id]->Initialize(dev_id, total_num_nodes);
+}
+
+void UnifiedCache::Finalize(int32_t dev_id)
+{
+    SetGPUDevice(dev_id);
+    cache_controller_[dev_id]->Finalize();
+}
+
+void UnifiedCache::FindFeat(int32_t* sampled_ids, int32_t* cache_offset, int32_t* node_counter,
+                            int32_t op_id, void* stream, int32_t dev_id)
+{
+    cache_controller_[dev_id]->FindFeat(sampled_ids, cache_offset, node_counter, op_id, stream);
+}
+
+void UnifiedCache::FindTopo(int32_t* input_ids, char* partition_index, int32_t* partition_offset,
+                            int32_t batch_size, int32_t op_id, void* strm_hdl, int32_t dev_id)
+{
+    cache_controller_[dev_id]->FindTopo(input_ids, partition_index, partition_offset, batch_size, op_id,
+                                        strm_hdl, dev_id);
+}
+
+void UnifiedCache::CacheProfiling(int32_t* sampled_ids, int32_t* agg_src_id, int32_t* agg_dst_id,
+                                  int32_t* agg_src_off, int32_t* agg_dst_off, int32_t* node_counter,
+                                  int32_t* edge_counter, void* stream, int32_t dev_id)
+{
+    cache_controller_[dev_id]->CacheProfiling(sampled_ids, agg_src_id, agg_dst_id, agg_src_off,
+                                              agg_dst_off, node_counter, edge_counter, is_presc_, stream);
+}
+
+// SS/cache/cache.cu:360-443
+void UnifiedCache::CandidateSelection(int cache_agg_mode, FeatureStorage* feature, GraphStorage*)
+{
+    int32_t Kg = 1 << cache_agg_mode;                 // :375-389
+    if (Kg > device_count_) Kg = device_count_;
+    if (Kg < 1) Kg = 1;
+    const int32_t Kc = device_count_ / Kg;
+    Kc_ = Kc;
+    Kg_ = Kg;
+    cache_agg_mode_ = cache_agg_mode;
+    const int32_t N = feature ? feature->TotalNodeNum() : total_num_nodes_;
+    total_num_nodes_ = N;
+    for (void* p : QF_) d_free_space(p);
+    for (void* p : QT_) d_free_space(p);
+    for (void* p : AF_) d_free_space(p);
+    for (void* p : AT_) d_free_space(p);
+    QF_.clear(); QT_.clear(); AF_.clear(); AT_.clear();
+
+    for (int32_t i = 0; i < Kc; i++) {
+        SetGPUDevice(i * Kg);
+        for (int which = 0; which < 2; which++) {     // 0: node hotness -> QF/AF, 1: edge hotness -> QT/AT
+            int32_t* order = (int32_t*)d_alloc_space((int64_t)N * sizeof(int32_t));
+            unsigned long long* agg = (unsigned long long*)d_alloc_space((int64_t)N * sizeof(unsigned long long));
+            HIP_CALL(hipMemset(agg, 0, (size_t)N * sizeof(unsigned long long)));
+            // aggregate_access on the leader reading each member's counters (peer loads over xGMI).
+            // When the counters were already all-reduced across processes (RCCL), every member
+            // holds the clique sum: take the leader's copy once.
+            const int32_t members = world_reduced ? 1 : Kg;
+            for (int32_t j = 0; j < members; j++) {
+                CacheController* cc = cache_controller_[i * Kg + j];
+                lg::aggregate_access(nullptr, agg, which == 0 ? cc->GetNodeAccessedMap() : cc->GetEdgeAccessedMap(), N);
+            }
+            lg::sort_hotness_desc(nullptr, agg, order, N);
+            if (which == 0) { QF_.push_back(order); AF_.push_back(agg); }
+            else { QT_.push_back(order); AT_.push_back(agg); }
+        }
+        HIP_CALL(hipDeviceSynchronize());
+    }
+    is_presc_ = false;
+}
+
+// SS/cache/cache.cu:445-551.  Same statement-by-statement arithmetic as oracle/legion_oracle.c
+// lgo_cost_model (float tables, double intermediates); prefix[-1] reads as 0.
+void UnifiedCache::CostModel(int, FeatureStorage* feature, GraphStorage* graph,
+                             std::vector<uint64_t>& counters, int32_t train_step)
+{
+    const int32_t N = feature->TotalNodeNum();
+    const int32_t D = feature->GetFloatFeatureLen();
+    const int64_t* csr_index = graph->GetCSRNodeIndexCPU();
+    node_capacity_.clear();
+    edge_capacity_.clear();
+    for (int32_t i = 0; i < Kc_; i++) {
+        SetGPUDevice(i * Kg_);
+        const int max_payload_size = CLS;
+        const int64_t memory_step = (int64_t)((double)(cache_memory_ * Kg_) * MIN_INTERVAL);
+        const uint64_t total_trans_of_topo = counters[0] + counters[1];
+        uint64_t total_trans_of_feat = 0;
+        for (int j = 0; j < Kg_; j++)     // the reference indexes controller j, not i*Kg+j (:462)
+            total_trans_of_feat += (uint64_t)((int64_t)(((int64_t)cache_controller_[j]->MaxIdNum() * train_step) * D) * sizeof(float)) /
+                                   (uint64_t)max_payload_size;
+
+        unsigned long long* d_prefix = (unsigned long long*)d_alloc_space((int64_t)N * 8);
+        unsigned long long* d_edge_mem = (unsigned long long*)d_alloc_space((int64_t)N * 8);
+        std::vector<uint64_t> h_node_prefix(N), h_edge_prefix(N), h_edge_mem_prefix(N);
+        lg::inclusive_scan_u64(nullptr, AF_[i], d_prefix, N);
+        HIP_CALL(hipMemcpy(h_node_prefix.data(), d_prefix, (size_t)N * 8, hipMemcpyDeviceToHost));
+        lg::inclusive_scan_u64(nullptr, AT_[i], d_prefix, N);
+        HIP_CALL(hipMemcpy(h_edge_prefix.data(), d_prefix, (size_t)N * 8, hipMemcpyDeviceToHost));
+        lg::edge_mem_in_order(nullptr, QT_[i], d_edge_mem, N, csr_index);
+        lg::inclusive_scan_u64(nullptr, d_edge_mem, d_prefix, N);
+        HIP_CALL(hipMemcpy(h_edge_mem_prefix.data(), d_prefix, (size_t)N * 8, hipMemcpyDeviceToHost));
+        d_free_space(d_prefix);
+        d_free_space(d_edge_mem);
+
+        const int64_t total_mem = cache_memory_ * Kg_;
+        if (memory_step <= 0) {
+            printf("cache_memory %lld is too small for the cost model\n", (long long)cache_memory_);
+            exit(EXIT_FAILURE);
+        }
+        const int64_t steps = (total_mem - 1) / memory_step + 1;
+        int64_t current_steps = 0;
+        int32_t node_num_topo = 0, node_num_feat = 0;
+        std::vector<float> trans_of_topo(steps + 1, 0), trans_of_feat(steps + 1, 0);
+        std::vector<float> cap_of_topo(steps + 1, 0), cap_of_feat(steps + 1, 0), trans_of_total(steps + 1, 0);
+        auto at = [](const std::vector<uint64_t>& v, int64_t k) -> uint64_t { return k < 0 ? 0 : v[k]; };
+        for (int64_t current_mem = 0; current_mem < total_mem; current_mem += memory_step) {
+            if ((uint64_t)current_mem > (uint64_t)N * D * sizeof(float))
+                node_num_feat = N;
+            else
+                node_num_feat = (int32_t)((uint64_t)(current_steps + 1) * ((uint64_t)memory_step / (D * sizeof(float))));
+            if ((uint64_t)current_mem > h_edge_mem_prefix[N - 1])
+                node_num_topo = N;
+            else
+                node_num_topo = (int32_t)(std::lower_bound(h_edge_mem_prefix.begin(), h_edge_mem_prefix.end(),
+                                                           (uint64_t)current_mem) - h_edge_mem_prefix.begin());
+            if (node_num_topo < N) {
+                trans_of_topo[current_steps] = (float)((double)total_trans_of_topo * 1.0 / (double)h_edge_prefix[N - 1] *
+                                                       (double)at(h_edge_prefix, (int64_t)node_num_topo - 1));
+                cap_of_topo[current_steps] = (float)(node_num_topo / Kg_);
+            }
+            if (node_num_feat < N) {
+                trans_of_feat[current_steps] = (float)((double)total_trans_of_feat * 1.0 / (double)h_node_prefix[N - 1] *
+                                                       (double)at(h_node_prefix, (int64_t)node_num_feat - 1));
+                cap_of_feat[current_steps] = (float)(node_num_feat / Kg_);
+            }
+            current_steps++;
+        }
+        for (int64_t sidx = 1; sidx < steps; sidx++)
+            trans_of_total[sidx] = trans_of_topo[sidx] + trans_of_feat[steps - 1 - sidx];
+        const int64_t max_sidx = std::max_element(trans_of_total.begin(), trans_of_total.end()) - trans_of_total.begin();
+        std::cout << "Alpha: " << (max_sidx * MIN_INTERVAL) << " Transactions: " << trans_of_total[max_sidx]
+                  << " on Clique: " << i << std::endl;
+        node_capacity_.push_back((int32_t)(cap_of_feat[steps - 1 - max_sidx] + 1));
+        edge_capacity_.push_back((int32_t)(cap_of_topo[max_sidx] + 1));
+        std::cout << "Feat capacity: " << cap_of_feat[steps - 1 - max_sidx] << " Topo capacity: "
+                  << cap_of_topo[max_sidx] << " on Clique: " << i << std::endl;
+    }
+}
+
+void UnifiedCache::SetCapacity(int32_t node_capacity, int32_t edge_capacity)
+{
+    node_capacity_.assign(Kc_, node_capacity);
+    edge_capacity_.assign(Kc_, edge_capacity);
+}
+
+int32_t UnifiedCache::NodeCapacity(int32_t dev_id) const
+{
+    if (node_capacity_.empty()) return 0;
+    return node_capacity_[dev_id / Kg_];
+}
+
+int32_t UnifiedCache::EdgeCapacity(int32_t dev_id) const
+{
+    if (edge_capacity_.empty()) return 0;
+    return edge_capacity_[dev_id / Kg_];
+}
+
+// SS/cache/cache.cu:553-611
+void UnifiedCache::FillUp(int cache_agg_mode, FeatureStorage* feature, GraphStorage* graph)
+{
+    (void)cache_agg_mode;
+    const int32_t N = feature->TotalNodeNum();
+    for (int32_t i = 0; i < Kc_; i++)
+        for (int32_t j = 0; j < Kg_; j++) {
+            SetGPUDevice(i * Kg_ + j);
+            cache_controller_[i * Kg_ + j]->InitializeMap(node_capacity_[i], edge_capacity_[i]);
+            cache_controller_[i * Kg_ + j]->Insert(QT_[i], QF_[i], Kg_, Kg_);
+        }
+    for (int32_t i = 0; i < device_count_; i++) {
+        SetGPUDevice(i);
+        d_free_space(d_float_feature_cache_ptr_[i]);
+        d_float_feature_cache_ptr_[i] = (float**)d_alloc_space(device_count_ * sizeof(float*));
+    }
+    float* cpu_float_feature = feature->GetAllFloatFeature();
+    cpu_float_features_ = cpu_float_feature;
+    for (int32_t i = 0; i < Kc_; i++) {
+        std::vector<float*> table(device_count_, nullptr);     // indexed by in-clique GPU j
+        for (int32_t j = 0; j < Kg_; j++) {
+            const int32_t dev_id = i * Kg_ + j;
+            if (float_feature_len_ > 0) {
+                SetGPUDevice(dev_id);
+                d_free_space(float_feature_cache_[dev_id]);
+                float* new_cache = (float*)d_alloc_space((int64_t)node_capacity_[i] * float_feature_len_ * sizeof(float));
+                lg::feat_fill_up(nullptr, node_capacity_[i], float_feature_len_, new_cache, cpu_float_feature,
+                                 QF_[i], Kg_, j, N);
+                HIP_CALL(hipDeviceSynchronize());
+                float_feature_cache_[dev_id] = new_cache;
+                table[j] = new_cache;
+            }
+        }
+        for (int32_t j = 0; j < Kg_; j++) {                   // :598-601
+            SetGPUDevice(i * Kg_ + j);
+            HIP_CALL(hipMemcpy(d_float_feature_cache_ptr_[i * Kg_ + j], table.data(),
+                               device_count_ * sizeof(float*), hipMemcpyHostToDevice));
+        }
+    }
+    for (int32_t i = 0; i < Kc_; i++) graph->GraphCache(QT_[i], i, Kg_, edge_capacity_[i]);   // :606-608
+    for (int32_t i = 0; i < device_count_; i++) {
+        SetGPUDevice(i);
+        HIP_CALL(hipDeviceSynchronize());
+    }
+}
+
+int32_t UnifiedCache::MaxIdNum(int32_t dev_id) { return cache_controller_[dev_id]->MaxIdNum(); }
+
+unsigned long long int* UnifiedCache::GetEdgeAccessedMap(int32_t dev_id)
+{
+    return cache_controller_[dev_id]->GetEdgeAccessedMap();
+}
+
+// SS/cache/cache.cu:726-748 -- lookup (FindFeat) fused into the gather
+void UnifiedCache::FeatCacheLookup(int32_t* sampled_ids, int32_t* cache_index, int32_t* node_counter,
+                                   float* dst_float_buffer, int32_t op_id, int32_t dev_id,
+                                   hipStream_t strm_hdl, int32_t max_rows)
+{
+    const bool filled = !node_capacity_.empty() && d_float_feature_cache_ptr_[dev_id] != nullptr &&
+                        cache_controller_[dev_id]->NodeMap() != nullptr;
+    (void)op_id;
+    lg::launch_gather(strm_hdl, cpu_float_features_, filled ? d_float_feature_cache_ptr_[dev_id] : nullptr,
+                      filled ? cache_controller_[dev_id]->NodeMap() : nullptr,
+                      filled ? NodeCapacity(dev_id) : 1, float_feature_len_, total_num_nodes_, sampled_ids,
+                      cache_index, node_counter, node_counter + 2, dst_float_buffer, max_rows);
+}
+
+// ---- C API ----------------------------------------------------------------------------------
+struct LegionCacheBox {   // the UnifiedCache plus what the C API needs to remember
+    UnifiedCache cache;
+    int32_t device_count = 0;
+    int32_t total_num_nodes = 0;
+};
+
+static UnifiedCache* as_cache(LegionUnifiedCache* c) { return c ? &reinterpret_cast<LegionCacheBox*>(c)->cache : nullptr; }
+static const UnifiedCache* as_cache(const LegionUnifiedCache* c) { return c ? &reinterpret_cast<const LegionCacheBox*>(c)->cache : nullptr; }
+
+extern "C" LegionUnifiedCache* legion_cache_create(int64_t cache_memory, int32_t float_feature_len,
+                                                   int32_t train_step, int32_t device_count,
+                                                   int32_t total_num_nodes)
+{
+    LegionCacheBox* b = new LegionCacheBox();
+    b->device_count = device_count;
+    b->total_num_nodes = total_num_nodes;
+    b->cache.Initialize(cache_memory, float_feature_len, train_step, device_count, 0, 0);
+    b->cache.total_num_nodes_ = total_num_nodes;
+    return reinterpret_cast<LegionUnifiedCache*>(b);
+}
+
+extern "C" void legion_cache_init_controller(LegionUnifiedCache* c, int32_t dev_id)
+{
+    if (!c) { printf("invalid cache ptr\n"); return; }
+    LegionCacheBox* b = reinterpret_cast<LegionCacheBox*>(c);
+    b->cache.InitializeCacheController(dev_id, b->total_num_nodes);
+}
+
+extern "C" void legion_cache_candidate_selection(LegionUnifiedCache* c, int32_t cache_agg_mode,
+                                                 LegionGraphStorage* graph, int32_t world_reduced)
+{
+    UnifiedCache* u = as_cache(c);
+    if (!u) { printf("invalid cache ptr\n"); return; }
+    u->world_reduced = world_reduced != 0;
+    u->CandidateSelection(cache_agg_mode, nullptr, reinterpret_cast<GraphStorage*>(graph));
+}
+
+extern "C" void legion_cache_cost_model(LegionUnifiedCache* c, LegionFeatureStorage* feature,
+                                        LegionGraphStorage* graph, const uint64_t* counters, int32_t train_step)
+{
+    UnifiedCache* u = as_cache(c);
+    if (!u || !feature || !graph) { printf("invalid cache/feature/graph ptr\n"); return; }
+    std::vector<uint64_t> cnt(2, 0);
+    if (counters) { cnt[0] = counters[0]; cnt[1] = counters[1]; }
+    u->CostModel(u->cache_agg_mode_, reinterpret_cast<FeatureStorage*>(feature),
+                 reinterpret_cast<GraphStorage*>(graph), cnt, train_step);
+}
+
+extern "C" void legion_cache_set_capacity(LegionUnifiedCache* c, int32_t node_capacity, int32_t edge_capacity)
+{
+    UnifiedCache* u = as_cache(c);
+    if (u) u->SetCapacity(node_capacity, edge_capacity);
+}
+
+extern "C" void legion_cache_fill_up(LegionUnifiedCache* c, LegionFeatureStorage* feature, LegionGraphStorage* graph)
+{
+    UnifiedCache* u = as_cache(c);
+    if (!u || !feature || !graph) { printf("invalid cache/feature/graph ptr\n"); return; }
+    u->FillUp(u->cache_agg_mode_, reinterpret_cast<FeatureStorage*>(feature), reinterpret_cast<GraphStorage*>(graph));
+}
+
+extern "C" void legion_cache_destroy(LegionUnifiedCache* c)
+{
+    if (!c) return;
+    LegionCacheBox* b = reinterpret_cast<LegionCacheBox*>(c);
+    for (int32_t i = 0; i < b->device_count; i++)
+        if (b->cache.Controller(i)) b->cache.Finalize(i);
+    delete b;
+}
+
+extern "C" int32_t legion_cache_node_capacity(const LegionUnifiedCache* c, int32_t dev_id)
+{
+    const UnifiedCache* u = as_cache(c);
+    return u ? u->NodeCapacity(dev_id) : 0;
+}
+
+extern "C" int32_t legion_cache_edge_capacity(const LegionUnifiedCache* c, int32_t dev_id)
+{
+    const UnifiedCache* u = as_cache(c);
+    return u ? u->EdgeCapacity(dev_id) : 0;
+}
+
+extern "C" int32_t legion_cache_max_id_num(const LegionUnifiedCache* c, int32_t dev_id)
+{
+    UnifiedCache* u = as_cache(const_cast<LegionUnifiedCache*>(c));
+    return u ? u->MaxIdNum(dev_id) : 0;
+}
+
+extern "C" void* legion_cache_array(LegionUnifiedCache* c, int32_t dev_id, int32_t which)
+{
+    UnifiedCache* u = as_cache(c);
+    if (!u) return nullptr;
+    const int32_t clique = dev_id / (u->Kg_ > 0 ? u->Kg_ : 1);
+    CacheController* cc = u->Controller(dev_id);
+    switch (which) {
+        case 0: return clique < (int32_t)u->QF_.size() ? u->QF_[clique] : nullptr;
+        case 1: return clique < (int32_t)u->QT_.size() ? u->QT_[clique] : nullptr;
+        case 2: return clique < (int32_t)u->AF_.size() ? u->AF_[clique] : nullptr;
+        case 3: return clique < (int32_t)u->AT_.size() ? u->AT_[clique] : nullptr;
+        case 4: return cc->GetNodeAccessedMap();
+        case 5: return cc->GetEdgeAccessedMap();
+        case 6: return const_cast<int32_t*>(cc->NodeMap());
+        case 7: return const_cast<char*>(cc->EdgeIndexMap());
+        case 8: return const_cast<int32_t*>(cc->EdgeOffsetMap());
+        default: return nullptr;
+    }
+}

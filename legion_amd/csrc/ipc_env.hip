@@ -1,0 +1,326 @@
+// ipc_env.hip -- server end of the server <-> trainer wire protocol.
+//
+// Reference: SS/engine/ipc_service.cu (CUDAIPCEnv :33-349), SS/engine/helper_multiprocess.cu
+// (only sharedMemoryCreate/Open/Close are used).  The protocol is kept bit-for-bit:
+//   * POSIX shm "simpleIPCshm" = struct { int32 steps[3]; IpcMemHandle(64 B) memHandle[8][2][7]; }
+//     slot order: 0 ids, 1 features, 2 labels, 3 agg_src, 4 agg_dst, 5 node_counter, 6 edge_counter
+//   * named semaphores sem_r_<dev>_<pipe> (trainer -> server, buffer free) and
+//     sem_w_<dev>_<pipe> (server -> trainer, batch ready), created with value 0
+//   * step schedule (train+valid)*epoch + test, valid/test batch = ceil(n_p / ceil(max n / 512))
+// hipIpcMemHandle_t is 64 bytes like cudaIpcMemHandle_t.  LEGION_IPC_NAMESPACE (optional env)
+// suffixes the shm/semaphore names so that independent servers (tests) can share a host.
+#include "legion_core.h"
+
+#include <fcntl.h>
+#include <semaphore.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <cerrno>
+#include <cstring>
+#include <iostream>
+
+static_assert(sizeof(hipIpcMemHandle_t) == 64, "IPC handle size is part of the wire format");
+
+typedef struct shmStruct_st {
+    int32_t steps[3];
+    hipIpcMemHandle_t memHandle[MAX_DEVICE][INTERBATCH_CON][MEMORY_USAGE];
+} shmStruct;
+
+typedef struct sharedMemoryInfo_st {
+    void* addr;
+    size_t size;
+    int shmFd;
+} sharedMemoryInfo;
+
+static std::string ipc_suffix()
+{
+    const char* ns = getenv("LEGION_IPC_NAMESPACE");
+    return ns ? std::string(ns) : std::string();
+}
+
+static int sharedMemoryCreate(const char* name, size_t sz, sharedMemoryInfo* info)
+{
+    info->size = sz;
+    info->shmFd = shm_open(name, O_RDWR | O_CREAT, 0777);
+    if (info->shmFd < 0) return errno;
+    if (ftruncate(info->shmFd, sz) != 0) return errno;
+    info->addr = mmap(0, sz, PROT_READ | PROT_WRITE, MAP_SHARED, info->shmFd, 0);
+    if (info->addr == MAP_FAILED || info->addr == NULL) return errno;
+    return 0;
+}
+
+static void sharedMemoryClose(sharedMemoryInfo* info)
+{
+    if (info->addr) munmap(info->addr, info->size);
+    if (info->shmFd >= 0) close(info->shmFd);
+    info->addr = nullptr;
+    info->shmFd = -1;
+}
+
+class HIPIPCEnv : public IPCEnv {
+public:
+    HIPIPCEnv(int32_t device_count, bool create_shm) : device_count_(device_count)
+    {
+        info_.addr = nullptr;
+        info_.shmFd = -1;
+        if (create_shm) {
+            shm_name_ = std::string("simpleIPCshm") + ipc_suffix();
+            if (sharedMemoryCreate(shm_name_.c_str(), sizeof(*shm_), &info_) != 0) {
+                printf("Failed to create shared memory slab\n");
+                exit(EXIT_FAILURE);
+            }
+            shm_ = (volatile shmStruct*)info_.addr;
+            memset((void*)shm_, 0, sizeof(*shm_));
+        } else {
+            local_ = new shmStruct();
+            memset(local_, 0, sizeof(*local_));
+            shm_ = local_;
+        }
+        ids_.resize(device_count);
+        float_features_.resize(device_count);
+        labels_.resize(device_count);
+        agg_src_.resize(device_count);
+        agg_dst_.resize(device_count);
+        node_counter_.resize(device_count);
+        edge_counter_.resize(device_count);
+        semr_.resize(device_count);
+        semw_.resize(device_count);
+    }
+
+    // ipc_service.cu:60-128
+    void Coordinate(BuildInfo* info) override
+    {
+        const int32_t partition_count = info->partition_count;
+        epoch_ = info->epoch;
+        raw_batch_size_ = info->raw_batch_size;
+        int32_t min_train_size = 1000000000;
+        for (int32_t i = 0; i < partition_count; i++)
+            if (info->training_set_num[i] < min_train_size) min_train_size = info->training_set_num[i];
+        train_step_ = (min_train_size - 1) / raw_batch_size_;
+        train_batch_size_.assign(partition_count, raw_batch_size_);
+
+        int32_t max_valid_size = 0;
+        const int32_t raw_valid_batch_size = 512;
+        for (int32_t i = 0; i < partition_count; i++)
+            if (info->validation_set_num[i] > max_valid_size) max_valid_size = info->validation_set_num[i];
+        valid_step_ = (max_valid_size - 1) / raw_valid_batch_size + 1;
+        valid_batch_size_.clear();
+        for (int32_t i = 0; i < partition_count; i++)
+            valid_batch_size_.push_back((info->validation_set_num[i] - 1) / valid_step_ + 1);
+
+        int32_t max_test_size = 0;
+        const int32_t raw_test_batch_size = 512;
+        for (int32_t i = 0; i < partition_count; i++)
+            if (info->testing_set_num[i] > max_test_size) max_test_size = info->testing_set_num[i];
+        test_step_ = (max_test_size - 1) / raw_test_batch_size + 1;
+        test_batch_size_.clear();
+        for (int32_t i = 0; i < partition_count; i++)
+            test_batch_size_.push_back((info->testing_set_num[i] - 1) / test_step_ + 1);
+
+        std::cout << "Train Steps: " << train_step_ << "\n";
+        std::cout << "Valid Steps: " << valid_step_ << "\n";
+        std::cout << "Test Steps: " << test_step_ << "\n";
+        shm_->steps[0] = train_step_;
+        shm_->steps[1] = valid_step_;
+        shm_->steps[2] = test_step_;
+    }
+
+    int32_t GetMaxStep() override { return ((train_step_ + valid_step_) * epoch_) + test_step_; }
+
+    // ipc_service.cu:134-195
+    void InitializeSamplesBuffer(int32_t batch_size, int32_t num_ids, int32_t feature_dim, int32_t device_id,
+                                 int32_t pipeline_depth) override
+    {
+        (void)feature_dim;
+        SetGPUDevice(device_id);
+        const std::string sfx = ipc_suffix();
+        semr_[device_id].resize(pipeline_depth);
+        semw_[device_id].resize(pipeline_depth);
+        for (int32_t i = 0; i < pipeline_depth; i++) {
+            void* new_ids = d_alloc_space((int64_t)num_ids * sizeof(int32_t));
+            void* new_labels = d_alloc_space((int64_t)batch_size * sizeof(int32_t));
+            void* new_agg_src = d_alloc_space((int64_t)num_ids * sizeof(int32_t));
+            void* new_agg_dst = d_alloc_space((int64_t)num_ids * sizeof(int32_t));
+            void* new_node_counter = d_alloc_space(16 * sizeof(int32_t));
+            void* new_edge_counter = d_alloc_space(16 * sizeof(int32_t));
+            HIP_CALL(hipMemset(new_node_counter, 0, 64));
+            HIP_CALL(hipMemset(new_edge_counter, 0, 64));
+            HIP_CALL(hipIpcGetMemHandle((hipIpcMemHandle_t*)&shm_->memHandle[device_id][i][0], new_ids));
+            HIP_CALL(hipIpcGetMemHandle((hipIpcMemHandle_t*)&shm_->memHandle[device_id][i][2], new_labels));
+            HIP_CALL(hipIpcGetMemHandle((hipIpcMemHandle_t*)&shm_->memHandle[device_id][i][3], new_agg_src));
+            HIP_CALL(hipIpcGetMemHandle((hipIpcMemHandle_t*)&shm_->memHandle[device_id][i][4], new_agg_dst));
+            HIP_CALL(hipIpcGetMemHandle((hipIpcMemHandle_t*)&shm_->memHandle[device_id][i][5], new_node_counter));
+            HIP_CALL(hipIpcGetMemHandle((hipIpcMemHandle_t*)&shm_->memHandle[device_id][i][6], new_edge_counter));
+            ids_[device_id].push_back(new_ids);
+            labels_[device_id].push_back(new_labels);
+            agg_src_[device_id].push_back(new_agg_src);
+            agg_dst_[device_id].push_back(new_agg_dst);
+            node_counter_[device_id].push_back(new_node_counter);
+            edge_counter_[device_id].push_back(new_edge_counter);
+
+            const std::string ssri = "sem_r_" + std::to_string(device_id) + "_" + std::to_string(i) + sfx;
+            const std::string sswi = "sem_w_" + std::to_string(device_id) + "_" + std::to_string(i) + sfx;
+            semr_[device_id][i] = sem_open(ssri.c_str(), O_CREAT | O_RDWR, 0666, 0);
+            if (semr_[device_id][i] == SEM_FAILED) {
+                printf("errno = %d\n", errno);
+                return;
+            }
+            semw_[device_id][i] = sem_open(sswi.c_str(), O_CREAT | O_RDWR, 0666, 0);
+            if (semw_[device_id][i] == SEM_FAILED) {
+                printf("errno = %d\n", errno);
+                return;
+            }
+        }
+        pipeline_depth_ = pipeline_depth;
+    }
+
+    // ipc_service.cu:197-207
+    void InitializeFeaturesBuffer(int32_t batch_size, int32_t num_ids, int32_t feature_dim, int32_t device_id,
+                                  int32_t pipeline_depth) override
+    {
+        (void)batch_size;
+        SetGPUDevice(device_id);
+        for (int32_t i = 0; i < pipeline_depth; i++) {
+            void* new_features = d_alloc_space((int64_t)num_ids * feature_dim * sizeof(float));
+            HIP_CALL(hipIpcGetMemHandle((hipIpcMemHandle_t*)&shm_->memHandle[device_id][i][1], new_features));
+            float_features_[device_id].push_back(new_features);
+        }
+    }
+
+    int32_t GetRawBatchsize() override { return raw_batch_size_; }
+
+    // ipc_service.cu:213-228
+    int32_t GetLocalBatchId(int32_t global_batch_id) override
+    {
+        int32_t local_batch_id = -1;
+        if (global_batch_id < ((train_step_ + valid_step_) * epoch_)) {
+            const int32_t epoch_batch_id = global_batch_id % (train_step_ + valid_step_);
+            local_batch_id = epoch_batch_id < train_step_ ? epoch_batch_id : epoch_batch_id - train_step_;
+        } else {
+            local_batch_id = (global_batch_id - ((train_step_ + valid_step_) * epoch_)) % test_step_;
+        }
+        return local_batch_id;
+    }
+
+    // ipc_service.cu:230-238
+    int32_t GetCurrentBatchsize(int32_t dev_id, int32_t current_mode) override
+    {
+        if (current_mode == TRAINMODE) return train_batch_size_[dev_id];
+        if (current_mode == VALIDMODE) return valid_batch_size_[dev_id];
+        return test_batch_size_[dev_id];
+    }
+
+    // ipc_service.cu:241-254
+    int32_t GetCurrentMode(int32_t global_batch_id) override
+    {
+        if (global_batch_id < ((train_step_ + valid_step_) * epoch_)) {
+            const int32_t epoch_batch_id = global_batch_id % (train_step_ + valid_step_);
+            return epoch_batch_id < train_step_ ? TRAINMODE : VALIDMODE;
+        }
+        return TESTMODE;
+    }
+
+    int32_t* GetIds(int32_t d, int32_t p) override { return (int32_t*)ids_[d][p % pipeline_depth_]; }
+    float* GetFloatFeatures(int32_t d, int32_t p) override { return (float*)float_features_[d][p % pipeline_depth_]; }
+    int32_t* GetLabels(int32_t d, int32_t p) override { return (int32_t*)labels_[d][p % pipeline_depth_]; }
+    int32_t* GetAggSrc(int32_t d, int32_t p) override { return (int32_t*)agg_src_[d][p % pipeline_depth_]; }
+    int32_t* GetAggDst(int32_t d, int32_t p) override { return (int32_t*)agg_dst_[d][p % pipeline_depth_]; }
+    int32_t* GetNodeCounter(int32_t d, int32_t p) override { return (int32_t*)node_counter_[d][p % pipeline_depth_]; }
+    int32_t* GetEdgeCounter(int32_t d, int32_t p) override { return (int32_t*)edge_counter_[d][p % pipeline_depth_]; }
+
+    void IPCPost(int32_t dev_id, int32_t current_pipe) override { sem_post(semw_[dev_id][current_pipe]); }
+    void IPCWait(int32_t dev_id, int32_t current_pipe) override { sem_wait(semr_[dev_id][current_pipe]); }
+
+    // ipc_service.cu:293-321
+    void Finalize() override
+    {
+        const std::string sfx = ipc_suffix();
+        for (int32_t i = 0; i < device_count_; i++) {
+            if (ids_[i].empty()) continue;
+            SetGPUDevice(i);
+            for (int32_t j = 0; j < pipeline_depth_; j++) {
+                d_free_space(ids_[i][j]);
+                if (j < (int32_t)float_features_[i].size()) d_free_space(float_features_[i][j]);
+                d_free_space(labels_[i][j]);
+                d_free_space(agg_src_[i][j]);
+                d_free_space(agg_dst_[i][j]);
+                d_free_space(node_counter_[i][j]);
+                d_free_space(edge_counter_[i][j]);
+                if (sem_close(semw_[i][j]) == -1) std::cout << "close sem " << i << " " << j << " failed\n";
+                sem_close(semr_[i][j]);
+                const std::string ssri = "sem_r_" + std::to_string(i) + "_" + std::to_string(j) + sfx;
+                const std::string sswi = "sem_w_" + std::to_string(i) + "_" + std::to_string(j) + sfx;
+                sem_unlink(ssri.c_str());
+                sem_unlink(sswi.c_str());
+            }
+            ids_[i].clear();
+        }
+        if (local_) {
+            delete local_;
+            local_ = nullptr;
+        } else {
+            sharedMemoryClose(&info_);
+            if (!shm_name_.empty()) shm_unlink(shm_name_.c_str());
+        }
+        shm_ = nullptr;
+    }
+
+    int32_t GetTrainStep() override { return train_step_; }
+
+private:
+    volatile shmStruct* shm_ = nullptr;
+    shmStruct* local_ = nullptr;
+    sharedMemoryInfo info_;
+    std::string shm_name_;
+    std::vector<std::vector<void*>> ids_, float_features_, labels_, agg_src_, agg_dst_, node_counter_, edge_counter_;
+    std::vector<std::vector<sem_t*>> semr_, semw_;
+    int32_t raw_batch_size_ = 0;
+    std::vector<int32_t> train_batch_size_, valid_batch_size_, test_batch_size_;
+    int32_t device_count_ = 0;
+    int32_t train_step_ = 0, valid_step_ = 0, test_step_ = 0;
+    int32_t epoch_ = 0;
+    int32_t pipeline_depth_ = INTERBATCH_CON;
+};
+
+IPCEnv* NewIPCEnvImpl(int32_t device_count, bool create_shm) { return new HIPIPCEnv(device_count, create_shm); }
+
+// ---- C API (ipc_service.h:35 NewIPCEnv + the host-only step arithmetic) ---------------------
+extern "C" LegionIPCEnv* NewIPCEnv(int32_t device_count)
+{
+    // LEGION_IPC_LOCAL=1: keep the slab in process memory (step arithmetic only, no /dev/shm entry)
+    const char* local = getenv("LEGION_IPC_LOCAL");
+    return reinterpret_cast<LegionIPCEnv*>(NewIPCEnvImpl(device_count, !(local && local[0] == '1')));
+}
+
+extern "C" void legion_ipc_coordinate(LegionIPCEnv* e, int32_t partition_count, const int32_t* train_num,
+                                      const int32_t* valid_num, const int32_t* test_num, int32_t raw_batch_size,
+                                      int32_t epoch)
+{
+    if (!e) { printf("invalid ipc env ptr\n"); return; }
+    BuildInfo info;
+    info.partition_count = partition_count;
+    info.training_set_num.assign(train_num, train_num + partition_count);
+    info.validation_set_num.assign(valid_num, valid_num + partition_count);
+    info.testing_set_num.assign(test_num, test_num + partition_count);
+    info.raw_batch_size = raw_batch_size;
+    info.epoch = epoch;
+    reinterpret_cast<IPCEnv*>(e)->Coordinate(&info);
+}
+
+extern "C" int32_t legion_ipc_train_step(LegionIPCEnv* e) { return reinterpret_cast<IPCEnv*>(e)->GetTrainStep(); }
+extern "C" int32_t legion_ipc_max_step(LegionIPCEnv* e) { return reinterpret_cast<IPCEnv*>(e)->GetMaxStep(); }
+extern "C" int32_t legion_ipc_current_mode(LegionIPCEnv* e, int32_t g) { return reinterpret_cast<IPCEnv*>(e)->GetCurrentMode(g); }
+extern "C" int32_t legion_ipc_local_batch_id(LegionIPCEnv* e, int32_t g) { return reinterpret_cast<IPCEnv*>(e)->GetLocalBatchId(g); }
+extern "C" int32_t legion_ipc_current_batchsize(LegionIPCEnv* e, int32_t d, int32_t m)
+{
+    return reinterpret_cast<IPCEnv*>(e)->GetCurrentBatchsize(d, m);
+}
+extern "C" void legion_ipc_finalize(LegionIPCEnv* e)
+{
+    if (!e) return;
+    IPCEnv* env = reinterpret_cast<IPCEnv*>(e);
+    env->Finalize();
+    delete env;
+}

@@ -1,0 +1,102 @@
+// kernels_synth.hip -- device-side generators for the synthetic workloads of BASELINE.md
+// (W1: RMAT-26, Graph500 a,b,c,d = 0.57,0.19,0.19,0.05; counter-hash float32 features).
+// The reference's offline dataset tooling (dataset/*, a Java WebGraph pipeline) is out of scope;
+// these produce arrays in the reference's in-memory formats directly in HBM.
+// Every value is a pure function of (seed, index), so a gathered feature row can be verified
+// byte-for-byte at full size without any host copy of the table (legion_synth_feature_check).
+#include "legion_core.h"
+
+namespace lg {
+
+__host__ __device__ inline uint64_t splitmix64(uint64_t x)
+{
+    x += 0x9E3779B97F4A7C15ull;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
+
+// one RMAT edge per thread; quadrant thresholds in 16.16 fixed point of (a, a+b, a+b+c)
+__global__ void rmat_kernel(int32_t scale, int64_t num_edges, uint64_t seed, int32_t* __restrict__ src_out,
+                            int32_t* __restrict__ dst_out)
+{
+    const uint32_t ta = (uint32_t)(0.57 * 65536.0), tab = (uint32_t)(0.76 * 65536.0), tabc = (uint32_t)(0.95 * 65536.0);
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < num_edges;
+         e += (int64_t)gridDim.x * blockDim.x) {
+        uint32_t u = 0, v = 0;
+        uint64_t h = 0;
+        for (int32_t level = 0; level < scale; level++) {
+            if ((level & 3) == 0) h = splitmix64(seed ^ ((uint64_t)e * 8ull + (uint64_t)(level >> 2)));
+            const uint32_t r = (uint32_t)(h >> ((level & 3) * 16)) & 0xFFFFu;
+            const uint32_t ubit = r >= tab ? 1u : 0u;                       // quadrants c, d
+            const uint32_t vbit = (r >= ta && r < tab) || r >= tabc ? 1u : 0u;   // quadrants b, d
+            u = (u << 1) | ubit;
+            v = (v << 1) | vbit;
+        }
+        if (u == v) v = u ^ 1u;                                             // no self loops
+        src_out[e] = (int32_t)u;
+        dst_out[e] = (int32_t)v;
+    }
+}
+
+__host__ __device__ inline float synth_feature_value(uint64_t seed, int64_t row, int32_t dim, int32_t f)
+{
+    const uint64_t h = splitmix64(seed ^ (uint64_t)(row * (int64_t)dim + f));
+    return (float)(int32_t)((uint32_t)(h >> 40)) * (1.0f / 8388608.0f) - 1.0f;   // 24 bits -> [-1, 1), exact
+}
+
+__global__ void synth_features_kernel(float* __restrict__ out, int64_t first_row, int64_t num_rows, int32_t dim,
+                                      uint64_t seed)
+{
+    const int64_t total = num_rows * dim;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / dim;
+        const int32_t f = (int32_t)(i - r * dim);
+        out[i] = synth_feature_value(seed, first_row + r, dim, f);
+    }
+}
+
+__global__ void synth_feature_check_kernel(const float* __restrict__ rows, const int32_t* __restrict__ ids,
+                                           int64_t num_rows, int32_t dim, uint64_t seed,
+                                           unsigned long long* __restrict__ mismatch)
+{
+    const int64_t total = num_rows * dim;
+    unsigned long long bad = 0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / dim;
+        const int32_t f = (int32_t)(i - r * dim);
+        const int32_t id = ids[r];
+        if (id < 0) continue;
+        const float want = synth_feature_value(seed, id, dim, f);
+        if (__float_as_uint(want) != __float_as_uint(rows[i])) bad++;
+    }
+    if (bad) atomicAdd(mismatch, bad);
+}
+
+}  // namespace lg
+
+extern "C" void legion_synth_rmat_edges(legion_stream_t stream, int32_t scale, int64_t num_edges, uint64_t seed,
+                                        int32_t* src_out, int32_t* dst_out)
+{
+    if (num_edges <= 0) return;
+    lg::rmat_kernel<<<4096, 256, 0, static_cast<hipStream_t>(stream)>>>(scale, num_edges, seed, src_out, dst_out);
+    hipCheckError();
+}
+
+extern "C" void legion_synth_features(legion_stream_t stream, float* out, int64_t first_row, int64_t num_rows,
+                                      int32_t dim, uint64_t seed)
+{
+    if (num_rows <= 0 || dim <= 0) return;
+    lg::synth_features_kernel<<<8192, 256, 0, static_cast<hipStream_t>(stream)>>>(out, first_row, num_rows, dim, seed);
+    hipCheckError();
+}
+
+extern "C" void legion_synth_feature_check(legion_stream_t stream, const float* rows, const int32_t* ids,
+                                           int64_t num_rows, int32_t dim, uint64_t seed,
+                                           unsigned long long* mismatch_count_devptr)
+{
+    if (num_rows <= 0 || dim <= 0) return;
+    lg::synth_feature_check_kernel<<<2048, 256, 0, static_cast<hipStream_t>(stream)>>>(rows, ids, num_rows, dim, seed,
+                                                                                      mismatch_count_devptr);
+    hipCheckError();
+}

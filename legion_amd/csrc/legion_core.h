@@ -1,0 +1,459 @@
+// legion_core.h -- host-side object model of the MI355X sampling server.
+//
+// The class and method names mirror the reference's plugin/operator interface for the hot path
+// (paths relative to the reference repo, SS = sampling_server/src):
+//   Operator / OpParams            SS/engine/operator.h:4-28
+//   Server / Runner / RunnerParams SS/engine/server.h:5-33
+//   MemoryPool                     SS/engine/memorypool.cuh:20-221
+//   GraphStorage                   SS/storage/graph_storage.cuh:7-24
+//   FeatureStorage                 SS/storage/feature_storage.cuh:6-34
+//   CacheController / UnifiedCache SS/cache/cache.cuh:10-177
+//   IPCEnv                         SS/engine/ipc_service.h:6-35
+// The implementations are new: device-resident counters (no host read-backs), a fused
+// first-touch/position state array instead of bitmap + position map, direct-mapped id->slot
+// tables instead of the vendored cuckoo hash, deterministic slot-ordered compaction.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <string>
+#include <vector>
+
+#include "../../include/legion_hip.h"
+
+#define INTERBATCH_CON LEGION_INTERBATCH_CON
+#define INTRABATCH_CON LEGION_INTRABATCH_CON
+#define MAX_DEVICE LEGION_MAX_DEVICE
+#define MEMORY_USAGE LEGION_MEMORY_USAGE
+#define TRAINMODE LEGION_TRAINMODE
+#define VALIDMODE LEGION_VALIDMODE
+#define TESTMODE LEGION_TESTMODE
+#define CACHEMISS_FLAG LEGION_CACHEMISS_FLAG
+
+// Error convention of the reference (cudaCheckError, SS/engine/operator_impl.cu:16-24): print and exit.
+#define hipCheckError()                                                                       \
+    {                                                                                         \
+        hipError_t e_ = hipGetLastError();                                                    \
+        if (e_ != hipSuccess) {                                                               \
+            printf("HIP failure %s:%d: '%s'\n", __FILE__, __LINE__, hipGetErrorString(e_));   \
+            exit(EXIT_FAILURE);                                                               \
+        }                                                                                     \
+    }
+#define HIP_CALL(expr)                                                                        \
+    {                                                                                         \
+        hipError_t e_ = (expr);                                                               \
+        if (e_ != hipSuccess) {                                                               \
+            printf("HIP failure %s:%d: '%s'\n", __FILE__, __LINE__, hipGetErrorString(e_));   \
+            exit(EXIT_FAILURE);                                                               \
+        }                                                                                     \
+    }
+
+// ---- position/first-touch state array (replaces accessed_map + position_map) ---------------
+// position_state[v] is LG_POS_UNTOUCHED between batches.  Inside a batch it holds either the
+// final position of v in sampled_ids (< LG_POS_PENDING) or, while a hop is being compacted,
+// LG_POS_PENDING + (lowest slot index that sampled v in this hop).
+#define LG_POS_UNTOUCHED 0x7F7F7F7F
+#define LG_POS_PENDING 0x40000000
+#define LG_MAX_SLOTS 0x3F000000
+
+// per-hop scratch written by the scan kernel, read by scatter / localise (device int32[16])
+enum HopScratch {
+    HS_FRONTIER_IS_SEEDS = 0,
+    HS_FRONTIER_OFF = 1,   // offset of the frontier inside agg_src_ids / agg_src_off
+    HS_FRONTIER_LEN = 2,
+    HS_NODE_BASE = 3,
+    HS_EDGE_BASE = 4,
+    HS_N_NEW = 5,
+    HS_N_EDGE = 6,
+    HS_SLOTS = 7,
+    HS_WORDS = 16
+};
+
+#define LG_TILE 256  // slots per tile == threads per block in the sampler kernels
+
+struct BuildInfo {  // SS/include/buildinfo.h (only the fields of the in-memory path)
+    int32_t partition_count = 0;
+    std::vector<int32_t> training_set_num, validation_set_num, testing_set_num;
+    std::vector<std::vector<int32_t>> training_set_ids, training_labels;
+    std::vector<std::vector<int32_t>> validation_set_ids, validation_labels;
+    std::vector<std::vector<int32_t>> testing_set_ids, testing_labels;
+    int32_t total_num_nodes = 0;
+    int32_t float_feature_len = 0;
+    float* host_float_feature = nullptr;   // device-dereferenceable (HBM or mapped pinned)
+    int64_t* csr_node_index = nullptr;     // device-dereferenceable
+    int32_t* csr_dst_node_ids = nullptr;
+    int64_t total_edge_num = 0;
+    int32_t epoch = 0;
+    int32_t raw_batch_size = 0;
+};
+
+// ---------------------------------------------------------------------------------------------
+class MemoryPool {
+public:
+    explicit MemoryPool(int32_t pipeline_depth)
+        : pipeline_depth_(pipeline_depth), float_features_(pipeline_depth, nullptr),
+          labels_(pipeline_depth, nullptr), node_counter_(pipeline_depth, nullptr),
+          edge_counter_(pipeline_depth, nullptr), sampled_ids_(pipeline_depth, nullptr),
+          agg_src_off_(pipeline_depth, nullptr), agg_dst_off_(pipeline_depth, nullptr) {}
+
+    int32_t GetIter() const { return iter_; }
+    int32_t GetCurrentMode() const { return mode_; }
+    int32_t GetCurrentPipe() const { return current_pipe_; }
+    int32_t PipelineDepth() const { return pipeline_depth_; }
+    float* GetFloatFeatures() const { return float_features_[current_pipe_]; }
+    int32_t* GetCacheSearchBuffer() const { return cache_search_buffer_; }
+    int32_t* GetLabels() const { return labels_[current_pipe_]; }
+    int32_t* GetPositionMap() const { return position_map_; }
+    int32_t* GetNodeCounter() const { return node_counter_[current_pipe_]; }
+    int32_t* GetEdgeCounter() const { return edge_counter_[current_pipe_]; }
+    int32_t* GetSampledIds() const { return sampled_ids_[current_pipe_]; }
+    int32_t* GetAggSrcId() const { return agg_src_ids_; }
+    int32_t* GetAggDstId() const { return agg_dst_ids_; }
+    int32_t* GetAggSrcOf() const { return agg_src_off_[current_pipe_]; }
+    int32_t* GetAggDstOf() const { return agg_dst_off_[current_pipe_]; }
+    char* GetTmpPartIdx() const { return tmp_part_ind_; }
+    int32_t* GetTmpPartOff() const { return tmp_part_off_; }
+
+    void SetFloatFeatures(float* p, int32_t pipe) { float_features_[pipe] = p; }
+    void SetCacheSearchBuffer(int32_t* p) { cache_search_buffer_ = p; }
+    void SetLabels(int32_t* p, int32_t pipe) { labels_[pipe] = p; }
+    void SetPositionMap(int32_t* p) { position_map_ = p; }
+    void SetNodeCounter(int32_t* p, int32_t pipe) { node_counter_[pipe] = p; }
+    void SetEdgeCounter(int32_t* p, int32_t pipe) { edge_counter_[pipe] = p; }
+    void SetSampledIds(int32_t* p, int32_t pipe) { sampled_ids_[pipe] = p; }
+    void SetAggSrcId(int32_t* p) { agg_src_ids_ = p; }
+    void SetAggDstId(int32_t* p) { agg_dst_ids_ = p; }
+    void SetAggSrcOf(int32_t* p, int32_t pipe) { agg_src_off_[pipe] = p; }
+    void SetAggDstOf(int32_t* p, int32_t pipe) { agg_dst_off_[pipe] = p; }
+    void SetTmpPartIdx(char* p) { tmp_part_ind_ = p; }
+    void SetTmpPartOff(int32_t* p) { tmp_part_off_ = p; }
+    void SetCurrentPipe(int32_t pipe) { current_pipe_ = pipe; }
+    void SetCurrentMode(int32_t mode) { mode_ = mode; }
+    void SetIter(int32_t iter) { iter_ = iter; }
+
+    // new in this build: sampler scratch (all device memory, private to the server)
+    int32_t* slot_dst = nullptr;       // [max_slots] sampled neighbour per slot (sign bit = first touch)
+    int32_t* tile_counts = nullptr;    // [2 * max_tiles] valid / first-touch counts per tile
+    int32_t* tile_prefix = nullptr;    // [2 * max_tiles] exclusive prefixes
+    int32_t* hop_scratch = nullptr;    // [HS_WORDS]
+    int32_t num_ids = 0;
+    int32_t max_slots = 0;             // largest hop = B * f1 * ... * fH
+    int32_t total_num_nodes = 0;
+    int32_t batch_size = 0;
+    int32_t float_feature_len = 0;
+    int64_t feature_rows = 0;
+    int32_t dev_id = 0;
+    bool owns_buffers = false;
+
+    void Finalize();
+
+private:
+    int32_t iter_ = 0;
+    int32_t mode_ = 0;
+    int32_t* cache_search_buffer_ = nullptr;
+    int32_t* position_map_ = nullptr;
+    int32_t* agg_src_ids_ = nullptr;
+    int32_t* agg_dst_ids_ = nullptr;
+    char* tmp_part_ind_ = nullptr;
+    int32_t* tmp_part_off_ = nullptr;
+    int32_t pipeline_depth_;
+    int32_t current_pipe_ = 0;
+    std::vector<float*> float_features_;
+    std::vector<int32_t*> labels_;
+    std::vector<int32_t*> node_counter_;
+    std::vector<int32_t*> edge_counter_;
+    std::vector<int32_t*> sampled_ids_;
+    std::vector<int32_t*> agg_src_off_;
+    std::vector<int32_t*> agg_dst_off_;
+};
+
+// ---------------------------------------------------------------------------------------------
+class GraphStorage {
+public:
+    virtual ~GraphStorage() = default;
+    virtual void Build(BuildInfo* info) = 0;
+    virtual void GraphCache(int32_t* QT, int32_t Ki, int32_t Kg, int32_t capacity) = 0;
+    virtual void Finalize() = 0;
+    virtual int32_t GetPartitionCount() const = 0;
+    virtual int64_t** GetCSRNodeIndex(int32_t part_id) const = 0;
+    virtual int32_t** GetCSRNodeMatrix(int32_t part_id) const = 0;
+    virtual int64_t* GetCSRNodeIndexCPU() const = 0;
+    virtual int32_t* GetCSRNodeMatrixCPU() const = 0;
+    virtual int32_t NodeNum() const = 0;
+    virtual int64_t EdgeNum() const = 0;
+};
+extern "C" GraphStorage* NewCompleteGraphStorage();
+
+class FeatureStorage {
+public:
+    virtual ~FeatureStorage() = default;
+    virtual void Build(BuildInfo* info, int in_memory_mode) = 0;
+    virtual void Finalize() = 0;
+    virtual int32_t* GetTrainingSetIds(int32_t part_id) const = 0;
+    virtual int32_t* GetValidationSetIds(int32_t part_id) const = 0;
+    virtual int32_t* GetTestingSetIds(int32_t part_id) const = 0;
+    virtual int32_t* GetTrainingLabels(int32_t part_id) const = 0;
+    virtual int32_t* GetValidationLabels(int32_t part_id) const = 0;
+    virtual int32_t* GetTestingLabels(int32_t part_id) const = 0;
+    virtual int32_t TrainingSetSize(int32_t part_id) const = 0;
+    virtual int32_t ValidationSetSize(int32_t part_id) const = 0;
+    virtual int32_t TestingSetSize(int32_t part_id) const = 0;
+    virtual int32_t TotalNodeNum() const = 0;
+    virtual float* GetAllFloatFeature() const = 0;
+    virtual int32_t GetFloatFeatureLen() const = 0;
+    // SSD tier: unreleased in the reference (feature_storage.cu:146-154 are TODO stubs); kept as no-ops
+    virtual void IOSubmit(int32_t*, int32_t*, int32_t*, float*, int32_t, int32_t, hipStream_t) {}
+    virtual void IOComplete() {}
+    // plain-buffer set-up used by the C API
+    virtual void SetIds(int32_t dev_id, int32_t mode, const int32_t* host_ids,
+                        const int32_t* host_labels, int32_t count) = 0;
+};
+extern "C" FeatureStorage* NewCompleteFeatureStorage();
+
+// ---------------------------------------------------------------------------------------------
+class CacheController {  // SS/cache/cache.cuh:10-62, the cache-policy plug-in point
+public:
+    virtual ~CacheController() = default;
+    virtual void Initialize(int32_t dev_id, int32_t total_num_nodes) = 0;
+    virtual void Finalize() = 0;
+    virtual void FindFeat(int32_t* sampled_ids, int32_t* cache_offset, int32_t* node_counter,
+                          int32_t op_id, void* stream) = 0;
+    virtual void FindTopo(int32_t* input_ids, char* partition_index, int32_t* partition_offset,
+                          int32_t batch_size, int32_t op_id, void* strm_hdl, int32_t device_id) = 0;
+    virtual void CacheProfiling(int32_t* sampled_ids, int32_t* agg_src_id, int32_t* agg_dst_id,
+                                int32_t* agg_src_off, int32_t* agg_dst_off, int32_t* node_counter,
+                                int32_t* edge_counter, bool is_presc, void* stream) = 0;
+    virtual void InitializeMap(int node_capacity, int edge_capacity) = 0;
+    virtual void Insert(int32_t* QT, int32_t* QF, int32_t cache_expand, int32_t Kg) = 0;
+    virtual void HybridInsert(int32_t* QF, int32_t cpu_cache_capacity, int32_t gpu_cache_capacity) = 0;
+    virtual void AccessCount(int32_t* d_key, int32_t num_keys, void* stream) = 0;
+    virtual unsigned long long int* GetNodeAccessedMap() = 0;
+    virtual unsigned long long int* GetEdgeAccessedMap() = 0;
+    virtual int32_t MaxIdNum() = 0;
+    // direct-mapped id->value tables (the bcht::find contract), device pointers, may be null
+    virtual const int32_t* NodeMap() const = 0;
+    virtual const char* EdgeIndexMap() const = 0;
+    virtual const int32_t* EdgeOffsetMap() const = 0;
+};
+CacheController* NewPreSCCacheController(int32_t train_step, int32_t device_count);
+
+class UnifiedCache {
+public:
+    void Initialize(int64_t cache_memory, int32_t float_feature_len, int32_t train_step,
+                    int32_t device_count, int32_t cpu_cache_capacity, int32_t gpu_cache_capacity);
+    void InitializeCacheController(int32_t dev_id, int32_t total_num_nodes);
+    void Finalize(int32_t dev_id);
+    void FindFeat(int32_t* sampled_ids, int32_t* cache_offset, int32_t* node_counter, int32_t op_id,
+                  void* stream, int32_t dev_id);
+    void FindTopo(int32_t* input_ids, char* partition_index, int32_t* partition_offset,
+                  int32_t batch_size, int32_t op_id, void* strm_hdl, int32_t dev_id);
+    void CacheProfiling(int32_t* sampled_ids, int32_t* agg_src_id, int32_t* agg_dst_id,
+                        int32_t* agg_src_off, int32_t* agg_dst_off, int32_t* node_counter,
+                        int32_t* edge_counter, void* stream, int32_t dev_id);
+    void CandidateSelection(int cache_agg_mode, FeatureStorage* feature, GraphStorage* graph);
+    void CostModel(int cache_agg_mode, FeatureStorage* feature, GraphStorage* graph,
+                   std::vector<uint64_t>& counters, int32_t train_step);
+    void FillUp(int cache_agg_mode, FeatureStorage* feature, GraphStorage* graph);
+    int32_t MaxIdNum(int32_t dev_id);
+    unsigned long long int* GetEdgeAccessedMap(int32_t dev_id);
+    void FeatCacheLookup(int32_t* sampled_ids, int32_t* cache_index, int32_t* node_counter,
+                         float* dst_float_buffer, int32_t op_id, int32_t dev_id, hipStream_t strm_hdl,
+                         int32_t max_rows);
+
+    // new / exposed for the C API and the fused kernels
+    void SetCapacity(int32_t node_capacity, int32_t edge_capacity);
+    int32_t NodeCapacity(int32_t dev_id) const;
+    int32_t EdgeCapacity(int32_t dev_id) const;
+    CacheController* Controller(int32_t dev_id) const { return cache_controller_[dev_id]; }
+    bool IsPresc() const { return is_presc_; }
+    bool world_reduced = false;   // hotness already all-reduced across processes (RCCL)
+    int32_t total_num_nodes_ = 0;
+    int32_t Kc_ = 1, Kg_ = 1;
+    int cache_agg_mode_ = 0;
+    std::vector<int32_t*> QF_, QT_;
+    std::vector<unsigned long long int*> AF_, AT_;
+    float** Global_Float_Feature_Cache(int32_t dev_id) const { return d_float_feature_cache_ptr_[dev_id]; }
+
+private:
+    int32_t device_count_ = 0;
+    std::vector<CacheController*> cache_controller_;
+    std::vector<int32_t> node_capacity_, edge_capacity_;
+    int32_t cpu_cache_capacity_ = 0, gpu_cache_capacity_ = 0;
+    int64_t cache_memory_ = 0;
+    std::vector<float*> float_feature_cache_;
+    std::vector<float**> d_float_feature_cache_ptr_;
+    int32_t float_feature_len_ = 0;
+    float* cpu_float_features_ = nullptr;
+    bool is_presc_ = true;
+};
+
+// ---------------------------------------------------------------------------------------------
+class IPCEnv {  // SS/engine/ipc_service.h:6-33
+public:
+    virtual ~IPCEnv() = default;
+    virtual void Coordinate(BuildInfo* info) = 0;
+    virtual int32_t GetMaxStep() = 0;
+    virtual void InitializeSamplesBuffer(int32_t batch_size, int32_t num_ids, int32_t feature_dim,
+                                         int32_t device_id, int32_t pipeline_depth) = 0;
+    virtual void InitializeFeaturesBuffer(int32_t batch_size, int32_t num_ids, int32_t feature_dim,
+                                          int32_t device_id, int32_t pipeline_depth) = 0;
+    virtual int32_t GetRawBatchsize() = 0;
+    virtual int32_t GetLocalBatchId(int32_t global_batch_id) = 0;
+    virtual int32_t GetCurrentBatchsize(int32_t dev_id, int32_t current_mode) = 0;
+    virtual int32_t GetCurrentMode(int32_t global_batch_id) = 0;
+    virtual int32_t* GetIds(int32_t dev_id, int32_t current_pipe) = 0;
+    virtual float* GetFloatFeatures(int32_t dev_id, int32_t current_pipe) = 0;
+    virtual int32_t* GetLabels(int32_t dev_id, int32_t current_pipe) = 0;
+    virtual int32_t* GetAggSrc(int32_t dev_id, int32_t current_pipe) = 0;
+    virtual int32_t* GetAggDst(int32_t dev_id, int32_t current_pipe) = 0;
+    virtual int32_t* GetNodeCounter(int32_t dev_id, int32_t current_pipe) = 0;
+    virtual int32_t* GetEdgeCounter(int32_t dev_id, int32_t current_pipe) = 0;
+    virtual void IPCPost(int32_t dev_id, int32_t current_pipe) = 0;
+    virtual void IPCWait(int32_t dev_id, int32_t current_pipe) = 0;
+    virtual void Finalize() = 0;
+    virtual int32_t GetTrainStep() = 0;
+};
+IPCEnv* NewIPCEnvImpl(int32_t device_count, bool create_shm);
+
+// ---------------------------------------------------------------------------------------------
+struct OpParams {  // SS/engine/operator.h:4-17
+    int device_id;
+    hipStream_t stream;
+    hipEvent_t event;
+    void* memorypool;
+    void* cache;
+    void* graph;
+    void* feature;
+    void* env;
+    int neighbor_count;
+    bool is_presc;
+    bool in_memory;
+    int hop_num;
+};
+
+class Operator {
+public:
+    virtual ~Operator() = default;
+    virtual void run(OpParams* params) = 0;
+};
+Operator* NewBatchGenerateOP(int op_id);
+Operator* NewRandomSampleOP(int op_id);
+Operator* NewCacheLookupOP(int op_id);
+Operator* NewSSDIOSubmitOP(int op_id);
+Operator* NewSSDIOCompleteOP(int op_id);
+
+struct RunnerParams {  // SS/engine/server.h:5-14
+    int device_id;
+    std::vector<int> fanout;
+    void* cache;
+    void* graph;
+    void* feature;
+    void* env;
+    int global_batch_id;
+    bool in_memory;
+};
+
+class Server {
+public:
+    virtual ~Server() = default;
+    virtual void Initialize(int global_shard_count, std::vector<int> fanout, int in_memory_mode) = 0;
+    virtual void PreSc(int cache_agg_mode) = 0;
+    virtual void Run() = 0;
+    virtual void Finalize() = 0;
+};
+
+class Runner {
+public:
+    virtual ~Runner() = default;
+    virtual void Initialize(RunnerParams* params) = 0;
+    virtual void InitializeFeaturesBuffer(RunnerParams* params) = 0;
+    virtual void RunPreSc(RunnerParams* params) = 0;
+    virtual void RunOnce(RunnerParams* params) = 0;
+    virtual void Finalize(RunnerParams* params) = 0;
+};
+Runner* NewGPURunner();
+
+void lg_pool_alloc_private(MemoryPool* mp, int32_t dev_id, int32_t total_num_nodes, int32_t batch_size,
+                           const int32_t* fanout, int32_t hop_num, int32_t float_feature_len);
+
+// alloc helpers, SS/engine/server_imp.cuh:2-51
+extern "C" void* d_alloc_space(int64_t num_bytes);
+extern "C" void d_free_space(void* d_ptr);
+extern "C" void* host_alloc_space(int64_t num_bytes);
+extern "C" void SetGPUDevice(int32_t shard_id);
+extern "C" int32_t GetGPUDevice();
+
+// ---------------------------------------------------------------------------------------------
+// kernel launchers (kernels_*.hip)
+namespace lg {
+
+void launch_batch_generate(hipStream_t s, int32_t* batch_ids, int32_t* labels, int32_t size,
+                           int32_t counter, const int32_t* all_ids, const int32_t* all_labels,
+                           int32_t total_cap, int32_t* position_map, int32_t* node_counter,
+                           int32_t* edge_counter, int32_t hop_num);
+
+struct SampleArgs {
+    int32_t op_id;
+    int32_t count;                  // fan-out of this hop
+    int32_t partition_count;        // P: slot of the full CSR in the pointer tables
+    int64_t* const* csr_node_index; // device table [P+1]
+    int32_t* const* csr_dst_node_ids;
+    const char* edge_index_map;     // id -> owner device or -2 (null: no topology cache)
+    const int32_t* edge_offset_map; // id -> row in the owner's cached CSR or -2
+    int32_t* sampled_ids;
+    int32_t* agg_src_ids;
+    int32_t* agg_dst_ids;
+    int32_t* agg_src_off;
+    int32_t* agg_dst_off;
+    char* tmp_part_ind;
+    int32_t* tmp_part_off;
+    int32_t* position_map;
+    int32_t* node_counter;
+    int32_t* edge_counter;
+    int32_t* slot_dst;
+    int32_t* tile_counts;
+    int32_t* tile_prefix;
+    int32_t* hop_scratch;
+    int32_t max_slots;              // capacity of slot_dst for this hop
+    unsigned long long* edge_access_time;  // presample only, else null
+    bool is_presc;
+};
+void launch_random_sample(hipStream_t s, const SampleArgs& a);
+
+void launch_gather(hipStream_t s, const float* full_table, const float* const* cache_tables,
+                   const int32_t* node_map, int32_t node_capacity, int32_t D, int32_t total_num_nodes,
+                   const int32_t* sampled_ids, int32_t* cache_index_out, const int32_t* range,
+                   int32_t* range_copy /* node_counter+2 or null */, float* dst, int32_t max_rows);
+
+void launch_clear_pos_map(hipStream_t s, int32_t* position_map, const int32_t* sampled_ids,
+                          const int32_t* node_counter);
+void launch_hotness_measure(hipStream_t s, const int32_t* sampled_ids, const int32_t* node_counter,
+                            unsigned long long* access_map);
+void launch_find(hipStream_t s, const int32_t* keys, int32_t n, const int32_t* map32,
+                 const char* map8, int32_t* out32, char* out8);
+void launch_draw_batch(hipStream_t s, const int32_t* idx, const int32_t* deg, int32_t* out, int32_t n);
+
+// set-up kernels (kernels_cache.hip)
+void aggregate_access(hipStream_t s, unsigned long long* agg, const unsigned long long* add, int32_t n);
+void sort_hotness_desc(hipStream_t s, unsigned long long* keys_inout, int32_t* order_out, int32_t n);
+void inclusive_scan_u64(hipStream_t s, const unsigned long long* in, unsigned long long* out, int32_t n);
+void edge_mem_in_order(hipStream_t s, const int32_t* order, unsigned long long* edge_mem, int32_t n,
+                       const int64_t* csr_index);
+void init_node_map(hipStream_t s, int32_t* node_map, const int32_t* QF, int32_t capacity, int32_t Kg,
+                   int32_t n);
+void init_edge_maps(hipStream_t s, char* index_map, int32_t* offset_map, const int32_t* QT,
+                    int32_t capacity, int32_t Kg, int32_t Ki, int32_t n);
+void fill_value_i32(hipStream_t s, int32_t* p, int32_t v, int64_t n);
+void fill_value_i8(hipStream_t s, char* p, char v, int64_t n);
+void feat_fill_up(hipStream_t s, int32_t capacity, int32_t D, float* cache, const float* table,
+                  const int32_t* QF, int32_t Kg, int32_t Ki, int32_t n);
+void topo_neighbor_count(hipStream_t s, const int32_t* QT, int32_t Kg, int32_t Ki, int32_t capacity,
+                         int32_t n, const int64_t* csr_index, int64_t* counts);
+void inclusive_scan_i64(hipStream_t s, const int64_t* in, int64_t* out, int32_t n);
+void topo_fill_up(hipStream_t s, const int32_t* QT, int32_t Kg, int32_t Ki, int32_t capacity, int32_t n,
+                  const int64_t* csr_index, const int32_t* csr_dst, const int64_t* d_index,
+                  int32_t* d_dst);
+}  // namespace lg

@@ -1,0 +1,293 @@
+// operators.hip -- the five extern "C" operator entry points and the Operator plug-in classes.
+//
+// Reference: SS/engine/operator_impl.cuh:11-63 (declarations), SS/engine/operator_impl.cu:92-172
+// (BatchGenerate), :401-499 (RandomSample), :502-519 (FeatureCacheLookup), :522-539 (IOSubmit),
+// :551-580 (IOComplete); SS/engine/operator.cu:15-122 (the five Operator::run bodies).
+//
+// Same names, argument order, null-pointer behaviour (message + return) and error convention.
+// Differences a maintainer should know about:
+//   * nothing here blocks on the device: the reference's 64-byte counter read-backs
+//     (operator_impl.cu:439-445, cache.cu:187-188) are gone because every kernel reads the
+//     frontier / node range from the counters in device memory;
+//   * FindTopo runs inside the sampling kernel and FindFeat inside the gather kernel; their
+//     outputs (tmp_part_ind/tmp_part_off, cache_search_buffer) are still written;
+//   * counter_update is folded into the kernels that produce the counts;
+//   * the accessed bitmap is fused into the position map (see legion_core.h), so BatchGenerate
+//     does not memset N/8 bytes per batch and IOComplete restores the map in every mode.
+#include "legion_core.h"
+
+#include <iostream>
+
+extern "C" void BatchGenerate(legion_stream_t strm_hdl, LegionFeatureStorage* feature_,
+                              LegionUnifiedCache* cache_, LegionMemoryPool* memorypool_,
+                              int32_t batch_size, int32_t counter, int32_t part_id, int32_t dev_id,
+                              int32_t mode, bool is_presc, int32_t hop_num);
+extern "C" void RandomSample(legion_stream_t strm_hdl, LegionGraphStorage* graph_, LegionUnifiedCache* cache_,
+                             LegionMemoryPool* memorypool_, int32_t count, int32_t dev_id, int32_t op_id,
+                             bool is_presc);
+
+// The C handles are the C++ objects themselves, except the cache, whose handle boxes the
+// UnifiedCache as its first member (cache.hip: LegionCacheBox).
+static inline UnifiedCache* cache_of(LegionUnifiedCache* c) { return reinterpret_cast<UnifiedCache*>(c); }
+
+extern "C" void BatchGenerate(legion_stream_t strm_hdl, LegionFeatureStorage* feature_,
+                              LegionUnifiedCache* cache_, LegionMemoryPool* memorypool_,
+                              int32_t batch_size, int32_t counter, int32_t part_id, int32_t dev_id,
+                              int32_t mode, bool is_presc, int32_t hop_num)
+{
+    (void)part_id; (void)cache_; (void)is_presc;
+    FeatureStorage* feature = reinterpret_cast<FeatureStorage*>(feature_);
+    MemoryPool* memorypool = reinterpret_cast<MemoryPool*>(memorypool_);
+    if (feature == nullptr || memorypool == nullptr) {
+        std::cout << "invalid storage ptr\n";
+        return;
+    }
+    int32_t* all_ids = nullptr;
+    int32_t* all_labels = nullptr;
+    int32_t total_cap = 0;
+    if (mode == TRAINMODE) {
+        all_ids = feature->GetTrainingSetIds(dev_id);
+        all_labels = feature->GetTrainingLabels(dev_id);
+        total_cap = feature->TrainingSetSize(dev_id);
+    } else if (mode == VALIDMODE) {
+        all_ids = feature->GetValidationSetIds(dev_id);
+        all_labels = feature->GetValidationLabels(dev_id);
+        total_cap = feature->ValidationSetSize(dev_id);
+    } else if (mode == TESTMODE) {
+        all_ids = feature->GetTestingSetIds(dev_id);
+        all_labels = feature->GetTestingLabels(dev_id);
+        total_cap = feature->TestingSetSize(dev_id);
+    } else {
+        std::cout << "invalid mode: " << mode << "\n";
+    }
+    if (all_ids == nullptr) {
+        std::cout << "invalid src id ptr\n";
+        return;
+    }
+    if (all_labels == nullptr) {
+        std::cout << "invalid label ptr\n";
+        return;
+    }
+    if (batch_size > memorypool->batch_size) {
+        std::cout << "batch size " << batch_size << " exceeds the pool's " << memorypool->batch_size << "\n";
+        return;
+    }
+    // operator_impl.cu:159
+    const int32_t size = ((int64_t)batch_size * (counter + 1) >= total_cap) ? (total_cap - batch_size * counter)
+                                                                          : batch_size;
+    lg::launch_batch_generate(static_cast<hipStream_t>(strm_hdl), memorypool->GetSampledIds(),
+                              memorypool->GetLabels(), size, counter, all_ids, all_labels, total_cap,
+                              memorypool->GetPositionMap(), memorypool->GetNodeCounter(),
+                              memorypool->GetEdgeCounter(), hop_num);
+    // cache->FindFeat(op 0) (:167-170) happens inside FeatureCacheLookup(op 1)
+}
+
+extern "C" void RandomSample(legion_stream_t strm_hdl, LegionGraphStorage* graph_, LegionUnifiedCache* cache_,
+                             LegionMemoryPool* memorypool_, int32_t count, int32_t dev_id, int32_t op_id,
+                             bool is_presc)
+{
+    GraphStorage* graph = reinterpret_cast<GraphStorage*>(graph_);
+    MemoryPool* memorypool = reinterpret_cast<MemoryPool*>(memorypool_);
+    UnifiedCache* cache = cache_of(cache_);
+    if (graph == nullptr || memorypool == nullptr) {
+        std::cout << "invalid storage ptr\n";
+        return;
+    }
+    if (op_id < INTRABATCH_CON || op_id % INTRABATCH_CON != 0 || count < 1) {
+        printf("Sampling Parameters Error\n");   // counter_update's complaint, operator_impl.cu:86-88
+        return;
+    }
+    lg::SampleArgs a;
+    a.op_id = op_id;
+    a.count = count;
+    a.partition_count = graph->GetPartitionCount();
+    a.csr_node_index = graph->GetCSRNodeIndex(dev_id);
+    a.csr_dst_node_ids = graph->GetCSRNodeMatrix(dev_id);
+    CacheController* cc = (cache && !is_presc) ? cache->Controller(dev_id) : nullptr;
+    a.edge_index_map = cc ? cc->EdgeIndexMap() : nullptr;
+    a.edge_offset_map = cc ? cc->EdgeOffsetMap() : nullptr;
+    a.sampled_ids = memorypool->GetSampledIds();
+    a.agg_src_ids = memorypool->GetAggSrcId();
+    a.agg_dst_ids = memorypool->GetAggDstId();
+    a.agg_src_off = memorypool->GetAggSrcOf();
+    a.agg_dst_off = memorypool->GetAggDstOf();
+    a.tmp_part_ind = memorypool->GetTmpPartIdx();
+    a.tmp_part_off = memorypool->GetTmpPartOff();
+    a.position_map = memorypool->GetPositionMap();
+    a.node_counter = memorypool->GetNodeCounter();
+    a.edge_counter = memorypool->GetEdgeCounter();
+    a.slot_dst = memorypool->slot_dst;
+    a.tile_counts = memorypool->tile_counts;
+    a.tile_prefix = memorypool->tile_prefix;
+    a.hop_scratch = memorypool->hop_scratch;
+    a.max_slots = memorypool->max_slots;
+    a.is_presc = is_presc;
+    a.edge_access_time = (is_presc && cache) ? cache->GetEdgeAccessedMap(dev_id) : nullptr;   // :473
+    lg::launch_random_sample(static_cast<hipStream_t>(strm_hdl), a);
+}
+
+extern "C" void FeatureCacheLookup(legion_stream_t strm_hdl, LegionUnifiedCache* cache_,
+                                   LegionMemoryPool* memorypool_, int32_t op_id, int32_t dev_id)
+{
+    MemoryPool* memorypool = reinterpret_cast<MemoryPool*>(memorypool_);
+    UnifiedCache* cache = cache_of(cache_);
+    if (cache == nullptr || memorypool == nullptr) {
+        std::cout << "invalid storage ptr\n";
+        return;
+    }
+    if (memorypool->GetFloatFeatures() == nullptr) {
+        std::cout << "feature buffer not initialized\n";
+        return;
+    }
+    int64_t max_rows = memorypool->feature_rows;
+    if (max_rows > memorypool->num_ids) max_rows = memorypool->num_ids;
+    cache->FeatCacheLookup(memorypool->GetSampledIds(), memorypool->GetCacheSearchBuffer(),
+                           memorypool->GetNodeCounter(), memorypool->GetFloatFeatures(), op_id, dev_id,
+                           static_cast<hipStream_t>(strm_hdl), (int32_t)max_rows);
+}
+
+extern "C" void IOSubmit(legion_stream_t, LegionFeatureStorage*, LegionMemoryPool*, int32_t, int32_t)
+{
+    // SSD tier: the reference body is commented out (operator_impl.cu:522-539); nothing to do
+}
+
+extern "C" void IOComplete(legion_stream_t strm_hdl, LegionUnifiedCache* cache_, LegionMemoryPool* memorypool_,
+                           int32_t dev_id, int32_t mode)
+{
+    MemoryPool* memorypool = reinterpret_cast<MemoryPool*>(memorypool_);
+    UnifiedCache* cache = cache_of(cache_);
+    if (memorypool == nullptr) {
+        std::cout << "invalid storage ptr\n";
+        return;
+    }
+    hipStream_t s = static_cast<hipStream_t>(strm_hdl);
+    if (mode == TRAINMODE && cache != nullptr)   // CacheProfiling only in train mode (:558,:578)
+        cache->CacheProfiling(memorypool->GetSampledIds(), memorypool->GetAggSrcId(), memorypool->GetAggDstId(),
+                              memorypool->GetAggSrcOf(), memorypool->GetAggDstOf(), memorypool->GetNodeCounter(),
+                              memorypool->GetEdgeCounter(), s, dev_id);
+    lg::launch_clear_pos_map(s, memorypool->GetPositionMap(), memorypool->GetSampledIds(),
+                             memorypool->GetNodeCounter());
+}
+
+// =============================================================================================
+// SS/engine/operator.cu:15-122
+class BatchGenerateOP : public Operator {
+public:
+    explicit BatchGenerateOP(int op_id) : op_id_(op_id) {}
+    void run(OpParams* params) override
+    {
+        MemoryPool* memorypool = (MemoryPool*)(params->memorypool);
+        IPCEnv* env = (IPCEnv*)(params->env);
+        const int32_t device_id = params->device_id;
+        const int32_t mode = memorypool->GetCurrentMode();
+        const int32_t iter = memorypool->GetIter();
+        const int32_t batch_size = env->GetCurrentBatchsize(device_id, mode);
+        BatchGenerate(params->stream, (LegionFeatureStorage*)params->feature, (LegionUnifiedCache*)params->cache,
+                      (LegionMemoryPool*)memorypool, batch_size, iter, device_id, device_id, mode,
+                      params->is_presc, params->hop_num);
+        HIP_CALL(hipEventRecord(params->event, params->stream));
+    }
+private:
+    int op_id_;
+};
+Operator* NewBatchGenerateOP(int op_id) { return new BatchGenerateOP(op_id); }
+
+class RandomSampleOP : public Operator {
+public:
+    explicit RandomSampleOP(int op_id) : op_id_(op_id) {}
+    void run(OpParams* params) override
+    {
+        RandomSample(params->stream, (LegionGraphStorage*)params->graph, (LegionUnifiedCache*)params->cache,
+                     (LegionMemoryPool*)params->memorypool, params->neighbor_count, params->device_id, op_id_,
+                     params->is_presc);
+        HIP_CALL(hipEventRecord(params->event, params->stream));
+    }
+private:
+    int op_id_;
+};
+Operator* NewRandomSampleOP(int op_id) { return new RandomSampleOP(op_id); }
+
+class CacheLookupOP : public Operator {
+public:
+    explicit CacheLookupOP(int op_id) : op_id_(op_id) {}
+    void run(OpParams* params) override
+    {
+        FeatureCacheLookup(params->stream, (LegionUnifiedCache*)params->cache,
+                           (LegionMemoryPool*)params->memorypool, op_id_, params->device_id);
+        HIP_CALL(hipEventRecord(params->event, params->stream));
+    }
+private:
+    int op_id_;
+};
+Operator* NewCacheLookupOP(int op_id) { return new CacheLookupOP(op_id); }
+
+class SSDIOSubmitOP : public Operator {
+public:
+    explicit SSDIOSubmitOP(int op_id) : op_id_(op_id) {}
+    void run(OpParams* params) override
+    {
+        IOSubmit(params->stream, (LegionFeatureStorage*)params->feature, (LegionMemoryPool*)params->memorypool,
+                 op_id_, params->device_id);
+        HIP_CALL(hipEventRecord(params->event, params->stream));
+    }
+private:
+    int op_id_;
+};
+Operator* NewSSDIOSubmitOP(int op_id) { return new SSDIOSubmitOP(op_id); }
+
+class SSDIOCompleteOP : public Operator {
+public:
+    explicit SSDIOCompleteOP(int op_id) : op_id_(op_id) {}
+    void run(OpParams* params) override
+    {
+        MemoryPool* memorypool = (MemoryPool*)(params->memorypool);
+        IOComplete(params->stream, (LegionUnifiedCache*)params->cache, (LegionMemoryPool*)memorypool,
+                   params->device_id, memorypool->GetCurrentMode());
+        HIP_CALL(hipEventRecord(params->event, params->stream));
+    }
+private:
+    int op_id_;
+};
+Operator* NewSSDIOCompleteOP(int op_id) { return new SSDIOCompleteOP(op_id); }
+
+// ---- kernel-level C entry points ----------------------------------------------------------
+extern "C" void legion_gather_rows(legion_stream_t stream, const float* full_table,
+                                   const float* const* cache_tables, const int32_t* node_map,
+                                   int32_t node_capacity, int32_t float_feature_len, int32_t total_num_nodes,
+                                   const int32_t* sampled_ids, int32_t* cache_index_out,
+                                   const int32_t* range_devptr, float* dst, int32_t max_rows)
+{
+    lg::launch_gather(static_cast<hipStream_t>(stream), full_table, cache_tables, node_map, node_capacity,
+                      float_feature_len, total_num_nodes, sampled_ids, cache_index_out, range_devptr, nullptr,
+                      dst, max_rows);
+}
+
+extern "C" void legion_draw_batch(legion_stream_t stream, const int32_t* idx, const int32_t* deg, int32_t* out,
+                                  int32_t n)
+{
+    lg::launch_draw_batch(static_cast<hipStream_t>(stream), idx, deg, out, n);
+}
+
+// One whole mini-batch in the op order of GPURunner::RunOnce / RunPreSc (SS/engine/server.cu:285-332)
+// without the IPC hand-off: what a Runner enqueues per batch, exposed for callers that own the
+// buffers themselves (tests, bench.py, an in-process trainer).
+extern "C" void legion_enqueue_batch(legion_stream_t strm_hdl, LegionGraphStorage* graph, LegionFeatureStorage* feature,
+                                     LegionUnifiedCache* cache, LegionMemoryPool* memorypool, int32_t batch_size,
+                                     int32_t counter, int32_t dev_id, int32_t mode, bool is_presc,
+                                     const int32_t* fanout, int32_t hop_num)
+{
+    BatchGenerate(strm_hdl, feature, cache, memorypool, batch_size, counter, dev_id, dev_id, mode, is_presc, hop_num);
+    if (!is_presc) {
+        FeatureCacheLookup(strm_hdl, cache, memorypool, 1, dev_id);
+        IOSubmit(strm_hdl, feature, memorypool, 2, dev_id);
+    }
+    for (int32_t h = 0; h < hop_num; h++) {
+        const int32_t op = INTRABATCH_CON * (h + 1);
+        RandomSample(strm_hdl, graph, cache, memorypool, fanout[h], dev_id, op, is_presc);
+        if (!is_presc) {
+            FeatureCacheLookup(strm_hdl, cache, memorypool, op + 1, dev_id);
+            IOSubmit(strm_hdl, feature, memorypool, op + 2, dev_id);
+        }
+    }
+    IOComplete(strm_hdl, cache, memorypool, dev_id, mode);
+}

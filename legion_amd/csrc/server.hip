@@ -1,0 +1,533 @@
+// server.hip -- StorageManagement, GPURunner, GPUServer and the binary / pybind-style entry.
+//
+// Reference: SS/storage/storage_management.cu (EnableP2PAccess :5-23, ReadMetaFIle :29-98,
+// LoadGraph :100-115, LoadFeature :118-232, Initialze :234-269), SS/engine/server.cu (GPUServer
+// :44-169, GPURunner :170-365, PreSCLoop/RunnerLoop :29-42), SS/main.cu,
+// sampling_server/sampling_server.cpp:7.
+//
+// Kept: the meta_config -> argv -> op DAG chain, one host thread per GPU, the op order
+// (3*(hops+1)+1 ops), the two-deep pipe with semaphores, the log lines ("System is ready for
+// serving" is the trainer's start signal).  Changed: all ops of a batch are enqueued on one HIP
+// stream without any host synchronisation in between (the kernels read their sizes on the
+// device), and the batch is posted only after the LAST op has completed (the reference records
+// only stream 0's last event).  Full CSR / feature table go to HBM when they fit
+// (288 GB per MI355X), to mapped pinned host memory otherwise.
+#include "legion_core.h"
+
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <chrono>
+#include <cstring>
+#include <fstream>
+#include <iostream>
+#include <sstream>
+#include <thread>
+
+// ---------------------------------------------------------------------------------------------
+static bool read_file_into(const std::string& path, void* dst, size_t bytes)
+{
+    int fd = open(path.c_str(), O_RDONLY);
+    if (fd == -1) {
+        std::cout << "cannout open file: " << path << "\n";
+        return false;
+    }
+    size_t done = 0;
+    char* p = (char*)dst;
+    while (done < bytes) {
+        ssize_t r = read(fd, p + done, bytes - done);
+        if (r <= 0) break;
+        done += (size_t)r;
+    }
+    close(fd);
+    if (done < bytes) memset(p + done, 0, bytes - done);
+    return done == bytes;
+}
+
+static int64_t file_size(const std::string& path)
+{
+    struct stat st;
+    if (stat(path.c_str(), &st) != 0) return -1;
+    return (int64_t)st.st_size;
+}
+
+// a host staging buffer pushed to HBM, or mapped pinned memory if HBM placement is not possible
+struct Placement {
+    void* dev_ptr = nullptr;
+    bool in_hbm = false;
+};
+
+static Placement place_table(const std::string& path, size_t bytes, bool want_hbm, bool zero_if_missing)
+{
+    Placement pl;
+    void* pinned = nullptr;
+    HIP_CALL(hipHostMalloc(&pinned, bytes ? bytes : 16, hipHostMallocMapped));
+    const bool present = file_size(path) >= 0;
+    if (present)
+        read_file_into(path, pinned, bytes);
+    else if (zero_if_missing)
+        memset(pinned, 0, bytes);
+    if (want_hbm) {
+        size_t free_b = 0, total_b = 0;
+        HIP_CALL(hipMemGetInfo(&free_b, &total_b));
+        if (bytes < free_b / 10 * 7) {
+            void* d = d_alloc_space((int64_t)bytes);
+            HIP_CALL(hipMemcpy(d, pinned, bytes, hipMemcpyHostToDevice));
+            HIP_CALL(hipHostFree(pinned));
+            pl.dev_ptr = d;
+            pl.in_hbm = true;
+            return pl;
+        }
+    }
+    HIP_CALL(hipHostGetDevicePointer(&pl.dev_ptr, pinned, 0));
+    return pl;
+}
+
+class StorageManagement {
+public:
+    // SS/storage/storage_management.cu:5-23
+    void EnableP2PAccess()
+    {
+        int32_t device_count = legion_device_count();
+        for (int32_t i = 0; i < device_count; i++) {
+            HIP_CALL(hipSetDevice(i));
+            for (int32_t j = 0; j < device_count; j++) {
+                if (j == i) continue;
+                int32_t accessible = 0;
+                HIP_CALL(hipDeviceCanAccessPeer(&accessible, i, j));
+                if (accessible) {
+                    hipError_t e = hipDeviceEnablePeerAccess(j, 0);
+                    if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) {
+                        printf("HIP failure %s:%d: '%s'\n", __FILE__, __LINE__, hipGetErrorString(e));
+                        exit(EXIT_FAILURE);
+                    }
+                    (void)hipGetLastError();
+                }
+            }
+        }
+    }
+
+    // SS/storage/storage_management.cu:29-98 (in-memory fields; the disk-mode extras are the
+    // unreleased SSD tier)
+    bool ReadMetaFIle(BuildInfo* info)
+    {
+        std::ifstream Metafile("./meta_config");
+        if (!Metafile.is_open()) {
+            std::cout << "unable to open meta config file" << "\n";
+            return false;
+        }
+        std::string buff;
+        getline(Metafile, buff);
+        std::istringstream iss(buff);
+        iss >> dataset_path_;
+        std::cout << "Dataset path:       " << dataset_path_ << "\n";
+        iss >> raw_batch_size_;
+        std::cout << "Raw Batchsize:      " << raw_batch_size_ << "\n";
+        info->raw_batch_size = raw_batch_size_;
+        iss >> node_num_;
+        std::cout << "Graph nodes num:    " << node_num_ << "\n";
+        iss >> edge_num_;
+        std::cout << "Graph edges num:    " << edge_num_ << "\n";
+        iss >> float_feature_len_;
+        std::cout << "Feature dim:        " << float_feature_len_ << "\n";
+        iss >> training_set_num_;
+        std::cout << "Training set num:   " << training_set_num_ << "\n";
+        iss >> validation_set_num_;
+        std::cout << "Validation set num: " << validation_set_num_ << "\n";
+        iss >> testing_set_num_;
+        std::cout << "Testing set num:    " << testing_set_num_ << "\n";
+        iss >> cache_memory_;
+        std::cout << "Cache memory:       " << cache_memory_ << "\n";
+        iss >> epoch_;
+        std::cout << "Train epoch:        " << epoch_ << "\n";
+        info->epoch = epoch_;
+        return true;
+    }
+
+    // SS/storage/storage_management.cu:100-115; file formats SURVEY.md A.5
+    void LoadGraph(BuildInfo* info)
+    {
+        info->total_edge_num = edge_num_;
+        const bool hbm = want_hbm();
+        Placement ip = place_table(dataset_path_ + "edge_src", (size_t)(node_num_ + 1) * sizeof(int64_t), hbm, true);
+        Placement ci = place_table(dataset_path_ + "edge_dst", (size_t)edge_num_ * sizeof(int32_t), hbm, true);
+        info->csr_node_index = (int64_t*)ip.dev_ptr;
+        info->csr_dst_node_ids = (int32_t*)ci.dev_ptr;
+        std::cout << "Topology placement: " << (ip.in_hbm && ci.in_hbm ? "HBM" : "pinned host") << "\n";
+    }
+
+    // SS/storage/storage_management.cu:118-232
+    void LoadFeature(BuildInfo* info)
+    {
+        const int32_t partition_count = info->partition_count;
+        info->training_set_ids.assign(partition_count, {});
+        info->training_labels.assign(partition_count, {});
+        info->validation_set_ids.assign(partition_count, {});
+        info->validation_labels.assign(partition_count, {});
+        info->testing_set_ids.assign(partition_count, {});
+        info->testing_labels.assign(partition_count, {});
+        std::vector<int32_t> training_ids(training_set_num_), validation_ids(validation_set_num_),
+            testing_ids(testing_set_num_), all_labels(node_num_, 0), partition_index;
+        read_file_into(dataset_path_ + "trainingset", training_ids.data(), training_ids.size() * 4);
+        read_file_into(dataset_path_ + "validationset", validation_ids.data(), validation_ids.size() * 4);
+        read_file_into(dataset_path_ + "testingset", testing_ids.data(), testing_ids.size() * 4);
+        // v2 of the reference leaves features uninitialised and labels zero (:162,:164); this build
+        // reads both files when they exist and zero-fills otherwise.
+        Placement fp = place_table(dataset_path_ + "features", (size_t)node_num_ * float_feature_len_ * sizeof(float),
+                                   want_hbm(), true);
+        if (file_size(dataset_path_ + "labels") >= 0)
+            read_file_into(dataset_path_ + "labels", all_labels.data(), all_labels.size() * 4);
+        const bool have_partition = file_size(dataset_path_ + "partition") >= (int64_t)node_num_ * 4;
+        if (have_partition) {
+            partition_index.resize(node_num_);
+            read_file_into(dataset_path_ + "partition", partition_index.data(), partition_index.size() * 4);
+        } else {
+            std::cout << "cannout open file: " << dataset_path_ + "partition" << "\n";
+        }
+        std::cout << "Finish Reading All Files\n";
+        int trainingset_count = 0;
+        for (int32_t tid : training_ids) {                                  // :171-184
+            const int32_t part_id = have_partition ? partition_index[tid] : tid % partition_count;
+            if (part_id < partition_count) {
+                info->training_set_ids[part_id].push_back(tid);
+                trainingset_count++;
+            }
+        }
+        std::cout << "training set count " << trainingset_count << "\n";
+        for (int32_t tid : validation_ids) info->validation_set_ids[tid % partition_count].push_back(tid);
+        for (int32_t tid : testing_ids) info->testing_set_ids[tid % partition_count].push_back(tid);
+        for (int32_t p = 0; p < partition_count; p++) {
+            for (int32_t id : info->training_set_ids[p]) info->training_labels[p].push_back(all_labels[id]);
+            for (int32_t id : info->validation_set_ids[p]) info->validation_labels[p].push_back(all_labels[id]);
+            for (int32_t id : info->testing_set_ids[p]) info->testing_labels[p].push_back(all_labels[id]);
+            info->training_set_num.push_back((int32_t)info->training_set_ids[p].size());
+            info->validation_set_num.push_back((int32_t)info->validation_set_ids[p].size());
+            info->testing_set_num.push_back((int32_t)info->testing_set_ids[p].size());
+        }
+        info->host_float_feature = (float*)fp.dev_ptr;
+        info->float_feature_len = float_feature_len_;
+        info->total_num_nodes = node_num_;
+        std::cout << "Feature placement:  " << (fp.in_hbm ? "HBM" : "pinned host") << "\n";
+    }
+
+    // SS/storage/storage_management.cu:234-269
+    bool Initialze(int32_t partition_count, int32_t in_memory_mode)
+    {
+        (void)in_memory_mode;
+        BuildInfo* info = new BuildInfo();
+        EnableP2PAccess();
+        info->partition_count = partition_count;
+        if (!ReadMetaFIle(info)) return false;
+        SetGPUDevice(0);
+        LoadGraph(info);
+        LoadFeature(info);
+        env_ = NewIPCEnvImpl(partition_count, true);
+        env_->Coordinate(info);
+        feature_ = NewCompleteFeatureStorage();
+        feature_->Build(info, in_memory_mode);
+        graph_ = NewCompleteGraphStorage();
+        graph_->Build(info);
+        hipCheckError();
+        cache_ = new UnifiedCache();
+        const int32_t train_step = env_->GetTrainStep();
+        SetGPUDevice(0);
+        cache_->Initialize(cache_memory_, float_feature_len_, train_step, partition_count, 0, 0);
+        std::cout << "Storage Initialized\n";
+        info_ = info;
+        return true;
+    }
+
+    GraphStorage* GetGraph() { return graph_; }
+    FeatureStorage* GetFeature() { return feature_; }
+    UnifiedCache* GetCache() { return cache_; }
+    IPCEnv* GetIPCEnv() { return env_; }
+
+private:
+    static bool want_hbm()
+    {
+        const char* p = getenv("LEGION_TABLE_PLACEMENT");   // "hbm" (default) | "pinned"
+        return !(p && strcmp(p, "pinned") == 0);
+    }
+    std::string dataset_path_;
+    int32_t raw_batch_size_ = 0, node_num_ = 0, float_feature_len_ = 0;
+    int64_t edge_num_ = 0, cache_memory_ = 0;
+    int32_t training_set_num_ = 0, validation_set_num_ = 0, testing_set_num_ = 0, epoch_ = 0;
+    GraphStorage* graph_ = nullptr;
+    FeatureStorage* feature_ = nullptr;
+    UnifiedCache* cache_ = nullptr;
+    IPCEnv* env_ = nullptr;
+    BuildInfo* info_ = nullptr;
+};
+
+// =============================================================================================
+class GPURunner : public Runner {
+public:
+    // SS/engine/server.cu:172-273
+    void Initialize(RunnerParams* params) override
+    {
+        SetGPUDevice(params->device_id);
+        local_dev_id_ = params->device_id;
+        UnifiedCache* cache = (UnifiedCache*)(params->cache);
+        FeatureStorage* feature = (FeatureStorage*)(params->feature);
+        IPCEnv* env = (IPCEnv*)(params->env);
+
+        streams_.resize(INTRABATCH_CON);
+        for (int i = 0; i < INTRABATCH_CON; i++) HIP_CALL(hipStreamCreate(&streams_[i]));
+
+        const int batch_size = env->GetRawBatchsize();
+        const int hop_num = (int)params->fanout.size();
+        std::vector<int32_t> fanout(params->fanout.begin(), params->fanout.end());
+
+        op_num_ = (hop_num + 1) * INTRABATCH_CON + 1;
+        op_factory_.resize(op_num_);
+        op_factory_[0] = NewBatchGenerateOP(0);
+        op_factory_[1] = NewCacheLookupOP(1);
+        op_factory_[2] = NewSSDIOSubmitOP(2);
+        for (int i = 0; i < hop_num; i++) {
+            op_factory_[INTRABATCH_CON * i + 3] = NewRandomSampleOP(INTRABATCH_CON * i + 3);
+            op_factory_[INTRABATCH_CON * i + 4] = NewCacheLookupOP(INTRABATCH_CON * i + 4);
+            op_factory_[INTRABATCH_CON * i + 5] = NewSSDIOSubmitOP(INTRABATCH_CON * i + 5);
+        }
+        op_factory_[op_num_ - 1] = NewSSDIOCompleteOP(op_num_ - 1);
+
+        interbatch_concurrency_ = INTERBATCH_CON;
+        const int total_num_nodes = feature->TotalNodeNum();
+        cache->InitializeCacheController(local_dev_id_, total_num_nodes);
+
+        memorypool_ = new MemoryPool(interbatch_concurrency_);
+        float_feature_len_ = feature->GetFloatFeatureLen();
+        lg_pool_alloc_private(memorypool_, local_dev_id_, total_num_nodes, batch_size, fanout.data(), hop_num,
+                              float_feature_len_);
+        num_ids_ = memorypool_->num_ids;
+        env->InitializeSamplesBuffer(batch_size, num_ids_, float_feature_len_, local_dev_id_, interbatch_concurrency_);
+        current_pipe_ = 0;
+        for (int i = 0; i < INTERBATCH_CON; i++) {
+            memorypool_->SetSampledIds(env->GetIds(local_dev_id_, i), i);
+            memorypool_->SetLabels(env->GetLabels(local_dev_id_, i), i);
+            memorypool_->SetAggSrcOf(env->GetAggSrc(local_dev_id_, i), i);
+            memorypool_->SetAggDstOf(env->GetAggDst(local_dev_id_, i), i);
+            memorypool_->SetNodeCounter(env->GetNodeCounter(local_dev_id_, i), i);
+            memorypool_->SetEdgeCounter(env->GetEdgeCounter(local_dev_id_, i), i);
+        }
+        // PreSC runs before the feature buffers exist; BatchGenerate/RandomSample never touch them.
+
+        events_.resize(op_num_);
+        op_params_.resize(op_num_);
+        for (int i = 0; i < op_num_; i++) {
+            op_params_[i] = new OpParams();
+            op_params_[i]->device_id = local_dev_id_;
+            op_params_[i]->stream = streams_[0];   // one in-order stream per batch, see file header
+            HIP_CALL(hipEventCreateWithFlags(&events_[i], hipEventDisableTiming));
+            op_params_[i]->event = events_[i];
+            op_params_[i]->memorypool = memorypool_;
+            op_params_[i]->cache = cache;
+            op_params_[i]->graph = params->graph;
+            op_params_[i]->feature = feature;
+            op_params_[i]->env = env;
+            op_params_[i]->in_memory = params->in_memory;
+            op_params_[i]->hop_num = hop_num;
+            op_params_[i]->neighbor_count = 0;
+        }
+        for (int i = 0; i < hop_num; i++)
+            op_params_[INTRABATCH_CON * i + INTRABATCH_CON]->neighbor_count = params->fanout[i];
+    }
+
+    // SS/engine/server.cu:275-283
+    void InitializeFeaturesBuffer(RunnerParams* params) override
+    {
+        UnifiedCache* cache = (UnifiedCache*)(params->cache);
+        int32_t num_ids = int32_t((cache->MaxIdNum(local_dev_id_)) * 1.2);
+        if (num_ids < 1) num_ids = 1;
+        IPCEnv* env = (IPCEnv*)(params->env);
+        env->InitializeFeaturesBuffer(0, num_ids, float_feature_len_, local_dev_id_, interbatch_concurrency_);
+        for (int i = 0; i < interbatch_concurrency_; i++)
+            memorypool_->SetFloatFeatures(env->GetFloatFeatures(local_dev_id_, i), i);
+        memorypool_->feature_rows = num_ids;
+    }
+
+    // SS/engine/server.cu:285-300
+    void RunPreSc(RunnerParams* params) override
+    {
+        SetGPUDevice(local_dev_id_);
+        memorypool_->SetCurrentMode(0);
+        memorypool_->SetIter(params->global_batch_id);
+        for (int i = 0; i < op_num_; i += INTRABATCH_CON) {
+            op_params_[i]->is_presc = true;
+            op_factory_[i]->run(op_params_[i]);
+        }
+        HIP_CALL(hipEventSynchronize(op_params_[op_num_ - 1]->event));
+    }
+
+    // SS/engine/server.cu:302-332
+    void RunOnce(RunnerParams* params) override
+    {
+        SetGPUDevice(local_dev_id_);
+        IPCEnv* env = (IPCEnv*)(params->env);
+        const int32_t batch_id = params->global_batch_id;
+        mode_ = env->GetCurrentMode(batch_id);
+        memorypool_->SetCurrentMode(mode_);
+        memorypool_->SetIter(env->GetLocalBatchId(batch_id));
+        env->IPCWait(local_dev_id_, current_pipe_);
+        for (int i = 0; i < op_num_; i++) {
+            op_params_[i]->is_presc = false;
+            op_factory_[i]->run(op_params_[i]);
+        }
+        HIP_CALL(hipEventSynchronize(op_params_[op_num_ - 1]->event));   // every op is on this stream
+        env->IPCPost(local_dev_id_, current_pipe_);
+        if (batch_id % 1000 == 0 && local_dev_id_ == 0) std::cout << "batch id: " << batch_id << "\n";
+        current_pipe_ = (current_pipe_ + 1) % interbatch_concurrency_;
+        memorypool_->SetCurrentPipe(current_pipe_);
+    }
+
+    void Finalize(RunnerParams* params) override
+    {
+        IPCEnv* env = (IPCEnv*)(params->env);
+        env->IPCWait(local_dev_id_, (current_pipe_ + 1) % interbatch_concurrency_);
+        SetGPUDevice(local_dev_id_);
+        memorypool_->Finalize();
+    }
+
+private:
+    int32_t num_ids_ = 0;
+    int32_t float_feature_len_ = 0;
+    MemoryPool* memorypool_ = nullptr;
+    int current_pipe_ = 0;
+    int interbatch_concurrency_ = INTERBATCH_CON;
+    int local_dev_id_ = 0;
+    int mode_ = 0;
+    int op_num_ = 0;
+    std::vector<hipStream_t> streams_;
+    std::vector<hipEvent_t> events_;
+    std::vector<Operator*> op_factory_;
+    std::vector<OpParams*> op_params_;
+};
+
+Runner* NewGPURunner() { return new GPURunner(); }
+
+// =============================================================================================
+static void PreSCLoop(int train_step, Runner* runner, RunnerParams* params)
+{
+    for (int i = 0; i < train_step; i++) {
+        params->global_batch_id = i;
+        runner->RunPreSc(params);
+    }
+    runner->InitializeFeaturesBuffer(params);
+}
+
+static void RunnerLoop(int max_step, Runner* runner, RunnerParams* params)
+{
+    for (int i = 0; i < max_step; i++) {
+        params->global_batch_id = i;
+        runner->RunOnce(params);
+    }
+}
+
+class GPUServer : public Server {
+public:
+    void Initialize(int global_shard_count, std::vector<int> fanout, int in_memory_mode) override
+    {
+        shard_count_ = global_shard_count;
+        if (in_memory_mode) std::cout << "In Memory Mode\n";
+        else std::cout << "In Disk Mode\n";
+        StorageManagement* storage_management = new StorageManagement();
+        if (!storage_management->Initialze(shard_count_, in_memory_mode)) exit(EXIT_FAILURE);
+        graph_ = storage_management->GetGraph();
+        feature_ = storage_management->GetFeature();
+        cache_ = storage_management->GetCache();
+        ipc_env_ = storage_management->GetIPCEnv();
+        train_step_ = ipc_env_->GetTrainStep();
+        max_step_ = ipc_env_->GetMaxStep();
+        runners_.resize(shard_count_);
+        params_.resize(shard_count_);
+        for (int i = 0; i < shard_count_; i++) {
+            SetGPUDevice(i);
+            RunnerParams* p = new RunnerParams();
+            p->device_id = i;
+            p->fanout = fanout;
+            p->cache = (void*)cache_;
+            p->graph = (void*)graph_;
+            p->feature = (void*)feature_;
+            p->env = (void*)ipc_env_;
+            p->global_batch_id = 0;
+            p->in_memory = 1;
+            params_[i] = p;
+            runners_[i] = NewGPURunner();
+            runners_[i]->Initialize(params_[i]);
+        }
+    }
+
+    // SS/engine/server.cu:90-117
+    void PreSc(int cache_agg_mode) override
+    {
+        std::chrono::steady_clock::time_point t1 = std::chrono::steady_clock::now();
+        std::vector<std::thread> pool;
+        for (int i = 0; i < shard_count_; i++) pool.emplace_back(&PreSCLoop, train_step_, runners_[i], params_[i]);
+        for (auto& th : pool) th.join();
+        // PCIe/xGMI transaction counters of the PreSC epoch (Intel PCM in the paper, hard-wired to
+        // {0,0} in v2, server.cu:105-106).  LEGION_LINK_COUNTERS="a,b" injects measured values.
+        std::vector<uint64_t> counters(2, 0);
+        if (const char* lc = getenv("LEGION_LINK_COUNTERS")) {
+            unsigned long long a = 0, b = 0;
+            if (sscanf(lc, "%llu,%llu", &a, &b) == 2) { counters[0] = a; counters[1] = b; }
+        }
+        double t = std::chrono::duration_cast<std::chrono::duration<double>>(std::chrono::steady_clock::now() - t1).count();
+        cache_->CandidateSelection(cache_agg_mode, feature_, graph_);
+        cache_->CostModel(cache_agg_mode, feature_, graph_, counters, train_step_);
+        cache_->FillUp(cache_agg_mode, feature_, graph_);
+        std::cout << "Preprocessing cost: " << t << " s\n";
+        std::cout << "System is ready for serving\n" << std::flush;
+    }
+
+    void Run() override
+    {
+        std::vector<std::thread> pool;
+        for (int i = 0; i < shard_count_; i++) pool.emplace_back(&RunnerLoop, max_step_, runners_[i], params_[i]);
+        for (auto& th : pool) th.join();
+    }
+
+    void Finalize() override
+    {
+        for (int i = 0; i < shard_count_; i++) runners_[i]->Finalize(params_[i]);
+        graph_->Finalize();
+        feature_->Finalize();
+        ipc_env_->Finalize();
+        std::cout << "Server Stopped\n";
+    }
+
+private:
+    GraphStorage* graph_ = nullptr;
+    FeatureStorage* feature_ = nullptr;
+    UnifiedCache* cache_ = nullptr;
+    IPCEnv* ipc_env_ = nullptr;
+    int shard_count_ = 0, train_step_ = 0, max_step_ = 0;
+    std::vector<Runner*> runners_;
+    std::vector<RunnerParams*> params_;
+};
+
+// ---- C API ----------------------------------------------------------------------------------
+extern "C" LegionServer* NewGPUServer(void) { return reinterpret_cast<LegionServer*>(static_cast<Server*>(new GPUServer())); }
+
+extern "C" void legion_server_initialize(LegionServer* s, int32_t global_shard_count, const int32_t* fanout,
+                                         int32_t hop_num, int32_t in_memory_mode)
+{
+    std::vector<int> f(fanout, fanout + hop_num);
+    reinterpret_cast<Server*>(s)->Initialize(global_shard_count, f, in_memory_mode);
+}
+extern "C" void legion_server_presc(LegionServer* s, int32_t cache_agg_mode) { reinterpret_cast<Server*>(s)->PreSc(cache_agg_mode); }
+extern "C" void legion_server_run(LegionServer* s) { reinterpret_cast<Server*>(s)->Run(); }
+extern "C" void legion_server_finalize(LegionServer* s) { reinterpret_cast<Server*>(s)->Finalize(); }
+
+// sampling_server/sampling_server.cpp:7-15
+extern "C" int32_t legion_run(const int32_t* fanout, int32_t hop_num, int32_t gpu_number, int32_t in_memory_mode,
+                              int32_t cache_mode)
+{
+    std::cout << "Start Sampling Server\n";
+    LegionServer* server = NewGPUServer();
+    legion_server_initialize(server, gpu_number, fanout, hop_num, in_memory_mode);
+    legion_server_presc(server, cache_mode);
+    legion_server_run(server);
+    legion_server_finalize(server);
+    return 0;
+}

@@ -1,0 +1,454 @@
+// storage.hip -- GraphStorage / FeatureStorage / MemoryPool for the MI355X build.
+//
+// Reference: SS/storage/graph_storage.cu:12-111 (pointer tables with P+1 slots, slot P = full
+// CSR, slot d = GPU d's cached CSR; GraphCache), SS/storage/feature_storage.cu:18-90 (per-GPU
+// seed/label arrays), SS/engine/server.cu:216-234 + SS/engine/ipc_service.cu:134-211 (buffers),
+// SS/engine/server_imp.cuh:2-51 (alloc helpers).
+//
+// Layout decision for 288 GB HBM: the "host" tier pointers (full CSR, full feature table) are just
+// device-dereferenceable pointers; the caller places them in HBM when they fit and in mapped
+// pinned memory otherwise.  Nothing here assumes which.
+#include "legion_core.h"
+
+#include <cstring>
+
+// ---- device helpers: logical device ids beyond the physical count map round-robin onto the
+//      physical GPUs, so that clique striping (Kg > 1) can be exercised on a 1-GPU box ----------
+static int lg_physical_count()
+{
+    static int n = -1;
+    if (n < 0) {
+        if (hipGetDeviceCount(&n) != hipSuccess || n < 1) {
+            printf("legion_hip: no HIP device available -- this library has no CPU fallback\n");
+            exit(EXIT_FAILURE);
+        }
+    }
+    return n;
+}
+
+extern "C" void SetGPUDevice(int32_t shard_id)
+{
+    HIP_CALL(hipSetDevice(shard_id % lg_physical_count()));
+}
+
+extern "C" int32_t GetGPUDevice()
+{
+    int32_t dev_id = -1;
+    HIP_CALL(hipGetDevice(&dev_id));
+    return dev_id;
+}
+
+extern "C" void* d_alloc_space(int64_t num_bytes)
+{
+    void* ret = nullptr;
+    HIP_CALL(hipMalloc(&ret, num_bytes > 0 ? (size_t)num_bytes : 16));
+    return ret;
+}
+
+extern "C" void d_free_space(void* d_ptr)
+{
+    if (d_ptr) HIP_CALL(hipFree(d_ptr));
+}
+
+extern "C" void* host_alloc_space(int64_t num_bytes)
+{
+    void* host_ptr = nullptr;
+    void* ret = nullptr;
+    HIP_CALL(hipHostMalloc(&host_ptr, num_bytes > 0 ? (size_t)num_bytes : 16, hipHostMallocMapped));
+    HIP_CALL(hipHostGetDevicePointer(&ret, host_ptr, 0));
+    return ret;
+}
+
+extern "C" int32_t legion_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+extern "C" const char* legion_version(void) { return "legion-hip 0.1 (gfx950)"; }
+
+// =============================================================================================
+class CompleteGraphStorage : public GraphStorage {
+public:
+    void Build(BuildInfo* info) override
+    {
+        partition_count_ = info->partition_count;
+        node_num_ = info->total_num_nodes;
+        edge_num_ = info->total_edge_num;
+        csr_node_index_cpu_ = info->csr_node_index;
+        csr_dst_node_ids_cpu_ = info->csr_dst_node_ids;
+        csr_node_index_.assign(partition_count_, nullptr);
+        csr_dst_node_ids_.assign(partition_count_, nullptr);
+        h_index_tab_.assign(partition_count_, std::vector<int64_t*>(partition_count_ + 1, nullptr));
+        h_dst_tab_.assign(partition_count_, std::vector<int32_t*>(partition_count_ + 1, nullptr));
+        for (int32_t i = 0; i < partition_count_; i++) {
+            SetGPUDevice(i);
+            csr_node_index_[i] = (int64_t**)d_alloc_space((partition_count_ + 1) * sizeof(int64_t*));
+            csr_dst_node_ids_[i] = (int32_t**)d_alloc_space((partition_count_ + 1) * sizeof(int32_t*));
+            // every GPU can reach the full CSR through slot P (the reference initialises only
+            // GPU 0's table before GraphCache copies it around, graph_storage.cu:62,77-80)
+            h_index_tab_[i][partition_count_] = csr_node_index_cpu_;
+            h_dst_tab_[i][partition_count_] = csr_dst_node_ids_cpu_;
+            Upload(i);
+        }
+    }
+
+    // SS/storage/graph_storage.cu:76-111: GPU i of clique Ki caches vertices QT[row*Kg + i]
+    void GraphCache(int32_t* QT, int32_t Ki, int32_t Kg, int32_t capacity) override
+    {
+        for (int32_t i = 0; i < Kg; i++) {
+            const int32_t dev = Ki * Kg + i;
+            SetGPUDevice(dev);
+            int64_t* neighbor_count = (int64_t*)d_alloc_space((int64_t)capacity * sizeof(int64_t));
+            lg::topo_neighbor_count(nullptr, QT, Kg, i, capacity, node_num_, csr_node_index_cpu_, neighbor_count);
+            int64_t* d_csr_node_index = (int64_t*)d_alloc_space(((int64_t)capacity + 1) * sizeof(int64_t));
+            HIP_CALL(hipMemset(d_csr_node_index, 0, ((size_t)capacity + 1) * sizeof(int64_t)));
+            if (capacity > 0) lg::inclusive_scan_i64(nullptr, neighbor_count, d_csr_node_index + 1, capacity);
+            int64_t cached_edges = 0;
+            HIP_CALL(hipMemcpy(&cached_edges, d_csr_node_index + capacity, sizeof(int64_t), hipMemcpyDeviceToHost));
+            int32_t* d_csr_dst_node_ids = (int32_t*)d_alloc_space(cached_edges * sizeof(int32_t));
+            lg::topo_fill_up(nullptr, QT, Kg, i, capacity, node_num_, csr_node_index_cpu_,
+                             csr_dst_node_ids_cpu_, d_csr_node_index, d_csr_dst_node_ids);
+            HIP_CALL(hipDeviceSynchronize());
+            d_free_space(neighbor_count);
+            owned_.push_back(d_csr_node_index);
+            owned_.push_back(d_csr_dst_node_ids);
+            for (int32_t j = 0; j < Kg; j++) {            // every member of the clique sees slot `dev`
+                h_index_tab_[Ki * Kg + j][dev] = d_csr_node_index;
+                h_dst_tab_[Ki * Kg + j][dev] = d_csr_dst_node_ids;
+            }
+        }
+        for (int32_t j = 0; j < Kg; j++) Upload(Ki * Kg + j);
+    }
+
+    void Finalize() override
+    {
+        for (void* p : owned_) d_free_space(p);
+        owned_.clear();
+        for (int32_t i = 0; i < partition_count_; i++) {
+            d_free_space(csr_node_index_[i]);
+            d_free_space(csr_dst_node_ids_[i]);
+        }
+        csr_node_index_.clear();
+        csr_dst_node_ids_.clear();
+    }
+
+    int32_t GetPartitionCount() const override { return partition_count_; }
+    int64_t** GetCSRNodeIndex(int32_t part_id) const override { return csr_node_index_[part_id]; }
+    int32_t** GetCSRNodeMatrix(int32_t part_id) const override { return csr_dst_node_ids_[part_id]; }
+    int64_t* GetCSRNodeIndexCPU() const override { return csr_node_index_cpu_; }
+    int32_t* GetCSRNodeMatrixCPU() const override { return csr_dst_node_ids_cpu_; }
+    int32_t NodeNum() const override { return node_num_; }
+    int64_t EdgeNum() const override { return edge_num_; }
+
+private:
+    void Upload(int32_t dev)
+    {
+        SetGPUDevice(dev);
+        HIP_CALL(hipMemcpy(csr_node_index_[dev], h_index_tab_[dev].data(),
+                           (partition_count_ + 1) * sizeof(int64_t*), hipMemcpyHostToDevice));
+        HIP_CALL(hipMemcpy(csr_dst_node_ids_[dev], h_dst_tab_[dev].data(),
+                           (partition_count_ + 1) * sizeof(int32_t*), hipMemcpyHostToDevice));
+    }
+
+    int32_t partition_count_ = 0;
+    int32_t node_num_ = 0;
+    int64_t edge_num_ = 0;
+    std::vector<int64_t**> csr_node_index_;
+    std::vector<int32_t**> csr_dst_node_ids_;
+    std::vector<std::vector<int64_t*>> h_index_tab_;
+    std::vector<std::vector<int32_t*>> h_dst_tab_;
+    int64_t* csr_node_index_cpu_ = nullptr;
+    int32_t* csr_dst_node_ids_cpu_ = nullptr;
+    std::vector<void*> owned_;
+};
+
+extern "C" GraphStorage* NewCompleteGraphStorage() { return new CompleteGraphStorage(); }
+
+// =============================================================================================
+class CompleteFeatureStorage : public FeatureStorage {
+public:
+    void Build(BuildInfo* info, int /*in_memory_mode*/) override
+    {
+        Configure(info->partition_count, info->total_num_nodes, info->float_feature_len,
+                  info->host_float_feature);
+        for (int32_t p = 0; p < partition_count_; p++) {
+            if (p < (int32_t)info->training_set_ids.size())
+                SetIds(p, TRAINMODE, info->training_set_ids[p].data(), info->training_labels[p].data(),
+                       (int32_t)info->training_set_ids[p].size());
+            if (p < (int32_t)info->validation_set_ids.size())
+                SetIds(p, VALIDMODE, info->validation_set_ids[p].data(), info->validation_labels[p].data(),
+                       (int32_t)info->validation_set_ids[p].size());
+            if (p < (int32_t)info->testing_set_ids.size())
+                SetIds(p, TESTMODE, info->testing_set_ids[p].data(), info->testing_labels[p].data(),
+                       (int32_t)info->testing_set_ids[p].size());
+        }
+    }
+
+    void Configure(int32_t partition_count, int32_t total_num_nodes, int32_t float_feature_len,
+                   float* all_float_feature)
+    {
+        partition_count_ = partition_count;
+        total_num_nodes_ = total_num_nodes;
+        float_feature_len_ = float_feature_len;
+        float_feature_ = all_float_feature;
+        for (int m = 0; m < 3; m++) {
+            ids_[m].assign(partition_count, nullptr);
+            labels_[m].assign(partition_count, nullptr);
+            size_[m].assign(partition_count, 0);
+        }
+    }
+
+    void SetIds(int32_t dev_id, int32_t mode, const int32_t* host_ids, const int32_t* host_labels,
+                int32_t count) override
+    {
+        SetGPUDevice(dev_id);
+        d_free_space(ids_[mode][dev_id]);
+        d_free_space(labels_[mode][dev_id]);
+        ids_[mode][dev_id] = (int32_t*)d_alloc_space((int64_t)count * sizeof(int32_t));
+        labels_[mode][dev_id] = (int32_t*)d_alloc_space((int64_t)count * sizeof(int32_t));
+        if (count > 0) {
+            HIP_CALL(hipMemcpy(ids_[mode][dev_id], host_ids, (size_t)count * 4, hipMemcpyHostToDevice));
+            if (host_labels)
+                HIP_CALL(hipMemcpy(labels_[mode][dev_id], host_labels, (size_t)count * 4, hipMemcpyHostToDevice))
+            else
+                HIP_CALL(hipMemset(labels_[mode][dev_id], 0, (size_t)count * 4));   // v2: labels are all 0 (F7)
+        }
+        size_[mode][dev_id] = count;
+    }
+
+    void Finalize() override
+    {
+        for (int m = 0; m < 3; m++)
+            for (size_t p = 0; p < ids_[m].size(); p++) {
+                d_free_space(ids_[m][p]);
+                d_free_space(labels_[m][p]);
+                ids_[m][p] = labels_[m][p] = nullptr;
+            }
+    }
+
+    int32_t* GetTrainingSetIds(int32_t p) const override { return ids_[TRAINMODE][p]; }
+    int32_t* GetValidationSetIds(int32_t p) const override { return ids_[VALIDMODE][p]; }
+    int32_t* GetTestingSetIds(int32_t p) const override { return ids_[TESTMODE][p]; }
+    int32_t* GetTrainingLabels(int32_t p) const override { return labels_[TRAINMODE][p]; }
+    int32_t* GetValidationLabels(int32_t p) const override { return labels_[VALIDMODE][p]; }
+    int32_t* GetTestingLabels(int32_t p) const override { return labels_[TESTMODE][p]; }
+    int32_t TrainingSetSize(int32_t p) const override { return size_[TRAINMODE][p]; }
+    int32_t ValidationSetSize(int32_t p) const override { return size_[VALIDMODE][p]; }
+    int32_t TestingSetSize(int32_t p) const override { return size_[TESTMODE][p]; }
+    int32_t TotalNodeNum() const override { return total_num_nodes_; }
+    float* GetAllFloatFeature() const override { return float_feature_; }
+    int32_t GetFloatFeatureLen() const override { return float_feature_len_; }
+
+private:
+    int32_t partition_count_ = 0, total_num_nodes_ = 0, float_feature_len_ = 0;
+    float* float_feature_ = nullptr;
+    std::vector<int32_t*> ids_[3], labels_[3];
+    std::vector<int32_t> size_[3];
+};
+
+extern "C" FeatureStorage* NewCompleteFeatureStorage() { return new CompleteFeatureStorage(); }
+
+// =============================================================================================
+void MemoryPool::Finalize()
+{
+    SetGPUDevice(dev_id);
+    d_free_space(cache_search_buffer_);
+    d_free_space(position_map_);
+    d_free_space(agg_src_ids_);
+    d_free_space(agg_dst_ids_);
+    d_free_space(tmp_part_ind_);
+    d_free_space(tmp_part_off_);
+    d_free_space(slot_dst);
+    d_free_space(tile_counts);
+    d_free_space(tile_prefix);
+    d_free_space(hop_scratch);
+    cache_search_buffer_ = position_map_ = agg_src_ids_ = agg_dst_ids_ = tmp_part_off_ = nullptr;
+    tmp_part_ind_ = nullptr;
+    slot_dst = tile_counts = tile_prefix = hop_scratch = nullptr;
+    if (owns_buffers) {
+        for (int i = 0; i < pipeline_depth_; i++) {
+            d_free_space(float_features_[i]);
+            d_free_space(labels_[i]);
+            d_free_space(node_counter_[i]);
+            d_free_space(edge_counter_[i]);
+            d_free_space(sampled_ids_[i]);
+            d_free_space(agg_src_off_[i]);
+            d_free_space(agg_dst_off_[i]);
+            float_features_[i] = nullptr;
+            labels_[i] = node_counter_[i] = edge_counter_[i] = sampled_ids_[i] = nullptr;
+            agg_src_off_[i] = agg_dst_off_[i] = nullptr;
+        }
+    }
+}
+
+// server-private scratch of one GPU: SS/engine/server.cu:216-234 plus the compaction scratch
+void lg_pool_alloc_private(MemoryPool* mp, int32_t dev_id, int32_t total_num_nodes, int32_t batch_size,
+                           const int32_t* fanout, int32_t hop_num, int32_t float_feature_len)
+{
+    SetGPUDevice(dev_id);
+    int64_t num_ids = batch_size, per = batch_size;         // server.cu:187-199
+    for (int i = 0; i < hop_num; i++) { per *= fanout[i]; num_ids += per; }
+    if (per > LG_MAX_SLOTS || num_ids > 0x7FFFFFFF) {
+        printf("legion_hip: batch %d with this fan-out needs %lld slots; limit is %d\n", batch_size,
+               (long long)per, LG_MAX_SLOTS);
+        exit(EXIT_FAILURE);
+    }
+    mp->dev_id = dev_id;
+    mp->num_ids = (int32_t)num_ids;
+    mp->max_slots = (int32_t)(hop_num > 0 ? per : batch_size);
+    mp->total_num_nodes = total_num_nodes;
+    mp->batch_size = batch_size;
+    mp->float_feature_len = float_feature_len;
+    mp->SetCacheSearchBuffer((int32_t*)d_alloc_space(num_ids * sizeof(int32_t)));
+    int32_t* position_map = (int32_t*)d_alloc_space((int64_t)total_num_nodes * sizeof(int32_t));
+    HIP_CALL(hipMemset(position_map, 0x7F, (size_t)total_num_nodes * sizeof(int32_t)));   // LG_POS_UNTOUCHED
+    mp->SetPositionMap(position_map);
+    mp->SetAggSrcId((int32_t*)d_alloc_space(num_ids * sizeof(int32_t)));
+    mp->SetAggDstId((int32_t*)d_alloc_space(num_ids * sizeof(int32_t)));
+    mp->SetTmpPartIdx((char*)d_alloc_space(num_ids * sizeof(char)));
+    mp->SetTmpPartOff((int32_t*)d_alloc_space(num_ids * sizeof(int32_t)));
+    const int64_t max_tiles = (mp->max_slots + LG_TILE - 1) / LG_TILE + 1;
+    mp->slot_dst = (int32_t*)d_alloc_space((int64_t)mp->max_slots * sizeof(int32_t));
+    mp->tile_counts = (int32_t*)d_alloc_space(2 * max_tiles * sizeof(int32_t));
+    mp->tile_prefix = (int32_t*)d_alloc_space(2 * max_tiles * sizeof(int32_t));
+    mp->hop_scratch = (int32_t*)d_alloc_space(HS_WORDS * sizeof(int32_t));
+    HIP_CALL(hipMemset(mp->hop_scratch, 0, HS_WORDS * sizeof(int32_t)));
+}
+
+// ---- C API ----------------------------------------------------------------------------------
+extern "C" LegionGraphStorage* legion_graph_create(int32_t partition_count, int32_t node_num,
+                                                   int64_t edge_num, const int64_t* csr_node_index,
+                                                   const int32_t* csr_dst_node_ids)
+{
+    BuildInfo info;
+    info.partition_count = partition_count;
+    info.total_num_nodes = node_num;
+    info.total_edge_num = edge_num;
+    info.csr_node_index = const_cast<int64_t*>(csr_node_index);
+    info.csr_dst_node_ids = const_cast<int32_t*>(csr_dst_node_ids);
+    GraphStorage* g = NewCompleteGraphStorage();
+    g->Build(&info);
+    return reinterpret_cast<LegionGraphStorage*>(g);
+}
+
+extern "C" void legion_graph_destroy(LegionGraphStorage* g_)
+{
+    GraphStorage* g = reinterpret_cast<GraphStorage*>(g_);
+    if (!g) return;
+    g->Finalize();
+    delete g;
+}
+
+extern "C" LegionFeatureStorage* legion_feature_create(int32_t partition_count, int32_t total_num_nodes,
+                                                       int32_t float_feature_len,
+                                                       const float* all_float_feature)
+{
+    CompleteFeatureStorage* f = new CompleteFeatureStorage();
+    f->Configure(partition_count, total_num_nodes, float_feature_len, const_cast<float*>(all_float_feature));
+    return reinterpret_cast<LegionFeatureStorage*>(static_cast<FeatureStorage*>(f));
+}
+
+extern "C" void legion_feature_set_ids(LegionFeatureStorage* f_, int32_t dev_id, int32_t mode,
+                                       const int32_t* host_ids, const int32_t* host_labels, int32_t count)
+{
+    FeatureStorage* f = reinterpret_cast<FeatureStorage*>(f_);
+    if (!f) { printf("invalid feature storage ptr\n"); return; }
+    if (mode < 0 || mode > 2) { printf("invalid mode: %d\n", mode); return; }
+    f->SetIds(dev_id, mode, host_ids, host_labels, count);
+}
+
+extern "C" void legion_feature_destroy(LegionFeatureStorage* f_)
+{
+    FeatureStorage* f = reinterpret_cast<FeatureStorage*>(f_);
+    if (!f) return;
+    f->Finalize();
+    delete f;
+}
+
+extern "C" LegionMemoryPool* legion_pool_create(int32_t dev_id, int32_t total_num_nodes, int32_t batch_size,
+                                                const int32_t* fanout, int32_t hop_num,
+                                                int32_t float_feature_len, int32_t pipeline_depth)
+{
+    if (pipeline_depth < 1) pipeline_depth = 1;
+    MemoryPool* mp = new MemoryPool(pipeline_depth);
+    lg_pool_alloc_private(mp, dev_id, total_num_nodes, batch_size, fanout, hop_num, float_feature_len);
+    mp->owns_buffers = true;
+    for (int i = 0; i < pipeline_depth; i++) {            // ipc_service.cu:134-161 without the handles
+        mp->SetSampledIds((int32_t*)d_alloc_space((int64_t)mp->num_ids * 4), i);
+        mp->SetLabels((int32_t*)d_alloc_space((int64_t)batch_size * 4), i);
+        mp->SetAggSrcOf((int32_t*)d_alloc_space((int64_t)mp->num_ids * 4), i);
+        mp->SetAggDstOf((int32_t*)d_alloc_space((int64_t)mp->num_ids * 4), i);
+        mp->SetNodeCounter((int32_t*)d_alloc_space(16 * 4), i);
+        mp->SetEdgeCounter((int32_t*)d_alloc_space(16 * 4), i);
+        mp->SetCurrentPipe(i);
+        HIP_CALL(hipMemset(mp->GetNodeCounter(), 0, 64));
+        HIP_CALL(hipMemset(mp->GetEdgeCounter(), 0, 64));
+    }
+    mp->SetCurrentPipe(0);
+    return reinterpret_cast<LegionMemoryPool*>(mp);
+}
+
+extern "C" void legion_pool_alloc_features(LegionMemoryPool* p_, int64_t rows)
+{
+    MemoryPool* mp = reinterpret_cast<MemoryPool*>(p_);
+    if (!mp) { printf("invalid memorypool ptr\n"); return; }
+    SetGPUDevice(mp->dev_id);
+    const int32_t cur = mp->GetCurrentPipe();
+    for (int i = 0; i < mp->PipelineDepth(); i++) {
+        mp->SetCurrentPipe(i);
+        d_free_space(mp->GetFloatFeatures());
+        mp->SetFloatFeatures((float*)d_alloc_space(rows * (int64_t)mp->float_feature_len * sizeof(float)), i);
+    }
+    mp->SetCurrentPipe(cur);
+    mp->feature_rows = rows;
+}
+
+extern "C" void legion_pool_set_current_pipe(LegionMemoryPool* p_, int32_t pipe)
+{
+    MemoryPool* mp = reinterpret_cast<MemoryPool*>(p_);
+    if (mp) mp->SetCurrentPipe(pipe % mp->PipelineDepth());
+}
+
+extern "C" void legion_pool_set_mode_iter(LegionMemoryPool* p_, int32_t mode, int32_t iter)
+{
+    MemoryPool* mp = reinterpret_cast<MemoryPool*>(p_);
+    if (mp) { mp->SetCurrentMode(mode); mp->SetIter(iter); }
+}
+
+extern "C" int32_t legion_pool_num_ids(const LegionMemoryPool* p_)
+{
+    const MemoryPool* mp = reinterpret_cast<const MemoryPool*>(p_);
+    return mp ? mp->num_ids : 0;
+}
+
+extern "C" void* legion_pool_buffer(LegionMemoryPool* p_, int32_t which)
+{
+    MemoryPool* mp = reinterpret_cast<MemoryPool*>(p_);
+    if (!mp) return nullptr;
+    switch (which) {
+        case 0: return mp->GetSampledIds();
+        case 1: return mp->GetFloatFeatures();
+        case 2: return mp->GetLabels();
+        case 3: return mp->GetAggSrcOf();
+        case 4: return mp->GetAggDstOf();
+        case 5: return mp->GetNodeCounter();
+        case 6: return mp->GetEdgeCounter();
+        case 7: return mp->GetAggSrcId();
+        case 8: return mp->GetAggDstId();
+        case 9: return mp->GetCacheSearchBuffer();
+        case 10: return mp->GetTmpPartIdx();
+        case 11: return mp->GetTmpPartOff();
+        case 12: return mp->GetPositionMap();
+        default: return nullptr;
+    }
+}
+
+extern "C" void legion_pool_destroy(LegionMemoryPool* p_)
+{
+    MemoryPool* mp = reinterpret_cast<MemoryPool*>(p_);
+    if (!mp) return;
+    mp->Finalize();
+    delete mp;
+}

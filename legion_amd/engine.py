@@ -1,0 +1,264 @@
+"""Host-side Python mirror of the reference's operator interface for the hot path.
+
+Same names and argument meaning as the reference (SS = sampling_server/src):
+  BatchGenerate / RandomSample / FeatureCacheLookup / IOSubmit / IOComplete
+                                         SS/engine/operator_impl.cuh:11-63
+  GraphStorage / FeatureStorage          SS/storage/graph_storage.cuh:7-24, feature_storage.cuh:6-34
+  MemoryPool                             SS/engine/memorypool.cuh:20-221
+  UnifiedCache                           SS/cache/cache.cuh:66-177
+Everything computes inside liblegion_hip.so (HIP kernels for gfx950) through the C ABI in
+include/legion_hip.h; PyTorch is used only to own device memory, streams and torch.distributed.
+There is no CPU path: constructing any of these without a GPU-backed library raises.
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import lib as _libmod
+
+INTERBATCH_CON = 2
+INTRABATCH_CON = 3
+TRAINMODE, VALIDMODE, TESTMODE = 0, 1, 2
+CACHEMISS_FLAG = -2
+
+_TYPESTR = {torch.int32: "<i4", torch.int64: "<i8", torch.float32: "<f4", torch.int8: "|i1",
+            torch.uint8: "|u1"}
+
+
+class _RawDevice:
+    def __init__(self, ptr, shape, dtype):
+        self.__cuda_array_interface__ = {
+            "shape": tuple(int(s) for s in shape), "typestr": _TYPESTR[dtype],
+            "data": (int(ptr), False), "version": 2, "strides": None}
+
+
+def device_view(ptr, shape, dtype, device):
+    """Zero-copy torch view of raw device memory owned by the library."""
+    n = 1
+    for s in shape:
+        n *= int(s)
+    if not ptr or n == 0:
+        return torch.empty(tuple(shape), dtype=dtype, device=device)
+    return torch.as_tensor(_RawDevice(ptr, shape, dtype), device=device)
+
+
+def _stream_handle(stream=None):
+    s = stream if stream is not None else torch.cuda.current_stream()
+    return ctypes.c_void_p(s.cuda_stream)
+
+
+def _ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
+
+
+def _i32_array(values):
+    arr = (ctypes.c_int32 * len(values))(*[int(v) for v in values])
+    return arr
+
+
+class GraphStorage:
+    """Full CSR (slot P of the pointer tables) from device tensors: indptr int64[N+1], col int32[E]."""
+
+    def __init__(self, partition_count, indptr, col):
+        assert indptr.dtype == torch.int64 and col.dtype == torch.int32
+        assert indptr.is_cuda and col.is_cuda and indptr.is_contiguous() and col.is_contiguous()
+        self._lib = _libmod.load()
+        self.indptr, self.col = indptr, col          # keep alive
+        self.partition_count = int(partition_count)
+        self.node_num = int(indptr.numel() - 1)
+        self.edge_num = int(col.numel())
+        self.handle = self._lib.legion_graph_create(self.partition_count, self.node_num, self.edge_num,
+                                                    _ptr(indptr), _ptr(col))
+
+    def close(self):
+        if self.handle:
+            self._lib.legion_graph_destroy(self.handle)
+            self.handle = None
+
+
+class FeatureStorage:
+    """Full feature table (device tensor float32[N, D], HBM or mapped pinned) + per-GPU seed sets."""
+
+    def __init__(self, partition_count, features, total_num_nodes=None, float_feature_len=None):
+        self._lib = _libmod.load()
+        self.features = features
+        if features is not None:
+            assert features.dtype == torch.float32 and features.is_contiguous()
+            total_num_nodes = features.shape[0] if total_num_nodes is None else total_num_nodes
+            float_feature_len = features.shape[1] if float_feature_len is None else float_feature_len
+        self.total_num_nodes = int(total_num_nodes)
+        self.float_feature_len = int(float_feature_len)
+        self.partition_count = int(partition_count)
+        self.handle = self._lib.legion_feature_create(self.partition_count, self.total_num_nodes,
+                                                      self.float_feature_len, _ptr(features))
+        self.set_sizes = {}
+
+    def set_ids(self, dev_id, mode, ids, labels=None):
+        ids = np.ascontiguousarray(ids, dtype=np.int32)
+        lab = None if labels is None else np.ascontiguousarray(labels, dtype=np.int32)
+        self._lib.legion_feature_set_ids(self.handle, int(dev_id), int(mode),
+                                         ids.ctypes.data_as(ctypes.c_void_p),
+                                         lab.ctypes.data_as(ctypes.c_void_p) if lab is not None else None,
+                                         int(ids.size))
+        self.set_sizes[(int(dev_id), int(mode))] = int(ids.size)
+
+    def close(self):
+        if self.handle:
+            self._lib.legion_feature_destroy(self.handle)
+            self.handle = None
+
+
+class MemoryPool:
+    _BUF = {"sampled_ids": (0, torch.int32), "float_features": (1, torch.float32),
+            "labels": (2, torch.int32), "agg_src_off": (3, torch.int32), "agg_dst_off": (4, torch.int32),
+            "node_counter": (5, torch.int32), "edge_counter": (6, torch.int32),
+            "agg_src_ids": (7, torch.int32), "agg_dst_ids": (8, torch.int32),
+            "cache_search_buffer": (9, torch.int32), "tmp_part_ind": (10, torch.int8),
+            "tmp_part_off": (11, torch.int32), "position_map": (12, torch.int32)}
+
+    def __init__(self, dev_id, total_num_nodes, batch_size, fanout, float_feature_len, pipeline_depth=1):
+        self._lib = _libmod.load()
+        self.dev_id = int(dev_id)
+        self.device = torch.device("cuda", self.dev_id % max(torch.cuda.device_count(), 1))
+        self.total_num_nodes = int(total_num_nodes)
+        self.batch_size = int(batch_size)
+        self.fanout = [int(f) for f in fanout]
+        self.float_feature_len = int(float_feature_len)
+        self.feature_rows = 0
+        self.handle = self._lib.legion_pool_create(self.dev_id, self.total_num_nodes, self.batch_size,
+                                                   _i32_array(self.fanout), len(self.fanout),
+                                                   self.float_feature_len, int(pipeline_depth))
+        self.num_ids = int(self._lib.legion_pool_num_ids(self.handle))
+
+    def alloc_features(self, rows):
+        self.feature_rows = int(rows)
+        self._lib.legion_pool_alloc_features(self.handle, self.feature_rows)
+
+    def set_current_pipe(self, pipe):
+        self._lib.legion_pool_set_current_pipe(self.handle, int(pipe))
+
+    def buffer(self, name):
+        which, dtype = self._BUF[name]
+        ptr = self._lib.legion_pool_buffer(self.handle, which)
+        if name in ("node_counter", "edge_counter"):
+            shape = (16,)
+        elif name == "labels":
+            shape = (self.batch_size,)
+        elif name == "float_features":
+            shape = (self.feature_rows, self.float_feature_len)
+        elif name == "position_map":
+            shape = (self.total_num_nodes,)
+        else:
+            shape = (self.num_ids,)
+        return device_view(ptr, shape, dtype, self.device)
+
+    def close(self):
+        if self.handle:
+            self._lib.legion_pool_destroy(self.handle)
+            self.handle = None
+
+
+class UnifiedCache:
+    _ARR = {"QF": (0, torch.int32), "QT": (1, torch.int32), "AF": (2, torch.int64), "AT": (3, torch.int64),
+            "node_access_time": (4, torch.int64), "edge_access_time": (5, torch.int64),
+            "node_map": (6, torch.int32), "edge_index_map": (7, torch.int8), "edge_offset_map": (8, torch.int32)}
+
+    def __init__(self, cache_memory, float_feature_len, train_step, device_count, total_num_nodes):
+        self._lib = _libmod.load()
+        self.device_count = int(device_count)
+        self.total_num_nodes = int(total_num_nodes)
+        self.handle = self._lib.legion_cache_create(int(cache_memory), int(float_feature_len), int(train_step),
+                                                    self.device_count, self.total_num_nodes)
+
+    def init_controller(self, dev_id):
+        self._lib.legion_cache_init_controller(self.handle, int(dev_id))
+
+    def candidate_selection(self, cache_agg_mode, graph, world_reduced=False):
+        self._lib.legion_cache_candidate_selection(self.handle, int(cache_agg_mode), graph.handle,
+                                                   1 if world_reduced else 0)
+
+    def cost_model(self, feature, graph, counters=(0, 0), train_step=0):
+        cnt = (ctypes.c_uint64 * 2)(int(counters[0]), int(counters[1]))
+        self._lib.legion_cache_cost_model(self.handle, feature.handle, graph.handle, cnt, int(train_step))
+
+    def set_capacity(self, node_capacity, edge_capacity):
+        self._lib.legion_cache_set_capacity(self.handle, int(node_capacity), int(edge_capacity))
+
+    def fill_up(self, feature, graph):
+        self._lib.legion_cache_fill_up(self.handle, feature.handle, graph.handle)
+
+    def node_capacity(self, dev_id=0):
+        return int(self._lib.legion_cache_node_capacity(self.handle, int(dev_id)))
+
+    def edge_capacity(self, dev_id=0):
+        return int(self._lib.legion_cache_edge_capacity(self.handle, int(dev_id)))
+
+    def max_id_num(self, dev_id=0):
+        return int(self._lib.legion_cache_max_id_num(self.handle, int(dev_id)))
+
+    def array(self, name, dev_id=0):
+        which, dtype = self._ARR[name]
+        ptr = self._lib.legion_cache_array(self.handle, int(dev_id), which)
+        device = torch.device("cuda", int(dev_id) % max(torch.cuda.device_count(), 1))
+        return device_view(ptr, (self.total_num_nodes,), dtype, device)
+
+    def close(self):
+        if self.handle:
+            self._lib.legion_cache_destroy(self.handle)
+            self.handle = None
+
+
+# ---- the five operators, reference names and argument order ------------------------------------
+def BatchGenerate(strm_hdl, feature, cache, memorypool, batch_size, counter, part_id, dev_id, mode,
+                  is_presc, hop_num):
+    _libmod.load().BatchGenerate(_stream_handle(strm_hdl), feature.handle, cache.handle if cache else None,
+                                 memorypool.handle, int(batch_size), int(counter), int(part_id), int(dev_id),
+                                 int(mode), bool(is_presc), int(hop_num))
+
+
+def RandomSample(strm_hdl, graph, cache, memorypool, count, dev_id, op_id, is_presc):
+    _libmod.load().RandomSample(_stream_handle(strm_hdl), graph.handle, cache.handle if cache else None,
+                                memorypool.handle, int(count), int(dev_id), int(op_id), bool(is_presc))
+
+
+def FeatureCacheLookup(strm_hdl, cache, memorypool, op_id, dev_id):
+    _libmod.load().FeatureCacheLookup(_stream_handle(strm_hdl), cache.handle, memorypool.handle, int(op_id),
+                                      int(dev_id))
+
+
+def IOSubmit(strm_hdl, feature, memorypool, op_id, dev_id):
+    _libmod.load().IOSubmit(_stream_handle(strm_hdl), feature.handle, memorypool.handle, int(op_id), int(dev_id))
+
+
+def IOComplete(strm_hdl, cache, memorypool, dev_id, mode):
+    _libmod.load().IOComplete(_stream_handle(strm_hdl), cache.handle if cache else None, memorypool.handle,
+                              int(dev_id), int(mode))
+
+
+def enqueue_batch(strm_hdl, graph, feature, cache, memorypool, batch_size, counter, dev_id, mode, is_presc,
+                  fanout):
+    """All ops of one mini-batch in GPURunner::RunOnce order (SS/engine/server.cu:302-332)."""
+    _libmod.load().legion_enqueue_batch(_stream_handle(strm_hdl), graph.handle, feature.handle,
+                                        cache.handle if cache else None, memorypool.handle, int(batch_size),
+                                        int(counter), int(dev_id), int(mode), bool(is_presc),
+                                        _i32_array(fanout), len(fanout))
+
+
+def read_batch(memorypool):
+    """Host copy of everything a trainer (and the parity tests) can observe about the current batch."""
+    nc = memorypool.buffer("node_counter").cpu().numpy().copy()
+    ec = memorypool.buffer("edge_counter").cpu().numpy().copy()
+    hop_num = int(nc[INTRABATCH_CON * 3 - 1])
+    n_nodes = int(nc[INTRABATCH_CON * 3 + hop_num])
+    n_edges = int(ec[INTRABATCH_CON * 3 + hop_num])
+    out = {"node_counter": nc, "edge_counter": ec, "hop_num": hop_num,
+           "sampled_ids": memorypool.buffer("sampled_ids")[:max(n_nodes, 0)].cpu().numpy().copy(),
+           "labels": memorypool.buffer("labels")[:max(int(nc[INTRABATCH_CON * 3]), 0)].cpu().numpy().copy(),
+           "agg_src_off": memorypool.buffer("agg_src_off")[:n_edges].cpu().numpy().copy(),
+           "agg_dst_off": memorypool.buffer("agg_dst_off")[:n_edges].cpu().numpy().copy(),
+           "agg_src_ids": memorypool.buffer("agg_src_ids")[:n_edges].cpu().numpy().copy(),
+           "agg_dst_ids": memorypool.buffer("agg_dst_ids")[:n_edges].cpu().numpy().copy()}
+    if memorypool.feature_rows > 0:
+        out["float_features"] = memorypool.buffer("float_features")[:n_nodes].cpu().numpy().copy()
+    return out

@@ -1,0 +1,98 @@
+"""ctypes binding of liblegion_hip.so (include/legion_hip.h).
+
+The library is the product; this module only declares its C ABI to Python.  There is no fallback:
+if the shared object is missing or does not load, importing callers get an ImportError that says
+how to build it, and nothing else in the package will run.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "liblegion_hip.so")
+
+c_i32, c_i64, c_u64 = ctypes.c_int32, ctypes.c_int64, ctypes.c_uint64
+c_p, c_bool = ctypes.c_void_p, ctypes.c_bool
+P_I32 = ctypes.POINTER(ctypes.c_int32)
+P_U64 = ctypes.POINTER(ctypes.c_uint64)
+
+# name -> (restype, argtypes); the order and meaning follow include/legion_hip.h
+SIGNATURES = {
+    # 1. operators (SS/engine/operator_impl.cuh:11-63)
+    "BatchGenerate": (None, [c_p, c_p, c_p, c_p, c_i32, c_i32, c_i32, c_i32, c_i32, c_bool, c_i32]),
+    "RandomSample": (None, [c_p, c_p, c_p, c_p, c_i32, c_i32, c_i32, c_bool]),
+    "FeatureCacheLookup": (None, [c_p, c_p, c_p, c_i32, c_i32]),
+    "IOSubmit": (None, [c_p, c_p, c_p, c_i32, c_i32]),
+    "IOComplete": (None, [c_p, c_p, c_p, c_i32, c_i32]),
+    "legion_enqueue_batch": (None, [c_p, c_p, c_p, c_p, c_p, c_i32, c_i32, c_i32, c_i32, c_bool, P_I32, c_i32]),
+    # 2. objects
+    "legion_graph_create": (c_p, [c_i32, c_i32, c_i64, c_p, c_p]),
+    "legion_graph_destroy": (None, [c_p]),
+    "legion_feature_create": (c_p, [c_i32, c_i32, c_i32, c_p]),
+    "legion_feature_set_ids": (None, [c_p, c_i32, c_i32, c_p, c_p, c_i32]),
+    "legion_feature_destroy": (None, [c_p]),
+    "legion_pool_create": (c_p, [c_i32, c_i32, c_i32, P_I32, c_i32, c_i32, c_i32]),
+    "legion_pool_alloc_features": (None, [c_p, c_i64]),
+    "legion_pool_set_current_pipe": (None, [c_p, c_i32]),
+    "legion_pool_set_mode_iter": (None, [c_p, c_i32, c_i32]),
+    "legion_pool_num_ids": (c_i32, [c_p]),
+    "legion_pool_buffer": (c_p, [c_p, c_i32]),
+    "legion_pool_destroy": (None, [c_p]),
+    "legion_cache_create": (c_p, [c_i64, c_i32, c_i32, c_i32, c_i32]),
+    "legion_cache_init_controller": (None, [c_p, c_i32]),
+    "legion_cache_candidate_selection": (None, [c_p, c_i32, c_p, c_i32]),
+    "legion_cache_cost_model": (None, [c_p, c_p, c_p, P_U64, c_i32]),
+    "legion_cache_set_capacity": (None, [c_p, c_i32, c_i32]),
+    "legion_cache_fill_up": (None, [c_p, c_p, c_p]),
+    "legion_cache_destroy": (None, [c_p]),
+    "legion_cache_node_capacity": (c_i32, [c_p, c_i32]),
+    "legion_cache_edge_capacity": (c_i32, [c_p, c_i32]),
+    "legion_cache_max_id_num": (c_i32, [c_p, c_i32]),
+    "legion_cache_array": (c_p, [c_p, c_i32, c_i32]),
+    # 3. server / ipc
+    "NewGPUServer": (c_p, []),
+    "legion_server_initialize": (None, [c_p, c_i32, P_I32, c_i32, c_i32]),
+    "legion_server_presc": (None, [c_p, c_i32]),
+    "legion_server_run": (None, [c_p]),
+    "legion_server_finalize": (None, [c_p]),
+    "legion_run": (c_i32, [P_I32, c_i32, c_i32, c_i32, c_i32]),
+    "NewIPCEnv": (c_p, [c_i32]),
+    "legion_ipc_coordinate": (None, [c_p, c_i32, P_I32, P_I32, P_I32, c_i32, c_i32]),
+    "legion_ipc_train_step": (c_i32, [c_p]),
+    "legion_ipc_max_step": (c_i32, [c_p]),
+    "legion_ipc_current_mode": (c_i32, [c_p, c_i32]),
+    "legion_ipc_local_batch_id": (c_i32, [c_p, c_i32]),
+    "legion_ipc_current_batchsize": (c_i32, [c_p, c_i32, c_i32]),
+    "legion_ipc_finalize": (None, [c_p]),
+    # 4. kernel-level
+    "legion_gather_rows": (None, [c_p, c_p, c_p, c_p, c_i32, c_i32, c_i32, c_p, c_p, c_p, c_p, c_i32]),
+    "legion_draw_batch": (None, [c_p, c_p, c_p, c_p, c_i32]),
+    # 5. synthetic workloads
+    "legion_synth_rmat_edges": (None, [c_p, c_i32, c_i64, c_u64, c_p, c_p]),
+    "legion_synth_features": (None, [c_p, c_p, c_i64, c_i64, c_i32, c_u64]),
+    "legion_synth_feature_check": (None, [c_p, c_p, c_p, c_i64, c_i32, c_u64, c_p]),
+    "legion_version": (ctypes.c_char_p, []),
+    "legion_device_count": (c_i32, []),
+}
+
+_lib = None
+
+
+def load():
+    """Returns the loaded library with argtypes set; raises ImportError if it is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: build it with `python -m legion_amd.build` "
+            "(hipcc --offload-arch=gfx950).  legion_amd has no CPU fallback.")
+    try:
+        lib = ctypes.CDLL(LIB_PATH, mode=ctypes.RTLD_GLOBAL)
+    except OSError as e:  # pragma: no cover
+        raise ImportError(f"cannot load {LIB_PATH}: {e}.  legion_amd has no CPU fallback.") from e
+    for name, (restype, argtypes) in SIGNATURES.items():
+        fn = getattr(lib, name)   # AttributeError here = header/library mismatch: fail loudly
+        fn.restype = restype
+        fn.argtypes = argtypes
+    _lib = lib
+    return lib

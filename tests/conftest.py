@@ -1,0 +1,29 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    from oracle import ffi
+    return ffi.load()
+
+
+@pytest.fixture(scope="session")
+def hip():
+    """The product library on a GPU box; GPU tests fail loudly (never skip) if it is not loadable."""
+    import torch
+    from legion_amd import lib
+    L = lib.load()
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    assert L.legion_device_count() >= 1
+    return L

@@ -1,0 +1,112 @@
+"""Parity of the HIP path (through the C ABI) with the oracle: bit-exact ids, positions, counters,
+hit masks; byte-identical gathered rows."""
+import numpy as np
+import pytest
+import torch
+
+from tests.gpu_harness import CpuSide, GpuSide
+from tests.helpers import Workload, check_invariants, compare_batches
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("scale,ef,fanout,batch,dim", [
+    (10, 8, [25, 10], 64, 16),
+    (12, 16, [25, 10], 256, 100),
+    (12, 4, [15, 10, 5], 128, 128),
+    (11, 8, [3], 500, 7),
+    (13, 8, [10, 10], 1024, 256),
+    (10, 2, [1, 1, 1, 1], 32, 6),
+])
+def test_serve_batches_no_cache(hip, scale, ef, fanout, batch, dim):
+    wl = Workload(scale=scale, edge_factor=ef, dim=dim)
+    gpu, cpu = GpuSide(wl, batch, fanout), CpuSide(wl, batch, fanout)
+    n_train = wl.sets[(0, 0)][0].size
+    for mode, counters in ((0, range(min(3, (n_train - 1) // batch))), (1, range(2)), (2, range(1))):
+        bs = batch if mode == 0 else 100
+        for counter in counters:
+            g, c = gpu.run(0, counter, mode, batch_size=bs), cpu.run(0, counter, mode, batch_size=bs)
+            compare_batches(g, c, f"mode {mode} batch {counter}: ")
+            assert np.all(g["cache_search_buffer"] == -2)          # nothing cached yet: all misses
+            check_invariants(wl, g, fanout)
+    # the fused state array is back to "untouched" after every batch
+    pm = gpu.pools[0].buffer("position_map")
+    assert bool((pm == 0x7F7F7F7F).all())
+    gpu.close(); cpu.close()
+
+
+def test_partial_last_batch_and_empty(hip):
+    wl = Workload(scale=9, edge_factor=8, dim=8, n_seeds=100, n_valid=37, n_test=5)
+    gpu, cpu = GpuSide(wl, 16, [4, 3]), CpuSide(wl, 16, [4, 3])
+    for counter in (1, 2, 3):       # 37 ids, batch 16: full, partial (5, read at the reference's quirky offset), empty
+        g, c = gpu.run(0, counter, 1), cpu.run(0, counter, 1)
+        compare_batches(g, c, f"valid batch {counter}: ")
+    gpu.close(); cpu.close()
+
+
+@pytest.mark.parametrize("P,mode_bits,capacity", [(1, 0, (300, 200)), (2, 1, (150, 90)), (4, 2, (64, 33)),
+                                                  (4, 1, (100, 50)), (8, 3, (40, 20)), (3, 0, (77, 10))])
+def test_presc_cache_build_and_serve(hip, P, mode_bits, capacity):
+    """PreSC epoch -> hotness -> order -> maps/fills -> serving with hits, on P logical GPUs striped
+    over cliques of 2^mode_bits (logical GPUs share the physical one on a 1-GPU box)."""
+    wl = Workload(scale=11, edge_factor=8, dim=32, partition_count=P, n_seeds=1200)
+    fanout, batch = [5, 4], 64
+    gpu, cpu = GpuSide(wl, batch, fanout), CpuSide(wl, batch, fanout)
+    steps = min((wl.sets[(p, 0)][0].size - 1) // batch for p in range(P))
+    assert steps >= 1
+    for p in range(P):
+        for it in range(steps):
+            g, c = gpu.run(p, it, 0, is_presc=True), cpu.run(p, it, 0, is_presc=True)
+            compare_batches(g, c, f"presc gpu {p} it {it}: ")
+    for p in range(P):
+        assert np.array_equal(gpu.cache.array("node_access_time", p).cpu().numpy().view(np.uint64), cpu.node_access[p])
+        assert np.array_equal(gpu.cache.array("edge_access_time", p).cpu().numpy().view(np.uint64), cpu.edge_access[p])
+        assert gpu.cache.max_id_num(p) == cpu.max_ids[p]
+    gpu.cache.candidate_selection(mode_bits, gpu.graph)
+    gpu.cache.set_capacity(*capacity)
+    gpu.cache.fill_up(gpu.feature, gpu.graph)
+    caches = cpu.build_cache(mode_bits, capacity=capacity)
+    Kg = cpu.Kg
+    for ki, oc in enumerate(caches):
+        lead = ki * Kg
+        assert np.array_equal(gpu.cache.array("QF", lead).cpu().numpy(), oc.arr("QF", np.int32))
+        assert np.array_equal(gpu.cache.array("QT", lead).cpu().numpy(), oc.arr("QT", np.int32))
+        assert np.array_equal(gpu.cache.array("AF", lead).cpu().numpy().view(np.uint64), oc.arr("AF", np.uint64))
+        for j in range(Kg):
+            assert np.array_equal(gpu.cache.array("node_map", lead + j).cpu().numpy(), oc.arr("node_map", np.int32))
+            assert np.array_equal(gpu.cache.array("edge_index_map", lead + j).cpu().numpy(), oc.arr("edge_index_map", np.int8))
+            assert np.array_equal(gpu.cache.array("edge_offset_map", lead + j).cpu().numpy(), oc.arr("edge_offset_map", np.int32))
+    hits = 0
+    for p in range(P):
+        for mode in (0, 1):
+            g, c = gpu.run(p, 0, mode), cpu.run(p, 0, mode)
+            compare_batches(g, c, f"serve gpu {p} mode {mode}: ")
+            assert np.array_equal(g["cache_search_buffer"], c["cache_search_buffer"])      # feature hit mask + slots
+            tp_g = gpu.pools[p].buffer("tmp_part_ind")[:int(g["edge_counter"][1])].cpu().numpy()
+            tp_c = np.ctypeslib.as_array(cpu.pools[p].p.contents.tmp_part_ind, shape=(max(int(c["edge_counter"][1]), 1),))[:tp_g.size]
+            assert np.array_equal(tp_g, tp_c)                                               # topology hit mask
+            hits += int((g["cache_search_buffer"] >= 0).sum())
+    assert hits > 0
+    gpu.close(); cpu.close()
+
+
+@pytest.mark.parametrize("cache_memory,counters", [(200_000, (0, 0)), (1_000_000, (0, 0)),
+                                                   (400_000, (50_000, 70_000)), (3_000_000, (9, 9)),
+                                                   (50_000_000, (0, 0))])
+def test_cost_model_matches_oracle(hip, cache_memory, counters):
+    wl = Workload(scale=12, edge_factor=8, dim=64, n_seeds=2000)
+    fanout, batch = [10, 5], 128
+    gpu, cpu = GpuSide(wl, batch, fanout, cache_memory=cache_memory), CpuSide(wl, batch, fanout)
+    steps = (wl.sets[(0, 0)][0].size - 1) // batch
+    for it in range(steps):
+        gpu.run(0, it, 0, is_presc=True)
+        cpu.run(0, it, 0, is_presc=True)
+    gpu.cache.candidate_selection(0, gpu.graph)
+    gpu.cache.cost_model(gpu.feature, gpu.graph, counters, steps)
+    oc = cpu.build_cache(0, cache_memory=cache_memory, train_step=steps, counters=counters)[0]
+    assert (gpu.cache.node_capacity(0), gpu.cache.edge_capacity(0)) == (oc.node_capacity, oc.edge_capacity)
+    gpu.cache.fill_up(gpu.feature, gpu.graph)
+    g, c = gpu.run(0, 0, 0), cpu.run(0, 0, 0)
+    compare_batches(g, c, "serve after cost model: ")
+    assert np.array_equal(g["cache_search_buffer"], c["cache_search_buffer"])
+    gpu.close(); cpu.close()
