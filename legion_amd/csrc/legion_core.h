@@ -265,6 +265,8 @@ public:
 
     // new / exposed for the C API and the fused kernels
     void SetCapacity(int32_t node_capacity, int32_t edge_capacity);
+    void BindFeatureTable(float* table, int32_t total_num_nodes) { cpu_float_features_ = table; total_num_nodes_ = total_num_nodes; }
+    float* FeatureTable() const { return cpu_float_features_; }
     int32_t NodeCapacity(int32_t dev_id) const;
     int32_t EdgeCapacity(int32_t dev_id) const;
     CacheController* Controller(int32_t dev_id) const { return cache_controller_[dev_id]; }

@@ -139,6 +139,10 @@ extern "C" void FeatureCacheLookup(legion_stream_t strm_hdl, LegionUnifiedCache*
         std::cout << "feature buffer not initialized\n";
         return;
     }
+    if (cache->FeatureTable() == nullptr) {   // bound by FillUp (cache.cu:581-582) or legion_enqueue_batch
+        std::cout << "invalid feature table ptr\n";
+        return;
+    }
     int64_t max_rows = memorypool->feature_rows;
     if (max_rows > memorypool->num_ids) max_rows = memorypool->num_ids;
     cache->FeatCacheLookup(memorypool->GetSampledIds(), memorypool->GetCacheSearchBuffer(),
@@ -276,6 +280,10 @@ extern "C" void legion_enqueue_batch(legion_stream_t strm_hdl, LegionGraphStorag
                                      int32_t counter, int32_t dev_id, int32_t mode, bool is_presc,
                                      const int32_t* fanout, int32_t hop_num)
 {
+    if (cache && feature && cache_of(cache)->FeatureTable() == nullptr) {
+        FeatureStorage* f = reinterpret_cast<FeatureStorage*>(feature);
+        cache_of(cache)->BindFeatureTable(f->GetAllFloatFeature(), f->TotalNodeNum());
+    }
     BatchGenerate(strm_hdl, feature, cache, memorypool, batch_size, counter, dev_id, dev_id, mode, is_presc, hop_num);
     if (!is_presc) {
         FeatureCacheLookup(strm_hdl, cache, memorypool, 1, dev_id);

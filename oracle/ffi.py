@@ -29,7 +29,7 @@ class Pool(ctypes.Structure):
                 ("agg_src_off", P_I32), ("agg_dst_off", P_I32), ("cache_search_buffer", P_I32),
                 ("tmp_part_ind", P_I8), ("tmp_part_off", P_I32), ("accessed_map", P_U32),
                 ("position_map", P_I32), ("node_counter", c_i32 * 16), ("edge_counter", c_i32 * 16),
-                ("float_features", P_F32), ("feature_rows", c_i64)]
+                ("float_features", P_F32), ("feature_rows", c_i64), ("feature_dim", c_i32)]
 
 
 class Graph(ctypes.Structure):

@@ -71,6 +71,7 @@ lgo_pool* lgo_pool_create(int32_t total_num_nodes, int32_t num_ids, int32_t batc
     p->accessed_map = (uint32_t*)xcalloc((size_t)(total_num_nodes / 32) + 1, 4);
     p->position_map = (int32_t*)xcalloc(total_num_nodes, 4);
     p->feature_rows = feature_rows;
+    p->feature_dim = feature_dim;
     p->float_features = (float*)xcalloc((size_t)feature_rows * (size_t)(feature_dim > 0 ? feature_dim : 1), 4);
     return p;
 }
@@ -421,30 +422,34 @@ void lgo_find_topo(const lgo_cache* c, const int32_t* input_ids, int8_t* part_in
 {
     for (int32_t i = 0; i < batch_size; i++) {
         int32_t id = input_ids[i];
-        part_ind[i] = c->edge_index_map[id];
-        part_off[i] = c->edge_offset_map[id];
+        part_ind[i] = id >= 0 ? c->edge_index_map[id] : (int8_t)LGO_CACHEMISS_FLAG;
+        part_off[i] = id >= 0 ? c->edge_offset_map[id] : LGO_CACHEMISS_FLAG;
     }
 }
 
-/* SS/cache/cache.cu:180-215 */
+/* SS/cache/cache.cu:180-215; c == NULL: nothing is cached, every find() returns the sentinel */
 void lgo_find_feat(const lgo_cache* c, lgo_pool* p, int32_t op_id)
 {
     int32_t node_off = p->node_counter[(op_id % LGO_INTRABATCH_CON) * 2];
     int32_t batch_size = p->node_counter[(op_id % LGO_INTRABATCH_CON) * 2 + 1];
-    for (int32_t i = 0; i < batch_size; i++)
-        p->cache_search_buffer[i] = c->node_map[p->sampled_ids[node_off + i]];
+    for (int32_t i = 0; i < batch_size; i++) {
+        int32_t id = p->sampled_ids[node_off + i];
+        p->cache_search_buffer[i] = (c && id >= 0) ? c->node_map[id] : LGO_CACHEMISS_FLAG;
+    }
 }
 
-/* SS/engine/operator_impl.cu:502-519 -> SS/cache/cache.cu:726-748 -> cache_impl.cuh:239-272 */
+/* SS/engine/operator_impl.cu:502-519 -> SS/cache/cache.cu:726-748 -> cache_impl.cuh:239-272.
+ * c == NULL restates serving before FillUp: no map, every row is a miss (cache_index = -2). */
 void lgo_feature_cache_lookup(const lgo_cache* c, lgo_pool* p, const float* host_features,
                               int32_t op_id)
 {
     lgo_counter_update(p->node_counter, p->edge_counter, op_id, 0, 0);          /* :515 */
-    const int32_t D = c->feature_dim;
-    const int32_t cap = c->node_capacity;
-    const int32_t N = c->total_num_nodes;
+    const int32_t D = c ? c->feature_dim : p->feature_dim;
+    const int32_t cap = c ? c->node_capacity : 1;
+    const int32_t N = p->total_num_nodes;
     int32_t node_off = p->node_counter[(op_id % LGO_INTRABATCH_CON) * 2];
     int32_t batch_size = p->node_counter[(op_id % LGO_INTRABATCH_CON) * 2 + 1];
+    if (D <= 0 || host_features == NULL) return;                                /* :256 */
     for (int32_t r = 0; r < batch_size; r++) {
         int32_t gidx = p->cache_search_buffer[r];
         float* dst = p->float_features + ((int64_t)node_off + r) * D;
@@ -467,8 +472,9 @@ int64_t lgo_run_batch(lgo_pool* p, const lgo_graph* g, const lgo_cache* c,
                       uint64_t* edge_access_time)
 {
     const int use_cache = (!is_presc && c != NULL);
+    const int serve = !is_presc;
     lgo_batch_generate(p, all_ids, all_labels, total_cap, batch_size, counter, hop_num);  /* op 0 */
-    if (use_cache) {
+    if (serve) {
         lgo_find_feat(c, p, 0);
         lgo_feature_cache_lookup(c, p, host_features, 1);                                 /* op 1 */
     }
@@ -486,7 +492,7 @@ int64_t lgo_run_batch(lgo_pool* p, const lgo_graph* g, const lgo_cache* c,
         }
         lgo_construct_graph(p);
         lgo_counter_update(p->node_counter, p->edge_counter, op, 0, 0);
-        if (use_cache) {
+        if (serve) {
             lgo_find_feat(c, p, op);
             lgo_feature_cache_lookup(c, p, host_features, op + 1);                        /* op 3h+4 */
         }
@@ -569,15 +575,10 @@ static void* lgo_bench_thread(void* arg_)
     lgo_pool* p = lgo_pool_create(a->N, a->num_ids, a->batch_size, rows, a->D);
     int32_t* zero_labels = (int32_t*)xcalloc(a->total_cap, 4);
     for (int32_t b = a->first; b < a->last; b += a->stride) {
-        a->edges += lgo_run_batch(p, a->g, NULL, NULL, a->all_ids, zero_labels, a->total_cap,
+        /* serve mode without a cache: topology from slot P, every feature row a miss (full table) */
+        a->edges += lgo_run_batch(p, a->g, NULL, a->features, a->all_ids, zero_labels, a->total_cap,
                                   a->batch_size, b, a->fanout, a->hop_num, LGO_VALIDMODE, 0, NULL, NULL);
-        int32_t n = p->node_counter[LGO_INTRABATCH_CON * 3 + a->hop_num];
-        a->nodes += n;
-        if (a->features) {   /* all-miss gather from the full table: cache_impl.cuh:262-266 */
-            for (int32_t r = 0; r < n; r++)
-                memcpy(p->float_features + (int64_t)r * a->D,
-                       a->features + (int64_t)(p->sampled_ids[r] % a->N) * a->D, (size_t)a->D * 4);
-        }
+        a->nodes += p->node_counter[LGO_INTRABATCH_CON * 3 + a->hop_num];
         /* valid mode leaves position_map dirty exactly as the reference does; harmless */
     }
     free(zero_labels);

@@ -70,6 +70,7 @@ typedef struct lgo_pool {
     int32_t   edge_counter[16];
     float*    float_features;       /* [feature_rows * D] */
     int64_t   feature_rows;
+    int32_t   feature_dim;
 } lgo_pool;
 
 lgo_pool* lgo_pool_create(int32_t total_num_nodes, int32_t num_ids, int32_t batch_size,

@@ -33,6 +33,8 @@ class GpuSide:
         torch.cuda.synchronize()
         out = engine.read_batch(self.pools[dev_id])
         out["cache_search_buffer"] = self.pools[dev_id].buffer("cache_search_buffer")[:max(int(out["node_counter"][1]), 0)].cpu().numpy().copy()
+        if is_presc:
+            out.pop("float_features", None)      # PreSC runs ops 0,3,6,..,last only: nothing is gathered
         return out
 
     def close(self):
@@ -66,6 +68,7 @@ class CpuSide:
         out = self.pools[dev_id].read_batch()
         if is_presc:
             self.max_ids[dev_id] = max(self.max_ids[dev_id], int(out["node_counter"][7]))
+            out.pop("float_features", None)
         return out
 
     def build_cache(self, cache_agg_mode, cache_memory=None, capacity=None, train_step=1, counters=(0, 0)):

@@ -23,7 +23,7 @@ def test_serve_batches_no_cache(hip, scale, ef, fanout, batch, dim):
     gpu, cpu = GpuSide(wl, batch, fanout), CpuSide(wl, batch, fanout)
     n_train = wl.sets[(0, 0)][0].size
     for mode, counters in ((0, range(min(3, (n_train - 1) // batch))), (1, range(2)), (2, range(1))):
-        bs = batch if mode == 0 else 100
+        bs = batch if mode == 0 else min(batch, 100)
         for counter in counters:
             g, c = gpu.run(0, counter, mode, batch_size=bs), cpu.run(0, counter, mode, batch_size=bs)
             compare_batches(g, c, f"mode {mode} batch {counter}: ")
@@ -82,9 +82,14 @@ def test_presc_cache_build_and_serve(hip, P, mode_bits, capacity):
             g, c = gpu.run(p, 0, mode), cpu.run(p, 0, mode)
             compare_batches(g, c, f"serve gpu {p} mode {mode}: ")
             assert np.array_equal(g["cache_search_buffer"], c["cache_search_buffer"])      # feature hit mask + slots
-            tp_g = gpu.pools[p].buffer("tmp_part_ind")[:int(g["edge_counter"][1])].cpu().numpy()
-            tp_c = np.ctypeslib.as_array(cpu.pools[p].p.contents.tmp_part_ind, shape=(max(int(c["edge_counter"][1]), 1),))[:tp_g.size]
+            H = len(fanout)                  # the last FindTopo covered the last hop's frontier
+            n_f = int(g["edge_counter"][9 + H - 1] - g["edge_counter"][9 + H - 2]) if H > 1 else int(g["node_counter"][9])
+            tp_g = gpu.pools[p].buffer("tmp_part_ind")[:n_f].cpu().numpy()
+            tp_c = np.ctypeslib.as_array(cpu.pools[p].p.contents.tmp_part_ind, shape=(max(n_f, 1),))[:n_f]
             assert np.array_equal(tp_g, tp_c)                                               # topology hit mask
+            to_g = gpu.pools[p].buffer("tmp_part_off")[:n_f].cpu().numpy()
+            to_c = np.ctypeslib.as_array(cpu.pools[p].p.contents.tmp_part_off, shape=(max(n_f, 1),))[:n_f]
+            assert np.array_equal(to_g, to_c)
             hits += int((g["cache_search_buffer"] >= 0).sum())
     assert hits > 0
     gpu.close(); cpu.close()
