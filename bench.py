@@ -1,0 +1,243 @@
+#!/usr/bin/env python3
+"""bench.py -- sampled edges/s + feature-gather GB/s of the hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+A "step" is one mini-batch through the whole hot path on one GPU: seed batch -> 2-hop sampling
+[25,10] -> per-hop feature-cache lookup + gather -> end-of-batch clean-up (the op order of the
+reference's GPURunner::RunOnce, SS/engine/server.cu:302-332), inputs resident in HBM.
+Workload: synthetic RMAT-26 (N = 2^26, E = 2^30), float32[N x 128] counter-hash
+features, B = 1024, seeds = a seeded permutation, GPU p of P takes seeds with id % P == p.
+
+One process per GPU.  The path shards by seeds with no per-batch exchange; the only collective is
+the one-time all-reduce (RCCL) of the PreSC hotness counters that sizes the caches.  Weak scaling:
+every rank runs K batches of B seeds; value = total sampled edges of all ranks / max-over-ranks time.
+
+Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel, the hop-2 gather:
+achieved = rows * (8*D + 8) bytes / HIP-event time around that launch, summed over the timed steps.
+`cpu_baseline` is the oracle's C restatement (oracle/, test infrastructure) timed on the host cores
+on a bounded sample of the same batches -- a reported baseline, not a target.
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0   # MI355X_MICROARCH.md: 8 TB/s spec
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--scale", type=int, default=26)
+    ap.add_argument("--edge-factor", type=int, default=16)
+    ap.add_argument("--dim", type=int, default=128)
+    ap.add_argument("--batch", type=int, default=1024)
+    ap.add_argument("--fanout", type=str, default="25,10")
+    ap.add_argument("--cache-memory", type=int, default=8 << 30, help="bytes per GPU fed to the cost model")
+    ap.add_argument("--presc-steps", type=int, default=512, help="PreSC batches per GPU (bounded epoch)")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU-baseline time; 0 disables")
+    ap.add_argument("--no-verify", action="store_true")
+    return ap.parse_args()
+
+
+def main():
+    args = parse_args()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    from legion_amd import engine, synth
+
+    fanout = [int(x) for x in args.fanout.split(",")]
+    H = len(fanout)
+    N = 1 << args.scale
+    D = args.dim
+    B = args.batch
+    t_setup = time.time()
+
+    # ---- workload, resident in HBM --------------------------------------------------------------
+    indptr, col = synth.rmat_csr_device(args.scale, args.edge_factor, 20231, dev)
+    features = synth.features_device(N, D, 7, dev)
+    need = (args.warmup + args.steps + 2) * B * world + B
+    need = max(need, (args.presc_steps + 2) * B * world)
+    all_seeds = synth.seed_ids(N, min(max(need * 2, N // 10), N), 11)
+    mine = np.ascontiguousarray(all_seeds[all_seeds % world == rank])      # storage_management.cu:178
+    assert mine.size > (args.warmup + args.steps + 1) * B, "not enough seeds for this rank"
+
+    graph = engine.GraphStorage(1, indptr, col)
+    feature = engine.FeatureStorage(1, features)
+    feature.set_ids(0, engine.TRAINMODE, mine, None)
+    train_step = min((mine.size - 1) // B, args.presc_steps)
+    cache = engine.UnifiedCache(args.cache_memory, D, train_step, 1, N)
+    cache.init_controller(0)
+    pool = engine.MemoryPool(0, N, B, fanout, D, pipeline_depth=1)
+
+    # ---- PreSC epoch (bounded) -> hotness -> all-reduce over ranks -> order -> cost model -> fills --
+    for it in range(train_step):
+        engine.enqueue_batch(None, graph, feature, cache, pool, B, it, 0, engine.TRAINMODE, True, fanout)
+    torch.cuda.synchronize()
+    if world > 1:   # the only collective of the path: RCCL all-reduce of the uint64 hotness counters
+        dist.all_reduce(cache.array("node_access_time", 0))
+        dist.all_reduce(cache.array("edge_access_time", 0))
+    max_ids = cache.max_id_num(0)
+    cache.candidate_selection(0, graph, world_reduced=(world > 1))
+    cache.cost_model(feature, graph, (0, 0), train_step)
+    cache.fill_up(feature, graph)
+    pool.alloc_features(int(max_ids * 1.2))                                  # server.cu:277
+    torch.cuda.synchronize()
+    setup_s = time.time() - t_setup
+
+    def run(it):
+        engine.enqueue_batch(None, graph, feature, cache, pool, B, it, 0, engine.TRAINMODE, False, fanout)
+
+    # ---- untimed counting pass over exactly the timed batches (deterministic) --------------------
+    first = args.warmup
+    edges = np.zeros(args.steps, dtype=np.int64)
+    rows = np.zeros((args.steps, H + 1), dtype=np.int64)
+    slots = np.zeros((args.steps, H), dtype=np.int64)
+    hits = 0
+    bad_words = 0
+    for k in range(args.steps):
+        run(first + k)
+        torch.cuda.synchronize()
+        nc = pool.buffer("node_counter").cpu().numpy()
+        ec = pool.buffer("edge_counter").cpu().numpy()
+        edges[k] = ec[9 + H]
+        rows[k, 0] = nc[9]
+        for h in range(H):
+            rows[k, h + 1] = nc[9 + h + 1] - nc[9 + h]
+            frontier = nc[9] if h == 0 else ec[9 + h] - ec[9 + h - 1]
+            slots[k, h] = int(frontier) * fanout[h]
+        if k == 0 and not args.no_verify:
+            # size-independent parity property at full size: every gathered row is byte-identical to
+            # the generator's value for its id; ids are unique; positions localise the edge endpoints
+            n = int(nc[9 + H])
+            ids = pool.buffer("sampled_ids")[:n]
+            bad_words = synth.feature_check_device(pool.buffer("float_features")[:n].contiguous(), ids.contiguous(), D, 7)
+            assert bad_words == 0, f"{bad_words} gathered words differ from the source rows"
+            assert int(torch.unique(ids).numel()) == n, "duplicate node ids in the batch"
+            e = int(ec[9 + H])
+            src_g = pool.buffer("agg_src_ids")[:e].long()
+            assert bool((ids.long()[pool.buffer("agg_src_off")[:e].long()] == src_g).all())
+            hits = int((pool.buffer("cache_search_buffer")[:int(nc[1])] >= 0).sum())
+
+    # ---- warm-up, then the timed region ----------------------------------------------------------
+    for it in range(args.warmup):
+        run(it)
+    torch.cuda.synchronize()
+    pool.profile_begin(args.steps * (H + 1))
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        run(first + k)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    ms, ops = pool.profile_end(args.steps * (H + 1))
+
+    tot_edges = torch.tensor([float(edges.sum())], dtype=torch.float64, device=dev)
+    t_max = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    gather_bytes_t = torch.tensor([float(rows.sum() * D * 4)], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(tot_edges)
+        dist.all_reduce(gather_bytes_t)
+        dist.all_reduce(t_max, op=dist.ReduceOp.MAX)
+    elapsed_max = float(t_max.item())
+
+    # ---- roofline of the dominant kernel: the last hop's gather (op 3H+1) -------------------------
+    last_op = 3 * H + 1
+    sel = ops == last_op
+    t_last = float(ms[sel].sum()) * 1e-3
+    rows_last = int(rows[:, H].sum())
+    bytes_per_row = 8 * D + 8
+    achieved = rows_last * bytes_per_row / t_last / 1e9 if t_last > 0 else 0.0
+    t_all_gathers = float(ms.sum()) * 1e-3
+    payload_gbps = float(rows.sum() * D * 4) / t_all_gathers / 1e9 if t_all_gathers > 0 else 0.0
+
+    if rank == 0:
+        out = {
+            "metric": "sampled_edges_per_sec",
+            "value": float(tot_edges.item()) / elapsed_max,
+            "unit": "edges/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed_max / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "int32+f32(copy)", "data": "synthetic",
+            "config": {"workload": f"RMAT-{args.scale} EF{args.edge_factor} (N={N}, E={N * args.edge_factor}), "
+                                   f"float32[N x {D}] features, batch {B}, fanout {fanout}, all tables resident in HBM",
+                       "parallelism": f"seed-sharded x{world}, replicated graph+features, cache_agg_mode 0",
+                       "cache_memory_bytes": args.cache_memory,
+                       "feature_cache_rows": cache.node_capacity(0), "topology_cache_vertices": cache.edge_capacity(0),
+                       "presc_batches": train_step},
+            "feature_gather_GBps": payload_gbps * 1.0,
+            "feature_gather_GBps_note": "payload bytes read (rows*D*4) / HIP-event time of all gather launches, rank 0",
+            "edges_per_step": float(edges.mean()), "rows_per_step": float(rows.sum(axis=1).mean()),
+            "seed_feature_cache_hits_step0": hits,
+            "roofline": {"bound": "hbm", "kernel": "gather_kernel<float4> (hop-%d gather, op %d)" % (H, last_op),
+                         "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+                         "bytes_per_row": bytes_per_row, "rows_per_launch": rows_last / max(int(sel.sum()), 1),
+                         "avg_launch_us": t_last / max(int(sel.sum()), 1) * 1e6},
+            "setup_seconds": setup_s,
+        }
+        if args.cpu_seconds > 0:
+            out["cpu_baseline"] = cpu_baseline(indptr, col, mine, N, B, fanout, first, args.cpu_seconds)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def cpu_baseline(indptr, col, seeds, N, B, fanout, first_batch, target_s):
+    """The oracle's sampler (same Legion semantics, same batches) on the host cores; topology only
+    (a 34 GB host copy of the feature table is not worth the PCIe time), so the unit is edges/s."""
+    from oracle import ffi
+    L = ffi.load()
+    ip = indptr.cpu().numpy()
+    cl = col.cpu().numpy()
+    g = ffi.OracleGraph(1, ip, cl)
+    cores = len(os.sched_getaffinity(0))
+    fan = np.asarray(fanout, dtype=np.int32)
+    sd = np.ascontiguousarray(seeds, dtype=np.int32)
+
+    def timed(nb):
+        secs = ctypes.c_double(0)
+        nodes = ctypes.c_int64(0)
+        e = L.lgo_bench_batches(ctypes.byref(g.g), N, ffi._p(sd, ffi.P_I32), int(sd.size), B, ffi._p(fan, ffi.P_I32),
+                                len(fanout), first_batch, nb, cores, None, 0, ctypes.byref(secs), ctypes.byref(nodes))
+        return int(e), secs.value
+
+    e, s = timed(cores)                       # calibration: one batch per thread
+    nb = int(max(cores, min(cores * 64, cores * target_s / max(s, 1e-3))))
+    nb = min(nb, (sd.size - 1) // B - first_batch)
+    e, s = timed(nb)
+    return {"value": e / s, "unit": "edges/s", "cores": cores, "kind": "port",
+            "sample": f"{nb} batches of {B} seeds (same RMAT graph, same fan-out, sampling only, no gather), "
+                      f"{s:.1f} s on {cores} threads"}
+
+
+if __name__ == "__main__":
+    main()

@@ -162,6 +162,22 @@ int32_t legion_ipc_local_batch_id(LegionIPCEnv* e, int32_t global_batch_id);
 int32_t legion_ipc_current_batchsize(LegionIPCEnv* e, int32_t dev_id, int32_t mode);
 void legion_ipc_finalize(LegionIPCEnv* e);
 
+/* Pipeline: `lanes` independent mini-batches in flight on one GPU, each with its own MemoryPool
+ * (outputs + private scratch) and HIP stream, each batch replayed as one hipGraph.  This is the
+ * MI355X-native form of the Runner's inter-batch pipe (SS/engine/server.cu:302-332 with
+ * INTERBATCH_CON output slots): submit() never blocks on the batch it enqueues, only on the lane's
+ * previous one.  feature_rows sizes each lane's feature buffer (SS/engine/server.cu:275-283). */
+typedef struct LegionPipeline LegionPipeline;
+LegionPipeline* legion_pipeline_create(LegionGraphStorage* graph, LegionFeatureStorage* feature,
+                                       LegionUnifiedCache* cache, int32_t dev_id, int32_t batch_size,
+                                       const int32_t* fanout, int32_t hop_num, int32_t lanes,
+                                       int64_t feature_rows, int32_t use_graph);
+int32_t legion_pipeline_submit(LegionPipeline* p, int32_t counter, int32_t mode);   /* returns the lane */
+void legion_pipeline_wait(LegionPipeline* p, int32_t lane);                          /* lane < 0: all lanes */
+LegionMemoryPool* legion_pipeline_pool(LegionPipeline* p, int32_t lane);
+legion_stream_t legion_pipeline_stream(LegionPipeline* p, int32_t lane);
+void legion_pipeline_destroy(LegionPipeline* p);
+
 /* =====================================================================================
  * 4. Kernel-level launchers (what the operators call), exported so the hot kernels can be
  *    measured and tested alone.
@@ -176,6 +192,11 @@ void legion_gather_rows(legion_stream_t stream, const float* full_table, const f
 /* the draw of SS/engine/operator_impl.cu:235-238 evaluated on the GPU for n (idx, deg) pairs */
 void legion_draw_batch(legion_stream_t stream, const int32_t* idx, const int32_t* deg, int32_t* out,
                        int32_t n);
+/* Measurement aid (no reference counterpart): while enabled, FeatureCacheLookup records a HIP event
+ * on its own stream before and after the gather launch.  _end returns how many gathers were timed
+ * and fills their elapsed ms and op ids; call it after synchronising the stream. */
+void legion_pool_profile_begin(LegionMemoryPool* p, int32_t max_ops);
+int32_t legion_pool_profile_end(LegionMemoryPool* p, float* out_ms, int32_t* out_op, int32_t cap);
 
 /* =====================================================================================
  * 5. Synthetic workload generators (RMAT + counter-hash features); device side.

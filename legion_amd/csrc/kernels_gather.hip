@@ -48,7 +48,12 @@ __global__ __launch_bounds__(LG_GATHER_THREADS) void gather_kernel(
     const int32_t dr = LG_GATHER_THREADS / C;          // row / chunk advance per 256-chunk step
     const int32_t dc = LG_GATHER_THREADS - dr * C;
 
-    for (int32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    // one tile per workgroup: the grid covers the whole feature buffer, surplus workgroups leave
+    // here, and the hardware dispatcher balances the rest (a grid-stride loop over a fixed grid
+    // left a 1-vs-2-tiles imbalance at typical sizes)
+    {
+        const int32_t tile = blockIdx.x;
+        if (tile >= ntiles) return;
         const int32_t r0 = tile * LG_GATHER_ROWS;
         const int32_t nr = min(LG_GATHER_ROWS, rows - r0);
         if (tid < nr) {
@@ -99,7 +104,6 @@ __global__ __launch_bounds__(LG_GATHER_THREADS) void gather_kernel(
                     __builtin_nontemporal_store(v[u], reinterpret_cast<VecT*>(dst_tile + (int64_t)rr[u] * D) + cc[u]);
             }
         }
-        __syncthreads();
     }
 }
 
@@ -110,8 +114,7 @@ void launch_gather(hipStream_t s, const float* full_table, const float* const* c
 {
     if (D <= 0 || max_rows <= 0) return;                // :256 float_feature_len > 0
     if (node_capacity < 1) node_capacity = 1;
-    int32_t grid = (max_rows + LG_GATHER_ROWS - 1) / LG_GATHER_ROWS;
-    if (grid > 256 * 8) grid = 256 * 8;                 // 256 CUs x 8 resident workgroups
+    const int32_t grid = (max_rows + LG_GATHER_ROWS - 1) / LG_GATHER_ROWS;
     typedef float v4 __attribute__((ext_vector_type(4)));
     typedef float v2 __attribute__((ext_vector_type(2)));
     if (D % 4 == 0)

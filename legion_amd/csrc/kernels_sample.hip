@@ -98,9 +98,11 @@ __global__ void batch_generate_kernel(int32_t* __restrict__ batch_ids, int32_t* 
                                       const int32_t* __restrict__ all_ids,
                                       const int32_t* __restrict__ all_labels, int32_t total_cap,
                                       int32_t* __restrict__ position_map, int32_t* __restrict__ nc,
-                                      int32_t* __restrict__ ec, int32_t hop_num)
+                                      int32_t* __restrict__ ec, int32_t hop_num,
+                                      const int32_t* __restrict__ iter_state)
 {
     const int32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (iter_state != nullptr) counter = iter_state[0];   // graph replay: iteration lives on the device
     if (idx < 16) {                    // memset of both counter blocks, operator_impl.cu:155-156,
         int32_t v = 0;                 // then counter_update(op 0), :64-68
         if (idx == 1) v = size;
@@ -126,12 +128,12 @@ __global__ void batch_generate_kernel(int32_t* __restrict__ batch_ids, int32_t* 
 void launch_batch_generate(hipStream_t s, int32_t* batch_ids, int32_t* labels, int32_t size,
                            int32_t counter, const int32_t* all_ids, const int32_t* all_labels,
                            int32_t total_cap, int32_t* position_map, int32_t* node_counter,
-                           int32_t* edge_counter, int32_t hop_num)
+                           int32_t* edge_counter, int32_t hop_num, const int32_t* iter_state)
 {
     const int32_t n = size > 16 ? size : 16;
     batch_generate_kernel<<<(n + 255) / 256, 256, 0, s>>>(batch_ids, labels, size, counter, all_ids,
                                                          all_labels, total_cap, position_map,
-                                                         node_counter, edge_counter, hop_num);
+                                                         node_counter, edge_counter, hop_num, iter_state);
     hipCheckError();
 }
 
@@ -427,8 +429,10 @@ void launch_random_sample(hipStream_t s, const SampleArgs& a)
 // ------------------------------------------------------------------------------------------
 __global__ void clear_pos_map_kernel(int32_t* __restrict__ position_map,
                                      const int32_t* __restrict__ sampled_ids,
-                                     const int32_t* __restrict__ nc)
+                                     const int32_t* __restrict__ nc, int32_t* __restrict__ iter_state)
 {
+    // last kernel of a batch: advance the device-resident iteration for the next graph replay
+    if (iter_state != nullptr && blockIdx.x == 0 && threadIdx.x == 0) iter_state[0] += iter_state[1];
     const int32_t hop_num = nc[INTRABATCH_CON * 3 - 1];
     const int32_t total = nc[INTRABATCH_CON * 3 + hop_num];
     for (int32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
@@ -438,9 +442,9 @@ __global__ void clear_pos_map_kernel(int32_t* __restrict__ position_map,
 }
 
 void launch_clear_pos_map(hipStream_t s, int32_t* position_map, const int32_t* sampled_ids,
-                          const int32_t* node_counter)
+                          const int32_t* node_counter, int32_t* iter_state)
 {
-    clear_pos_map_kernel<<<1024, 256, 0, s>>>(position_map, sampled_ids, node_counter);
+    clear_pos_map_kernel<<<1024, 256, 0, s>>>(position_map, sampled_ids, node_counter, iter_state);
     hipCheckError();
 }
 

@@ -141,12 +141,23 @@ public:
     int32_t* hop_scratch = nullptr;    // [HS_WORDS]
     int32_t num_ids = 0;
     int32_t max_slots = 0;             // largest hop = B * f1 * ... * fH
+    std::vector<int64_t> max_new;      // [h] upper bound of new nodes of op 3h (h = 0: the seeds)
     int32_t total_num_nodes = 0;
     int32_t batch_size = 0;
     int32_t float_feature_len = 0;
     int64_t feature_rows = 0;
     int32_t dev_id = 0;
     bool owns_buffers = false;
+
+    // graph replay: {next iteration, stride} on the device; when set, BatchGenerate reads the
+    // iteration there and IOComplete advances it (no per-replay kernel-argument update)
+    int32_t* iter_state = nullptr;
+
+    // optional per-op timing with HIP events on the op's own stream (bench.py roofline leg)
+    std::vector<hipEvent_t> prof_events;   // pairs: [2*i] before, [2*i+1] after
+    std::vector<int32_t> prof_op;          // op id of each pair
+    int32_t prof_used = 0;
+    bool prof_on = false;
 
     void Finalize();
 
@@ -395,7 +406,7 @@ namespace lg {
 void launch_batch_generate(hipStream_t s, int32_t* batch_ids, int32_t* labels, int32_t size,
                            int32_t counter, const int32_t* all_ids, const int32_t* all_labels,
                            int32_t total_cap, int32_t* position_map, int32_t* node_counter,
-                           int32_t* edge_counter, int32_t hop_num);
+                           int32_t* edge_counter, int32_t hop_num, const int32_t* iter_state);
 
 struct SampleArgs {
     int32_t op_id;
@@ -431,7 +442,7 @@ void launch_gather(hipStream_t s, const float* full_table, const float* const* c
                    int32_t* range_copy /* node_counter+2 or null */, float* dst, int32_t max_rows);
 
 void launch_clear_pos_map(hipStream_t s, int32_t* position_map, const int32_t* sampled_ids,
-                          const int32_t* node_counter);
+                          const int32_t* node_counter, int32_t* iter_state);
 void launch_hotness_measure(hipStream_t s, const int32_t* sampled_ids, const int32_t* node_counter,
                             unsigned long long* access_map);
 void launch_find(hipStream_t s, const int32_t* keys, int32_t n, const int32_t* map32,

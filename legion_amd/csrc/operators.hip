@@ -78,7 +78,7 @@ extern "C" void BatchGenerate(legion_stream_t strm_hdl, LegionFeatureStorage* fe
     lg::launch_batch_generate(static_cast<hipStream_t>(strm_hdl), memorypool->GetSampledIds(),
                               memorypool->GetLabels(), size, counter, all_ids, all_labels, total_cap,
                               memorypool->GetPositionMap(), memorypool->GetNodeCounter(),
-                              memorypool->GetEdgeCounter(), hop_num);
+                              memorypool->GetEdgeCounter(), hop_num, memorypool->iter_state);
     // cache->FindFeat(op 0) (:167-170) happens inside FeatureCacheLookup(op 1)
 }
 
@@ -145,9 +145,19 @@ extern "C" void FeatureCacheLookup(legion_stream_t strm_hdl, LegionUnifiedCache*
     }
     int64_t max_rows = memorypool->feature_rows;
     if (max_rows > memorypool->num_ids) max_rows = memorypool->num_ids;
+    const size_t hop = (size_t)(op_id / INTRABATCH_CON);          // grid bound: new nodes of op 3h <= B f1..fh
+    if (hop < memorypool->max_new.size() && memorypool->max_new[hop] < max_rows) max_rows = memorypool->max_new[hop];
+    hipStream_t s = static_cast<hipStream_t>(strm_hdl);
+    const bool prof = memorypool->prof_on && (size_t)(2 * memorypool->prof_used + 1) < memorypool->prof_events.size();
+    if (prof) HIP_CALL(hipEventRecord(memorypool->prof_events[2 * memorypool->prof_used], s));
     cache->FeatCacheLookup(memorypool->GetSampledIds(), memorypool->GetCacheSearchBuffer(),
                            memorypool->GetNodeCounter(), memorypool->GetFloatFeatures(), op_id, dev_id,
-                           static_cast<hipStream_t>(strm_hdl), (int32_t)max_rows);
+                           s, (int32_t)max_rows);
+    if (prof) {
+        HIP_CALL(hipEventRecord(memorypool->prof_events[2 * memorypool->prof_used + 1], s));
+        memorypool->prof_op[memorypool->prof_used] = op_id;
+        memorypool->prof_used++;
+    }
 }
 
 extern "C" void IOSubmit(legion_stream_t, LegionFeatureStorage*, LegionMemoryPool*, int32_t, int32_t)
@@ -170,7 +180,7 @@ extern "C" void IOComplete(legion_stream_t strm_hdl, LegionUnifiedCache* cache_,
                               memorypool->GetAggSrcOf(), memorypool->GetAggDstOf(), memorypool->GetNodeCounter(),
                               memorypool->GetEdgeCounter(), s, dev_id);
     lg::launch_clear_pos_map(s, memorypool->GetPositionMap(), memorypool->GetSampledIds(),
-                             memorypool->GetNodeCounter());
+                             memorypool->GetNodeCounter(), memorypool->iter_state);
 }
 
 // =============================================================================================
@@ -298,4 +308,35 @@ extern "C" void legion_enqueue_batch(legion_stream_t strm_hdl, LegionGraphStorag
         }
     }
     IOComplete(strm_hdl, cache, memorypool, dev_id, mode);
+}
+
+// ---- gather-op timing (HIP events recorded on the op's stream around the gather launch) -------
+extern "C" void legion_pool_profile_begin(LegionMemoryPool* p_, int32_t max_ops)
+{
+    MemoryPool* mp = reinterpret_cast<MemoryPool*>(p_);
+    if (!mp) return;
+    SetGPUDevice(mp->dev_id);
+    while ((int32_t)mp->prof_events.size() < 2 * max_ops) {
+        hipEvent_t e;
+        HIP_CALL(hipEventCreate(&e));
+        mp->prof_events.push_back(e);
+    }
+    mp->prof_op.assign(max_ops, -1);
+    mp->prof_used = 0;
+    mp->prof_on = true;
+}
+
+// Stops recording; out_ms[i] / out_op[i] = elapsed time and op id of the i-th timed gather.
+// The caller must have synchronised the stream.  Returns the number of timed ops.
+extern "C" int32_t legion_pool_profile_end(LegionMemoryPool* p_, float* out_ms, int32_t* out_op, int32_t cap)
+{
+    MemoryPool* mp = reinterpret_cast<MemoryPool*>(p_);
+    if (!mp) return 0;
+    mp->prof_on = false;
+    int32_t n = mp->prof_used < cap ? mp->prof_used : cap;
+    for (int32_t i = 0; i < n; i++) {
+        HIP_CALL(hipEventElapsedTime(&out_ms[i], mp->prof_events[2 * i], mp->prof_events[2 * i + 1]));
+        out_op[i] = mp->prof_op[i];
+    }
+    return n;
 }

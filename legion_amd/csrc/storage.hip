@@ -289,7 +289,8 @@ void lg_pool_alloc_private(MemoryPool* mp, int32_t dev_id, int32_t total_num_nod
 {
     SetGPUDevice(dev_id);
     int64_t num_ids = batch_size, per = batch_size;         // server.cu:187-199
-    for (int i = 0; i < hop_num; i++) { per *= fanout[i]; num_ids += per; }
+    mp->max_new.assign(1, batch_size);
+    for (int i = 0; i < hop_num; i++) { per *= fanout[i]; num_ids += per; mp->max_new.push_back(per); }
     if (per > LG_MAX_SLOTS || num_ids > 0x7FFFFFFF) {
         printf("legion_hip: batch %d with this fan-out needs %lld slots; limit is %d\n", batch_size,
                (long long)per, LG_MAX_SLOTS);

@@ -131,6 +131,21 @@ class MemoryPool:
                                                    self.float_feature_len, int(pipeline_depth))
         self.num_ids = int(self._lib.legion_pool_num_ids(self.handle))
 
+    @classmethod
+    def _borrowed(cls, handle, dev_id, total_num_nodes, batch_size, fanout, float_feature_len, feature_rows):
+        """View of a pool owned by a Pipeline lane (close() is a no-op)."""
+        self = cls.__new__(cls)
+        self._lib = _libmod.load()
+        self.dev_id = int(dev_id)
+        self.device = torch.device("cuda", self.dev_id % max(torch.cuda.device_count(), 1))
+        self.total_num_nodes, self.batch_size = int(total_num_nodes), int(batch_size)
+        self.fanout = [int(f) for f in fanout]
+        self.float_feature_len, self.feature_rows = int(float_feature_len), int(feature_rows)
+        self.handle = handle
+        self.num_ids = int(self._lib.legion_pool_num_ids(handle))
+        self._borrowed_handle = True
+        return self
+
     def alloc_features(self, rows):
         self.feature_rows = int(rows)
         self._lib.legion_pool_alloc_features(self.handle, self.feature_rows)
@@ -153,9 +168,45 @@ class MemoryPool:
             shape = (self.num_ids,)
         return device_view(ptr, shape, dtype, self.device)
 
+    def profile_begin(self, max_ops):
+        self._lib.legion_pool_profile_begin(self.handle, int(max_ops))
+
+    def profile_end(self, max_ops):
+        """(ms, op_id) arrays of the gathers timed since profile_begin; synchronise the stream first."""
+        ms = (ctypes.c_float * max_ops)()
+        ops = (ctypes.c_int32 * max_ops)()
+        n = self._lib.legion_pool_profile_end(self.handle, ms, ops, int(max_ops))
+        return np.array(ms[:n], dtype=np.float64), np.array(ops[:n], dtype=np.int32)
+
+    def close(self):
+        if self.handle and not getattr(self, "_borrowed_handle", False):
+            self._lib.legion_pool_destroy(self.handle)
+        self.handle = None
+
+
+class Pipeline:
+    """`lanes` mini-batches in flight on one GPU, each replayed as one hipGraph (pipeline.hip)."""
+
+    def __init__(self, graph, feature, cache, dev_id, batch_size, fanout, lanes, feature_rows, use_graph=True):
+        self._lib = _libmod.load()
+        self.lanes = int(lanes)
+        self.fanout = [int(f) for f in fanout]
+        self.handle = self._lib.legion_pipeline_create(graph.handle, feature.handle, cache.handle, int(dev_id),
+                                                       int(batch_size), _i32_array(self.fanout), len(self.fanout),
+                                                       self.lanes, int(feature_rows), 1 if use_graph else 0)
+        self.pools = [MemoryPool._borrowed(self._lib.legion_pipeline_pool(self.handle, i), dev_id,
+                                           feature.total_num_nodes, batch_size, fanout, feature.float_feature_len,
+                                           feature_rows) for i in range(self.lanes)]
+
+    def submit(self, counter, mode=TRAINMODE):
+        return int(self._lib.legion_pipeline_submit(self.handle, int(counter), int(mode)))
+
+    def wait(self, lane=-1):
+        self._lib.legion_pipeline_wait(self.handle, int(lane))
+
     def close(self):
         if self.handle:
-            self._lib.legion_pool_destroy(self.handle)
+            self._lib.legion_pipeline_destroy(self.handle)
             self.handle = None
 
 

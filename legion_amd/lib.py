@@ -63,9 +63,17 @@ SIGNATURES = {
     "legion_ipc_local_batch_id": (c_i32, [c_p, c_i32]),
     "legion_ipc_current_batchsize": (c_i32, [c_p, c_i32, c_i32]),
     "legion_ipc_finalize": (None, [c_p]),
+    "legion_pipeline_create": (c_p, [c_p, c_p, c_p, c_i32, c_i32, P_I32, c_i32, c_i32, c_i64, c_i32]),
+    "legion_pipeline_submit": (c_i32, [c_p, c_i32, c_i32]),
+    "legion_pipeline_wait": (None, [c_p, c_i32]),
+    "legion_pipeline_pool": (c_p, [c_p, c_i32]),
+    "legion_pipeline_stream": (c_p, [c_p, c_i32]),
+    "legion_pipeline_destroy": (None, [c_p]),
     # 4. kernel-level
     "legion_gather_rows": (None, [c_p, c_p, c_p, c_p, c_i32, c_i32, c_i32, c_p, c_p, c_p, c_p, c_i32]),
     "legion_draw_batch": (None, [c_p, c_p, c_p, c_p, c_i32]),
+    "legion_pool_profile_begin": (None, [c_p, c_i32]),
+    "legion_pool_profile_end": (c_i32, [c_p, ctypes.POINTER(ctypes.c_float), P_I32, c_i32]),
     # 5. synthetic workloads
     "legion_synth_rmat_edges": (None, [c_p, c_i32, c_i64, c_u64, c_p, c_p]),
     "legion_synth_features": (None, [c_p, c_p, c_i64, c_i64, c_i32, c_u64]),
