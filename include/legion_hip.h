@@ -177,6 +177,14 @@ void legion_pipeline_wait(LegionPipeline* p, int32_t lane);                     
 LegionMemoryPool* legion_pipeline_pool(LegionPipeline* p, int32_t lane);
 legion_stream_t legion_pipeline_stream(LegionPipeline* p, int32_t lane);
 void legion_pipeline_destroy(LegionPipeline* p);
+/* Measurement aid: HIP events on each lane's stream around every gather launch.  While it is on,
+ * batches are launched eagerly (HIP cannot time events recorded by graph nodes).  read() fills, per
+ * gather op id, the summed elapsed ms and the launch count of every batch waited for since begin();
+ * returns the op count. */
+void legion_pipeline_profile_begin(LegionPipeline* p);
+void legion_pipeline_profile_end(LegionPipeline* p);
+int32_t legion_pipeline_profile_read(LegionPipeline* p, int32_t* op_ids, double* ms_sums, int64_t* counts,
+                                     int32_t cap);
 
 /* =====================================================================================
  * 4. Kernel-level launchers (what the operators call), exported so the hot kernels can be

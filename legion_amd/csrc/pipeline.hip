@@ -18,6 +18,7 @@
 
 #include <map>
 
+extern "C" void legion_pool_profile_begin(LegionMemoryPool* p_, int32_t max_ops);
 extern "C" void legion_enqueue_batch(legion_stream_t strm_hdl, LegionGraphStorage* graph, LegionFeatureStorage* feature,
                                      LegionUnifiedCache* cache, LegionMemoryPool* memorypool, int32_t batch_size,
                                      int32_t counter, int32_t dev_id, int32_t mode, bool is_presc,
@@ -31,6 +32,8 @@ struct Lane {
     std::map<int64_t, hipGraphExec_t> exec;   // key: mode * 2^32 + batch_size
     int32_t next_iter = -1;                   // value iter_state[0] will hold when the lane is idle
     int32_t* h_iter = nullptr;                // pinned {iter, stride} staging
+    int32_t prof_pairs = 0;                   // timed gathers of the batch in flight
+    std::map<int64_t, int32_t> exec_pairs;    // per captured graph
 };
 
 struct LegionPipeline {
@@ -43,6 +46,9 @@ struct LegionPipeline {
     std::vector<Lane> lanes;
     bool use_graph;
     int32_t rr = 0;
+    bool profiling = false;
+    std::map<int32_t, double> prof_ms;        // op id -> summed elapsed ms of its gather launches
+    std::map<int32_t, int64_t> prof_cnt;
 };
 
 static int32_t set_size_for(FeatureStorage* f, int32_t dev_id, int32_t mode)
@@ -85,11 +91,20 @@ extern "C" LegionPipeline* legion_pipeline_create(LegionGraphStorage* graph, Leg
     return p;
 }
 
-static void lane_wait(Lane& ln)
+static void lane_wait(LegionPipeline* p, Lane& ln)
 {
     if (ln.busy) {
         HIP_CALL(hipEventSynchronize(ln.done));
         ln.busy = false;
+        if (p->profiling) {                         // collect the HIP-event times of the finished batch
+            for (int32_t i = 0; i < ln.prof_pairs; i++) {
+                float ms = 0.f;
+                HIP_CALL(hipEventElapsedTime(&ms, ln.pool->prof_events[2 * i], ln.pool->prof_events[2 * i + 1]));
+                p->prof_ms[ln.pool->prof_op[i]] += ms;
+                p->prof_cnt[ln.pool->prof_op[i]] += 1;
+            }
+        }
+        ln.prof_pairs = 0;
     }
 }
 
@@ -102,21 +117,23 @@ extern "C" int32_t legion_pipeline_submit(LegionPipeline* p, int32_t counter, in
     const int32_t li = p->rr;
     p->rr = (p->rr + 1) % p->lanes_n;
     Lane& ln = p->lanes[li];
-    lane_wait(ln);
+    lane_wait(p, ln);
     ln.pool->SetCurrentMode(mode);
+    ln.pool->prof_used = 0;
     ln.pool->SetIter(counter);
     const int32_t total_cap = set_size_for(p->feature, p->dev_id, mode);
     const bool full = (int64_t)p->batch_size * (counter + 1) < total_cap;     // operator_impl.cu:159
     LegionGraphStorage* g = reinterpret_cast<LegionGraphStorage*>(p->graph);
     LegionFeatureStorage* f = reinterpret_cast<LegionFeatureStorage*>(p->feature);
     LegionMemoryPool* mp = reinterpret_cast<LegionMemoryPool*>(ln.pool);
-    if (!p->use_graph || !full) {
+    if (!p->use_graph || !full || p->profiling) {   // HIP cannot time events recorded by graph nodes
         int32_t* saved = ln.pool->iter_state;
         ln.pool->iter_state = nullptr;                  // eager: iteration by value
         legion_enqueue_batch(ln.stream, g, f, p->cache_handle, mp, p->batch_size, counter, p->dev_id, mode, false,
                              p->fanout.data(), p->hop_num);
         ln.pool->iter_state = saved;
         ln.next_iter = -1;
+        ln.prof_pairs = ln.pool->prof_used;
     } else {
         if (ln.next_iter != counter) {                  // (re)position the device-resident iteration
             ln.h_iter[0] = counter;
@@ -136,7 +153,9 @@ extern "C" int32_t legion_pipeline_submit(LegionPipeline* p, int32_t counter, in
             HIP_CALL(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
             HIP_CALL(hipGraphDestroy(graph));
             it = ln.exec.emplace(key, exec).first;
+            ln.exec_pairs[key] = ln.pool->prof_used;   // event-record nodes captured with the gathers
         }
+        ln.prof_pairs = ln.exec_pairs[key];
         HIP_CALL(hipGraphLaunch(it->second, ln.stream));
         ln.next_iter = counter + p->lanes_n;            // what the last kernel leaves in iter_state[0]
     }
@@ -149,8 +168,8 @@ extern "C" void legion_pipeline_wait(LegionPipeline* p, int32_t lane)
 {
     if (!p) return;
     SetGPUDevice(p->dev_id);
-    if (lane >= 0) { lane_wait(p->lanes[lane % p->lanes_n]); return; }
-    for (Lane& ln : p->lanes) lane_wait(ln);
+    if (lane >= 0) { lane_wait(p, p->lanes[lane % p->lanes_n]); return; }
+    for (Lane& ln : p->lanes) lane_wait(p, ln);
 }
 
 extern "C" LegionMemoryPool* legion_pipeline_pool(LegionPipeline* p, int32_t lane)
@@ -168,7 +187,7 @@ extern "C" void legion_pipeline_destroy(LegionPipeline* p)
     if (!p) return;
     SetGPUDevice(p->dev_id);
     for (Lane& ln : p->lanes) {
-        lane_wait(ln);
+        lane_wait(p, ln);
         HIP_CALL(hipStreamSynchronize(ln.stream));
         for (auto& kv : ln.exec) HIP_CALL(hipGraphExecDestroy(kv.second));
         d_free_space(ln.pool->iter_state);
@@ -179,4 +198,48 @@ extern "C" void legion_pipeline_destroy(LegionPipeline* p)
         HIP_CALL(hipStreamDestroy(ln.stream));
     }
     delete p;
+}
+
+// Gather timing over the live pipeline: HIP events recorded on each lane's stream right before and
+// after every gather launch.  hipEventElapsedTime rejects events recorded by graph nodes
+// ('invalid resource handle' on ROCm 7.2), so batches submitted while profiling is on are launched
+// eagerly (same kernels, same lanes).  read() returns, per gather op id, the summed elapsed ms and
+// launch count of all batches that have been waited for since begin().
+extern "C" void legion_pipeline_profile_begin(LegionPipeline* p)
+{
+    if (!p) return;
+    SetGPUDevice(p->dev_id);
+    for (Lane& ln : p->lanes) {
+        lane_wait(p, ln);
+        HIP_CALL(hipStreamSynchronize(ln.stream));
+        legion_pool_profile_begin(reinterpret_cast<LegionMemoryPool*>(ln.pool), p->hop_num + 1);
+    }
+    p->prof_ms.clear();
+    p->prof_cnt.clear();
+    p->profiling = true;
+}
+
+extern "C" void legion_pipeline_profile_end(LegionPipeline* p)
+{
+    if (!p) return;
+    for (Lane& ln : p->lanes) {
+        lane_wait(p, ln);
+        ln.pool->prof_on = false;
+    }
+    p->profiling = false;
+}
+
+extern "C" int32_t legion_pipeline_profile_read(LegionPipeline* p, int32_t* op_ids, double* ms_sums, int64_t* counts,
+                                                int32_t cap)
+{
+    if (!p) return 0;
+    int32_t n = 0;
+    for (auto& kv : p->prof_ms) {
+        if (n >= cap) break;
+        op_ids[n] = kv.first;
+        ms_sums[n] = kv.second;
+        counts[n] = p->prof_cnt[kv.first];
+        n++;
+    }
+    return n;
 }

@@ -204,6 +204,20 @@ class Pipeline:
     def wait(self, lane=-1):
         self._lib.legion_pipeline_wait(self.handle, int(lane))
 
+    def profile_begin(self):
+        self._lib.legion_pipeline_profile_begin(self.handle)
+
+    def profile_end(self):
+        self._lib.legion_pipeline_profile_end(self.handle)
+
+    def profile_read(self):
+        """{gather op id: (summed ms, launches)} for every batch waited for since profile_begin()."""
+        ops = (ctypes.c_int32 * 16)()
+        ms = (ctypes.c_double * 16)()
+        cnt = (ctypes.c_int64 * 16)()
+        n = self._lib.legion_pipeline_profile_read(self.handle, ops, ms, cnt, 16)
+        return {int(ops[i]): (float(ms[i]), int(cnt[i])) for i in range(n)}
+
     def close(self):
         if self.handle:
             self._lib.legion_pipeline_destroy(self.handle)

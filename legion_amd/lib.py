@@ -69,6 +69,10 @@ SIGNATURES = {
     "legion_pipeline_pool": (c_p, [c_p, c_i32]),
     "legion_pipeline_stream": (c_p, [c_p, c_i32]),
     "legion_pipeline_destroy": (None, [c_p]),
+    "legion_pipeline_profile_begin": (None, [c_p]),
+    "legion_pipeline_profile_end": (None, [c_p]),
+    "legion_pipeline_profile_read": (c_i32, [c_p, P_I32, ctypes.POINTER(ctypes.c_double),
+                                             ctypes.POINTER(ctypes.c_int64), c_i32]),
     # 4. kernel-level
     "legion_gather_rows": (None, [c_p, c_p, c_p, c_p, c_i32, c_i32, c_i32, c_p, c_p, c_p, c_p, c_i32]),
     "legion_draw_batch": (None, [c_p, c_p, c_p, c_p, c_i32]),
