@@ -63,8 +63,13 @@ def build_lib(force=False, verbose=True):
     return LIB
 
 
-def build_trainer(verbose=True):
+def build_trainer(verbose=True, force=False):
     tdir = os.path.join(HERE, "trainer")
+    import glob
+    built = glob.glob(os.path.join(tdir, "ipc_service*.so"))
+    srcs = [os.path.join(tdir, "ipc_service.cpp"), os.path.join(tdir, "setup.py")]
+    if built and not force and not _newer(built[0], srcs):
+        return built[0]
     env = dict(os.environ, PYTORCH_ROCM_ARCH=ARCH)
     cmd = [sys.executable, "setup.py", "build_ext", "--inplace"]
     if verbose:

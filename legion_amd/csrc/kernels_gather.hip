@@ -30,7 +30,7 @@ __global__ __launch_bounds__(LG_GATHER_THREADS) void gather_kernel(
     const int32_t* __restrict__ node_map, int32_t node_capacity, int32_t D, int32_t total_num_nodes,
     const int32_t* __restrict__ sampled_ids, int32_t* __restrict__ cache_index_out,
     const int32_t* __restrict__ range, int32_t* __restrict__ range_copy, float* __restrict__ dst,
-    int32_t max_rows)
+    int32_t max_rows, int32_t dst_rows)
 {
     constexpr int VEC = sizeof(VecT) / sizeof(float);
     __shared__ const float* s_ptr[LG_GATHER_ROWS];
@@ -42,6 +42,8 @@ __global__ __launch_bounds__(LG_GATHER_THREADS) void gather_kernel(
         range_copy[1] = rows;
     }
     if (rows > max_rows) rows = max_rows;
+    if (rows > dst_rows - off) rows = dst_rows - off;   // never write past the feature buffer (the
+                                                        // reference sizes it 1.2 x PreSC max and would overrun)
     const int32_t ntiles = (rows + LG_GATHER_ROWS - 1) / LG_GATHER_ROWS;
     const int32_t tid = threadIdx.x;
     const int32_t C = D / VEC;                         // chunks per row
@@ -110,7 +112,7 @@ __global__ __launch_bounds__(LG_GATHER_THREADS) void gather_kernel(
 void launch_gather(hipStream_t s, const float* full_table, const float* const* cache_tables,
                    const int32_t* node_map, int32_t node_capacity, int32_t D, int32_t total_num_nodes,
                    const int32_t* sampled_ids, int32_t* cache_index_out, const int32_t* range,
-                   int32_t* range_copy, float* dst, int32_t max_rows)
+                   int32_t* range_copy, float* dst, int32_t max_rows, int32_t dst_rows)
 {
     if (D <= 0 || max_rows <= 0) return;                // :256 float_feature_len > 0
     if (node_capacity < 1) node_capacity = 1;
@@ -119,13 +121,13 @@ void launch_gather(hipStream_t s, const float* full_table, const float* const* c
     typedef float v2 __attribute__((ext_vector_type(2)));
     if (D % 4 == 0)
         gather_kernel<v4><<<grid, LG_GATHER_THREADS, 0, s>>>(full_table, cache_tables, node_map,
-            node_capacity, D, total_num_nodes, sampled_ids, cache_index_out, range, range_copy, dst, max_rows);
+            node_capacity, D, total_num_nodes, sampled_ids, cache_index_out, range, range_copy, dst, max_rows, dst_rows);
     else if (D % 2 == 0)
         gather_kernel<v2><<<grid, LG_GATHER_THREADS, 0, s>>>(full_table, cache_tables, node_map,
-            node_capacity, D, total_num_nodes, sampled_ids, cache_index_out, range, range_copy, dst, max_rows);
+            node_capacity, D, total_num_nodes, sampled_ids, cache_index_out, range, range_copy, dst, max_rows, dst_rows);
     else
         gather_kernel<float><<<grid, LG_GATHER_THREADS, 0, s>>>(full_table, cache_tables, node_map,
-            node_capacity, D, total_num_nodes, sampled_ids, cache_index_out, range, range_copy, dst, max_rows);
+            node_capacity, D, total_num_nodes, sampled_ids, cache_index_out, range, range_copy, dst, max_rows, dst_rows);
     hipCheckError();
 }
 

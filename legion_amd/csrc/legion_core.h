@@ -272,7 +272,7 @@ public:
     unsigned long long int* GetEdgeAccessedMap(int32_t dev_id);
     void FeatCacheLookup(int32_t* sampled_ids, int32_t* cache_index, int32_t* node_counter,
                          float* dst_float_buffer, int32_t op_id, int32_t dev_id, hipStream_t strm_hdl,
-                         int32_t max_rows);
+                         int32_t max_rows, int32_t dst_rows);
 
     // new / exposed for the C API and the fused kernels
     void SetCapacity(int32_t node_capacity, int32_t edge_capacity);
@@ -439,7 +439,8 @@ void launch_random_sample(hipStream_t s, const SampleArgs& a);
 void launch_gather(hipStream_t s, const float* full_table, const float* const* cache_tables,
                    const int32_t* node_map, int32_t node_capacity, int32_t D, int32_t total_num_nodes,
                    const int32_t* sampled_ids, int32_t* cache_index_out, const int32_t* range,
-                   int32_t* range_copy /* node_counter+2 or null */, float* dst, int32_t max_rows);
+                   int32_t* range_copy /* node_counter+2 or null */, float* dst, int32_t max_rows,
+                   int32_t dst_rows /* rows the destination buffer holds */);
 
 void launch_clear_pos_map(hipStream_t s, int32_t* position_map, const int32_t* sampled_ids,
                           const int32_t* node_counter, int32_t* iter_state);

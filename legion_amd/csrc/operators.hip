@@ -145,6 +145,7 @@ extern "C" void FeatureCacheLookup(legion_stream_t strm_hdl, LegionUnifiedCache*
     }
     int64_t max_rows = memorypool->feature_rows;
     if (max_rows > memorypool->num_ids) max_rows = memorypool->num_ids;
+    const int32_t dst_rows = (int32_t)max_rows;
     const size_t hop = (size_t)(op_id / INTRABATCH_CON);          // grid bound: new nodes of op 3h <= B f1..fh
     if (hop < memorypool->max_new.size() && memorypool->max_new[hop] < max_rows) max_rows = memorypool->max_new[hop];
     hipStream_t s = static_cast<hipStream_t>(strm_hdl);
@@ -152,7 +153,7 @@ extern "C" void FeatureCacheLookup(legion_stream_t strm_hdl, LegionUnifiedCache*
     if (prof) HIP_CALL(hipEventRecord(memorypool->prof_events[2 * memorypool->prof_used], s));
     cache->FeatCacheLookup(memorypool->GetSampledIds(), memorypool->GetCacheSearchBuffer(),
                            memorypool->GetNodeCounter(), memorypool->GetFloatFeatures(), op_id, dev_id,
-                           s, (int32_t)max_rows);
+                           s, (int32_t)max_rows, dst_rows);
     if (prof) {
         HIP_CALL(hipEventRecord(memorypool->prof_events[2 * memorypool->prof_used + 1], s));
         memorypool->prof_op[memorypool->prof_used] = op_id;
@@ -273,7 +274,7 @@ extern "C" void legion_gather_rows(legion_stream_t stream, const float* full_tab
 {
     lg::launch_gather(static_cast<hipStream_t>(stream), full_table, cache_tables, node_map, node_capacity,
                       float_feature_len, total_num_nodes, sampled_ids, cache_index_out, range_devptr, nullptr,
-                      dst, max_rows);
+                      dst, max_rows, 0x7FFFFFFF);
 }
 
 extern "C" void legion_draw_batch(legion_stream_t stream, const int32_t* idx, const int32_t* deg, int32_t* out,

@@ -19,6 +19,7 @@
 #include <sys/stat.h>
 #include <unistd.h>
 
+#include <algorithm>
 #include <chrono>
 #include <cstring>
 #include <fstream>
@@ -276,7 +277,12 @@ public:
         streams_.resize(INTRABATCH_CON);
         for (int i = 0; i < INTRABATCH_CON; i++) HIP_CALL(hipStreamCreate(&streams_[i]));
 
-        const int batch_size = env->GetRawBatchsize();
+        // The reference sizes every buffer from the raw (training) batch size (server.cu:181-199) although
+        // validation/test batches can be larger (ceil(n / ceil(max n / 512)), ipc_service.cu:91-115) and
+        // then overrun `labels`; here the pool is sized for the largest batch of any mode.
+        int batch_size = env->GetRawBatchsize();
+        for (int mode = TRAINMODE; mode <= TESTMODE; mode++)
+            batch_size = std::max(batch_size, (int)env->GetCurrentBatchsize(local_dev_id_, mode));
         const int hop_num = (int)params->fanout.size();
         std::vector<int32_t> fanout(params->fanout.begin(), params->fanout.end());
 
@@ -339,6 +345,12 @@ public:
     {
         UnifiedCache* cache = (UnifiedCache*)(params->cache);
         int32_t num_ids = int32_t((cache->MaxIdNum(local_dev_id_)) * 1.2);
+        // MaxIdNum was measured on training batches; validation/test batches can be larger than the
+        // raw batch (see Initialize): scale the reference's 1.2x rule by that ratio, never beyond num_ids
+        IPCEnv* env_ = (IPCEnv*)(params->env);
+        int64_t scaled = (int64_t)num_ids * ((memorypool_->batch_size + env_->GetRawBatchsize() - 1) / env_->GetRawBatchsize());
+        if (scaled > memorypool_->num_ids) scaled = memorypool_->num_ids;
+        num_ids = (int32_t)scaled;
         if (num_ids < 1) num_ids = 1;
         IPCEnv* env = (IPCEnv*)(params->env);
         env->InitializeFeaturesBuffer(0, num_ids, float_feature_len_, local_dev_id_, interbatch_concurrency_);

@@ -1,0 +1,214 @@
+// ipc_service.cpp -- trainer end of the server <-> trainer boundary: the PyTorch extension module
+// `ipc_service` that Legion's training scripts import (training_backend/legion_graphsage.py:72-128).
+//
+// Reference: training_backend/ipc_service.cpp:93-100 (module + function names),
+// training_backend/ipc_cuda_kernel.cu:35-235 (GPUIPCEnv, cuda_get_next),
+// training_backend/helper_multiprocess.cpp (sharedMemoryCreate).  Same module name, same six
+// functions, same return shapes/dtypes, same shm slab / semaphore names / IPC-handle slot order
+// (0 ids, 1 features, 2 labels, 3 agg_src, 4 agg_dst, 5 node_counter, 6 edge_counter).
+// HIP runtime calls replace the CUDA ones (hipIpcOpenMemHandle, hipMemcpy); there is no device
+// code in this module.  LEGION_IPC_NAMESPACE (optional) must match the server's.
+#include <fcntl.h>
+#include <semaphore.h>
+#include <sys/mman.h>
+#include <unistd.h>
+
+#include <cerrno>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <iostream>
+#include <string>
+#include <vector>
+
+#include <hip/hip_runtime_api.h>
+#include <torch/extension.h>
+
+#define INTRABATCH_CON 3
+#define INTERBATCH_CON 2
+#define MAX_DEVICE 8
+#define MEMORY_USAGE 7
+
+#define hipCheckError()                                                                       \
+    {                                                                                         \
+        hipError_t e_ = hipGetLastError();                                                    \
+        if (e_ != hipSuccess) {                                                               \
+            printf("HIP failure %s:%d: '%s'\n", __FILE__, __LINE__, hipGetErrorString(e_));   \
+            exit(EXIT_FAILURE);                                                               \
+        }                                                                                     \
+    }
+
+typedef struct shmStruct_st {
+    int32_t steps[3];
+    hipIpcMemHandle_t memHandle[MAX_DEVICE][INTERBATCH_CON][MEMORY_USAGE];
+} shmStruct;
+static_assert(sizeof(hipIpcMemHandle_t) == 64, "IPC handle size is part of the wire format");
+
+static std::string ipc_suffix()
+{
+    const char* ns = getenv("LEGION_IPC_NAMESPACE");
+    return ns ? std::string(ns) : std::string();
+}
+
+class GPUIPCEnv {
+public:
+    int Initialize()
+    {
+        int central_device = -1;
+        hipGetDevice(&central_device);
+        hipCheckError();
+        const std::string shm_name = std::string("simpleIPCshm") + ipc_suffix();
+        int fd = shm_open(shm_name.c_str(), O_RDWR | O_CREAT, 0777);
+        if (fd < 0 || ftruncate(fd, sizeof(shmStruct)) != 0) {
+            printf("Failed to create shared memory slab\n");
+            exit(EXIT_FAILURE);
+        }
+        void* addr = mmap(0, sizeof(shmStruct), PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+        if (addr == MAP_FAILED) {
+            printf("Failed to create shared memory slab\n");
+            exit(EXIT_FAILURE);
+        }
+        volatile shmStruct* shm = (volatile shmStruct*)addr;
+        train_step_ = shm->steps[0];
+        valid_step_ = shm->steps[1];
+        test_step_ = shm->steps[2];
+        std::vector<void*>* slots[MEMORY_USAGE] = {&ids_, &float_features_, &labels_, &agg_src_, &agg_dst_,
+                                                   &node_counter_, &edge_counter_};
+        for (auto* s : slots) s->assign(INTERBATCH_CON, nullptr);
+        for (int i = 0; i < INTERBATCH_CON; i++) {
+            for (int k = 0; k < MEMORY_USAGE; k++) {
+                hipIpcMemHandle_t h = *(hipIpcMemHandle_t*)&shm->memHandle[central_device][i][k];
+                hipError_t e = hipIpcOpenMemHandle(&(*slots[k])[i], h, hipIpcMemLazyEnablePeerAccess);
+                if (e != hipSuccess) {
+                    printf("HIP failure %s:%d: '%s' (slot %d pipe %d)\n", __FILE__, __LINE__, hipGetErrorString(e), k, i);
+                    exit(EXIT_FAILURE);
+                }
+            }
+        }
+        std::cout << "HIP: " << central_device << " IPC shared memory opened\n";
+        semr_.resize(INTERBATCH_CON);
+        semw_.resize(INTERBATCH_CON);
+        const std::string sfx = ipc_suffix();
+        for (int i = 0; i < INTERBATCH_CON; i++) {
+            const std::string ssri = "sem_r_" + std::to_string(central_device) + "_" + std::to_string(i) + sfx;
+            const std::string sswi = "sem_w_" + std::to_string(central_device) + "_" + std::to_string(i) + sfx;
+            semr_[i] = sem_open(ssri.c_str(), O_CREAT | O_RDWR, 0666, 0);
+            if (semr_[i] == SEM_FAILED) {
+                printf("errno = %d\n", errno);
+                return -1;
+            }
+            semw_[i] = sem_open(sswi.c_str(), O_CREAT | O_RDWR, 0666, 0);
+            if (semw_[i] == SEM_FAILED) {
+                printf("errno = %d\n", errno);
+                return -1;
+            }
+            sem_post(semr_[i]);   // both pipe slots start free (ipc_cuda_kernel.cu:91)
+        }
+        current_pipe_ = 0;
+        device_ = central_device;
+        munmap(addr, sizeof(shmStruct));
+        close(fd);
+        return central_device;
+    }
+
+    void Wait() { sem_wait(semw_[current_pipe_]); }
+    void Post()
+    {
+        sem_post(semr_[current_pipe_]);
+        current_pipe_ = (current_pipe_ + 1) % INTERBATCH_CON;
+    }
+    int32_t* GetIds() { return (int32_t*)ids_[current_pipe_]; }
+    float* GetFloatFeatures() { return (float*)float_features_[current_pipe_]; }
+    int32_t* GetLabels() { return (int32_t*)labels_[current_pipe_]; }
+    int32_t* GetAggSrc() { return (int32_t*)agg_src_[current_pipe_]; }
+    int32_t* GetAggDst() { return (int32_t*)agg_dst_[current_pipe_]; }
+    int32_t* GetNodeCounter() { return (int32_t*)node_counter_[current_pipe_]; }
+    int32_t* GetEdgeCounter() { return (int32_t*)edge_counter_[current_pipe_]; }
+    int32_t GetTrainStep() { return train_step_; }
+    int32_t GetValidStep() { return valid_step_; }
+    int32_t GetTestStep() { return test_step_; }
+    int Device() const { return device_; }
+
+    void Finalize()
+    {
+        std::vector<void*>* slots[MEMORY_USAGE] = {&ids_, &float_features_, &labels_, &agg_src_, &agg_dst_,
+                                                   &node_counter_, &edge_counter_};
+        for (int i = 0; i < INTERBATCH_CON; i++) {
+            for (auto* s : slots) hipIpcCloseMemHandle((*s)[i]);
+            if (sem_close(semw_[i]) == -1) std::cout << "close sem " << i << " failed\n";
+            sem_close(semr_[i]);
+        }
+    }
+
+private:
+    std::vector<void*> ids_, float_features_, labels_, agg_src_, agg_dst_, node_counter_, edge_counter_;
+    std::vector<sem_t*> semw_, semr_;
+    int32_t train_step_ = 0, valid_step_ = 0, test_step_ = 0;
+    int current_pipe_ = 0;
+    int device_ = 0;
+};
+
+static GPUIPCEnv* env = nullptr;
+static int32_t h_node_counter[16];
+static int32_t h_edge_counter[16];
+
+void InitializeIPC()
+{
+    env = new GPUIPCEnv();
+    env->Initialize();
+}
+
+void FinalizeIPC() { env->Finalize(); }
+
+// training_backend/ipc_cuda_kernel.cu:177-235 + training_backend/ipc_service.cpp:44-59
+std::vector<torch::Tensor> get_next(int feature_dim)
+{
+    env->Wait();
+    hipMemcpy(h_node_counter, env->GetNodeCounter(), 16 * sizeof(int32_t), hipMemcpyDeviceToHost);
+    hipMemcpy(h_edge_counter, env->GetEdgeCounter(), 16 * sizeof(int32_t), hipMemcpyDeviceToHost);
+    hipCheckError();
+    const int hop_num = h_node_counter[INTRABATCH_CON * 3 - 1];
+    const auto dev = torch::Device(torch::kCUDA, env->Device());
+    const auto i32 = torch::TensorOptions().dtype(torch::kI32).device(dev);
+    const auto f32 = torch::TensorOptions().dtype(torch::kF32).device(dev);
+    std::vector<torch::Tensor> ret;
+    const long long n_total = h_node_counter[INTRABATCH_CON * 3 + hop_num];
+    ret.push_back(torch::from_blob(env->GetIds(), {n_total}, i32));
+    ret.push_back(torch::from_blob(env->GetFloatFeatures(), {n_total, (long long)feature_dim}, f32));
+    ret.push_back(torch::from_blob(env->GetLabels(), {(long long)h_node_counter[INTRABATCH_CON * 3]}, i32));
+    for (int i = hop_num; i > 0; i--) {   // cumulative edge prefixes, outermost block first
+        const long long n_edges = h_edge_counter[INTRABATCH_CON * 3 + i];
+        ret.push_back(torch::from_blob(env->GetAggSrc(), {n_edges}, i32));
+        ret.push_back(torch::from_blob(env->GetAggDst(), {n_edges}, i32));
+    }
+    return ret;
+}
+
+// training_backend/ipc_service.cpp:61-79
+std::vector<int> get_block_size()
+{
+    std::vector<int> ret;
+    const int hop_num = h_node_counter[INTRABATCH_CON * 3 - 1];
+    for (int i = hop_num; i > 0; i--) {
+        ret.push_back(h_node_counter[INTRABATCH_CON * 3 + i]);
+        ret.push_back(h_node_counter[INTRABATCH_CON * 3 + i - 1]);
+    }
+    return ret;
+}
+
+std::vector<int32_t> get_steps()
+{
+    return {env->GetTrainStep(), env->GetValidStep(), env->GetTestStep()};
+}
+
+void Synchronize() { env->Post(); }
+
+PYBIND11_MODULE(TORCH_EXTENSION_NAME, m)
+{
+    m.def("get_next", &get_next, "dataset get next (HIP)");
+    m.def("get_block_size", &get_block_size, "get dgl block size (HIP)");
+    m.def("get_steps", &get_steps, "get steps (HIP)");
+    m.def("initialize", &InitializeIPC, "InitializeIPC (HIP)");
+    m.def("finalize", &FinalizeIPC, "FinalizeIPC (HIP)");
+    m.def("synchronize", &Synchronize, "synchronize (HIP)");
+}

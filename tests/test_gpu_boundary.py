@@ -1,0 +1,134 @@
+"""The drop-in boundary end to end: the `sampling_server` binary (meta_config + argv, dataset files in
+the reference's formats, shm slab + semaphores + IPC handles) serving a fake trainer that walks the
+protocol of training_backend/legion_graphsage.py:72-128 through the `ipc_service` extension.  Every
+batch the trainer sees is compared with the oracle (ids, features, labels, COO blocks, block sizes)."""
+import os
+import subprocess
+import sys
+import time
+
+import numpy as np
+import pytest
+
+from legion_amd import synth
+from oracle import ffi
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def write_dataset(path, wl_indptr, wl_col, feats, labels, train, valid, test):
+    os.makedirs(path, exist_ok=True)
+    wl_indptr.astype(np.int64).tofile(os.path.join(path, "edge_src"))
+    wl_col.astype(np.int32).tofile(os.path.join(path, "edge_dst"))
+    feats.astype(np.float32).tofile(os.path.join(path, "features"))
+    labels.astype(np.int32).tofile(os.path.join(path, "labels"))
+    train.astype(np.int32).tofile(os.path.join(path, "trainingset"))
+    valid.astype(np.int32).tofile(os.path.join(path, "validationset"))
+    test.astype(np.int32).tofile(os.path.join(path, "testingset"))
+
+
+def test_server_binary_serves_fake_trainer(hip, tmp_path):
+    import torch
+    sys.path.insert(0, os.path.join(ROOT, "legion_amd", "trainer"))
+    import ipc_service
+
+    scale, D, B, fanout, epoch, cache_memory = 11, 24, 48, [5, 3], 2, 60_000
+    indptr, col = synth.rmat_csr_numpy(scale, 8, 20231)
+    N = indptr.size - 1
+    feats = synth.features_numpy(0, N, D, 7)
+    labels = (np.arange(N) % 47).astype(np.int32)
+    perm = np.random.RandomState(3).permutation(N).astype(np.int32)
+    train, valid, test = perm[:500], perm[500:590], perm[590:640]
+    ds = str(tmp_path / "ds") + "/"
+    write_dataset(ds, indptr, col, feats, labels, train, valid, test)
+    work = tmp_path / "run"
+    work.mkdir()
+    (work / "meta_config").write_text("{} {} {} {} {} {} {} {} {} {}".format(
+        ds, B, N, col.size, D, train.size, valid.size, test.size, cache_memory, epoch))
+    ns = f"_t{os.getpid()}"
+    env = dict(os.environ, LEGION_IPC_NAMESPACE=ns)
+    os.environ["LEGION_IPC_NAMESPACE"] = ns
+    log = open(work / "server.log", "w")
+    server = subprocess.Popen([os.path.join(ROOT, "legion_amd", "bin", "sampling_server"), "1", "0"] +
+                              [str(f) for f in fanout], cwd=work, env=env, stdout=log, stderr=subprocess.STDOUT)
+    try:
+        deadline = time.time() + 120
+        while "System is ready for serving" not in open(work / "server.log").read():
+            assert server.poll() is None, open(work / "server.log").read()
+            assert time.time() < deadline, "server did not become ready"
+            time.sleep(0.1)
+
+        # ---- oracle replay of the whole server life: PreSC -> cache -> schedule ------------------
+        g = ffi.OracleGraph(1, indptr, col)
+        st = ffi.Steps()
+        L = ffi.load()
+        import ctypes
+        one = lambda v: (ctypes.c_int32 * 1)(v)
+        L.lgo_coordinate(ctypes.byref(st), 1, one(train.size), one(valid.size), one(test.size), B, epoch)
+        node_acc, edge_acc = np.zeros(N, dtype=np.uint64), np.zeros(N, dtype=np.uint64)
+        pool = ffi.OraclePool(N, B, fanout, ffi.num_ids_for(B, fanout), D)
+        max_ids = 0
+        for it in range(st.train_step):
+            pool.run_batch(g, None, None, train, labels[train], B, it, 0, True, node_acc, edge_acc)
+            max_ids = max(max_ids, int(pool.read_batch()["node_counter"][7]))
+        cache = ffi.OracleCache(N, D, 1, 0)
+        cache.candidate_selection([node_acc], [edge_acc])
+        cache.cost_model(cache_memory, indptr, (0, 0), [max_ids], st.train_step)
+        cache.fill_up(feats, indptr, col)
+        g.attach_cache(cache)
+        sets = {0: train, 1: valid, 2: test}
+
+        # ---- the trainer's side of the protocol ---------------------------------------------------
+        torch.cuda.set_device(0)
+        ipc_service.initialize()
+        assert ipc_service.get_steps() == [st.train_step, st.valid_step, st.test_step]
+        total = L.lgo_max_step(ctypes.byref(st))
+        assert total == (st.train_step + st.valid_step) * epoch + st.test_step
+        H = len(fanout)
+        for gb in range(total):
+            mode = L.lgo_current_mode(ctypes.byref(st), gb)
+            it = L.lgo_local_batch_id(ctypes.byref(st), gb)
+            bs = L.lgo_current_batchsize(ctypes.byref(st), 0, mode)
+            out = ipc_service.get_next(D)
+            sizes = ipc_service.get_block_size()
+            pool.run_batch(g, cache, feats, sets[mode], labels[sets[mode]], bs, it, mode, False)
+            want = pool.read_batch()
+            nc, ec = want["node_counter"], want["edge_counter"]
+            assert len(out) == 3 + 2 * H
+            ids, fts, lab = out[0], out[1], out[2]
+            assert ids.dtype == torch.int32 and fts.dtype == torch.float32 and lab.dtype == torch.int32
+            assert ids.is_cuda and tuple(fts.shape) == (int(nc[9 + H]), D)
+            assert np.array_equal(ids.cpu().numpy(), want["sampled_ids"]), f"batch {gb}"
+            assert np.array_equal(lab.cpu().numpy(), want["labels"])
+            got_f = fts.cpu().numpy()
+            if not np.array_equal(got_f.view(np.uint32), want["float_features"].view(np.uint32)):
+                bad = np.nonzero((got_f.view(np.uint32) != want["float_features"].view(np.uint32)).any(axis=1))[0]
+                src_rows = [int(np.nonzero((feats.view(np.uint32) == got_f[r].view(np.uint32)).all(axis=1))[0][:1].sum()) for r in bad[:8]]
+                raise AssertionError(f"batch {gb} mode {mode}: rows {bad[:20]} of {got_f.shape[0]} differ; ids there "
+                                     f"{want['sampled_ids'][bad[:8]]}, rows actually hold features of {src_rows}; "
+                                     f"node_map of those ids {cache.arr('node_map', np.int32)[want['sampled_ids'][bad[:8]]]}; "
+                                     f"cap {cache.node_capacity} nc {nc[:12]}")
+            for k, h in enumerate(range(H, 0, -1)):      # cumulative prefixes, outermost block first
+                n_e = int(ec[9 + h])
+                assert np.array_equal(out[3 + 2 * k].cpu().numpy(), want["agg_src_off"][:n_e])
+                assert np.array_equal(out[4 + 2 * k].cpu().numpy(), want["agg_dst_off"][:n_e])
+            exp_sizes = []
+            for h in range(H, 0, -1):
+                exp_sizes += [int(nc[9 + h]), int(nc[9 + h - 1])]
+            assert list(sizes) == exp_sizes
+            del out, ids, fts, lab
+            torch.cuda.synchronize()
+            ipc_service.synchronize()
+        ipc_service.finalize()
+        server.wait(timeout=60)
+        assert server.returncode == 0
+        text = open(work / "server.log").read()
+        assert "Server Stopped" in text and "Train Steps: %d" % st.train_step in text
+    finally:
+        if server.poll() is None:
+            server.kill()
+        log.close()
+        for name in os.listdir("/dev/shm"):
+            if name.endswith(ns):
+                os.unlink(os.path.join("/dev/shm", name))
