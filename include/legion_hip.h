@@ -135,6 +135,15 @@ int32_t legion_cache_max_id_num(const LegionUnifiedCache* c, int32_t dev_id);
 /* which: 0 QF 1 QT (int32[N]) 2 AF 3 AT (uint64[N]) 4 node_access_time 5 edge_access_time
  *        (uint64[N], per device) 6 node_map 8 edge_offset_map (int32[N]) 7 edge_index_map (int8[N]) */
 void* legion_cache_array(LegionUnifiedCache* c, int32_t dev_id, int32_t which);
+/* UnifiedCache::FindTopo / FindFeat (SS/cache/cache.cu:335-357) on device arrays.  The sampler and
+ * the gather resolve rows themselves (row headers, fused lookup); these remain for callers that
+ * want the reference's explicit outputs: owner device / row offset or -2, cache slot or -2. */
+void legion_cache_find_topo(LegionUnifiedCache* c, int32_t dev_id, legion_stream_t stream,
+                            const int32_t* input_ids, int32_t batch_size, char* partition_index,
+                            int32_t* partition_offset);
+void legion_cache_find_feat(LegionUnifiedCache* c, int32_t dev_id, legion_stream_t stream,
+                            const int32_t* sampled_ids, int32_t* cache_offset, const int32_t* node_counter,
+                            int32_t op_id);
 
 /* =====================================================================================
  * 3. Runner / Server / IPC -- SS/engine/server.h:5-33, SS/engine/ipc_service.h:6-35,

@@ -538,3 +538,22 @@ extern "C" void* legion_cache_array(LegionUnifiedCache* c, int32_t dev_id, int32
         default: return nullptr;
     }
 }
+
+// UnifiedCache::FindTopo / FindFeat as plain calls (SS/cache/cache.cu:335-357): device arrays in and out
+extern "C" void legion_cache_find_topo(LegionUnifiedCache* c, int32_t dev_id, legion_stream_t stream,
+                                       const int32_t* input_ids, int32_t batch_size, char* partition_index,
+                                       int32_t* partition_offset)
+{
+    UnifiedCache* u = as_cache(c);
+    if (!u) { printf("invalid cache ptr\n"); return; }
+    u->FindTopo(const_cast<int32_t*>(input_ids), partition_index, partition_offset, batch_size, 0, stream, dev_id);
+}
+
+extern "C" void legion_cache_find_feat(LegionUnifiedCache* c, int32_t dev_id, legion_stream_t stream,
+                                       const int32_t* sampled_ids, int32_t* cache_offset,
+                                       const int32_t* node_counter, int32_t op_id)
+{
+    UnifiedCache* u = as_cache(c);
+    if (!u) { printf("invalid cache ptr\n"); return; }
+    u->FindFeat(const_cast<int32_t*>(sampled_ids), cache_offset, const_cast<int32_t*>(node_counter), op_id, stream, dev_id);
+}

@@ -143,8 +143,10 @@ void launch_batch_generate(hipStream_t s, int32_t* batch_ids, int32_t* labels, i
 struct HopGeom {
     const int32_t* frontier;
     int32_t frontier_len;
-    int32_t total;     // slots
-    int32_t ntiles;
+    int32_t frontier_off;   // offset of the frontier inside the per-edge arrays (0 for the seeds)
+    int32_t total;          // slots
+    int32_t ntiles;         // 256-slot tiles (compaction granularity)
+    int32_t nsuper;         // LG_SUPER-slot super tiles (work granularity of one workgroup)
 };
 
 __device__ __forceinline__ HopGeom hop_geometry(const SampleArgs& a)
@@ -153,123 +155,143 @@ __device__ __forceinline__ HopGeom hop_geometry(const SampleArgs& a)
     if (a.op_id == INTRABATCH_CON) {            // operator_impl.cu:201-203
         g.frontier = a.sampled_ids;
         g.frontier_len = a.node_counter[1];
+        g.frontier_off = 0;
     } else {                                    // :204-207
-        g.frontier = a.agg_src_ids + a.edge_counter[0];
+        g.frontier_off = a.edge_counter[0];
+        g.frontier = a.agg_src_ids + g.frontier_off;
         g.frontier_len = a.edge_counter[1];
     }
     int64_t total = (int64_t)(g.frontier_len > 0 ? g.frontier_len : 0) * a.count;
     if (total > a.max_slots) total = a.max_slots;   // never true for a pool sized by server.cu:187-199
     g.total = (int32_t)total;
     g.ntiles = (g.total + LG_TILE - 1) / LG_TILE;
+    g.nsuper = (g.total + LG_SUPER - 1) / LG_SUPER;
     return g;
 }
 
 // ------------------------------------------------------------------------------------------
-// K1: sample.  LDS holds the tile's frontier rows.
+// K1: sample.  A workgroup owns a super tile of 1024 consecutive slots, four per lane (lane l of
+// wave w handles slots idx0 + u*256 + 64w + l, u = 0..3), so every wave-instruction still
+// covers 64 consecutive slots and each lane keeps four independent column loads and atomics in
+// flight.  The super tile's frontier row headers ({start, degree, CSR slot}, 16 B) are staged in
+// LDS: for hop >= 2 they were written next to the edges by the previous hop's scatter (one
+// coalesced 16-byte load per frontier entry), for hop 1 they are looked up in the per-vertex
+// header table here.
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(LG_TILE) void sample_kernel(SampleArgs a)
 {
-    __shared__ int64_t s_start[LG_TILE];
-    __shared__ const int32_t* s_col[LG_TILE];
-    __shared__ int32_t s_deg[LG_TILE];
-    __shared__ int32_t s_src[LG_TILE];
+    __shared__ RowHdr s_hdr[LG_SUPER];
 
     const HopGeom g = hop_geometry(a);
     const int32_t tid = threadIdx.x;
     const int32_t count = a.count;
-    const bool use_topo_cache = (!a.is_presc) && (a.edge_index_map != nullptr);
+    const bool seeds = (a.op_id == INTRABATCH_CON);
+    const RowHdr* fh = a.fh_edge + g.frontier_off;
 
-    for (int32_t tile = blockIdx.x; tile < g.ntiles; tile += gridDim.x) {
-        const int32_t idx0 = tile * LG_TILE;
-        const int32_t last = min(idx0 + LG_TILE - 1, g.total - 1);
+    for (int32_t st = blockIdx.x; st < g.nsuper; st += gridDim.x) {
+        const int32_t idx0 = st * LG_SUPER;
+        const int32_t last = min(idx0 + LG_SUPER - 1, g.total - 1);
         const int32_t j0 = idx0 / count;
-        const int32_t nsrc = last / count - j0 + 1;          // <= LG_TILE
+        const int32_t nsrc = last / count - j0 + 1;          // <= LG_SUPER
 
-        // stage the frontier rows of this tile (FindTopo + row header), one lane per row
+        // the draws do not depend on the frontier: start their table loads first
+        uint32_t x[LG_SLOTS_PER_LANE];
+#pragma unroll
+        for (int u = 0; u < LG_SLOTS_PER_LANE; u++) x[u] = minstd_pow((uint32_t)(idx0 + u * LG_TILE + tid) + 1u);
+
         for (int32_t t = tid; t < nsrc; t += LG_TILE) {
-            const int32_t j = j0 + t;
-            const int32_t src = g.frontier[j];
-            int32_t owner = CACHEMISS_FLAG, off = CACHEMISS_FLAG, deg = 0;
-            int64_t start = 0;
-            const int32_t* col = nullptr;
-            if (src >= 0) {
-                if (use_topo_cache) {
-                    owner = (int32_t)a.edge_index_map[src];
-                    off = a.edge_offset_map[src];
+            RowHdr h;
+            if (seeds) {
+                const int32_t src = g.frontier[j0 + t];
+                if (src >= 0) {
+                    h = a.row_hdr[src];
+                } else {
+                    h.start = 0; h.deg = 0; h.slot = a.partition_count;
                 }
-                const int32_t slot = owner < 0 ? a.partition_count : owner;   // :224-230
-                const int32_t row = owner < 0 ? src : off;
-                const int64_t* ip = a.csr_node_index[slot];
-                start = ip[row];
-                deg = (int32_t)(ip[row + 1] - start);
-                col = a.csr_dst_node_ids[slot];
+            } else {
+                h = fh[j0 + t];
             }
-            if (!a.is_presc) {                 // the FindTopo outputs (hit mask = part_ind >= 0)
-                a.tmp_part_ind[j] = (char)owner;
-                a.tmp_part_off[j] = off;
-            }
-            s_start[t] = start;
-            s_col[t] = col;
-            s_deg[t] = deg;
-            s_src[t] = src;
+            s_hdr[t] = h;
+            if (!a.is_presc)   // FindTopo's hit mask: owner device of the cached row, or -2 (cache.cu:217-225)
+                a.tmp_part_ind[j0 + t] = (char)(h.slot == a.partition_count ? CACHEMISS_FLAG : h.slot);
         }
         __syncthreads();
 
-        const int32_t idx = idx0 + tid;
-        if (idx < g.total) {
-            const int32_t q = idx / count;
-            const int32_t k = idx - q * count;
-            const int32_t t = q - j0;
-            const int32_t deg = s_deg[t];
-            int32_t out = -1;
-            if (k < deg) {                                            // :232-233 (src < 0 has deg 0)
-                const uint32_t x = minstd_pow((uint32_t)idx + 1u);    // discard(idx) + one draw
-                const int32_t pick = draw_from_x(x, deg);             // :235-238
-                const int32_t dst = s_col[t][s_start[t] + (int64_t)pick];   // :239-243
-                if (dst >= 0) {                                       // :244
-                    out = dst;
-                    atomicMin(a.position_map + dst, LG_POS_PENDING + idx);
-                    if (a.edge_access_time) atomicAdd(a.edge_access_time + s_src[t], 1ull);   // :358
+        int32_t dst[LG_SLOTS_PER_LANE];
+#pragma unroll
+        for (int u = 0; u < LG_SLOTS_PER_LANE; u++) {
+            const int32_t idx = idx0 + u * LG_TILE + tid;
+            dst[u] = -1;
+            if (idx < g.total) {
+                const int32_t q = idx / count;
+                const int32_t k = idx - q * count;
+                const RowHdr h = s_hdr[q - j0];
+                if (k < h.deg) {                                           // :232-233 (src < 0 has deg 0)
+                    const int32_t pick = draw_from_x(x[u], h.deg);         // :235-238
+                    dst[u] = a.csr_dst_node_ids[h.slot][h.start + (int64_t)pick];   // :239-243
                 }
             }
-            a.slot_dst[idx] = out;
+        }
+#pragma unroll
+        for (int u = 0; u < LG_SLOTS_PER_LANE; u++) {
+            const int32_t idx = idx0 + u * LG_TILE + tid;
+            if (idx < g.total) {
+                if (dst[u] >= 0) {                                         // :244
+                    atomicMin(a.position_map + dst[u], LG_POS_PENDING + idx);
+                    if (a.edge_access_time)                                // :358
+                        atomicAdd(a.edge_access_time + g.frontier[idx / count], 1ull);
+                } else {
+                    dst[u] = -1;
+                }
+                a.slot_dst[idx] = dst[u];
+            }
         }
         __syncthreads();
     }
 }
 
 // ------------------------------------------------------------------------------------------
-// K2: per-tile counts of valid edges and first touches
+// K2: per-256-slot-tile counts of valid edges and first touches
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(LG_TILE) void flag_count_kernel(SampleArgs a)
 {
-    __shared__ int32_t s_cnt[2][LG_TILE / 64];
+    __shared__ int32_t s_cnt[LG_SLOTS_PER_LANE][2][LG_TILE / 64];
     const HopGeom g = hop_geometry(a);
     const int32_t tid = threadIdx.x;
     const int32_t wave = tid >> 6, lane = tid & 63;
 
-    for (int32_t tile = blockIdx.x; tile < g.ntiles; tile += gridDim.x) {
-        const int32_t idx = tile * LG_TILE + tid;
-        bool valid = false, first = false;
-        if (idx < g.total) {
-            const int32_t v = a.slot_dst[idx];
-            valid = v >= 0;
-            if (valid) {
-                first = a.position_map[v] == LG_POS_PENDING + idx;
-                if (first) a.slot_dst[idx] = v | (int32_t)0x80000000;
+    for (int32_t st = blockIdx.x; st < g.nsuper; st += gridDim.x) {
+        const int32_t idx0 = st * LG_SUPER;
+        int32_t v[LG_SLOTS_PER_LANE], pm[LG_SLOTS_PER_LANE];
+#pragma unroll
+        for (int u = 0; u < LG_SLOTS_PER_LANE; u++) {
+            const int32_t idx = idx0 + u * LG_TILE + tid;
+            v[u] = idx < g.total ? a.slot_dst[idx] : -1;
+        }
+#pragma unroll
+        for (int u = 0; u < LG_SLOTS_PER_LANE; u++) pm[u] = v[u] >= 0 ? a.position_map[v[u]] : 0;
+#pragma unroll
+        for (int u = 0; u < LG_SLOTS_PER_LANE; u++) {
+            const int32_t idx = idx0 + u * LG_TILE + tid;
+            const bool valid = v[u] >= 0;
+            const bool first = valid && pm[u] == LG_POS_PENDING + idx;
+            if (first) a.slot_dst[idx] = v[u] | (int32_t)0x80000000;
+            const unsigned long long mv = __ballot(valid);
+            const unsigned long long mf = __ballot(first);
+            if (lane == 0) {
+                s_cnt[u][0][wave] = __popcll(mv);
+                s_cnt[u][1][wave] = __popcll(mf);
             }
         }
-        const unsigned long long mv = __ballot(valid);
-        const unsigned long long mf = __ballot(first);
-        if (lane == 0) {
-            s_cnt[0][wave] = __popcll(mv);
-            s_cnt[1][wave] = __popcll(mf);
-        }
         __syncthreads();
-        if (tid < 2) {
-            int32_t c = 0;
-            for (int w = 0; w < LG_TILE / 64; w++) c += s_cnt[tid][w];
-            a.tile_counts[2 * tile + tid] = c;
+        if (tid < 2 * LG_SLOTS_PER_LANE) {
+            const int u = tid >> 1, which = tid & 1;
+            const int32_t tile = st * LG_SLOTS_PER_LANE + u;
+            if (tile < g.ntiles) {
+                int32_t c = 0;
+                for (int w = 0; w < LG_TILE / 64; w++) c += s_cnt[u][which][w];
+                a.tile_counts[2 * tile + which] = c;
+            }
         }
         __syncthreads();
     }
@@ -340,14 +362,17 @@ __global__ __launch_bounds__(LG_SCAN_THREADS) void scan_kernel(SampleArgs a)
 }
 
 // ------------------------------------------------------------------------------------------
-// K4: slot-ordered compaction
+// K4: slot-ordered compaction (ballot + mbcnt prefix inside each 256-slot tile).  Besides the
+// edges and the new nodes it writes, next to every edge, the row header of the sampled
+// neighbour: the next hop's frontier then needs no dependent lookup.
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(LG_TILE) void scatter_kernel(SampleArgs a)
 {
-    __shared__ int32_t s_cnt[2][LG_TILE / 64];
+    __shared__ int32_t s_cnt[LG_SLOTS_PER_LANE][2][LG_TILE / 64];
     const int32_t* hs = a.hop_scratch;
     const int32_t total = hs[HS_SLOTS];
     const int32_t ntiles = (total + LG_TILE - 1) / LG_TILE;
+    const int32_t nsuper = (total + LG_SUPER - 1) / LG_SUPER;
     const bool seeds = hs[HS_FRONTIER_IS_SEEDS] != 0;
     const int32_t f_off = hs[HS_FRONTIER_OFF];
     const int32_t node_base = hs[HS_NODE_BASE], edge_base = hs[HS_EDGE_BASE];
@@ -356,33 +381,49 @@ __global__ __launch_bounds__(LG_TILE) void scatter_kernel(SampleArgs a)
     const int32_t wave = tid >> 6, lane = tid & 63;
     const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
 
-    for (int32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        const int32_t idx = tile * LG_TILE + tid;
-        int32_t v = -1;
-        if (idx < total) v = a.slot_dst[idx];
-        const bool valid = v != -1;
-        const bool first = valid && v < 0;
-        const int32_t dst = v & 0x7FFFFFFF;
-        const unsigned long long mv = __ballot(valid);
-        const unsigned long long mf = __ballot(first);
-        if (lane == 0) {
-            s_cnt[0][wave] = __popcll(mv);
-            s_cnt[1][wave] = __popcll(mf);
+    for (int32_t st = blockIdx.x; st < nsuper; st += gridDim.x) {
+        const int32_t idx0 = st * LG_SUPER;
+        int32_t v[LG_SLOTS_PER_LANE];
+        unsigned long long mv[LG_SLOTS_PER_LANE], mf[LG_SLOTS_PER_LANE];
+#pragma unroll
+        for (int u = 0; u < LG_SLOTS_PER_LANE; u++) {
+            const int32_t idx = idx0 + u * LG_TILE + tid;
+            v[u] = idx < total ? a.slot_dst[idx] : -1;
+        }
+#pragma unroll
+        for (int u = 0; u < LG_SLOTS_PER_LANE; u++) {
+            const bool valid = v[u] != -1;
+            const bool first = valid && v[u] < 0;
+            mv[u] = __ballot(valid);
+            mf[u] = __ballot(first);
+            if (lane == 0) {
+                s_cnt[u][0][wave] = __popcll(mv[u]);
+                s_cnt[u][1][wave] = __popcll(mf[u]);
+            }
         }
         __syncthreads();
-        int32_t we = 0, wn = 0;
-        for (int w = 0; w < wave; w++) { we += s_cnt[0][w]; wn += s_cnt[1][w]; }
-        if (valid) {
-            const int32_t e = edge_base + a.tile_prefix[2 * tile] + we + __popcll(mv & lt);
-            const int32_t q = idx / a.count;
-            a.agg_src_ids[e] = dst;                            // :256, :276
-            a.agg_dst_ids[e] = frontier[q];                    // :257, :277
-            // position of the node sampled for == construct_graph's position_map[agg_dst_ids[e]]
-            a.agg_dst_off[e] = seeds ? q : a.agg_src_off[f_off + q];
-            if (first) {
-                const int32_t n = node_base + a.tile_prefix[2 * tile + 1] + wn + __popcll(mf & lt);
-                a.sampled_ids[n] = dst;                        // :270
-                a.position_map[dst] = n;                       // :271
+#pragma unroll
+        for (int u = 0; u < LG_SLOTS_PER_LANE; u++) {
+            const int32_t idx = idx0 + u * LG_TILE + tid;
+            const int32_t tile = st * LG_SLOTS_PER_LANE + u;
+            const bool valid = v[u] != -1;
+            if (valid && tile < ntiles) {
+                const bool first = v[u] < 0;
+                const int32_t dst = v[u] & 0x7FFFFFFF;
+                int32_t we = 0, wn = 0;
+                for (int w = 0; w < wave; w++) { we += s_cnt[u][0][w]; wn += s_cnt[u][1][w]; }
+                const int32_t e = edge_base + a.tile_prefix[2 * tile] + we + __popcll(mv[u] & lt);
+                const int32_t q = idx / a.count;
+                a.agg_src_ids[e] = dst;                            // :256, :276
+                a.agg_dst_ids[e] = frontier[q];                    // :257, :277
+                // position of the node sampled for == construct_graph's position_map[agg_dst_ids[e]]
+                a.agg_dst_off[e] = seeds ? q : a.agg_src_off[f_off + q];
+                if (!a.last_hop) a.fh_edge[e] = a.row_hdr[dst];    // next hop's frontier header
+                if (first) {
+                    const int32_t n = node_base + a.tile_prefix[2 * tile + 1] + wn + __popcll(mf[u] & lt);
+                    a.sampled_ids[n] = dst;                        // :270
+                    a.position_map[dst] = n;                       // :271
+                }
             }
         }
         __syncthreads();
@@ -392,21 +433,36 @@ __global__ __launch_bounds__(LG_TILE) void scatter_kernel(SampleArgs a)
 // ------------------------------------------------------------------------------------------
 // K5: construct_graph's neighbour side
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void localise_kernel(SampleArgs a)
+__global__ __launch_bounds__(LG_TILE) void localise_kernel(SampleArgs a)
 {
     const int32_t* hs = a.hop_scratch;
     const int32_t n_edge = hs[HS_N_EDGE], edge_base = hs[HS_EDGE_BASE];
-    for (int32_t e = blockIdx.x * blockDim.x + threadIdx.x; e < n_edge; e += gridDim.x * blockDim.x)
-        a.agg_src_off[edge_base + e] = a.position_map[a.agg_src_ids[edge_base + e]];   // :289-293
+    const int32_t nsuper = (n_edge + LG_SUPER - 1) / LG_SUPER;
+    for (int32_t st = blockIdx.x; st < nsuper; st += gridDim.x) {
+        int32_t id[LG_SLOTS_PER_LANE], pos[LG_SLOTS_PER_LANE];
+#pragma unroll
+        for (int u = 0; u < LG_SLOTS_PER_LANE; u++) {
+            const int32_t e = st * LG_SUPER + u * LG_TILE + threadIdx.x;
+            id[u] = e < n_edge ? a.agg_src_ids[edge_base + e] : -1;
+        }
+#pragma unroll
+        for (int u = 0; u < LG_SLOTS_PER_LANE; u++) pos[u] = id[u] >= 0 ? a.position_map[id[u]] : 0;   // :289-293
+#pragma unroll
+        for (int u = 0; u < LG_SLOTS_PER_LANE; u++) {
+            const int32_t e = st * LG_SUPER + u * LG_TILE + threadIdx.x;
+            if (e < n_edge) a.agg_src_off[edge_base + e] = pos[u];
+        }
+    }
 }
 
 void launch_random_sample(hipStream_t s, const SampleArgs& a)
 {
-    // fixed grids that stride over tiles: enough workgroups to fill 256 CUs x 8, never more
-    // than the hop can use
-    int32_t max_tiles = (a.max_slots + LG_TILE - 1) / LG_TILE;
-    if (max_tiles < 1) max_tiles = 1;
-    const int32_t grid = max_tiles < 2048 ? max_tiles : 2048;
+    // Fixed grids that stride over super tiles.  The cap keeps one hop from occupying every wave
+    // slot of the chip while its lanes wait on memory, so kernels of other in-flight batches
+    // (pipeline lanes) can run beside it.
+    int32_t max_super = (a.max_slots + LG_SUPER - 1) / LG_SUPER;
+    if (max_super < 1) max_super = 1;
+    const int32_t grid = max_super < 1024 ? max_super : 1024;
     sample_kernel<<<grid, LG_TILE, 0, s>>>(a);
     hipCheckError();
     flag_count_kernel<<<grid, LG_TILE, 0, s>>>(a);
@@ -415,10 +471,56 @@ void launch_random_sample(hipStream_t s, const SampleArgs& a)
     hipCheckError();
     scatter_kernel<<<grid, LG_TILE, 0, s>>>(a);
     hipCheckError();
-    int32_t lgrid = (a.max_slots + 255) / 256;
-    if (lgrid < 1) lgrid = 1;
-    if (lgrid > 2048) lgrid = 2048;
-    localise_kernel<<<lgrid, 256, 0, s>>>(a);
+    localise_kernel<<<grid, LG_TILE, 0, s>>>(a);
+    hipCheckError();
+}
+
+// ------------------------------------------------------------------------------------------
+// per-vertex row headers (GraphStorage): every vertex starts in the full CSR (slot P) ...
+// ------------------------------------------------------------------------------------------
+__global__ void init_row_hdr_kernel(RowHdr* __restrict__ hdr, const int64_t* __restrict__ csr_index, int32_t n,
+                                    int32_t slot)
+{
+    for (int32_t v = blockIdx.x * blockDim.x + threadIdx.x; v < n; v += gridDim.x * blockDim.x) {
+        RowHdr h;
+        h.start = csr_index[v];
+        h.deg = (int32_t)(csr_index[v + 1] - h.start);
+        h.slot = slot;
+        hdr[v] = h;
+    }
+}
+
+void init_row_headers(hipStream_t s, RowHdr* hdr, const int64_t* csr_index, int32_t n, int32_t slot)
+{
+    int32_t grid = (n + 255) / 256;
+    if (grid > 4096) grid = 4096;
+    if (grid < 1) grid = 1;
+    init_row_hdr_kernel<<<grid, 256, 0, s>>>(hdr, csr_index, n, slot);
+    hipCheckError();
+}
+
+// ... and the vertices GPU `Ki` of the clique caches (QT[r*Kg + Ki], r < capacity) point into its CSR
+__global__ void cache_row_hdr_kernel(RowHdr* __restrict__ hdr, const int32_t* __restrict__ QT, int32_t Kg, int32_t Ki,
+                                     int32_t capacity, int32_t n, const int64_t* __restrict__ d_index, int32_t slot)
+{
+    for (int32_t r = blockIdx.x * blockDim.x + threadIdx.x; r < capacity; r += gridDim.x * blockDim.x) {
+        const int64_t t = (int64_t)r * Kg + Ki;
+        if (t >= n) continue;
+        RowHdr h;
+        h.start = d_index[r];
+        h.deg = (int32_t)(d_index[r + 1] - h.start);
+        h.slot = slot;
+        hdr[QT[t]] = h;
+    }
+}
+
+void cache_row_headers(hipStream_t s, RowHdr* hdr, const int32_t* QT, int32_t Kg, int32_t Ki, int32_t capacity,
+                       int32_t n, const int64_t* d_index, int32_t slot)
+{
+    if (capacity <= 0) return;
+    int32_t grid = (capacity + 255) / 256;
+    if (grid > 4096) grid = 4096;
+    cache_row_hdr_kernel<<<grid, 256, 0, s>>>(hdr, QT, Kg, Ki, capacity, n, d_index, slot);
     hipCheckError();
 }
 
@@ -444,7 +546,7 @@ __global__ void clear_pos_map_kernel(int32_t* __restrict__ position_map,
 void launch_clear_pos_map(hipStream_t s, int32_t* position_map, const int32_t* sampled_ids,
                           const int32_t* node_counter, int32_t* iter_state)
 {
-    clear_pos_map_kernel<<<1024, 256, 0, s>>>(position_map, sampled_ids, node_counter, iter_state);
+    clear_pos_map_kernel<<<512, 256, 0, s>>>(position_map, sampled_ids, node_counter, iter_state);
     hipCheckError();
 }
 

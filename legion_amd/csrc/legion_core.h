@@ -72,7 +72,19 @@ enum HopScratch {
     HS_WORDS = 16
 };
 
-#define LG_TILE 256  // slots per tile == threads per block in the sampler kernels
+#define LG_TILE 256            // compaction tile == threads per workgroup in the sampler kernels
+#define LG_SLOTS_PER_LANE 4    // independent slots each lane keeps in flight
+#define LG_SUPER (LG_TILE * LG_SLOTS_PER_LANE)   // slots one workgroup owns per iteration
+
+// Per-vertex row header: where the adjacency of v lives (slot of the CSR pointer tables: P = the
+// full CSR, d < P = GPU d's cached CSR), its first edge and its degree.  One 16-byte read resolves
+// what the reference does with two hash finds + two indptr reads (cache.cu:217-225,
+// operator_impl.cu:224-230).
+struct alignas(16) RowHdr {
+    int64_t start;
+    int32_t deg;
+    int32_t slot;
+};
 
 struct BuildInfo {  // SS/include/buildinfo.h (only the fields of the in-memory path)
     int32_t partition_count = 0;
@@ -138,6 +150,7 @@ public:
     int32_t* slot_dst = nullptr;       // [max_slots] sampled neighbour per slot (sign bit = first touch)
     int32_t* tile_counts = nullptr;    // [2 * max_tiles] valid / first-touch counts per tile
     int32_t* tile_prefix = nullptr;    // [2 * max_tiles] exclusive prefixes
+    RowHdr* fh_edge = nullptr;         // [num_ids] frontier row headers written by scatter
     int32_t* hop_scratch = nullptr;    // [HS_WORDS]
     int32_t num_ids = 0;
     int32_t max_slots = 0;             // largest hop = B * f1 * ... * fH
@@ -195,6 +208,7 @@ public:
     virtual int32_t* GetCSRNodeMatrixCPU() const = 0;
     virtual int32_t NodeNum() const = 0;
     virtual int64_t EdgeNum() const = 0;
+    virtual const RowHdr* GetRowHeaders(int32_t part_id) const = 0;   // new: [N] per GPU
 };
 extern "C" GraphStorage* NewCompleteGraphStorage();
 
@@ -412,10 +426,10 @@ struct SampleArgs {
     int32_t op_id;
     int32_t count;                  // fan-out of this hop
     int32_t partition_count;        // P: slot of the full CSR in the pointer tables
-    int64_t* const* csr_node_index; // device table [P+1]
-    int32_t* const* csr_dst_node_ids;
-    const char* edge_index_map;     // id -> owner device or -2 (null: no topology cache)
-    const int32_t* edge_offset_map; // id -> row in the owner's cached CSR or -2
+    int32_t* const* csr_dst_node_ids;   // device table [P+1] of column arrays
+    const RowHdr* row_hdr;          // [N] per-vertex row headers of this GPU
+    RowHdr* fh_edge;                // [num_ids] header of every sampled neighbour, next to its edge
+    bool last_hop;                  // no next hop: scatter skips the header lookup
     int32_t* sampled_ids;
     int32_t* agg_src_ids;
     int32_t* agg_dst_ids;
@@ -446,6 +460,9 @@ void launch_clear_pos_map(hipStream_t s, int32_t* position_map, const int32_t* s
                           const int32_t* node_counter, int32_t* iter_state);
 void launch_hotness_measure(hipStream_t s, const int32_t* sampled_ids, const int32_t* node_counter,
                             unsigned long long* access_map);
+void init_row_headers(hipStream_t s, RowHdr* hdr, const int64_t* csr_index, int32_t n, int32_t slot);
+void cache_row_headers(hipStream_t s, RowHdr* hdr, const int32_t* QT, int32_t Kg, int32_t Ki, int32_t capacity,
+                       int32_t n, const int64_t* d_index, int32_t slot);
 void launch_find(hipStream_t s, const int32_t* keys, int32_t n, const int32_t* map32,
                  const char* map8, int32_t* out32, char* out8);
 void launch_draw_batch(hipStream_t s, const int32_t* idx, const int32_t* deg, int32_t* out, int32_t n);

@@ -101,11 +101,10 @@ extern "C" void RandomSample(legion_stream_t strm_hdl, LegionGraphStorage* graph
     a.op_id = op_id;
     a.count = count;
     a.partition_count = graph->GetPartitionCount();
-    a.csr_node_index = graph->GetCSRNodeIndex(dev_id);
     a.csr_dst_node_ids = graph->GetCSRNodeMatrix(dev_id);
-    CacheController* cc = (cache && !is_presc) ? cache->Controller(dev_id) : nullptr;
-    a.edge_index_map = cc ? cc->EdgeIndexMap() : nullptr;
-    a.edge_offset_map = cc ? cc->EdgeOffsetMap() : nullptr;
+    a.row_hdr = graph->GetRowHeaders(dev_id);
+    a.fh_edge = memorypool->fh_edge;
+    a.last_hop = (size_t)(op_id / INTRABATCH_CON) + 1 >= memorypool->max_new.size();
     a.sampled_ids = memorypool->GetSampledIds();
     a.agg_src_ids = memorypool->GetAggSrcId();
     a.agg_dst_ids = memorypool->GetAggDstId();

@@ -91,6 +91,10 @@ public:
             h_index_tab_[i][partition_count_] = csr_node_index_cpu_;
             h_dst_tab_[i][partition_count_] = csr_dst_node_ids_cpu_;
             Upload(i);
+            // per-vertex row headers: everything starts in the full CSR (slot P)
+            row_hdr_.push_back((RowHdr*)d_alloc_space((int64_t)node_num_ * sizeof(RowHdr)));
+            lg::init_row_headers(nullptr, row_hdr_[i], csr_node_index_cpu_, node_num_, partition_count_);
+            HIP_CALL(hipDeviceSynchronize());
         }
     }
 
@@ -118,6 +122,12 @@ public:
                 h_index_tab_[Ki * Kg + j][dev] = d_csr_node_index;
                 h_dst_tab_[Ki * Kg + j][dev] = d_csr_dst_node_ids;
             }
+            for (int32_t j = 0; j < Kg; j++) {            // ... and resolves the cached vertices to it
+                SetGPUDevice(Ki * Kg + j);
+                lg::cache_row_headers(nullptr, row_hdr_[Ki * Kg + j], QT, Kg, i, capacity, node_num_,
+                                      d_csr_node_index, dev);
+                HIP_CALL(hipDeviceSynchronize());
+            }
         }
         for (int32_t j = 0; j < Kg; j++) Upload(Ki * Kg + j);
     }
@@ -126,6 +136,8 @@ public:
     {
         for (void* p : owned_) d_free_space(p);
         owned_.clear();
+        for (RowHdr* p : row_hdr_) d_free_space(p);
+        row_hdr_.clear();
         for (int32_t i = 0; i < partition_count_; i++) {
             d_free_space(csr_node_index_[i]);
             d_free_space(csr_dst_node_ids_[i]);
@@ -141,6 +153,7 @@ public:
     int32_t* GetCSRNodeMatrixCPU() const override { return csr_dst_node_ids_cpu_; }
     int32_t NodeNum() const override { return node_num_; }
     int64_t EdgeNum() const override { return edge_num_; }
+    const RowHdr* GetRowHeaders(int32_t part_id) const override { return row_hdr_[part_id]; }
 
 private:
     void Upload(int32_t dev)
@@ -162,6 +175,7 @@ private:
     int64_t* csr_node_index_cpu_ = nullptr;
     int32_t* csr_dst_node_ids_cpu_ = nullptr;
     std::vector<void*> owned_;
+    std::vector<RowHdr*> row_hdr_;
 };
 
 extern "C" GraphStorage* NewCompleteGraphStorage() { return new CompleteGraphStorage(); }
@@ -264,6 +278,8 @@ void MemoryPool::Finalize()
     d_free_space(tile_counts);
     d_free_space(tile_prefix);
     d_free_space(hop_scratch);
+    d_free_space(fh_edge);
+    fh_edge = nullptr;
     cache_search_buffer_ = position_map_ = agg_src_ids_ = agg_dst_ids_ = tmp_part_off_ = nullptr;
     tmp_part_ind_ = nullptr;
     slot_dst = tile_counts = tile_prefix = hop_scratch = nullptr;
@@ -314,6 +330,7 @@ void lg_pool_alloc_private(MemoryPool* mp, int32_t dev_id, int32_t total_num_nod
     mp->slot_dst = (int32_t*)d_alloc_space((int64_t)mp->max_slots * sizeof(int32_t));
     mp->tile_counts = (int32_t*)d_alloc_space(2 * max_tiles * sizeof(int32_t));
     mp->tile_prefix = (int32_t*)d_alloc_space(2 * max_tiles * sizeof(int32_t));
+    mp->fh_edge = (RowHdr*)d_alloc_space(num_ids * sizeof(RowHdr));
     mp->hop_scratch = (int32_t*)d_alloc_space(HS_WORDS * sizeof(int32_t));
     HIP_CALL(hipMemset(mp->hop_scratch, 0, HS_WORDS * sizeof(int32_t)));
 }

@@ -262,6 +262,15 @@ class UnifiedCache:
     def max_id_num(self, dev_id=0):
         return int(self._lib.legion_cache_max_id_num(self.handle, int(dev_id)))
 
+    def find_topo(self, dev_id, input_ids):
+        """(partition_index int8, partition_offset int32) for a device int32 tensor of vertex ids."""
+        n = int(input_ids.numel())
+        ind = torch.empty(n, dtype=torch.int8, device=input_ids.device)
+        off = torch.empty(n, dtype=torch.int32, device=input_ids.device)
+        self._lib.legion_cache_find_topo(self.handle, int(dev_id), _stream_handle(None), _ptr(input_ids), n,
+                                         _ptr(ind), _ptr(off))
+        return ind, off
+
     def array(self, name, dev_id=0):
         which, dtype = self._ARR[name]
         ptr = self._lib.legion_cache_array(self.handle, int(dev_id), which)

@@ -48,6 +48,8 @@ SIGNATURES = {
     "legion_cache_edge_capacity": (c_i32, [c_p, c_i32]),
     "legion_cache_max_id_num": (c_i32, [c_p, c_i32]),
     "legion_cache_array": (c_p, [c_p, c_i32, c_i32]),
+    "legion_cache_find_topo": (None, [c_p, c_i32, c_p, c_p, c_i32, c_p, c_p]),
+    "legion_cache_find_feat": (None, [c_p, c_i32, c_p, c_p, c_p, c_p, c_i32]),
     # 3. server / ipc
     "NewGPUServer": (c_p, []),
     "legion_server_initialize": (None, [c_p, c_i32, P_I32, c_i32, c_i32]),

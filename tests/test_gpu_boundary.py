@@ -67,7 +67,8 @@ def test_server_binary_serves_fake_trainer(hip, tmp_path):
         one = lambda v: (ctypes.c_int32 * 1)(v)
         L.lgo_coordinate(ctypes.byref(st), 1, one(train.size), one(valid.size), one(test.size), B, epoch)
         node_acc, edge_acc = np.zeros(N, dtype=np.uint64), np.zeros(N, dtype=np.uint64)
-        pool = ffi.OraclePool(N, B, fanout, ffi.num_ids_for(B, fanout), D)
+        max_bs = max(B, st.valid_bs[0], st.test_bs[0])      # validation batches (90) exceed the raw batch (48)
+        pool = ffi.OraclePool(N, max_bs, fanout, ffi.num_ids_for(max_bs, fanout), D)
         max_ids = 0
         for it in range(st.train_step):
             pool.run_batch(g, None, None, train, labels[train], B, it, 0, True, node_acc, edge_acc)

@@ -82,14 +82,18 @@ def test_presc_cache_build_and_serve(hip, P, mode_bits, capacity):
             g, c = gpu.run(p, 0, mode), cpu.run(p, 0, mode)
             compare_batches(g, c, f"serve gpu {p} mode {mode}: ")
             assert np.array_equal(g["cache_search_buffer"], c["cache_search_buffer"])      # feature hit mask + slots
-            H = len(fanout)                  # the last FindTopo covered the last hop's frontier
+            H = len(fanout)                  # the last sampler pass covered the last hop's frontier
             n_f = int(g["edge_counter"][9 + H - 1] - g["edge_counter"][9 + H - 2]) if H > 1 else int(g["node_counter"][9])
             tp_g = gpu.pools[p].buffer("tmp_part_ind")[:n_f].cpu().numpy()
             tp_c = np.ctypeslib.as_array(cpu.pools[p].p.contents.tmp_part_ind, shape=(max(n_f, 1),))[:n_f]
             assert np.array_equal(tp_g, tp_c)                                               # topology hit mask
-            to_g = gpu.pools[p].buffer("tmp_part_off")[:n_f].cpu().numpy()
+            # explicit FindTopo (owner + row offset) on the same frontier
+            f_lo = int(g["edge_counter"][9 + H - 2]) if H > 1 else 0
+            frontier = (g["agg_src_ids"][f_lo:f_lo + n_f] if H > 1 else g["sampled_ids"][:n_f]).astype(np.int32)
+            ind, off = gpu.cache.find_topo(p, torch.from_numpy(frontier).cuda())
+            torch.cuda.synchronize()
             to_c = np.ctypeslib.as_array(cpu.pools[p].p.contents.tmp_part_off, shape=(max(n_f, 1),))[:n_f]
-            assert np.array_equal(to_g, to_c)
+            assert np.array_equal(ind.cpu().numpy(), tp_c) and np.array_equal(off.cpu().numpy(), to_c)
             hits += int((g["cache_search_buffer"] >= 0).sum())
     assert hits > 0
     gpu.close(); cpu.close()
