@@ -49,7 +49,8 @@ def parse_args():
     ap.add_argument("--cache-memory", type=int, default=8 << 30, help="bytes per GPU fed to the cost model")
     ap.add_argument("--presc-steps", type=int, default=512, help="PreSC batches per GPU (bounded epoch)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU-baseline time; 0 disables")
-    ap.add_argument("--lanes", type=int, default=4, help="mini-batches in flight per GPU (pipeline lanes)")
+    ap.add_argument("--group", type=int, default=4, help="mini-batches served by every launch (lanes of a group)")
+    ap.add_argument("--slots", type=int, default=2, help="groups in flight per GPU")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
     ap.add_argument("--no-verify", action="store_true")
     return ap.parse_args()
@@ -106,7 +107,9 @@ def main():
     cache.fill_up(feature, graph)
     feature_rows = int(max_ids * 1.2)                                        # server.cu:277
     pool.close()
-    pipe = engine.Pipeline(graph, feature, cache, 0, B, fanout, args.lanes, feature_rows, not args.no_graph)
+    G = args.group
+    assert args.steps % G == 0 and args.warmup % G == 0, "--steps and --warmup must be multiples of --group"
+    pipe = engine.Pipeline(graph, feature, cache, 0, B, fanout, G, feature_rows, not args.no_graph, args.slots)
     torch.cuda.synchronize()
     setup_s = time.time() - t_setup
 
@@ -116,9 +119,10 @@ def main():
     rows = np.zeros((args.steps, H + 1), dtype=np.int64)
     hits = 0
     for k in range(args.steps):
-        lane = pipe.submit(first + k)
-        pipe.wait(lane)
-        pl = pipe.pools[lane]
+        if k % G == 0:
+            slot = pipe.submit(first + k)
+            pipe.wait(slot)
+        pl = pipe.pools[slot][k % G]
         nc = pl.buffer("node_counter").cpu().numpy()
         ec = pl.buffer("edge_counter").cpu().numpy()
         edges[k] = ec[9 + H]
@@ -140,14 +144,14 @@ def main():
             hits = int((pl.buffer("cache_search_buffer")[:int(nc[1])] >= 0).sum())
 
     # ---- warm-up, then the timed region: K batches replayed as hipGraphs over `lanes` lanes ---------
-    for it in range(args.warmup):
+    for it in range(0, args.warmup, G):
         pipe.submit(it)
     pipe.wait()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for k in range(args.steps):
+    for k in range(0, args.steps, G):
         pipe.submit(first + k)
     pipe.wait()
     torch.cuda.synchronize()
@@ -159,12 +163,12 @@ def main():
     # ---- the same K batches once more with HIP events around every gather launch (recorded on the
     #      lane's own stream).  Eager launches: HIP cannot time events recorded by graph nodes. ------
     pipe.profile_begin()
-    for it in range(args.warmup):
+    for it in range(0, args.warmup, G):
         pipe.submit(it)
     pipe.wait()
     warm = pipe.profile_read()
     t1 = time.perf_counter()
-    for k in range(args.steps):
+    for k in range(0, args.steps, G):
         pipe.submit(first + k)
     pipe.wait()
     elapsed_profiled = time.perf_counter() - t1
@@ -203,7 +207,7 @@ def main():
             "config": {"workload": f"RMAT-{args.scale} EF{args.edge_factor} (N={N}, E={N * args.edge_factor}), "
                                    f"float32[N x {D}] features, batch {B}, fanout {fanout}, all tables resident in HBM",
                        "parallelism": f"seed-sharded x{world}, replicated graph+features, cache_agg_mode 0",
-                       "lanes_in_flight": args.lanes, "hipgraph": not args.no_graph,
+                       "batches_per_launch_group": G, "groups_in_flight": args.slots, "hipgraph": not args.no_graph,
                        "cache_memory_bytes": args.cache_memory,
                        "feature_cache_rows": cache.node_capacity(0), "topology_cache_vertices": cache.edge_capacity(0),
                        "presc_batches": train_step},
@@ -217,8 +221,8 @@ def main():
                          "bytes_per_row": bytes_per_row, "rows_per_launch": rows_last / max(n_last, 1),
                          "launches": n_last, "avg_launch_us": t_last / max(n_last, 1) * 1e6,
                          "measured": "HIP events on the launch stream around each hop-%d gather over the same %d "
-                                     "batches, %d lanes in flight, eager launches (ms_per_step %.4f)"
-                                     % (H, args.steps, args.lanes, elapsed_profiled / args.steps * 1e3)},
+                                     "batches, %d batches per launch, eager launches (ms_per_step %.4f)"
+                                     % (H, args.steps, G, elapsed_profiled / args.steps * 1e3)},
             "setup_seconds": setup_s,
         }
         if args.cpu_seconds > 0:

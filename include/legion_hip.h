@@ -171,23 +171,36 @@ int32_t legion_ipc_local_batch_id(LegionIPCEnv* e, int32_t global_batch_id);
 int32_t legion_ipc_current_batchsize(LegionIPCEnv* e, int32_t dev_id, int32_t mode);
 void legion_ipc_finalize(LegionIPCEnv* e);
 
-/* Pipeline: `lanes` independent mini-batches in flight on one GPU, each with its own MemoryPool
- * (outputs + private scratch) and HIP stream, each batch replayed as one hipGraph.  This is the
- * MI355X-native form of the Runner's inter-batch pipe (SS/engine/server.cu:302-332 with
- * INTERBATCH_CON output slots): submit() never blocks on the batch it enqueues, only on the lane's
- * previous one.  feature_rows sizes each lane's feature buffer (SS/engine/server.cu:275-283). */
+/* Lane groups: every kernel of the path takes an array of per-mini-batch buffer descriptors and is
+ * launched with grid.y = lanes, so ONE launch of each kernel serves `n` independent mini-batches
+ * (lane i produces batch counter0 + i into pool i).  The reference-shaped operators above are the
+ * n = 1 case.  No reference counterpart: this is how the path keeps 256 CUs busy at B = 1024. */
+typedef struct LegionLaneGroup LegionLaneGroup;
+LegionLaneGroup* legion_group_create(LegionMemoryPool** pools, int32_t n);
+void legion_group_set_iter_state(LegionLaneGroup* g, int32_t* iter_state_devptr);
+void legion_group_destroy(LegionLaneGroup* g);
+void legion_enqueue_group(legion_stream_t strm_hdl, LegionGraphStorage* graph, LegionFeatureStorage* feature,
+                          LegionUnifiedCache* cache, LegionLaneGroup* group, int32_t batch_size,
+                          int32_t counter0, int32_t dev_id, int32_t mode, const int32_t* fanout, int32_t hop_num);
+
+/* Pipeline: `slots` groups of `group_size` mini-batches in flight on one GPU; each group is replayed
+ * as one hipGraph on its own stream (sizes and the batch index live on the device, so a replay
+ * needs no argument update).  The MI355X-native form of the Runner's inter-batch pipe
+ * (SS/engine/server.cu:302-332 with INTERBATCH_CON output slots): submit() never blocks on the
+ * group it enqueues, only on the slot's previous one.  feature_rows sizes each lane's feature buffer
+ * (SS/engine/server.cu:275-283). */
 typedef struct LegionPipeline LegionPipeline;
 LegionPipeline* legion_pipeline_create(LegionGraphStorage* graph, LegionFeatureStorage* feature,
                                        LegionUnifiedCache* cache, int32_t dev_id, int32_t batch_size,
-                                       const int32_t* fanout, int32_t hop_num, int32_t lanes,
-                                       int64_t feature_rows, int32_t use_graph);
-int32_t legion_pipeline_submit(LegionPipeline* p, int32_t counter, int32_t mode);   /* returns the lane */
-void legion_pipeline_wait(LegionPipeline* p, int32_t lane);                          /* lane < 0: all lanes */
-LegionMemoryPool* legion_pipeline_pool(LegionPipeline* p, int32_t lane);
-legion_stream_t legion_pipeline_stream(LegionPipeline* p, int32_t lane);
+                                       const int32_t* fanout, int32_t hop_num, int32_t group_size,
+                                       int32_t slots, int64_t feature_rows, int32_t use_graph);
+/* enqueues batches counter0 .. counter0 + group_size - 1; returns the slot */
+int32_t legion_pipeline_submit(LegionPipeline* p, int32_t counter0, int32_t mode);
+void legion_pipeline_wait(LegionPipeline* p, int32_t slot);                          /* slot < 0: all slots */
+LegionMemoryPool* legion_pipeline_pool(LegionPipeline* p, int32_t slot, int32_t lane);
 void legion_pipeline_destroy(LegionPipeline* p);
-/* Measurement aid: HIP events on each lane's stream around every gather launch.  While it is on,
- * batches are launched eagerly (HIP cannot time events recorded by graph nodes).  read() fills, per
+/* Measurement aid: HIP events on each slot's stream around every gather launch.  While it is on,
+ * groups are launched eagerly (HIP cannot time events recorded by graph nodes).  read() fills, per
  * gather op id, the summed elapsed ms and the launch count of every batch waited for since begin();
  * returns the op count. */
 void legion_pipeline_profile_begin(LegionPipeline* p);

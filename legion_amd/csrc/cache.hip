@@ -417,17 +417,21 @@ unsigned long long int* UnifiedCache::GetEdgeAccessedMap(int32_t dev_id)
 }
 
 // SS/cache/cache.cu:726-748 -- lookup (FindFeat) fused into the gather
-void UnifiedCache::FeatCacheLookup(int32_t* sampled_ids, int32_t* cache_index, int32_t* node_counter,
-                                   float* dst_float_buffer, int32_t op_id, int32_t dev_id,
-                                   hipStream_t strm_hdl, int32_t max_rows, int32_t dst_rows)
+void UnifiedCache::FeatCacheLookup(const LanePtrs* d_lanes, int32_t n_lanes, int32_t op_id, int32_t dev_id,
+                                   hipStream_t strm_hdl, int32_t max_rows)
 {
     const bool filled = !node_capacity_.empty() && d_float_feature_cache_ptr_[dev_id] != nullptr &&
                         cache_controller_[dev_id]->NodeMap() != nullptr;
     (void)op_id;
-    lg::launch_gather(strm_hdl, cpu_float_features_, filled ? d_float_feature_cache_ptr_[dev_id] : nullptr,
-                      filled ? cache_controller_[dev_id]->NodeMap() : nullptr,
-                      filled ? NodeCapacity(dev_id) : 1, float_feature_len_, total_num_nodes_, sampled_ids,
-                      cache_index, node_counter, node_counter + 2, dst_float_buffer, max_rows, dst_rows);
+    lg::GatherParams g;
+    g.full_table = cpu_float_features_;
+    g.cache_tables = filled ? d_float_feature_cache_ptr_[dev_id] : nullptr;
+    g.node_map = filled ? cache_controller_[dev_id]->NodeMap() : nullptr;
+    g.node_capacity = filled ? NodeCapacity(dev_id) : 1;
+    g.D = float_feature_len_;
+    g.total_num_nodes = total_num_nodes_;
+    g.max_rows = max_rows;
+    lg::launch_gather(strm_hdl, g, d_lanes, n_lanes);
 }
 
 // ---- C API ----------------------------------------------------------------------------------

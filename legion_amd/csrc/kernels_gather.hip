@@ -18,117 +18,131 @@
 // Roofline: HBM.  Algorithmic bytes per row = 8*D + 8 (D*4 read + D*4 written + id + index).
 #include "legion_core.h"
 
+#include <cstring>
+
 namespace lg {
 
 #define LG_GATHER_ROWS 64
 #define LG_GATHER_THREADS 256
 #define LG_GATHER_UNROLL 4
 
-template <typename VecT>
-__global__ __launch_bounds__(LG_GATHER_THREADS) void gather_kernel(
-    const float* __restrict__ full_table, const float* const* __restrict__ cache_tables,
-    const int32_t* __restrict__ node_map, int32_t node_capacity, int32_t D, int32_t total_num_nodes,
-    const int32_t* __restrict__ sampled_ids, int32_t* __restrict__ cache_index_out,
-    const int32_t* __restrict__ range, int32_t* __restrict__ range_copy, float* __restrict__ dst,
-    int32_t max_rows, int32_t dst_rows)
+template <typename VecT, int ROWS = LG_GATHER_ROWS, int UNROLL = LG_GATHER_UNROLL>
+__global__ __launch_bounds__(LG_GATHER_THREADS) void gather_kernel(GatherParams gp, const LanePtrs* __restrict__ lanes,
+                                                                   bool copy_range)
 {
     constexpr int VEC = sizeof(VecT) / sizeof(float);
-    __shared__ const float* s_ptr[LG_GATHER_ROWS];
+    __shared__ const float* s_ptr[ROWS];
 
+    const LanePtrs& L = lanes[blockIdx.y];
+    const int32_t* range = L.node_counter;               // {offset, count} of the current new-node range
     const int32_t off = range[0];
     int32_t rows = range[1];
-    if (blockIdx.x == 0 && threadIdx.x == 0 && range_copy) {   // counter_update(op%3==1), operator_impl.cu:83-85
-        range_copy[0] = off;
-        range_copy[1] = rows;
+    if (copy_range && blockIdx.x == 0 && threadIdx.x == 0) {   // counter_update(op%3==1), operator_impl.cu:83-85
+        L.node_counter[2] = off;
+        L.node_counter[3] = rows;
     }
-    if (rows > max_rows) rows = max_rows;
-    if (rows > dst_rows - off) rows = dst_rows - off;   // never write past the feature buffer (the
-                                                        // reference sizes it 1.2 x PreSC max and would overrun)
-    const int32_t ntiles = (rows + LG_GATHER_ROWS - 1) / LG_GATHER_ROWS;
+    if (rows > gp.max_rows) rows = gp.max_rows;
+    if (rows > L.feature_rows - off) rows = L.feature_rows - off;   // never write past the feature buffer (the
+                                                                    // reference sizes it 1.2 x PreSC max and would overrun)
+    const int32_t ntiles = (rows + ROWS - 1) / ROWS;
     const int32_t tid = threadIdx.x;
+    const int32_t D = gp.D;
     const int32_t C = D / VEC;                         // chunks per row
     const int32_t dr = LG_GATHER_THREADS / C;          // row / chunk advance per 256-chunk step
     const int32_t dc = LG_GATHER_THREADS - dr * C;
 
-    // one tile per workgroup: the grid covers the whole feature buffer, surplus workgroups leave
-    // here, and the hardware dispatcher balances the rest (a grid-stride loop over a fixed grid
-    // left a 1-vs-2-tiles imbalance at typical sizes)
-    {
-        const int32_t tile = blockIdx.x;
-        if (tile >= ntiles) return;
-        const int32_t r0 = tile * LG_GATHER_ROWS;
-        const int32_t nr = min(LG_GATHER_ROWS, rows - r0);
-        if (tid < nr) {
-            const int32_t id = sampled_ids[off + r0 + tid];
-            int32_t g = CACHEMISS_FLAG;
-            if (node_map != nullptr && id >= 0) g = node_map[id];
-            cache_index_out[r0 + tid] = g;             // FindFeat writes from index 0 each hop
-            const float* p = nullptr;
-            if (g < 0) {
-                if (id >= 0) p = full_table + (int64_t)(id % total_num_nodes) * D;   // :262-266
-            } else {
-                const int32_t didx = g / node_capacity, fidx = g - didx * node_capacity;   // :259-260
-                p = cache_tables[didx] + (int64_t)fidx * D;                                  // :268
-            }
-            s_ptr[tid] = p;
+    // one tile per workgroup: the grid covers the largest range the op can have, surplus workgroups
+    // leave here, and the hardware dispatcher balances the rest
+    const int32_t tile = blockIdx.x;
+    if (tile >= ntiles) return;
+    const int32_t r0 = tile * ROWS;
+    const int32_t nr = min(ROWS, rows - r0);
+    for (int32_t t = tid; t < nr; t += LG_GATHER_THREADS) {
+        const int32_t id = L.sampled_ids[off + r0 + t];
+        int32_t g = CACHEMISS_FLAG;
+        if (gp.node_map != nullptr && id >= 0) g = gp.node_map[id];
+        L.cache_search_buffer[r0 + t] = g;             // FindFeat writes from index 0 each hop
+        const float* p = nullptr;
+        if (g < 0) {
+            if (id >= 0) p = gp.full_table + (int64_t)(id % gp.total_num_nodes) * D;   // :262-266
+        } else {
+            const int32_t didx = g / gp.node_capacity, fidx = g - didx * gp.node_capacity;   // :259-260
+            p = gp.cache_tables[didx] + (int64_t)fidx * D;                                   // :268
         }
-        __syncthreads();
+        s_ptr[t] = p;
+    }
+    __syncthreads();
 
-        const int32_t nchunks = nr * C;
-        float* dst_tile = dst + (int64_t)(off + r0) * D;
-        int32_t q = tid;
-        int32_t r = q / C;
-        int32_t c = q - r * C;
-        while (q < nchunks) {
-            VecT v[LG_GATHER_UNROLL];
-            int32_t rr[LG_GATHER_UNROLL], cc[LG_GATHER_UNROLL];
-            bool ok[LG_GATHER_UNROLL];
+    const int32_t nchunks = nr * C;
+    float* dst_tile = L.float_features + (int64_t)(off + r0) * D;
+    int32_t q = tid;
+    int32_t r = q / C;
+    int32_t c = q - r * C;
+    while (q < nchunks) {
+        VecT v[UNROLL];
+        int32_t rr[UNROLL], cc[UNROLL];
+        bool ok[UNROLL];
 #pragma unroll
-            for (int u = 0; u < LG_GATHER_UNROLL; u++) {
-                rr[u] = r;
-                cc[u] = c;
-                ok[u] = false;
-                if (q < nchunks) {
-                    const float* p = s_ptr[r];
-                    if (p != nullptr) {
-                        v[u] = __builtin_nontemporal_load(reinterpret_cast<const VecT*>(p) + c);
-                        ok[u] = true;
-                    }
+        for (int u = 0; u < UNROLL; u++) {
+            rr[u] = r;
+            cc[u] = c;
+            ok[u] = false;
+            if (q < nchunks) {
+                const float* p = s_ptr[r];
+                if (p != nullptr) {
+                    v[u] = reinterpret_cast<const VecT*>(p)[c];     // plain loads: measured 74% of HBM peak vs 63% nontemporal
+                    ok[u] = true;
                 }
-                q += LG_GATHER_THREADS;
-                r += dr;
-                c += dc;
-                if (c >= C) { c -= C; r += 1; }
             }
+            q += LG_GATHER_THREADS;
+            r += dr;
+            c += dc;
+            if (c >= C) { c -= C; r += 1; }
+        }
 #pragma unroll
-            for (int u = 0; u < LG_GATHER_UNROLL; u++) {
-                if (ok[u])
-                    __builtin_nontemporal_store(v[u], reinterpret_cast<VecT*>(dst_tile + (int64_t)rr[u] * D) + cc[u]);
-            }
+        for (int u = 0; u < UNROLL; u++) {
+            if (ok[u])     // write-once output: nontemporal stores
+                __builtin_nontemporal_store(v[u], reinterpret_cast<VecT*>(dst_tile + (int64_t)rr[u] * D) + cc[u]);
         }
     }
 }
 
-void launch_gather(hipStream_t s, const float* full_table, const float* const* cache_tables,
-                   const int32_t* node_map, int32_t node_capacity, int32_t D, int32_t total_num_nodes,
-                   const int32_t* sampled_ids, int32_t* cache_index_out, const int32_t* range,
-                   int32_t* range_copy, float* dst, int32_t max_rows, int32_t dst_rows)
+static void launch_gather_impl(hipStream_t s, GatherParams g, const LanePtrs* d_lanes, int32_t n_lanes, bool copy_range)
 {
-    if (D <= 0 || max_rows <= 0) return;                // :256 float_feature_len > 0
-    if (node_capacity < 1) node_capacity = 1;
-    const int32_t grid = (max_rows + LG_GATHER_ROWS - 1) / LG_GATHER_ROWS;
+    if (g.D <= 0 || g.max_rows <= 0) return;            // :256 float_feature_len > 0
+    if (g.node_capacity < 1) g.node_capacity = 1;
+    const dim3 grid((g.max_rows + LG_GATHER_ROWS - 1) / LG_GATHER_ROWS, n_lanes);
     typedef float v4 __attribute__((ext_vector_type(4)));
     typedef float v2 __attribute__((ext_vector_type(2)));
-    if (D % 4 == 0)
-        gather_kernel<v4><<<grid, LG_GATHER_THREADS, 0, s>>>(full_table, cache_tables, node_map,
-            node_capacity, D, total_num_nodes, sampled_ids, cache_index_out, range, range_copy, dst, max_rows, dst_rows);
-    else if (D % 2 == 0)
-        gather_kernel<v2><<<grid, LG_GATHER_THREADS, 0, s>>>(full_table, cache_tables, node_map,
-            node_capacity, D, total_num_nodes, sampled_ids, cache_index_out, range, range_copy, dst, max_rows, dst_rows);
+    if (g.D % 4 == 0)
+        gather_kernel<v4><<<grid, LG_GATHER_THREADS, 0, s>>>(g, d_lanes, copy_range);
+    else if (g.D % 2 == 0)
+        gather_kernel<v2><<<grid, LG_GATHER_THREADS, 0, s>>>(g, d_lanes, copy_range);
     else
-        gather_kernel<float><<<grid, LG_GATHER_THREADS, 0, s>>>(full_table, cache_tables, node_map,
-            node_capacity, D, total_num_nodes, sampled_ids, cache_index_out, range, range_copy, dst, max_rows, dst_rows);
+        gather_kernel<float><<<grid, LG_GATHER_THREADS, 0, s>>>(g, d_lanes, copy_range);
     hipCheckError();
+}
+
+void launch_gather(hipStream_t s, const GatherParams& g, const LanePtrs* d_lanes, int32_t n_lanes)
+{
+    launch_gather_impl(s, g, d_lanes, n_lanes, true);
+}
+
+// stand-alone form (tests, probes): explicit arrays; a one-lane descriptor is staged on the stream
+void launch_gather_explicit(hipStream_t s, const GatherParams& g, const int32_t* sampled_ids,
+                            int32_t* cache_index_out, const int32_t* range, float* dst, int32_t dst_rows)
+{
+    static thread_local LanePtrs* d_lane = nullptr;
+    if (d_lane == nullptr) HIP_CALL(hipMalloc(&d_lane, sizeof(LanePtrs)));
+    LanePtrs h;
+    memset(&h, 0, sizeof(h));
+    h.sampled_ids = const_cast<int32_t*>(sampled_ids);
+    h.cache_search_buffer = cache_index_out;
+    h.node_counter = const_cast<int32_t*>(range);
+    h.float_features = dst;
+    h.feature_rows = dst_rows;
+    HIP_CALL(hipMemcpyAsync(d_lane, &h, sizeof(h), hipMemcpyHostToDevice, s));   // pageable source: staged before return
+    launch_gather_impl(s, g, d_lane, 1, false);
 }
 
 }  // namespace lg

@@ -93,53 +93,74 @@ void launch_draw_batch(hipStream_t s, const int32_t* idx, const int32_t* deg, in
 // ------------------------------------------------------------------------------------------
 // batch_generate + counter_update(0)
 // ------------------------------------------------------------------------------------------
-__global__ void batch_generate_kernel(int32_t* __restrict__ batch_ids, int32_t* __restrict__ labels,
-                                      int32_t size, int32_t counter,
-                                      const int32_t* __restrict__ all_ids,
-                                      const int32_t* __restrict__ all_labels, int32_t total_cap,
-                                      int32_t* __restrict__ position_map, int32_t* __restrict__ nc,
-                                      int32_t* __restrict__ ec, int32_t hop_num,
-                                      const int32_t* __restrict__ iter_state)
+__global__ void batch_generate_kernel(SeedParams p, const LanePtrs* __restrict__ lanes)
 {
+    const LanePtrs& L = lanes[blockIdx.y];
     const int32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (iter_state != nullptr) counter = iter_state[0];   // graph replay: iteration lives on the device
+    // lane i of a group takes iteration base + i; under graph replay the base lives on the device
+    const int32_t counter = (p.iter_state != nullptr ? p.iter_state[0] : p.counter0) + (int32_t)blockIdx.y;
+    // operator_impl.cu:159 -- the clamped last batch (may be <= 0: nothing is sampled)
+    const int32_t size = ((int64_t)p.batch_size * (counter + 1) >= p.total_cap)
+                             ? (p.total_cap - p.batch_size * counter) : p.batch_size;
     if (idx < 16) {                    // memset of both counter blocks, operator_impl.cu:155-156,
         int32_t v = 0;                 // then counter_update(op 0), :64-68
         if (idx == 1) v = size;
         if (idx == INTRABATCH_CON * 3) v = size;
-        if (idx == INTRABATCH_CON * 3 - 1) v = hop_num;
-        nc[idx] = v;
-        ec[idx] = 0;
+        if (idx == INTRABATCH_CON * 3 - 1) v = p.hop_num;
+        L.node_counter[idx] = v;
+        L.edge_counter[idx] = 0;
     }
     if (idx < size) {
         const int64_t at = (int64_t)size * counter + idx;     // kernel receives `size` as batch_size (:162)
-        if (at >= total_cap) {
-            batch_ids[idx] = -1;
-            labels[idx] = -1;
+        if (at >= p.total_cap) {
+            L.sampled_ids[idx] = -1;
+            L.labels[idx] = -1;
         } else {
-            const int32_t src_id = all_ids[at % total_cap];
-            batch_ids[idx] = src_id;
-            atomicMin(position_map + src_id, idx);            // seeds are unique (":26 assume no duplicate")
-            labels[idx] = all_labels[at % total_cap];
+            const int32_t src_id = p.all_ids[at % p.total_cap];
+            L.sampled_ids[idx] = src_id;
+            atomicMin(L.position_map + src_id, idx);          // seeds are unique (":26 assume no duplicate")
+            L.labels[idx] = p.all_labels[at % p.total_cap];
         }
     }
 }
 
-void launch_batch_generate(hipStream_t s, int32_t* batch_ids, int32_t* labels, int32_t size,
-                           int32_t counter, const int32_t* all_ids, const int32_t* all_labels,
-                           int32_t total_cap, int32_t* position_map, int32_t* node_counter,
-                           int32_t* edge_counter, int32_t hop_num, const int32_t* iter_state)
+void launch_batch_generate(hipStream_t s, const SeedParams& p, const LanePtrs* d_lanes, int32_t n_lanes)
 {
-    const int32_t n = size > 16 ? size : 16;
-    batch_generate_kernel<<<(n + 255) / 256, 256, 0, s>>>(batch_ids, labels, size, counter, all_ids,
-                                                         all_labels, total_cap, position_map,
-                                                         node_counter, edge_counter, hop_num, iter_state);
+    const int32_t n = p.batch_size > 16 ? p.batch_size : 16;
+    batch_generate_kernel<<<dim3((n + 255) / 256, n_lanes), 256, 0, s>>>(p, d_lanes);
     hipCheckError();
 }
 
 // ------------------------------------------------------------------------------------------
 // hop geometry shared by the three pre-scan kernels: read from the live counters
 // ------------------------------------------------------------------------------------------
+// the kernels' view of one lane: the launch-wide hop parameters + that lane's buffers
+struct SampleArgs {
+    int32_t op_id, count, partition_count, max_slots;
+    int32_t* const* csr_dst_node_ids;
+    const RowHdr* row_hdr;
+    bool last_hop, is_presc;
+    unsigned long long* edge_access_time;
+    int32_t* sampled_ids; int32_t* agg_src_ids; int32_t* agg_dst_ids; int32_t* agg_src_off; int32_t* agg_dst_off;
+    char* tmp_part_ind; int32_t* position_map; int32_t* node_counter; int32_t* edge_counter;
+    int32_t* slot_dst; int32_t* tile_counts; int32_t* tile_prefix; int32_t* hop_scratch; RowHdr* fh_edge;
+};
+
+__device__ __forceinline__ SampleArgs lane_args(const HopParams& p, const LanePtrs* __restrict__ lanes)
+{
+    const LanePtrs& L = lanes[blockIdx.y];
+    SampleArgs a;
+    a.op_id = p.op_id; a.count = p.count; a.partition_count = p.partition_count; a.max_slots = p.max_slots;
+    a.csr_dst_node_ids = p.csr_dst_node_ids; a.row_hdr = p.row_hdr; a.last_hop = p.last_hop; a.is_presc = p.is_presc;
+    a.edge_access_time = p.edge_access_time;
+    a.sampled_ids = L.sampled_ids; a.agg_src_ids = L.agg_src_ids; a.agg_dst_ids = L.agg_dst_ids;
+    a.agg_src_off = L.agg_src_off; a.agg_dst_off = L.agg_dst_off; a.tmp_part_ind = L.tmp_part_ind;
+    a.position_map = L.position_map; a.node_counter = L.node_counter; a.edge_counter = L.edge_counter;
+    a.slot_dst = L.slot_dst; a.tile_counts = L.tile_counts; a.tile_prefix = L.tile_prefix;
+    a.hop_scratch = L.hop_scratch; a.fh_edge = L.fh_edge;
+    return a;
+}
+
 struct HopGeom {
     const int32_t* frontier;
     int32_t frontier_len;
@@ -178,8 +199,9 @@ __device__ __forceinline__ HopGeom hop_geometry(const SampleArgs& a)
 // coalesced 16-byte load per frontier entry), for hop 1 they are looked up in the per-vertex
 // header table here.
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(LG_TILE) void sample_kernel(SampleArgs a)
+__global__ __launch_bounds__(LG_TILE) void sample_kernel(HopParams hp, const LanePtrs* __restrict__ lanes)
 {
+    const SampleArgs a = lane_args(hp, lanes);
     __shared__ RowHdr s_hdr[LG_SUPER];
 
     const HopGeom g = hop_geometry(a);
@@ -253,8 +275,9 @@ __global__ __launch_bounds__(LG_TILE) void sample_kernel(SampleArgs a)
 // ------------------------------------------------------------------------------------------
 // K2: per-256-slot-tile counts of valid edges and first touches
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(LG_TILE) void flag_count_kernel(SampleArgs a)
+__global__ __launch_bounds__(LG_TILE) void flag_count_kernel(HopParams hp, const LanePtrs* __restrict__ lanes)
 {
+    const SampleArgs a = lane_args(hp, lanes);
     __shared__ int32_t s_cnt[LG_SLOTS_PER_LANE][2][LG_TILE / 64];
     const HopGeom g = hop_geometry(a);
     const int32_t tid = threadIdx.x;
@@ -302,8 +325,9 @@ __global__ __launch_bounds__(LG_TILE) void flag_count_kernel(SampleArgs a)
 //     copy the following gather op would make (counter_update(op+1)).
 // ------------------------------------------------------------------------------------------
 #define LG_SCAN_THREADS 1024
-__global__ __launch_bounds__(LG_SCAN_THREADS) void scan_kernel(SampleArgs a)
+__global__ __launch_bounds__(LG_SCAN_THREADS) void scan_kernel(HopParams hp, const LanePtrs* __restrict__ lanes)
 {
+    const SampleArgs a = lane_args(hp, lanes);
     __shared__ int32_t s_e[LG_SCAN_THREADS];
     __shared__ int32_t s_n[LG_SCAN_THREADS];
     const HopGeom g = hop_geometry(a);
@@ -366,8 +390,9 @@ __global__ __launch_bounds__(LG_SCAN_THREADS) void scan_kernel(SampleArgs a)
 // edges and the new nodes it writes, next to every edge, the row header of the sampled
 // neighbour: the next hop's frontier then needs no dependent lookup.
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(LG_TILE) void scatter_kernel(SampleArgs a)
+__global__ __launch_bounds__(LG_TILE) void scatter_kernel(HopParams hp, const LanePtrs* __restrict__ lanes)
 {
+    const SampleArgs a = lane_args(hp, lanes);
     __shared__ int32_t s_cnt[LG_SLOTS_PER_LANE][2][LG_TILE / 64];
     const int32_t* hs = a.hop_scratch;
     const int32_t total = hs[HS_SLOTS];
@@ -433,8 +458,9 @@ __global__ __launch_bounds__(LG_TILE) void scatter_kernel(SampleArgs a)
 // ------------------------------------------------------------------------------------------
 // K5: construct_graph's neighbour side
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(LG_TILE) void localise_kernel(SampleArgs a)
+__global__ __launch_bounds__(LG_TILE) void localise_kernel(HopParams hp, const LanePtrs* __restrict__ lanes)
 {
+    const SampleArgs a = lane_args(hp, lanes);
     const int32_t* hs = a.hop_scratch;
     const int32_t n_edge = hs[HS_N_EDGE], edge_base = hs[HS_EDGE_BASE];
     const int32_t nsuper = (n_edge + LG_SUPER - 1) / LG_SUPER;
@@ -455,23 +481,23 @@ __global__ __launch_bounds__(LG_TILE) void localise_kernel(SampleArgs a)
     }
 }
 
-void launch_random_sample(hipStream_t s, const SampleArgs& a)
+void launch_random_sample(hipStream_t s, const HopParams& p, const LanePtrs* d_lanes, int32_t n_lanes)
 {
-    // Fixed grids that stride over super tiles.  The cap keeps one hop from occupying every wave
-    // slot of the chip while its lanes wait on memory, so kernels of other in-flight batches
-    // (pipeline lanes) can run beside it.
-    int32_t max_super = (a.max_slots + LG_SUPER - 1) / LG_SUPER;
+    // Fixed grids that stride over super tiles; grid.y = lanes (independent mini-batches of a group).
+    int32_t max_super = (p.max_slots + LG_SUPER - 1) / LG_SUPER;
     if (max_super < 1) max_super = 1;
-    const int32_t grid = max_super < 1024 ? max_super : 1024;
-    sample_kernel<<<grid, LG_TILE, 0, s>>>(a);
+    int32_t gx = max_super < 1024 ? max_super : 1024;
+    while (gx > 64 && (int64_t)gx * n_lanes > 4096) gx /= 2;    // keep the whole launch near 2 x resident capacity
+    const dim3 grid(gx, n_lanes);
+    sample_kernel<<<grid, LG_TILE, 0, s>>>(p, d_lanes);
     hipCheckError();
-    flag_count_kernel<<<grid, LG_TILE, 0, s>>>(a);
+    flag_count_kernel<<<grid, LG_TILE, 0, s>>>(p, d_lanes);
     hipCheckError();
-    scan_kernel<<<1, LG_SCAN_THREADS, 0, s>>>(a);
+    scan_kernel<<<dim3(1, n_lanes), LG_SCAN_THREADS, 0, s>>>(p, d_lanes);
     hipCheckError();
-    scatter_kernel<<<grid, LG_TILE, 0, s>>>(a);
+    scatter_kernel<<<grid, LG_TILE, 0, s>>>(p, d_lanes);
     hipCheckError();
-    localise_kernel<<<grid, LG_TILE, 0, s>>>(a);
+    localise_kernel<<<grid, LG_TILE, 0, s>>>(p, d_lanes);
     hipCheckError();
 }
 
@@ -529,24 +555,25 @@ void cache_row_headers(hipStream_t s, RowHdr* hdr, const int32_t* QT, int32_t Kg
 // position_map in train mode only, operator_impl.cu:542-548; here the state array doubles as the
 // accessed bitmap, so it is restored in every mode instead of memsetting N/8 bytes per batch).
 // ------------------------------------------------------------------------------------------
-__global__ void clear_pos_map_kernel(int32_t* __restrict__ position_map,
-                                     const int32_t* __restrict__ sampled_ids,
-                                     const int32_t* __restrict__ nc, int32_t* __restrict__ iter_state)
+__global__ void clear_pos_map_kernel(const LanePtrs* __restrict__ lanes, int32_t* __restrict__ iter_state)
 {
-    // last kernel of a batch: advance the device-resident iteration for the next graph replay
-    if (iter_state != nullptr && blockIdx.x == 0 && threadIdx.x == 0) iter_state[0] += iter_state[1];
+    const LanePtrs& L = lanes[blockIdx.y];
+    // last kernel of a batch group: advance the device-resident iteration for the next graph replay
+    if (iter_state != nullptr && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) iter_state[0] += iter_state[1];
+    const int32_t* nc = L.node_counter;
     const int32_t hop_num = nc[INTRABATCH_CON * 3 - 1];
     const int32_t total = nc[INTRABATCH_CON * 3 + hop_num];
     for (int32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
-        const int32_t id = sampled_ids[i];
-        if (id >= 0) position_map[id] = LG_POS_UNTOUCHED;
+        const int32_t id = L.sampled_ids[i];
+        if (id >= 0) L.position_map[id] = LG_POS_UNTOUCHED;
     }
 }
 
-void launch_clear_pos_map(hipStream_t s, int32_t* position_map, const int32_t* sampled_ids,
-                          const int32_t* node_counter, int32_t* iter_state)
+void launch_clear_pos_map(hipStream_t s, const LanePtrs* d_lanes, int32_t n_lanes, int32_t* iter_state)
 {
-    clear_pos_map_kernel<<<512, 256, 0, s>>>(position_map, sampled_ids, node_counter, iter_state);
+    int32_t gx = 512;
+    while (gx > 64 && gx * n_lanes > 2048) gx /= 2;
+    clear_pos_map_kernel<<<dim3(gx, n_lanes), 256, 0, s>>>(d_lanes, iter_state);
     hipCheckError();
 }
 

@@ -102,6 +102,32 @@ struct BuildInfo {  // SS/include/buildinfo.h (only the fields of the in-memory 
     int32_t raw_batch_size = 0;
 };
 
+// Everything a kernel needs to know about ONE in-flight mini-batch (a lane): the buffers of its
+// MemoryPool.  Arrays of these live in device memory; kernels are launched with grid.y = number of
+// lanes and each workgroup works on lanes[blockIdx.y], so one launch serves a whole group of
+// independent mini-batches (the per-kernel latency floor is paid once per group, not per batch).
+struct LanePtrs {
+    int32_t* sampled_ids;
+    int32_t* labels;
+    int32_t* agg_src_ids;
+    int32_t* agg_dst_ids;
+    int32_t* agg_src_off;
+    int32_t* agg_dst_off;
+    char* tmp_part_ind;
+    int32_t* position_map;
+    int32_t* node_counter;
+    int32_t* edge_counter;
+    int32_t* slot_dst;
+    int32_t* tile_counts;
+    int32_t* tile_prefix;
+    int32_t* hop_scratch;
+    RowHdr* fh_edge;
+    int32_t* cache_search_buffer;
+    float* float_features;
+    int32_t feature_rows;
+    int32_t pad_;
+};
+
 // ---------------------------------------------------------------------------------------------
 class MemoryPool {
 public:
@@ -129,20 +155,23 @@ public:
     char* GetTmpPartIdx() const { return tmp_part_ind_; }
     int32_t* GetTmpPartOff() const { return tmp_part_off_; }
 
-    void SetFloatFeatures(float* p, int32_t pipe) { float_features_[pipe] = p; }
-    void SetCacheSearchBuffer(int32_t* p) { cache_search_buffer_ = p; }
-    void SetLabels(int32_t* p, int32_t pipe) { labels_[pipe] = p; }
-    void SetPositionMap(int32_t* p) { position_map_ = p; }
-    void SetNodeCounter(int32_t* p, int32_t pipe) { node_counter_[pipe] = p; }
-    void SetEdgeCounter(int32_t* p, int32_t pipe) { edge_counter_[pipe] = p; }
-    void SetSampledIds(int32_t* p, int32_t pipe) { sampled_ids_[pipe] = p; }
-    void SetAggSrcId(int32_t* p) { agg_src_ids_ = p; }
-    void SetAggDstId(int32_t* p) { agg_dst_ids_ = p; }
-    void SetAggSrcOf(int32_t* p, int32_t pipe) { agg_src_off_[pipe] = p; }
-    void SetAggDstOf(int32_t* p, int32_t pipe) { agg_dst_off_[pipe] = p; }
-    void SetTmpPartIdx(char* p) { tmp_part_ind_ = p; }
+    void SetFloatFeatures(float* p, int32_t pipe) { float_features_[pipe] = p; lanes_dirty_ = true; }
+    void SetCacheSearchBuffer(int32_t* p) { cache_search_buffer_ = p; lanes_dirty_ = true; }
+    void SetLabels(int32_t* p, int32_t pipe) { labels_[pipe] = p; lanes_dirty_ = true; }
+    void SetPositionMap(int32_t* p) { position_map_ = p; lanes_dirty_ = true; }
+    void SetNodeCounter(int32_t* p, int32_t pipe) { node_counter_[pipe] = p; lanes_dirty_ = true; }
+    void SetEdgeCounter(int32_t* p, int32_t pipe) { edge_counter_[pipe] = p; lanes_dirty_ = true; }
+    void SetSampledIds(int32_t* p, int32_t pipe) { sampled_ids_[pipe] = p; lanes_dirty_ = true; }
+    void SetAggSrcId(int32_t* p) { agg_src_ids_ = p; lanes_dirty_ = true; }
+    void SetAggDstId(int32_t* p) { agg_dst_ids_ = p; lanes_dirty_ = true; }
+    void SetAggSrcOf(int32_t* p, int32_t pipe) { agg_src_off_[pipe] = p; lanes_dirty_ = true; }
+    void SetAggDstOf(int32_t* p, int32_t pipe) { agg_dst_off_[pipe] = p; lanes_dirty_ = true; }
+    void SetTmpPartIdx(char* p) { tmp_part_ind_ = p; lanes_dirty_ = true; }
     void SetTmpPartOff(int32_t* p) { tmp_part_off_ = p; }
     void SetCurrentPipe(int32_t pipe) { current_pipe_ = pipe; }
+    LanePtrs HostLane(int32_t pipe) const;          // the pool's buffers of one pipe slot
+    const LanePtrs* DeviceLane();                    // device copy of HostLane(current pipe)
+    void InvalidateDeviceLanes() { lanes_dirty_ = true; }
     void SetCurrentMode(int32_t mode) { mode_ = mode; }
     void SetIter(int32_t iter) { iter_ = iter; }
 
@@ -185,6 +214,9 @@ private:
     int32_t* tmp_part_off_ = nullptr;
     int32_t pipeline_depth_;
     int32_t current_pipe_ = 0;
+    LanePtrs* d_lanes_ = nullptr;      // [pipeline_depth] device copies
+    bool lanes_dirty_ = true;
+    int64_t uploaded_rows_ = -1;
     std::vector<float*> float_features_;
     std::vector<int32_t*> labels_;
     std::vector<int32_t*> node_counter_;
@@ -284,9 +316,9 @@ public:
     void FillUp(int cache_agg_mode, FeatureStorage* feature, GraphStorage* graph);
     int32_t MaxIdNum(int32_t dev_id);
     unsigned long long int* GetEdgeAccessedMap(int32_t dev_id);
-    void FeatCacheLookup(int32_t* sampled_ids, int32_t* cache_index, int32_t* node_counter,
-                         float* dst_float_buffer, int32_t op_id, int32_t dev_id, hipStream_t strm_hdl,
-                         int32_t max_rows, int32_t dst_rows);
+    // the gather over a group of lanes (the reference's per-array arguments live in LanePtrs)
+    void FeatCacheLookup(const LanePtrs* d_lanes, int32_t n_lanes, int32_t op_id, int32_t dev_id,
+                         hipStream_t strm_hdl, int32_t max_rows);
 
     // new / exposed for the C API and the fused kernels
     void SetCapacity(int32_t node_capacity, int32_t edge_capacity);
@@ -417,47 +449,45 @@ extern "C" int32_t GetGPUDevice();
 // kernel launchers (kernels_*.hip)
 namespace lg {
 
-void launch_batch_generate(hipStream_t s, int32_t* batch_ids, int32_t* labels, int32_t size,
-                           int32_t counter, const int32_t* all_ids, const int32_t* all_labels,
-                           int32_t total_cap, int32_t* position_map, int32_t* node_counter,
-                           int32_t* edge_counter, int32_t hop_num, const int32_t* iter_state);
-
-struct SampleArgs {
+struct HopParams {                  // what every lane of a launch shares
     int32_t op_id;
     int32_t count;                  // fan-out of this hop
     int32_t partition_count;        // P: slot of the full CSR in the pointer tables
     int32_t* const* csr_dst_node_ids;   // device table [P+1] of column arrays
     const RowHdr* row_hdr;          // [N] per-vertex row headers of this GPU
-    RowHdr* fh_edge;                // [num_ids] header of every sampled neighbour, next to its edge
     bool last_hop;                  // no next hop: scatter skips the header lookup
-    int32_t* sampled_ids;
-    int32_t* agg_src_ids;
-    int32_t* agg_dst_ids;
-    int32_t* agg_src_off;
-    int32_t* agg_dst_off;
-    char* tmp_part_ind;
-    int32_t* tmp_part_off;
-    int32_t* position_map;
-    int32_t* node_counter;
-    int32_t* edge_counter;
-    int32_t* slot_dst;
-    int32_t* tile_counts;
-    int32_t* tile_prefix;
-    int32_t* hop_scratch;
-    int32_t max_slots;              // capacity of slot_dst for this hop
-    unsigned long long* edge_access_time;  // presample only, else null
     bool is_presc;
+    int32_t max_slots;              // capacity of slot_dst for this hop
+    unsigned long long* edge_access_time;  // presample only (single lane), else null
 };
-void launch_random_sample(hipStream_t s, const SampleArgs& a);
+void launch_random_sample(hipStream_t s, const HopParams& p, const LanePtrs* d_lanes, int32_t n_lanes);
 
-void launch_gather(hipStream_t s, const float* full_table, const float* const* cache_tables,
-                   const int32_t* node_map, int32_t node_capacity, int32_t D, int32_t total_num_nodes,
-                   const int32_t* sampled_ids, int32_t* cache_index_out, const int32_t* range,
-                   int32_t* range_copy /* node_counter+2 or null */, float* dst, int32_t max_rows,
-                   int32_t dst_rows /* rows the destination buffer holds */);
+struct GatherParams {
+    const float* full_table;
+    const float* const* cache_tables;
+    const int32_t* node_map;
+    int32_t node_capacity;
+    int32_t D;
+    int32_t total_num_nodes;
+    int32_t max_rows;               // grid bound: rows any lane can have for this op
+};
+void launch_gather(hipStream_t s, const GatherParams& g, const LanePtrs* d_lanes, int32_t n_lanes);
+// stand-alone form for tests / probes: explicit arrays, one lane
+void launch_gather_explicit(hipStream_t s, const GatherParams& g, const int32_t* sampled_ids,
+                            int32_t* cache_index_out, const int32_t* range, float* dst, int32_t dst_rows);
 
-void launch_clear_pos_map(hipStream_t s, int32_t* position_map, const int32_t* sampled_ids,
-                          const int32_t* node_counter, int32_t* iter_state);
+struct SeedParams {
+    int32_t batch_size;
+    int32_t counter0;               // lane i takes iteration counter0 + i (or iter_state[0] + i)
+    const int32_t* all_ids;
+    const int32_t* all_labels;
+    int32_t total_cap;
+    int32_t hop_num;
+    const int32_t* iter_state;      // device {next iteration, stride} or null
+};
+void launch_batch_generate(hipStream_t s, const SeedParams& p, const LanePtrs* d_lanes, int32_t n_lanes);
+
+void launch_clear_pos_map(hipStream_t s, const LanePtrs* d_lanes, int32_t n_lanes, int32_t* iter_state);
 void launch_hotness_measure(hipStream_t s, const int32_t* sampled_ids, const int32_t* node_counter,
                             unsigned long long* access_map);
 void init_row_headers(hipStream_t s, RowHdr* hdr, const int64_t* csr_index, int32_t n, int32_t slot);

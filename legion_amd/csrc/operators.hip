@@ -30,21 +30,19 @@ extern "C" void RandomSample(legion_stream_t strm_hdl, LegionGraphStorage* graph
 // UnifiedCache as its first member (cache.hip: LegionCacheBox).
 static inline UnifiedCache* cache_of(LegionUnifiedCache* c) { return reinterpret_cast<UnifiedCache*>(c); }
 
-extern "C" void BatchGenerate(legion_stream_t strm_hdl, LegionFeatureStorage* feature_,
-                              LegionUnifiedCache* cache_, LegionMemoryPool* memorypool_,
-                              int32_t batch_size, int32_t counter, int32_t part_id, int32_t dev_id,
-                              int32_t mode, bool is_presc, int32_t hop_num)
+// ---- lane-group bodies: every operator works on n lanes (n = 1 for the reference-shaped calls) ----
+struct LegionLaneGroup {
+    std::vector<MemoryPool*> pools;
+    LanePtrs* d_lanes = nullptr;      // contiguous device copy of every pool's current lane
+    int32_t* iter_state = nullptr;    // device {next iteration of lane 0, stride} for graph replay, or null
+};
+
+static bool seed_set(FeatureStorage* feature, int32_t dev_id, int32_t mode, int32_t*& all_ids, int32_t*& all_labels,
+                     int32_t& total_cap)
 {
-    (void)part_id; (void)cache_; (void)is_presc;
-    FeatureStorage* feature = reinterpret_cast<FeatureStorage*>(feature_);
-    MemoryPool* memorypool = reinterpret_cast<MemoryPool*>(memorypool_);
-    if (feature == nullptr || memorypool == nullptr) {
-        std::cout << "invalid storage ptr\n";
-        return;
-    }
-    int32_t* all_ids = nullptr;
-    int32_t* all_labels = nullptr;
-    int32_t total_cap = 0;
+    all_ids = nullptr;
+    all_labels = nullptr;
+    total_cap = 0;
     if (mode == TRAINMODE) {
         all_ids = feature->GetTrainingSetIds(dev_id);
         all_labels = feature->GetTrainingLabels(dev_id);
@@ -62,24 +60,100 @@ extern "C" void BatchGenerate(legion_stream_t strm_hdl, LegionFeatureStorage* fe
     }
     if (all_ids == nullptr) {
         std::cout << "invalid src id ptr\n";
-        return;
+        return false;
     }
     if (all_labels == nullptr) {
         std::cout << "invalid label ptr\n";
+        return false;
+    }
+    return true;
+}
+
+static void do_batch_generate(hipStream_t s, FeatureStorage* feature, const LanePtrs* d_lanes, int32_t n_lanes,
+                              MemoryPool* pool0, int32_t batch_size, int32_t counter, int32_t dev_id, int32_t mode,
+                              int32_t hop_num, const int32_t* iter_state)
+{
+    lg::SeedParams p;
+    int32_t* all_ids = nullptr;
+    int32_t* all_labels = nullptr;
+    if (!seed_set(feature, dev_id, mode, all_ids, all_labels, p.total_cap)) return;
+    p.all_ids = all_ids;
+    p.all_labels = all_labels;
+    if (batch_size > pool0->batch_size) {
+        std::cout << "batch size " << batch_size << " exceeds the pool's " << pool0->batch_size << "\n";
         return;
     }
-    if (batch_size > memorypool->batch_size) {
-        std::cout << "batch size " << batch_size << " exceeds the pool's " << memorypool->batch_size << "\n";
+    p.batch_size = batch_size;
+    p.counter0 = counter;
+    p.hop_num = hop_num;
+    p.iter_state = iter_state;
+    lg::launch_batch_generate(s, p, d_lanes, n_lanes);
+    // cache->FindFeat(op 0) (operator_impl.cu:167-170) happens inside FeatureCacheLookup(op 1)
+}
+
+static void do_random_sample(hipStream_t s, GraphStorage* graph, UnifiedCache* cache, const LanePtrs* d_lanes,
+                             int32_t n_lanes, MemoryPool* pool0, int32_t count, int32_t dev_id, int32_t op_id,
+                             bool is_presc)
+{
+    if (op_id < INTRABATCH_CON || op_id % INTRABATCH_CON != 0 || count < 1) {
+        printf("Sampling Parameters Error\n");   // counter_update's complaint, operator_impl.cu:86-88
         return;
     }
-    // operator_impl.cu:159
-    const int32_t size = ((int64_t)batch_size * (counter + 1) >= total_cap) ? (total_cap - batch_size * counter)
-                                                                          : batch_size;
-    lg::launch_batch_generate(static_cast<hipStream_t>(strm_hdl), memorypool->GetSampledIds(),
-                              memorypool->GetLabels(), size, counter, all_ids, all_labels, total_cap,
-                              memorypool->GetPositionMap(), memorypool->GetNodeCounter(),
-                              memorypool->GetEdgeCounter(), hop_num, memorypool->iter_state);
-    // cache->FindFeat(op 0) (:167-170) happens inside FeatureCacheLookup(op 1)
+    lg::HopParams p;
+    p.op_id = op_id;
+    p.count = count;
+    p.partition_count = graph->GetPartitionCount();
+    p.csr_dst_node_ids = graph->GetCSRNodeMatrix(dev_id);
+    p.row_hdr = graph->GetRowHeaders(dev_id);
+    p.last_hop = (size_t)(op_id / INTRABATCH_CON) + 1 >= pool0->max_new.size();
+    p.is_presc = is_presc;
+    const size_t hop = (size_t)(op_id / INTRABATCH_CON);          // slots of this hop <= B f1..fh
+    p.max_slots = (int32_t)(hop < pool0->max_new.size() ? pool0->max_new[hop] : pool0->max_slots);
+    p.edge_access_time = (is_presc && cache) ? cache->GetEdgeAccessedMap(dev_id) : nullptr;   // :473
+    lg::launch_random_sample(s, p, d_lanes, n_lanes);
+}
+
+static void do_feature_lookup(hipStream_t s, UnifiedCache* cache, const LanePtrs* d_lanes, int32_t n_lanes,
+                              MemoryPool* pool0, int32_t op_id, int32_t dev_id, std::vector<MemoryPool*>* prof_pools)
+{
+    if (pool0->GetFloatFeatures() == nullptr) {
+        std::cout << "feature buffer not initialized\n";
+        return;
+    }
+    if (cache->FeatureTable() == nullptr) {   // bound by FillUp (cache.cu:581-582) or legion_enqueue_batch
+        std::cout << "invalid feature table ptr\n";
+        return;
+    }
+    int64_t max_rows = pool0->feature_rows;
+    if (max_rows > pool0->num_ids) max_rows = pool0->num_ids;
+    const size_t hop = (size_t)(op_id / INTRABATCH_CON);          // grid bound: new nodes of op 3h <= B f1..fh
+    if (hop < pool0->max_new.size() && pool0->max_new[hop] < max_rows) max_rows = pool0->max_new[hop];
+    MemoryPool* pp = pool0;
+    const bool prof = pp->prof_on && (size_t)(2 * pp->prof_used + 1) < pp->prof_events.size();
+    (void)prof_pools;
+    if (prof) HIP_CALL(hipEventRecord(pp->prof_events[2 * pp->prof_used], s));
+    cache->FeatCacheLookup(d_lanes, n_lanes, op_id, dev_id, s, (int32_t)max_rows);
+    if (prof) {
+        HIP_CALL(hipEventRecord(pp->prof_events[2 * pp->prof_used + 1], s));
+        pp->prof_op[pp->prof_used] = op_id;
+        pp->prof_used++;
+    }
+}
+
+extern "C" void BatchGenerate(legion_stream_t strm_hdl, LegionFeatureStorage* feature_,
+                              LegionUnifiedCache* cache_, LegionMemoryPool* memorypool_,
+                              int32_t batch_size, int32_t counter, int32_t part_id, int32_t dev_id,
+                              int32_t mode, bool is_presc, int32_t hop_num)
+{
+    (void)part_id; (void)cache_; (void)is_presc;
+    FeatureStorage* feature = reinterpret_cast<FeatureStorage*>(feature_);
+    MemoryPool* memorypool = reinterpret_cast<MemoryPool*>(memorypool_);
+    if (feature == nullptr || memorypool == nullptr) {
+        std::cout << "invalid storage ptr\n";
+        return;
+    }
+    do_batch_generate(static_cast<hipStream_t>(strm_hdl), feature, memorypool->DeviceLane(), 1, memorypool,
+                      batch_size, counter, dev_id, mode, hop_num, memorypool->iter_state);
 }
 
 extern "C" void RandomSample(legion_stream_t strm_hdl, LegionGraphStorage* graph_, LegionUnifiedCache* cache_,
@@ -88,41 +162,12 @@ extern "C" void RandomSample(legion_stream_t strm_hdl, LegionGraphStorage* graph
 {
     GraphStorage* graph = reinterpret_cast<GraphStorage*>(graph_);
     MemoryPool* memorypool = reinterpret_cast<MemoryPool*>(memorypool_);
-    UnifiedCache* cache = cache_of(cache_);
     if (graph == nullptr || memorypool == nullptr) {
         std::cout << "invalid storage ptr\n";
         return;
     }
-    if (op_id < INTRABATCH_CON || op_id % INTRABATCH_CON != 0 || count < 1) {
-        printf("Sampling Parameters Error\n");   // counter_update's complaint, operator_impl.cu:86-88
-        return;
-    }
-    lg::SampleArgs a;
-    a.op_id = op_id;
-    a.count = count;
-    a.partition_count = graph->GetPartitionCount();
-    a.csr_dst_node_ids = graph->GetCSRNodeMatrix(dev_id);
-    a.row_hdr = graph->GetRowHeaders(dev_id);
-    a.fh_edge = memorypool->fh_edge;
-    a.last_hop = (size_t)(op_id / INTRABATCH_CON) + 1 >= memorypool->max_new.size();
-    a.sampled_ids = memorypool->GetSampledIds();
-    a.agg_src_ids = memorypool->GetAggSrcId();
-    a.agg_dst_ids = memorypool->GetAggDstId();
-    a.agg_src_off = memorypool->GetAggSrcOf();
-    a.agg_dst_off = memorypool->GetAggDstOf();
-    a.tmp_part_ind = memorypool->GetTmpPartIdx();
-    a.tmp_part_off = memorypool->GetTmpPartOff();
-    a.position_map = memorypool->GetPositionMap();
-    a.node_counter = memorypool->GetNodeCounter();
-    a.edge_counter = memorypool->GetEdgeCounter();
-    a.slot_dst = memorypool->slot_dst;
-    a.tile_counts = memorypool->tile_counts;
-    a.tile_prefix = memorypool->tile_prefix;
-    a.hop_scratch = memorypool->hop_scratch;
-    a.max_slots = memorypool->max_slots;
-    a.is_presc = is_presc;
-    a.edge_access_time = (is_presc && cache) ? cache->GetEdgeAccessedMap(dev_id) : nullptr;   // :473
-    lg::launch_random_sample(static_cast<hipStream_t>(strm_hdl), a);
+    do_random_sample(static_cast<hipStream_t>(strm_hdl), graph, cache_of(cache_), memorypool->DeviceLane(), 1,
+                     memorypool, count, dev_id, op_id, is_presc);
 }
 
 extern "C" void FeatureCacheLookup(legion_stream_t strm_hdl, LegionUnifiedCache* cache_,
@@ -134,30 +179,8 @@ extern "C" void FeatureCacheLookup(legion_stream_t strm_hdl, LegionUnifiedCache*
         std::cout << "invalid storage ptr\n";
         return;
     }
-    if (memorypool->GetFloatFeatures() == nullptr) {
-        std::cout << "feature buffer not initialized\n";
-        return;
-    }
-    if (cache->FeatureTable() == nullptr) {   // bound by FillUp (cache.cu:581-582) or legion_enqueue_batch
-        std::cout << "invalid feature table ptr\n";
-        return;
-    }
-    int64_t max_rows = memorypool->feature_rows;
-    if (max_rows > memorypool->num_ids) max_rows = memorypool->num_ids;
-    const int32_t dst_rows = (int32_t)max_rows;
-    const size_t hop = (size_t)(op_id / INTRABATCH_CON);          // grid bound: new nodes of op 3h <= B f1..fh
-    if (hop < memorypool->max_new.size() && memorypool->max_new[hop] < max_rows) max_rows = memorypool->max_new[hop];
-    hipStream_t s = static_cast<hipStream_t>(strm_hdl);
-    const bool prof = memorypool->prof_on && (size_t)(2 * memorypool->prof_used + 1) < memorypool->prof_events.size();
-    if (prof) HIP_CALL(hipEventRecord(memorypool->prof_events[2 * memorypool->prof_used], s));
-    cache->FeatCacheLookup(memorypool->GetSampledIds(), memorypool->GetCacheSearchBuffer(),
-                           memorypool->GetNodeCounter(), memorypool->GetFloatFeatures(), op_id, dev_id,
-                           s, (int32_t)max_rows, dst_rows);
-    if (prof) {
-        HIP_CALL(hipEventRecord(memorypool->prof_events[2 * memorypool->prof_used + 1], s));
-        memorypool->prof_op[memorypool->prof_used] = op_id;
-        memorypool->prof_used++;
-    }
+    do_feature_lookup(static_cast<hipStream_t>(strm_hdl), cache, memorypool->DeviceLane(), 1, memorypool, op_id,
+                      dev_id, nullptr);
 }
 
 extern "C" void IOSubmit(legion_stream_t, LegionFeatureStorage*, LegionMemoryPool*, int32_t, int32_t)
@@ -179,8 +202,7 @@ extern "C" void IOComplete(legion_stream_t strm_hdl, LegionUnifiedCache* cache_,
         cache->CacheProfiling(memorypool->GetSampledIds(), memorypool->GetAggSrcId(), memorypool->GetAggDstId(),
                               memorypool->GetAggSrcOf(), memorypool->GetAggDstOf(), memorypool->GetNodeCounter(),
                               memorypool->GetEdgeCounter(), s, dev_id);
-    lg::launch_clear_pos_map(s, memorypool->GetPositionMap(), memorypool->GetSampledIds(),
-                             memorypool->GetNodeCounter(), memorypool->iter_state);
+    lg::launch_clear_pos_map(s, memorypool->DeviceLane(), 1, memorypool->iter_state);
 }
 
 // =============================================================================================
@@ -271,9 +293,16 @@ extern "C" void legion_gather_rows(legion_stream_t stream, const float* full_tab
                                    const int32_t* sampled_ids, int32_t* cache_index_out,
                                    const int32_t* range_devptr, float* dst, int32_t max_rows)
 {
-    lg::launch_gather(static_cast<hipStream_t>(stream), full_table, cache_tables, node_map, node_capacity,
-                      float_feature_len, total_num_nodes, sampled_ids, cache_index_out, range_devptr, nullptr,
-                      dst, max_rows, 0x7FFFFFFF);
+    lg::GatherParams g;
+    g.full_table = full_table;
+    g.cache_tables = cache_tables;
+    g.node_map = node_map;
+    g.node_capacity = node_capacity;
+    g.D = float_feature_len;
+    g.total_num_nodes = total_num_nodes;
+    g.max_rows = max_rows;
+    lg::launch_gather_explicit(static_cast<hipStream_t>(stream), g, sampled_ids, cache_index_out, range_devptr, dst,
+                               0x7FFFFFFF);
 }
 
 extern "C" void legion_draw_batch(legion_stream_t stream, const int32_t* idx, const int32_t* deg, int32_t* out,
@@ -285,29 +314,75 @@ extern "C" void legion_draw_batch(legion_stream_t stream, const int32_t* idx, co
 // One whole mini-batch in the op order of GPURunner::RunOnce / RunPreSc (SS/engine/server.cu:285-332)
 // without the IPC hand-off: what a Runner enqueues per batch, exposed for callers that own the
 // buffers themselves (tests, bench.py, an in-process trainer).
+static void enqueue_lanes(hipStream_t s, GraphStorage* graph, FeatureStorage* feature, UnifiedCache* cache,
+                          const LanePtrs* d_lanes, int32_t n_lanes, MemoryPool* pool0, int32_t* iter_state,
+                          int32_t batch_size, int32_t counter, int32_t dev_id, int32_t mode, bool is_presc,
+                          const int32_t* fanout, int32_t hop_num)
+{
+    if (cache && feature && cache->FeatureTable() == nullptr)
+        cache->BindFeatureTable(feature->GetAllFloatFeature(), feature->TotalNodeNum());
+    do_batch_generate(s, feature, d_lanes, n_lanes, pool0, batch_size, counter, dev_id, mode, hop_num, iter_state);
+    if (!is_presc) do_feature_lookup(s, cache, d_lanes, n_lanes, pool0, 1, dev_id, nullptr);
+    for (int32_t h = 0; h < hop_num; h++) {
+        const int32_t op = INTRABATCH_CON * (h + 1);
+        do_random_sample(s, graph, cache, d_lanes, n_lanes, pool0, fanout[h], dev_id, op, is_presc);
+        if (!is_presc) do_feature_lookup(s, cache, d_lanes, n_lanes, pool0, op + 1, dev_id, nullptr);
+    }
+    if (is_presc && mode == TRAINMODE && cache != nullptr)     // CacheProfiling (one lane only in PreSC)
+        cache->CacheProfiling(pool0->GetSampledIds(), pool0->GetAggSrcId(), pool0->GetAggDstId(), pool0->GetAggSrcOf(),
+                              pool0->GetAggDstOf(), pool0->GetNodeCounter(), pool0->GetEdgeCounter(), s, dev_id);
+    lg::launch_clear_pos_map(s, d_lanes, n_lanes, iter_state);
+}
+
 extern "C" void legion_enqueue_batch(legion_stream_t strm_hdl, LegionGraphStorage* graph, LegionFeatureStorage* feature,
                                      LegionUnifiedCache* cache, LegionMemoryPool* memorypool, int32_t batch_size,
                                      int32_t counter, int32_t dev_id, int32_t mode, bool is_presc,
                                      const int32_t* fanout, int32_t hop_num)
 {
-    if (cache && feature && cache_of(cache)->FeatureTable() == nullptr) {
-        FeatureStorage* f = reinterpret_cast<FeatureStorage*>(feature);
-        cache_of(cache)->BindFeatureTable(f->GetAllFloatFeature(), f->TotalNodeNum());
+    MemoryPool* mp = reinterpret_cast<MemoryPool*>(memorypool);
+    if (!graph || !feature || !mp) { std::cout << "invalid storage ptr\n"; return; }
+    enqueue_lanes(static_cast<hipStream_t>(strm_hdl), reinterpret_cast<GraphStorage*>(graph),
+                  reinterpret_cast<FeatureStorage*>(feature), cache_of(cache), mp->DeviceLane(), 1, mp, mp->iter_state,
+                  batch_size, counter, dev_id, mode, is_presc, fanout, hop_num);
+}
+
+// ---- lane groups: G independent mini-batches served by every launch ---------------------------
+extern "C" LegionLaneGroup* legion_group_create(LegionMemoryPool** pools, int32_t n)
+{
+    LegionLaneGroup* g = new LegionLaneGroup();
+    std::vector<LanePtrs> h;
+    for (int32_t i = 0; i < n; i++) {
+        MemoryPool* mp = reinterpret_cast<MemoryPool*>(pools[i]);
+        g->pools.push_back(mp);
+        h.push_back(mp->HostLane(mp->GetCurrentPipe()));
     }
-    BatchGenerate(strm_hdl, feature, cache, memorypool, batch_size, counter, dev_id, dev_id, mode, is_presc, hop_num);
-    if (!is_presc) {
-        FeatureCacheLookup(strm_hdl, cache, memorypool, 1, dev_id);
-        IOSubmit(strm_hdl, feature, memorypool, 2, dev_id);
-    }
-    for (int32_t h = 0; h < hop_num; h++) {
-        const int32_t op = INTRABATCH_CON * (h + 1);
-        RandomSample(strm_hdl, graph, cache, memorypool, fanout[h], dev_id, op, is_presc);
-        if (!is_presc) {
-            FeatureCacheLookup(strm_hdl, cache, memorypool, op + 1, dev_id);
-            IOSubmit(strm_hdl, feature, memorypool, op + 2, dev_id);
-        }
-    }
-    IOComplete(strm_hdl, cache, memorypool, dev_id, mode);
+    SetGPUDevice(g->pools[0]->dev_id);
+    g->d_lanes = (LanePtrs*)d_alloc_space((int64_t)n * sizeof(LanePtrs));
+    HIP_CALL(hipMemcpy(g->d_lanes, h.data(), h.size() * sizeof(LanePtrs), hipMemcpyHostToDevice));
+    return g;
+}
+
+extern "C" void legion_group_set_iter_state(LegionLaneGroup* g, int32_t* iter_state_devptr) { if (g) g->iter_state = iter_state_devptr; }
+
+extern "C" void legion_group_destroy(LegionLaneGroup* g)
+{
+    if (!g) return;
+    d_free_space(g->d_lanes);
+    delete g;
+}
+
+// Lane i of the group produces batch `counter0 + i` (serve mode).  One launch of every kernel covers
+// all lanes (grid.y = lanes).
+extern "C" void legion_enqueue_group(legion_stream_t strm_hdl, LegionGraphStorage* graph, LegionFeatureStorage* feature,
+                                     LegionUnifiedCache* cache, LegionLaneGroup* group, int32_t batch_size,
+                                     int32_t counter0, int32_t dev_id, int32_t mode, const int32_t* fanout,
+                                     int32_t hop_num)
+{
+    if (!graph || !feature || !group || group->pools.empty()) { std::cout << "invalid storage ptr\n"; return; }
+    enqueue_lanes(static_cast<hipStream_t>(strm_hdl), reinterpret_cast<GraphStorage*>(graph),
+                  reinterpret_cast<FeatureStorage*>(feature), cache_of(cache), group->d_lanes,
+                  (int32_t)group->pools.size(), group->pools[0], group->iter_state, batch_size, counter0, dev_id, mode,
+                  false, fanout, hop_num);
 }
 
 // ---- gather-op timing (HIP events recorded on the op's stream around the gather launch) -------

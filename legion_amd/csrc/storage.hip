@@ -265,9 +265,51 @@ private:
 extern "C" FeatureStorage* NewCompleteFeatureStorage() { return new CompleteFeatureStorage(); }
 
 // =============================================================================================
+LanePtrs MemoryPool::HostLane(int32_t pipe) const
+{
+    LanePtrs h;
+    memset(&h, 0, sizeof(h));
+    h.sampled_ids = sampled_ids_[pipe];
+    h.labels = labels_[pipe];
+    h.agg_src_ids = agg_src_ids_;
+    h.agg_dst_ids = agg_dst_ids_;
+    h.agg_src_off = agg_src_off_[pipe];
+    h.agg_dst_off = agg_dst_off_[pipe];
+    h.tmp_part_ind = tmp_part_ind_;
+    h.position_map = position_map_;
+    h.node_counter = node_counter_[pipe];
+    h.edge_counter = edge_counter_[pipe];
+    h.slot_dst = slot_dst;
+    h.tile_counts = tile_counts;
+    h.tile_prefix = tile_prefix;
+    h.hop_scratch = hop_scratch;
+    h.fh_edge = fh_edge;
+    h.cache_search_buffer = cache_search_buffer_;
+    h.float_features = float_features_[pipe];
+    int64_t rows = feature_rows < num_ids ? feature_rows : num_ids;
+    h.feature_rows = (int32_t)rows;
+    return h;
+}
+
+const LanePtrs* MemoryPool::DeviceLane()
+{
+    if (lanes_dirty_ || d_lanes_ == nullptr || uploaded_rows_ != feature_rows) {
+        SetGPUDevice(dev_id);
+        if (d_lanes_ == nullptr) d_lanes_ = (LanePtrs*)d_alloc_space((int64_t)pipeline_depth_ * sizeof(LanePtrs));
+        std::vector<LanePtrs> h(pipeline_depth_);
+        for (int32_t i = 0; i < pipeline_depth_; i++) h[i] = HostLane(i);
+        HIP_CALL(hipMemcpy(d_lanes_, h.data(), h.size() * sizeof(LanePtrs), hipMemcpyHostToDevice));
+        lanes_dirty_ = false;
+        uploaded_rows_ = feature_rows;
+    }
+    return d_lanes_ + current_pipe_;
+}
+
 void MemoryPool::Finalize()
 {
     SetGPUDevice(dev_id);
+    d_free_space(d_lanes_);
+    d_lanes_ = nullptr;
     d_free_space(cache_search_buffer_);
     d_free_space(position_map_);
     d_free_space(agg_src_ids_);

@@ -184,25 +184,49 @@ class MemoryPool:
         self.handle = None
 
 
-class Pipeline:
-    """`lanes` mini-batches in flight on one GPU, each replayed as one hipGraph (pipeline.hip)."""
+class LaneGroup:
+    """G pools served by every launch (grid.y = G); lane i produces batch counter0 + i."""
 
-    def __init__(self, graph, feature, cache, dev_id, batch_size, fanout, lanes, feature_rows, use_graph=True):
+    def __init__(self, pools):
         self._lib = _libmod.load()
-        self.lanes = int(lanes)
+        self.pools = list(pools)
+        arr = (ctypes.c_void_p * len(self.pools))(*[p.handle for p in self.pools])
+        self.handle = self._lib.legion_group_create(arr, len(self.pools))
+
+    def enqueue(self, strm_hdl, graph, feature, cache, batch_size, counter0, dev_id, mode, fanout):
+        self._lib.legion_enqueue_group(_stream_handle(strm_hdl), graph.handle, feature.handle,
+                                       cache.handle if cache else None, self.handle, int(batch_size), int(counter0),
+                                       int(dev_id), int(mode), _i32_array(fanout), len(fanout))
+
+    def close(self):
+        if self.handle:
+            self._lib.legion_group_destroy(self.handle)
+            self.handle = None
+
+
+class Pipeline:
+    """`slots` groups of `group_size` mini-batches in flight on one GPU, each group replayed as one
+    hipGraph (pipeline.hip).  submit(counter0) enqueues batches counter0 .. counter0+group_size-1."""
+
+    def __init__(self, graph, feature, cache, dev_id, batch_size, fanout, group_size, feature_rows, use_graph=True,
+                 slots=2):
+        self._lib = _libmod.load()
+        self.group_size, self.slots = int(group_size), int(slots)
         self.fanout = [int(f) for f in fanout]
         self.handle = self._lib.legion_pipeline_create(graph.handle, feature.handle, cache.handle, int(dev_id),
                                                        int(batch_size), _i32_array(self.fanout), len(self.fanout),
-                                                       self.lanes, int(feature_rows), 1 if use_graph else 0)
-        self.pools = [MemoryPool._borrowed(self._lib.legion_pipeline_pool(self.handle, i), dev_id,
-                                           feature.total_num_nodes, batch_size, fanout, feature.float_feature_len,
-                                           feature_rows) for i in range(self.lanes)]
+                                                       self.group_size, self.slots, int(feature_rows),
+                                                       1 if use_graph else 0)
+        self.pools = [[MemoryPool._borrowed(self._lib.legion_pipeline_pool(self.handle, s, g), dev_id,
+                                            feature.total_num_nodes, batch_size, fanout, feature.float_feature_len,
+                                            feature_rows) for g in range(self.group_size)]
+                      for s in range(self.slots)]
 
-    def submit(self, counter, mode=TRAINMODE):
-        return int(self._lib.legion_pipeline_submit(self.handle, int(counter), int(mode)))
+    def submit(self, counter0, mode=TRAINMODE):
+        return int(self._lib.legion_pipeline_submit(self.handle, int(counter0), int(mode)))
 
-    def wait(self, lane=-1):
-        self._lib.legion_pipeline_wait(self.handle, int(lane))
+    def wait(self, slot=-1):
+        self._lib.legion_pipeline_wait(self.handle, int(slot))
 
     def profile_begin(self):
         self._lib.legion_pipeline_profile_begin(self.handle)

@@ -65,11 +65,14 @@ SIGNATURES = {
     "legion_ipc_local_batch_id": (c_i32, [c_p, c_i32]),
     "legion_ipc_current_batchsize": (c_i32, [c_p, c_i32, c_i32]),
     "legion_ipc_finalize": (None, [c_p]),
-    "legion_pipeline_create": (c_p, [c_p, c_p, c_p, c_i32, c_i32, P_I32, c_i32, c_i32, c_i64, c_i32]),
+    "legion_group_create": (c_p, [ctypes.POINTER(c_p), c_i32]),
+    "legion_group_set_iter_state": (None, [c_p, c_p]),
+    "legion_group_destroy": (None, [c_p]),
+    "legion_enqueue_group": (None, [c_p, c_p, c_p, c_p, c_p, c_i32, c_i32, c_i32, c_i32, P_I32, c_i32]),
+    "legion_pipeline_create": (c_p, [c_p, c_p, c_p, c_i32, c_i32, P_I32, c_i32, c_i32, c_i32, c_i64, c_i32]),
     "legion_pipeline_submit": (c_i32, [c_p, c_i32, c_i32]),
     "legion_pipeline_wait": (None, [c_p, c_i32]),
-    "legion_pipeline_pool": (c_p, [c_p, c_i32]),
-    "legion_pipeline_stream": (c_p, [c_p, c_i32]),
+    "legion_pipeline_pool": (c_p, [c_p, c_i32, c_i32]),
     "legion_pipeline_destroy": (None, [c_p]),
     "legion_pipeline_profile_begin": (None, [c_p]),
     "legion_pipeline_profile_end": (None, [c_p]),

@@ -121,11 +121,12 @@ def test_cost_model_matches_oracle(hip, cache_memory, counters):
     gpu.close(); cpu.close()
 
 
-@pytest.mark.parametrize("lanes,use_graph", [(1, True), (3, True), (4, False), (2, True)])
-def test_pipeline_lanes_and_graph_replay(hip, lanes, use_graph):
-    """Multi-lane hipGraph replay produces exactly the batches the eager single-lane path does:
-    every batch of a short run (including the clamped last batch, which falls back to eager) is
-    compared with the oracle."""
+@pytest.mark.parametrize("group,slots,use_graph", [(1, 1, True), (3, 2, True), (4, 2, False), (2, 3, True), (8, 2, True)])
+def test_pipeline_groups_and_graph_replay(hip, group, slots, use_graph):
+    """Grouped launches (grid.y = lanes) + hipGraph replay produce exactly the batches the one-lane
+    eager path does: every batch of a short run -- including the clamped last batch and the empty
+    batches past the end of the set, whose sizes are computed on the device -- is compared with the
+    oracle."""
     from legion_amd import engine
     wl = Workload(scale=11, edge_factor=8, dim=32, n_seeds=700)
     fanout, batch = [6, 3], 64
@@ -137,24 +138,47 @@ def test_pipeline_lanes_and_graph_replay(hip, lanes, use_graph):
     gpu.cache.set_capacity(150, 80)
     gpu.cache.fill_up(gpu.feature, gpu.graph)
     cpu.build_cache(0, capacity=(150, 80))
-    pipe = engine.Pipeline(gpu.graph, gpu.feature, gpu.cache, 0, batch, fanout, lanes, gpu.pools[0].num_ids, use_graph)
-    n_batches = (wl.sets[(0, 0)][0].size + batch - 1) // batch     # last one is partial
-    for rep in range(2):                                          # second epoch re-positions the device iteration
+    pipe = engine.Pipeline(gpu.graph, gpu.feature, gpu.cache, 0, batch, fanout, group, gpu.pools[0].num_ids, use_graph, slots)
+    n_batches = (wl.sets[(0, 0)][0].size + batch - 1) // batch     # the last one is partial
+    n_groups = (n_batches + group - 1) // group                    # the last group may reach past the set
+    for rep in range(2):                                          # the second epoch re-positions the device iteration
         pending = []
-        for it in range(n_batches):
-            lane = pipe.submit(it, 0)
-            pending.append((it, lane))
-            if len(pending) == lanes or it == n_batches - 1:
-                for jt, ln in pending:
-                    pipe.wait(ln)
-                    g = engine.read_batch(pipe.pools[ln])
-                    c = cpu.run(0, jt, 0)
-                    compare_batches(g, c, f"lanes {lanes} rep {rep} batch {jt}: ")
+        for gi in range(n_groups):
+            slot = pipe.submit(gi * group, 0)
+            pending.append((gi, slot))
+            if len(pending) == slots or gi == n_groups - 1:
+                for gj, sl in pending:
+                    pipe.wait(sl)
+                    for lane in range(group):
+                        got = engine.read_batch(pipe.pools[sl][lane])
+                        want = cpu.run(0, gj * group + lane, 0)
+                        compare_batches(got, want, f"group {group} slots {slots} rep {rep} batch {gj * group + lane}: ")
                 pending = []
-    # a different mode on the same lanes uses its own graph
-    for it in range(2):
-        ln = pipe.submit(it, 1)
-        pipe.wait(ln)
-        compare_batches(engine.read_batch(pipe.pools[ln]), cpu.run(0, it, 1), f"valid batch {it}: ")
+    # a different mode on the same slots uses its own graph
+    sl = pipe.submit(0, 1)
+    pipe.wait(sl)
+    for lane in range(min(group, 2)):
+        compare_batches(engine.read_batch(pipe.pools[sl][lane]), cpu.run(0, lane, 1), f"valid batch {lane}: ")
     pipe.close()
+    gpu.close(); cpu.close()
+
+
+def test_lane_group_eager(hip):
+    """legion_enqueue_group on caller-owned pools (no pipeline, no graph)."""
+    from legion_amd import engine
+    wl = Workload(scale=10, edge_factor=8, dim=16, n_seeds=400)
+    fanout, batch = [4, 4, 2], 32
+    gpu, cpu = GpuSide(wl, batch, fanout), CpuSide(wl, batch, fanout)
+    pools = [engine.MemoryPool(0, wl.N, batch, fanout, wl.D) for _ in range(5)]
+    for p in pools:
+        p.alloc_features(p.num_ids)
+    grp = engine.LaneGroup(pools)
+    for c0 in (0, 5):
+        grp.enqueue(None, gpu.graph, gpu.feature, gpu.cache, batch, c0, 0, 0, fanout)
+        torch.cuda.synchronize()
+        for lane, p in enumerate(pools):
+            compare_batches(engine.read_batch(p), cpu.run(0, c0 + lane, 0), f"lane {lane} of group at {c0}: ")
+    grp.close()
+    for p in pools:
+        p.close()
     gpu.close(); cpu.close()
