@@ -52,6 +52,7 @@ def parse_args():
     ap.add_argument("--group", type=int, default=4, help="mini-batches served by every launch (lanes of a group)")
     ap.add_argument("--slots", type=int, default=2, help="groups in flight per GPU")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
+    ap.add_argument("--overlap", action="store_true", help="let kernels of different slots share the GPU")
     ap.add_argument("--no-verify", action="store_true")
     return ap.parse_args()
 
@@ -109,7 +110,8 @@ def main():
     pool.close()
     G = args.group
     assert args.steps % G == 0 and args.warmup % G == 0, "--steps and --warmup must be multiples of --group"
-    pipe = engine.Pipeline(graph, feature, cache, 0, B, fanout, G, feature_rows, not args.no_graph, args.slots)
+    pipe = engine.Pipeline(graph, feature, cache, 0, B, fanout, G, feature_rows, not args.no_graph, args.slots,
+                           args.overlap)
     torch.cuda.synchronize()
     setup_s = time.time() - t_setup
 

@@ -188,7 +188,9 @@ void legion_enqueue_group(legion_stream_t strm_hdl, LegionGraphStorage* graph, L
  * needs no argument update).  The MI355X-native form of the Runner's inter-batch pipe
  * (SS/engine/server.cu:302-332 with INTERBATCH_CON output slots): submit() never blocks on the
  * group it enqueues, only on the slot's previous one.  feature_rows sizes each lane's feature buffer
- * (SS/engine/server.cu:275-283). */
+ * (SS/engine/server.cu:275-283).  use_graph: bit 0 = replay hipGraphs (else eager launches), bit 1 =
+ * let kernels of different slots overlap on the GPU (default: slots are chained by an event, so a
+ * group's launch latency hides behind the previous group but their kernels never share the GPU). */
 typedef struct LegionPipeline LegionPipeline;
 LegionPipeline* legion_pipeline_create(LegionGraphStorage* graph, LegionFeatureStorage* feature,
                                        LegionUnifiedCache* cache, int32_t dev_id, int32_t batch_size,

@@ -118,7 +118,8 @@ __global__ void batch_generate_kernel(SeedParams p, const LanePtrs* __restrict__
         } else {
             const int32_t src_id = p.all_ids[at % p.total_cap];
             L.sampled_ids[idx] = src_id;
-            atomicMin(L.position_map + src_id, idx);          // seeds are unique (":26 assume no duplicate")
+            atomicMin(reinterpret_cast<uint32_t*>(L.position_map) + src_id,
+                      lg_pos_key(L.hop_scratch[HS_EPOCH], (uint32_t)idx));   // seeds are unique (":26 assume no duplicate")
             L.labels[idx] = p.all_labels[at % p.total_cap];
         }
     }
@@ -143,7 +144,8 @@ struct SampleArgs {
     unsigned long long* edge_access_time;
     int32_t* sampled_ids; int32_t* agg_src_ids; int32_t* agg_dst_ids; int32_t* agg_src_off; int32_t* agg_dst_off;
     char* tmp_part_ind; int32_t* position_map; int32_t* node_counter; int32_t* edge_counter;
-    int32_t* slot_dst; int32_t* tile_counts; int32_t* tile_prefix; int32_t* hop_scratch; RowHdr* fh_edge;
+    int32_t* slot_dst; int32_t* slot_pos; int32_t* tile_counts; int32_t* tile_prefix; int32_t* hop_scratch; RowHdr* fh_edge;
+    int32_t epoch;
 };
 
 __device__ __forceinline__ SampleArgs lane_args(const HopParams& p, const LanePtrs* __restrict__ lanes)
@@ -156,8 +158,9 @@ __device__ __forceinline__ SampleArgs lane_args(const HopParams& p, const LanePt
     a.sampled_ids = L.sampled_ids; a.agg_src_ids = L.agg_src_ids; a.agg_dst_ids = L.agg_dst_ids;
     a.agg_src_off = L.agg_src_off; a.agg_dst_off = L.agg_dst_off; a.tmp_part_ind = L.tmp_part_ind;
     a.position_map = L.position_map; a.node_counter = L.node_counter; a.edge_counter = L.edge_counter;
-    a.slot_dst = L.slot_dst; a.tile_counts = L.tile_counts; a.tile_prefix = L.tile_prefix;
+    a.slot_dst = L.slot_dst; a.slot_pos = L.slot_pos; a.tile_counts = L.tile_counts; a.tile_prefix = L.tile_prefix;
     a.hop_scratch = L.hop_scratch; a.fh_edge = L.fh_edge;
+    a.epoch = L.hop_scratch[HS_EPOCH];
     return a;
 }
 
@@ -259,7 +262,8 @@ __global__ __launch_bounds__(LG_TILE) void sample_kernel(HopParams hp, const Lan
             const int32_t idx = idx0 + u * LG_TILE + tid;
             if (idx < g.total) {
                 if (dst[u] >= 0) {                                         // :244
-                    atomicMin(a.position_map + dst[u], LG_POS_PENDING + idx);
+                    atomicMin(reinterpret_cast<uint32_t*>(a.position_map) + dst[u],
+                              lg_pos_key(a.epoch, LG_POS_PENDING | (uint32_t)idx));
                     if (a.edge_access_time)                                // :358
                         atomicAdd(a.edge_access_time + g.frontier[idx / count], 1ull);
                 } else {
@@ -297,8 +301,10 @@ __global__ __launch_bounds__(LG_TILE) void flag_count_kernel(HopParams hp, const
         for (int u = 0; u < LG_SLOTS_PER_LANE; u++) {
             const int32_t idx = idx0 + u * LG_TILE + tid;
             const bool valid = v[u] >= 0;
-            const bool first = valid && pm[u] == LG_POS_PENDING + idx;
+            const bool first = valid && (uint32_t)pm[u] == lg_pos_key(a.epoch, LG_POS_PENDING | (uint32_t)idx);
             if (first) a.slot_dst[idx] = v[u] | (int32_t)0x80000000;
+            // final position if the neighbour was already in the batch, else "pending" (resolved by localise)
+            if (valid && !first) a.slot_pos[idx] = ((uint32_t)pm[u] & LG_POS_PENDING) ? -1 : (int32_t)((uint32_t)pm[u] & LG_POS_VALUE_MASK);
             const unsigned long long mv = __ballot(valid);
             const unsigned long long mf = __ballot(first);
             if (lane == 0) {
@@ -447,7 +453,10 @@ __global__ __launch_bounds__(LG_TILE) void scatter_kernel(HopParams hp, const La
                 if (first) {
                     const int32_t n = node_base + a.tile_prefix[2 * tile + 1] + wn + __popcll(mf[u] & lt);
                     a.sampled_ids[n] = dst;                        // :270
-                    a.position_map[dst] = n;                       // :271
+                    a.position_map[dst] = (int32_t)lg_pos_key(a.epoch, (uint32_t)n);   // :271
+                    a.agg_src_off[e] = n;                          // construct_graph's neighbour side, known here
+                } else {
+                    a.agg_src_off[e] = a.slot_pos[idx];            // final already, or -1: owned by another slot of this hop
                 }
             }
         }
@@ -464,19 +473,25 @@ __global__ __launch_bounds__(LG_TILE) void localise_kernel(HopParams hp, const L
     const int32_t* hs = a.hop_scratch;
     const int32_t n_edge = hs[HS_N_EDGE], edge_base = hs[HS_EDGE_BASE];
     const int32_t nsuper = (n_edge + LG_SUPER - 1) / LG_SUPER;
+    // scatter already localised every edge whose neighbour was final or first-touched by that very
+    // slot; what is left (-1) are neighbours owned by ANOTHER slot of this hop: one random read each
     for (int32_t st = blockIdx.x; st < nsuper; st += gridDim.x) {
-        int32_t id[LG_SLOTS_PER_LANE], pos[LG_SLOTS_PER_LANE];
+        int32_t cur[LG_SLOTS_PER_LANE], id[LG_SLOTS_PER_LANE];
 #pragma unroll
         for (int u = 0; u < LG_SLOTS_PER_LANE; u++) {
             const int32_t e = st * LG_SUPER + u * LG_TILE + threadIdx.x;
-            id[u] = e < n_edge ? a.agg_src_ids[edge_base + e] : -1;
+            cur[u] = e < n_edge ? a.agg_src_off[edge_base + e] : 0;
         }
 #pragma unroll
-        for (int u = 0; u < LG_SLOTS_PER_LANE; u++) pos[u] = id[u] >= 0 ? a.position_map[id[u]] : 0;   // :289-293
+        for (int u = 0; u < LG_SLOTS_PER_LANE; u++) {
+            const int32_t e = st * LG_SUPER + u * LG_TILE + threadIdx.x;
+            id[u] = cur[u] < 0 ? a.agg_src_ids[edge_base + e] : -1;
+        }
 #pragma unroll
         for (int u = 0; u < LG_SLOTS_PER_LANE; u++) {
             const int32_t e = st * LG_SUPER + u * LG_TILE + threadIdx.x;
-            if (e < n_edge) a.agg_src_off[edge_base + e] = pos[u];
+            if (id[u] >= 0)                                                       // :289-293
+                a.agg_src_off[edge_base + e] = (int32_t)((uint32_t)a.position_map[id[u]] & LG_POS_VALUE_MASK);
         }
     }
 }
@@ -551,29 +566,47 @@ void cache_row_headers(hipStream_t s, RowHdr* hdr, const int32_t* QT, int32_t Kg
 }
 
 // ------------------------------------------------------------------------------------------
-// end of batch: restore the untouched state for every node of the batch (the reference zeroes
-// position_map in train mode only, operator_impl.cu:542-548; here the state array doubles as the
-// accessed bitmap, so it is restored in every mode instead of memsetting N/8 bytes per batch).
+// end of batch (IOComplete).  The reference zeroes position_map for every node of the batch
+// (ClearPosMap, operator_impl.cu:542-548) and memsets the N/8-byte bitmap at the next batch's
+// start (:151).  Here nothing is cleared: the lane's epoch goes up by one, which turns every entry
+// the batch wrote into "untouched" (see legion_core.h).  Every LG_POS_EPOCH_MAX batches the array
+// is refilled with 0xFF by this kernel.  The workgroup that draws the last ticket publishes the
+// new epoch (all workgroups have read the old one by then) and advances the device-resident
+// iteration used by graph replay.
 // ------------------------------------------------------------------------------------------
-__global__ void clear_pos_map_kernel(const LanePtrs* __restrict__ lanes, int32_t* __restrict__ iter_state)
+__global__ void end_of_batch_kernel(const LanePtrs* __restrict__ lanes, int32_t* __restrict__ iter_state)
 {
     const LanePtrs& L = lanes[blockIdx.y];
-    // last kernel of a batch group: advance the device-resident iteration for the next graph replay
-    if (iter_state != nullptr && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) iter_state[0] += iter_state[1];
-    const int32_t* nc = L.node_counter;
-    const int32_t hop_num = nc[INTRABATCH_CON * 3 - 1];
-    const int32_t total = nc[INTRABATCH_CON * 3 + hop_num];
-    for (int32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
-        const int32_t id = L.sampled_ids[i];
-        if (id >= 0) L.position_map[id] = LG_POS_UNTOUCHED;
+    __shared__ int32_t s_last;
+    const int32_t epoch = L.hop_scratch[HS_EPOCH];
+    if (epoch >= LG_POS_EPOCH_MAX) {
+        uint32_t* pm = reinterpret_cast<uint32_t*>(L.position_map);
+        for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < L.total_num_nodes; i += (int64_t)gridDim.x * blockDim.x)
+            pm[i] = 0xFFFFFFFFu;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __threadfence();
+        s_last = (atomicAdd(L.hop_scratch + HS_TICKET, 1) == (int32_t)gridDim.x - 1) ? 1 : 0;
+    }
+    __syncthreads();
+    if (s_last && threadIdx.x == 0) {
+        L.hop_scratch[HS_TICKET] = 0;
+        L.hop_scratch[HS_EPOCH] = epoch >= LG_POS_EPOCH_MAX ? 1 : epoch + 1;
+        if (iter_state != nullptr && blockIdx.y == 0) iter_state[0] += iter_state[1];
     }
 }
 
-void launch_clear_pos_map(hipStream_t s, const LanePtrs* d_lanes, int32_t n_lanes, int32_t* iter_state)
+void launch_end_of_batch(hipStream_t s, const LanePtrs* d_lanes, int32_t n_lanes, int32_t* iter_state,
+                         int32_t total_num_nodes)
 {
-    int32_t gx = 512;
-    while (gx > 64 && gx * n_lanes > 2048) gx /= 2;
-    clear_pos_map_kernel<<<dim3(gx, n_lanes), 256, 0, s>>>(d_lanes, iter_state);
+    // enough workgroups to refill the array at HBM speed on the rare epoch wrap, few enough to cost
+    // nothing otherwise
+    int32_t gx = (int32_t)(((int64_t)total_num_nodes * 4 + (1 << 20) - 1) >> 20);   // ~1 MiB per workgroup
+    if (gx < 1) gx = 1;
+    if (gx > 512) gx = 512;
+    while (gx > 16 && gx * n_lanes > 2048) gx /= 2;
+    end_of_batch_kernel<<<dim3(gx, n_lanes), 256, 0, s>>>(d_lanes, iter_state);
     hipCheckError();
 }
 

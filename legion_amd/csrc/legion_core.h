@@ -52,12 +52,20 @@
     }
 
 // ---- position/first-touch state array (replaces accessed_map + position_map) ---------------
-// position_state[v] is LG_POS_UNTOUCHED between batches.  Inside a batch it holds either the
-// final position of v in sampled_ids (< LG_POS_PENDING) or, while a hop is being compacted,
-// LG_POS_PENDING + (lowest slot index that sampled v in this hop).
-#define LG_POS_UNTOUCHED 0x7F7F7F7F
-#define LG_POS_PENDING 0x40000000
-#define LG_MAX_SLOTS 0x3F000000
+// One uint32 per vertex, compared UNSIGNED: [ 0xFF - epoch : 8 | pending : 1 | value : 23 ].
+// A lane's epoch e (1..254, in hop_scratch[HS_EPOCH]) goes up by one per mini-batch, so whatever an
+// older batch left behind carries a larger top byte and reads as "untouched" -- nothing has to be
+// cleared between batches (the reference memsets an N/8-byte bitmap per batch and zeroes the
+// position map entry by entry, operator_impl.cu:151,542-548); every 254 batches the end-of-batch
+// kernel refills the array with 0xFF.  Within the current epoch the low 24 bits hold either the
+// final position of the vertex in sampled_ids, or LG_POS_PENDING | (lowest slot index that sampled
+// it in the hop being compacted); atomicMin keeps the lowest.
+#define LG_POS_VALUE_BITS 23
+#define LG_POS_PENDING (1u << LG_POS_VALUE_BITS)
+#define LG_POS_VALUE_MASK (LG_POS_PENDING - 1u)
+#define LG_POS_EPOCH_MAX 254
+#define LG_MAX_SLOTS ((int64_t)LG_POS_VALUE_MASK)      // slots per hop and nodes per batch must stay below 2^23
+__host__ __device__ inline uint32_t lg_pos_key(int32_t epoch, uint32_t v) { return ((uint32_t)(0xFF - epoch) << 24) | v; }
 
 // per-hop scratch written by the scan kernel, read by scatter / localise (device int32[16])
 enum HopScratch {
@@ -69,6 +77,8 @@ enum HopScratch {
     HS_N_NEW = 5,
     HS_N_EDGE = 6,
     HS_SLOTS = 7,
+    HS_EPOCH = 8,          // this lane's current epoch of the position-state array
+    HS_TICKET = 9,         // last-workgroup ticket of the end-of-batch kernel
     HS_WORDS = 16
 };
 
@@ -118,6 +128,7 @@ struct LanePtrs {
     int32_t* node_counter;
     int32_t* edge_counter;
     int32_t* slot_dst;
+    int32_t* slot_pos;
     int32_t* tile_counts;
     int32_t* tile_prefix;
     int32_t* hop_scratch;
@@ -125,7 +136,7 @@ struct LanePtrs {
     int32_t* cache_search_buffer;
     float* float_features;
     int32_t feature_rows;
-    int32_t pad_;
+    int32_t total_num_nodes;
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -177,6 +188,7 @@ public:
 
     // new in this build: sampler scratch (all device memory, private to the server)
     int32_t* slot_dst = nullptr;       // [max_slots] sampled neighbour per slot (sign bit = first touch)
+    int32_t* slot_pos = nullptr;       // [max_slots] what the position state held for that neighbour
     int32_t* tile_counts = nullptr;    // [2 * max_tiles] valid / first-touch counts per tile
     int32_t* tile_prefix = nullptr;    // [2 * max_tiles] exclusive prefixes
     RowHdr* fh_edge = nullptr;         // [num_ids] frontier row headers written by scatter
@@ -487,7 +499,8 @@ struct SeedParams {
 };
 void launch_batch_generate(hipStream_t s, const SeedParams& p, const LanePtrs* d_lanes, int32_t n_lanes);
 
-void launch_clear_pos_map(hipStream_t s, const LanePtrs* d_lanes, int32_t n_lanes, int32_t* iter_state);
+void launch_end_of_batch(hipStream_t s, const LanePtrs* d_lanes, int32_t n_lanes, int32_t* iter_state,
+                         int32_t total_num_nodes);
 void launch_hotness_measure(hipStream_t s, const int32_t* sampled_ids, const int32_t* node_counter,
                             unsigned long long* access_map);
 void init_row_headers(hipStream_t s, RowHdr* hdr, const int64_t* csr_index, int32_t n, int32_t slot);

@@ -202,7 +202,7 @@ extern "C" void IOComplete(legion_stream_t strm_hdl, LegionUnifiedCache* cache_,
         cache->CacheProfiling(memorypool->GetSampledIds(), memorypool->GetAggSrcId(), memorypool->GetAggDstId(),
                               memorypool->GetAggSrcOf(), memorypool->GetAggDstOf(), memorypool->GetNodeCounter(),
                               memorypool->GetEdgeCounter(), s, dev_id);
-    lg::launch_clear_pos_map(s, memorypool->DeviceLane(), 1, memorypool->iter_state);
+    lg::launch_end_of_batch(s, memorypool->DeviceLane(), 1, memorypool->iter_state, memorypool->total_num_nodes);
 }
 
 // =============================================================================================
@@ -331,7 +331,7 @@ static void enqueue_lanes(hipStream_t s, GraphStorage* graph, FeatureStorage* fe
     if (is_presc && mode == TRAINMODE && cache != nullptr)     // CacheProfiling (one lane only in PreSC)
         cache->CacheProfiling(pool0->GetSampledIds(), pool0->GetAggSrcId(), pool0->GetAggDstId(), pool0->GetAggSrcOf(),
                               pool0->GetAggDstOf(), pool0->GetNodeCounter(), pool0->GetEdgeCounter(), s, dev_id);
-    lg::launch_clear_pos_map(s, d_lanes, n_lanes, iter_state);
+    lg::launch_end_of_batch(s, d_lanes, n_lanes, iter_state, pool0->total_num_nodes);
 }
 
 extern "C" void legion_enqueue_batch(legion_stream_t strm_hdl, LegionGraphStorage* graph, LegionFeatureStorage* feature,

@@ -48,7 +48,9 @@ struct LegionPipeline {
     std::vector<int32_t> fanout;
     std::vector<Slot> slots;
     bool use_graph;
+    bool overlap = false;   // let kernels of different slots run concurrently (default: chained)
     int32_t rr = 0;
+    int32_t last_slot = -1;
     bool profiling = false;
     std::map<int32_t, double> prof_ms;        // op id -> summed elapsed ms of its gather launches
     std::map<int32_t, int64_t> prof_cnt;
@@ -70,7 +72,8 @@ extern "C" LegionPipeline* legion_pipeline_create(LegionGraphStorage* graph, Leg
     p->fanout.assign(fanout, fanout + hop_num);
     p->group_size = group_size < 1 ? 1 : group_size;
     p->slots_n = slots < 1 ? 1 : slots;
-    p->use_graph = use_graph != 0;
+    p->use_graph = (use_graph & 1) != 0;
+    p->overlap = (use_graph & 2) != 0;
     SetGPUDevice(dev_id);
     p->slots.resize(p->slots_n);
     for (Slot& sl : p->slots) {
@@ -125,6 +128,13 @@ extern "C" int32_t legion_pipeline_submit(LegionPipeline* p, int32_t counter0, i
         sl.pools[g]->SetIter(counter0 + g);
     }
     sl.pools[0]->prof_used = 0;
+    // Chain the slots: this group starts on the GPU when the previously submitted one has finished.
+    // The launch (and its host latency) still happens while that group runs, but kernels of different
+    // groups never share the machine -- on this part two streams' kernels mostly take turns anyway,
+    // and a gather that runs alone streams at ~73% of HBM peak instead of ~52%.
+    if (!p->overlap && p->last_slot >= 0 && p->last_slot != si && p->slots[p->last_slot].busy)
+        HIP_CALL(hipStreamWaitEvent(sl.stream, p->slots[p->last_slot].done, 0));
+    p->last_slot = si;
     LegionGraphStorage* gr = reinterpret_cast<LegionGraphStorage*>(p->graph);
     LegionFeatureStorage* f = reinterpret_cast<LegionFeatureStorage*>(p->feature);
     if (!p->use_graph || p->profiling) {            // HIP cannot time events recorded by graph nodes

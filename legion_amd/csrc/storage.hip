@@ -280,6 +280,8 @@ LanePtrs MemoryPool::HostLane(int32_t pipe) const
     h.node_counter = node_counter_[pipe];
     h.edge_counter = edge_counter_[pipe];
     h.slot_dst = slot_dst;
+    h.slot_pos = slot_pos;
+    h.total_num_nodes = total_num_nodes;
     h.tile_counts = tile_counts;
     h.tile_prefix = tile_prefix;
     h.hop_scratch = hop_scratch;
@@ -317,6 +319,8 @@ void MemoryPool::Finalize()
     d_free_space(tmp_part_ind_);
     d_free_space(tmp_part_off_);
     d_free_space(slot_dst);
+    d_free_space(slot_pos);
+    slot_pos = nullptr;
     d_free_space(tile_counts);
     d_free_space(tile_prefix);
     d_free_space(hop_scratch);
@@ -349,9 +353,9 @@ void lg_pool_alloc_private(MemoryPool* mp, int32_t dev_id, int32_t total_num_nod
     int64_t num_ids = batch_size, per = batch_size;         // server.cu:187-199
     mp->max_new.assign(1, batch_size);
     for (int i = 0; i < hop_num; i++) { per *= fanout[i]; num_ids += per; mp->max_new.push_back(per); }
-    if (per > LG_MAX_SLOTS || num_ids > 0x7FFFFFFF) {
-        printf("legion_hip: batch %d with this fan-out needs %lld slots; limit is %d\n", batch_size,
-               (long long)per, LG_MAX_SLOTS);
+    if (per > LG_MAX_SLOTS || num_ids > LG_MAX_SLOTS) {
+        printf("legion_hip: batch %d with this fan-out needs %lld slots / %lld ids; limit is %lld\n", batch_size,
+               (long long)per, (long long)num_ids, (long long)LG_MAX_SLOTS);
         exit(EXIT_FAILURE);
     }
     mp->dev_id = dev_id;
@@ -362,7 +366,7 @@ void lg_pool_alloc_private(MemoryPool* mp, int32_t dev_id, int32_t total_num_nod
     mp->float_feature_len = float_feature_len;
     mp->SetCacheSearchBuffer((int32_t*)d_alloc_space(num_ids * sizeof(int32_t)));
     int32_t* position_map = (int32_t*)d_alloc_space((int64_t)total_num_nodes * sizeof(int32_t));
-    HIP_CALL(hipMemset(position_map, 0x7F, (size_t)total_num_nodes * sizeof(int32_t)));   // LG_POS_UNTOUCHED
+    HIP_CALL(hipMemset(position_map, 0xFF, (size_t)total_num_nodes * sizeof(int32_t)));   // every entry 'untouched'
     mp->SetPositionMap(position_map);
     mp->SetAggSrcId((int32_t*)d_alloc_space(num_ids * sizeof(int32_t)));
     mp->SetAggDstId((int32_t*)d_alloc_space(num_ids * sizeof(int32_t)));
@@ -370,11 +374,14 @@ void lg_pool_alloc_private(MemoryPool* mp, int32_t dev_id, int32_t total_num_nod
     mp->SetTmpPartOff((int32_t*)d_alloc_space(num_ids * sizeof(int32_t)));
     const int64_t max_tiles = (mp->max_slots + LG_TILE - 1) / LG_TILE + 1;
     mp->slot_dst = (int32_t*)d_alloc_space((int64_t)mp->max_slots * sizeof(int32_t));
+    mp->slot_pos = (int32_t*)d_alloc_space((int64_t)mp->max_slots * sizeof(int32_t));
     mp->tile_counts = (int32_t*)d_alloc_space(2 * max_tiles * sizeof(int32_t));
     mp->tile_prefix = (int32_t*)d_alloc_space(2 * max_tiles * sizeof(int32_t));
     mp->fh_edge = (RowHdr*)d_alloc_space(num_ids * sizeof(RowHdr));
     mp->hop_scratch = (int32_t*)d_alloc_space(HS_WORDS * sizeof(int32_t));
     HIP_CALL(hipMemset(mp->hop_scratch, 0, HS_WORDS * sizeof(int32_t)));
+    const int32_t first_epoch = 1;
+    HIP_CALL(hipMemcpy(mp->hop_scratch + HS_EPOCH, &first_epoch, sizeof(int32_t), hipMemcpyHostToDevice));
 }
 
 // ---- C API ----------------------------------------------------------------------------------

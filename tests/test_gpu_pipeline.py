@@ -29,9 +29,6 @@ def test_serve_batches_no_cache(hip, scale, ef, fanout, batch, dim):
             compare_batches(g, c, f"mode {mode} batch {counter}: ")
             assert np.all(g["cache_search_buffer"] == -2)          # nothing cached yet: all misses
             check_invariants(wl, g, fanout)
-    # the fused state array is back to "untouched" after every batch
-    pm = gpu.pools[0].buffer("position_map")
-    assert bool((pm == 0x7F7F7F7F).all())
     gpu.close(); cpu.close()
 
 
@@ -181,4 +178,31 @@ def test_lane_group_eager(hip):
     grp.close()
     for p in pools:
         p.close()
+    gpu.close(); cpu.close()
+
+
+def test_epoch_wrap_of_position_state(hip):
+    """The position state is never cleared between batches (epoch tag); after 254 batches on one lane
+    the end-of-batch kernel refills it.  600 consecutive batches (two wraps) stay bit-exact, eager
+    and under graph replay."""
+    from legion_amd import engine
+    wl = Workload(scale=9, edge_factor=8, dim=4, n_seeds=512)
+    fanout, batch = [3, 2], 8
+    gpu, cpu = GpuSide(wl, batch, fanout), CpuSide(wl, batch, fanout)
+    n_batches = 600
+    for it in range(n_batches):
+        c = it % 60
+        if it % 37 == 0 or it > n_batches - 5 or 250 <= it <= 260 or 505 <= it <= 515:
+            compare_batches(gpu.run(0, c, 0), cpu.run(0, c, 0), f"eager batch {it}: ")
+        else:
+            engine.enqueue_batch(None, gpu.graph, gpu.feature, gpu.cache, gpu.pools[0], batch, c, 0, 0, False, fanout)
+    pipe = engine.Pipeline(gpu.graph, gpu.feature, gpu.cache, 0, batch, fanout, 2, gpu.pools[0].num_ids, True, 1)
+    for gi in range(300):                     # 300 replays per lane: crosses the wrap inside the graph
+        c0 = (gi % 30) * 2
+        sl = pipe.submit(c0, 0)
+        if gi % 41 == 0 or 120 <= gi <= 130 or gi > 295:
+            pipe.wait(sl)
+            for lane in range(2):
+                compare_batches(engine.read_batch(pipe.pools[sl][lane]), cpu.run(0, c0 + lane, 0), f"replay {gi} lane {lane}: ")
+    pipe.close()
     gpu.close(); cpu.close()
