@@ -39,8 +39,8 @@ HBM_PEAK_GBPS = 8000.0   # MI355X_MICROARCH.md: 8 TB/s spec
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=256)
+    ap.add_argument("--warmup", type=int, default=32)
     ap.add_argument("--scale", type=int, default=26)
     ap.add_argument("--edge-factor", type=int, default=16)
     ap.add_argument("--dim", type=int, default=128)
@@ -49,7 +49,7 @@ def parse_args():
     ap.add_argument("--cache-memory", type=int, default=8 << 30, help="bytes per GPU fed to the cost model")
     ap.add_argument("--presc-steps", type=int, default=512, help="PreSC batches per GPU (bounded epoch)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU-baseline time; 0 disables")
-    ap.add_argument("--group", type=int, default=4, help="mini-batches served by every launch (lanes of a group)")
+    ap.add_argument("--group", type=int, default=32, help="mini-batches served by every launch (lanes of a group)")
     ap.add_argument("--slots", type=int, default=2, help="groups in flight per GPU")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
     ap.add_argument("--overlap", action="store_true", help="let kernels of different slots share the GPU")
@@ -109,7 +109,6 @@ def main():
     feature_rows = int(max_ids * 1.2)                                        # server.cu:277
     pool.close()
     G = args.group
-    assert args.steps % G == 0 and args.warmup % G == 0, "--steps and --warmup must be multiples of --group"
     pipe = engine.Pipeline(graph, feature, cache, 0, B, fanout, G, feature_rows, not args.no_graph, args.slots,
                            args.overlap)
     torch.cuda.synchronize()
@@ -122,7 +121,7 @@ def main():
     hits = 0
     for k in range(args.steps):
         if k % G == 0:
-            slot = pipe.submit(first + k)
+            slot = pipe.submit(first + k, n_active=min(G, args.steps - k))
             pipe.wait(slot)
         pl = pipe.pools[slot][k % G]
         nc = pl.buffer("node_counter").cpu().numpy()
@@ -146,15 +145,13 @@ def main():
             hits = int((pl.buffer("cache_search_buffer")[:int(nc[1])] >= 0).sum())
 
     # ---- warm-up, then the timed region: K batches replayed as hipGraphs over `lanes` lanes ---------
-    for it in range(0, args.warmup, G):
-        pipe.submit(it)
+    pipe.run_range(0, args.warmup)
     pipe.wait()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for k in range(0, args.steps, G):
-        pipe.submit(first + k)
+    pipe.run_range(first, args.steps)
     pipe.wait()
     torch.cuda.synchronize()
     if world > 1:
@@ -165,13 +162,11 @@ def main():
     # ---- the same K batches once more with HIP events around every gather launch (recorded on the
     #      lane's own stream).  Eager launches: HIP cannot time events recorded by graph nodes. ------
     pipe.profile_begin()
-    for it in range(0, args.warmup, G):
-        pipe.submit(it)
+    pipe.run_range(0, args.warmup)
     pipe.wait()
     warm = pipe.profile_read()
     t1 = time.perf_counter()
-    for k in range(0, args.steps, G):
-        pipe.submit(first + k)
+    pipe.run_range(first, args.steps)
     pipe.wait()
     elapsed_profiled = time.perf_counter() - t1
     prof = pipe.profile_read()

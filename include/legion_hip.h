@@ -182,6 +182,10 @@ void legion_group_destroy(LegionLaneGroup* g);
 void legion_enqueue_group(legion_stream_t strm_hdl, LegionGraphStorage* graph, LegionFeatureStorage* feature,
                           LegionUnifiedCache* cache, LegionLaneGroup* group, int32_t batch_size,
                           int32_t counter0, int32_t dev_id, int32_t mode, const int32_t* fanout, int32_t hop_num);
+/* same with only the first n_active lanes working */
+void legion_enqueue_group_n(legion_stream_t strm_hdl, LegionGraphStorage* graph, LegionFeatureStorage* feature,
+                            LegionUnifiedCache* cache, LegionLaneGroup* group, int32_t n_active, int32_t batch_size,
+                            int32_t counter0, int32_t dev_id, int32_t mode, const int32_t* fanout, int32_t hop_num);
 
 /* Pipeline: `slots` groups of `group_size` mini-batches in flight on one GPU; each group is replayed
  * as one hipGraph on its own stream (sizes and the batch index live on the device, so a replay
@@ -198,6 +202,8 @@ LegionPipeline* legion_pipeline_create(LegionGraphStorage* graph, LegionFeatureS
                                        int32_t slots, int64_t feature_rows, int32_t use_graph);
 /* enqueues batches counter0 .. counter0 + group_size - 1; returns the slot */
 int32_t legion_pipeline_submit(LegionPipeline* p, int32_t counter0, int32_t mode);
+/* only the first n_active lanes work (tail of a run that is not a multiple of group_size) */
+int32_t legion_pipeline_submit_n(LegionPipeline* p, int32_t counter0, int32_t mode, int32_t n_active);
 void legion_pipeline_wait(LegionPipeline* p, int32_t slot);                          /* slot < 0: all slots */
 LegionMemoryPool* legion_pipeline_pool(LegionPipeline* p, int32_t slot, int32_t lane);
 void legion_pipeline_destroy(LegionPipeline* p);

@@ -585,10 +585,8 @@ __global__ void end_of_batch_kernel(const LanePtrs* __restrict__ lanes, int32_t*
             pm[i] = 0xFFFFFFFFu;
     }
     __syncthreads();
-    if (threadIdx.x == 0) {
-        __threadfence();
+    if (threadIdx.x == 0)   // no fence needed: the kernel boundary publishes the refill and the new epoch
         s_last = (atomicAdd(L.hop_scratch + HS_TICKET, 1) == (int32_t)gridDim.x - 1) ? 1 : 0;
-    }
     __syncthreads();
     if (s_last && threadIdx.x == 0) {
         L.hop_scratch[HS_TICKET] = 0;

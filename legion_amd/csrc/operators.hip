@@ -373,16 +373,24 @@ extern "C" void legion_group_destroy(LegionLaneGroup* g)
 
 // Lane i of the group produces batch `counter0 + i` (serve mode).  One launch of every kernel covers
 // all lanes (grid.y = lanes).
+extern "C" void legion_enqueue_group_n(legion_stream_t strm_hdl, LegionGraphStorage* graph, LegionFeatureStorage* feature,
+                                       LegionUnifiedCache* cache, LegionLaneGroup* group, int32_t n_active,
+                                       int32_t batch_size, int32_t counter0, int32_t dev_id, int32_t mode,
+                                       const int32_t* fanout, int32_t hop_num)
+{
+    if (!graph || !feature || !group || group->pools.empty()) { std::cout << "invalid storage ptr\n"; return; }
+    if (n_active < 1 || n_active > (int32_t)group->pools.size()) n_active = (int32_t)group->pools.size();
+    enqueue_lanes(static_cast<hipStream_t>(strm_hdl), reinterpret_cast<GraphStorage*>(graph),
+                  reinterpret_cast<FeatureStorage*>(feature), cache_of(cache), group->d_lanes, n_active, group->pools[0],
+                  group->iter_state, batch_size, counter0, dev_id, mode, false, fanout, hop_num);
+}
+
 extern "C" void legion_enqueue_group(legion_stream_t strm_hdl, LegionGraphStorage* graph, LegionFeatureStorage* feature,
                                      LegionUnifiedCache* cache, LegionLaneGroup* group, int32_t batch_size,
                                      int32_t counter0, int32_t dev_id, int32_t mode, const int32_t* fanout,
                                      int32_t hop_num)
 {
-    if (!graph || !feature || !group || group->pools.empty()) { std::cout << "invalid storage ptr\n"; return; }
-    enqueue_lanes(static_cast<hipStream_t>(strm_hdl), reinterpret_cast<GraphStorage*>(graph),
-                  reinterpret_cast<FeatureStorage*>(feature), cache_of(cache), group->d_lanes,
-                  (int32_t)group->pools.size(), group->pools[0], group->iter_state, batch_size, counter0, dev_id, mode,
-                  false, fanout, hop_num);
+    legion_enqueue_group_n(strm_hdl, graph, feature, cache, group, 0, batch_size, counter0, dev_id, mode, fanout, hop_num);
 }
 
 // ---- gather-op timing (HIP events recorded on the op's stream around the gather launch) -------

@@ -21,10 +21,10 @@ struct LegionLaneGroup;
 extern "C" LegionLaneGroup* legion_group_create(LegionMemoryPool** pools, int32_t n);
 extern "C" void legion_group_set_iter_state(LegionLaneGroup* g, int32_t* iter_state_devptr);
 extern "C" void legion_group_destroy(LegionLaneGroup* g);
-extern "C" void legion_enqueue_group(legion_stream_t strm_hdl, LegionGraphStorage* graph, LegionFeatureStorage* feature,
-                                     LegionUnifiedCache* cache, LegionLaneGroup* group, int32_t batch_size,
-                                     int32_t counter0, int32_t dev_id, int32_t mode, const int32_t* fanout,
-                                     int32_t hop_num);
+extern "C" void legion_enqueue_group_n(legion_stream_t strm_hdl, LegionGraphStorage* graph, LegionFeatureStorage* feature,
+                                       LegionUnifiedCache* cache, LegionLaneGroup* group, int32_t n_active,
+                                       int32_t batch_size, int32_t counter0, int32_t dev_id, int32_t mode,
+                                       const int32_t* fanout, int32_t hop_num);
 extern "C" void legion_pool_profile_begin(LegionMemoryPool* p_, int32_t max_ops);
 
 struct Slot {
@@ -33,7 +33,7 @@ struct Slot {
     hipStream_t stream = nullptr;
     hipEvent_t done = nullptr;
     bool busy = false;
-    std::map<int64_t, hipGraphExec_t> exec;   // key: mode * 2^32 + batch_size
+    std::map<int64_t, hipGraphExec_t> exec;   // key: (mode, active lanes, batch_size)
     int32_t* d_iter = nullptr;                // device {next counter0, stride}
     int32_t* h_iter = nullptr;                // pinned staging
     int32_t next_iter = -1;                   // what d_iter[0] will hold once the slot is idle
@@ -115,9 +115,18 @@ static void slot_wait(LegionPipeline* p, Slot& sl)
 // Enqueues the group of batches counter0 .. counter0 + G - 1 of `mode` on the next slot (round robin)
 // and returns the slot index.  The slot's previous group must have been consumed: this call waits
 // for its completion first.
+extern "C" int32_t legion_pipeline_submit_n(LegionPipeline* p, int32_t counter0, int32_t mode, int32_t n_active);
 extern "C" int32_t legion_pipeline_submit(LegionPipeline* p, int32_t counter0, int32_t mode)
 {
+    return legion_pipeline_submit_n(p, counter0, mode, p ? p->group_size : 0);
+}
+
+// Same with only the first n_active lanes of the group working (the tail of a run whose length is
+// not a multiple of the group size).
+extern "C" int32_t legion_pipeline_submit_n(LegionPipeline* p, int32_t counter0, int32_t mode, int32_t n_active)
+{
     if (!p) { printf("invalid pipeline ptr\n"); return -1; }
+    if (n_active < 1 || n_active > p->group_size) n_active = p->group_size;
     SetGPUDevice(p->dev_id);
     const int32_t si = p->rr;
     p->rr = (p->rr + 1) % p->slots_n;
@@ -139,8 +148,8 @@ extern "C" int32_t legion_pipeline_submit(LegionPipeline* p, int32_t counter0, i
     LegionFeatureStorage* f = reinterpret_cast<LegionFeatureStorage*>(p->feature);
     if (!p->use_graph || p->profiling) {            // HIP cannot time events recorded by graph nodes
         legion_group_set_iter_state(sl.group, nullptr);     // eager: iteration by value
-        legion_enqueue_group(sl.stream, gr, f, p->cache_handle, sl.group, p->batch_size, counter0, p->dev_id, mode,
-                             p->fanout.data(), p->hop_num);
+        legion_enqueue_group_n(sl.stream, gr, f, p->cache_handle, sl.group, n_active, p->batch_size, counter0,
+                               p->dev_id, mode, p->fanout.data(), p->hop_num);
         sl.next_iter = -1;
         sl.prof_pairs = sl.pools[0]->prof_used;
     } else {
@@ -150,22 +159,23 @@ extern "C" int32_t legion_pipeline_submit(LegionPipeline* p, int32_t counter0, i
             sl.h_iter[1] = p->group_size * p->slots_n;
             HIP_CALL(hipMemcpyAsync(sl.d_iter, sl.h_iter, 2 * sizeof(int32_t), hipMemcpyHostToDevice, sl.stream));
         }
-        const int64_t key = ((int64_t)mode << 32) | (uint32_t)p->batch_size;
+        const int64_t key = ((int64_t)mode << 40) | ((int64_t)n_active << 32) | (uint32_t)p->batch_size;
         auto it = sl.exec.find(key);
         if (it == sl.exec.end()) {
             hipGraph_t graph = nullptr;
             hipGraphExec_t exec = nullptr;
             HIP_CALL(hipStreamSynchronize(sl.stream));
             HIP_CALL(hipStreamBeginCapture(sl.stream, hipStreamCaptureModeThreadLocal));
-            legion_enqueue_group(sl.stream, gr, f, p->cache_handle, sl.group, p->batch_size, counter0, p->dev_id, mode,
-                                 p->fanout.data(), p->hop_num);
+            legion_enqueue_group_n(sl.stream, gr, f, p->cache_handle, sl.group, n_active, p->batch_size, counter0,
+                                   p->dev_id, mode, p->fanout.data(), p->hop_num);
             HIP_CALL(hipStreamEndCapture(sl.stream, &graph));
             HIP_CALL(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
             HIP_CALL(hipGraphDestroy(graph));
             it = sl.exec.emplace(key, exec).first;
         }
         HIP_CALL(hipGraphLaunch(it->second, sl.stream));
-        sl.next_iter = counter0 + p->group_size * p->slots_n;   // what the last kernel leaves in d_iter[0]
+        // what the last kernel leaves in d_iter[0] (a partial group breaks the regular stride)
+        sl.next_iter = n_active == p->group_size ? counter0 + p->group_size * p->slots_n : -1;
     }
     HIP_CALL(hipEventRecord(sl.done, sl.stream));
     sl.busy = true;

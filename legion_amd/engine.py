@@ -222,8 +222,18 @@ class Pipeline:
                                             feature_rows) for g in range(self.group_size)]
                       for s in range(self.slots)]
 
-    def submit(self, counter0, mode=TRAINMODE):
-        return int(self._lib.legion_pipeline_submit(self.handle, int(counter0), int(mode)))
+    def submit(self, counter0, mode=TRAINMODE, n_active=None):
+        if n_active is None or n_active >= self.group_size:
+            return int(self._lib.legion_pipeline_submit(self.handle, int(counter0), int(mode)))
+        return int(self._lib.legion_pipeline_submit_n(self.handle, int(counter0), int(mode), int(n_active)))
+
+    def run_range(self, first, count, mode=TRAINMODE):
+        """Submits batches first .. first+count-1 as full groups plus, if needed, one partial group."""
+        k = 0
+        while k < count:
+            n = min(self.group_size, count - k)
+            self.submit(first + k, mode, n)
+            k += n
 
     def wait(self, slot=-1):
         self._lib.legion_pipeline_wait(self.handle, int(slot))

@@ -71,6 +71,8 @@ SIGNATURES = {
     "legion_enqueue_group": (None, [c_p, c_p, c_p, c_p, c_p, c_i32, c_i32, c_i32, c_i32, P_I32, c_i32]),
     "legion_pipeline_create": (c_p, [c_p, c_p, c_p, c_i32, c_i32, P_I32, c_i32, c_i32, c_i32, c_i64, c_i32]),
     "legion_pipeline_submit": (c_i32, [c_p, c_i32, c_i32]),
+    "legion_pipeline_submit_n": (c_i32, [c_p, c_i32, c_i32, c_i32]),
+    "legion_enqueue_group_n": (None, [c_p, c_p, c_p, c_p, c_p, c_i32, c_i32, c_i32, c_i32, c_i32, P_I32, c_i32]),
     "legion_pipeline_wait": (None, [c_p, c_i32]),
     "legion_pipeline_pool": (c_p, [c_p, c_i32, c_i32]),
     "legion_pipeline_destroy": (None, [c_p]),

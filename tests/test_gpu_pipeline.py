@@ -206,3 +206,24 @@ def test_epoch_wrap_of_position_state(hip):
                 compare_batches(engine.read_batch(pipe.pools[sl][lane]), cpu.run(0, c0 + lane, 0), f"replay {gi} lane {lane}: ")
     pipe.close()
     gpu.close(); cpu.close()
+
+
+def test_pipeline_partial_group(hip):
+    """run_range with a length that is not a multiple of the group size: the tail group runs with
+    fewer active lanes (its own graph)."""
+    from legion_amd import engine
+    wl = Workload(scale=10, edge_factor=8, dim=8, n_seeds=600)
+    fanout, batch = [4, 3], 32
+    gpu, cpu = GpuSide(wl, batch, fanout), CpuSide(wl, batch, fanout)
+    pipe = engine.Pipeline(gpu.graph, gpu.feature, gpu.cache, 0, batch, fanout, 4, gpu.pools[0].num_ids, True, 2)
+    for first, count in ((0, 7), (3, 9), (0, 2)):
+        pipe.run_range(first, count)
+        pipe.wait()
+        last_group_first = first + (count - 1) // 4 * 4
+        slot = ((count + 3) // 4 - 1 + getattr(test_pipeline_partial_group, "_subs", 0)) % 2
+        test_pipeline_partial_group._subs = getattr(test_pipeline_partial_group, "_subs", 0) + (count + 3) // 4
+        for lane in range(count - (last_group_first - first)):
+            compare_batches(engine.read_batch(pipe.pools[slot][lane]), cpu.run(0, last_group_first + lane, 0),
+                            f"range {first}+{count} tail lane {lane}: ")
+    pipe.close()
+    gpu.close(); cpu.close()
