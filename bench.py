@@ -192,6 +192,22 @@ def main():
     t_all_gathers = sum(v[0] for v in prof.values()) * 1e-3
     payload_gbps = float(rows.sum() * D * 4) / t_all_gathers / 1e9 if t_all_gathers > 0 else 0.0
 
+    # HBM traffic of that kernel cannot be read live: it comes from the committed PMC summary
+    # (profiles/rNN/pmc_gather_kernel.json: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of
+    # this same command, gfx950 corrections applied), used only when it was taken on this configuration
+    traffic, traffic_src = None, None
+    import glob
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "pmc_gather_kernel.json")), reverse=True):
+        try:
+            pmc = json.load(open(f))
+        except (OSError, ValueError):
+            continue
+        if pmc.get("batches_per_launch_group") == G and f"batch {B}," in pmc.get("config", "") and f"N x {D}]" in pmc.get("config", "") \
+                and f"RMAT-{args.scale} " in pmc.get("config", ""):
+            traffic = pmc["traffic_bytes_per_launch"] / pmc["rows_per_launch"] * (rows_last / max(n_last, 1))
+            traffic_src = os.path.relpath(f, ROOT)
+            break
+
     if rank == 0:
         out = {
             "metric": "sampled_edges_per_sec",
@@ -214,7 +230,8 @@ def main():
             "seed_feature_cache_hits_step0": hits,
             "roofline": {"bound": "hbm", "kernel": "gather_kernel<float4> (hop-%d gather, op %d)" % (H, last_op),
                          "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_unit": "bytes per launch",
+                         "traffic_source": traffic_src, "algorithmic_bytes_per_launch": rows_last / max(n_last, 1) * bytes_per_row,
                          "bytes_per_row": bytes_per_row, "rows_per_launch": rows_last / max(n_last, 1),
                          "launches": n_last, "avg_launch_us": t_last / max(n_last, 1) * 1e6,
                          "measured": "HIP events on the launch stream around each hop-%d gather over the same %d "
