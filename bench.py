@@ -9,6 +9,8 @@ A "step" is one mini-batch through the whole hot path on one GPU: seed batch -> 
 reference's GPURunner::RunOnce, SS/engine/server.cu:302-332), inputs resident in HBM.
 Workload: synthetic RMAT-26 (N = 2^26, E = 2^30), float32[N x 128] counter-hash
 features, B = 1024, seeds = a seeded permutation, GPU p of P takes seeds with id % P == p.
+Mini-batches are served in groups: every kernel launch covers --group (default 64) independent
+batches (grid.y = lanes) and a group's op list is one hipGraph replay (legion_amd/csrc/pipeline.hip).
 
 One process per GPU.  The path shards by seeds with no per-batch exchange; the only collective is
 the one-time all-reduce (RCCL) of the PreSC hotness counters that sizes the caches.  Weak scaling:
@@ -40,7 +42,7 @@ def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=256)
-    ap.add_argument("--warmup", type=int, default=32)
+    ap.add_argument("--warmup", type=int, default=64)
     ap.add_argument("--scale", type=int, default=26)
     ap.add_argument("--edge-factor", type=int, default=16)
     ap.add_argument("--dim", type=int, default=128)
@@ -49,7 +51,7 @@ def parse_args():
     ap.add_argument("--cache-memory", type=int, default=8 << 30, help="bytes per GPU fed to the cost model")
     ap.add_argument("--presc-steps", type=int, default=512, help="PreSC batches per GPU (bounded epoch)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU-baseline time; 0 disables")
-    ap.add_argument("--group", type=int, default=32, help="mini-batches served by every launch (lanes of a group)")
+    ap.add_argument("--group", type=int, default=64, help="mini-batches served by every launch (lanes of a group)")
     ap.add_argument("--slots", type=int, default=2, help="groups in flight per GPU")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
     ap.add_argument("--overlap", action="store_true", help="let kernels of different slots share the GPU")
@@ -59,6 +61,11 @@ def parse_args():
 
 def main():
     args = parse_args()
+    # the library logs the reference's lines ("Alpha: ...", "Feat capacity: ...") on stdout from every
+    # rank; keep the real stdout for the one JSON line and send everything else to stderr
+    sys.stdout.flush()
+    json_out = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -239,9 +246,10 @@ def main():
                                      % (H, args.steps, G, elapsed_profiled / args.steps * 1e3)},
             "setup_seconds": setup_s,
         }
-        if args.cpu_seconds > 0:
+        if args.cpu_seconds > 0 and world == 1:      # reported at N = 1 only
             out["cpu_baseline"] = cpu_baseline(indptr, col, mine, N, B, fanout, first, args.cpu_seconds)
-        print(json.dumps(out), flush=True)
+        json_out.write(json.dumps(out) + "\n")
+        json_out.flush()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -303,8 +303,11 @@ __global__ __launch_bounds__(LG_TILE) void flag_count_kernel(HopParams hp, const
             const bool valid = v[u] >= 0;
             const bool first = valid && (uint32_t)pm[u] == lg_pos_key(a.epoch, LG_POS_PENDING | (uint32_t)idx);
             if (first) a.slot_dst[idx] = v[u] | (int32_t)0x80000000;
-            // final position if the neighbour was already in the batch, else "pending" (resolved by localise)
-            if (valid && !first) a.slot_pos[idx] = ((uint32_t)pm[u] & LG_POS_PENDING) ? -1 : (int32_t)((uint32_t)pm[u] & LG_POS_VALUE_MASK);
+            // final position if the neighbour was already in the batch; else it is owned by another slot of
+            // this hop: remember WHICH (-2 - owner slot), localise picks that slot's new position up
+            if (valid && !first)
+                a.slot_pos[idx] = ((uint32_t)pm[u] & LG_POS_PENDING) ? -2 - (int32_t)((uint32_t)pm[u] & LG_POS_VALUE_MASK)
+                                                                    : (int32_t)((uint32_t)pm[u] & LG_POS_VALUE_MASK);
             const unsigned long long mv = __ballot(valid);
             const unsigned long long mf = __ballot(first);
             if (lane == 0) {
@@ -453,10 +456,13 @@ __global__ __launch_bounds__(LG_TILE) void scatter_kernel(HopParams hp, const La
                 if (first) {
                     const int32_t n = node_base + a.tile_prefix[2 * tile + 1] + wn + __popcll(mf[u] & lt);
                     a.sampled_ids[n] = dst;                        // :270
-                    a.position_map[dst] = (int32_t)lg_pos_key(a.epoch, (uint32_t)n);   // :271
+                    // :271 -- later hops look the position up in the state array; after the last hop nobody
+                    // does, and same-hop duplicates resolve through slot_pos (a small, cache-resident array)
+                    if (!a.last_hop) a.position_map[dst] = (int32_t)lg_pos_key(a.epoch, (uint32_t)n);
+                    a.slot_pos[idx] = n;
                     a.agg_src_off[e] = n;                          // construct_graph's neighbour side, known here
                 } else {
-                    a.agg_src_off[e] = a.slot_pos[idx];            // final already, or -1: owned by another slot of this hop
+                    a.agg_src_off[e] = a.slot_pos[idx];            // final already, or -2 - owner slot
                 }
             }
         }
@@ -474,9 +480,10 @@ __global__ __launch_bounds__(LG_TILE) void localise_kernel(HopParams hp, const L
     const int32_t n_edge = hs[HS_N_EDGE], edge_base = hs[HS_EDGE_BASE];
     const int32_t nsuper = (n_edge + LG_SUPER - 1) / LG_SUPER;
     // scatter already localised every edge whose neighbour was final or first-touched by that very
-    // slot; what is left (-1) are neighbours owned by ANOTHER slot of this hop: one random read each
+    // slot; what is left (< 0) are neighbours owned by ANOTHER slot of this hop, whose new position
+    // scatter left in slot_pos[owner]: one read of a small array each (:289-293)
     for (int32_t st = blockIdx.x; st < nsuper; st += gridDim.x) {
-        int32_t cur[LG_SLOTS_PER_LANE], id[LG_SLOTS_PER_LANE];
+        int32_t cur[LG_SLOTS_PER_LANE];
 #pragma unroll
         for (int u = 0; u < LG_SLOTS_PER_LANE; u++) {
             const int32_t e = st * LG_SUPER + u * LG_TILE + threadIdx.x;
@@ -485,13 +492,7 @@ __global__ __launch_bounds__(LG_TILE) void localise_kernel(HopParams hp, const L
 #pragma unroll
         for (int u = 0; u < LG_SLOTS_PER_LANE; u++) {
             const int32_t e = st * LG_SUPER + u * LG_TILE + threadIdx.x;
-            id[u] = cur[u] < 0 ? a.agg_src_ids[edge_base + e] : -1;
-        }
-#pragma unroll
-        for (int u = 0; u < LG_SLOTS_PER_LANE; u++) {
-            const int32_t e = st * LG_SUPER + u * LG_TILE + threadIdx.x;
-            if (id[u] >= 0)                                                       // :289-293
-                a.agg_src_off[edge_base + e] = (int32_t)((uint32_t)a.position_map[id[u]] & LG_POS_VALUE_MASK);
+            if (cur[u] < 0) a.agg_src_off[edge_base + e] = a.slot_pos[-2 - cur[u]];
         }
     }
 }

@@ -89,7 +89,12 @@ extern "C" LegionPipeline* legion_pipeline_create(LegionGraphStorage* graph, Leg
         sl.d_iter = (int32_t*)d_alloc_space(2 * sizeof(int32_t));
         HIP_CALL(hipMemset(sl.d_iter, 0, 2 * sizeof(int32_t)));
         HIP_CALL(hipHostMalloc((void**)&sl.h_iter, 2 * sizeof(int32_t), hipHostMallocDefault));
-        HIP_CALL(hipStreamCreateWithFlags(&sl.stream, hipStreamNonBlocking));
+        // chained slots share one in-order stream (back-to-back graph launches, no event round trip);
+        // overlapping slots get a stream each
+        if (p->overlap || &sl == &p->slots[0])
+            HIP_CALL(hipStreamCreateWithFlags(&sl.stream, hipStreamNonBlocking))
+        else
+            sl.stream = p->slots[0].stream;
         HIP_CALL(hipEventCreateWithFlags(&sl.done, hipEventDisableTiming));
     }
     return p;
@@ -141,8 +146,7 @@ extern "C" int32_t legion_pipeline_submit_n(LegionPipeline* p, int32_t counter0,
     // The launch (and its host latency) still happens while that group runs, but kernels of different
     // groups never share the machine -- on this part two streams' kernels mostly take turns anyway,
     // and a gather that runs alone streams at ~73% of HBM peak instead of ~52%.
-    if (!p->overlap && p->last_slot >= 0 && p->last_slot != si && p->slots[p->last_slot].busy)
-        HIP_CALL(hipStreamWaitEvent(sl.stream, p->slots[p->last_slot].done, 0));
+    // (chained slots share one stream, so the order is the stream's own)
     p->last_slot = si;
     LegionGraphStorage* gr = reinterpret_cast<LegionGraphStorage*>(p->graph);
     LegionFeatureStorage* f = reinterpret_cast<LegionFeatureStorage*>(p->feature);
@@ -209,7 +213,7 @@ extern "C" void legion_pipeline_destroy(LegionPipeline* p)
         HIP_CALL(hipHostFree(sl.h_iter));
         for (MemoryPool* mp : sl.pools) legion_pool_destroy(reinterpret_cast<LegionMemoryPool*>(mp));
         HIP_CALL(hipEventDestroy(sl.done));
-        HIP_CALL(hipStreamDestroy(sl.stream));
+        if (p->overlap || &sl == &p->slots[0]) HIP_CALL(hipStreamDestroy(sl.stream));
     }
     delete p;
 }
