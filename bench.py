@@ -56,6 +56,9 @@ def parse_args():
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
     ap.add_argument("--overlap", action="store_true", help="let kernels of different slots share the GPU")
     ap.add_argument("--no-verify", action="store_true")
+    ap.add_argument("--backend", type=str, default="nccl", help="torch.distributed backend (nccl = RCCL)")
+    ap.add_argument("--force-device", type=int, default=-1,
+                    help="put every rank on this GPU (testing the N > 1 code path on a 1-GPU box, with --backend gloo)")
     return ap.parse_args()
 
 
@@ -70,13 +73,19 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    if args.force_device >= 0:
+        local_rank = args.force_device
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(args.backend, rank=rank, world_size=world)
 
     from legion_amd import engine, synth
+    engine.set_device_base(local_rank)      # this process's logical GPU 0 = physical GPU LOCAL_RANK
 
     fanout = [int(x) for x in args.fanout.split(",")]
     H = len(fanout)

@@ -247,6 +247,11 @@ void legion_synth_feature_check(legion_stream_t stream, const float* rows, const
                                 int64_t num_rows, int32_t dim, uint64_t seed,
                                 unsigned long long* mismatch_count_devptr);
 
+/* One process per GPU: logical GPU d of this process is physical GPU (base + d) % device_count.
+ * Call once before creating any object (bench.py passes LOCAL_RANK). */
+void legion_set_device_base(int32_t base);
+int32_t legion_get_device_base(void);
+
 /* library / device info */
 const char* legion_version(void);
 int32_t legion_device_count(void);

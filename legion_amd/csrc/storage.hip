@@ -26,9 +26,14 @@ static int lg_physical_count()
     return n;
 }
 
+// One process per GPU (torchrun): the process's logical GPU 0 is physical GPU `base` (= LOCAL_RANK)
+static int g_device_base = 0;
+extern "C" void legion_set_device_base(int32_t base) { g_device_base = base < 0 ? 0 : base; }
+extern "C" int32_t legion_get_device_base(void) { return g_device_base; }
+
 extern "C" void SetGPUDevice(int32_t shard_id)
 {
-    HIP_CALL(hipSetDevice(shard_id % lg_physical_count()));
+    HIP_CALL(hipSetDevice((g_device_base + shard_id) % lg_physical_count()));
 }
 
 extern "C" int32_t GetGPUDevice()

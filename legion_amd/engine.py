@@ -43,6 +43,16 @@ def device_view(ptr, shape, dtype, device):
     return torch.as_tensor(_RawDevice(ptr, shape, dtype), device=device)
 
 
+def set_device_base(base):
+    """One process per GPU: this process's logical GPU 0 is physical GPU `base` (LOCAL_RANK)."""
+    _libmod.load().legion_set_device_base(int(base))
+
+
+def _torch_device(dev_id):
+    base = int(_libmod.load().legion_get_device_base())
+    return torch.device("cuda", (base + int(dev_id)) % max(torch.cuda.device_count(), 1))
+
+
 def _stream_handle(stream=None):
     s = stream if stream is not None else torch.cuda.current_stream()
     return ctypes.c_void_p(s.cuda_stream)
@@ -120,7 +130,7 @@ class MemoryPool:
     def __init__(self, dev_id, total_num_nodes, batch_size, fanout, float_feature_len, pipeline_depth=1):
         self._lib = _libmod.load()
         self.dev_id = int(dev_id)
-        self.device = torch.device("cuda", self.dev_id % max(torch.cuda.device_count(), 1))
+        self.device = _torch_device(self.dev_id)
         self.total_num_nodes = int(total_num_nodes)
         self.batch_size = int(batch_size)
         self.fanout = [int(f) for f in fanout]
@@ -137,7 +147,7 @@ class MemoryPool:
         self = cls.__new__(cls)
         self._lib = _libmod.load()
         self.dev_id = int(dev_id)
-        self.device = torch.device("cuda", self.dev_id % max(torch.cuda.device_count(), 1))
+        self.device = _torch_device(self.dev_id)
         self.total_num_nodes, self.batch_size = int(total_num_nodes), int(batch_size)
         self.fanout = [int(f) for f in fanout]
         self.float_feature_len, self.feature_rows = int(float_feature_len), int(feature_rows)
@@ -308,8 +318,7 @@ class UnifiedCache:
     def array(self, name, dev_id=0):
         which, dtype = self._ARR[name]
         ptr = self._lib.legion_cache_array(self.handle, int(dev_id), which)
-        device = torch.device("cuda", int(dev_id) % max(torch.cuda.device_count(), 1))
-        return device_view(ptr, (self.total_num_nodes,), dtype, device)
+        return device_view(ptr, (self.total_num_nodes,), dtype, _torch_device(dev_id))
 
     def close(self):
         if self.handle:
