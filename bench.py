@@ -283,13 +283,20 @@ def cpu_baseline(indptr, col, seeds, N, B, fanout, first_batch, target_s):
                                 len(fanout), first_batch, nb, cores, None, 0, ctypes.byref(secs), ctypes.byref(nodes))
         return int(e), secs.value
 
+    dgl_note = "DGL unavailable on this box (import dgl failed); the oracle's C sampler stands in (BASELINE.md 2.3)"
+    try:
+        import dgl  # noqa: F401
+        dgl_note = "dgl importable but not used: its sampler has different semantics (SURVEY.md A.9)"
+    except Exception:
+        pass
     e, s = timed(cores)                       # calibration: one batch per thread
     nb = int(max(cores, min(cores * 64, cores * target_s / max(s, 1e-3))))
     nb = min(nb, (sd.size - 1) // B - first_batch)
     e, s = timed(nb)
     return {"value": e / s, "unit": "edges/s", "cores": cores, "kind": "port",
             "sample": f"{nb} batches of {B} seeds (same RMAT graph, same fan-out, sampling only, no gather), "
-                      f"{s:.1f} s on {cores} threads"}
+                      f"{s:.1f} s on {cores} threads",
+            "dgl": dgl_note}
 
 
 if __name__ == "__main__":
