@@ -34,7 +34,8 @@ __global__ __launch_bounds__(LG_GATHER_THREADS) void gather_kernel(GatherParams 
     __shared__ const float* s_ptr[ROWS];
 
     const LanePtrs& L = lanes[blockIdx.y];
-    const int32_t* range = L.node_counter;               // {offset, count} of the current new-node range
+    // {offset, count} of the new-node range: the live counters, or the per-hop snapshot
+    const int32_t* range = gp.hop >= 0 ? L.hop_scratch + HS_RANGE + 2 * gp.hop : L.node_counter;
     const int32_t off = range[0];
     int32_t rows = range[1];
     if (copy_range && blockIdx.x == 0 && threadIdx.x == 0) {   // counter_update(op%3==1), operator_impl.cu:83-85
@@ -141,8 +142,10 @@ void launch_gather_explicit(hipStream_t s, const GatherParams& g, const int32_t*
     h.node_counter = const_cast<int32_t*>(range);
     h.float_features = dst;
     h.feature_rows = dst_rows;
+    GatherParams ge = g;
+    ge.hop = -1;
     HIP_CALL(hipMemcpyAsync(d_lane, &h, sizeof(h), hipMemcpyHostToDevice, s));   // pageable source: staged before return
-    launch_gather_impl(s, g, d_lane, 1, false);
+    launch_gather_impl(s, ge, d_lane, 1, false);
 }
 
 }  // namespace lg

@@ -109,6 +109,10 @@ __global__ void batch_generate_kernel(SeedParams p, const LanePtrs* __restrict__
         if (idx == INTRABATCH_CON * 3 - 1) v = p.hop_num;
         L.node_counter[idx] = v;
         L.edge_counter[idx] = 0;
+        if (idx == 0) {                // range snapshot for the seeds' gather (op 1)
+            L.hop_scratch[HS_RANGE] = 0;
+            L.hop_scratch[HS_RANGE + 1] = size;
+        }
     }
     if (idx < size) {
         const int64_t at = (int64_t)size * counter + idx;     // kernel receives `size` as batch_size (:162)
@@ -379,6 +383,8 @@ __global__ __launch_bounds__(LG_SCAN_THREADS) void scan_kernel(HopParams hp, con
         hs[HS_N_NEW] = n_new;
         hs[HS_N_EDGE] = n_edge;
         hs[HS_SLOTS] = g.total;
+        hs[HS_RANGE + 2 * (a.op_id / INTRABATCH_CON)] = nc0 + nc1;     // range snapshot for this hop's gather
+        hs[HS_RANGE + 2 * (a.op_id / INTRABATCH_CON) + 1] = n_new;
         // counter_update(op_id), op_id % 3 == 0: operator_impl.cu:69-82, with nc[6] = n_new and
         // ec[2] = n_edge being what the reference's atomicAdds (:263-264) leave there
         const int32_t h = a.op_id / INTRABATCH_CON;

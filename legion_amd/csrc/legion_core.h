@@ -79,7 +79,8 @@ enum HopScratch {
     HS_SLOTS = 7,
     HS_EPOCH = 8,          // this lane's current epoch of the position-state array
     HS_TICKET = 9,         // last-workgroup ticket of the end-of-batch kernel
-    HS_WORDS = 16
+    HS_RANGE = 10,         // [HS_RANGE + 2h], [+1]: {offset, count} of the new nodes of op 3h, kept for its gather
+    HS_WORDS = 32
 };
 
 #define LG_TILE 256            // compaction tile == threads per workgroup in the sampler kernels
@@ -330,7 +331,7 @@ public:
     unsigned long long int* GetEdgeAccessedMap(int32_t dev_id);
     // the gather over a group of lanes (the reference's per-array arguments live in LanePtrs)
     void FeatCacheLookup(const LanePtrs* d_lanes, int32_t n_lanes, int32_t op_id, int32_t dev_id,
-                         hipStream_t strm_hdl, int32_t max_rows);
+                         hipStream_t strm_hdl, int32_t max_rows, bool use_snapshot);
 
     // new / exposed for the C API and the fused kernels
     void SetCapacity(int32_t node_capacity, int32_t edge_capacity);
@@ -482,6 +483,8 @@ struct GatherParams {
     int32_t D;
     int32_t total_num_nodes;
     int32_t max_rows;               // grid bound: rows any lane can have for this op
+    int32_t hop;                    // >= 0: take the range from hop_scratch[HS_RANGE + 2*hop] (snapshot that later
+                                    // hops do not overwrite, so the gather may run beside the next hop); < 0: node_counter[0..1]
 };
 void launch_gather(hipStream_t s, const GatherParams& g, const LanePtrs* d_lanes, int32_t n_lanes);
 // stand-alone form for tests / probes: explicit arrays, one lane

@@ -114,7 +114,7 @@ static void do_random_sample(hipStream_t s, GraphStorage* graph, UnifiedCache* c
 }
 
 static void do_feature_lookup(hipStream_t s, UnifiedCache* cache, const LanePtrs* d_lanes, int32_t n_lanes,
-                              MemoryPool* pool0, int32_t op_id, int32_t dev_id, std::vector<MemoryPool*>* prof_pools)
+                              MemoryPool* pool0, int32_t op_id, int32_t dev_id, bool use_snapshot)
 {
     if (pool0->GetFloatFeatures() == nullptr) {
         std::cout << "feature buffer not initialized\n";
@@ -130,9 +130,8 @@ static void do_feature_lookup(hipStream_t s, UnifiedCache* cache, const LanePtrs
     if (hop < pool0->max_new.size() && pool0->max_new[hop] < max_rows) max_rows = pool0->max_new[hop];
     MemoryPool* pp = pool0;
     const bool prof = pp->prof_on && (size_t)(2 * pp->prof_used + 1) < pp->prof_events.size();
-    (void)prof_pools;
     if (prof) HIP_CALL(hipEventRecord(pp->prof_events[2 * pp->prof_used], s));
-    cache->FeatCacheLookup(d_lanes, n_lanes, op_id, dev_id, s, (int32_t)max_rows);
+    cache->FeatCacheLookup(d_lanes, n_lanes, op_id, dev_id, s, (int32_t)max_rows, use_snapshot);
     if (prof) {
         HIP_CALL(hipEventRecord(pp->prof_events[2 * pp->prof_used + 1], s));
         pp->prof_op[pp->prof_used] = op_id;
@@ -179,8 +178,9 @@ extern "C" void FeatureCacheLookup(legion_stream_t strm_hdl, LegionUnifiedCache*
         std::cout << "invalid storage ptr\n";
         return;
     }
+    // reference semantics: gather the CURRENT new-node range (node_counter[0..1], counter_update(op%3==1))
     do_feature_lookup(static_cast<hipStream_t>(strm_hdl), cache, memorypool->DeviceLane(), 1, memorypool, op_id,
-                      dev_id, nullptr);
+                      dev_id, false);
 }
 
 extern "C" void IOSubmit(legion_stream_t, LegionFeatureStorage*, LegionMemoryPool*, int32_t, int32_t)
@@ -322,11 +322,13 @@ static void enqueue_lanes(hipStream_t s, GraphStorage* graph, FeatureStorage* fe
     if (cache && feature && cache->FeatureTable() == nullptr)
         cache->BindFeatureTable(feature->GetAllFloatFeature(), feature->TotalNodeNum());
     do_batch_generate(s, feature, d_lanes, n_lanes, pool0, batch_size, counter, dev_id, mode, hop_num, iter_state);
-    if (!is_presc) do_feature_lookup(s, cache, d_lanes, n_lanes, pool0, 1, dev_id, nullptr);
+    // inside a whole-batch enqueue every gather reads the {offset, count} snapshot its producer left in
+    // hop_scratch[HS_RANGE + 2h] (not overwritten by later hops)
+    if (!is_presc) do_feature_lookup(s, cache, d_lanes, n_lanes, pool0, 1, dev_id, true);
     for (int32_t h = 0; h < hop_num; h++) {
         const int32_t op = INTRABATCH_CON * (h + 1);
         do_random_sample(s, graph, cache, d_lanes, n_lanes, pool0, fanout[h], dev_id, op, is_presc);
-        if (!is_presc) do_feature_lookup(s, cache, d_lanes, n_lanes, pool0, op + 1, dev_id, nullptr);
+        if (!is_presc) do_feature_lookup(s, cache, d_lanes, n_lanes, pool0, op + 1, dev_id, true);
     }
     if (is_presc && mode == TRAINMODE && cache != nullptr)     // CacheProfiling (one lane only in PreSC)
         cache->CacheProfiling(pool0->GetSampledIds(), pool0->GetAggSrcId(), pool0->GetAggDstId(), pool0->GetAggSrcOf(),
