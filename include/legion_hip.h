@@ -247,6 +247,12 @@ void legion_synth_feature_check(legion_stream_t stream, const float* rows, const
                                 int64_t num_rows, int32_t dim, uint64_t seed,
                                 unsigned long long* mismatch_count_devptr);
 
+/* Spill-over tier: mapped pinned host memory (what the reference uses for the full CSR / feature table,
+ * SS/storage/storage_management.cu:106-107,161).  Returns the pointer the GPU dereferences; *host_ptr_out
+ * is the host-side address to fill and to pass to legion_host_free. */
+void* legion_host_alloc(int64_t num_bytes, void** host_ptr_out);
+void legion_host_free(void* host_ptr);
+
 /* One process per GPU: logical GPU d of this process is physical GPU (base + d) % device_count.
  * Call once before creating any object (bench.py passes LOCAL_RANK). */
 void legion_set_device_base(int32_t base);

@@ -64,6 +64,23 @@ extern "C" void* host_alloc_space(int64_t num_bytes)
     return ret;
 }
 
+// spill-over tier: mapped pinned host memory the GPU dereferences over PCIe (SS/engine/server_imp.cuh:41-51,
+// storage_management.cu:106-107,161); returns the device-side pointer, *host_ptr_out the host-side one
+extern "C" void* legion_host_alloc(int64_t num_bytes, void** host_ptr_out)
+{
+    void* host_ptr = nullptr;
+    void* dev_ptr = nullptr;
+    HIP_CALL(hipHostMalloc(&host_ptr, num_bytes > 0 ? (size_t)num_bytes : 16, hipHostMallocMapped));
+    HIP_CALL(hipHostGetDevicePointer(&dev_ptr, host_ptr, 0));
+    if (host_ptr_out) *host_ptr_out = host_ptr;
+    return dev_ptr;
+}
+
+extern "C" void legion_host_free(void* host_ptr)
+{
+    if (host_ptr) HIP_CALL(hipHostFree(host_ptr));
+}
+
 extern "C" int32_t legion_device_count(void)
 {
     int n = 0;

@@ -53,6 +53,29 @@ def _torch_device(dev_id):
     return torch.device("cuda", (base + int(dev_id)) % max(torch.cuda.device_count(), 1))
 
 
+class PinnedArray:
+    """A numpy-visible array in mapped pinned host memory that the GPU reads in place over PCIe: the
+    spill-over tier for tables that do not fit HBM (the reference's only tier for the full CSR/features)."""
+
+    def __init__(self, array):
+        array = np.ascontiguousarray(array)
+        self._lib = _libmod.load()
+        host = ctypes.c_void_p()
+        self.dev_ptr = self._lib.legion_host_alloc(int(array.nbytes), ctypes.byref(host))
+        self.host_ptr = host.value
+        self.shape, self.dtype = array.shape, array.dtype
+        ctypes.memmove(self.host_ptr, array.ctypes.data, array.nbytes)
+
+    def tensor(self, device):
+        tdt = {np.dtype(np.int32): torch.int32, np.dtype(np.int64): torch.int64, np.dtype(np.float32): torch.float32}[self.dtype]
+        return device_view(self.dev_ptr, self.shape, tdt, device)
+
+    def close(self):
+        if self.host_ptr:
+            self._lib.legion_host_free(ctypes.c_void_p(self.host_ptr))
+            self.host_ptr = None
+
+
 def _stream_handle(stream=None):
     s = stream if stream is not None else torch.cuda.current_stream()
     return ctypes.c_void_p(s.cuda_stream)

@@ -89,6 +89,8 @@ SIGNATURES = {
     "legion_synth_rmat_edges": (None, [c_p, c_i32, c_i64, c_u64, c_p, c_p]),
     "legion_synth_features": (None, [c_p, c_p, c_i64, c_i64, c_i32, c_u64]),
     "legion_synth_feature_check": (None, [c_p, c_p, c_p, c_i64, c_i32, c_u64, c_p]),
+    "legion_host_alloc": (c_p, [c_i64, ctypes.POINTER(c_p)]),
+    "legion_host_free": (None, [c_p]),
     "legion_set_device_base": (None, [c_i32]),
     "legion_get_device_base": (c_i32, []),
     "legion_version": (ctypes.c_char_p, []),
