@@ -134,6 +134,8 @@ def main():
     first = args.warmup
     edges = np.zeros(args.steps, dtype=np.int64)
     rows = np.zeros((args.steps, H + 1), dtype=np.int64)
+    hop_edges = np.zeros((args.steps, H), dtype=np.int64)
+    hop_slots = np.zeros((args.steps, H), dtype=np.int64)
     hits = 0
     for k in range(args.steps):
         if k % G == 0:
@@ -146,6 +148,8 @@ def main():
         rows[k, 0] = nc[9]
         for h in range(H):
             rows[k, h + 1] = nc[9 + h + 1] - nc[9 + h]
+            hop_edges[k, h] = ec[9 + h + 1] - ec[9 + h]
+            hop_slots[k, h] = (nc[9] if h == 0 else ec[9 + h] - ec[9 + h - 1]) * fanout[h]
         if k == 0 and not args.no_verify:
             # size-independent parity properties at full size: every gathered row is byte-identical to
             # the generator's value for its id; ids are unique; positions localise the edge endpoints
@@ -207,6 +211,10 @@ def main():
     achieved = rows_last * bytes_per_row / t_last / 1e9 if t_last > 0 else 0.0
     t_all_gathers = sum(v[0] for v in prof.values()) * 1e-3
     payload_gbps = float(rows.sum() * D * 4) / t_all_gathers / 1e9 if t_all_gathers > 0 else 0.0
+    # sampler side: bytes = sum_h [S_h*25/f_h + E_h*44 + U_h*8]; time = step time minus the gathers
+    samp_bytes = sum(float(hop_slots[:, h].sum()) * 25.0 / fanout[h] + float(hop_edges[:, h].sum()) * 44.0 +
+                     float(rows[:, h + 1].sum()) * 8.0 for h in range(H))
+    t_sampling = max(elapsed - t_all_gathers, 1e-9)
 
     # HBM traffic of that kernel cannot be read live: it comes from the committed PMC summary
     # (profiles/rNN/pmc_gather_kernel.json: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of
@@ -242,6 +250,11 @@ def main():
                        "presc_batches": train_step},
             "feature_gather_GBps": payload_gbps * 1.0,
             "feature_gather_GBps_note": "payload bytes read (rows*D*4) / HIP-event time of all gather launches, rank 0",
+            "sampling_only": {"edges_per_sec": float(edges.sum()) / t_sampling, "algorithmic_GBps": samp_bytes / t_sampling / 1e9,
+                              "frac_of_hbm_peak": samp_bytes / t_sampling / 1e9 / HBM_PEAK_GBPS,
+                              "note": "rank 0; time = timed region minus the HIP-event time of all gather launches; the "
+                                      "sampler is bound by scattered 4-byte atomics (~25 G/s) and loads (~48 G/s), "
+                                      "see tools/micro/random_access.hip"},
             "edges_per_step": float(edges.mean()), "rows_per_step": float(rows.sum(axis=1).mean()),
             "seed_feature_cache_hits_step0": hits,
             "roofline": {"bound": "hbm", "kernel": "gather_kernel<float4> (hop-%d gather, op %d)" % (H, last_op),
