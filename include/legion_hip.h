@@ -128,6 +128,22 @@ void legion_cache_set_capacity(LegionUnifiedCache* c, int32_t node_capacity, int
 /* SS/cache/cache.cu:553-611 */
 void legion_cache_fill_up(LegionUnifiedCache* c, LegionFeatureStorage* feature, LegionGraphStorage* graph);
 void legion_cache_destroy(LegionUnifiedCache* c);
+/* A clique spread over PROCESSES (one process per GPU, Kg = world size): every rank owns member
+ * `dev` = its rank (legion_set_local_device), builds its own stripe, publishes three IPC handles
+ * (feature cache, cached CSR indptr, cached CSR columns; 192 bytes), opens the other members' handles
+ * and links them into its pointer tables: remote cache rows and adjacency are then read with direct
+ * peer loads over xGMI, as the reference does over NVLink inside one process (cache_impl.cuh:268,
+ * operator_impl.cu:228-242).  Order on every rank: PreSC -> all-reduce hotness (RCCL) ->
+ * set_peer_max_ids -> candidate_selection(world_reduced = 1) -> cost_model -> fill_up_local -> export ->
+ * all-gather handles -> import_peer for every other rank -> fill_up_link. */
+void legion_set_local_device(int32_t dev);
+void legion_cache_set_peer_max_ids(LegionUnifiedCache* c, const int32_t* max_ids, int32_t n);
+void legion_cache_fill_up_local(LegionUnifiedCache* c, LegionFeatureStorage* feature, LegionGraphStorage* graph);
+void legion_cache_export(LegionUnifiedCache* c, LegionGraphStorage* graph, int32_t dev_id, void* handles192);
+void legion_cache_import_peer(LegionUnifiedCache* c, LegionGraphStorage* graph, int32_t local_dev, int32_t peer_dev,
+                              const void* handles192);
+void legion_cache_fill_up_link(LegionUnifiedCache* c, LegionFeatureStorage* feature, LegionGraphStorage* graph);
+
 /* introspection for the parity tests; arrays are device pointers on the clique leader */
 int32_t legion_cache_node_capacity(const LegionUnifiedCache* c, int32_t dev_id);
 int32_t legion_cache_edge_capacity(const LegionUnifiedCache* c, int32_t dev_id);

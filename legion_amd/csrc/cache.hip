@@ -245,7 +245,14 @@ void UnifiedCache::CandidateSelection(int cache_agg_mode, FeatureStorage* featur
     QF_.clear(); QT_.clear(); AF_.clear(); AT_.clear();
 
     for (int32_t i = 0; i < Kc; i++) {
-        SetGPUDevice(i * Kg);
+        int32_t lead = -1;                             // the clique leader; in a clique spread over processes
+        for (int32_t j = 0; j < Kg && lead < 0; j++)   // every process leads with its own member
+            if (lg_is_local(i * Kg + j)) lead = i * Kg + j;
+        if (lead < 0) {
+            QF_.push_back(nullptr); AF_.push_back(nullptr); QT_.push_back(nullptr); AT_.push_back(nullptr);
+            continue;
+        }
+        SetGPUDevice(lead);
         for (int which = 0; which < 2; which++) {     // 0: node hotness -> QF/AF, 1: edge hotness -> QT/AT
             int32_t* order = (int32_t*)d_alloc_space((int64_t)N * sizeof(int32_t));
             unsigned long long* agg = (unsigned long long*)d_alloc_space((int64_t)N * sizeof(unsigned long long));
@@ -253,8 +260,8 @@ void UnifiedCache::CandidateSelection(int cache_agg_mode, FeatureStorage* featur
             // aggregate_access on the leader reading each member's counters (peer loads over xGMI).
             // When the counters were already all-reduced across processes (RCCL), every member
             // holds the clique sum: take the leader's copy once.
-            const int32_t members = world_reduced ? 1 : Kg;
-            for (int32_t j = 0; j < members; j++) {
+            for (int32_t j = 0; j < Kg; j++) {
+                if (world_reduced ? (i * Kg + j != lead) : !lg_is_local(i * Kg + j)) continue;
                 CacheController* cc = cache_controller_[i * Kg + j];
                 lg::aggregate_access(nullptr, agg, which == 0 ? cc->GetNodeAccessedMap() : cc->GetEdgeAccessedMap(), N);
             }
@@ -278,13 +285,16 @@ void UnifiedCache::CostModel(int, FeatureStorage* feature, GraphStorage* graph,
     node_capacity_.clear();
     edge_capacity_.clear();
     for (int32_t i = 0; i < Kc_; i++) {
-        SetGPUDevice(i * Kg_);
+        if (QF_[i] == nullptr) { node_capacity_.push_back(0); edge_capacity_.push_back(0); continue; }
+        for (int32_t j = 0; j < Kg_; j++)
+            if (lg_is_local(i * Kg_ + j)) { SetGPUDevice(i * Kg_ + j); break; }
         const int max_payload_size = CLS;
         const int64_t memory_step = (int64_t)((double)(cache_memory_ * Kg_) * MIN_INTERVAL);
         const uint64_t total_trans_of_topo = counters[0] + counters[1];
         uint64_t total_trans_of_feat = 0;
         for (int j = 0; j < Kg_; j++)     // the reference indexes controller j, not i*Kg+j (:462)
-            total_trans_of_feat += (uint64_t)((int64_t)(((int64_t)cache_controller_[j]->MaxIdNum() * train_step) * D) * sizeof(float)) /
+            total_trans_of_feat += (uint64_t)((int64_t)(((int64_t)(j < (int32_t)peer_max_ids_.size() ? peer_max_ids_[j]
+                                                                   : cache_controller_[j]->MaxIdNum()) * train_step) * D) * sizeof(float)) /
                                    (uint64_t)max_payload_size;
 
         unsigned long long* d_prefix = (unsigned long long*)d_alloc_space((int64_t)N * 8);
@@ -363,47 +373,60 @@ int32_t UnifiedCache::EdgeCapacity(int32_t dev_id) const
     return edge_capacity_[dev_id / Kg_];
 }
 
-// SS/cache/cache.cu:553-611
+// SS/cache/cache.cu:553-611, in two steps so that a clique spread over processes can exchange its
+// stripes in between (in one process FillUp = FillUpLocal + FillUpLink).
 void UnifiedCache::FillUp(int cache_agg_mode, FeatureStorage* feature, GraphStorage* graph)
 {
     (void)cache_agg_mode;
+    FillUpLocal(feature, graph);
+    FillUpLink(feature, graph);
+}
+
+void UnifiedCache::FillUpLocal(FeatureStorage* feature, GraphStorage* graph)
+{
     const int32_t N = feature->TotalNodeNum();
-    for (int32_t i = 0; i < Kc_; i++)
-        for (int32_t j = 0; j < Kg_; j++) {
-            SetGPUDevice(i * Kg_ + j);
-            cache_controller_[i * Kg_ + j]->InitializeMap(node_capacity_[i], edge_capacity_[i]);
-            cache_controller_[i * Kg_ + j]->Insert(QT_[i], QF_[i], Kg_, Kg_);
-        }
-    for (int32_t i = 0; i < device_count_; i++) {
-        SetGPUDevice(i);
-        d_free_space(d_float_feature_cache_ptr_[i]);
-        d_float_feature_cache_ptr_[i] = (float**)d_alloc_space(device_count_ * sizeof(float*));
-    }
     float* cpu_float_feature = feature->GetAllFloatFeature();
     cpu_float_features_ = cpu_float_feature;
-    for (int32_t i = 0; i < Kc_; i++) {
-        std::vector<float*> table(device_count_, nullptr);     // indexed by in-clique GPU j
+    for (int32_t i = 0; i < Kc_; i++)
         for (int32_t j = 0; j < Kg_; j++) {
             const int32_t dev_id = i * Kg_ + j;
-            if (float_feature_len_ > 0) {
-                SetGPUDevice(dev_id);
+            if (!lg_is_local(dev_id) || QF_[i] == nullptr) continue;
+            SetGPUDevice(dev_id);
+            cache_controller_[dev_id]->InitializeMap(node_capacity_[i], edge_capacity_[i]);
+            cache_controller_[dev_id]->Insert(QT_[i], QF_[i], Kg_, Kg_);
+            d_free_space(d_float_feature_cache_ptr_[dev_id]);
+            d_float_feature_cache_ptr_[dev_id] = (float**)d_alloc_space(device_count_ * sizeof(float*));
+            if (float_feature_len_ > 0) {                      // this member's stripe: rows QF[r*Kg + j]
                 d_free_space(float_feature_cache_[dev_id]);
                 float* new_cache = (float*)d_alloc_space((int64_t)node_capacity_[i] * float_feature_len_ * sizeof(float));
                 lg::feat_fill_up(nullptr, node_capacity_[i], float_feature_len_, new_cache, cpu_float_feature,
                                  QF_[i], Kg_, j, N);
                 HIP_CALL(hipDeviceSynchronize());
                 float_feature_cache_[dev_id] = new_cache;
-                table[j] = new_cache;
             }
         }
+    for (int32_t i = 0; i < Kc_; i++)
+        if (QT_[i] != nullptr) graph->GraphCacheBuildLocal(QT_[i], i, Kg_, edge_capacity_[i]);
+}
+
+void UnifiedCache::FillUpLink(FeatureStorage* feature, GraphStorage* graph)
+{
+    (void)feature;
+    for (int32_t i = 0; i < Kc_; i++) {
+        if (QF_[i] == nullptr) continue;
+        std::vector<float*> table(device_count_, nullptr);     // indexed by in-clique GPU j (cache.cu:594)
+        for (int32_t j = 0; j < Kg_; j++) table[j] = float_feature_cache_[i * Kg_ + j];   // local stripe or peer pointer
         for (int32_t j = 0; j < Kg_; j++) {                   // :598-601
-            SetGPUDevice(i * Kg_ + j);
-            HIP_CALL(hipMemcpy(d_float_feature_cache_ptr_[i * Kg_ + j], table.data(),
-                               device_count_ * sizeof(float*), hipMemcpyHostToDevice));
+            const int32_t dev_id = i * Kg_ + j;
+            if (!lg_is_local(dev_id)) continue;
+            SetGPUDevice(dev_id);
+            HIP_CALL(hipMemcpy(d_float_feature_cache_ptr_[dev_id], table.data(), device_count_ * sizeof(float*),
+                               hipMemcpyHostToDevice));
         }
+        graph->GraphCacheLink(QT_[i], i, Kg_, edge_capacity_[i]);   // :606-608
     }
-    for (int32_t i = 0; i < Kc_; i++) graph->GraphCache(QT_[i], i, Kg_, edge_capacity_[i]);   // :606-608
     for (int32_t i = 0; i < device_count_; i++) {
+        if (!lg_is_local(i)) continue;
         SetGPUDevice(i);
         HIP_CALL(hipDeviceSynchronize());
     }
@@ -502,7 +525,7 @@ extern "C" void legion_cache_destroy(LegionUnifiedCache* c)
     if (!c) return;
     LegionCacheBox* b = reinterpret_cast<LegionCacheBox*>(c);
     for (int32_t i = 0; i < b->device_count; i++)
-        if (b->cache.Controller(i)) b->cache.Finalize(i);
+        if (b->cache.Controller(i) && lg_is_local(i)) b->cache.Finalize(i);
     delete b;
 }
 
@@ -561,4 +584,61 @@ extern "C" void legion_cache_find_feat(LegionUnifiedCache* c, int32_t dev_id, le
     UnifiedCache* u = as_cache(c);
     if (!u) { printf("invalid cache ptr\n"); return; }
     u->FindFeat(const_cast<int32_t*>(sampled_ids), cache_offset, const_cast<int32_t*>(node_counter), op_id, stream, dev_id);
+}
+
+// ---- a clique spread over processes (one process per GPU): exchange of the stripes ---------------
+// Order on every rank: [PreSC] -> all-reduce hotness -> legion_cache_set_peer_max_ids ->
+// candidate_selection(world_reduced) -> cost_model -> legion_cache_fill_up_local -> legion_cache_export ->
+// all-gather the handles -> legion_cache_import_peer for every other rank -> legion_cache_fill_up_link.
+struct LegionStripeHandles {          // what one member publishes: 3 IPC handles
+    hipIpcMemHandle_t feat_cache, topo_index, topo_col;
+};
+static_assert(sizeof(LegionStripeHandles) == 192, "three 64-byte IPC handles");
+
+extern "C" void legion_cache_set_peer_max_ids(LegionUnifiedCache* c, const int32_t* max_ids, int32_t n)
+{
+    UnifiedCache* u = as_cache(c);
+    if (u) u->SetPeerMaxIds(max_ids, n);
+}
+
+extern "C" void legion_cache_fill_up_local(LegionUnifiedCache* c, LegionFeatureStorage* feature, LegionGraphStorage* graph)
+{
+    UnifiedCache* u = as_cache(c);
+    if (!u || !feature || !graph) { printf("invalid cache/feature/graph ptr\n"); return; }
+    u->FillUpLocal(reinterpret_cast<FeatureStorage*>(feature), reinterpret_cast<GraphStorage*>(graph));
+}
+
+extern "C" void legion_cache_fill_up_link(LegionUnifiedCache* c, LegionFeatureStorage* feature, LegionGraphStorage* graph)
+{
+    UnifiedCache* u = as_cache(c);
+    if (!u || !feature || !graph) { printf("invalid cache/feature/graph ptr\n"); return; }
+    u->FillUpLink(reinterpret_cast<FeatureStorage*>(feature), reinterpret_cast<GraphStorage*>(graph));
+}
+
+extern "C" void legion_cache_export(LegionUnifiedCache* c, LegionGraphStorage* graph, int32_t dev_id, void* handles192)
+{
+    UnifiedCache* u = as_cache(c);
+    GraphStorage* g = reinterpret_cast<GraphStorage*>(graph);
+    if (!u || !g || !handles192) { printf("invalid cache/graph ptr\n"); return; }
+    SetGPUDevice(dev_id);
+    LegionStripeHandles* h = reinterpret_cast<LegionStripeHandles*>(handles192);
+    HIP_CALL(hipIpcGetMemHandle(&h->feat_cache, u->FeatureCachePtr(dev_id)));
+    HIP_CALL(hipIpcGetMemHandle(&h->topo_index, g->CachedCSRIndex(dev_id)));
+    HIP_CALL(hipIpcGetMemHandle(&h->topo_col, g->CachedCSRDst(dev_id)));
+}
+
+extern "C" void legion_cache_import_peer(LegionUnifiedCache* c, LegionGraphStorage* graph, int32_t local_dev,
+                                         int32_t peer_dev, const void* handles192)
+{
+    UnifiedCache* u = as_cache(c);
+    GraphStorage* g = reinterpret_cast<GraphStorage*>(graph);
+    if (!u || !g || !handles192) { printf("invalid cache/graph ptr\n"); return; }
+    SetGPUDevice(local_dev);
+    const LegionStripeHandles* h = reinterpret_cast<const LegionStripeHandles*>(handles192);
+    void *feat = nullptr, *ti = nullptr, *tc = nullptr;
+    HIP_CALL(hipIpcOpenMemHandle(&feat, h->feat_cache, hipIpcMemLazyEnablePeerAccess));
+    HIP_CALL(hipIpcOpenMemHandle(&ti, h->topo_index, hipIpcMemLazyEnablePeerAccess));
+    HIP_CALL(hipIpcOpenMemHandle(&tc, h->topo_col, hipIpcMemLazyEnablePeerAccess));
+    u->SetPeerFeatureCache(peer_dev, (float*)feat);
+    g->SetPeerCSR(peer_dev, (int64_t*)ti, (int32_t*)tc);
 }

@@ -254,6 +254,15 @@ public:
     virtual int32_t NodeNum() const = 0;
     virtual int64_t EdgeNum() const = 0;
     virtual const RowHdr* GetRowHeaders(int32_t part_id) const = 0;   // new: [N] per GPU
+    // GraphCache in two steps, so that a clique spread over processes can exchange the stripes in
+    // between: build the cached CSR of every LOCAL member, then link every known member's CSR into the
+    // local members' pointer tables and row headers.  SetPeerCSR registers a member owned by another
+    // process (pointers opened from its IPC handles).
+    virtual void GraphCacheBuildLocal(int32_t* QT, int32_t Ki, int32_t Kg, int32_t capacity) = 0;
+    virtual void GraphCacheLink(int32_t* QT, int32_t Ki, int32_t Kg, int32_t capacity) = 0;
+    virtual void SetPeerCSR(int32_t dev, int64_t* csr_node_index, int32_t* csr_dst_node_ids) = 0;
+    virtual int64_t* CachedCSRIndex(int32_t dev) const = 0;
+    virtual int32_t* CachedCSRDst(int32_t dev) const = 0;
 };
 extern "C" GraphStorage* NewCompleteGraphStorage();
 
@@ -327,6 +336,11 @@ public:
     void CostModel(int cache_agg_mode, FeatureStorage* feature, GraphStorage* graph,
                    std::vector<uint64_t>& counters, int32_t train_step);
     void FillUp(int cache_agg_mode, FeatureStorage* feature, GraphStorage* graph);
+    void FillUpLocal(FeatureStorage* feature, GraphStorage* graph);   // maps + the local members' stripes
+    void FillUpLink(FeatureStorage* feature, GraphStorage* graph);    // pointer tables over every known member
+    void SetPeerFeatureCache(int32_t dev, float* ptr) { float_feature_cache_[dev] = ptr; }
+    float* FeatureCachePtr(int32_t dev) const { return float_feature_cache_[dev]; }
+    void SetPeerMaxIds(const int32_t* v, int32_t n) { peer_max_ids_.assign(v, v + n); }
     int32_t MaxIdNum(int32_t dev_id);
     unsigned long long int* GetEdgeAccessedMap(int32_t dev_id);
     // the gather over a group of lanes (the reference's per-array arguments live in LanePtrs)
@@ -360,6 +374,7 @@ private:
     int32_t float_feature_len_ = 0;
     float* cpu_float_features_ = nullptr;
     bool is_presc_ = true;
+    std::vector<int32_t> peer_max_ids_;   // MaxIdNum of every clique member when they live in other processes
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -447,6 +462,10 @@ public:
     virtual void Finalize(RunnerParams* params) = 0;
 };
 Runner* NewGPURunner();
+
+// one process per GPU with a clique spread over processes: only device `dev` is owned by this process
+extern "C" void legion_set_local_device(int32_t dev);
+bool lg_is_local(int32_t dev);
 
 void lg_pool_alloc_private(MemoryPool* mp, int32_t dev_id, int32_t total_num_nodes, int32_t batch_size,
                            const int32_t* fanout, int32_t hop_num, int32_t float_feature_len);

@@ -31,6 +31,10 @@ static int g_device_base = 0;
 extern "C" void legion_set_device_base(int32_t base) { g_device_base = base < 0 ? 0 : base; }
 extern "C" int32_t legion_get_device_base(void) { return g_device_base; }
 
+static int g_local_only = -1;
+extern "C" void legion_set_local_device(int32_t dev) { g_local_only = dev; }
+bool lg_is_local(int32_t dev) { return g_local_only < 0 || dev == g_local_only; }
+
 extern "C" void SetGPUDevice(int32_t shard_id)
 {
     HIP_CALL(hipSetDevice((g_device_base + shard_id) % lg_physical_count()));
@@ -104,7 +108,11 @@ public:
         csr_dst_node_ids_.assign(partition_count_, nullptr);
         h_index_tab_.assign(partition_count_, std::vector<int64_t*>(partition_count_ + 1, nullptr));
         h_dst_tab_.assign(partition_count_, std::vector<int32_t*>(partition_count_ + 1, nullptr));
+        row_hdr_.assign(partition_count_, nullptr);
+        topo_index_.assign(partition_count_, nullptr);
+        topo_col_.assign(partition_count_, nullptr);
         for (int32_t i = 0; i < partition_count_; i++) {
+            if (!lg_is_local(i)) continue;
             SetGPUDevice(i);
             csr_node_index_[i] = (int64_t**)d_alloc_space((partition_count_ + 1) * sizeof(int64_t*));
             csr_dst_node_ids_[i] = (int32_t**)d_alloc_space((partition_count_ + 1) * sizeof(int32_t*));
@@ -114,7 +122,7 @@ public:
             h_dst_tab_[i][partition_count_] = csr_dst_node_ids_cpu_;
             Upload(i);
             // per-vertex row headers: everything starts in the full CSR (slot P)
-            row_hdr_.push_back((RowHdr*)d_alloc_space((int64_t)node_num_ * sizeof(RowHdr)));
+            row_hdr_[i] = (RowHdr*)d_alloc_space((int64_t)node_num_ * sizeof(RowHdr));
             lg::init_row_headers(nullptr, row_hdr_[i], csr_node_index_cpu_, node_num_, partition_count_);
             HIP_CALL(hipDeviceSynchronize());
         }
@@ -123,8 +131,15 @@ public:
     // SS/storage/graph_storage.cu:76-111: GPU i of clique Ki caches vertices QT[row*Kg + i]
     void GraphCache(int32_t* QT, int32_t Ki, int32_t Kg, int32_t capacity) override
     {
+        GraphCacheBuildLocal(QT, Ki, Kg, capacity);
+        GraphCacheLink(QT, Ki, Kg, capacity);
+    }
+
+    void GraphCacheBuildLocal(int32_t* QT, int32_t Ki, int32_t Kg, int32_t capacity) override
+    {
         for (int32_t i = 0; i < Kg; i++) {
             const int32_t dev = Ki * Kg + i;
+            if (!lg_is_local(dev)) continue;
             SetGPUDevice(dev);
             int64_t* neighbor_count = (int64_t*)d_alloc_space((int64_t)capacity * sizeof(int64_t));
             lg::topo_neighbor_count(nullptr, QT, Kg, i, capacity, node_num_, csr_node_index_cpu_, neighbor_count);
@@ -140,19 +155,38 @@ public:
             d_free_space(neighbor_count);
             owned_.push_back(d_csr_node_index);
             owned_.push_back(d_csr_dst_node_ids);
-            for (int32_t j = 0; j < Kg; j++) {            // every member of the clique sees slot `dev`
-                h_index_tab_[Ki * Kg + j][dev] = d_csr_node_index;
-                h_dst_tab_[Ki * Kg + j][dev] = d_csr_dst_node_ids;
-            }
-            for (int32_t j = 0; j < Kg; j++) {            // ... and resolves the cached vertices to it
-                SetGPUDevice(Ki * Kg + j);
-                lg::cache_row_headers(nullptr, row_hdr_[Ki * Kg + j], QT, Kg, i, capacity, node_num_,
-                                      d_csr_node_index, dev);
+            topo_index_[dev] = d_csr_node_index;
+            topo_col_[dev] = d_csr_dst_node_ids;
+        }
+    }
+
+    void GraphCacheLink(int32_t* QT, int32_t Ki, int32_t Kg, int32_t capacity) override
+    {
+        for (int32_t j = 0; j < Kg; j++) {                // every LOCAL member of the clique ...
+            const int32_t member = Ki * Kg + j;
+            if (!lg_is_local(member)) continue;
+            SetGPUDevice(member);
+            for (int32_t i = 0; i < Kg; i++) {            // ... sees every member's cached CSR it knows of
+                const int32_t dev = Ki * Kg + i;
+                if (topo_index_[dev] == nullptr) continue;
+                h_index_tab_[member][dev] = topo_index_[dev];
+                h_dst_tab_[member][dev] = topo_col_[dev];
+                // resolve the vertices that member caches to its CSR (reads its indptr: a peer load when
+                // the member is another GPU)
+                lg::cache_row_headers(nullptr, row_hdr_[member], QT, Kg, i, capacity, node_num_, topo_index_[dev], dev);
                 HIP_CALL(hipDeviceSynchronize());
             }
+            Upload(member);
         }
-        for (int32_t j = 0; j < Kg; j++) Upload(Ki * Kg + j);
     }
+
+    void SetPeerCSR(int32_t dev, int64_t* csr_node_index, int32_t* csr_dst_node_ids) override
+    {
+        topo_index_[dev] = csr_node_index;
+        topo_col_[dev] = csr_dst_node_ids;
+    }
+    int64_t* CachedCSRIndex(int32_t dev) const override { return topo_index_[dev]; }
+    int32_t* CachedCSRDst(int32_t dev) const override { return topo_col_[dev]; }
 
     void Finalize() override
     {
@@ -161,6 +195,7 @@ public:
         for (RowHdr* p : row_hdr_) d_free_space(p);
         row_hdr_.clear();
         for (int32_t i = 0; i < partition_count_; i++) {
+            if (!lg_is_local(i)) continue;
             d_free_space(csr_node_index_[i]);
             d_free_space(csr_dst_node_ids_[i]);
         }
@@ -198,6 +233,8 @@ private:
     int32_t* csr_dst_node_ids_cpu_ = nullptr;
     std::vector<void*> owned_;
     std::vector<RowHdr*> row_hdr_;
+    std::vector<int64_t*> topo_index_;   // [P] cached CSR of each GPU (local build or peer pointer)
+    std::vector<int32_t*> topo_col_;
 };
 
 extern "C" GraphStorage* NewCompleteGraphStorage() { return new CompleteGraphStorage(); }

@@ -48,6 +48,11 @@ def set_device_base(base):
     _libmod.load().legion_set_device_base(int(base))
 
 
+def set_local_device(dev):
+    """A clique spread over processes: this process owns logical GPU `dev` only (dev = its rank)."""
+    _libmod.load().legion_set_local_device(int(dev))
+
+
 def _torch_device(dev_id):
     base = int(_libmod.load().legion_get_device_base())
     return torch.device("cuda", (base + int(dev_id)) % max(torch.cuda.device_count(), 1))
@@ -319,6 +324,24 @@ class UnifiedCache:
 
     def fill_up(self, feature, graph):
         self._lib.legion_cache_fill_up(self.handle, feature.handle, graph.handle)
+
+    def fill_up_distributed(self, feature, graph, rank, world, max_ids_all, all_gather_bytes):
+        """FillUp of a clique spread over `world` processes (this process owns member `rank`):
+        local stripe -> export 3 IPC handles -> all-gather -> open the peers' -> link.
+        `all_gather_bytes(b: bytes) -> list[bytes]` is the caller's collective (torch.distributed)."""
+        self._lib.legion_cache_fill_up_local(self.handle, feature.handle, graph.handle)
+        mine = ctypes.create_string_buffer(192)
+        self._lib.legion_cache_export(self.handle, graph.handle, int(rank), mine)
+        everyone = all_gather_bytes(mine.raw)
+        self._peer_handles = [ctypes.create_string_buffer(b, 192) for b in everyone]
+        for peer in range(world):
+            if peer != rank:
+                self._lib.legion_cache_import_peer(self.handle, graph.handle, int(rank), peer, self._peer_handles[peer])
+        self._lib.legion_cache_fill_up_link(self.handle, feature.handle, graph.handle)
+
+    def set_peer_max_ids(self, max_ids_all):
+        arr = _i32_array(max_ids_all)
+        self._lib.legion_cache_set_peer_max_ids(self.handle, arr, len(max_ids_all))
 
     def node_capacity(self, dev_id=0):
         return int(self._lib.legion_cache_node_capacity(self.handle, int(dev_id)))

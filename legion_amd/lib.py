@@ -44,6 +44,12 @@ SIGNATURES = {
     "legion_cache_set_capacity": (None, [c_p, c_i32, c_i32]),
     "legion_cache_fill_up": (None, [c_p, c_p, c_p]),
     "legion_cache_destroy": (None, [c_p]),
+    "legion_set_local_device": (None, [c_i32]),
+    "legion_cache_set_peer_max_ids": (None, [c_p, P_I32, c_i32]),
+    "legion_cache_fill_up_local": (None, [c_p, c_p, c_p]),
+    "legion_cache_export": (None, [c_p, c_p, c_i32, c_p]),
+    "legion_cache_import_peer": (None, [c_p, c_p, c_i32, c_i32, c_p]),
+    "legion_cache_fill_up_link": (None, [c_p, c_p, c_p]),
     "legion_cache_node_capacity": (c_i32, [c_p, c_i32]),
     "legion_cache_edge_capacity": (c_i32, [c_p, c_i32]),
     "legion_cache_max_id_num": (c_i32, [c_p, c_i32]),
