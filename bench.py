@@ -56,6 +56,9 @@ def parse_args():
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
     ap.add_argument("--overlap", action="store_true", help="let kernels of different slots share the GPU")
     ap.add_argument("--no-verify", action="store_true")
+    ap.add_argument("--stripe", action="store_true",
+                    help="N > 1: one clique of N GPUs, feature/topology caches striped over the ranks and read "
+                         "through peer pointers over xGMI (default: every GPU caches for itself, no peer traffic)")
     ap.add_argument("--backend", type=str, default="nccl", help="torch.distributed backend (nccl = RCCL)")
     ap.add_argument("--force-device", type=int, default=-1,
                     help="put every rank on this GPU (testing the N > 1 code path on a 1-GPU box, with --backend gloo)")
@@ -85,7 +88,12 @@ def main():
             dist.init_process_group(args.backend, rank=rank, world_size=world)
 
     from legion_amd import engine, synth
-    engine.set_device_base(local_rank)      # this process's logical GPU 0 = physical GPU LOCAL_RANK
+    stripe = args.stripe and world > 1
+    P = world if stripe else 1              # logical GPUs the objects know about
+    d = rank if stripe else 0               # the one this process owns
+    engine.set_device_base(max(local_rank - d, 0))   # logical GPU d of this process = physical GPU LOCAL_RANK
+    if stripe:
+        engine.set_local_device(d)
 
     fanout = [int(x) for x in args.fanout.split(",")]
     H = len(fanout)
@@ -103,29 +111,48 @@ def main():
     mine = np.ascontiguousarray(all_seeds[all_seeds % world == rank])      # storage_management.cu:178
     assert mine.size > (args.warmup + args.steps + 1) * B, "not enough seeds for this rank"
 
-    graph = engine.GraphStorage(1, indptr, col)
-    feature = engine.FeatureStorage(1, features)
-    feature.set_ids(0, engine.TRAINMODE, mine, None)
+    graph = engine.GraphStorage(P, indptr, col)
+    feature = engine.FeatureStorage(P, features)
+    feature.set_ids(d, engine.TRAINMODE, mine, None)
     train_step = min((mine.size - 1) // B, args.presc_steps)
-    cache = engine.UnifiedCache(args.cache_memory, D, train_step, 1, N)
-    cache.init_controller(0)
-    pool = engine.MemoryPool(0, N, B, fanout, D, pipeline_depth=1)
+    if world > 1:                           # train_step = min over partitions (ipc_service.cu:73-82)
+        ts = torch.tensor([train_step], device=dev)
+        dist.all_reduce(ts, op=dist.ReduceOp.MIN)
+        train_step = int(ts.item())
+    cache = engine.UnifiedCache(args.cache_memory, D, train_step, P, N)
+    cache.init_controller(d)
+    pool = engine.MemoryPool(d, N, B, fanout, D, pipeline_depth=1)
 
     # ---- PreSC epoch (bounded) -> hotness -> all-reduce over ranks -> order -> cost model -> fills --
     for it in range(train_step):
-        engine.enqueue_batch(None, graph, feature, cache, pool, B, it, 0, engine.TRAINMODE, True, fanout)
+        engine.enqueue_batch(None, graph, feature, cache, pool, B, it, d, engine.TRAINMODE, True, fanout)
     torch.cuda.synchronize()
     if world > 1:   # the only collective of the path: RCCL all-reduce of the uint64 hotness counters
-        dist.all_reduce(cache.array("node_access_time", 0))
-        dist.all_reduce(cache.array("edge_access_time", 0))
-    max_ids = cache.max_id_num(0)
-    cache.candidate_selection(0, graph, world_reduced=(world > 1))
-    cache.cost_model(feature, graph, (0, 0), train_step)
-    cache.fill_up(feature, graph)
+        dist.all_reduce(cache.array("node_access_time", d))
+        dist.all_reduce(cache.array("edge_access_time", d))
+    max_ids = cache.max_id_num(d)
+    if stripe:
+        mids = [None] * world
+        dist.all_gather_object(mids, max_ids)
+        cache.set_peer_max_ids(mids)
+        cache.candidate_selection(int(np.log2(world)), graph, world_reduced=True)
+        cache.cost_model(feature, graph, (0, 0), train_step)
+
+        def all_gather_bytes(b):
+            out = [None] * world
+            dist.all_gather_object(out, b)
+            return out
+
+        cache.fill_up_distributed(feature, graph, d, world, mids, all_gather_bytes)
+        dist.barrier()
+    else:
+        cache.candidate_selection(0, graph, world_reduced=(world > 1))
+        cache.cost_model(feature, graph, (0, 0), train_step)
+        cache.fill_up(feature, graph)
     feature_rows = int(max_ids * 1.2)                                        # server.cu:277
     pool.close()
     G = args.group
-    pipe = engine.Pipeline(graph, feature, cache, 0, B, fanout, G, feature_rows, not args.no_graph, args.slots,
+    pipe = engine.Pipeline(graph, feature, cache, d, B, fanout, G, feature_rows, not args.no_graph, args.slots,
                            args.overlap)
     torch.cuda.synchronize()
     setup_s = time.time() - t_setup
@@ -243,10 +270,12 @@ def main():
             "dtype": "int32+f32(copy)", "data": "synthetic",
             "config": {"workload": f"RMAT-{args.scale} EF{args.edge_factor} (N={N}, E={N * args.edge_factor}), "
                                    f"float32[N x {D}] features, batch {B}, fanout {fanout}, all tables resident in HBM",
-                       "parallelism": f"seed-sharded x{world}, replicated graph+features, cache_agg_mode 0",
+                       "parallelism": (f"seed-sharded x{world}, replicated graph+features, one clique of {world}: caches "
+                                       f"striped over the ranks, peer reads over xGMI (cache_agg_mode {int(np.log2(world))})")
+                       if stripe else f"seed-sharded x{world}, replicated graph+features, cache_agg_mode 0",
                        "batches_per_launch_group": G, "groups_in_flight": args.slots, "hipgraph": not args.no_graph,
                        "cache_memory_bytes": args.cache_memory,
-                       "feature_cache_rows": cache.node_capacity(0), "topology_cache_vertices": cache.edge_capacity(0),
+                       "feature_cache_rows": cache.node_capacity(d), "topology_cache_vertices": cache.edge_capacity(d),
                        "presc_batches": train_step},
             "feature_gather_GBps": payload_gbps * 1.0,
             "feature_gather_GBps_note": "payload bytes read (rows*D*4) / HIP-event time of all gather launches, rank 0",
