@@ -319,6 +319,10 @@ static void enqueue_lanes(hipStream_t s, GraphStorage* graph, FeatureStorage* fe
                           int32_t batch_size, int32_t counter, int32_t dev_id, int32_t mode, bool is_presc,
                           const int32_t* fanout, int32_t hop_num)
 {
+    if (cache == nullptr && !is_presc) {
+        std::cout << "invalid cache ptr\n";     // serving needs the cache object (it owns the feature tiers)
+        return;
+    }
     if (cache && feature && cache->FeatureTable() == nullptr)
         cache->BindFeatureTable(feature->GetAllFloatFeature(), feature->TotalNodeNum());
     do_batch_generate(s, feature, d_lanes, n_lanes, pool0, batch_size, counter, dev_id, mode, hop_num, iter_state);
