@@ -123,7 +123,7 @@ __global__ void batch_generate_kernel(SeedParams p, const LanePtrs* __restrict__
             const int32_t src_id = p.all_ids[at % p.total_cap];
             L.sampled_ids[idx] = src_id;
             atomicMin(reinterpret_cast<uint32_t*>(L.position_map) + src_id,
-                      lg_pos_key(L.hop_scratch[HS_EPOCH], (uint32_t)idx));   // seeds are unique (":26 assume no duplicate")
+                      lg_pos_fmt(L.hop_scratch[HS_EPOCH], L.hop_scratch[HS_VALUE_BITS]).hi | (uint32_t)idx);   // seeds are unique (":26 assume no duplicate")
             L.labels[idx] = p.all_labels[at % p.total_cap];
         }
     }
@@ -149,7 +149,7 @@ struct SampleArgs {
     int32_t* sampled_ids; int32_t* agg_src_ids; int32_t* agg_dst_ids; int32_t* agg_src_off; int32_t* agg_dst_off;
     char* tmp_part_ind; int32_t* position_map; int32_t* node_counter; int32_t* edge_counter;
     int32_t* slot_dst; int32_t* slot_pos; int32_t* tile_counts; int32_t* tile_prefix; int32_t* hop_scratch; RowHdr* fh_edge;
-    int32_t epoch;
+    PosFmt pf;
 };
 
 __device__ __forceinline__ SampleArgs lane_args(const HopParams& p, const LanePtrs* __restrict__ lanes)
@@ -164,7 +164,7 @@ __device__ __forceinline__ SampleArgs lane_args(const HopParams& p, const LanePt
     a.position_map = L.position_map; a.node_counter = L.node_counter; a.edge_counter = L.edge_counter;
     a.slot_dst = L.slot_dst; a.slot_pos = L.slot_pos; a.tile_counts = L.tile_counts; a.tile_prefix = L.tile_prefix;
     a.hop_scratch = L.hop_scratch; a.fh_edge = L.fh_edge;
-    a.epoch = L.hop_scratch[HS_EPOCH];
+    a.pf = lg_pos_fmt(L.hop_scratch[HS_EPOCH], L.hop_scratch[HS_VALUE_BITS]);
     return a;
 }
 
@@ -267,7 +267,7 @@ __global__ __launch_bounds__(LG_TILE) void sample_kernel(HopParams hp, const Lan
             if (idx < g.total) {
                 if (dst[u] >= 0) {                                         // :244
                     atomicMin(reinterpret_cast<uint32_t*>(a.position_map) + dst[u],
-                              lg_pos_key(a.epoch, LG_POS_PENDING | (uint32_t)idx));
+                              (a.pf.hi | a.pf.pending | (uint32_t)idx));
                     if (a.edge_access_time)                                // :358
                         atomicAdd(a.edge_access_time + g.frontier[idx / count], 1ull);
                 } else {
@@ -305,13 +305,13 @@ __global__ __launch_bounds__(LG_TILE) void flag_count_kernel(HopParams hp, const
         for (int u = 0; u < LG_SLOTS_PER_LANE; u++) {
             const int32_t idx = idx0 + u * LG_TILE + tid;
             const bool valid = v[u] >= 0;
-            const bool first = valid && (uint32_t)pm[u] == lg_pos_key(a.epoch, LG_POS_PENDING | (uint32_t)idx);
+            const bool first = valid && (uint32_t)pm[u] == (a.pf.hi | a.pf.pending | (uint32_t)idx);
             if (first) a.slot_dst[idx] = v[u] | (int32_t)0x80000000;
             // final position if the neighbour was already in the batch; else it is owned by another slot of
             // this hop: remember WHICH (-2 - owner slot), localise picks that slot's new position up
             if (valid && !first)
-                a.slot_pos[idx] = ((uint32_t)pm[u] & LG_POS_PENDING) ? -2 - (int32_t)((uint32_t)pm[u] & LG_POS_VALUE_MASK)
-                                                                    : (int32_t)((uint32_t)pm[u] & LG_POS_VALUE_MASK);
+                a.slot_pos[idx] = ((uint32_t)pm[u] & a.pf.pending) ? -2 - (int32_t)((uint32_t)pm[u] & a.pf.vmask)
+                                                                    : (int32_t)((uint32_t)pm[u] & a.pf.vmask);
             const unsigned long long mv = __ballot(valid);
             const unsigned long long mf = __ballot(first);
             if (lane == 0) {
@@ -464,7 +464,7 @@ __global__ __launch_bounds__(LG_TILE) void scatter_kernel(HopParams hp, const La
                     a.sampled_ids[n] = dst;                        // :270
                     // :271 -- later hops look the position up in the state array; after the last hop nobody
                     // does, and same-hop duplicates resolve through slot_pos (a small, cache-resident array)
-                    if (!a.last_hop) a.position_map[dst] = (int32_t)lg_pos_key(a.epoch, (uint32_t)n);
+                    if (!a.last_hop) a.position_map[dst] = (int32_t)(a.pf.hi | (uint32_t)n);
                     a.slot_pos[idx] = n;
                     a.agg_src_off[e] = n;                          // construct_graph's neighbour side, known here
                 } else {
@@ -576,7 +576,7 @@ void cache_row_headers(hipStream_t s, RowHdr* hdr, const int32_t* QT, int32_t Kg
 // end of batch (IOComplete).  The reference zeroes position_map for every node of the batch
 // (ClearPosMap, operator_impl.cu:542-548) and memsets the N/8-byte bitmap at the next batch's
 // start (:151).  Here nothing is cleared: the lane's epoch goes up by one, which turns every entry
-// the batch wrote into "untouched" (see legion_core.h).  Every LG_POS_EPOCH_MAX batches the array
+// the batch wrote into "untouched" (see legion_core.h).  Every lg_pos_epoch_max(vb) batches the array
 // is refilled with 0xFF by this kernel.  The workgroup that draws the last ticket publishes the
 // new epoch (all workgroups have read the old one by then) and advances the device-resident
 // iteration used by graph replay.
@@ -586,7 +586,8 @@ __global__ void end_of_batch_kernel(const LanePtrs* __restrict__ lanes, int32_t*
     const LanePtrs& L = lanes[blockIdx.y];
     __shared__ int32_t s_last;
     const int32_t epoch = L.hop_scratch[HS_EPOCH];
-    if (epoch >= LG_POS_EPOCH_MAX) {
+    const int32_t epoch_max = lg_pos_epoch_max(L.hop_scratch[HS_VALUE_BITS]);
+    if (epoch >= epoch_max) {
         uint32_t* pm = reinterpret_cast<uint32_t*>(L.position_map);
         for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < L.total_num_nodes; i += (int64_t)gridDim.x * blockDim.x)
             pm[i] = 0xFFFFFFFFu;
@@ -597,7 +598,7 @@ __global__ void end_of_batch_kernel(const LanePtrs* __restrict__ lanes, int32_t*
     __syncthreads();
     if (s_last && threadIdx.x == 0) {
         L.hop_scratch[HS_TICKET] = 0;
-        L.hop_scratch[HS_EPOCH] = epoch >= LG_POS_EPOCH_MAX ? 1 : epoch + 1;
+        L.hop_scratch[HS_EPOCH] = epoch >= epoch_max ? 1 : epoch + 1;
         if (iter_state != nullptr && blockIdx.y == 0) iter_state[0] += iter_state[1];
     }
 }

@@ -52,20 +52,32 @@
     }
 
 // ---- position/first-touch state array (replaces accessed_map + position_map) ---------------
-// One uint32 per vertex, compared UNSIGNED: [ 0xFF - epoch : 8 | pending : 1 | value : 23 ].
-// A lane's epoch e (1..254, in hop_scratch[HS_EPOCH]) goes up by one per mini-batch, so whatever an
-// older batch left behind carries a larger top byte and reads as "untouched" -- nothing has to be
-// cleared between batches (the reference memsets an N/8-byte bitmap per batch and zeroes the
-// position map entry by entry, operator_impl.cu:151,542-548); every 254 batches the end-of-batch
-// kernel refills the array with 0xFF.  Within the current epoch the low 24 bits hold either the
-// final position of the vertex in sampled_ids, or LG_POS_PENDING | (lowest slot index that sampled
-// it in the hop being compacted); atomicMin keeps the lowest.
-#define LG_POS_VALUE_BITS 23
-#define LG_POS_PENDING (1u << LG_POS_VALUE_BITS)
-#define LG_POS_VALUE_MASK (LG_POS_PENDING - 1u)
-#define LG_POS_EPOCH_MAX 254
-#define LG_MAX_SLOTS ((int64_t)LG_POS_VALUE_MASK)      // slots per hop and nodes per batch must stay below 2^23
-__host__ __device__ inline uint32_t lg_pos_key(int32_t epoch, uint32_t v) { return ((uint32_t)(0xFF - epoch) << 24) | v; }
+// One uint32 per vertex, compared UNSIGNED: [ EMAX - epoch : 31-vb | pending : 1 | value : vb ],
+// EMAX = 2^(31-vb) - 1.  vb (hop_scratch[HS_VALUE_BITS]) is fixed per pool: 23 unless the pool's
+// worst-case slot / id count needs more (B=8000, fan-out 25,10,10 -> 25), at most 28.
+// A lane's epoch e (1..EMAX-1; 1..254 for vb = 23; in hop_scratch[HS_EPOCH]) goes up by one per
+// mini-batch, so whatever an older batch left behind carries a larger top field and reads as
+// "untouched" -- nothing has to be cleared between batches (the reference memsets an N/8-byte bitmap
+// per batch and zeroes the position map entry by entry, operator_impl.cu:151,542-548); every EMAX-1
+// batches the end-of-batch kernel refills the array with 0xFF.  Within the current epoch the low
+// vb+1 bits hold either the final position of the vertex in sampled_ids, or pending | (lowest slot
+// index that sampled it in the hop being compacted); atomicMin keeps the lowest.
+#define LG_POS_VALUE_BITS_MIN 23
+#define LG_POS_VALUE_BITS_MAX 28
+struct PosFmt {
+    uint32_t hi;        // (EMAX - epoch) << (vb + 1)
+    uint32_t pending;   // 1 << vb
+    uint32_t vmask;     // pending - 1
+};
+__host__ __device__ inline int32_t lg_pos_epoch_max(int32_t vb) { return (int32_t)((1u << (31 - vb)) - 2u); }
+__host__ __device__ inline PosFmt lg_pos_fmt(int32_t epoch, int32_t vb)
+{
+    PosFmt f;
+    f.hi = (((1u << (31 - vb)) - 1u) - (uint32_t)epoch) << (vb + 1);
+    f.pending = 1u << vb;
+    f.vmask = f.pending - 1u;
+    return f;
+}
 
 // per-hop scratch written by the scan kernel, read by scatter / localise (device int32[16])
 enum HopScratch {
@@ -79,6 +91,7 @@ enum HopScratch {
     HS_SLOTS = 7,
     HS_EPOCH = 8,          // this lane's current epoch of the position-state array
     HS_TICKET = 9,         // last-workgroup ticket of the end-of-batch kernel
+    HS_VALUE_BITS = 30,    // vb of the position-state format (fixed at pool creation)
     HS_RANGE = 10,         // [HS_RANGE + 2h], [+1]: {offset, count} of the new nodes of op 3h, kept for its gather
     HS_WORDS = 32
 };

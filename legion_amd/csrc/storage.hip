@@ -412,9 +412,12 @@ void lg_pool_alloc_private(MemoryPool* mp, int32_t dev_id, int32_t total_num_nod
     int64_t num_ids = batch_size, per = batch_size;         // server.cu:187-199
     mp->max_new.assign(1, batch_size);
     for (int i = 0; i < hop_num; i++) { per *= fanout[i]; num_ids += per; mp->max_new.push_back(per); }
-    if (per > LG_MAX_SLOTS || num_ids > LG_MAX_SLOTS) {
-        printf("legion_hip: batch %d with this fan-out needs %lld slots / %lld ids; limit is %lld\n", batch_size,
-               (long long)per, (long long)num_ids, (long long)LG_MAX_SLOTS);
+    int32_t value_bits = LG_POS_VALUE_BITS_MIN;          // position-state format, see legion_core.h
+    if (const char* e = getenv("LEGION_POS_VALUE_BITS")) value_bits = std::max(value_bits, atoi(e));
+    while (value_bits <= LG_POS_VALUE_BITS_MAX && (num_ids >> value_bits) != 0) value_bits++;
+    if (value_bits > LG_POS_VALUE_BITS_MAX) {
+        printf("legion_hip: batch %d with this fan-out needs %lld slots / %lld ids; limit is 2^%d\n", batch_size,
+               (long long)per, (long long)num_ids, LG_POS_VALUE_BITS_MAX);
         exit(EXIT_FAILURE);
     }
     mp->dev_id = dev_id;
@@ -441,6 +444,7 @@ void lg_pool_alloc_private(MemoryPool* mp, int32_t dev_id, int32_t total_num_nod
     HIP_CALL(hipMemset(mp->hop_scratch, 0, HS_WORDS * sizeof(int32_t)));
     const int32_t first_epoch = 1;
     HIP_CALL(hipMemcpy(mp->hop_scratch + HS_EPOCH, &first_epoch, sizeof(int32_t), hipMemcpyHostToDevice));
+    HIP_CALL(hipMemcpy(mp->hop_scratch + HS_VALUE_BITS, &value_bits, sizeof(int32_t), hipMemcpyHostToDevice));
 }
 
 // ---- C API ----------------------------------------------------------------------------------

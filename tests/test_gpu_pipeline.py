@@ -208,6 +208,21 @@ def test_epoch_wrap_of_position_state(hip):
     gpu.close(); cpu.close()
 
 
+def test_wide_position_format(hip, monkeypatch):
+    """Pools whose worst-case slot count needs more than 23 value bits switch to a wider value field
+    and a shorter epoch field (28 bits -> 6 epochs between refills).  Forced here through
+    LEGION_POS_VALUE_BITS on a small pool: 40 batches cross the refill six times and stay bit-exact."""
+    from legion_amd import engine
+    for bits in ("27", "28"):
+        monkeypatch.setenv("LEGION_POS_VALUE_BITS", bits)
+        wl = Workload(scale=9, edge_factor=8, dim=4, n_seeds=512)
+        fanout, batch = [3, 2, 2], 8
+        gpu, cpu = GpuSide(wl, batch, fanout), CpuSide(wl, batch, fanout)
+        for it in range(40):
+            compare_batches(gpu.run(0, it % 60, 0), cpu.run(0, it % 60, 0), f"vb={bits} batch {it}: ")
+        gpu.close(); cpu.close()
+
+
 def test_pipeline_partial_group(hip):
     """run_range with a length that is not a multiple of the group size: the tail group runs with
     fewer active lanes (its own graph)."""
