@@ -60,6 +60,8 @@ def parse_args():
                     help="N > 1: one clique of N GPUs, feature/topology caches striped over the ranks and read "
                          "through peer pointers over xGMI (default: every GPU caches for itself, no peer traffic)")
     ap.add_argument("--backend", type=str, default="nccl", help="torch.distributed backend (nccl = RCCL)")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="initialise torch.distributed and run the collectives even at N = 1 (exercises the RCCL calls on a 1-GPU box)")
     ap.add_argument("--force-device", type=int, default=-1,
                     help="put every rank on this GPU (testing the N > 1 code path on a 1-GPU box, with --backend gloo)")
     return ap.parse_args()
@@ -80,8 +82,10 @@ def main():
         local_rank = args.force_device
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    use_dist = world > 1 or args.force_dist
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         if args.backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
@@ -115,7 +119,7 @@ def main():
     feature = engine.FeatureStorage(P, features)
     feature.set_ids(d, engine.TRAINMODE, mine, None)
     train_step = min((mine.size - 1) // B, args.presc_steps)
-    if world > 1:                           # train_step = min over partitions (ipc_service.cu:73-82)
+    if use_dist:                            # train_step = min over partitions (ipc_service.cu:73-82)
         ts = torch.tensor([train_step], device=dev)
         dist.all_reduce(ts, op=dist.ReduceOp.MIN)
         train_step = int(ts.item())
@@ -127,7 +131,7 @@ def main():
     for it in range(train_step):
         engine.enqueue_batch(None, graph, feature, cache, pool, B, it, d, engine.TRAINMODE, True, fanout)
     torch.cuda.synchronize()
-    if world > 1:   # the only collective of the path: RCCL all-reduce of the uint64 hotness counters
+    if use_dist:    # the only collective of the path: RCCL all-reduce of the uint64 hotness counters
         dist.all_reduce(cache.array("node_access_time", d))
         dist.all_reduce(cache.array("edge_access_time", d))
     max_ids = cache.max_id_num(d)
@@ -146,7 +150,7 @@ def main():
         cache.fill_up_distributed(feature, graph, d, world, mids, all_gather_bytes)
         dist.barrier()
     else:
-        cache.candidate_selection(0, graph, world_reduced=(world > 1))
+        cache.candidate_selection(0, graph, world_reduced=use_dist)
         cache.cost_model(feature, graph, (0, 0), train_step)
         cache.fill_up(feature, graph)
     feature_rows = int(max_ids * 1.2)                                        # server.cu:277
@@ -194,14 +198,14 @@ def main():
     # ---- warm-up, then the timed region: K batches replayed as hipGraphs over `lanes` lanes ---------
     pipe.run_range(0, args.warmup)
     pipe.wait()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     pipe.run_range(first, args.steps)
     pipe.wait()
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
@@ -223,7 +227,7 @@ def main():
     tot_edges = torch.tensor([float(edges.sum())], dtype=torch.float64, device=dev)
     t_max = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     gather_bytes_t = torch.tensor([float(rows.sum() * D * 4)], dtype=torch.float64, device=dev)
-    if world > 1:
+    if use_dist:
         dist.all_reduce(tot_edges)
         dist.all_reduce(gather_bytes_t)
         dist.all_reduce(t_max, op=dist.ReduceOp.MAX)
@@ -301,7 +305,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(indptr, col, mine, N, B, fanout, first, args.cpu_seconds)
         json_out.write(json.dumps(out) + "\n")
         json_out.flush()
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 
