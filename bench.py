@@ -41,8 +41,8 @@ HBM_PEAK_GBPS = 8000.0   # MI355X_MICROARCH.md: 8 TB/s spec
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=256)
-    ap.add_argument("--warmup", type=int, default=64)
+    ap.add_argument("--steps", type=int, default=512)
+    ap.add_argument("--warmup", type=int, default=128)
     ap.add_argument("--scale", type=int, default=26)
     ap.add_argument("--edge-factor", type=int, default=16)
     ap.add_argument("--dim", type=int, default=128)
@@ -51,10 +51,12 @@ def parse_args():
     ap.add_argument("--cache-memory", type=int, default=8 << 30, help="bytes per GPU fed to the cost model")
     ap.add_argument("--presc-steps", type=int, default=512, help="PreSC batches per GPU (bounded epoch)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU-baseline time; 0 disables")
-    ap.add_argument("--group", type=int, default=64, help="mini-batches served by every launch (lanes of a group)")
+    ap.add_argument("--group", type=int, default=128, help="mini-batches served by every launch (lanes of a group)")
     ap.add_argument("--slots", type=int, default=2, help="groups in flight per GPU")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
     ap.add_argument("--overlap", action="store_true", help="let kernels of different slots share the GPU")
+    ap.add_argument("--split", action="store_true",
+                    help="sampler phase and gather phase of every group on two streams (sampler k+1 under gathers k)")
     ap.add_argument("--no-verify", action="store_true")
     ap.add_argument("--stripe", action="store_true",
                     help="N > 1: one clique of N GPUs, feature/topology caches striped over the ranks and read "
@@ -157,7 +159,7 @@ def main():
     pool.close()
     G = args.group
     pipe = engine.Pipeline(graph, feature, cache, d, B, fanout, G, feature_rows, not args.no_graph, args.slots,
-                           args.overlap)
+                           args.overlap, args.split)
     torch.cuda.synchronize()
     setup_s = time.time() - t_setup
 

@@ -96,6 +96,11 @@ enum HopScratch {
     HS_WORDS = 32
 };
 
+// phases of a whole-batch enqueue (legion_enqueue_group_phase)
+#define LG_PHASE_ALL 0      // reference op order: gather right after the op that produced its rows
+#define LG_PHASE_SAMPLE 1   // BatchGenerate + every RandomSample + IOComplete
+#define LG_PHASE_GATHER 2   // every FeatureCacheLookup, from the per-op range snapshots
+
 #define LG_TILE 256            // compaction tile == threads per workgroup in the sampler kernels
 #define LG_SLOTS_PER_LANE 4    // independent slots each lane keeps in flight
 #define LG_SUPER (LG_TILE * LG_SLOTS_PER_LANE)   // slots one workgroup owns per iteration

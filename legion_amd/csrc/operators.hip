@@ -317,7 +317,7 @@ extern "C" void legion_draw_batch(legion_stream_t stream, const int32_t* idx, co
 static void enqueue_lanes(hipStream_t s, GraphStorage* graph, FeatureStorage* feature, UnifiedCache* cache,
                           const LanePtrs* d_lanes, int32_t n_lanes, MemoryPool* pool0, int32_t* iter_state,
                           int32_t batch_size, int32_t counter, int32_t dev_id, int32_t mode, bool is_presc,
-                          const int32_t* fanout, int32_t hop_num)
+                          const int32_t* fanout, int32_t hop_num, int32_t phase = LG_PHASE_ALL)
 {
     if (cache == nullptr && !is_presc) {
         std::cout << "invalid cache ptr\n";     // serving needs the cache object (it owns the feature tiers)
@@ -325,15 +325,18 @@ static void enqueue_lanes(hipStream_t s, GraphStorage* graph, FeatureStorage* fe
     }
     if (cache && feature && cache->FeatureTable() == nullptr)
         cache->BindFeatureTable(feature->GetAllFloatFeature(), feature->TotalNodeNum());
-    do_batch_generate(s, feature, d_lanes, n_lanes, pool0, batch_size, counter, dev_id, mode, hop_num, iter_state);
     // inside a whole-batch enqueue every gather reads the {offset, count} snapshot its producer left in
-    // hop_scratch[HS_RANGE + 2h] (not overwritten by later hops)
-    if (!is_presc) do_feature_lookup(s, cache, d_lanes, n_lanes, pool0, 1, dev_id, true);
+    // hop_scratch[HS_RANGE + 2h] (not overwritten by later hops), so the gathers may also run as a
+    // phase of their own after the whole sampler (LG_PHASE_GATHER, on another stream: pipeline.hip)
+    const bool sampler = phase != LG_PHASE_GATHER, gathers = phase != LG_PHASE_SAMPLE && !is_presc;
+    if (sampler) do_batch_generate(s, feature, d_lanes, n_lanes, pool0, batch_size, counter, dev_id, mode, hop_num, iter_state);
+    if (gathers) do_feature_lookup(s, cache, d_lanes, n_lanes, pool0, 1, dev_id, true);
     for (int32_t h = 0; h < hop_num; h++) {
         const int32_t op = INTRABATCH_CON * (h + 1);
-        do_random_sample(s, graph, cache, d_lanes, n_lanes, pool0, fanout[h], dev_id, op, is_presc);
-        if (!is_presc) do_feature_lookup(s, cache, d_lanes, n_lanes, pool0, op + 1, dev_id, true);
+        if (sampler) do_random_sample(s, graph, cache, d_lanes, n_lanes, pool0, fanout[h], dev_id, op, is_presc);
+        if (gathers) do_feature_lookup(s, cache, d_lanes, n_lanes, pool0, op + 1, dev_id, true);
     }
+    if (!sampler) return;
     if (is_presc && mode == TRAINMODE && cache != nullptr)     // CacheProfiling (one lane only in PreSC)
         cache->CacheProfiling(pool0->GetSampledIds(), pool0->GetAggSrcId(), pool0->GetAggDstId(), pool0->GetAggSrcOf(),
                               pool0->GetAggDstOf(), pool0->GetNodeCounter(), pool0->GetEdgeCounter(), s, dev_id);
@@ -379,16 +382,25 @@ extern "C" void legion_group_destroy(LegionLaneGroup* g)
 
 // Lane i of the group produces batch `counter0 + i` (serve mode).  One launch of every kernel covers
 // all lanes (grid.y = lanes).
-extern "C" void legion_enqueue_group_n(legion_stream_t strm_hdl, LegionGraphStorage* graph, LegionFeatureStorage* feature,
-                                       LegionUnifiedCache* cache, LegionLaneGroup* group, int32_t n_active,
-                                       int32_t batch_size, int32_t counter0, int32_t dev_id, int32_t mode,
-                                       const int32_t* fanout, int32_t hop_num)
+extern "C" void legion_enqueue_group_phase(legion_stream_t strm_hdl, LegionGraphStorage* graph, LegionFeatureStorage* feature,
+                                           LegionUnifiedCache* cache, LegionLaneGroup* group, int32_t n_active,
+                                           int32_t batch_size, int32_t counter0, int32_t dev_id, int32_t mode,
+                                           const int32_t* fanout, int32_t hop_num, int32_t phase)
 {
     if (!graph || !feature || !group || group->pools.empty()) { std::cout << "invalid storage ptr\n"; return; }
     if (n_active < 1 || n_active > (int32_t)group->pools.size()) n_active = (int32_t)group->pools.size();
     enqueue_lanes(static_cast<hipStream_t>(strm_hdl), reinterpret_cast<GraphStorage*>(graph),
                   reinterpret_cast<FeatureStorage*>(feature), cache_of(cache), group->d_lanes, n_active, group->pools[0],
-                  group->iter_state, batch_size, counter0, dev_id, mode, false, fanout, hop_num);
+                  group->iter_state, batch_size, counter0, dev_id, mode, false, fanout, hop_num, phase);
+}
+
+extern "C" void legion_enqueue_group_n(legion_stream_t strm_hdl, LegionGraphStorage* graph, LegionFeatureStorage* feature,
+                                       LegionUnifiedCache* cache, LegionLaneGroup* group, int32_t n_active,
+                                       int32_t batch_size, int32_t counter0, int32_t dev_id, int32_t mode,
+                                       const int32_t* fanout, int32_t hop_num)
+{
+    legion_enqueue_group_phase(strm_hdl, graph, feature, cache, group, n_active, batch_size, counter0, dev_id, mode,
+                               fanout, hop_num, LG_PHASE_ALL);
 }
 
 extern "C" void legion_enqueue_group(legion_stream_t strm_hdl, LegionGraphStorage* graph, LegionFeatureStorage* feature,

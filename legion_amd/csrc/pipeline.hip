@@ -12,7 +12,12 @@
 //   * the whole op list of a group is captured once per (slot, mode) into a hipGraph; nothing in it
 //     depends on host-side values: sizes (including the clamped last batch) are computed on the
 //     device and the batch index lives in iter_state on the device, advanced by the last kernel;
-//   * `slots` groups are in flight (default 2): while the consumer reads slot s, slot s+1 runs.
+//   * `slots` groups are in flight (default 2): while the consumer reads slot s, slot s+1 runs;
+//   * split mode (use_graph bit 2): the sampler of a group is bound by scattered 4-byte atomics and
+//     loads (~2 TB/s of HBM traffic, waves mostly waiting), its gathers by HBM streaming.  The two
+//     phases are captured as two graphs and run on two streams -- every group's sampler on a
+//     high-priority stream, every group's gathers on another, gathers(k) waiting on sampler(k) -- so
+//     sampler(k+1) runs under gathers(k) and the two kinds of memory traffic share the machine.
 #include "legion_core.h"
 
 #include <map>
@@ -25,6 +30,10 @@ extern "C" void legion_enqueue_group_n(legion_stream_t strm_hdl, LegionGraphStor
                                        LegionUnifiedCache* cache, LegionLaneGroup* group, int32_t n_active,
                                        int32_t batch_size, int32_t counter0, int32_t dev_id, int32_t mode,
                                        const int32_t* fanout, int32_t hop_num);
+extern "C" void legion_enqueue_group_phase(legion_stream_t strm_hdl, LegionGraphStorage* graph, LegionFeatureStorage* feature,
+                                           LegionUnifiedCache* cache, LegionLaneGroup* group, int32_t n_active,
+                                           int32_t batch_size, int32_t counter0, int32_t dev_id, int32_t mode,
+                                           const int32_t* fanout, int32_t hop_num, int32_t phase);
 extern "C" void legion_pool_profile_begin(LegionMemoryPool* p_, int32_t max_ops);
 
 struct Slot {
@@ -32,8 +41,9 @@ struct Slot {
     LegionLaneGroup* group = nullptr;
     hipStream_t stream = nullptr;
     hipEvent_t done = nullptr;
+    hipEvent_t sampled = nullptr;             // split mode: the group's sampler phase has finished
     bool busy = false;
-    std::map<int64_t, hipGraphExec_t> exec;   // key: (mode, active lanes, batch_size)
+    std::map<int64_t, hipGraphExec_t> exec;   // key: (mode, active lanes, batch_size, phase)
     int32_t* d_iter = nullptr;                // device {next counter0, stride}
     int32_t* h_iter = nullptr;                // pinned staging
     int32_t next_iter = -1;                   // what d_iter[0] will hold once the slot is idle
@@ -49,6 +59,9 @@ struct LegionPipeline {
     std::vector<Slot> slots;
     bool use_graph;
     bool overlap = false;   // let kernels of different slots run concurrently (default: chained)
+    bool split = false;     // sampler and gather phases on two streams (see the header comment)
+    hipStream_t sample_stream = nullptr;
+    bool gather_high = false;
     int32_t rr = 0;
     int32_t last_slot = -1;
     bool profiling = false;
@@ -74,7 +87,17 @@ extern "C" LegionPipeline* legion_pipeline_create(LegionGraphStorage* graph, Leg
     p->slots_n = slots < 1 ? 1 : slots;
     p->use_graph = (use_graph & 1) != 0;
     p->overlap = (use_graph & 2) != 0;
+    p->split = (use_graph & 4) != 0;
+    if (p->split) p->overlap = false;
     SetGPUDevice(dev_id);
+    if (p->split) {
+        int lo = 0, hi = 0;                                  // hi is the numerically lowest = highest priority
+        HIP_CALL(hipDeviceGetStreamPriorityRange(&lo, &hi));
+        const char* pe = getenv("LEGION_SPLIT_PRIORITY");
+        const int prio = pe ? atoi(pe) : 1;                  // 1: sampler first, 0: equal, -1: gathers first
+        HIP_CALL(hipStreamCreateWithPriority(&p->sample_stream, hipStreamNonBlocking, prio > 0 ? hi : lo));
+        if (prio < 0) p->gather_high = true;
+    }
     p->slots.resize(p->slots_n);
     for (Slot& sl : p->slots) {
         std::vector<LegionMemoryPool*> handles;
@@ -91,11 +114,16 @@ extern "C" LegionPipeline* legion_pipeline_create(LegionGraphStorage* graph, Leg
         HIP_CALL(hipHostMalloc((void**)&sl.h_iter, 2 * sizeof(int32_t), hipHostMallocDefault));
         // chained slots share one in-order stream (back-to-back graph launches, no event round trip);
         // overlapping slots get a stream each
-        if (p->overlap || &sl == &p->slots[0])
+        if (p->gather_high && &sl == &p->slots[0]) {
+            int lo = 0, hi = 0;
+            HIP_CALL(hipDeviceGetStreamPriorityRange(&lo, &hi));
+            HIP_CALL(hipStreamCreateWithPriority(&sl.stream, hipStreamNonBlocking, hi));
+        } else if (p->overlap || &sl == &p->slots[0])
             HIP_CALL(hipStreamCreateWithFlags(&sl.stream, hipStreamNonBlocking))
         else
             sl.stream = p->slots[0].stream;
         HIP_CALL(hipEventCreateWithFlags(&sl.done, hipEventDisableTiming));
+        HIP_CALL(hipEventCreateWithFlags(&sl.sampled, hipEventDisableTiming));
     }
     return p;
 }
@@ -150,10 +178,19 @@ extern "C" int32_t legion_pipeline_submit_n(LegionPipeline* p, int32_t counter0,
     p->last_slot = si;
     LegionGraphStorage* gr = reinterpret_cast<LegionGraphStorage*>(p->graph);
     LegionFeatureStorage* f = reinterpret_cast<LegionFeatureStorage*>(p->feature);
+    // split mode: phase 1 on the sampler stream, phase 2 on the slot's (gather) stream behind it
+    hipStream_t s1 = p->split ? p->sample_stream : sl.stream;
+    const int32_t first_phase = p->split ? LG_PHASE_SAMPLE : LG_PHASE_ALL;
     if (!p->use_graph || p->profiling) {            // HIP cannot time events recorded by graph nodes
         legion_group_set_iter_state(sl.group, nullptr);     // eager: iteration by value
-        legion_enqueue_group_n(sl.stream, gr, f, p->cache_handle, sl.group, n_active, p->batch_size, counter0,
-                               p->dev_id, mode, p->fanout.data(), p->hop_num);
+        legion_enqueue_group_phase(s1, gr, f, p->cache_handle, sl.group, n_active, p->batch_size, counter0,
+                                   p->dev_id, mode, p->fanout.data(), p->hop_num, first_phase);
+        if (p->split) {
+            HIP_CALL(hipEventRecord(sl.sampled, s1));
+            HIP_CALL(hipStreamWaitEvent(sl.stream, sl.sampled, 0));
+            legion_enqueue_group_phase(sl.stream, gr, f, p->cache_handle, sl.group, n_active, p->batch_size, counter0,
+                                       p->dev_id, mode, p->fanout.data(), p->hop_num, LG_PHASE_GATHER);
+        }
         sl.next_iter = -1;
         sl.prof_pairs = sl.pools[0]->prof_used;
     } else {
@@ -161,23 +198,34 @@ extern "C" int32_t legion_pipeline_submit_n(LegionPipeline* p, int32_t counter0,
         if (sl.next_iter != counter0) {                     // (re)position the device-resident iteration
             sl.h_iter[0] = counter0;
             sl.h_iter[1] = p->group_size * p->slots_n;
-            HIP_CALL(hipMemcpyAsync(sl.d_iter, sl.h_iter, 2 * sizeof(int32_t), hipMemcpyHostToDevice, sl.stream));
+            HIP_CALL(hipMemcpyAsync(sl.d_iter, sl.h_iter, 2 * sizeof(int32_t), hipMemcpyHostToDevice, s1));
         }
-        const int64_t key = ((int64_t)mode << 40) | ((int64_t)n_active << 32) | (uint32_t)p->batch_size;
-        auto it = sl.exec.find(key);
-        if (it == sl.exec.end()) {
-            hipGraph_t graph = nullptr;
-            hipGraphExec_t exec = nullptr;
-            HIP_CALL(hipStreamSynchronize(sl.stream));
-            HIP_CALL(hipStreamBeginCapture(sl.stream, hipStreamCaptureModeThreadLocal));
-            legion_enqueue_group_n(sl.stream, gr, f, p->cache_handle, sl.group, n_active, p->batch_size, counter0,
-                                   p->dev_id, mode, p->fanout.data(), p->hop_num);
-            HIP_CALL(hipStreamEndCapture(sl.stream, &graph));
-            HIP_CALL(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
-            HIP_CALL(hipGraphDestroy(graph));
-            it = sl.exec.emplace(key, exec).first;
+        auto exec_of = [&](hipStream_t strm, int32_t phase) {
+            const int64_t key = ((int64_t)phase << 48) | ((int64_t)mode << 40) | ((int64_t)n_active << 32) |
+                                (uint32_t)p->batch_size;
+            auto it = sl.exec.find(key);
+            if (it == sl.exec.end()) {
+                hipGraph_t graph = nullptr;
+                hipGraphExec_t exec = nullptr;
+                HIP_CALL(hipStreamSynchronize(strm));
+                HIP_CALL(hipStreamBeginCapture(strm, hipStreamCaptureModeThreadLocal));
+                legion_enqueue_group_phase(strm, gr, f, p->cache_handle, sl.group, n_active, p->batch_size, counter0,
+                                           p->dev_id, mode, p->fanout.data(), p->hop_num, phase);
+                HIP_CALL(hipStreamEndCapture(strm, &graph));
+                HIP_CALL(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+                HIP_CALL(hipGraphDestroy(graph));
+                it = sl.exec.emplace(key, exec).first;
+            }
+            return it->second;
+        };
+        hipGraphExec_t e1 = exec_of(s1, first_phase);
+        hipGraphExec_t e2 = p->split ? exec_of(sl.stream, LG_PHASE_GATHER) : nullptr;
+        HIP_CALL(hipGraphLaunch(e1, s1));
+        if (p->split) {
+            HIP_CALL(hipEventRecord(sl.sampled, s1));
+            HIP_CALL(hipStreamWaitEvent(sl.stream, sl.sampled, 0));
+            HIP_CALL(hipGraphLaunch(e2, sl.stream));
         }
-        HIP_CALL(hipGraphLaunch(it->second, sl.stream));
         // what the last kernel leaves in d_iter[0] (a partial group breaks the regular stride)
         sl.next_iter = n_active == p->group_size ? counter0 + p->group_size * p->slots_n : -1;
     }
@@ -204,6 +252,7 @@ extern "C" void legion_pipeline_destroy(LegionPipeline* p)
 {
     if (!p) return;
     SetGPUDevice(p->dev_id);
+    if (p->sample_stream) HIP_CALL(hipStreamSynchronize(p->sample_stream));
     for (Slot& sl : p->slots) {
         slot_wait(p, sl);
         HIP_CALL(hipStreamSynchronize(sl.stream));
@@ -213,8 +262,10 @@ extern "C" void legion_pipeline_destroy(LegionPipeline* p)
         HIP_CALL(hipHostFree(sl.h_iter));
         for (MemoryPool* mp : sl.pools) legion_pool_destroy(reinterpret_cast<LegionMemoryPool*>(mp));
         HIP_CALL(hipEventDestroy(sl.done));
+        HIP_CALL(hipEventDestroy(sl.sampled));
         if (p->overlap || &sl == &p->slots[0]) HIP_CALL(hipStreamDestroy(sl.stream));
     }
+    if (p->sample_stream) HIP_CALL(hipStreamDestroy(p->sample_stream));
     delete p;
 }
 

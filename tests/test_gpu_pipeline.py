@@ -118,12 +118,14 @@ def test_cost_model_matches_oracle(hip, cache_memory, counters):
     gpu.close(); cpu.close()
 
 
-@pytest.mark.parametrize("group,slots,use_graph", [(1, 1, True), (3, 2, True), (4, 2, False), (2, 3, True), (8, 2, True)])
-def test_pipeline_groups_and_graph_replay(hip, group, slots, use_graph):
+@pytest.mark.parametrize("group,slots,use_graph,split", [(1, 1, True, False), (3, 2, True, False), (4, 2, False, False),
+                                                         (2, 3, True, False), (8, 2, True, False), (3, 2, True, True),
+                                                         (4, 2, False, True), (2, 3, True, True), (1, 1, True, True)])
+def test_pipeline_groups_and_graph_replay(hip, group, slots, use_graph, split):
     """Grouped launches (grid.y = lanes) + hipGraph replay produce exactly the batches the one-lane
     eager path does: every batch of a short run -- including the clamped last batch and the empty
     batches past the end of the set, whose sizes are computed on the device -- is compared with the
-    oracle."""
+    oracle.  split = sampler phase and gather phase as two graphs on two streams."""
     from legion_amd import engine
     wl = Workload(scale=11, edge_factor=8, dim=32, n_seeds=700)
     fanout, batch = [6, 3], 64
@@ -135,7 +137,8 @@ def test_pipeline_groups_and_graph_replay(hip, group, slots, use_graph):
     gpu.cache.set_capacity(150, 80)
     gpu.cache.fill_up(gpu.feature, gpu.graph)
     cpu.build_cache(0, capacity=(150, 80))
-    pipe = engine.Pipeline(gpu.graph, gpu.feature, gpu.cache, 0, batch, fanout, group, gpu.pools[0].num_ids, use_graph, slots)
+    pipe = engine.Pipeline(gpu.graph, gpu.feature, gpu.cache, 0, batch, fanout, group, gpu.pools[0].num_ids, use_graph, slots,
+                           split=split)
     n_batches = (wl.sets[(0, 0)][0].size + batch - 1) // batch     # the last one is partial
     n_groups = (n_batches + group - 1) // group                    # the last group may reach past the set
     for rep in range(2):                                          # the second epoch re-positions the device iteration

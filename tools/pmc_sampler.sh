@@ -8,7 +8,7 @@ for grp in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" "SQ_INS
   out=$R/gpurun_out/pmc_s/g$i
   mkdir -p $out
   echo "$grp" > $out/group.txt
-  timeout 300 rocprofv3 --kernel-trace --pmc $grp --output-format csv -d $out -- python3 $R/bench.py --steps 128 --warmup 64 --presc-steps 64 --cpu-seconds 0 --no-verify > $out/bench.json 2> $out/err.txt
+  timeout 300 rocprofv3 --kernel-trace --pmc $grp --output-format csv -d $out -- python3 $R/bench.py --group 64 --steps 128 --warmup 64 --presc-steps 64 --cpu-seconds 0 --no-verify > $out/bench.json 2> $out/err.txt
   echo "group $i rc=$?"
   # keep only the folded summary (the raw csv is large)
   python3 - "$out" <<'PY'
