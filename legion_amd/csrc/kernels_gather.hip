@@ -31,16 +31,18 @@ __global__ __launch_bounds__(LG_GATHER_THREADS) void gather_kernel(GatherParams 
                                                                    bool copy_range)
 {
     constexpr int VEC = sizeof(VecT) / sizeof(float);
-    __shared__ const float* s_ptr[ROWS];
+    __shared__ const LG_G float* s_ptr[ROWS];
 
     const LanePtrs& L = lanes[blockIdx.y];
     // {offset, count} of the new-node range: the live counters, or the per-hop snapshot
-    const int32_t* range = gp.hop >= 0 ? L.hop_scratch + HS_RANGE + 2 * gp.hop : L.node_counter;
+    const LG_G int32_t* range = LG_GPTR(const int32_t, gp.hop >= 0 ? L.hop_scratch + HS_RANGE + 2 * gp.hop : L.node_counter);
+    const LG_G int32_t* sampled_ids = LG_GPTR(const int32_t, L.sampled_ids);
+    LG_G int32_t* cache_search_buffer = LG_GPTR(int32_t, L.cache_search_buffer);
     const int32_t off = range[0];
     int32_t rows = range[1];
     if (copy_range && blockIdx.x == 0 && threadIdx.x == 0) {   // counter_update(op%3==1), operator_impl.cu:83-85
-        L.node_counter[2] = off;
-        L.node_counter[3] = rows;
+        LG_GPTR(int32_t, L.node_counter)[2] = off;
+        LG_GPTR(int32_t, L.node_counter)[3] = rows;
     }
     if (rows > gp.max_rows) rows = gp.max_rows;
     if (rows > L.feature_rows - off) rows = L.feature_rows - off;   // never write past the feature buffer (the
@@ -59,23 +61,23 @@ __global__ __launch_bounds__(LG_GATHER_THREADS) void gather_kernel(GatherParams 
     const int32_t r0 = tile * ROWS;
     const int32_t nr = min(ROWS, rows - r0);
     for (int32_t t = tid; t < nr; t += LG_GATHER_THREADS) {
-        const int32_t id = L.sampled_ids[off + r0 + t];
+        const int32_t id = sampled_ids[off + r0 + t];
         int32_t g = CACHEMISS_FLAG;
         if (gp.node_map != nullptr && id >= 0) g = gp.node_map[id];
-        L.cache_search_buffer[r0 + t] = g;             // FindFeat writes from index 0 each hop
-        const float* p = nullptr;
+        cache_search_buffer[r0 + t] = g;             // FindFeat writes from index 0 each hop
+        const LG_G float* p = nullptr;
         if (g < 0) {
-            if (id >= 0) p = gp.full_table + (int64_t)(id % gp.total_num_nodes) * D;   // :262-266
+            if (id >= 0) p = LG_GPTR(const float, gp.full_table) + (int64_t)(id % gp.total_num_nodes) * D;   // :262-266
         } else {
             const int32_t didx = g / gp.node_capacity, fidx = g - didx * gp.node_capacity;   // :259-260
-            p = gp.cache_tables[didx] + (int64_t)fidx * D;                                   // :268
+            p = LG_GPTR(const float, gp.cache_tables[didx]) + (int64_t)fidx * D;                                   // :268
         }
         s_ptr[t] = p;
     }
     __syncthreads();
 
     const int32_t nchunks = nr * C;
-    float* dst_tile = L.float_features + (int64_t)(off + r0) * D;
+    LG_G float* dst_tile = LG_GPTR(float, L.float_features) + (int64_t)(off + r0) * D;
     int32_t q = tid;
     int32_t r = q / C;
     int32_t c = q - r * C;
@@ -89,9 +91,9 @@ __global__ __launch_bounds__(LG_GATHER_THREADS) void gather_kernel(GatherParams 
             cc[u] = c;
             ok[u] = false;
             if (q < nchunks) {
-                const float* p = s_ptr[r];
+                const LG_G float* p = s_ptr[r];
                 if (p != nullptr) {
-                    v[u] = reinterpret_cast<const VecT*>(p)[c];     // plain loads: measured 74% of HBM peak vs 63% nontemporal
+                    v[u] = ((const LG_G VecT*)p)[c];     // plain loads: measured 74% of HBM peak vs 63% nontemporal
                     ok[u] = true;
                 }
             }
@@ -103,7 +105,7 @@ __global__ __launch_bounds__(LG_GATHER_THREADS) void gather_kernel(GatherParams 
 #pragma unroll
         for (int u = 0; u < UNROLL; u++) {
             if (ok[u])     // write-once output: nontemporal stores
-                __builtin_nontemporal_store(v[u], reinterpret_cast<VecT*>(dst_tile + (int64_t)rr[u] * D) + cc[u]);
+                __builtin_nontemporal_store(v[u], (LG_G VecT*)(dst_tile + (int64_t)rr[u] * D) + cc[u]);
         }
     }
 }

@@ -90,12 +90,28 @@ void launch_draw_batch(hipStream_t s, const int32_t* idx, const int32_t* deg, in
     hipCheckError();
 }
 
+// the per-batch buffers the two bracket kernels touch, as global-address-space pointers
+struct BracketLane {
+    LG_G int32_t* sampled_ids; LG_G int32_t* labels; LG_G int32_t* node_counter; LG_G int32_t* edge_counter;
+    LG_G int32_t* hop_scratch; LG_G uint32_t* position_map;
+    int32_t total_num_nodes;
+};
+__device__ __forceinline__ BracketLane bracket_lane(const LanePtrs& P)
+{
+    BracketLane L;
+    L.sampled_ids = LG_GPTR(int32_t, P.sampled_ids); L.labels = LG_GPTR(int32_t, P.labels);
+    L.node_counter = LG_GPTR(int32_t, P.node_counter); L.edge_counter = LG_GPTR(int32_t, P.edge_counter);
+    L.hop_scratch = LG_GPTR(int32_t, P.hop_scratch); L.position_map = LG_GPTR(uint32_t, P.position_map);
+    L.total_num_nodes = P.total_num_nodes;
+    return L;
+}
+
 // ------------------------------------------------------------------------------------------
 // batch_generate + counter_update(0)
 // ------------------------------------------------------------------------------------------
 __global__ void batch_generate_kernel(SeedParams p, const LanePtrs* __restrict__ lanes)
 {
-    const LanePtrs& L = lanes[blockIdx.y];
+    const BracketLane L = bracket_lane(lanes[blockIdx.y]);
     const int32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
     // lane i of a group takes iteration base + i; under graph replay the base lives on the device
     const int32_t counter = (p.iter_state != nullptr ? p.iter_state[0] : p.counter0) + (int32_t)blockIdx.y;
@@ -122,8 +138,9 @@ __global__ void batch_generate_kernel(SeedParams p, const LanePtrs* __restrict__
         } else {
             const int32_t src_id = p.all_ids[at % p.total_cap];
             L.sampled_ids[idx] = src_id;
-            atomicMin(reinterpret_cast<uint32_t*>(L.position_map) + src_id,
-                      lg_pos_fmt(L.hop_scratch[HS_EPOCH], L.hop_scratch[HS_VALUE_BITS]).hi | (uint32_t)idx);   // seeds are unique (":26 assume no duplicate")
+            __hip_atomic_fetch_min(L.position_map + src_id,
+                                   lg_pos_fmt(L.hop_scratch[HS_EPOCH], L.hop_scratch[HS_VALUE_BITS]).hi | (uint32_t)idx,
+                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // seeds are unique (":26 assume no duplicate")
             L.labels[idx] = p.all_labels[at % p.total_cap];
         }
     }
@@ -143,33 +160,60 @@ void launch_batch_generate(hipStream_t s, const SeedParams& p, const LanePtrs* d
 struct SampleArgs {
     int32_t op_id, count, partition_count, max_slots;
     int32_t* const* csr_dst_node_ids;
-    const RowHdr* row_hdr;
+    const LG_G RowHdr* row_hdr;
     bool last_hop, is_presc;
-    unsigned long long* edge_access_time;
-    int32_t* sampled_ids; int32_t* agg_src_ids; int32_t* agg_dst_ids; int32_t* agg_src_off; int32_t* agg_dst_off;
-    char* tmp_part_ind; int32_t* position_map; int32_t* node_counter; int32_t* edge_counter;
-    int32_t* slot_dst; int32_t* slot_pos; int32_t* tile_counts; int32_t* tile_prefix; int32_t* hop_scratch; RowHdr* fh_edge;
+    LG_G unsigned long long* edge_access_time;
+    // the lane's buffers, in the global address space (see LG_G in legion_core.h)
+    LG_G int32_t* sampled_ids; LG_G int32_t* agg_src_ids; LG_G int32_t* agg_dst_ids; LG_G int32_t* agg_src_off; LG_G int32_t* agg_dst_off;
+    LG_G char* tmp_part_ind; LG_G uint32_t* position_map; LG_G int32_t* node_counter; LG_G int32_t* edge_counter;
+    LG_G int32_t* slot_dst; LG_G int32_t* slot_pos; LG_G int32_t* tile_counts; LG_G int32_t* tile_prefix; LG_G int32_t* hop_scratch;
+    LG_G RowHdr* fh_edge;
     PosFmt pf;
 };
+
+// 16-byte header load / store through a global-address-space pointer (no implicit struct copy across
+// address spaces in HIP C++)
+typedef int32_t lg_v4i __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ RowHdr load_hdr(const LG_G RowHdr* p)
+{
+    const lg_v4i t = *(const LG_G lg_v4i*)p;
+    RowHdr h;
+    h.start = (int64_t)(((uint64_t)(uint32_t)t.y << 32) | (uint32_t)t.x);
+    h.deg = t.z;
+    h.slot = t.w;
+    return h;
+}
+__device__ __forceinline__ void store_hdr(LG_G RowHdr* p, const RowHdr& h)
+{
+    lg_v4i t;
+    t.x = (int32_t)(uint32_t)h.start;
+    t.y = (int32_t)((uint64_t)h.start >> 32);
+    t.z = h.deg;
+    t.w = h.slot;
+    *(LG_G lg_v4i*)p = t;
+}
 
 __device__ __forceinline__ SampleArgs lane_args(const HopParams& p, const LanePtrs* __restrict__ lanes)
 {
     const LanePtrs& L = lanes[blockIdx.y];
     SampleArgs a;
     a.op_id = p.op_id; a.count = p.count; a.partition_count = p.partition_count; a.max_slots = p.max_slots;
-    a.csr_dst_node_ids = p.csr_dst_node_ids; a.row_hdr = p.row_hdr; a.last_hop = p.last_hop; a.is_presc = p.is_presc;
-    a.edge_access_time = p.edge_access_time;
-    a.sampled_ids = L.sampled_ids; a.agg_src_ids = L.agg_src_ids; a.agg_dst_ids = L.agg_dst_ids;
-    a.agg_src_off = L.agg_src_off; a.agg_dst_off = L.agg_dst_off; a.tmp_part_ind = L.tmp_part_ind;
-    a.position_map = L.position_map; a.node_counter = L.node_counter; a.edge_counter = L.edge_counter;
-    a.slot_dst = L.slot_dst; a.slot_pos = L.slot_pos; a.tile_counts = L.tile_counts; a.tile_prefix = L.tile_prefix;
-    a.hop_scratch = L.hop_scratch; a.fh_edge = L.fh_edge;
-    a.pf = lg_pos_fmt(L.hop_scratch[HS_EPOCH], L.hop_scratch[HS_VALUE_BITS]);
+    a.csr_dst_node_ids = p.csr_dst_node_ids; a.row_hdr = LG_GPTR(const RowHdr, p.row_hdr); a.last_hop = p.last_hop; a.is_presc = p.is_presc;
+    a.edge_access_time = LG_GPTR(unsigned long long, p.edge_access_time);
+    a.sampled_ids = LG_GPTR(int32_t, L.sampled_ids); a.agg_src_ids = LG_GPTR(int32_t, L.agg_src_ids);
+    a.agg_dst_ids = LG_GPTR(int32_t, L.agg_dst_ids); a.agg_src_off = LG_GPTR(int32_t, L.agg_src_off);
+    a.agg_dst_off = LG_GPTR(int32_t, L.agg_dst_off); a.tmp_part_ind = LG_GPTR(char, L.tmp_part_ind);
+    a.position_map = LG_GPTR(uint32_t, L.position_map); a.node_counter = LG_GPTR(int32_t, L.node_counter);
+    a.edge_counter = LG_GPTR(int32_t, L.edge_counter); a.slot_dst = LG_GPTR(int32_t, L.slot_dst);
+    a.slot_pos = LG_GPTR(int32_t, L.slot_pos); a.tile_counts = LG_GPTR(int32_t, L.tile_counts);
+    a.tile_prefix = LG_GPTR(int32_t, L.tile_prefix); a.hop_scratch = LG_GPTR(int32_t, L.hop_scratch);
+    a.fh_edge = LG_GPTR(RowHdr, L.fh_edge);
+    a.pf = lg_pos_fmt(a.hop_scratch[HS_EPOCH], a.hop_scratch[HS_VALUE_BITS]);
     return a;
 }
 
 struct HopGeom {
-    const int32_t* frontier;
+    const LG_G int32_t* frontier;
     int32_t frontier_len;
     int32_t frontier_off;   // offset of the frontier inside the per-edge arrays (0 for the seeds)
     int32_t total;          // slots
@@ -215,7 +259,7 @@ __global__ __launch_bounds__(LG_TILE) void sample_kernel(HopParams hp, const Lan
     const int32_t tid = threadIdx.x;
     const int32_t count = a.count;
     const bool seeds = (a.op_id == INTRABATCH_CON);
-    const RowHdr* fh = a.fh_edge + g.frontier_off;
+    const LG_G RowHdr* fh = a.fh_edge + g.frontier_off;
 
     for (int32_t st = blockIdx.x; st < g.nsuper; st += gridDim.x) {
         const int32_t idx0 = st * LG_SUPER;
@@ -233,12 +277,12 @@ __global__ __launch_bounds__(LG_TILE) void sample_kernel(HopParams hp, const Lan
             if (seeds) {
                 const int32_t src = g.frontier[j0 + t];
                 if (src >= 0) {
-                    h = a.row_hdr[src];
+                    h = load_hdr(a.row_hdr + src);
                 } else {
                     h.start = 0; h.deg = 0; h.slot = a.partition_count;
                 }
             } else {
-                h = fh[j0 + t];
+                h = load_hdr(fh + j0 + t);
             }
             s_hdr[t] = h;
             if (!a.is_presc)   // FindTopo's hit mask: owner device of the cached row, or -2 (cache.cu:217-225)
@@ -257,7 +301,7 @@ __global__ __launch_bounds__(LG_TILE) void sample_kernel(HopParams hp, const Lan
                 const RowHdr h = s_hdr[q - j0];
                 if (k < h.deg) {                                           // :232-233 (src < 0 has deg 0)
                     const int32_t pick = draw_from_x(x[u], h.deg);         // :235-238
-                    dst[u] = a.csr_dst_node_ids[h.slot][h.start + (int64_t)pick];   // :239-243
+                    dst[u] = LG_GPTR(const int32_t, a.csr_dst_node_ids[h.slot])[h.start + (int64_t)pick];   // :239-243
                 }
             }
         }
@@ -266,10 +310,11 @@ __global__ __launch_bounds__(LG_TILE) void sample_kernel(HopParams hp, const Lan
             const int32_t idx = idx0 + u * LG_TILE + tid;
             if (idx < g.total) {
                 if (dst[u] >= 0) {                                         // :244
-                    atomicMin(reinterpret_cast<uint32_t*>(a.position_map) + dst[u],
-                              (a.pf.hi | a.pf.pending | (uint32_t)idx));
+                    __hip_atomic_fetch_min(a.position_map + dst[u], a.pf.hi | a.pf.pending | (uint32_t)idx,
+                                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     if (a.edge_access_time)                                // :358
-                        atomicAdd(a.edge_access_time + g.frontier[idx / count], 1ull);
+                        __hip_atomic_fetch_add(a.edge_access_time + g.frontier[idx / count], 1ull, __ATOMIC_RELAXED,
+                                               __HIP_MEMORY_SCOPE_AGENT);
                 } else {
                     dst[u] = -1;
                 }
@@ -344,8 +389,8 @@ __global__ __launch_bounds__(LG_SCAN_THREADS) void scan_kernel(HopParams hp, con
     __shared__ int32_t s_e[LG_SCAN_THREADS];
     __shared__ int32_t s_n[LG_SCAN_THREADS];
     const HopGeom g = hop_geometry(a);
-    int32_t* nc = a.node_counter;
-    int32_t* ec = a.edge_counter;
+    LG_G int32_t* nc = a.node_counter;
+    LG_G int32_t* ec = a.edge_counter;
     const int32_t nc0 = nc[0], nc1 = nc[1], ec0 = ec[0], ec1 = ec[1];
     const int32_t tid = threadIdx.x;
 
@@ -374,7 +419,7 @@ __global__ __launch_bounds__(LG_SCAN_THREADS) void scan_kernel(HopParams hp, con
     if (tid == 0) {
         const int32_t n_edge = s_e[LG_SCAN_THREADS - 1];
         const int32_t n_new = s_n[LG_SCAN_THREADS - 1];
-        int32_t* hs = a.hop_scratch;
+        LG_G int32_t* hs = a.hop_scratch;
         hs[HS_FRONTIER_IS_SEEDS] = (a.op_id == INTRABATCH_CON) ? 1 : 0;
         hs[HS_FRONTIER_OFF] = (a.op_id == INTRABATCH_CON) ? 0 : ec0;
         hs[HS_FRONTIER_LEN] = g.frontier_len;
@@ -409,14 +454,14 @@ __global__ __launch_bounds__(LG_TILE) void scatter_kernel(HopParams hp, const La
 {
     const SampleArgs a = lane_args(hp, lanes);
     __shared__ int32_t s_cnt[LG_SLOTS_PER_LANE][2][LG_TILE / 64];
-    const int32_t* hs = a.hop_scratch;
+    const LG_G int32_t* hs = a.hop_scratch;
     const int32_t total = hs[HS_SLOTS];
     const int32_t ntiles = (total + LG_TILE - 1) / LG_TILE;
     const int32_t nsuper = (total + LG_SUPER - 1) / LG_SUPER;
     const bool seeds = hs[HS_FRONTIER_IS_SEEDS] != 0;
     const int32_t f_off = hs[HS_FRONTIER_OFF];
     const int32_t node_base = hs[HS_NODE_BASE], edge_base = hs[HS_EDGE_BASE];
-    const int32_t* frontier = seeds ? a.sampled_ids : a.agg_src_ids + f_off;
+    const LG_G int32_t* frontier = seeds ? a.sampled_ids : a.agg_src_ids + f_off;
     const int32_t tid = threadIdx.x;
     const int32_t wave = tid >> 6, lane = tid & 63;
     const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
@@ -458,7 +503,7 @@ __global__ __launch_bounds__(LG_TILE) void scatter_kernel(HopParams hp, const La
                 a.agg_dst_ids[e] = frontier[q];                    // :257, :277
                 // position of the node sampled for == construct_graph's position_map[agg_dst_ids[e]]
                 a.agg_dst_off[e] = seeds ? q : a.agg_src_off[f_off + q];
-                if (!a.last_hop) a.fh_edge[e] = a.row_hdr[dst];    // next hop's frontier header
+                if (!a.last_hop) store_hdr(a.fh_edge + e, load_hdr(a.row_hdr + dst));    // next hop's frontier header
                 if (first) {
                     const int32_t n = node_base + a.tile_prefix[2 * tile + 1] + wn + __popcll(mf[u] & lt);
                     a.sampled_ids[n] = dst;                        // :270
@@ -482,7 +527,7 @@ __global__ __launch_bounds__(LG_TILE) void scatter_kernel(HopParams hp, const La
 __global__ __launch_bounds__(LG_TILE) void localise_kernel(HopParams hp, const LanePtrs* __restrict__ lanes)
 {
     const SampleArgs a = lane_args(hp, lanes);
-    const int32_t* hs = a.hop_scratch;
+    const LG_G int32_t* hs = a.hop_scratch;
     const int32_t n_edge = hs[HS_N_EDGE], edge_base = hs[HS_EDGE_BASE];
     const int32_t nsuper = (n_edge + LG_SUPER - 1) / LG_SUPER;
     // scatter already localised every edge whose neighbour was final or first-touched by that very
@@ -583,18 +628,19 @@ void cache_row_headers(hipStream_t s, RowHdr* hdr, const int32_t* QT, int32_t Kg
 // ------------------------------------------------------------------------------------------
 __global__ void end_of_batch_kernel(const LanePtrs* __restrict__ lanes, int32_t* __restrict__ iter_state)
 {
-    const LanePtrs& L = lanes[blockIdx.y];
+    const BracketLane L = bracket_lane(lanes[blockIdx.y]);
     __shared__ int32_t s_last;
     const int32_t epoch = L.hop_scratch[HS_EPOCH];
     const int32_t epoch_max = lg_pos_epoch_max(L.hop_scratch[HS_VALUE_BITS]);
     if (epoch >= epoch_max) {
-        uint32_t* pm = reinterpret_cast<uint32_t*>(L.position_map);
+        LG_G uint32_t* pm = L.position_map;
         for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < L.total_num_nodes; i += (int64_t)gridDim.x * blockDim.x)
             pm[i] = 0xFFFFFFFFu;
     }
     __syncthreads();
     if (threadIdx.x == 0)   // no fence needed: the kernel boundary publishes the refill and the new epoch
-        s_last = (atomicAdd(L.hop_scratch + HS_TICKET, 1) == (int32_t)gridDim.x - 1) ? 1 : 0;
+        s_last = (__hip_atomic_fetch_add(L.hop_scratch + HS_TICKET, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ==
+                  (int32_t)gridDim.x - 1) ? 1 : 0;
     __syncthreads();
     if (s_last && threadIdx.x == 0) {
         L.hop_scratch[HS_TICKET] = 0;

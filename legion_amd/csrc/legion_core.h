@@ -96,6 +96,13 @@ enum HopScratch {
     HS_WORDS = 32
 };
 
+// Device code: a pointer that was loaded from memory (LanePtrs, pointer tables, LDS) is "generic" to
+// the compiler, which then emits flat_* instructions; those count on lgkmcnt as well as vmcnt, so every
+// LDS wait also waits for the memory operations in flight.  Kernels cast such pointers to the global
+// address space once (every buffer of this library is HBM, peer HBM or mapped host memory).
+#define LG_G __attribute__((address_space(1)))
+#define LG_GPTR(T, p) ((LG_G T*)(p))
+
 // phases of a whole-batch enqueue (legion_enqueue_group_phase)
 #define LG_PHASE_ALL 0      // reference op order: gather right after the op that produced its rows
 #define LG_PHASE_SAMPLE 1   // BatchGenerate + every RandomSample + IOComplete
