@@ -93,8 +93,8 @@ void launch_draw_batch(hipStream_t s, const int32_t* idx, const int32_t* deg, in
 // the per-batch buffers the two bracket kernels touch, as global-address-space pointers
 struct BracketLane {
     LG_G int32_t* sampled_ids; LG_G int32_t* labels; LG_G int32_t* node_counter; LG_G int32_t* edge_counter;
-    LG_G int32_t* hop_scratch; LG_G uint32_t* position_map;
-    int32_t total_num_nodes;
+    LG_G int32_t* hop_scratch; LG_G uint32_t* position_map; LG_G int32_t* slot_mark;
+    int32_t total_num_nodes, max_slots;
 };
 __device__ __forceinline__ BracketLane bracket_lane(const LanePtrs& P)
 {
@@ -102,7 +102,8 @@ __device__ __forceinline__ BracketLane bracket_lane(const LanePtrs& P)
     L.sampled_ids = LG_GPTR(int32_t, P.sampled_ids); L.labels = LG_GPTR(int32_t, P.labels);
     L.node_counter = LG_GPTR(int32_t, P.node_counter); L.edge_counter = LG_GPTR(int32_t, P.edge_counter);
     L.hop_scratch = LG_GPTR(int32_t, P.hop_scratch); L.position_map = LG_GPTR(uint32_t, P.position_map);
-    L.total_num_nodes = P.total_num_nodes;
+    L.slot_mark = LG_GPTR(int32_t, P.slot_mark);
+    L.total_num_nodes = P.total_num_nodes; L.max_slots = P.max_slots;
     return L;
 }
 
@@ -166,9 +167,10 @@ struct SampleArgs {
     // the lane's buffers, in the global address space (see LG_G in legion_core.h)
     LG_G int32_t* sampled_ids; LG_G int32_t* agg_src_ids; LG_G int32_t* agg_dst_ids; LG_G int32_t* agg_src_off; LG_G int32_t* agg_dst_off;
     LG_G char* tmp_part_ind; LG_G uint32_t* position_map; LG_G int32_t* node_counter; LG_G int32_t* edge_counter;
-    LG_G int32_t* slot_dst; LG_G int32_t* slot_pos; LG_G int32_t* tile_counts; LG_G int32_t* tile_prefix; LG_G int32_t* hop_scratch;
+    LG_G int32_t* slot_dst; LG_G int32_t* slot_pos; LG_G int32_t* slot_mark; LG_G int32_t* tile_counts; LG_G int32_t* tile_prefix; LG_G int32_t* hop_scratch;
     LG_G RowHdr* fh_edge;
     PosFmt pf;
+    int32_t mark_tag;   // (epoch, hop): what slot_mark holds for a slot that lost its first touch in THIS hop
 };
 
 // 16-byte header load / store through a global-address-space pointer (no implicit struct copy across
@@ -205,10 +207,11 @@ __device__ __forceinline__ SampleArgs lane_args(const HopParams& p, const LanePt
     a.agg_dst_off = LG_GPTR(int32_t, L.agg_dst_off); a.tmp_part_ind = LG_GPTR(char, L.tmp_part_ind);
     a.position_map = LG_GPTR(uint32_t, L.position_map); a.node_counter = LG_GPTR(int32_t, L.node_counter);
     a.edge_counter = LG_GPTR(int32_t, L.edge_counter); a.slot_dst = LG_GPTR(int32_t, L.slot_dst);
-    a.slot_pos = LG_GPTR(int32_t, L.slot_pos); a.tile_counts = LG_GPTR(int32_t, L.tile_counts);
+    a.slot_pos = LG_GPTR(int32_t, L.slot_pos); a.slot_mark = LG_GPTR(int32_t, L.slot_mark); a.tile_counts = LG_GPTR(int32_t, L.tile_counts);
     a.tile_prefix = LG_GPTR(int32_t, L.tile_prefix); a.hop_scratch = LG_GPTR(int32_t, L.hop_scratch);
     a.fh_edge = LG_GPTR(RowHdr, L.fh_edge);
     a.pf = lg_pos_fmt(a.hop_scratch[HS_EPOCH], a.hop_scratch[HS_VALUE_BITS]);
+    a.mark_tag = (a.hop_scratch[HS_EPOCH] << 8) | (p.op_id / INTRABATCH_CON);
     return a;
 }
 
@@ -310,8 +313,26 @@ __global__ __launch_bounds__(LG_TILE) void sample_kernel(HopParams hp, const Lan
             const int32_t idx = idx0 + u * LG_TILE + tid;
             if (idx < g.total) {
                 if (dst[u] >= 0) {                                         // :244
-                    __hip_atomic_fetch_min(a.position_map + dst[u], a.pf.hi | a.pf.pending | (uint32_t)idx,
-                                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    // First touch goes to the LOWEST slot that sampled the vertex.  The atomic returns what
+                    // it replaced, so every loser is known without a second look at the state array:
+                    //   old < key : the vertex is already in the batch (final position) or a lower slot of this
+                    //               hop holds it -> this slot lost, and knows to whom;
+                    //   old > key, this epoch : old is a higher slot that held it until now -> THAT slot lost to
+                    //               this one (it wrote nothing itself, so the two stores below have one writer);
+                    //   otherwise : untouched so far; this slot holds it unless a lower one shows up.
+                    // A loser gets the hop's tag in slot_mark and, in slot_pos, the final position or -2 - (the
+                    // slot it lost to); the chain of losers ends at the winner (localise follows it).
+                    const uint32_t key = a.pf.hi | a.pf.pending | (uint32_t)idx;
+                    const uint32_t old = __hip_atomic_fetch_min(a.position_map + dst[u], key, __ATOMIC_RELAXED,
+                                                                __HIP_MEMORY_SCOPE_AGENT);
+                    if (old < key) {
+                        a.slot_mark[idx] = a.mark_tag;
+                        a.slot_pos[idx] = (old & a.pf.pending) ? -2 - (int32_t)(old & a.pf.vmask) : (int32_t)(old & a.pf.vmask);
+                    } else if ((old & ~(a.pf.pending | a.pf.vmask)) == a.pf.hi) {
+                        const int32_t loser = (int32_t)(old & a.pf.vmask);
+                        a.slot_mark[loser] = a.mark_tag;
+                        a.slot_pos[loser] = -2 - idx;
+                    }
                     if (a.edge_access_time)                                // :358
                         __hip_atomic_fetch_add(a.edge_access_time + g.frontier[idx / count], 1ull, __ATOMIC_RELAXED,
                                                __HIP_MEMORY_SCOPE_AGENT);
@@ -326,7 +347,8 @@ __global__ __launch_bounds__(LG_TILE) void sample_kernel(HopParams hp, const Lan
 }
 
 // ------------------------------------------------------------------------------------------
-// K2: per-256-slot-tile counts of valid edges and first touches
+// K2: per-256-slot-tile counts of valid edges and first touches (coalesced reads only: the sample
+//     kernel left a mark on every slot that lost its first touch)
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(LG_TILE) void flag_count_kernel(HopParams hp, const LanePtrs* __restrict__ lanes)
 {
@@ -338,25 +360,19 @@ __global__ __launch_bounds__(LG_TILE) void flag_count_kernel(HopParams hp, const
 
     for (int32_t st = blockIdx.x; st < g.nsuper; st += gridDim.x) {
         const int32_t idx0 = st * LG_SUPER;
-        int32_t v[LG_SLOTS_PER_LANE], pm[LG_SLOTS_PER_LANE];
+        int32_t v[LG_SLOTS_PER_LANE], mk[LG_SLOTS_PER_LANE];
 #pragma unroll
         for (int u = 0; u < LG_SLOTS_PER_LANE; u++) {
             const int32_t idx = idx0 + u * LG_TILE + tid;
             v[u] = idx < g.total ? a.slot_dst[idx] : -1;
+            mk[u] = idx < g.total ? a.slot_mark[idx] : 0;
         }
-#pragma unroll
-        for (int u = 0; u < LG_SLOTS_PER_LANE; u++) pm[u] = v[u] >= 0 ? a.position_map[v[u]] : 0;
 #pragma unroll
         for (int u = 0; u < LG_SLOTS_PER_LANE; u++) {
             const int32_t idx = idx0 + u * LG_TILE + tid;
             const bool valid = v[u] >= 0;
-            const bool first = valid && (uint32_t)pm[u] == (a.pf.hi | a.pf.pending | (uint32_t)idx);
+            const bool first = valid && mk[u] != a.mark_tag;     // nobody marked it a loser in this hop
             if (first) a.slot_dst[idx] = v[u] | (int32_t)0x80000000;
-            // final position if the neighbour was already in the batch; else it is owned by another slot of
-            // this hop: remember WHICH (-2 - owner slot), localise picks that slot's new position up
-            if (valid && !first)
-                a.slot_pos[idx] = ((uint32_t)pm[u] & a.pf.pending) ? -2 - (int32_t)((uint32_t)pm[u] & a.pf.vmask)
-                                                                    : (int32_t)((uint32_t)pm[u] & a.pf.vmask);
             const unsigned long long mv = __ballot(valid);
             const unsigned long long mf = __ballot(first);
             if (lane == 0) {
@@ -532,7 +548,7 @@ __global__ __launch_bounds__(LG_TILE) void localise_kernel(HopParams hp, const L
     const int32_t nsuper = (n_edge + LG_SUPER - 1) / LG_SUPER;
     // scatter already localised every edge whose neighbour was final or first-touched by that very
     // slot; what is left (< 0) are neighbours owned by ANOTHER slot of this hop, whose new position
-    // scatter left in slot_pos[owner]: one read of a small array each (:289-293)
+    // scatter left in slot_pos[winner]: a short walk through a small array (:289-293)
     for (int32_t st = blockIdx.x; st < nsuper; st += gridDim.x) {
         int32_t cur[LG_SLOTS_PER_LANE];
 #pragma unroll
@@ -543,7 +559,11 @@ __global__ __launch_bounds__(LG_TILE) void localise_kernel(HopParams hp, const L
 #pragma unroll
         for (int u = 0; u < LG_SLOTS_PER_LANE; u++) {
             const int32_t e = st * LG_SUPER + u * LG_TILE + threadIdx.x;
-            if (cur[u] < 0) a.agg_src_off[edge_base + e] = a.slot_pos[-2 - cur[u]];
+            if (cur[u] < 0) {      // -2 - (slot it lost to); that slot may have lost to a lower one in turn
+                int32_t c = cur[u];
+                for (int it = 0; it < 65536 && c < -1; it++) c = a.slot_pos[-2 - c];   // strictly descending slots
+                a.agg_src_off[edge_base + e] = c;
+            }
         }
     }
 }
@@ -636,6 +656,9 @@ __global__ void end_of_batch_kernel(const LanePtrs* __restrict__ lanes, int32_t*
         LG_G uint32_t* pm = L.position_map;
         for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < L.total_num_nodes; i += (int64_t)gridDim.x * blockDim.x)
             pm[i] = 0xFFFFFFFFu;
+        // the loser marks carry (epoch, hop): epochs are about to repeat
+        for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < L.max_slots; i += (int64_t)gridDim.x * blockDim.x)
+            L.slot_mark[i] = 0;
     }
     __syncthreads();
     if (threadIdx.x == 0)   // no fence needed: the kernel boundary publishes the refill and the new epoch

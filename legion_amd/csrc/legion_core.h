@@ -155,6 +155,7 @@ struct LanePtrs {
     int32_t* edge_counter;
     int32_t* slot_dst;
     int32_t* slot_pos;
+    int32_t* slot_mark;
     int32_t* tile_counts;
     int32_t* tile_prefix;
     int32_t* hop_scratch;
@@ -163,6 +164,7 @@ struct LanePtrs {
     float* float_features;
     int32_t feature_rows;
     int32_t total_num_nodes;
+    int32_t max_slots;
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -215,6 +217,7 @@ public:
     // new in this build: sampler scratch (all device memory, private to the server)
     int32_t* slot_dst = nullptr;       // [max_slots] sampled neighbour per slot (sign bit = first touch)
     int32_t* slot_pos = nullptr;       // [max_slots] what the position state held for that neighbour
+    int32_t* slot_mark = nullptr;      // [max_slots] (epoch, hop) tag of the hop in which the slot lost its first touch
     int32_t* tile_counts = nullptr;    // [2 * max_tiles] valid / first-touch counts per tile
     int32_t* tile_prefix = nullptr;    // [2 * max_tiles] exclusive prefixes
     RowHdr* fh_edge = nullptr;         // [num_ids] frontier row headers written by scatter

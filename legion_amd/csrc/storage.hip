@@ -340,6 +340,8 @@ LanePtrs MemoryPool::HostLane(int32_t pipe) const
     h.edge_counter = edge_counter_[pipe];
     h.slot_dst = slot_dst;
     h.slot_pos = slot_pos;
+    h.slot_mark = slot_mark;
+    h.max_slots = max_slots;
     h.total_num_nodes = total_num_nodes;
     h.tile_counts = tile_counts;
     h.tile_prefix = tile_prefix;
@@ -380,6 +382,8 @@ void MemoryPool::Finalize()
     d_free_space(slot_dst);
     d_free_space(slot_pos);
     slot_pos = nullptr;
+    d_free_space(slot_mark);
+    slot_mark = nullptr;
     d_free_space(tile_counts);
     d_free_space(tile_prefix);
     d_free_space(hop_scratch);
@@ -437,6 +441,8 @@ void lg_pool_alloc_private(MemoryPool* mp, int32_t dev_id, int32_t total_num_nod
     const int64_t max_tiles = (mp->max_slots + LG_TILE - 1) / LG_TILE + 1;
     mp->slot_dst = (int32_t*)d_alloc_space((int64_t)mp->max_slots * sizeof(int32_t));
     mp->slot_pos = (int32_t*)d_alloc_space((int64_t)mp->max_slots * sizeof(int32_t));
+    mp->slot_mark = (int32_t*)d_alloc_space((int64_t)mp->max_slots * sizeof(int32_t));
+    HIP_CALL(hipMemset(mp->slot_mark, 0, (size_t)mp->max_slots * sizeof(int32_t)));
     mp->tile_counts = (int32_t*)d_alloc_space(2 * max_tiles * sizeof(int32_t));
     mp->tile_prefix = (int32_t*)d_alloc_space(2 * max_tiles * sizeof(int32_t));
     mp->fh_edge = (RowHdr*)d_alloc_space(num_ids * sizeof(RowHdr));
