@@ -58,6 +58,9 @@ def parse_args():
     ap.add_argument("--split", action="store_true",
                     help="sampler phase and gather phase of every group on two streams (sampler k+1 under gathers k)")
     ap.add_argument("--no-verify", action="store_true")
+    ap.add_argument("--measured-counters", action="store_true",
+                    help="feed the cost model with the topology transactions the sampler counted during PreSC "
+                         "(default: {0,0} as the reference's v2 does)")
     ap.add_argument("--stripe", action="store_true",
                     help="N > 1: one clique of N GPUs, feature/topology caches striped over the ranks and read "
                          "through peer pointers over xGMI (default: every GPU caches for itself, no peer traffic)")
@@ -137,12 +140,18 @@ def main():
         dist.all_reduce(cache.array("node_access_time", d))
         dist.all_reduce(cache.array("edge_access_time", d))
     max_ids = cache.max_id_num(d)
+    topo_tx = cache.topo_transactions(d)
+    if use_dist:
+        tt = torch.tensor([topo_tx], dtype=torch.int64, device=dev if args.backend == "nccl" else "cpu")
+        dist.all_reduce(tt)
+        topo_tx = int(tt.item())
+    counters = (topo_tx, 0) if args.measured_counters else (0, 0)
     if stripe:
         mids = [None] * world
         dist.all_gather_object(mids, max_ids)
         cache.set_peer_max_ids(mids)
         cache.candidate_selection(int(np.log2(world)), graph, world_reduced=True)
-        cache.cost_model(feature, graph, (0, 0), train_step)
+        cache.cost_model(feature, graph, counters, train_step)
 
         def all_gather_bytes(b):
             out = [None] * world
@@ -153,7 +162,7 @@ def main():
         dist.barrier()
     else:
         cache.candidate_selection(0, graph, world_reduced=use_dist)
-        cache.cost_model(feature, graph, (0, 0), train_step)
+        cache.cost_model(feature, graph, counters, train_step)
         cache.fill_up(feature, graph)
     feature_rows = int(max_ids * 1.2)                                        # server.cu:277
     pool.close()
@@ -282,7 +291,8 @@ def main():
                        "batches_per_launch_group": G, "groups_in_flight": args.slots, "hipgraph": not args.no_graph,
                        "cache_memory_bytes": args.cache_memory,
                        "feature_cache_rows": cache.node_capacity(d), "topology_cache_vertices": cache.edge_capacity(d),
-                       "presc_batches": train_step},
+                       "presc_batches": train_step, "presc_topology_transactions": topo_tx,
+                       "cost_model_counters": list(counters)},
             "feature_gather_GBps": payload_gbps * 1.0,
             "feature_gather_GBps_note": "payload bytes read (rows*D*4) / HIP-event time of all gather launches, rank 0",
             "sampling_only": {"edges_per_sec": float(edges.sum()) / t_sampling, "algorithmic_GBps": samp_bytes / t_sampling / 1e9,

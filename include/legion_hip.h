@@ -148,6 +148,12 @@ void legion_cache_fill_up_link(LegionUnifiedCache* c, LegionFeatureStorage* feat
 int32_t legion_cache_node_capacity(const LegionUnifiedCache* c, int32_t dev_id);
 int32_t legion_cache_edge_capacity(const LegionUnifiedCache* c, int32_t dev_id);
 int32_t legion_cache_max_id_num(const LegionUnifiedCache* c, int32_t dev_id);
+/* 64-byte transactions GPU dev_id's PreSC epoch spent on topology reads, counted by the sampler itself
+ * (per sampled row: 1 for the row-pointer pair + min(fan-out, ceil(4*deg/64)) for the picks).  This is the
+ * quantity the paper took from Intel PCM and v2 hard-wires to 0 (SS/engine/server.cu:105-110,
+ * SS/engine/monitor.cuh); sum it over the GPUs and pass it as counters[0] to legion_cache_cost_model to
+ * restore the topology-vs-feature trade-off, or pass {0,0} to reproduce v2. */
+uint64_t legion_cache_topo_transactions(LegionUnifiedCache* c, int32_t dev_id);
 /* which: 0 QF 1 QT (int32[N]) 2 AF 3 AT (uint64[N]) 4 node_access_time 5 edge_access_time
  *        (uint64[N], per device) 6 node_map 8 edge_offset_map (int32[N]) 7 edge_index_map (int8[N]) */
 void* legion_cache_array(LegionUnifiedCache* c, int32_t dev_id, int32_t which);

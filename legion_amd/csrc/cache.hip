@@ -52,9 +52,10 @@ public:
         SetGPUDevice(dev_id);
         const int64_t bytes = (int64_t)total_num_nodes * sizeof(unsigned long long);
         node_access_time_ = (unsigned long long*)d_alloc_space(bytes);
-        edge_access_time_ = (unsigned long long*)d_alloc_space(bytes);
+        // one extra word behind the edge counters: the PreSC epoch's topology transaction count
+        edge_access_time_ = (unsigned long long*)d_alloc_space(bytes + (int64_t)sizeof(unsigned long long));
         HIP_CALL(hipMemset(node_access_time_, 0, (size_t)bytes));
-        HIP_CALL(hipMemset(edge_access_time_, 0, (size_t)bytes));
+        HIP_CALL(hipMemset(edge_access_time_, 0, (size_t)bytes + sizeof(unsigned long long)));
         d_max_ids_ = (int32_t*)d_alloc_space(4);
         HIP_CALL(hipMemset(d_max_ids_, 0, 4));
         iter_ = 0;
@@ -126,6 +127,7 @@ public:
     void AccessCount(int32_t*, int32_t, void*) override {}
     unsigned long long int* GetNodeAccessedMap() override { return node_access_time_; }
     unsigned long long int* GetEdgeAccessedMap() override { return edge_access_time_; }
+    unsigned long long int* GetTopoTransactions() override { return edge_access_time_ ? edge_access_time_ + total_num_nodes_ : nullptr; }
 
     // SS/cache/cache.cu:180-215 -- range taken from the device counters, no read-back
     void FindFeat(int32_t* sampled_ids, int32_t* cache_offset, int32_t* node_counter, int32_t op_id,
@@ -539,6 +541,22 @@ extern "C" int32_t legion_cache_edge_capacity(const LegionUnifiedCache* c, int32
 {
     const UnifiedCache* u = as_cache(c);
     return u ? u->EdgeCapacity(dev_id) : 0;
+}
+
+// 64-byte transactions the topology reads of GPU dev_id's PreSC epoch amount to (the quantity the
+// paper measured with Intel PCM on the PCIe root ports and v2 hard-wires to 0, SS/engine/server.cu:105-110):
+// per sampled row one transaction for the row-pointer pair plus min(fan-out, ceil(4*deg/64)) for the picks.
+extern "C" uint64_t legion_cache_topo_transactions(LegionUnifiedCache* c, int32_t dev_id)
+{
+    UnifiedCache* u = as_cache(c);
+    if (!u) return 0;
+    CacheController* cc = u->Controller(dev_id);
+    if (!cc || !cc->GetTopoTransactions()) return 0;
+    SetGPUDevice(dev_id);
+    unsigned long long v = 0;
+    HIP_CALL(hipDeviceSynchronize());
+    HIP_CALL(hipMemcpy(&v, cc->GetTopoTransactions(), sizeof(v), hipMemcpyDeviceToHost));
+    return (uint64_t)v;
 }
 
 extern "C" int32_t legion_cache_max_id_num(const LegionUnifiedCache* c, int32_t dev_id)

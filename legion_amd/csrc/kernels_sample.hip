@@ -164,6 +164,7 @@ struct SampleArgs {
     const LG_G RowHdr* row_hdr;
     bool last_hop, is_presc;
     LG_G unsigned long long* edge_access_time;
+    LG_G unsigned long long* topo_transactions;
     // the lane's buffers, in the global address space (see LG_G in legion_core.h)
     LG_G int32_t* sampled_ids; LG_G int32_t* agg_src_ids; LG_G int32_t* agg_dst_ids; LG_G int32_t* agg_src_off; LG_G int32_t* agg_dst_off;
     LG_G char* tmp_part_ind; LG_G uint32_t* position_map; LG_G int32_t* node_counter; LG_G int32_t* edge_counter;
@@ -202,6 +203,7 @@ __device__ __forceinline__ SampleArgs lane_args(const HopParams& p, const LanePt
     a.op_id = p.op_id; a.count = p.count; a.partition_count = p.partition_count; a.max_slots = p.max_slots;
     a.csr_dst_node_ids = p.csr_dst_node_ids; a.row_hdr = LG_GPTR(const RowHdr, p.row_hdr); a.last_hop = p.last_hop; a.is_presc = p.is_presc;
     a.edge_access_time = LG_GPTR(unsigned long long, p.edge_access_time);
+    a.topo_transactions = LG_GPTR(unsigned long long, p.topo_transactions);
     a.sampled_ids = LG_GPTR(int32_t, L.sampled_ids); a.agg_src_ids = LG_GPTR(int32_t, L.agg_src_ids);
     a.agg_dst_ids = LG_GPTR(int32_t, L.agg_dst_ids); a.agg_src_off = LG_GPTR(int32_t, L.agg_src_off);
     a.agg_dst_off = LG_GPTR(int32_t, L.agg_dst_off); a.tmp_part_ind = LG_GPTR(char, L.tmp_part_ind);
@@ -275,21 +277,33 @@ __global__ __launch_bounds__(LG_TILE) void sample_kernel(HopParams hp, const Lan
 #pragma unroll
         for (int u = 0; u < LG_SLOTS_PER_LANE; u++) x[u] = minstd_pow((uint32_t)(idx0 + u * LG_TILE + tid) + 1u);
 
+        unsigned long long tx = 0;
         for (int32_t t = tid; t < nsrc; t += LG_TILE) {
             RowHdr h;
+            bool real = true;
             if (seeds) {
                 const int32_t src = g.frontier[j0 + t];
                 if (src >= 0) {
                     h = load_hdr(a.row_hdr + src);
                 } else {
                     h.start = 0; h.deg = 0; h.slot = a.partition_count;
+                    real = false;
                 }
             } else {
                 h = load_hdr(fh + j0 + t);
             }
             s_hdr[t] = h;
+            // PreSC: what this row's topology reads cost in 64-byte transactions (row-pointer pair + the
+            // sectors its picks can touch); a row is counted by the super tile its first slot falls in
+            if (a.topo_transactions && real && (int64_t)(j0 + t) * count >= idx0)
+                tx += 1ull + (unsigned long long)min(count, (h.deg * 4 + 63) / 64);
             if (!a.is_presc)   // FindTopo's hit mask: owner device of the cached row, or -2 (cache.cu:217-225)
                 a.tmp_part_ind[j0 + t] = (char)(h.slot == a.partition_count ? CACHEMISS_FLAG : h.slot);
+        }
+        if (a.topo_transactions) {               // wave sum, one atomic per wave
+            for (int off = 32; off > 0; off >>= 1) tx += __shfl_down(tx, off);
+            if ((tid & 63) == 0 && tx != 0)
+                __hip_atomic_fetch_add(a.topo_transactions, tx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         __syncthreads();
 

@@ -339,6 +339,7 @@ public:
     virtual void AccessCount(int32_t* d_key, int32_t num_keys, void* stream) = 0;
     virtual unsigned long long int* GetNodeAccessedMap() = 0;
     virtual unsigned long long int* GetEdgeAccessedMap() = 0;
+    virtual unsigned long long int* GetTopoTransactions() = 0;   // device counter, see sample_kernel
     virtual int32_t MaxIdNum() = 0;
     // direct-mapped id->value tables (the bcht::find contract), device pointers, may be null
     virtual const int32_t* NodeMap() const = 0;
@@ -519,6 +520,7 @@ struct HopParams {                  // what every lane of a launch shares
     bool is_presc;
     int32_t max_slots;              // capacity of slot_dst for this hop
     unsigned long long* edge_access_time;  // presample only (single lane), else null
+    unsigned long long* topo_transactions; // presample only: 64-byte transactions the hop's topology reads amount to
 };
 void launch_random_sample(hipStream_t s, const HopParams& p, const LanePtrs* d_lanes, int32_t n_lanes);
 

@@ -110,6 +110,7 @@ static void do_random_sample(hipStream_t s, GraphStorage* graph, UnifiedCache* c
     const size_t hop = (size_t)(op_id / INTRABATCH_CON);          // slots of this hop <= B f1..fh
     p.max_slots = (int32_t)(hop < pool0->max_new.size() ? pool0->max_new[hop] : pool0->max_slots);
     p.edge_access_time = (is_presc && cache) ? cache->GetEdgeAccessedMap(dev_id) : nullptr;   // :473
+    p.topo_transactions = (is_presc && cache) ? cache->Controller(dev_id)->GetTopoTransactions() : nullptr;
     lg::launch_random_sample(s, p, d_lanes, n_lanes);
 }
 

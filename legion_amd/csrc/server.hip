@@ -478,11 +478,25 @@ public:
         for (int i = 0; i < shard_count_; i++) pool.emplace_back(&PreSCLoop, train_step_, runners_[i], params_[i]);
         for (auto& th : pool) th.join();
         // PCIe/xGMI transaction counters of the PreSC epoch (Intel PCM in the paper, hard-wired to
-        // {0,0} in v2, server.cu:105-106).  LEGION_LINK_COUNTERS="a,b" injects measured values.
+        // {0,0} in v2, server.cu:105-106).  LEGION_LINK_COUNTERS="a,b" injects values;
+        // LEGION_LINK_COUNTERS=measured uses what the sampler itself counted during this epoch
+        // (legion_cache_topo_transactions: 64-byte transactions of the topology reads, summed over the GPUs).
         std::vector<uint64_t> counters(2, 0);
         if (const char* lc = getenv("LEGION_LINK_COUNTERS")) {
             unsigned long long a = 0, b = 0;
-            if (sscanf(lc, "%llu,%llu", &a, &b) == 2) { counters[0] = a; counters[1] = b; }
+            if (strcmp(lc, "measured") == 0) {
+                for (int i = 0; i < shard_count_; i++) {
+                    unsigned long long v = 0;
+                    SetGPUDevice(i);
+                    HIP_CALL(hipDeviceSynchronize());
+                    HIP_CALL(hipMemcpy(&v, cache_->Controller(i)->GetTopoTransactions(), sizeof(v), hipMemcpyDeviceToHost));
+                    counters[0] += v;
+                }
+                std::cout << "Topology transactions: " << counters[0] << "\n";
+            } else if (sscanf(lc, "%llu,%llu", &a, &b) == 2) {
+                counters[0] = a;
+                counters[1] = b;
+            }
         }
         double t = std::chrono::duration_cast<std::chrono::duration<double>>(std::chrono::steady_clock::now() - t1).count();
         cache_->CandidateSelection(cache_agg_mode, feature_, graph_);

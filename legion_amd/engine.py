@@ -352,6 +352,10 @@ class UnifiedCache:
     def max_id_num(self, dev_id=0):
         return int(self._lib.legion_cache_max_id_num(self.handle, int(dev_id)))
 
+    def topo_transactions(self, dev_id):
+        """64-byte transactions of GPU dev_id's PreSC topology reads (the PCM counter of the paper; see legion_hip.h)."""
+        return int(self._lib.legion_cache_topo_transactions(self.handle, int(dev_id)))
+
     def find_topo(self, dev_id, input_ids):
         """(partition_index int8, partition_offset int32) for a device int32 tensor of vertex ids."""
         n = int(input_ids.numel())

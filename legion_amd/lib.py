@@ -53,6 +53,7 @@ SIGNATURES = {
     "legion_cache_node_capacity": (c_i32, [c_p, c_i32]),
     "legion_cache_edge_capacity": (c_i32, [c_p, c_i32]),
     "legion_cache_max_id_num": (c_i32, [c_p, c_i32]),
+    "legion_cache_topo_transactions": (ctypes.c_uint64, [c_p, c_i32]),
     "legion_cache_array": (c_p, [c_p, c_i32, c_i32]),
     "legion_cache_find_topo": (None, [c_p, c_i32, c_p, c_p, c_i32, c_p, c_p]),
     "legion_cache_find_feat": (None, [c_p, c_i32, c_p, c_p, c_p, c_p, c_i32]),

@@ -118,6 +118,53 @@ def test_cost_model_matches_oracle(hip, cache_memory, counters):
     gpu.close(); cpu.close()
 
 
+def expected_topo_transactions(wl, batch, fanout):
+    """What the sampler counts for one PreSC batch (legion_hip.h): per real frontier row one 64-byte
+    transaction for the row-pointer pair plus min(fan-out, ceil(4*deg/64)) for the picks."""
+    nc, ec = batch["node_counter"], batch["edge_counter"]
+    deg = np.diff(wl.indptr)
+    total = 0
+    for h, count in enumerate(fanout):
+        if h == 0:
+            frontier = batch["sampled_ids"][:int(nc[9])]
+        else:
+            frontier = batch["agg_src_ids"][int(ec[9 + h - 1]):int(ec[9 + h])]
+        frontier = frontier[frontier >= 0]
+        total += int(np.sum(1 + np.minimum(count, (deg[frontier] * 4 + 63) // 64)))
+    return total
+
+
+def test_presc_topology_transactions_feed_cost_model(hip):
+    """The sampler counts, during PreSC, the 64-byte transactions its topology reads amount to (the PCM
+    counter of the paper, zero in v2).  The count matches the same sum taken over the oracle's batches
+    (three hops, partial last batch), and the cost model fed with it picks the capacities the oracle's
+    cost model picks for the same counters -- with a topology share this time."""
+    wl = Workload(scale=12, edge_factor=8, dim=64, n_seeds=1000)
+    fanout, batch = [10, 5, 3], 128
+    cache_memory = 600_000
+    gpu, cpu = GpuSide(wl, batch, fanout, cache_memory=cache_memory), CpuSide(wl, batch, fanout)
+    steps = (wl.sets[(0, 0)][0].size + batch - 1) // batch        # including the partial last batch
+    want = 0
+    for it in range(steps):
+        g, c = gpu.run(0, it, 0, is_presc=True), cpu.run(0, it, 0, is_presc=True)
+        compare_batches(g, c, f"presc batch {it}: ")
+        want += expected_topo_transactions(wl, c, fanout)
+    got = gpu.cache.topo_transactions(0)
+    assert got == want and got > 0
+    gpu.cache.candidate_selection(0, gpu.graph)
+    gpu.cache.cost_model(gpu.feature, gpu.graph, (got, 0), steps)
+    oc = cpu.build_cache(0, cache_memory=cache_memory, train_step=steps, counters=(got, 0))[0]
+    assert (gpu.cache.node_capacity(0), gpu.cache.edge_capacity(0)) == (oc.node_capacity, oc.edge_capacity)
+    gpu.cache.cost_model(gpu.feature, gpu.graph, (0, 0), steps)
+    v2_caps = (gpu.cache.node_capacity(0), gpu.cache.edge_capacity(0))
+    gpu.cache.cost_model(gpu.feature, gpu.graph, (got, 0), steps)
+    assert gpu.cache.edge_capacity(0) >= v2_caps[1]            # measured counters never shrink the topology share
+    gpu.cache.fill_up(gpu.feature, gpu.graph)
+    g, c = gpu.run(0, 0, 0), cpu.run(0, 0, 0)
+    compare_batches(g, c, "serve after measured cost model: ")
+    gpu.close(); cpu.close()
+
+
 @pytest.mark.parametrize("group,slots,use_graph,split", [(1, 1, True, False), (3, 2, True, False), (4, 2, False, False),
                                                          (2, 3, True, False), (8, 2, True, False), (3, 2, True, True),
                                                          (4, 2, False, True), (2, 3, True, True), (1, 1, True, True)])
