@@ -53,7 +53,7 @@ def test_server_binary_serves_fake_trainer(hip, tmp_path):
     server = subprocess.Popen([os.path.join(ROOT, "legion_amd", "bin", "sampling_server"), "1", "0"] +
                               [str(f) for f in fanout], cwd=work, env=env, stdout=log, stderr=subprocess.STDOUT)
     try:
-        deadline = time.time() + 120
+        deadline = time.time() + 400      # a cold box pages the ROCm libraries in first
         while "System is ready for serving" not in open(work / "server.log").read():
             assert server.poll() is None, open(work / "server.log").read()
             assert time.time() < deadline, "server did not become ready"

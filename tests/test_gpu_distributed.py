@@ -107,7 +107,7 @@ def test_clique_across_processes(hip, world):
     procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
-    res = sorted(q.get(timeout=240) for _ in range(world))
+    res = sorted(q.get(timeout=600) for _ in range(world))
     for p in procs:
         p.join(timeout=60)
     for rank, status, remote in res:
