@@ -334,11 +334,11 @@ def cpu_baseline(indptr, col, seeds, N, B, fanout, first_batch, target_s):
     fan = np.asarray(fanout, dtype=np.int32)
     sd = np.ascontiguousarray(seeds, dtype=np.int32)
 
-    def timed(nb):
+    def timed(nb, threads=cores):
         secs = ctypes.c_double(0)
         nodes = ctypes.c_int64(0)
         e = L.lgo_bench_batches(ctypes.byref(g.g), N, ffi._p(sd, ffi.P_I32), int(sd.size), B, ffi._p(fan, ffi.P_I32),
-                                len(fanout), first_batch, nb, cores, None, 0, ctypes.byref(secs), ctypes.byref(nodes))
+                                len(fanout), first_batch, nb, threads, None, 0, ctypes.byref(secs), ctypes.byref(nodes))
         return int(e), secs.value
 
     dgl_note = "DGL unavailable on this box (import dgl failed); the oracle's C sampler stands in (BASELINE.md 2.3)"
@@ -351,7 +351,10 @@ def cpu_baseline(indptr, col, seeds, N, B, fanout, first_batch, target_s):
     nb = int(max(cores, min(cores * 64, cores * target_s / max(s, 1e-3))))
     nb = min(nb, (sd.size - 1) // B - first_batch)
     e, s = timed(nb)
+    e1, s1 = timed(4, 1)                      # the same sampler on one thread (SURVEY 8d asks for both)
+    e1, s1 = timed(int(max(4, min(256, 2.0 * 4 / max(s1, 1e-3)))), 1)
     return {"value": e / s, "unit": "edges/s", "cores": cores, "kind": "port",
+            "single_thread_edges_per_sec": e1 / s1,
             "sample": f"{nb} batches of {B} seeds (same RMAT graph, same fan-out, sampling only, no gather), "
                       f"{s:.1f} s on {cores} threads",
             "dgl": dgl_note}
