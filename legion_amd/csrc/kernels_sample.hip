@@ -517,34 +517,52 @@ __global__ __launch_bounds__(LG_TILE) void scatter_kernel(HopParams hp, const La
             }
         }
         __syncthreads();
+        // phase 1: every load of the thread's four slots (nothing is stored in between, so they are all
+        // in flight together: the buffers may alias as far as the compiler knows)
+        int32_t e_at[LG_SLOTS_PER_LANE], n_at[LG_SLOTS_PER_LANE], src_of[LG_SLOTS_PER_LANE], src_pos[LG_SLOTS_PER_LANE];
+        int32_t lost_pos[LG_SLOTS_PER_LANE];
+        RowHdr nh[LG_SLOTS_PER_LANE];
 #pragma unroll
         for (int u = 0; u < LG_SLOTS_PER_LANE; u++) {
             const int32_t idx = idx0 + u * LG_TILE + tid;
             const int32_t tile = st * LG_SLOTS_PER_LANE + u;
-            const bool valid = v[u] != -1;
-            if (valid && tile < ntiles) {
+            e_at[u] = -1;
+            if (v[u] != -1 && tile < ntiles) {
                 const bool first = v[u] < 0;
                 const int32_t dst = v[u] & 0x7FFFFFFF;
                 int32_t we = 0, wn = 0;
                 for (int w = 0; w < wave; w++) { we += s_cnt[u][0][w]; wn += s_cnt[u][1][w]; }
-                const int32_t e = edge_base + a.tile_prefix[2 * tile] + we + __popcll(mv[u] & lt);
+                e_at[u] = edge_base + a.tile_prefix[2 * tile] + we + __popcll(mv[u] & lt);
+                n_at[u] = first ? node_base + a.tile_prefix[2 * tile + 1] + wn + __popcll(mf[u] & lt) : -1;
                 const int32_t q = idx / a.count;
-                a.agg_src_ids[e] = dst;                            // :256, :276
-                a.agg_dst_ids[e] = frontier[q];                    // :257, :277
+                src_of[u] = frontier[q];
                 // position of the node sampled for == construct_graph's position_map[agg_dst_ids[e]]
-                a.agg_dst_off[e] = seeds ? q : a.agg_src_off[f_off + q];
-                if (!a.last_hop) store_hdr(a.fh_edge + e, load_hdr(a.row_hdr + dst));    // next hop's frontier header
-                if (first) {
-                    const int32_t n = node_base + a.tile_prefix[2 * tile + 1] + wn + __popcll(mf[u] & lt);
-                    a.sampled_ids[n] = dst;                        // :270
-                    // :271 -- later hops look the position up in the state array; after the last hop nobody
-                    // does, and same-hop duplicates resolve through slot_pos (a small, cache-resident array)
-                    if (!a.last_hop) a.position_map[dst] = (int32_t)(a.pf.hi | (uint32_t)n);
-                    a.slot_pos[idx] = n;
-                    a.agg_src_off[e] = n;                          // construct_graph's neighbour side, known here
-                } else {
-                    a.agg_src_off[e] = a.slot_pos[idx];            // final already, or -2 - owner slot
-                }
+                src_pos[u] = seeds ? q : a.agg_src_off[f_off + q];
+                if (!a.last_hop) nh[u] = load_hdr(a.row_hdr + dst);      // next hop's frontier header
+                lost_pos[u] = first ? 0 : a.slot_pos[idx];               // final already, or -2 - (slot it lost to)
+            }
+        }
+        // phase 2: the stores
+#pragma unroll
+        for (int u = 0; u < LG_SLOTS_PER_LANE; u++) {
+            const int32_t idx = idx0 + u * LG_TILE + tid;
+            const int32_t e = e_at[u];
+            if (e < 0) continue;
+            const int32_t dst = v[u] & 0x7FFFFFFF;
+            a.agg_src_ids[e] = dst;                                // :256, :276
+            a.agg_dst_ids[e] = src_of[u];                          // :257, :277
+            a.agg_dst_off[e] = src_pos[u];
+            if (!a.last_hop) store_hdr(a.fh_edge + e, nh[u]);
+            const int32_t n = n_at[u];
+            if (n >= 0) {
+                a.sampled_ids[n] = dst;                            // :270
+                // :271 -- later hops look the position up in the state array; after the last hop nobody
+                // does, and same-hop duplicates resolve through slot_pos (a small, cache-resident array)
+                if (!a.last_hop) a.position_map[dst] = (int32_t)(a.pf.hi | (uint32_t)n);
+                a.slot_pos[idx] = n;
+                a.agg_src_off[e] = n;                              // construct_graph's neighbour side, known here
+            } else {
+                a.agg_src_off[e] = lost_pos[u];
             }
         }
         __syncthreads();
