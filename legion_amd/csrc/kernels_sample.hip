@@ -9,21 +9,26 @@
 //   ClearPosMap      SS/engine/operator_impl.cu:542-548
 // How it computes it is new.  The reference compacts edges/new nodes with shared + global
 // atomicAdd (order is a race) and reads its counters back to the host twice per hop.  Here:
-//   * sample_kernel: one lane per output slot, a 256-slot tile per workgroup; the tile's
-//     frontier rows (src id, CSR row start/degree, column base) are staged once in LDS; the
-//     minstd draw is a table-driven modular power + one IEEE double divide; the neighbour is
-//     published with atomicMin(position_state[dst], PENDING + slot) so that the LOWEST slot
-//     owns a first touch (deterministic, unlike atomicOr on a bitmap);
-//   * flag_count_kernel: wave ballots count valid edges / first touches per tile;
-//   * scan_kernel (one workgroup): exclusive prefix over tiles + the whole counter_update state
-//     machine, so no host round trip and no <<<1,1>>> launches;
+//   * sample_kernel: a workgroup owns 1024 consecutive slots, four per lane; the tile's frontier row
+//     headers (row start, degree, CSR slot) are staged once in LDS; the minstd draw is a table-driven
+//     modular power + one IEEE double divide; the neighbour is published with
+//     atomicMin(position_state[dst], PENDING + slot) so that the LOWEST slot owns a first touch
+//     (deterministic, unlike atomicOr on a bitmap), and the value the atomic returns tells which slot
+//     lost (slot_mark / slot_pos), so nothing re-reads the state array;
+//   * flag_count_kernel: first touch = valid and not marked a loser; wave ballots count valid edges /
+//     first touches per 256-slot tile;
+//   * scan_kernel (one workgroup per lane): exclusive prefix over tiles + the whole counter_update
+//     state machine, so no host round trip and no <<<1,1>>> launches;
 //   * scatter_kernel: ballot + mbcnt prefix inside the tile -> slot-ordered compaction of edges
-//     (global ids + the frontier's local position) and of new nodes;
-//   * localise_kernel: agg_src_off[e] = position of the sampled neighbour.
+//     (global ids + both local positions when known) and of new nodes, + the next hop's row headers;
+//   * localise_kernel: agg_src_off[e] of the edges whose neighbour another slot of the hop owns.
+// Every kernel runs with grid.y = lanes (independent mini-batches, LanePtrs) and takes its pointers
+// from the lane descriptor as global-address-space pointers.
 // Every kernel is a fixed-size grid that strides over tiles and reads the frontier length from
 // device memory, so the whole hop is enqueued without knowing any size on the host.
 //
-// Roofline: HBM-bound irregular gather (4-byte column reads, 4-byte atomics); no MFMA.
+// Bound: the rate of scattered 4-byte atomics and loads (~19 G atomics/s on data-dependent addresses),
+// not HBM bytes; no MFMA.
 #include "legion_core.h"
 
 namespace lg {
