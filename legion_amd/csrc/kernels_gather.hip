@@ -38,11 +38,16 @@ __global__ __launch_bounds__(LG_GATHER_THREADS) void gather_kernel(GatherParams 
     const LG_G int32_t* range = LG_GPTR(const int32_t, gp.hop >= 0 ? L.hop_scratch + HS_RANGE + 2 * gp.hop : L.node_counter);
     const LG_G int32_t* sampled_ids = LG_GPTR(const int32_t, L.sampled_ids);
     LG_G int32_t* cache_search_buffer = LG_GPTR(int32_t, L.cache_search_buffer);
-    const int32_t off = range[0];
+    int32_t off = range[0];
     int32_t rows = range[1];
     if (copy_range && blockIdx.x == 0 && threadIdx.x == 0) {   // counter_update(op%3==1), operator_impl.cu:83-85
         LG_GPTR(int32_t, L.node_counter)[2] = off;
         LG_GPTR(int32_t, L.node_counter)[3] = rows;
+    }
+    if (gp.hop >= 0 && gp.first_hop < gp.hop) {                // earlier hops' ranges ride along (adjacent rows)
+        const int32_t off0 = LG_GPTR(const int32_t, L.hop_scratch)[HS_RANGE + 2 * gp.first_hop];
+        rows += off - off0;
+        off = off0;
     }
     if (rows > gp.max_rows) rows = gp.max_rows;
     if (rows > L.feature_rows - off) rows = L.feature_rows - off;   // never write past the feature buffer (the
@@ -146,6 +151,7 @@ void launch_gather_explicit(hipStream_t s, const GatherParams& g, const int32_t*
     h.feature_rows = dst_rows;
     GatherParams ge = g;
     ge.hop = -1;
+    ge.first_hop = -1;
     HIP_CALL(hipMemcpyAsync(d_lane, &h, sizeof(h), hipMemcpyHostToDevice, s));   // pageable source: staged before return
     launch_gather_impl(s, ge, d_lane, 1, false);
 }

@@ -373,8 +373,9 @@ public:
     int32_t MaxIdNum(int32_t dev_id);
     unsigned long long int* GetEdgeAccessedMap(int32_t dev_id);
     // the gather over a group of lanes (the reference's per-array arguments live in LanePtrs)
+    // first_op_id < op_id: one launch also covers the new-node ranges of the earlier ops first_op_id, +3, ...
     void FeatCacheLookup(const LanePtrs* d_lanes, int32_t n_lanes, int32_t op_id, int32_t dev_id,
-                         hipStream_t strm_hdl, int32_t max_rows, bool use_snapshot);
+                         hipStream_t strm_hdl, int32_t max_rows, bool use_snapshot, int32_t first_op_id = -1);
 
     // new / exposed for the C API and the fused kernels
     void SetCapacity(int32_t node_capacity, int32_t edge_capacity);
@@ -534,6 +535,8 @@ struct GatherParams {
     int32_t max_rows;               // grid bound: rows any lane can have for this op
     int32_t hop;                    // >= 0: take the range from hop_scratch[HS_RANGE + 2*hop] (snapshot that later
                                     // hops do not overwrite, so the gather may run beside the next hop); < 0: node_counter[0..1]
+    int32_t first_hop;              // with hop >= 0: also gather the ranges of hops first_hop .. hop-1 (they are adjacent in
+                                    // sampled_ids); == hop for a plain single-op gather
 };
 void launch_gather(hipStream_t s, const GatherParams& g, const LanePtrs* d_lanes, int32_t n_lanes);
 // stand-alone form for tests / probes: explicit arrays, one lane

@@ -115,7 +115,7 @@ static void do_random_sample(hipStream_t s, GraphStorage* graph, UnifiedCache* c
 }
 
 static void do_feature_lookup(hipStream_t s, UnifiedCache* cache, const LanePtrs* d_lanes, int32_t n_lanes,
-                              MemoryPool* pool0, int32_t op_id, int32_t dev_id, bool use_snapshot)
+                              MemoryPool* pool0, int32_t op_id, int32_t dev_id, bool use_snapshot, int32_t first_op_id = -1)
 {
     if (pool0->GetFloatFeatures() == nullptr) {
         std::cout << "feature buffer not initialized\n";
@@ -128,11 +128,15 @@ static void do_feature_lookup(hipStream_t s, UnifiedCache* cache, const LanePtrs
     int64_t max_rows = pool0->feature_rows;
     if (max_rows > pool0->num_ids) max_rows = pool0->num_ids;
     const size_t hop = (size_t)(op_id / INTRABATCH_CON);          // grid bound: new nodes of op 3h <= B f1..fh
-    if (hop < pool0->max_new.size() && pool0->max_new[hop] < max_rows) max_rows = pool0->max_new[hop];
+    int64_t bound = 0;                                            // + the earlier ops that ride along
+    for (size_t h = (use_snapshot && first_op_id >= 0 && first_op_id < op_id) ? (size_t)(first_op_id / INTRABATCH_CON) : hop;
+         h <= hop && h < pool0->max_new.size(); h++)
+        bound += pool0->max_new[h];
+    if (hop < pool0->max_new.size() && bound < max_rows) max_rows = bound;
     MemoryPool* pp = pool0;
     const bool prof = pp->prof_on && (size_t)(2 * pp->prof_used + 1) < pp->prof_events.size();
     if (prof) HIP_CALL(hipEventRecord(pp->prof_events[2 * pp->prof_used], s));
-    cache->FeatCacheLookup(d_lanes, n_lanes, op_id, dev_id, s, (int32_t)max_rows, use_snapshot);
+    cache->FeatCacheLookup(d_lanes, n_lanes, op_id, dev_id, s, (int32_t)max_rows, use_snapshot, first_op_id);
     if (prof) {
         HIP_CALL(hipEventRecord(pp->prof_events[2 * pp->prof_used + 1], s));
         pp->prof_op[pp->prof_used] = op_id;
@@ -331,11 +335,15 @@ static void enqueue_lanes(hipStream_t s, GraphStorage* graph, FeatureStorage* fe
     // phase of their own after the whole sampler (LG_PHASE_GATHER, on another stream: pipeline.hip)
     const bool sampler = phase != LG_PHASE_GATHER, gathers = phase != LG_PHASE_SAMPLE && !is_presc;
     if (sampler) do_batch_generate(s, feature, d_lanes, n_lanes, pool0, batch_size, counter, dev_id, mode, hop_num, iter_state);
-    if (gathers) do_feature_lookup(s, cache, d_lanes, n_lanes, pool0, 1, dev_id, true);
+    // The seeds' rows (op 1) are few and directly in front of hop 1's: when a later gather follows (so that
+    // what FindFeat leaves in cache_search_buffer is the last op's either way), one launch fetches both.
+    const bool seeds_ride_along = hop_num >= 2;
+    if (gathers && !seeds_ride_along) do_feature_lookup(s, cache, d_lanes, n_lanes, pool0, 1, dev_id, true);
     for (int32_t h = 0; h < hop_num; h++) {
         const int32_t op = INTRABATCH_CON * (h + 1);
         if (sampler) do_random_sample(s, graph, cache, d_lanes, n_lanes, pool0, fanout[h], dev_id, op, is_presc);
-        if (gathers) do_feature_lookup(s, cache, d_lanes, n_lanes, pool0, op + 1, dev_id, true);
+        if (gathers) do_feature_lookup(s, cache, d_lanes, n_lanes, pool0, op + 1, dev_id, true,
+                                       (h == 0 && seeds_ride_along) ? 1 : -1);
     }
     if (!sampler) return;
     if (is_presc && mode == TRAINMODE && cache != nullptr)     // CacheProfiling (one lane only in PreSC)
