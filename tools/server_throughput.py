@@ -1,0 +1,92 @@
+"""Throughput of the drop-in boundary itself: the `sampling_server` binary serving a trainer that only
+consumes (get_next -> synchronize), on a synthetic dataset written in the reference's file formats.
+Usage (GPU box):  python tools/server_throughput.py [--scale 22] [--batch 8000] [--dim 128]
+Prints one JSON line: batches/s and sampled edges/s through the IPC hand-off (train mode, one GPU)."""
+import argparse, json, os, subprocess, sys, tempfile, time
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "legion_amd", "trainer"))
+from legion_amd import synth  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--scale", type=int, default=22)
+    ap.add_argument("--batch", type=int, default=8000)
+    ap.add_argument("--dim", type=int, default=128)
+    ap.add_argument("--fanout", type=str, default="25,10")
+    ap.add_argument("--train-batches", type=int, default=60)
+    ap.add_argument("--cache-memory", type=int, default=1 << 30)
+    a = ap.parse_args()
+    fanout = [int(x) for x in a.fanout.split(",")]
+    dev = torch.device("cuda:0")
+    N = 1 << a.scale
+    indptr, col = synth.rmat_csr_device(a.scale, 16, 20231, dev)
+    feats = synth.features_device(N, a.dim, 7, dev)
+    train = synth.seed_ids(N, a.batch * a.train_batches + 1, 11).astype(np.int32)
+    valid, test = train[:a.batch], train[:a.batch]
+    tmp = tempfile.mkdtemp(prefix="legion_srv_", dir="/tmp")
+    ds = os.path.join(tmp, "ds") + "/"
+    os.makedirs(ds)
+    indptr.cpu().numpy().astype(np.int64).tofile(ds + "edge_src")
+    col.cpu().numpy().astype(np.int32).tofile(ds + "edge_dst")
+    feats.cpu().numpy().tofile(ds + "features")
+    (np.arange(N) % 47).astype(np.int32).tofile(ds + "labels")
+    train.tofile(ds + "trainingset"); valid.tofile(ds + "validationset"); test.tofile(ds + "testingset")
+    E = int(col.numel())
+    del indptr, col, feats
+    torch.cuda.empty_cache()
+    work = os.path.join(tmp, "run")
+    os.makedirs(work)
+    open(os.path.join(work, "meta_config"), "w").write("{} {} {} {} {} {} {} {} {} {}".format(
+        ds, a.batch, N, E, a.dim, train.size, valid.size, test.size, a.cache_memory, 1))
+    ns = f"_b{os.getpid()}"
+    os.environ["LEGION_IPC_NAMESPACE"] = ns
+    log = open(os.path.join(work, "server.log"), "w")
+    server = subprocess.Popen([os.path.join(ROOT, "legion_amd", "bin", "sampling_server"), "1", "0"] + [str(f) for f in fanout],
+                              cwd=work, env=dict(os.environ), stdout=log, stderr=subprocess.STDOUT)
+    try:
+        deadline = time.time() + 600
+        while "System is ready for serving" not in open(os.path.join(work, "server.log")).read():
+            assert server.poll() is None, open(os.path.join(work, "server.log")).read()
+            assert time.time() < deadline
+            time.sleep(0.2)
+        import ipc_service
+        torch.cuda.set_device(0)
+        ipc_service.initialize()
+        tr, va, te = ipc_service.get_steps()
+        H = len(fanout)
+        edges, t0, n_timed = 0, None, 0
+        for i in range(tr + va + te):
+            out = ipc_service.get_next(a.dim)
+            if i < tr:
+                if i == 5:
+                    torch.cuda.synchronize(); t0 = time.perf_counter(); edges = 0; n_timed = 0
+                edges += int(out[3].numel())          # outermost block = every edge of the batch
+                n_timed += 1
+            del out
+            ipc_service.synchronize()
+            if i == tr - 1:
+                torch.cuda.synchronize(); t1 = time.perf_counter()
+        ipc_service.finalize()
+        server.wait(timeout=120)
+        dt = t1 - t0
+        print(json.dumps({"path": "sampling_server binary -> shm/semaphores/IPC handles -> ipc_service consumer",
+                          "workload": f"RMAT-{a.scale} EF16, D={a.dim}, batch {a.batch}, fanout {fanout}, train mode, 1 GPU",
+                          "batches_per_sec": n_timed / dt, "edges_per_sec": edges / dt, "timed_batches": n_timed,
+                          "ms_per_batch": dt / n_timed * 1e3}))
+    finally:
+        if server.poll() is None:
+            server.kill()
+        log.close()
+        for name in os.listdir("/dev/shm"):
+            if name.endswith(ns):
+                os.unlink(os.path.join("/dev/shm", name))
+        subprocess.call(["rm", "-rf", tmp])
+
+
+if __name__ == "__main__":
+    main()
