@@ -22,6 +22,7 @@
 #include <algorithm>
 #include <chrono>
 #include <cstring>
+#include <map>
 #include <fstream>
 #include <iostream>
 #include <sstream>
@@ -263,6 +264,11 @@ private:
 };
 
 // =============================================================================================
+extern "C" void legion_enqueue_batch(legion_stream_t strm_hdl, LegionGraphStorage* graph, LegionFeatureStorage* feature,
+                                     LegionUnifiedCache* cache, LegionMemoryPool* memorypool, int32_t batch_size,
+                                     int32_t counter, int32_t dev_id, int32_t mode, bool is_presc,
+                                     const int32_t* fanout, int32_t hop_num);
+
 class GPURunner : public Runner {
 public:
     // SS/engine/server.cu:172-273
@@ -382,15 +388,55 @@ public:
         memorypool_->SetCurrentMode(mode_);
         memorypool_->SetIter(env->GetLocalBatchId(batch_id));
         env->IPCWait(local_dev_id_, current_pipe_);
-        for (int i = 0; i < op_num_; i++) {
-            op_params_[i]->is_presc = false;
-            op_factory_[i]->run(op_params_[i]);
+        if (use_graph_) {
+            RunOnceGraph(params, env->GetLocalBatchId(batch_id), (int32_t)env->GetCurrentBatchsize(local_dev_id_, mode_));
+        } else {
+            for (int i = 0; i < op_num_; i++) {
+                op_params_[i]->is_presc = false;
+                op_factory_[i]->run(op_params_[i]);
+            }
+            HIP_CALL(hipEventSynchronize(op_params_[op_num_ - 1]->event));   // every op is on this stream
         }
-        HIP_CALL(hipEventSynchronize(op_params_[op_num_ - 1]->event));   // every op is on this stream
         env->IPCPost(local_dev_id_, current_pipe_);
         if (batch_id % 1000 == 0 && local_dev_id_ == 0) std::cout << "batch id: " << batch_id << "\n";
         current_pipe_ = (current_pipe_ + 1) % interbatch_concurrency_;
         memorypool_->SetCurrentPipe(current_pipe_);
+    }
+
+    // The op list of one batch (the same kernels the operators launch, in the same order) captured once
+    // per (pipe slot, mode) into a hipGraph; the iteration is a device word written before every replay.
+    // One replay costs one launch instead of ~16 launches + 16 event records (LEGION_RUNNER_GRAPH=0: eager).
+    void RunOnceGraph(RunnerParams* params, int32_t local_batch_id, int32_t batch_size)
+    {
+        hipStream_t s = streams_[0];
+        if (d_iter_ == nullptr) {
+            d_iter_ = (int32_t*)d_alloc_space(2 * sizeof(int32_t));
+            HIP_CALL(hipHostMalloc((void**)&h_iter_, 2 * sizeof(int32_t), hipHostMallocDefault));
+        }
+        h_iter_[0] = local_batch_id;
+        h_iter_[1] = 0;                                     // the host positions the iteration every time
+        HIP_CALL(hipMemcpyAsync(d_iter_, h_iter_, 2 * sizeof(int32_t), hipMemcpyHostToDevice, s));
+        memorypool_->iter_state = d_iter_;
+        const int key = current_pipe_ * 4 + mode_;
+        auto it = graphs_.find(key);
+        if (it == graphs_.end()) {
+            std::vector<int32_t> fanout(params->fanout.begin(), params->fanout.end());
+            hipGraph_t graph = nullptr;
+            hipGraphExec_t exec = nullptr;
+            (void)memorypool_->DeviceLane();                // uploads the lane descriptors if they changed: not inside a capture
+            HIP_CALL(hipStreamSynchronize(s));
+            HIP_CALL(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+            legion_enqueue_batch(s, (LegionGraphStorage*)params->graph, (LegionFeatureStorage*)params->feature,
+                                 (LegionUnifiedCache*)params->cache, (LegionMemoryPool*)memorypool_, batch_size,
+                                 local_batch_id, local_dev_id_, mode_, false, fanout.data(), (int32_t)fanout.size());
+            HIP_CALL(hipStreamEndCapture(s, &graph));
+            HIP_CALL(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+            HIP_CALL(hipGraphDestroy(graph));
+            it = graphs_.emplace(key, exec).first;
+        }
+        HIP_CALL(hipGraphLaunch(it->second, s));
+        HIP_CALL(hipStreamSynchronize(s));
+        memorypool_->iter_state = nullptr;
     }
 
     void Finalize(RunnerParams* params) override
@@ -414,6 +460,10 @@ private:
     std::vector<hipEvent_t> events_;
     std::vector<Operator*> op_factory_;
     std::vector<OpParams*> op_params_;
+    bool use_graph_ = [] { const char* e = getenv("LEGION_RUNNER_GRAPH"); return e == nullptr || atoi(e) != 0; }();
+    std::map<int, hipGraphExec_t> graphs_;    // key: pipe slot * 4 + mode
+    int32_t* d_iter_ = nullptr;
+    int32_t* h_iter_ = nullptr;
 };
 
 Runner* NewGPURunner() { return new GPURunner(); }
