@@ -387,9 +387,18 @@ public:
         mode_ = env->GetCurrentMode(batch_id);
         memorypool_->SetCurrentMode(mode_);
         memorypool_->SetIter(env->GetLocalBatchId(batch_id));
+        if (use_graph_ && pending_pipe_ >= 0 && hipEventQuery(batch_done_[pending_pipe_]) == hipSuccess)
+            FlushPending(env);                              // already finished: do not make the trainer wait for our wait
         env->IPCWait(local_dev_id_, current_pipe_);
         if (use_graph_) {
+            // the batch is only enqueued here; the previous one (other pipe slot) is handed over meanwhile
             RunOnceGraph(params, env->GetLocalBatchId(batch_id), (int32_t)env->GetCurrentBatchsize(local_dev_id_, mode_));
+            FlushPending(env);
+            pending_pipe_ = current_pipe_;
+            if (batch_id % 1000 == 0 && local_dev_id_ == 0) std::cout << "batch id: " << batch_id << "\n";
+            current_pipe_ = (current_pipe_ + 1) % interbatch_concurrency_;
+            memorypool_->SetCurrentPipe(current_pipe_);
+            return;
         } else {
             for (int i = 0; i < op_num_; i++) {
                 op_params_[i]->is_presc = false;
@@ -411,11 +420,13 @@ public:
         hipStream_t s = streams_[0];
         if (d_iter_ == nullptr) {
             d_iter_ = (int32_t*)d_alloc_space(2 * sizeof(int32_t));
-            HIP_CALL(hipHostMalloc((void**)&h_iter_, 2 * sizeof(int32_t), hipHostMallocDefault));
+            HIP_CALL(hipHostMalloc((void**)&h_iter_, 2 * INTERBATCH_CON * sizeof(int32_t), hipHostMallocDefault));
+            for (int i = 0; i < INTERBATCH_CON; i++) HIP_CALL(hipEventCreateWithFlags(&batch_done_[i], hipEventDisableTiming));
         }
-        h_iter_[0] = local_batch_id;
-        h_iter_[1] = 0;                                     // the host positions the iteration every time
-        HIP_CALL(hipMemcpyAsync(d_iter_, h_iter_, 2 * sizeof(int32_t), hipMemcpyHostToDevice, s));
+        int32_t* h = h_iter_ + 2 * current_pipe_;           // one staging pair per pipe slot: the copy is asynchronous
+        h[0] = local_batch_id;
+        h[1] = 0;                                           // the host positions the iteration every time
+        HIP_CALL(hipMemcpyAsync(d_iter_, h, 2 * sizeof(int32_t), hipMemcpyHostToDevice, s));
         memorypool_->iter_state = d_iter_;
         const int key = current_pipe_ * 4 + mode_;
         auto it = graphs_.find(key);
@@ -435,13 +446,26 @@ public:
             it = graphs_.emplace(key, exec).first;
         }
         HIP_CALL(hipGraphLaunch(it->second, s));
-        HIP_CALL(hipStreamSynchronize(s));
+        HIP_CALL(hipEventRecord(batch_done_[current_pipe_], s));
         memorypool_->iter_state = nullptr;
+    }
+
+    // hands the batch enqueued by the previous RunOnce to the trainer once the GPU has finished it; by then
+    // the next batch is already queued behind it on the same stream (they share the scratch arrays, the
+    // trainer-visible buffers are per pipe slot)
+    void FlushPending(IPCEnv* env)
+    {
+        if (pending_pipe_ < 0) return;
+        HIP_CALL(hipEventSynchronize(batch_done_[pending_pipe_]));
+        env->IPCPost(local_dev_id_, pending_pipe_);
+        pending_pipe_ = -1;
     }
 
     void Finalize(RunnerParams* params) override
     {
         IPCEnv* env = (IPCEnv*)(params->env);
+        SetGPUDevice(local_dev_id_);
+        FlushPending(env);
         env->IPCWait(local_dev_id_, (current_pipe_ + 1) % interbatch_concurrency_);
         SetGPUDevice(local_dev_id_);
         memorypool_->Finalize();
@@ -464,6 +488,8 @@ private:
     std::map<int, hipGraphExec_t> graphs_;    // key: pipe slot * 4 + mode
     int32_t* d_iter_ = nullptr;
     int32_t* h_iter_ = nullptr;
+    hipEvent_t batch_done_[INTERBATCH_CON] = {};
+    int pending_pipe_ = -1;                   // pipe slot whose batch is enqueued but not yet handed over
 };
 
 Runner* NewGPURunner() { return new GPURunner(); }
