@@ -96,6 +96,11 @@ def main():
         else:
             dist.init_process_group(args.backend, rank=rank, world_size=world)
 
+    if int(os.environ.get("LOCAL_RANK", "0")) == 0:
+        import __graft_entry__
+        __graft_entry__.ensure_built()          # fresh checkout: build the in-tree artefacts once (rank 0)
+    if use_dist:
+        dist.barrier()
     from legion_amd import engine, synth
     stripe = args.stripe and world > 1
     P = world if stripe else 1              # logical GPUs the objects know about

@@ -9,19 +9,8 @@ if ROOT not in sys.path:
 
 
 def _ensure_built():
-    """The native artefacts are built in-tree and kept out of git.  A checkout without them (and with
-    hipcc at hand) is built once before the tests run -- the same call the driver's build step makes.
-    This is not a fallback of the product: legion_amd itself refuses to work without its library."""
-    import glob
-    import shutil
-    need = [os.path.join(ROOT, "legion_amd", "liblegion_hip.so"),
-            os.path.join(ROOT, "legion_amd", "bin", "sampling_server")]
-    missing = [p for p in need if not os.path.exists(p)]
-    if not glob.glob(os.path.join(ROOT, "legion_amd", "trainer", "ipc_service*.so")):
-        missing.append("ipc_service extension")
-    if missing and (shutil.which("hipcc") or os.path.exists("/opt/rocm/bin/hipcc")):
-        import __graft_entry__
-        __graft_entry__.build()
+    import __graft_entry__
+    __graft_entry__.ensure_built()     # a checkout without the in-tree native artefacts is built once
 
 
 def pytest_configure(config):
