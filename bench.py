@@ -218,13 +218,27 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    pipe.run_range(first, args.steps)
+    last_group = pipe.run_range(first, args.steps)
     pipe.wait()
     torch.cuda.synchronize()
     if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    if not args.no_verify and last_group is not None:
+        # the last group of the timed region is still in its slot: its batches must be the ones the counting
+        # pass saw (replays are deterministic), and its last lane passes the full-size property checks
+        slot, k0, n_lanes = last_group
+        for lane in range(n_lanes):
+            pl = pipe.pools[slot][lane]
+            nc = pl.buffer("node_counter").cpu().numpy()
+            ec = pl.buffer("edge_counter").cpu().numpy()
+            k = k0 - first + lane
+            assert ec[9 + H] == edges[k] and nc[9 + H] - nc[9] == rows[k, 1:].sum(), f"replayed batch {k0 + lane} differs"
+        n = int(nc[9 + H])
+        ids = pl.buffer("sampled_ids")[:n]
+        assert synth.feature_check_device(pl.buffer("float_features")[:n].contiguous(), ids.contiguous(), D, 7) == 0
+        assert int(torch.unique(ids).numel()) == n
 
     # ---- the same K batches once more with HIP events around every gather launch (recorded on the
     #      lane's own stream).  Eager launches: HIP cannot time events recorded by graph nodes. ------

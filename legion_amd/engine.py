@@ -266,12 +266,14 @@ class Pipeline:
         return int(self._lib.legion_pipeline_submit_n(self.handle, int(counter0), int(mode), int(n_active)))
 
     def run_range(self, first, count, mode=TRAINMODE):
-        """Submits batches first .. first+count-1 as full groups plus, if needed, one partial group."""
-        k = 0
+        """Submits batches first .. first+count-1 as full groups plus, if needed, one partial group.
+        Returns (slot, first batch, lanes) of the last group submitted."""
+        k, last = 0, None
         while k < count:
             n = min(self.group_size, count - k)
-            self.submit(first + k, mode, n)
+            last = (self.submit(first + k, mode, n), first + k, n)
             k += n
+        return last
 
     def wait(self, slot=-1):
         self._lib.legion_pipeline_wait(self.handle, int(slot))
