@@ -51,7 +51,8 @@ def parse_args():
     ap.add_argument("--cache-memory", type=int, default=8 << 30, help="bytes per GPU fed to the cost model")
     ap.add_argument("--presc-steps", type=int, default=512, help="PreSC batches per GPU (bounded epoch)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU-baseline time; 0 disables")
-    ap.add_argument("--group", type=int, default=128, help="mini-batches served by every launch (lanes of a group)")
+    ap.add_argument("--group", type=int, default=0,
+                    help="mini-batches served by every launch (lanes of a group); 0 = 131072 // batch, at most 128")
     ap.add_argument("--slots", type=int, default=2, help="groups in flight per GPU")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
     ap.add_argument("--overlap", action="store_true", help="let kernels of different slots share the GPU")
@@ -171,7 +172,7 @@ def main():
         cache.fill_up(feature, graph)
     feature_rows = int(max_ids * 1.2)                                        # server.cu:277
     pool.close()
-    G = args.group
+    G = args.group if args.group > 0 else max(1, min(128, 131072 // B))
     pipe = engine.Pipeline(graph, feature, cache, d, B, fanout, G, feature_rows, not args.no_graph, args.slots,
                            args.overlap, args.split)
     torch.cuda.synchronize()
@@ -317,7 +318,7 @@ def main():
             "sampling_only": {"edges_per_sec": float(edges.sum()) / t_sampling, "algorithmic_GBps": samp_bytes / t_sampling / 1e9,
                               "frac_of_hbm_peak": samp_bytes / t_sampling / 1e9 / HBM_PEAK_GBPS,
                               "note": "rank 0; time = timed region minus the HIP-event time of all gather launches; the "
-                                      "sampler is bound by scattered 4-byte atomics (~25 G/s) and loads (~48 G/s), "
+                                      "sampler is bound by scattered 4-byte atomics (~17-19 G/s beyond the Infinity Cache) and loads (~47 G/s), "
                                       "see tools/micro/random_access.hip"},
             "edges_per_step": float(edges.mean()), "rows_per_step": float(rows.sum(axis=1).mean()),
             "seed_feature_cache_hits_step0": hits,
