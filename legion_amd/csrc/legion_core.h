@@ -53,16 +53,18 @@
 
 // ---- position/first-touch state array (replaces accessed_map + position_map) ---------------
 // One uint32 per vertex, compared UNSIGNED: [ EMAX - epoch : 31-vb | pending : 1 | value : vb ],
-// EMAX = 2^(31-vb) - 1.  vb (hop_scratch[HS_VALUE_BITS]) is fixed per pool: 23 unless the pool's
-// worst-case slot / id count needs more (B=8000, fan-out 25,10,10 -> 25), at most 28.
-// A lane's epoch e (1..EMAX-1; 1..254 for vb = 23; in hop_scratch[HS_EPOCH]) goes up by one per
+// EMAX = 2^(31-vb) - 1.  vb (hop_scratch[HS_VALUE_BITS]) is fixed per pool: just enough for the pool's
+// worst-case id count (B = 1024, fan-out 25,10 -> 19; B = 8000 -> 22; B = 8000, 25,10,10 -> 25), 16..28, so
+// that the epoch field is as wide as possible: the refill below writes N x 4 B, and at vb = 19 it runs
+// every 4094 batches instead of every 254 (1 MB per batch at N = 2^26 with 8 epoch bits).
+// A lane's epoch e (1..EMAX-1; in hop_scratch[HS_EPOCH]) goes up by one per
 // mini-batch, so whatever an older batch left behind carries a larger top field and reads as
 // "untouched" -- nothing has to be cleared between batches (the reference memsets an N/8-byte bitmap
 // per batch and zeroes the position map entry by entry, operator_impl.cu:151,542-548); every EMAX-1
 // batches the end-of-batch kernel refills the array with 0xFF.  Within the current epoch the low
 // vb+1 bits hold either the final position of the vertex in sampled_ids, or pending | (lowest slot
 // index that sampled it in the hop being compacted); atomicMin keeps the lowest.
-#define LG_POS_VALUE_BITS_MIN 23
+#define LG_POS_VALUE_BITS_MIN 16
 #define LG_POS_VALUE_BITS_MAX 28
 struct PosFmt {
     uint32_t hi;        // (EMAX - epoch) << (vb + 1)

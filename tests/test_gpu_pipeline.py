@@ -231,11 +231,12 @@ def test_lane_group_eager(hip):
     gpu.close(); cpu.close()
 
 
-def test_epoch_wrap_of_position_state(hip):
-    """The position state is never cleared between batches (epoch tag); after 254 batches on one lane
-    the end-of-batch kernel refills it.  600 consecutive batches (two wraps) stay bit-exact, eager
-    and under graph replay."""
+def test_epoch_wrap_of_position_state(hip, monkeypatch):
+    """The position state is never cleared between batches (epoch tag); with 8 epoch bits (23 value bits,
+    forced here: a pool this small would get 15 epoch bits) the end-of-batch kernel refills it after 254
+    batches on one lane.  600 consecutive batches (two wraps) stay bit-exact, eager and under graph replay."""
     from legion_amd import engine
+    monkeypatch.setenv("LEGION_POS_VALUE_BITS", "23")
     wl = Workload(scale=9, edge_factor=8, dim=4, n_seeds=512)
     fanout, batch = [3, 2], 8
     gpu, cpu = GpuSide(wl, batch, fanout), CpuSide(wl, batch, fanout)
