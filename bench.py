@@ -4,12 +4,16 @@
     python bench.py --gpus N --steps K --warmup W
     (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
 
-A "step" is one mini-batch through the whole hot path on one GPU: seed batch -> 2-hop sampling
-[25,10] -> per-hop feature-cache lookup + gather -> end-of-batch clean-up (the op order of the
-reference's GPURunner::RunOnce, SS/engine/server.cu:302-332), inputs resident in HBM.
+A "step" is ONE LAUNCH GROUP through the whole hot path on one GPU: `batches_per_step` (= --group,
+default 128 at B = 1024) independent mini-batches, each seed batch -> 2-hop sampling [25,10] -> per-hop
+feature-cache lookup + gather -> end-of-batch clean-up (the op order of the reference's
+GPURunner::RunOnce, SS/engine/server.cu:302-332), served by one hipGraph replay, inputs resident in HBM.
+The timed region is exactly K steps between barrier + synchronize brackets; because K steps of ~1 ms are
+far too short to time (launch latency, clock ramp), the same region is repeated until >= --min-seconds of
+GPU work have been timed and the MEDIAN region (max over ranks per repeat) gives `value`.
 Workload: synthetic RMAT-26 (N = 2^26, E = 2^30), float32[N x 128] counter-hash
 features, B = 1024, seeds = a seeded permutation, GPU p of P takes seeds with id % P == p.
-Mini-batches are served in groups: every kernel launch covers --group (default 64) independent
+Mini-batches are served in groups: every kernel launch covers --group (default 131072 / B, at most 128) independent
 batches (grid.y = lanes) and a group's op list is one hipGraph replay (legion_amd/csrc/pipeline.hip).
 
 One process per GPU.  The path shards by seeds with no per-batch exchange; the only collective is
@@ -41,8 +45,13 @@ HBM_PEAK_GBPS = 8000.0   # MI355X_MICROARCH.md: 8 TB/s spec
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=512)
-    ap.add_argument("--warmup", type=int, default=128)
+    ap.add_argument("--steps", type=int, default=32, help="timed steps; a step = one launch group of --group mini-batches")
+    ap.add_argument("--warmup", type=int, default=8, help="untimed warm-up steps (launch groups)")
+    ap.add_argument("--min-seconds", type=float, default=1.5,
+                    help="repeat the K-step timed region until this much time has been measured (median reported)")
+    ap.add_argument("--max-repeats", type=int, default=400)
+    ap.add_argument("--scramble", action="store_true",
+                    help="Graph500-style label scrambling of the RMAT vertices (hubs no longer sit at the low ids)")
     ap.add_argument("--scale", type=int, default=26)
     ap.add_argument("--edge-factor", type=int, default=16)
     ap.add_argument("--dim", type=int, default=128)
@@ -115,16 +124,19 @@ def main():
     N = 1 << args.scale
     D = args.dim
     B = args.batch
+    G = args.group if args.group > 0 else max(1, min(128, 131072 // B))   # mini-batches per step (launch group)
+    n_warm, n_timed = args.warmup * G, args.steps * G                      # in mini-batches
     t_setup = time.time()
 
     # ---- workload, resident in HBM --------------------------------------------------------------
-    indptr, col = synth.rmat_csr_device(args.scale, args.edge_factor, 20231, dev)
+    indptr, col = synth.rmat_csr_device(args.scale, args.edge_factor, 20231, dev, scramble=args.scramble)
     features = synth.features_device(N, D, 7, dev)
-    need = (args.warmup + args.steps + 2) * B * world + B
+    need = (n_warm + n_timed + 2) * B * world + B
     need = max(need, (args.presc_steps + 2) * B * world)
     all_seeds = synth.seed_ids(N, min(max(need * 2, N // 10), N), 11)
     mine = np.ascontiguousarray(all_seeds[all_seeds % world == rank])      # storage_management.cu:178
-    assert mine.size > (args.warmup + args.steps + 1) * B, "not enough seeds for this rank"
+    assert mine.size > (n_warm + n_timed + 1) * B, \
+        f"not enough seeds for this rank: {mine.size} < {(n_warm + n_timed + 1) * B} (lower --steps/--warmup/--group)"
 
     graph = engine.GraphStorage(P, indptr, col)
     feature = engine.FeatureStorage(P, features)
@@ -172,22 +184,21 @@ def main():
         cache.fill_up(feature, graph)
     feature_rows = int(max_ids * 1.2)                                        # server.cu:277
     pool.close()
-    G = args.group if args.group > 0 else max(1, min(128, 131072 // B))
     pipe = engine.Pipeline(graph, feature, cache, d, B, fanout, G, feature_rows, not args.no_graph, args.slots,
                            args.overlap, args.split)
     torch.cuda.synchronize()
     setup_s = time.time() - t_setup
 
     # ---- untimed counting pass over exactly the timed batches (deterministic) --------------------
-    first = args.warmup
-    edges = np.zeros(args.steps, dtype=np.int64)
-    rows = np.zeros((args.steps, H + 1), dtype=np.int64)
-    hop_edges = np.zeros((args.steps, H), dtype=np.int64)
-    hop_slots = np.zeros((args.steps, H), dtype=np.int64)
+    first = n_warm
+    edges = np.zeros(n_timed, dtype=np.int64)
+    rows = np.zeros((n_timed, H + 1), dtype=np.int64)
+    hop_edges = np.zeros((n_timed, H), dtype=np.int64)
+    hop_slots = np.zeros((n_timed, H), dtype=np.int64)
     hits = 0
-    for k in range(args.steps):
+    for k in range(n_timed):
         if k % G == 0:
-            slot = pipe.submit(first + k, n_active=min(G, args.steps - k))
+            slot = pipe.submit(first + k)
             pipe.wait(slot)
         pl = pipe.pools[slot][k % G]
         nc = pl.buffer("node_counter").cpu().numpy()
@@ -212,20 +223,42 @@ def main():
             assert bool((ids.long()[pl.buffer("agg_src_off")[:e].long()] == src_g).all())
             hits = int((pl.buffer("cache_search_buffer")[:int(nc[1])] >= 0).sum())
 
-    # ---- warm-up, then the timed region: K batches replayed as hipGraphs over `lanes` lanes ---------
-    pipe.run_range(0, args.warmup)
+    # ---- warm-up, then the timed region: exactly K steps (K hipGraph replays of G batches each) between
+    #      barrier + synchronize brackets.  The region is repeated (same batches: an epoch over the same
+    #      seeds, replays are deterministic) until --min-seconds have been timed; every rank runs the same
+    #      number of repeats, per repeat the MAX over ranks counts, and the median repeat is reported. -------
+    pipe.run_range(0, n_warm)
     pipe.wait()
+
+    def timed_region():
+        if use_dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        last = pipe.run_range(first, n_timed)
+        pipe.wait()
+        torch.cuda.synchronize()
+        if use_dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+        return time.perf_counter() - t0, last
+
+    el0, last_group = timed_region()
+    reps_t = torch.tensor([max(1, min(args.max_repeats, int(np.ceil(args.min_seconds / max(el0, 1e-6)))))],
+                          dtype=torch.int64, device=dev)
     if use_dist:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    last_group = pipe.run_range(first, args.steps)
-    pipe.wait()
-    torch.cuda.synchronize()
+        dist.all_reduce(reps_t, op=dist.ReduceOp.MAX)
+    repeats = int(reps_t.item())
+    region_s = [el0]
+    for _ in range(repeats - 1):
+        el, last_group = timed_region()
+        region_s.append(el)
+    region_t = torch.tensor(region_s, dtype=torch.float64, device=dev)
     if use_dist:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
+        dist.all_reduce(region_t, op=dist.ReduceOp.MAX)              # per repeat: the slowest rank
+    region_s = region_t.cpu().numpy()
+    elapsed_max = float(np.median(region_s))
+    elapsed = float(np.median(np.asarray(region_s)))                 # used for the rank-0 sampler/gather split below
     if not args.no_verify and last_group is not None:
         # the last group of the timed region is still in its slot: its batches must be the ones the counting
         # pass saw (replays are deterministic), and its last lane passes the full-size property checks
@@ -244,11 +277,11 @@ def main():
     # ---- the same K batches once more with HIP events around every gather launch (recorded on the
     #      lane's own stream).  Eager launches: HIP cannot time events recorded by graph nodes. ------
     pipe.profile_begin()
-    pipe.run_range(0, args.warmup)
+    pipe.run_range(0, n_warm)
     pipe.wait()
     warm = pipe.profile_read()
     t1 = time.perf_counter()
-    pipe.run_range(first, args.steps)
+    pipe.run_range(first, n_timed)
     pipe.wait()
     elapsed_profiled = time.perf_counter() - t1
     prof = pipe.profile_read()
@@ -256,13 +289,10 @@ def main():
     prof = {op: (ms - warm.get(op, (0.0, 0))[0], cnt - warm.get(op, (0.0, 0))[1]) for op, (ms, cnt) in prof.items()}
 
     tot_edges = torch.tensor([float(edges.sum())], dtype=torch.float64, device=dev)
-    t_max = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     gather_bytes_t = torch.tensor([float(rows.sum() * D * 4)], dtype=torch.float64, device=dev)
     if use_dist:
         dist.all_reduce(tot_edges)
         dist.all_reduce(gather_bytes_t)
-        dist.all_reduce(t_max, op=dist.ReduceOp.MAX)
-    elapsed_max = float(t_max.item())
 
     # ---- roofline of the dominant kernel: the last hop's gather (op 3H+1) -------------------------
     last_op = 3 * H + 1
@@ -289,7 +319,7 @@ def main():
         except (OSError, ValueError):
             continue
         if pmc.get("batches_per_launch_group") == G and f"batch {B}," in pmc.get("config", "") and f"N x {D}]" in pmc.get("config", "") \
-                and f"RMAT-{args.scale} " in pmc.get("config", ""):
+                and f"RMAT-{args.scale} " in pmc.get("config", "") and ("scrambled" in pmc.get("config", "")) == bool(args.scramble):
             traffic = pmc["traffic_bytes_per_launch"] / pmc["rows_per_launch"] * (rows_last / max(n_last, 1))
             traffic_src = os.path.relpath(f, ROOT)
             break
@@ -301,10 +331,17 @@ def main():
             "unit": "edges/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed_max / args.steps * 1e3,
+            "batches_per_step": G, "ms_per_batch": elapsed_max / n_timed * 1e3,
+            "timed_region": {"steps": args.steps, "repeats": repeats, "median_s": elapsed_max,
+                             "min_s": float(region_s.min()), "max_s": float(region_s.max()),
+                             "total_timed_s": float(region_s.sum()),
+                             "note": "exactly K steps per region between barrier+synchronize brackets; region repeated over the "
+                                     "same batches until --min-seconds; per repeat the max over ranks; value uses the median"},
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "int32+f32(copy)", "data": "synthetic",
             "config": {"workload": f"RMAT-{args.scale} EF{args.edge_factor} (N={N}, E={N * args.edge_factor}), "
-                                   f"float32[N x {D}] features, batch {B}, fanout {fanout}, all tables resident in HBM",
+                                   f"float32[N x {D}] features, batch {B}, fanout {fanout}, all tables resident in HBM"
+                                   + (", vertex labels scrambled" if args.scramble else ""),
                        "parallelism": (f"seed-sharded x{world}, replicated graph+features, one clique of {world}: caches "
                                        f"striped over the ranks, peer reads over xGMI (cache_agg_mode {int(np.log2(world))})")
                        if stripe else f"seed-sharded x{world}, replicated graph+features, cache_agg_mode 0",
@@ -320,7 +357,8 @@ def main():
                               "note": "rank 0; time = timed region minus the HIP-event time of all gather launches; the "
                                       "sampler is bound by scattered 4-byte atomics (~17-19 G/s beyond the Infinity Cache) and loads (~47 G/s), "
                                       "see tools/micro/random_access.hip"},
-            "edges_per_step": float(edges.mean()), "rows_per_step": float(rows.sum(axis=1).mean()),
+            "edges_per_step": float(edges.sum()) / args.steps, "rows_per_step": float(rows.sum()) / args.steps,
+            "edges_per_batch": float(edges.mean()), "rows_per_batch": float(rows.sum(axis=1).mean()),
             "seed_feature_cache_hits_step0": hits,
             "roofline": {"bound": "hbm", "kernel": "gather_kernel<float4> (hop-%d gather, op %d)" % (H, last_op),
                          "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
@@ -328,9 +366,10 @@ def main():
                          "traffic_source": traffic_src, "algorithmic_bytes_per_launch": rows_last / max(n_last, 1) * bytes_per_row,
                          "bytes_per_row": bytes_per_row, "rows_per_launch": rows_last / max(n_last, 1),
                          "launches": n_last, "avg_launch_us": t_last / max(n_last, 1) * 1e6,
-                         "measured": "HIP events on the launch stream around each hop-%d gather over the same %d "
-                                     "batches, %d batches per launch, eager launches (ms_per_step %.4f)"
-                                     % (H, args.steps, G, elapsed_profiled / args.steps * 1e3)},
+                         "measured": "HIP events on the launch stream around each hop-%d gather launch over the same %d "
+                                     "steps, %d batches per launch, eager launches (wall clock of that pass: ms_per_step %.4f; "
+                                     "hipGraph replay, timed region: %.4f)"
+                                     % (H, args.steps, G, elapsed_profiled / args.steps * 1e3, elapsed_max / args.steps * 1e3)},
             "setup_seconds": setup_s,
         }
         if args.cpu_seconds > 0 and world == 1:      # reported at N = 1 only

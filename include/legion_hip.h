@@ -263,6 +263,9 @@ int32_t legion_pool_profile_end(LegionMemoryPool* p, float* out_ms, int32_t* out
  * ===================================================================================== */
 void legion_synth_rmat_edges(legion_stream_t stream, int32_t scale, int64_t num_edges, uint64_t seed,
                              int32_t* src_out, int32_t* dst_out);
+/* same edges with Graph500-style label scrambling (a keyed bijection of [0, 2^scale)); key 0 = none */
+void legion_synth_rmat_edges_scrambled(legion_stream_t stream, int32_t scale, int64_t num_edges, uint64_t seed,
+                                       int32_t* src_out, int32_t* dst_out, uint64_t scramble_key);
 void legion_synth_features(legion_stream_t stream, float* out, int64_t first_row, int64_t num_rows,
                            int32_t dim, uint64_t seed);
 void legion_synth_feature_check(legion_stream_t stream, const float* rows, const int32_t* ids,

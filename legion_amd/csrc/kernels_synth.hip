@@ -16,9 +16,24 @@ __host__ __device__ inline uint64_t splitmix64(uint64_t x)
     return x ^ (x >> 31);
 }
 
+// Graph500-style label scrambling: a bijection of [0, 2^scale) (odd multiplier, xor-shift, odd multiplier:
+// every step is invertible modulo 2^scale), so hubs no longer sit at the low vertex ids and hot rows of
+// node_map / RowHdr / the feature table are spread over the whole id range like in a real graph.
+__host__ __device__ inline uint32_t scramble_label(uint32_t x, int32_t scale, uint64_t key)
+{
+    const uint32_t mask = scale >= 32 ? 0xFFFFFFFFu : ((1u << scale) - 1u);
+    const uint32_t m1 = (uint32_t)(key) | 1u, m2 = (uint32_t)(key >> 32) | 1u;
+    const int32_t sh = scale > 1 ? (scale + 1) / 2 : 1;
+    x = (x * m1 + (uint32_t)(key >> 17)) & mask;
+    x ^= x >> sh;
+    x = (x * m2) & mask;
+    x ^= x >> sh;
+    return x & mask;
+}
+
 // one RMAT edge per thread; quadrant thresholds in 16.16 fixed point of (a, a+b, a+b+c)
 __global__ void rmat_kernel(int32_t scale, int64_t num_edges, uint64_t seed, int32_t* __restrict__ src_out,
-                            int32_t* __restrict__ dst_out)
+                            int32_t* __restrict__ dst_out, uint64_t scramble_key)
 {
     const uint32_t ta = (uint32_t)(0.57 * 65536.0), tab = (uint32_t)(0.76 * 65536.0), tabc = (uint32_t)(0.95 * 65536.0);
     for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < num_edges;
@@ -34,6 +49,10 @@ __global__ void rmat_kernel(int32_t scale, int64_t num_edges, uint64_t seed, int
             v = (v << 1) | vbit;
         }
         if (u == v) v = u ^ 1u;                                             // no self loops
+        if (scramble_key != 0) {
+            u = scramble_label(u, scale, scramble_key);
+            v = scramble_label(v, scale, scramble_key);
+        }
         src_out[e] = (int32_t)u;
         dst_out[e] = (int32_t)v;
     }
@@ -75,12 +94,19 @@ __global__ void synth_feature_check_kernel(const float* __restrict__ rows, const
 
 }  // namespace lg
 
+extern "C" void legion_synth_rmat_edges_scrambled(legion_stream_t stream, int32_t scale, int64_t num_edges, uint64_t seed,
+                                                  int32_t* src_out, int32_t* dst_out, uint64_t scramble_key)
+{
+    if (num_edges <= 0) return;
+    lg::rmat_kernel<<<4096, 256, 0, static_cast<hipStream_t>(stream)>>>(scale, num_edges, seed, src_out, dst_out,
+                                                                       scramble_key);
+    hipCheckError();
+}
+
 extern "C" void legion_synth_rmat_edges(legion_stream_t stream, int32_t scale, int64_t num_edges, uint64_t seed,
                                         int32_t* src_out, int32_t* dst_out)
 {
-    if (num_edges <= 0) return;
-    lg::rmat_kernel<<<4096, 256, 0, static_cast<hipStream_t>(stream)>>>(scale, num_edges, seed, src_out, dst_out);
-    hipCheckError();
+    legion_synth_rmat_edges_scrambled(stream, scale, num_edges, seed, src_out, dst_out, 0);
 }
 
 extern "C" void legion_synth_features(legion_stream_t stream, float* out, int64_t first_row, int64_t num_rows,

@@ -94,6 +94,7 @@ SIGNATURES = {
     "legion_pool_profile_end": (c_i32, [c_p, ctypes.POINTER(ctypes.c_float), P_I32, c_i32]),
     # 5. synthetic workloads
     "legion_synth_rmat_edges": (None, [c_p, c_i32, c_i64, c_u64, c_p, c_p]),
+    "legion_synth_rmat_edges_scrambled": (None, [c_p, c_i32, c_i64, c_u64, c_p, c_p, c_u64]),
     "legion_synth_features": (None, [c_p, c_p, c_i64, c_i64, c_i32, c_u64]),
     "legion_synth_feature_check": (None, [c_p, c_p, c_p, c_i64, c_i32, c_u64, c_p]),
     "legion_host_alloc": (c_p, [c_i64, ctypes.POINTER(c_p)]),

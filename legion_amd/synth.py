@@ -24,8 +24,26 @@ def splitmix64_np(x):
         return x ^ (x >> np.uint64(31))
 
 
-def rmat_edges_numpy(scale, num_edges, seed):
-    """Same edges as legion_synth_rmat_edges (kernels_synth.hip: rmat_kernel)."""
+SCRAMBLE_KEY = 0x9E3779B97F4A7C15 ^ 20231     # bench.py --scramble / tests: any non-zero 64-bit key
+
+
+def scramble_labels_numpy(x, scale, key):
+    """kernels_synth.hip: scramble_label -- a bijection of [0, 2^scale)."""
+    mask = np.uint64((1 << scale) - 1)
+    m1 = np.uint64((key & 0xFFFFFFFF) | 1)
+    m2 = np.uint64(((key >> 32) & 0xFFFFFFFF) | 1)
+    add = np.uint64((key >> 17) & 0xFFFFFFFF)
+    sh = np.uint64((scale + 1) // 2 if scale > 1 else 1)
+    x = np.asarray(x, dtype=np.uint64)
+    x = (x * m1 + add) & mask
+    x = x ^ (x >> sh)
+    x = (x * m2) & mask
+    x = x ^ (x >> sh)
+    return (x & mask).astype(np.uint32)
+
+
+def rmat_edges_numpy(scale, num_edges, seed, scramble_key=0):
+    """Same edges as legion_synth_rmat_edges[_scrambled] (kernels_synth.hip: rmat_kernel)."""
     e = np.arange(num_edges, dtype=np.uint64)
     u = np.zeros(num_edges, dtype=np.uint32)
     v = np.zeros(num_edges, dtype=np.uint32)
@@ -41,6 +59,8 @@ def rmat_edges_numpy(scale, num_edges, seed):
         v = (v << np.uint32(1)) | vbit
     same = u == v
     v[same] = u[same] ^ np.uint32(1)
+    if scramble_key:
+        u, v = scramble_labels_numpy(u, scale, scramble_key), scramble_labels_numpy(v, scale, scramble_key)
     return u.astype(np.int32), v.astype(np.int32)
 
 
@@ -53,9 +73,9 @@ def csr_from_edges_numpy(num_nodes, src, dst):
     return indptr, col
 
 
-def rmat_csr_numpy(scale, edge_factor, seed):
+def rmat_csr_numpy(scale, edge_factor, seed, scramble=False):
     n = 1 << scale
-    src, dst = rmat_edges_numpy(scale, n * edge_factor, seed)
+    src, dst = rmat_edges_numpy(scale, n * edge_factor, seed, SCRAMBLE_KEY if scramble else 0)
     return csr_from_edges_numpy(n, src, dst)
 
 
@@ -89,7 +109,7 @@ def seed_ids(num_nodes, count, seed):
 
 
 # ---- device generators -------------------------------------------------------------------------
-def rmat_csr_device(scale, edge_factor, seed, device="cuda:0"):
+def rmat_csr_device(scale, edge_factor, seed, device="cuda:0", scramble=False):
     import torch
     from . import lib as _libmod
     lib = _libmod.load()
@@ -98,8 +118,8 @@ def rmat_csr_device(scale, edge_factor, seed, device="cuda:0"):
     src = torch.empty(e, dtype=torch.int32, device=device)
     dst = torch.empty(e, dtype=torch.int32, device=device)
     stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
-    lib.legion_synth_rmat_edges(stream, scale, e, seed, ctypes.c_void_p(src.data_ptr()),
-                                ctypes.c_void_p(dst.data_ptr()))
+    lib.legion_synth_rmat_edges_scrambled(stream, scale, e, seed, ctypes.c_void_p(src.data_ptr()),
+                                          ctypes.c_void_p(dst.data_ptr()), SCRAMBLE_KEY if scramble else 0)
     counts = torch.bincount(src, minlength=n)
     indptr = torch.zeros(n + 1, dtype=torch.int64, device=device)
     torch.cumsum(counts, 0, out=indptr[1:])

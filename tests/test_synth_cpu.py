@@ -30,3 +30,19 @@ def test_seed_ids_are_a_permutation_prefix():
     assert np.array_equal(synth.seed_ids(1 << 12, 100, 11), s[:100])
     t = synth.seed_ids(1000, 300, 11)
     assert np.unique(t).size == 300 and t.max() < 1000
+
+
+def test_label_scrambling_is_a_bijection_that_keeps_the_graph():
+    for scale in (1, 5, 10, 13):
+        x = np.arange(1 << scale)
+        y = synth.scramble_labels_numpy(x, scale, synth.SCRAMBLE_KEY)
+        assert np.array_equal(np.sort(y), x)
+    ip, col = synth.rmat_csr_numpy(10, 8, 20231)
+    ips, cols = synth.rmat_csr_numpy(10, 8, 20231, scramble=True)
+    perm = synth.scramble_labels_numpy(np.arange(1024), 10, synth.SCRAMBLE_KEY).astype(np.int64)
+    deg, degs = np.diff(ip), np.diff(ips)
+    assert np.array_equal(degs[perm], deg)                       # vertex v became perm[v], same degree
+    for v in (0, 1, 2, 77, 1023):                                # and the same (relabelled) neighbours
+        assert np.array_equal(np.sort(perm[col[ip[v]:ip[v + 1]]]), np.sort(cols[ips[perm[v]]:ips[perm[v] + 1]]))
+    hubs = np.argsort(-degs)[:32]
+    assert hubs.max() > 512                                      # hubs are no longer the low ids
