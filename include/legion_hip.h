@@ -108,6 +108,16 @@ int32_t legion_pool_num_ids(const LegionMemoryPool* p);
  *        7 agg_src_ids 8 agg_dst_ids 9 cache_search_buffer 10 tmp_part_ind 11 tmp_part_off
  *        12 position_map.  Returns the device pointer of the CURRENT pipe slot. */
 void* legion_pool_buffer(LegionMemoryPool* p, int32_t which);
+/* New in this build.  The first-touch/position state of a pool (the reference's accessed_map + position_map,
+ * SS/engine/memorypool.cuh:120-135) is either a direct uint32[N] array (fastest; N x 4 B per pool) or a compact
+ * open-addressing table sized by num_ids (LEGION_DEDUP=direct|table|auto, auto = table when the arrays of all
+ * pools in flight would exceed a quarter of HBM).  Both give bit-identical batches. */
+int32_t legion_pool_uses_table(const LegionMemoryPool* p);
+int64_t legion_pool_state_bytes(const LegionMemoryPool* p);
+/* Sticky error bits raised on the device for this pool (0 = none): 1 position table full, 2 batch larger than the
+ * feature buffer (gather stopped at its end; the reference overruns, SS/engine/server.cu:277), 4 internal.  The
+ * word lives in host-visible memory: reading it after the batch completed needs no copy. */
+int32_t legion_pool_error(const LegionMemoryPool* p);
 void legion_pool_destroy(LegionMemoryPool* p);
 
 /* UnifiedCache: SS/cache/cache.cu:295-321 (Initialize), :323-328 (InitializeCacheController). */

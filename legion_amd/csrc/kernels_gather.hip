@@ -50,8 +50,13 @@ __global__ __launch_bounds__(LG_GATHER_THREADS) void gather_kernel(GatherParams 
         off = off0;
     }
     if (rows > gp.max_rows) rows = gp.max_rows;
-    if (rows > L.feature_rows - off) rows = L.feature_rows - off;   // never write past the feature buffer (the
-                                                                    // reference sizes it 1.2 x PreSC max and would overrun)
+    if (rows > L.feature_rows - off) {     // never write past the feature buffer (the reference sizes it 1.2 x the PreSC
+        rows = L.feature_rows - off;       // maximum and would overrun, SS/engine/server.cu:277): stop at its end and say so
+        if (blockIdx.x == 0 && threadIdx.x == 0 && L.hop_scratch != nullptr) {
+            __hip_atomic_fetch_or(LG_GPTR(int32_t, L.hop_scratch) + HS_ERROR, LG_ERR_FEATURE_ROWS, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (L.err_flag) __hip_atomic_fetch_or(LG_GPTR(int32_t, L.err_flag), LG_ERR_FEATURE_ROWS, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
     const int32_t ntiles = (rows + ROWS - 1) / ROWS;
     const int32_t tid = threadIdx.x;
     const int32_t D = gp.D;

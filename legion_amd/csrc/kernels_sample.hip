@@ -99,6 +99,7 @@ void launch_draw_batch(hipStream_t s, const int32_t* idx, const int32_t* deg, in
 struct BracketLane {
     LG_G int32_t* sampled_ids; LG_G int32_t* labels; LG_G int32_t* node_counter; LG_G int32_t* edge_counter;
     LG_G int32_t* hop_scratch; LG_G uint32_t* position_map; LG_G int32_t* slot_mark;
+    LG_G unsigned long long* pos_table; uint32_t pos_mask; LG_G int32_t* err_flag;
     int32_t total_num_nodes, max_slots;
 };
 __device__ __forceinline__ BracketLane bracket_lane(const LanePtrs& P)
@@ -108,8 +109,62 @@ __device__ __forceinline__ BracketLane bracket_lane(const LanePtrs& P)
     L.node_counter = LG_GPTR(int32_t, P.node_counter); L.edge_counter = LG_GPTR(int32_t, P.edge_counter);
     L.hop_scratch = LG_GPTR(int32_t, P.hop_scratch); L.position_map = LG_GPTR(uint32_t, P.position_map);
     L.slot_mark = LG_GPTR(int32_t, P.slot_mark);
+    L.pos_table = LG_GPTR(unsigned long long, P.pos_table); L.pos_mask = P.pos_table_mask;
+    L.err_flag = LG_GPTR(int32_t, P.err_flag);
     L.total_num_nodes = P.total_num_nodes; L.max_slots = P.max_slots;
     return L;
+}
+
+__device__ __forceinline__ void raise_error(LG_G int32_t* hop_scratch, LG_G int32_t* err_flag, int32_t bits)
+{
+    __hip_atomic_fetch_or(hop_scratch + HS_ERROR, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (err_flag) __hip_atomic_fetch_or(err_flag, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+// ------------------------------------------------------------------------------------------
+// Compact position state (legion_core.h): one claim = an ordered-linear-probing insert of
+// [epoch | vertex | pending | value] with one atomicMin(u64) per probe.  `low` is pending | slot for a
+// sampled neighbour, the final position for a seed.  Whoever is merged away (same vertex, larger value)
+// is a slot that lost its first touch: it gets the hop's mark and, in slot_pos, the final position or
+// -2 - (the slot it lost to) -- written by the one thread that saw the merge.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ void table_claim(LG_G unsigned long long* tab, uint32_t mask, const PosFmt& pf, int32_t id,
+                                            uint32_t low, LG_G int32_t* slot_mark, LG_G int32_t* slot_pos, int32_t mark_tag,
+                                            LG_G int32_t* hop_scratch, LG_G int32_t* err_flag)
+{
+    unsigned long long w = lg_tab_word(pf, id, low);
+    uint32_t p = lg_tab_hash(id) & mask;
+    const int sh = pf.vb + 1;
+    const uint32_t lowmask = pf.pending | pf.vmask;
+    for (uint32_t it = 0; it <= mask; it++) {
+        const unsigned long long old = __hip_atomic_fetch_min(tab + p, w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (!lg_tab_current(pf, old)) return;                 // took a stale or empty word's place
+        if (((old ^ w) >> sh) == 0) {                         // the same vertex: the lower value stays
+            const uint32_t a = (uint32_t)old & lowmask, b = (uint32_t)w & lowmask;
+            const uint32_t surv = a < b ? a : b, elim = a < b ? b : a;
+            if ((elim & pf.pending) && slot_mark != nullptr) {
+                const int32_t loser = (int32_t)(elim & pf.vmask);
+                slot_mark[loser] = mark_tag;
+                slot_pos[loser] = (surv & pf.pending) ? -2 - (int32_t)(surv & pf.vmask) : (int32_t)(surv & pf.vmask);
+            }
+            return;
+        }
+        if (old > w) w = old;                                 // displaced a larger word: carry it on
+        p = (p + 1) & mask;
+    }
+    raise_error(hop_scratch, err_flag, LG_ERR_TABLE_FULL);
+}
+
+// where the (present) vertex lives: plain loads, the table is not being claimed while this runs
+__device__ __forceinline__ uint32_t table_find(const LG_G unsigned long long* tab, uint32_t mask, const PosFmt& pf, int32_t id)
+{
+    uint32_t p = lg_tab_hash(id) & mask;
+    const unsigned long long want = lg_tab_word(pf, id, 0) >> (pf.vb + 1);
+    for (uint32_t it = 0; it <= mask; it++) {
+        if ((tab[p] >> (pf.vb + 1)) == want) return p;
+        p = (p + 1) & mask;
+    }
+    return 0xFFFFFFFFu;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -144,9 +199,12 @@ __global__ void batch_generate_kernel(SeedParams p, const LanePtrs* __restrict__
         } else {
             const int32_t src_id = p.all_ids[at % p.total_cap];
             L.sampled_ids[idx] = src_id;
-            __hip_atomic_fetch_min(L.position_map + src_id,
-                                   lg_pos_fmt(L.hop_scratch[HS_EPOCH], L.hop_scratch[HS_VALUE_BITS]).hi | (uint32_t)idx,
-                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // seeds are unique (":26 assume no duplicate")
+            const PosFmt pf = lg_pos_fmt(L.hop_scratch[HS_EPOCH], L.hop_scratch[HS_VALUE_BITS]);
+            if (L.pos_table != nullptr)
+                table_claim(L.pos_table, L.pos_mask, pf, src_id, (uint32_t)idx, nullptr, nullptr, 0, L.hop_scratch, L.err_flag);
+            else
+                __hip_atomic_fetch_min(L.position_map + src_id, pf.hi | (uint32_t)idx,
+                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // seeds are unique (":26 assume no duplicate")
             L.labels[idx] = p.all_labels[at % p.total_cap];
         }
     }
@@ -175,6 +233,7 @@ struct SampleArgs {
     LG_G char* tmp_part_ind; LG_G uint32_t* position_map; LG_G int32_t* node_counter; LG_G int32_t* edge_counter;
     LG_G int32_t* slot_dst; LG_G int32_t* slot_pos; LG_G int32_t* slot_mark; LG_G int32_t* tile_counts; LG_G int32_t* tile_prefix; LG_G int32_t* hop_scratch;
     LG_G RowHdr* fh_edge;
+    LG_G unsigned long long* pos_table; uint32_t pos_mask; LG_G int32_t* err_flag;
     PosFmt pf;
     int32_t mark_tag;   // (epoch, hop): what slot_mark holds for a slot that lost its first touch in THIS hop
 };
@@ -217,6 +276,8 @@ __device__ __forceinline__ SampleArgs lane_args(const HopParams& p, const LanePt
     a.slot_pos = LG_GPTR(int32_t, L.slot_pos); a.slot_mark = LG_GPTR(int32_t, L.slot_mark); a.tile_counts = LG_GPTR(int32_t, L.tile_counts);
     a.tile_prefix = LG_GPTR(int32_t, L.tile_prefix); a.hop_scratch = LG_GPTR(int32_t, L.hop_scratch);
     a.fh_edge = LG_GPTR(RowHdr, L.fh_edge);
+    a.pos_table = LG_GPTR(unsigned long long, L.pos_table); a.pos_mask = L.pos_table_mask;
+    a.err_flag = LG_GPTR(int32_t, L.err_flag);
     a.pf = lg_pos_fmt(a.hop_scratch[HS_EPOCH], a.hop_scratch[HS_VALUE_BITS]);
     a.mark_tag = (a.hop_scratch[HS_EPOCH] << 8) | (p.op_id / INTRABATCH_CON);
     return a;
@@ -260,6 +321,7 @@ __device__ __forceinline__ HopGeom hop_geometry(const SampleArgs& a)
 // coalesced 16-byte load per frontier entry), for hop 1 they are looked up in the per-vertex
 // header table here.
 // ------------------------------------------------------------------------------------------
+template <bool TABLE>
 __global__ __launch_bounds__(LG_TILE) void sample_kernel(HopParams hp, const LanePtrs* __restrict__ lanes)
 {
     const SampleArgs a = lane_args(hp, lanes);
@@ -341,16 +403,21 @@ __global__ __launch_bounds__(LG_TILE) void sample_kernel(HopParams hp, const Lan
                     //   otherwise : untouched so far; this slot holds it unless a lower one shows up.
                     // A loser gets the hop's tag in slot_mark and, in slot_pos, the final position or -2 - (the
                     // slot it lost to); the chain of losers ends at the winner (localise follows it).
-                    const uint32_t key = a.pf.hi | a.pf.pending | (uint32_t)idx;
-                    const uint32_t old = __hip_atomic_fetch_min(a.position_map + dst[u], key, __ATOMIC_RELAXED,
-                                                                __HIP_MEMORY_SCOPE_AGENT);
-                    if (old < key) {
-                        a.slot_mark[idx] = a.mark_tag;
-                        a.slot_pos[idx] = (old & a.pf.pending) ? -2 - (int32_t)(old & a.pf.vmask) : (int32_t)(old & a.pf.vmask);
-                    } else if ((old & ~(a.pf.pending | a.pf.vmask)) == a.pf.hi) {
-                        const int32_t loser = (int32_t)(old & a.pf.vmask);
-                        a.slot_mark[loser] = a.mark_tag;
-                        a.slot_pos[loser] = -2 - idx;
+                    if (TABLE) {      // compact form: the same outcome through the lane's open-addressing table
+                        table_claim(a.pos_table, a.pos_mask, a.pf, dst[u], a.pf.pending | (uint32_t)idx, a.slot_mark, a.slot_pos,
+                                    a.mark_tag, a.hop_scratch, a.err_flag);
+                    } else {
+                        const uint32_t key = a.pf.hi | a.pf.pending | (uint32_t)idx;
+                        const uint32_t old = __hip_atomic_fetch_min(a.position_map + dst[u], key, __ATOMIC_RELAXED,
+                                                                    __HIP_MEMORY_SCOPE_AGENT);
+                        if (old < key) {
+                            a.slot_mark[idx] = a.mark_tag;
+                            a.slot_pos[idx] = (old & a.pf.pending) ? -2 - (int32_t)(old & a.pf.vmask) : (int32_t)(old & a.pf.vmask);
+                        } else if ((old & ~(a.pf.pending | a.pf.vmask)) == a.pf.hi) {
+                            const int32_t loser = (int32_t)(old & a.pf.vmask);
+                            a.slot_mark[loser] = a.mark_tag;
+                            a.slot_pos[loser] = -2 - idx;
+                        }
                     }
                     if (a.edge_access_time)                                // :358
                         __hip_atomic_fetch_add(a.edge_access_time + g.frontier[idx / count], 1ull, __ATOMIC_RELAXED,
@@ -526,6 +593,7 @@ __global__ __launch_bounds__(LG_TILE) void scatter_kernel(HopParams hp, const La
         // in flight together: the buffers may alias as far as the compiler knows)
         int32_t e_at[LG_SLOTS_PER_LANE], n_at[LG_SLOTS_PER_LANE], src_of[LG_SLOTS_PER_LANE], src_pos[LG_SLOTS_PER_LANE];
         int32_t lost_pos[LG_SLOTS_PER_LANE];
+        uint32_t tab_at[LG_SLOTS_PER_LANE];
         RowHdr nh[LG_SLOTS_PER_LANE];
 #pragma unroll
         for (int u = 0; u < LG_SLOTS_PER_LANE; u++) {
@@ -545,6 +613,7 @@ __global__ __launch_bounds__(LG_TILE) void scatter_kernel(HopParams hp, const La
                 src_pos[u] = seeds ? q : a.agg_src_off[f_off + q];
                 if (!a.last_hop) nh[u] = load_hdr(a.row_hdr + dst);      // next hop's frontier header
                 lost_pos[u] = first ? 0 : a.slot_pos[idx];               // final already, or -2 - (slot it lost to)
+                tab_at[u] = (first && !a.last_hop && a.pos_table != nullptr) ? table_find(a.pos_table, a.pos_mask, a.pf, dst) : 0u;
             }
         }
         // phase 2: the stores
@@ -563,7 +632,14 @@ __global__ __launch_bounds__(LG_TILE) void scatter_kernel(HopParams hp, const La
                 a.sampled_ids[n] = dst;                            // :270
                 // :271 -- later hops look the position up in the state array; after the last hop nobody
                 // does, and same-hop duplicates resolve through slot_pos (a small, cache-resident array)
-                if (!a.last_hop) a.position_map[dst] = (int32_t)(a.pf.hi | (uint32_t)n);
+                if (!a.last_hop) {
+                    if (a.pos_table == nullptr)
+                        a.position_map[dst] = (int32_t)(a.pf.hi | (uint32_t)n);
+                    else if (tab_at[u] != 0xFFFFFFFFu)
+                        a.pos_table[tab_at[u]] = lg_tab_word(a.pf, dst, (uint32_t)n);
+                    else
+                        raise_error(a.hop_scratch, a.err_flag, LG_ERR_TABLE_FULL);
+                }
                 a.slot_pos[idx] = n;
                 a.agg_src_off[e] = n;                              // construct_graph's neighbour side, known here
             } else {
@@ -598,14 +674,15 @@ __global__ __launch_bounds__(LG_TILE) void localise_kernel(HopParams hp, const L
             const int32_t e = st * LG_SUPER + u * LG_TILE + threadIdx.x;
             if (cur[u] < 0) {      // -2 - (slot it lost to); that slot may have lost to a lower one in turn
                 int32_t c = cur[u];
-                for (int it = 0; it < 65536 && c < -1; it++) c = a.slot_pos[-2 - c];   // strictly descending slots
+                for (int it = 0; it < (1 << 20) && c < -1; it++) c = a.slot_pos[-2 - c];   // strictly descending slots
+                if (c < -1) raise_error(a.hop_scratch, a.err_flag, LG_ERR_CHAIN);         // cannot happen: every chain ends at a winner
                 a.agg_src_off[edge_base + e] = c;
             }
         }
     }
 }
 
-void launch_random_sample(hipStream_t s, const HopParams& p, const LanePtrs* d_lanes, int32_t n_lanes)
+void launch_random_sample(hipStream_t s, const HopParams& p, const LanePtrs* d_lanes, int32_t n_lanes, bool table_form)
 {
     // Fixed grids that stride over super tiles; grid.y = lanes (independent mini-batches of a group).
     int32_t max_super = (p.max_slots + LG_SUPER - 1) / LG_SUPER;
@@ -613,7 +690,10 @@ void launch_random_sample(hipStream_t s, const HopParams& p, const LanePtrs* d_l
     int32_t gx = max_super < 1024 ? max_super : 1024;
     while (gx > 64 && (int64_t)gx * n_lanes > 4096) gx /= 2;    // keep the whole launch near 2 x resident capacity
     const dim3 grid(gx, n_lanes);
-    sample_kernel<<<grid, LG_TILE, 0, s>>>(p, d_lanes);
+    if (table_form)
+        sample_kernel<true><<<grid, LG_TILE, 0, s>>>(p, d_lanes);
+    else
+        sample_kernel<false><<<grid, LG_TILE, 0, s>>>(p, d_lanes);
     hipCheckError();
     flag_count_kernel<<<grid, LG_TILE, 0, s>>>(p, d_lanes);
     hipCheckError();
@@ -690,9 +770,14 @@ __global__ void end_of_batch_kernel(const LanePtrs* __restrict__ lanes, int32_t*
     const int32_t epoch = L.hop_scratch[HS_EPOCH];
     const int32_t epoch_max = lg_pos_epoch_max(L.hop_scratch[HS_VALUE_BITS]);
     if (epoch >= epoch_max) {
-        LG_G uint32_t* pm = L.position_map;
-        for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < L.total_num_nodes; i += (int64_t)gridDim.x * blockDim.x)
-            pm[i] = 0xFFFFFFFFu;
+        if (L.pos_table != nullptr) {
+            for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i <= (int64_t)L.pos_mask; i += (int64_t)gridDim.x * blockDim.x)
+                L.pos_table[i] = ~0ull;
+        } else {
+            LG_G uint32_t* pm = L.position_map;
+            for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < L.total_num_nodes; i += (int64_t)gridDim.x * blockDim.x)
+                pm[i] = 0xFFFFFFFFu;
+        }
         // the loser marks carry (epoch, hop): epochs are about to repeat
         for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < L.max_slots; i += (int64_t)gridDim.x * blockDim.x)
             L.slot_mark[i] = 0;
@@ -710,11 +795,11 @@ __global__ void end_of_batch_kernel(const LanePtrs* __restrict__ lanes, int32_t*
 }
 
 void launch_end_of_batch(hipStream_t s, const LanePtrs* d_lanes, int32_t n_lanes, int32_t* iter_state,
-                         int32_t total_num_nodes)
+                         int64_t state_bytes)
 {
-    // enough workgroups to refill the array at HBM speed on the rare epoch wrap, few enough to cost
-    // nothing otherwise
-    int32_t gx = (int32_t)(((int64_t)total_num_nodes * 4 + (1 << 20) - 1) >> 20);   // ~1 MiB per workgroup
+    // enough workgroups to refill the position state (array or table) at HBM speed on the rare epoch wrap,
+    // few enough to cost nothing otherwise
+    int32_t gx = (int32_t)((state_bytes + (1 << 20) - 1) >> 20);   // ~1 MiB per workgroup
     if (gx < 1) gx = 1;
     if (gx > 512) gx = 512;
     while (gx > 16 && gx * n_lanes > 2048) gx /= 2;

@@ -64,21 +64,51 @@
 // batches the end-of-batch kernel refills the array with 0xFF.  Within the current epoch the low
 // vb+1 bits hold either the final position of the vertex in sampled_ids, or pending | (lowest slot
 // index that sampled it in the hop being compacted); atomicMin keeps the lowest.
+//
+// The array costs N x 4 B per lane (268 MB at N = 2^26; a 128-lane group with two slots pins 69 GB), which is
+// the fastest layout measured (tools/micro/dedup_tables.hip) but does not scale to the
+// billion-vertex graphs of legion_server.py:73-88 or to N = 2^28 with many lanes.  The COMPACT form keeps the
+// same state in a per-lane open-addressing table sized by the pool's worst-case id count, not by N:
+//   uint64 word = [ EMAX - epoch : 32-vb | vertex id : 31 | pending : 1 | value : vb ],  empty = all ones.
+// One atomicMin(u64) per probe (ordered linear probing): a stale or empty word is replaced; a word of the
+// same vertex merges (lowest value stays: a known position beats any pending slot, a lower slot beats a
+// higher one); a LARGER word of another vertex is displaced and carried by the displacing thread to the next
+// position, a smaller one sends the claim itself on.  Words only ever decrease at a position within an
+// epoch, so a vertex has one home however the claims interleave, and every word that is merged away is
+// merged away exactly once -- by the thread that observes it -- which keeps "one writer per loser mark".
+// Same epochs, same refill rule (T x 8 B instead of N x 4 B).  Selected per pool: LEGION_DEDUP=direct|table|auto
+// (auto: table when the direct arrays of all lanes in flight would take more than a quarter of HBM).
 #define LG_POS_VALUE_BITS_MIN 16
 #define LG_POS_VALUE_BITS_MAX 28
 struct PosFmt {
     uint32_t hi;        // (EMAX - epoch) << (vb + 1)
     uint32_t pending;   // 1 << vb
     uint32_t vmask;     // pending - 1
+    uint32_t hifield;   // EMAX - epoch (unshifted): the top 32-vb bits of a table word
+    int32_t vb;
 };
 __host__ __device__ inline int32_t lg_pos_epoch_max(int32_t vb) { return (int32_t)((1u << (31 - vb)) - 2u); }
 __host__ __device__ inline PosFmt lg_pos_fmt(int32_t epoch, int32_t vb)
 {
     PosFmt f;
-    f.hi = (((1u << (31 - vb)) - 1u) - (uint32_t)epoch) << (vb + 1);
+    f.hifield = ((1u << (31 - vb)) - 1u) - (uint32_t)epoch;
+    f.hi = f.hifield << (vb + 1);
     f.pending = 1u << vb;
     f.vmask = f.pending - 1u;
+    f.vb = vb;
     return f;
+}
+// table form
+__host__ __device__ inline uint64_t lg_tab_word(const PosFmt& f, int32_t id, uint32_t low)
+{
+    return ((uint64_t)f.hifield << (32 + f.vb)) | ((uint64_t)(uint32_t)id << (f.vb + 1)) | (uint64_t)low;
+}
+__host__ __device__ inline bool lg_tab_current(const PosFmt& f, uint64_t w) { return (uint32_t)(w >> (32 + f.vb)) == f.hifield; }
+__host__ __device__ inline uint32_t lg_tab_hash(int32_t id)
+{
+    uint32_t x = (uint32_t)id;
+    x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+    return x;
 }
 
 // per-hop scratch written by the scan kernel, read by scatter / localise (device int32[16])
@@ -94,9 +124,15 @@ enum HopScratch {
     HS_EPOCH = 8,          // this lane's current epoch of the position-state array
     HS_TICKET = 9,         // last-workgroup ticket of the end-of-batch kernel
     HS_VALUE_BITS = 30,    // vb of the position-state format (fixed at pool creation)
+    HS_ERROR = 29,         // sticky error bits of the lane (LG_ERR_*), also mirrored to the pool's host-visible flag
     HS_RANGE = 10,         // [HS_RANGE + 2h], [+1]: {offset, count} of the new nodes of op 3h, kept for its gather
     HS_WORDS = 32
 };
+
+// error bits a kernel can raise for its lane (MemoryPool::ErrorBits / legion_pool_error)
+#define LG_ERR_TABLE_FULL 1       // compact position table had no free word (cannot happen for a pool-sized table)
+#define LG_ERR_FEATURE_ROWS 2     // the batch has more rows than the feature buffer: the gather stopped at its end
+#define LG_ERR_CHAIN 4            // localise_kernel ran out of steps following a loser chain
 
 // Device code: a pointer that was loaded from memory (LanePtrs, pointer tables, LDS) is "generic" to
 // the compiler, which then emits flat_* instructions; those count on lgkmcnt as well as vmcnt, so every
@@ -152,7 +188,10 @@ struct LanePtrs {
     int32_t* agg_src_off;
     int32_t* agg_dst_off;
     char* tmp_part_ind;
-    int32_t* position_map;
+    int32_t* position_map;             // direct form: uint32[N]; null in table form
+    unsigned long long* pos_table;     // table form: uint64[pos_table_mask + 1]; null in direct form
+    uint32_t pos_table_mask;
+    int32_t* err_flag;                 // mapped pinned host word: kernels OR LG_ERR_* bits into it
     int32_t* node_counter;
     int32_t* edge_counter;
     int32_t* slot_dst;
@@ -224,6 +263,11 @@ public:
     int32_t* tile_prefix = nullptr;    // [2 * max_tiles] exclusive prefixes
     RowHdr* fh_edge = nullptr;         // [num_ids] frontier row headers written by scatter
     int32_t* hop_scratch = nullptr;    // [HS_WORDS]
+    unsigned long long* pos_table = nullptr;   // compact position state (table form), else null
+    uint32_t pos_table_mask = 0;
+    int32_t* err_host = nullptr;       // host-visible error word (mapped pinned), err_dev = its device address
+    int32_t* err_dev = nullptr;
+    int32_t ErrorBits() const { return err_host ? *(volatile int32_t*)err_host : 0; }
     int32_t num_ids = 0;
     int32_t max_slots = 0;             // largest hop = B * f1 * ... * fH
     std::vector<int64_t> max_new;      // [h] upper bound of new nodes of op 3h (h = 0: the seeds)
@@ -501,6 +545,9 @@ bool lg_is_local(int32_t dev);
 
 void lg_pool_alloc_private(MemoryPool* mp, int32_t dev_id, int32_t total_num_nodes, int32_t batch_size,
                            const int32_t* fanout, int32_t hop_num, int32_t float_feature_len);
+// how many pools of this shape the caller is about to keep in flight on the device (Pipeline: lanes x slots);
+// feeds the direct-vs-table choice of the position state (LEGION_DEDUP=auto).  Thread-local; 0 = one pool.
+void lg_set_pool_lanes_hint(int32_t lanes);
 
 // alloc helpers, SS/engine/server_imp.cuh:2-51
 extern "C" void* d_alloc_space(int64_t num_bytes);
@@ -525,7 +572,7 @@ struct HopParams {                  // what every lane of a launch shares
     unsigned long long* edge_access_time;  // presample only (single lane), else null
     unsigned long long* topo_transactions; // presample only: 64-byte transactions the hop's topology reads amount to
 };
-void launch_random_sample(hipStream_t s, const HopParams& p, const LanePtrs* d_lanes, int32_t n_lanes);
+void launch_random_sample(hipStream_t s, const HopParams& p, const LanePtrs* d_lanes, int32_t n_lanes, bool table_form);
 
 struct GatherParams {
     const float* full_table;
@@ -557,7 +604,7 @@ struct SeedParams {
 void launch_batch_generate(hipStream_t s, const SeedParams& p, const LanePtrs* d_lanes, int32_t n_lanes);
 
 void launch_end_of_batch(hipStream_t s, const LanePtrs* d_lanes, int32_t n_lanes, int32_t* iter_state,
-                         int32_t total_num_nodes);
+                         int64_t state_bytes);
 void launch_hotness_measure(hipStream_t s, const int32_t* sampled_ids, const int32_t* node_counter,
                             unsigned long long* access_map);
 void init_row_headers(hipStream_t s, RowHdr* hdr, const int64_t* csr_index, int32_t n, int32_t slot);

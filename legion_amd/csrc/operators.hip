@@ -37,6 +37,11 @@ struct LegionLaneGroup {
     int32_t* iter_state = nullptr;    // device {next iteration of lane 0, stride} for graph replay, or null
 };
 
+static inline int64_t pool_state_bytes(const MemoryPool* mp)
+{
+    return mp->pos_table ? ((int64_t)mp->pos_table_mask + 1) * 8 : (int64_t)mp->total_num_nodes * 4;
+}
+
 static bool seed_set(FeatureStorage* feature, int32_t dev_id, int32_t mode, int32_t*& all_ids, int32_t*& all_labels,
                      int32_t& total_cap)
 {
@@ -111,7 +116,7 @@ static void do_random_sample(hipStream_t s, GraphStorage* graph, UnifiedCache* c
     p.max_slots = (int32_t)(hop < pool0->max_new.size() ? pool0->max_new[hop] : pool0->max_slots);
     p.edge_access_time = (is_presc && cache) ? cache->GetEdgeAccessedMap(dev_id) : nullptr;   // :473
     p.topo_transactions = (is_presc && cache) ? cache->Controller(dev_id)->GetTopoTransactions() : nullptr;
-    lg::launch_random_sample(s, p, d_lanes, n_lanes);
+    lg::launch_random_sample(s, p, d_lanes, n_lanes, pool0->pos_table != nullptr);
 }
 
 static void do_feature_lookup(hipStream_t s, UnifiedCache* cache, const LanePtrs* d_lanes, int32_t n_lanes,
@@ -207,7 +212,7 @@ extern "C" void IOComplete(legion_stream_t strm_hdl, LegionUnifiedCache* cache_,
         cache->CacheProfiling(memorypool->GetSampledIds(), memorypool->GetAggSrcId(), memorypool->GetAggDstId(),
                               memorypool->GetAggSrcOf(), memorypool->GetAggDstOf(), memorypool->GetNodeCounter(),
                               memorypool->GetEdgeCounter(), s, dev_id);
-    lg::launch_end_of_batch(s, memorypool->DeviceLane(), 1, memorypool->iter_state, memorypool->total_num_nodes);
+    lg::launch_end_of_batch(s, memorypool->DeviceLane(), 1, memorypool->iter_state, pool_state_bytes(memorypool));
 }
 
 // =============================================================================================
@@ -349,7 +354,7 @@ static void enqueue_lanes(hipStream_t s, GraphStorage* graph, FeatureStorage* fe
     if (is_presc && mode == TRAINMODE && cache != nullptr)     // CacheProfiling (one lane only in PreSC)
         cache->CacheProfiling(pool0->GetSampledIds(), pool0->GetAggSrcId(), pool0->GetAggDstId(), pool0->GetAggSrcOf(),
                               pool0->GetAggDstOf(), pool0->GetNodeCounter(), pool0->GetEdgeCounter(), s, dev_id);
-    lg::launch_end_of_batch(s, d_lanes, n_lanes, iter_state, pool0->total_num_nodes);
+    lg::launch_end_of_batch(s, d_lanes, n_lanes, iter_state, pool_state_bytes(pool0));
 }
 
 extern "C" void legion_enqueue_batch(legion_stream_t strm_hdl, LegionGraphStorage* graph, LegionFeatureStorage* feature,

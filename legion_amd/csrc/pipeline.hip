@@ -99,6 +99,7 @@ extern "C" LegionPipeline* legion_pipeline_create(LegionGraphStorage* graph, Leg
         if (prio < 0) p->gather_high = true;
     }
     p->slots.resize(p->slots_n);
+    lg_set_pool_lanes_hint(p->group_size * p->slots_n);   // direct-vs-table choice of the position state sees every lane
     for (Slot& sl : p->slots) {
         std::vector<LegionMemoryPool*> handles;
         for (int32_t g = 0; g < p->group_size; g++) {
@@ -125,6 +126,7 @@ extern "C" LegionPipeline* legion_pipeline_create(LegionGraphStorage* graph, Leg
         HIP_CALL(hipEventCreateWithFlags(&sl.done, hipEventDisableTiming));
         HIP_CALL(hipEventCreateWithFlags(&sl.sampled, hipEventDisableTiming));
     }
+    lg_set_pool_lanes_hint(0);
     return p;
 }
 

@@ -336,6 +336,9 @@ LanePtrs MemoryPool::HostLane(int32_t pipe) const
     h.agg_dst_off = agg_dst_off_[pipe];
     h.tmp_part_ind = tmp_part_ind_;
     h.position_map = position_map_;
+    h.pos_table = pos_table;
+    h.pos_table_mask = pos_table_mask;
+    h.err_flag = err_dev;
     h.node_counter = node_counter_[pipe];
     h.edge_counter = edge_counter_[pipe];
     h.slot_dst = slot_dst;
@@ -375,6 +378,10 @@ void MemoryPool::Finalize()
     d_lanes_ = nullptr;
     d_free_space(cache_search_buffer_);
     d_free_space(position_map_);
+    d_free_space(pos_table);
+    pos_table = nullptr;
+    if (err_host) HIP_CALL(hipHostFree(err_host));
+    err_host = err_dev = nullptr;
     d_free_space(agg_src_ids_);
     d_free_space(agg_dst_ids_);
     d_free_space(tmp_part_ind_);
@@ -408,6 +415,22 @@ void MemoryPool::Finalize()
     }
 }
 
+// ---- direct array or compact table for the position state (legion_core.h) ------------------------
+static thread_local int32_t g_pool_lanes_hint = 0;
+void lg_set_pool_lanes_hint(int32_t lanes) { g_pool_lanes_hint = lanes; }
+
+static bool lg_use_pos_table(int64_t total_num_nodes)
+{
+    if (const char* e = getenv("LEGION_DEDUP")) {
+        if (strcmp(e, "table") == 0) return true;
+        if (strcmp(e, "direct") == 0) return false;
+    }
+    size_t free_b = 0, total_b = 0;
+    HIP_CALL(hipMemGetInfo(&free_b, &total_b));
+    const int64_t lanes = g_pool_lanes_hint > 0 ? g_pool_lanes_hint : 1;
+    return total_num_nodes * 4 * lanes > (int64_t)(total_b / 4);
+}
+
 // server-private scratch of one GPU: SS/engine/server.cu:216-234 plus the compaction scratch
 void lg_pool_alloc_private(MemoryPool* mp, int32_t dev_id, int32_t total_num_nodes, int32_t batch_size,
                            const int32_t* fanout, int32_t hop_num, int32_t float_feature_len)
@@ -431,9 +454,29 @@ void lg_pool_alloc_private(MemoryPool* mp, int32_t dev_id, int32_t total_num_nod
     mp->batch_size = batch_size;
     mp->float_feature_len = float_feature_len;
     mp->SetCacheSearchBuffer((int32_t*)d_alloc_space(num_ids * sizeof(int32_t)));
-    int32_t* position_map = (int32_t*)d_alloc_space((int64_t)total_num_nodes * sizeof(int32_t));
-    HIP_CALL(hipMemset(position_map, 0xFF, (size_t)total_num_nodes * sizeof(int32_t)));   // every entry 'untouched'
-    mp->SetPositionMap(position_map);
+    if (lg_use_pos_table(total_num_nodes)) {
+        // compact form: at least 1.5 x the pool's worst-case id count, so a free word always exists
+        uint32_t bits = 10;
+        while (((int64_t)1 << bits) < num_ids + num_ids / 2) bits++;
+        if (const char* e = getenv("LEGION_POS_TABLE_BITS")) bits = (uint32_t)atoi(e);   // tests: force a crowded table
+        mp->pos_table_mask = (1u << bits) - 1u;
+        mp->pos_table = (unsigned long long*)d_alloc_space(((int64_t)1 << bits) * sizeof(unsigned long long));
+        HIP_CALL(hipMemset(mp->pos_table, 0xFF, ((size_t)1 << bits) * sizeof(unsigned long long)));
+        mp->SetPositionMap(nullptr);
+    } else {
+        int32_t* position_map = (int32_t*)d_alloc_space((int64_t)total_num_nodes * sizeof(int32_t));
+        HIP_CALL(hipMemset(position_map, 0xFF, (size_t)total_num_nodes * sizeof(int32_t)));   // every entry 'untouched'
+        mp->SetPositionMap(position_map);
+    }
+    {   // host-visible error word (kernels OR LG_ERR_* into it; reading it costs the host nothing)
+        void* h = nullptr;
+        void* dptr = nullptr;
+        HIP_CALL(hipHostMalloc(&h, 64, hipHostMallocMapped));
+        memset(h, 0, 64);
+        HIP_CALL(hipHostGetDevicePointer(&dptr, h, 0));
+        mp->err_host = (int32_t*)h;
+        mp->err_dev = (int32_t*)dptr;
+    }
     mp->SetAggSrcId((int32_t*)d_alloc_space(num_ids * sizeof(int32_t)));
     mp->SetAggDstId((int32_t*)d_alloc_space(num_ids * sizeof(int32_t)));
     mp->SetTmpPartIdx((char*)d_alloc_space(num_ids * sizeof(char)));
@@ -579,6 +622,28 @@ extern "C" void* legion_pool_buffer(LegionMemoryPool* p_, int32_t which)
         case 12: return mp->GetPositionMap();
         default: return nullptr;
     }
+}
+
+// LG_ERR_* bits raised by the kernels for this pool since it was created (0 = none); host-visible memory,
+// valid once the batch has completed
+extern "C" int32_t legion_pool_error(const LegionMemoryPool* p_)
+{
+    const MemoryPool* mp = reinterpret_cast<const MemoryPool*>(p_);
+    return mp ? mp->ErrorBits() : 0;
+}
+
+// 1 if the pool keeps its position state in the compact table form, 0 for the direct uint32[N] array
+extern "C" int32_t legion_pool_uses_table(const LegionMemoryPool* p_)
+{
+    const MemoryPool* mp = reinterpret_cast<const MemoryPool*>(p_);
+    return (mp && mp->pos_table != nullptr) ? 1 : 0;
+}
+
+extern "C" int64_t legion_pool_state_bytes(const LegionMemoryPool* p_)
+{
+    const MemoryPool* mp = reinterpret_cast<const MemoryPool*>(p_);
+    if (!mp) return 0;
+    return mp->pos_table ? ((int64_t)mp->pos_table_mask + 1) * 8 : (int64_t)mp->total_num_nodes * 4;
 }
 
 extern "C" void legion_pool_destroy(LegionMemoryPool* p_)

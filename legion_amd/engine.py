@@ -71,6 +71,23 @@ class PinnedArray:
         self.shape, self.dtype = array.shape, array.dtype
         ctypes.memmove(self.host_ptr, array.ctypes.data, array.nbytes)
 
+    @classmethod
+    def empty(cls, shape, dtype):
+        """Uninitialised mapped pinned array (fill it through .tensor(device) or .numpy())."""
+        self = cls.__new__(cls)
+        self._lib = _libmod.load()
+        self.shape, self.dtype = tuple(int(s) for s in shape), np.dtype(dtype)
+        nbytes = int(np.prod(self.shape, dtype=np.int64)) * self.dtype.itemsize
+        host = ctypes.c_void_p()
+        self.dev_ptr = self._lib.legion_host_alloc(nbytes, ctypes.byref(host))
+        self.host_ptr = host.value
+        return self
+
+    def numpy(self):
+        n = int(np.prod(self.shape, dtype=np.int64))
+        buf = (ctypes.c_char * (n * self.dtype.itemsize)).from_address(self.host_ptr)
+        return np.frombuffer(buf, dtype=self.dtype, count=n).reshape(self.shape)
+
     def tensor(self, device):
         tdt = {np.dtype(np.int32): torch.int32, np.dtype(np.int64): torch.int64, np.dtype(np.float32): torch.float32}[self.dtype]
         return device_view(self.dev_ptr, self.shape, tdt, device)
@@ -205,6 +222,17 @@ class MemoryPool:
         else:
             shape = (self.num_ids,)
         return device_view(ptr, shape, dtype, self.device)
+
+    def uses_table(self):
+        """True if the pool's first-touch/position state is the compact table form (LEGION_DEDUP)."""
+        return bool(self._lib.legion_pool_uses_table(self.handle))
+
+    def state_bytes(self):
+        return int(self._lib.legion_pool_state_bytes(self.handle))
+
+    def error(self):
+        """Sticky LG_ERR_* bits raised on the device for this pool (0 = none)."""
+        return int(self._lib.legion_pool_error(self.handle))
 
     def profile_begin(self, max_ops):
         self._lib.legion_pool_profile_begin(self.handle, int(max_ops))

@@ -141,6 +141,17 @@ def features_device(num_rows, dim, seed, device="cuda:0"):
     return out
 
 
+def features_device_rows(first_row, num_rows, dim, seed, device="cuda:0"):
+    """Rows first_row .. first_row+num_rows-1 of the same table (chunked generation of tables that do not live in HBM)."""
+    import torch
+    from . import lib as _libmod
+    lib = _libmod.load()
+    out = torch.empty((num_rows, dim), dtype=torch.float32, device=device)
+    stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    lib.legion_synth_features(stream, ctypes.c_void_p(out.data_ptr()), int(first_row), int(num_rows), dim, seed)
+    return out
+
+
 def feature_check_device(rows, ids, dim, seed):
     """Number of float32 words in `rows` that differ bitwise from the generator's value for ids."""
     import torch

@@ -33,3 +33,11 @@ def hip():
     assert torch.cuda.is_available(), "GPU tests need a GPU"
     assert L.legion_device_count() >= 1
     return L
+
+
+@pytest.fixture(params=["direct", "table"])
+def dedup(request, monkeypatch):
+    """Runs a GPU test once per form of the first-touch/position state (legion_core.h): the direct
+    uint32[N] array and the compact open-addressing table.  Both must give bit-identical batches."""
+    monkeypatch.setenv("LEGION_DEDUP", request.param)
+    return request.param

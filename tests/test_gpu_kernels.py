@@ -118,6 +118,9 @@ def test_synth_generators_match_numpy(hip):
     indptr, col = synth.rmat_csr_device(12, 8, 20231)
     ip, cl = synth.rmat_csr_numpy(12, 8, 20231)
     assert np.array_equal(indptr.cpu().numpy(), ip) and np.array_equal(col.cpu().numpy(), cl)
+    indptr, col = synth.rmat_csr_device(13, 4, 20231, scramble=True)          # Graph500-style label scrambling
+    ip, cl = synth.rmat_csr_numpy(13, 4, 20231, scramble=True)
+    assert np.array_equal(indptr.cpu().numpy(), ip) and np.array_equal(col.cpu().numpy(), cl)
     f = synth.features_device(3000, 100, 7)
     assert np.array_equal(f.cpu().numpy().view(np.uint32), synth.features_numpy(0, 3000, 100, 7).view(np.uint32))
     ids = torch.tensor([5, 17, -1, 2999], dtype=torch.int32).cuda()

@@ -18,9 +18,10 @@ pytestmark = pytest.mark.gpu
     (13, 8, [10, 10], 1024, 256),
     (10, 2, [1, 1, 1, 1], 32, 6),
 ])
-def test_serve_batches_no_cache(hip, scale, ef, fanout, batch, dim):
+def test_serve_batches_no_cache(hip, dedup, scale, ef, fanout, batch, dim):
     wl = Workload(scale=scale, edge_factor=ef, dim=dim)
     gpu, cpu = GpuSide(wl, batch, fanout), CpuSide(wl, batch, fanout)
+    assert gpu.pools[0].uses_table() == (dedup == "table")
     n_train = wl.sets[(0, 0)][0].size
     for mode, counters in ((0, range(min(3, (n_train - 1) // batch))), (1, range(2)), (2, range(1))):
         bs = batch if mode == 0 else min(batch, 100)
@@ -32,7 +33,7 @@ def test_serve_batches_no_cache(hip, scale, ef, fanout, batch, dim):
     gpu.close(); cpu.close()
 
 
-def test_partial_last_batch_and_empty(hip):
+def test_partial_last_batch_and_empty(hip, dedup):
     wl = Workload(scale=9, edge_factor=8, dim=8, n_seeds=100, n_valid=37, n_test=5)
     gpu, cpu = GpuSide(wl, 16, [4, 3]), CpuSide(wl, 16, [4, 3])
     for counter in (1, 2, 3):       # 37 ids, batch 16: full, partial (5, read at the reference's quirky offset), empty
@@ -43,7 +44,7 @@ def test_partial_last_batch_and_empty(hip):
 
 @pytest.mark.parametrize("P,mode_bits,capacity", [(1, 0, (300, 200)), (2, 1, (150, 90)), (4, 2, (64, 33)),
                                                   (4, 1, (100, 50)), (8, 3, (40, 20)), (3, 0, (77, 10))])
-def test_presc_cache_build_and_serve(hip, P, mode_bits, capacity):
+def test_presc_cache_build_and_serve(hip, dedup, P, mode_bits, capacity):
     """PreSC epoch -> hotness -> order -> maps/fills -> serving with hits, on P logical GPUs striped
     over cliques of 2^mode_bits (logical GPUs share the physical one on a 1-GPU box)."""
     wl = Workload(scale=11, edge_factor=8, dim=32, partition_count=P, n_seeds=1200)
@@ -168,7 +169,7 @@ def test_presc_topology_transactions_feed_cost_model(hip):
 @pytest.mark.parametrize("group,slots,use_graph,split", [(1, 1, True, False), (3, 2, True, False), (4, 2, False, False),
                                                          (2, 3, True, False), (8, 2, True, False), (3, 2, True, True),
                                                          (4, 2, False, True), (2, 3, True, True), (1, 1, True, True)])
-def test_pipeline_groups_and_graph_replay(hip, group, slots, use_graph, split):
+def test_pipeline_groups_and_graph_replay(hip, dedup, group, slots, use_graph, split):
     """Grouped launches (grid.y = lanes) + hipGraph replay produce exactly the batches the one-lane
     eager path does: every batch of a short run -- including the clamped last batch and the empty
     batches past the end of the set, whose sizes are computed on the device -- is compared with the
@@ -210,7 +211,7 @@ def test_pipeline_groups_and_graph_replay(hip, group, slots, use_graph, split):
     gpu.close(); cpu.close()
 
 
-def test_lane_group_eager(hip):
+def test_lane_group_eager(hip, dedup):
     """legion_enqueue_group on caller-owned pools (no pipeline, no graph)."""
     from legion_amd import engine
     wl = Workload(scale=10, edge_factor=8, dim=16, n_seeds=400)
@@ -231,7 +232,7 @@ def test_lane_group_eager(hip):
     gpu.close(); cpu.close()
 
 
-def test_epoch_wrap_of_position_state(hip, monkeypatch):
+def test_epoch_wrap_of_position_state(hip, dedup, monkeypatch):
     """The position state is never cleared between batches (epoch tag); with 8 epoch bits (23 value bits,
     forced here: a pool this small would get 15 epoch bits) the end-of-batch kernel refills it after 254
     batches on one lane.  600 consecutive batches (two wraps) stay bit-exact, eager and under graph replay."""
@@ -259,7 +260,7 @@ def test_epoch_wrap_of_position_state(hip, monkeypatch):
     gpu.close(); cpu.close()
 
 
-def test_wide_position_format(hip, monkeypatch):
+def test_wide_position_format(hip, dedup, monkeypatch):
     """Pools whose worst-case slot count needs more than 23 value bits switch to a wider value field
     and a shorter epoch field (28 bits -> 6 epochs between refills).  Forced here through
     LEGION_POS_VALUE_BITS on a small pool: 40 batches cross the refill six times and stay bit-exact."""
@@ -272,6 +273,32 @@ def test_wide_position_format(hip, monkeypatch):
         for it in range(40):
             compare_batches(gpu.run(0, it % 60, 0), cpu.run(0, it % 60, 0), f"vb={bits} batch {it}: ")
         gpu.close(); cpu.close()
+
+
+def test_crowded_position_table(hip, monkeypatch):
+    """The compact table under pressure: forced down to 2^10 words for batches of up to ~950 distinct vertices
+    (load up to 0.93), so that claims walk long probe runs and displaced words are carried far.  Still bit-exact,
+    no error raised; with a table smaller than a batch the kernels raise LG_ERR_TABLE_FULL instead of hanging."""
+    monkeypatch.setenv("LEGION_DEDUP", "table")
+    monkeypatch.setenv("LEGION_POS_TABLE_BITS", "10")
+    wl = Workload(scale=14, edge_factor=8, dim=4, n_seeds=3000)
+    fanout, batch = [5, 3], 160
+    gpu, cpu = GpuSide(wl, batch, fanout), CpuSide(wl, batch, fanout)
+    assert gpu.pools[0].uses_table() and gpu.pools[0].state_bytes() == 1024 * 8
+    most = 0
+    for it in range(12):
+        g, c = gpu.run(0, it, 0), cpu.run(0, it, 0)
+        compare_batches(g, c, f"crowded table batch {it}: ")
+        most = max(most, g["sampled_ids"].size)
+    assert 850 < most < 1024 and gpu.pools[0].error() == 0
+    gpu.close(); cpu.close()
+    monkeypatch.setenv("LEGION_POS_TABLE_BITS", "9")             # 512 words < a batch's vertices
+    gpu = GpuSide(wl, batch, fanout)
+    from legion_amd import engine
+    engine.enqueue_batch(None, gpu.graph, gpu.feature, gpu.cache, gpu.pools[0], batch, 0, 0, 0, False, fanout)
+    torch.cuda.synchronize()
+    assert gpu.pools[0].error() & 1
+    gpu.close()
 
 
 def test_pipeline_partial_group(hip):
