@@ -43,7 +43,8 @@ static std::string ipc_suffix()
 static int sharedMemoryCreate(const char* name, size_t sz, sharedMemoryInfo* info)
 {
     info->size = sz;
-    info->shmFd = shm_open(name, O_RDWR | O_CREAT, 0777);
+    shm_unlink(name);   // the server owns the name and starts first: never inherit a crashed run's slab
+    info->shmFd = shm_open(name, O_RDWR | O_CREAT | O_EXCL, 0777);
     if (info->shmFd < 0) return errno;
     if (ftruncate(info->shmFd, sz) != 0) return errno;
     info->addr = mmap(0, sz, PROT_READ | PROT_WRITE, MAP_SHARED, info->shmFd, 0);
@@ -162,12 +163,17 @@ public:
 
             const std::string ssri = "sem_r_" + std::to_string(device_id) + "_" + std::to_string(i) + sfx;
             const std::string sswi = "sem_w_" + std::to_string(device_id) + "_" + std::to_string(i) + sfx;
-            semr_[device_id][i] = sem_open(ssri.c_str(), O_CREAT | O_RDWR, 0666, 0);
+            // a crashed run (every HIP error path exits without Finalize) leaves semaphores with counts behind; a stale
+            // sem_r count would let this server overwrite a buffer the trainer still reads, a stale sem_w count would
+            // hand the trainer a batch that was never produced.  The server owns the names and starts first.
+            sem_unlink(ssri.c_str());
+            sem_unlink(sswi.c_str());
+            semr_[device_id][i] = sem_open(ssri.c_str(), O_CREAT | O_EXCL | O_RDWR, 0666, 0);
             if (semr_[device_id][i] == SEM_FAILED) {
                 printf("errno = %d\n", errno);
                 return;
             }
-            semw_[device_id][i] = sem_open(sswi.c_str(), O_CREAT | O_RDWR, 0666, 0);
+            semw_[device_id][i] = sem_open(sswi.c_str(), O_CREAT | O_EXCL | O_RDWR, 0666, 0);
             if (semw_[device_id][i] == SEM_FAILED) {
                 printf("errno = %d\n", errno);
                 return;

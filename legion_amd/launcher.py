@@ -100,8 +100,12 @@ def Run(args):
         cache_agg_mode = cache_agg_mode_for(group_size)
     else:
         cache_agg_mode = 0
-    fanout = " ".join(str(f) for f in parse_fanout(args.fanout))
-    return os.system("{} {} {} {}".format(server_binary(), gpu_number, int(cache_agg_mode), fanout))
+    # The reference ignores the binary's status (legion_server.py:110).  Here it is returned as a process exit
+    # code: subprocess.call gives the exit status itself (os.system's raw wait status, e.g. 256 for exit(1),
+    # would wrap to 0 in sys.exit), and a death by signal n becomes 128 + n like a shell reports it.
+    rc = subprocess.call([server_binary(), str(gpu_number), str(int(cache_agg_mode))] +
+                         [str(f) for f in parse_fanout(args.fanout)])
+    return 128 - rc if rc < 0 else rc
 
 
 def parse_fanout(value):

@@ -132,6 +132,7 @@ def test_config3_shape_full_size_striped_clique(hip):
     N = 1 << scale
     dev = torch.device("cuda:0")
     indptr, col = synth.rmat_csr_device(scale, 16, 20231, dev, scramble=True)
+    torch.cuda.empty_cache()
     feats = synth.features_device(N, D, 7, dev)
     seeds = synth.seed_ids(N, N // 4, 11)
     graph, feature = engine.GraphStorage(P, indptr, col), engine.FeatureStorage(P, feats)
@@ -183,6 +184,7 @@ def test_config4_shape_2pow28_vertices(hip):
     N = 1 << scale
     dev = torch.device("cuda:0")
     indptr, col = synth.rmat_csr_device(scale, 4, 20231, dev, scramble=True)
+    torch.cuda.empty_cache()
     assert int(indptr[-1]) == N * 4 and int(col.max()) < N and int(col.max()) >= N // 2
     feats = synth.features_device(N, D, 7, dev)                          # 137 GB
     seeds = synth.seed_ids(N, 400_000, 11)
@@ -232,6 +234,7 @@ def test_config2_shape_full_size_pinned_spill(hip):
     N = 1 << scale
     dev = torch.device("cuda:0")
     indptr_d, col_d = synth.rmat_csr_device(scale, 8, 20231, dev, scramble=True)
+    torch.cuda.empty_cache()
     p_indptr = engine.PinnedArray.empty((N + 1,), np.int64)
     p_col = engine.PinnedArray.empty((int(col_d.numel()),), np.int32)
     p_feat = engine.PinnedArray.empty((N, D), np.float32)

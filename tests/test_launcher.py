@@ -49,3 +49,26 @@ def test_cli_defaults_match_reference():
     a = launcher.build_argparser().parse_args([])
     assert (a.dataset_path, a.dataset_name, a.train_batch_size, a.gpu_number, a.epoch, a.cache_memory, a.usenvlink) == \
         ("./dataset", "ukunion", 8000, 2, 2, 38000000, 1)
+
+
+def test_failing_server_gives_nonzero_exit(tmp_path, monkeypatch):
+    """A sampling_server that exits with EXIT_FAILURE (every HIP error, a missing meta_config ...) or dies by a
+    signal must not look like success to whoever started legion_server.py."""
+    import stat
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for body, want in (("exit 1", 1), ("exit 0", 0), ("kill -9 $$", 137)):
+        fake = tmp_path / "fake_server"
+        fake.write_text("#!/bin/sh\n" + body + "\n")
+        fake.chmod(fake.stat().st_mode | stat.S_IEXEC)
+        monkeypatch.setattr(launcher, "server_binary", lambda f=str(fake): f)
+        monkeypatch.chdir(tmp_path)
+        args = launcher.build_argparser().parse_args(["--dataset_name", "products", "--usenvlink", "0", "--fanout", "25,10"])
+        assert launcher.Run(args) == want
+    # and end to end through legion_server.py's sys.exit
+    code = ("import sys; sys.path.insert(0, %r); from legion_amd import launcher; "
+            "launcher.server_binary = lambda: %r; sys.exit(launcher.main(['--dataset_name','products','--usenvlink','0']))")
+    fake.write_text("#!/bin/sh\nexit 1\n")
+    rc = subprocess.call([sys.executable, "-c", code % (root, str(fake))], cwd=tmp_path)
+    assert rc == 1
