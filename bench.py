@@ -50,6 +50,12 @@ def parse_args():
     ap.add_argument("--min-seconds", type=float, default=1.5,
                     help="repeat the K-step timed region until this much time has been measured (median reported)")
     ap.add_argument("--max-repeats", type=int, default=400)
+    ap.add_argument("--dedup", type=str, default="auto", choices=["auto", "direct", "table"],
+                    help="form of the per-lane first-touch/position state: direct uint32[N] array, compact open-addressing "
+                         "table, or auto (table when the arrays of all lanes in flight would exceed a quarter of HBM)")
+    ap.add_argument("--placement", type=str, default="hbm", choices=["hbm", "pinned"],
+                    help="pinned: full CSR and full feature table in mapped pinned host memory (the reference's only tier; "
+                         "BASELINE configs[2]): cache hits come from HBM, misses are read in place over PCIe")
     ap.add_argument("--scramble", action="store_true",
                     help="Graph500-style label scrambling of the RMAT vertices (hubs no longer sit at the low ids)")
     ap.add_argument("--scale", type=int, default=26)
@@ -129,8 +135,24 @@ def main():
     t_setup = time.time()
 
     # ---- workload, resident in HBM --------------------------------------------------------------
+    if args.dedup != "auto":
+        os.environ["LEGION_DEDUP"] = args.dedup
     indptr, col = synth.rmat_csr_device(args.scale, args.edge_factor, 20231, dev, scramble=args.scramble)
-    features = synth.features_device(N, D, 7, dev)
+    torch.cuda.empty_cache()
+    pinned = []
+    if args.placement == "pinned":
+        # generate on the device, park in mapped pinned host memory; the device copies of the CSR stay for the checks
+        indptr_hbm, col_hbm = indptr, col
+        pinned = [engine.PinnedArray.empty((N + 1,), np.int64), engine.PinnedArray.empty((int(col.numel()),), np.int32),
+                  engine.PinnedArray.empty((N, D), np.float32)]
+        indptr, col, features = (p.tensor(dev) for p in pinned)
+        indptr.copy_(indptr_hbm)
+        col.copy_(col_hbm)
+        for r0 in range(0, N, 1 << 22):
+            features[r0:r0 + (1 << 22)].copy_(synth.features_device_rows(r0, min(1 << 22, N - r0), D, 7, dev))
+        torch.cuda.synchronize()
+    else:
+        features = synth.features_device(N, D, 7, dev)
     need = (n_warm + n_timed + 2) * B * world + B
     need = max(need, (args.presc_steps + 2) * B * world)
     all_seeds = synth.seed_ids(N, min(max(need * 2, N // 10), N), 11)
@@ -196,6 +218,8 @@ def main():
     hop_edges = np.zeros((n_timed, H), dtype=np.int64)
     hop_slots = np.zeros((n_timed, H), dtype=np.int64)
     hits = 0
+    node_map = cache.array("node_map", d) if cache.node_capacity(d) > 0 else torch.empty(0, dtype=torch.int32, device=dev)
+    feat_hit_rows = feat_miss_rows = 0           # over every timed batch (all hops)
     for k in range(n_timed):
         if k % G == 0:
             slot = pipe.submit(first + k)
@@ -205,6 +229,10 @@ def main():
         ec = pl.buffer("edge_counter").cpu().numpy()
         edges[k] = ec[9 + H]
         rows[k, 0] = nc[9]
+        if node_map.numel() > 0 and (args.placement == "pinned" or k < G):
+            hm = node_map[pl.buffer("sampled_ids")[:int(nc[9 + H])].long()] >= 0
+            feat_hit_rows += int(hm.sum())
+            feat_miss_rows += int(hm.numel() - int(hm.sum()))
         for h in range(H):
             rows[k, h + 1] = nc[9 + h + 1] - nc[9 + h]
             hop_edges[k, h] = ec[9 + h + 1] - ec[9 + h]
@@ -340,7 +368,10 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "int32+f32(copy)", "data": "synthetic",
             "config": {"workload": f"RMAT-{args.scale} EF{args.edge_factor} (N={N}, E={N * args.edge_factor}), "
-                                   f"float32[N x {D}] features, batch {B}, fanout {fanout}, all tables resident in HBM"
+                                   f"float32[N x {D}] features, batch {B}, fanout {fanout}, " +
+                                   ("all tables resident in HBM" if args.placement == "hbm" else
+                                    "full CSR + full feature table in mapped pinned host memory (read over PCIe on a miss), "
+                                    "hotness-ranked feature/topology caches in HBM")
                                    + (", vertex labels scrambled" if args.scramble else ""),
                        "parallelism": (f"seed-sharded x{world}, replicated graph+features, one clique of {world}: caches "
                                        f"striped over the ranks, peer reads over xGMI (cache_agg_mode {int(np.log2(world))})")
@@ -371,7 +402,19 @@ def main():
                                      "hipGraph replay, timed region: %.4f)"
                                      % (H, args.steps, G, elapsed_profiled / args.steps * 1e3, elapsed_max / args.steps * 1e3)},
             "setup_seconds": setup_s,
+            "position_state": {"form": "table" if pipe.pools[0][0].uses_table() else "direct",
+                               "bytes_per_lane": pipe.pools[0][0].state_bytes(), "lanes": G * args.slots},
+            "feature_cache_hit_rate": feat_hit_rows / max(feat_hit_rows + feat_miss_rows, 1),
+            "feature_cache_hit_rate_over": "every timed batch" if args.placement == "pinned" else "the first timed step",
         }
+        if args.placement == "pinned":
+            miss_frac = feat_miss_rows / max(feat_hit_rows + feat_miss_rows, 1)
+            miss_gbps = float(rows.sum() * D * 4) * miss_frac / t_all_gathers / 1e9 if t_all_gathers > 0 else 0.0
+            out["miss_path"] = {"feature_rows_missed_frac": miss_frac, "pcie_feature_GBps": miss_gbps,
+                                "pcie_peak_GBps": 64.0, "frac_of_pcie_peak": miss_gbps / 64.0,
+                                "note": "missed rows x D x 4 bytes / HIP-event time of all gather launches (hits are served from "
+                                        "HBM inside the same launches); PCIe Gen5 x16 = 64 GB/s per direction; topology misses "
+                                        "(4-byte column reads) cross the same link during the sampler kernels"}
         if args.cpu_seconds > 0 and world == 1:      # reported at N = 1 only
             out["cpu_baseline"] = cpu_baseline(indptr, col, mine, N, B, fanout, first, args.cpu_seconds)
         json_out.write(json.dumps(out) + "\n")

@@ -18,15 +18,27 @@
 #include <unistd.h>
 
 #include <cerrno>
+#include <cstddef>
 #include <cstring>
 #include <iostream>
 
 static_assert(sizeof(hipIpcMemHandle_t) == 64, "IPC handle size is part of the wire format");
 
+// The reference's slab (SS/engine/ipc_service.cu:28-31) is the PREFIX of this one, byte for byte: a trainer
+// built from the reference maps only that prefix.  Behind it this build publishes, per (device, pipe slot), the
+// 16 + 16 counters of the batch in that slot in HOST memory: the slab is registered with HIP and the GPU writes
+// them itself, so the trainer end needs no device-to-host copy per batch (the reference does two blocking
+// 64-byte cudaMemcpy per get_next, TB/ipc_cuda_kernel.cu:186-187).
+#define LEGION_SHM_EXT_MAGIC 0x4C47494F   /* "LGIO" */
 typedef struct shmStruct_st {
     int32_t steps[3];
     hipIpcMemHandle_t memHandle[MAX_DEVICE][INTERBATCH_CON][MEMORY_USAGE];
+    int32_t ext_magic;                                         // LEGION_SHM_EXT_MAGIC once the mirror below is live
+    int32_t ext_reserved[3];
+    int32_t counters[MAX_DEVICE][INTERBATCH_CON][32];          // [0..15] node_counter, [16..31] edge_counter
 } shmStruct;
+static_assert(offsetof(shmStruct, memHandle) == 12 && offsetof(shmStruct, ext_magic) == 12 + MAX_DEVICE * INTERBATCH_CON * MEMORY_USAGE * 64,
+              "the reference's slab layout is the wire format");
 
 typedef struct sharedMemoryInfo_st {
     void* addr;
@@ -74,6 +86,18 @@ public:
             }
             shm_ = (volatile shmStruct*)info_.addr;
             memset((void*)shm_, 0, sizeof(*shm_));
+            // let the GPUs write the per-slot counter mirror straight into the slab
+            if (!getenv("LEGION_NO_SHM_MIRROR") &&
+                hipHostRegister(info_.addr, sizeof(shmStruct), hipHostRegisterPortable | hipHostRegisterMapped) == hipSuccess) {
+                void* dptr = nullptr;
+                if (hipHostGetDevicePointer(&dptr, info_.addr, 0) == hipSuccess && dptr != nullptr) {
+                    shm_dev_ = (shmStruct*)dptr;
+                    registered_ = true;
+                } else {
+                    (void)hipHostUnregister(info_.addr);
+                }
+            }
+            (void)hipGetLastError();
         } else {
             local_ = new shmStruct();
             memset(local_, 0, sizeof(*local_));
@@ -236,6 +260,15 @@ public:
     int32_t* GetNodeCounter(int32_t d, int32_t p) override { return (int32_t*)node_counter_[d][p % pipeline_depth_]; }
     int32_t* GetEdgeCounter(int32_t d, int32_t p) override { return (int32_t*)edge_counter_[d][p % pipeline_depth_]; }
 
+    // device address of the host-visible counter mirror of (device, pipe slot), or null when the slab could not be
+    // registered (then the trainer end falls back to copying the counters from the device buffers)
+    int32_t* GetCounterMirror(int32_t d, int32_t p) override
+    {
+        return shm_dev_ ? &shm_dev_->counters[d][p % pipeline_depth_][0] : nullptr;
+    }
+    void PublishMirror() override { if (shm_dev_) shm_->ext_magic = LEGION_SHM_EXT_MAGIC; }
+    bool IPCTryWait(int32_t dev_id, int32_t current_pipe) override { return sem_trywait(semr_[dev_id][current_pipe]) == 0; }
+
     void IPCPost(int32_t dev_id, int32_t current_pipe) override { sem_post(semw_[dev_id][current_pipe]); }
     void IPCWait(int32_t dev_id, int32_t current_pipe) override { sem_wait(semr_[dev_id][current_pipe]); }
 
@@ -267,6 +300,9 @@ public:
             delete local_;
             local_ = nullptr;
         } else {
+            if (registered_) (void)hipHostUnregister(info_.addr);
+            registered_ = false;
+            shm_dev_ = nullptr;
             sharedMemoryClose(&info_);
             if (!shm_name_.empty()) shm_unlink(shm_name_.c_str());
         }
@@ -277,6 +313,8 @@ public:
 
 private:
     volatile shmStruct* shm_ = nullptr;
+    shmStruct* shm_dev_ = nullptr;      // the slab as the GPUs see it (registered host memory)
+    bool registered_ = false;
     shmStruct* local_ = nullptr;
     sharedMemoryInfo info_;
     std::string shm_name_;

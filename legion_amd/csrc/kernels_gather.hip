@@ -141,6 +141,55 @@ void launch_gather(hipStream_t s, const GatherParams& g, const LanePtrs* d_lanes
     launch_gather_impl(s, g, d_lanes, n_lanes, true);
 }
 
+// ------------------------------------------------------------------------------------------
+// Hand-over of a finished mini-batch from a lane of a launch group to one of the two trainer-visible pipe
+// slots (SS/engine/ipc_service.cu:134-211: ids, labels, agg_src, agg_dst, node_counter, edge_counter; the
+// feature rows are gathered straight into the slot by gather_kernel).  Sizes come from the lane's counters on
+// the device.  The counters also go to the slot's host-visible mirror (ipc_env.hip), with node_counter[2..3]
+// already holding what the last gather op leaves there (counter_update(op%3==1), operator_impl.cu:83-85).
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void deliver_kernel(const LanePtrs* __restrict__ lane_p, DeliverParams d)
+{
+    const LanePtrs& L = *lane_p;
+    const LG_G int32_t* nc = LG_GPTR(const int32_t, L.node_counter);
+    const LG_G int32_t* ec = LG_GPTR(const int32_t, L.edge_counter);
+    const LG_G int32_t* hs = LG_GPTR(const int32_t, L.hop_scratch);
+    const int32_t hop_num = nc[INTRABATCH_CON * 3 - 1];
+    int32_t n = nc[INTRABATCH_CON * 3 + hop_num], e = ec[INTRABATCH_CON * 3 + hop_num], b = nc[INTRABATCH_CON * 3];
+    n = n < 0 ? 0 : (n > d.num_ids ? d.num_ids : n);
+    e = e < 0 ? 0 : (e > d.num_ids ? d.num_ids : e);
+    b = b < 0 ? 0 : (b > d.batch_cap ? d.batch_cap : b);
+    const int32_t gid = blockIdx.x * blockDim.x + threadIdx.x, gsz = gridDim.x * blockDim.x;
+    typedef int32_t v4 __attribute__((ext_vector_type(4)));
+    auto copy = [&](const int32_t* src, int32_t* dst, int32_t count) {
+        const LG_G v4* s4 = (const LG_G v4*)src;
+        LG_G v4* d4 = (LG_G v4*)dst;
+        const int32_t q = count >> 2;
+        for (int32_t i = gid; i < q; i += gsz) d4[i] = s4[i];
+        for (int32_t i = (q << 2) + gid; i < count; i += gsz) LG_GPTR(int32_t, dst)[i] = LG_GPTR(const int32_t, src)[i];
+    };
+    copy(L.sampled_ids, d.sampled_ids, n);
+    copy(L.agg_src_off, d.agg_src_off, e);
+    copy(L.agg_dst_off, d.agg_dst_off, e);
+    copy(L.labels, d.labels, b);
+    if (gid < 32) {
+        int32_t v = gid < 16 ? nc[gid] : ec[gid - 16];
+        if (gid == 2) v = hs[HS_RANGE + 2 * hop_num];
+        if (gid == 3) v = hs[HS_RANGE + 2 * hop_num + 1];
+        LG_GPTR(int32_t, gid < 16 ? d.node_counter : d.edge_counter)[gid & 15] = v;
+        if (d.mirror != nullptr) LG_GPTR(int32_t, d.mirror)[gid] = v;      // host memory: visible once the batch's event completed
+    }
+}
+
+void launch_deliver(hipStream_t s, const LanePtrs* d_lane, const DeliverParams& d)
+{
+    int32_t grid = (d.num_ids / 4 + 255) / 256;
+    if (grid > 512) grid = 512;
+    if (grid < 1) grid = 1;
+    deliver_kernel<<<grid, 256, 0, s>>>(d_lane, d);
+    hipCheckError();
+}
+
 // stand-alone form (tests, probes): explicit arrays; a one-lane descriptor is staged on the stream
 void launch_gather_explicit(hipStream_t s, const GatherParams& g, const int32_t* sampled_ids,
                             int32_t* cache_index_out, const int32_t* range, float* dst, int32_t dst_rows)

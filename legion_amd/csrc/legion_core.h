@@ -476,6 +476,10 @@ public:
     virtual int32_t* GetEdgeCounter(int32_t dev_id, int32_t current_pipe) = 0;
     virtual void IPCPost(int32_t dev_id, int32_t current_pipe) = 0;
     virtual void IPCWait(int32_t dev_id, int32_t current_pipe) = 0;
+    // new in this build (see ipc_env.hip): host-visible per-slot counter mirror written by the GPU, non-blocking wait
+    virtual int32_t* GetCounterMirror(int32_t dev_id, int32_t current_pipe) = 0;
+    virtual void PublishMirror() = 0;
+    virtual bool IPCTryWait(int32_t dev_id, int32_t current_pipe) = 0;
     virtual void Finalize() = 0;
     virtual int32_t GetTrainStep() = 0;
 };
@@ -588,6 +592,15 @@ struct GatherParams {
                                     // sampled_ids); == hop for a plain single-op gather
 };
 void launch_gather(hipStream_t s, const GatherParams& g, const LanePtrs* d_lanes, int32_t n_lanes);
+// hand-over of a lane's finished batch to a trainer-visible pipe slot (kernels_gather.hip)
+struct DeliverParams {
+    int32_t* sampled_ids; int32_t* labels; int32_t* agg_src_off; int32_t* agg_dst_off;   // the slot's buffers
+    int32_t* node_counter; int32_t* edge_counter;
+    int32_t* mirror;          // device address of the slot's host-visible counter mirror [32], or null
+    int32_t num_ids;          // capacity of the id / edge arrays
+    int32_t batch_cap;        // capacity of labels
+};
+void launch_deliver(hipStream_t s, const LanePtrs* d_lane, const DeliverParams& d);
 // stand-alone form for tests / probes: explicit arrays, one lane
 void launch_gather_explicit(hipStream_t s, const GatherParams& g, const int32_t* sampled_ids,
                             int32_t* cache_index_out, const int32_t* range, float* dst, int32_t dst_rows);
