@@ -74,6 +74,9 @@ def parse_args():
     ap.add_argument("--split", action="store_true",
                     help="sampler phase and gather phase of every group on two streams (sampler k+1 under gathers k)")
     ap.add_argument("--no-verify", action="store_true")
+    ap.add_argument("--no-boundary", action="store_true",
+                    help="skip the drop-in boundary leg (sampling_server binary -> shm/semaphores/IPC handles -> ipc_service "
+                         "consumer on an RMAT-22 data set written in the reference's file formats; N = 1 only, ~15 s)")
     ap.add_argument("--measured-counters", action="store_true",
                     help="feed the cost model with the topology transactions the sampler counted during PreSC "
                          "(default: {0,0} as the reference's v2 does)")
@@ -415,6 +418,8 @@ def main():
                                 "note": "missed rows x D x 4 bytes / HIP-event time of all gather launches (hits are served from "
                                         "HBM inside the same launches); PCIe Gen5 x16 = 64 GB/s per direction; topology misses "
                                         "(4-byte column reads) cross the same link during the sampler kernels"}
+        if world == 1 and not args.no_boundary and args.placement == "hbm":
+            out.update(boundary_leg(args, fanout))
         if args.cpu_seconds > 0 and world == 1:      # reported at N = 1 only
             out["cpu_baseline"] = cpu_baseline(indptr, col, mine, N, B, fanout, first, args.cpu_seconds)
         json_out.write(json.dumps(out) + "\n")
@@ -422,6 +427,25 @@ def main():
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def boundary_leg(args, fanout):
+    """The same kernels behind the reference's own server <-> trainer protocol (tools/server_throughput.py): the
+    `sampling_server` binary serving a Python `ipc_service` consumer one mini-batch per semaphore hand-off into one of two
+    pipe slots.  Reported beside the headline, never as `value`."""
+    import subprocess
+    cmd = [sys.executable, os.path.join(ROOT, "tools", "server_throughput.py"), "--scale", str(min(args.scale, 22)),
+           "--batch", str(args.batch), "--dim", str(args.dim), "--fanout", ",".join(str(f) for f in fanout),
+           "--train-batches", str(max(64, min(3000, (3 << 20) // args.batch)))]
+    try:
+        res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+        line = [ln for ln in res.stdout.splitlines() if ln.startswith("{")][-1]
+        r = json.loads(line)
+        return {"boundary_batches_per_sec": r["batches_per_sec"], "boundary_edges_per_sec": r["edges_per_sec"],
+                "boundary": {"path": r["path"], "workload": r["workload"], "ms_per_batch": r["ms_per_batch"],
+                             "timed_batches": r["timed_batches"]}}
+    except Exception as e:            # the headline must not depend on this leg
+        return {"boundary_batches_per_sec": None, "boundary": {"error": repr(e)[:300]}}
 
 
 def cpu_baseline(indptr, col, seeds, N, B, fanout, first_batch, target_s):

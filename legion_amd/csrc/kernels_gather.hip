@@ -18,6 +18,7 @@
 // Roofline: HBM.  Algorithmic bytes per row = 8*D + 8 (D*4 read + D*4 written + id + index).
 #include "legion_core.h"
 
+#include <cstdlib>
 #include <cstring>
 
 namespace lg {
@@ -25,6 +26,63 @@ namespace lg {
 #define LG_GATHER_ROWS 64
 #define LG_GATHER_THREADS 256
 #define LG_GATHER_UNROLL 4
+
+// ------------------------------------------------------------------------------------------
+// Hand-over of a finished mini-batch from a lane of a launch group to one of the two trainer-visible pipe
+// slots (SS/engine/ipc_service.cu:134-211: ids, labels, agg_src, agg_dst, node_counter, edge_counter; the
+// feature rows are gathered straight into the slot by gather_kernel).  Sizes come from the lane's counters on
+// the device.  The counters also go to the slot's host-visible mirror (ipc_env.hip), with node_counter[2..3]
+// already holding what the last gather op leaves there (counter_update(op%3==1), operator_impl.cu:83-85).
+// ------------------------------------------------------------------------------------------
+// slice `part` of `parts` of the hand-over, done by one workgroup (all of it when parts == 1)
+__device__ __forceinline__ void deliver_slice(const LanePtrs& L, const DeliverParams& d, int32_t part, int32_t parts)
+{
+    const LG_G int32_t* nc = LG_GPTR(const int32_t, L.node_counter);
+    const LG_G int32_t* ec = LG_GPTR(const int32_t, L.edge_counter);
+    const LG_G int32_t* hs = LG_GPTR(const int32_t, L.hop_scratch);
+    const int32_t hop_num = nc[INTRABATCH_CON * 3 - 1];
+    int32_t n = nc[INTRABATCH_CON * 3 + hop_num], e = ec[INTRABATCH_CON * 3 + hop_num], b = nc[INTRABATCH_CON * 3];
+    n = n < 0 ? 0 : (n > d.num_ids ? d.num_ids : n);
+    e = e < 0 ? 0 : (e > d.num_ids ? d.num_ids : e);
+    b = b < 0 ? 0 : (b > d.batch_cap ? d.batch_cap : b);
+    const int32_t tid = threadIdx.x, nthr = blockDim.x;
+    typedef int32_t v4 __attribute__((ext_vector_type(4)));
+    auto copy = [&](const int32_t* src, int32_t* dst, int32_t count) {
+        const int32_t per = (((count + parts - 1) / parts) + 3) & ~3;     // slices start 16-byte aligned
+        const int32_t lo = part * per, hi = min(lo + per, count);
+        if (lo >= hi) return;
+        const LG_G v4* s4 = (const LG_G v4*)(src + lo);
+        LG_G v4* d4 = (LG_G v4*)(dst + lo);
+        const int32_t q = (hi - lo) >> 2;
+        for (int32_t i = tid; i < q; i += nthr) d4[i] = s4[i];
+        for (int32_t i = lo + (q << 2) + tid; i < hi; i += nthr) LG_GPTR(int32_t, dst)[i] = LG_GPTR(const int32_t, src)[i];
+    };
+    copy(L.sampled_ids, d.sampled_ids, n);
+    copy(L.agg_src_off, d.agg_src_off, e);
+    copy(L.agg_dst_off, d.agg_dst_off, e);
+    copy(L.labels, d.labels, b);
+    if (part == 0 && tid < 32) {
+        int32_t v = tid < 16 ? nc[tid] : ec[tid - 16];
+        if (tid == 2) v = hs[HS_RANGE + 2 * hop_num];
+        if (tid == 3) v = hs[HS_RANGE + 2 * hop_num + 1];
+        LG_GPTR(int32_t, tid < 16 ? d.node_counter : d.edge_counter)[tid & 15] = v;
+        if (d.mirror != nullptr) LG_GPTR(int32_t, d.mirror)[tid] = v;      // host memory: visible once the batch's event completed
+    }
+}
+
+__global__ __launch_bounds__(256) void deliver_kernel(const LanePtrs* __restrict__ lane_p, DeliverParams d)
+{
+    deliver_slice(*lane_p, d, blockIdx.x, gridDim.x);
+}
+
+void launch_deliver(hipStream_t s, const LanePtrs* d_lane, const DeliverParams& d)
+{
+    int32_t grid = (d.num_ids / 4 + 1023) / 1024;
+    if (grid > 512) grid = 512;
+    if (grid < 1) grid = 1;
+    deliver_kernel<<<grid, 256, 0, s>>>(d_lane, d);
+    hipCheckError();
+}
 
 template <typename VecT, int ROWS = LG_GATHER_ROWS, int UNROLL = LG_GATHER_UNROLL>
 __global__ __launch_bounds__(LG_GATHER_THREADS) void gather_kernel(GatherParams gp, const LanePtrs* __restrict__ lanes,
@@ -58,6 +116,10 @@ __global__ __launch_bounds__(LG_GATHER_THREADS) void gather_kernel(GatherParams 
         }
     }
     const int32_t ntiles = (rows + ROWS - 1) / ROWS;
+    if (L.deliver != nullptr) {      // this lane's gather also hands the batch over to a pipe slot: every active workgroup a slice
+        const int32_t parts = ntiles > 0 ? ntiles : 1;
+        if ((int32_t)blockIdx.x < parts) deliver_slice(L, *static_cast<const DeliverParams*>(L.deliver), blockIdx.x, parts);
+    }
     const int32_t tid = threadIdx.x;
     const int32_t D = gp.D;
     const int32_t C = D / VEC;                         // chunks per row
@@ -127,7 +189,14 @@ static void launch_gather_impl(hipStream_t s, GatherParams g, const LanePtrs* d_
     const dim3 grid((g.max_rows + LG_GATHER_ROWS - 1) / LG_GATHER_ROWS, n_lanes);
     typedef float v4 __attribute__((ext_vector_type(4)));
     typedef float v2 __attribute__((ext_vector_type(2)));
-    if (g.D % 4 == 0)
+    // a launch of one or a few lanes (the Runner's per-batch hand-over) has too few 64-row tiles to keep 256 CUs
+    // busy: 16-row tiles give it 4 x the workgroups (a full lane group is indifferent to the tile size)
+    constexpr int kSmallRows = 16;
+    const int env_small = [] { const char* e = getenv("LEGION_GATHER_SMALL_TILES"); return e ? atoi(e) : 1; }();
+    if (g.D % 4 == 0 && env_small && (int64_t)grid.x * n_lanes < 4096) {
+        const dim3 grid_s((g.max_rows + kSmallRows - 1) / kSmallRows, n_lanes);
+        gather_kernel<v4, kSmallRows><<<grid_s, LG_GATHER_THREADS, 0, s>>>(g, d_lanes, copy_range);
+    } else if (g.D % 4 == 0)
         gather_kernel<v4><<<grid, LG_GATHER_THREADS, 0, s>>>(g, d_lanes, copy_range);
     else if (g.D % 2 == 0)
         gather_kernel<v2><<<grid, LG_GATHER_THREADS, 0, s>>>(g, d_lanes, copy_range);
@@ -139,55 +208,6 @@ static void launch_gather_impl(hipStream_t s, GatherParams g, const LanePtrs* d_
 void launch_gather(hipStream_t s, const GatherParams& g, const LanePtrs* d_lanes, int32_t n_lanes)
 {
     launch_gather_impl(s, g, d_lanes, n_lanes, true);
-}
-
-// ------------------------------------------------------------------------------------------
-// Hand-over of a finished mini-batch from a lane of a launch group to one of the two trainer-visible pipe
-// slots (SS/engine/ipc_service.cu:134-211: ids, labels, agg_src, agg_dst, node_counter, edge_counter; the
-// feature rows are gathered straight into the slot by gather_kernel).  Sizes come from the lane's counters on
-// the device.  The counters also go to the slot's host-visible mirror (ipc_env.hip), with node_counter[2..3]
-// already holding what the last gather op leaves there (counter_update(op%3==1), operator_impl.cu:83-85).
-// ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void deliver_kernel(const LanePtrs* __restrict__ lane_p, DeliverParams d)
-{
-    const LanePtrs& L = *lane_p;
-    const LG_G int32_t* nc = LG_GPTR(const int32_t, L.node_counter);
-    const LG_G int32_t* ec = LG_GPTR(const int32_t, L.edge_counter);
-    const LG_G int32_t* hs = LG_GPTR(const int32_t, L.hop_scratch);
-    const int32_t hop_num = nc[INTRABATCH_CON * 3 - 1];
-    int32_t n = nc[INTRABATCH_CON * 3 + hop_num], e = ec[INTRABATCH_CON * 3 + hop_num], b = nc[INTRABATCH_CON * 3];
-    n = n < 0 ? 0 : (n > d.num_ids ? d.num_ids : n);
-    e = e < 0 ? 0 : (e > d.num_ids ? d.num_ids : e);
-    b = b < 0 ? 0 : (b > d.batch_cap ? d.batch_cap : b);
-    const int32_t gid = blockIdx.x * blockDim.x + threadIdx.x, gsz = gridDim.x * blockDim.x;
-    typedef int32_t v4 __attribute__((ext_vector_type(4)));
-    auto copy = [&](const int32_t* src, int32_t* dst, int32_t count) {
-        const LG_G v4* s4 = (const LG_G v4*)src;
-        LG_G v4* d4 = (LG_G v4*)dst;
-        const int32_t q = count >> 2;
-        for (int32_t i = gid; i < q; i += gsz) d4[i] = s4[i];
-        for (int32_t i = (q << 2) + gid; i < count; i += gsz) LG_GPTR(int32_t, dst)[i] = LG_GPTR(const int32_t, src)[i];
-    };
-    copy(L.sampled_ids, d.sampled_ids, n);
-    copy(L.agg_src_off, d.agg_src_off, e);
-    copy(L.agg_dst_off, d.agg_dst_off, e);
-    copy(L.labels, d.labels, b);
-    if (gid < 32) {
-        int32_t v = gid < 16 ? nc[gid] : ec[gid - 16];
-        if (gid == 2) v = hs[HS_RANGE + 2 * hop_num];
-        if (gid == 3) v = hs[HS_RANGE + 2 * hop_num + 1];
-        LG_GPTR(int32_t, gid < 16 ? d.node_counter : d.edge_counter)[gid & 15] = v;
-        if (d.mirror != nullptr) LG_GPTR(int32_t, d.mirror)[gid] = v;      // host memory: visible once the batch's event completed
-    }
-}
-
-void launch_deliver(hipStream_t s, const LanePtrs* d_lane, const DeliverParams& d)
-{
-    int32_t grid = (d.num_ids / 4 + 255) / 256;
-    if (grid > 512) grid = 512;
-    if (grid < 1) grid = 1;
-    deliver_kernel<<<grid, 256, 0, s>>>(d_lane, d);
-    hipCheckError();
 }
 
 // stand-alone form (tests, probes): explicit arrays; a one-lane descriptor is staged on the stream

@@ -192,6 +192,8 @@ struct LanePtrs {
     unsigned long long* pos_table;     // table form: uint64[pos_table_mask + 1]; null in direct form
     uint32_t pos_table_mask;
     int32_t* err_flag;                 // mapped pinned host word: kernels OR LG_ERR_* bits into it
+    const void* deliver;               // lg::DeliverParams* (device) or null: the gather of this lane also hands its batch
+                                       // over to that trainer-visible pipe slot (GPURunner's hand-over descriptors)
     int32_t* node_counter;
     int32_t* edge_counter;
     int32_t* slot_dst;
@@ -578,6 +580,15 @@ struct HopParams {                  // what every lane of a launch shares
 };
 void launch_random_sample(hipStream_t s, const HopParams& p, const LanePtrs* d_lanes, int32_t n_lanes, bool table_form);
 
+// hand-over of a lane's finished batch to a trainer-visible pipe slot (kernels_gather.hip)
+struct DeliverParams {
+    int32_t* sampled_ids; int32_t* labels; int32_t* agg_src_off; int32_t* agg_dst_off;   // the slot's buffers
+    int32_t* node_counter; int32_t* edge_counter;
+    int32_t* mirror;          // device address of the slot's host-visible counter mirror [32], or null
+    int32_t num_ids;          // capacity of the id / edge arrays
+    int32_t batch_cap;        // capacity of labels
+};
+
 struct GatherParams {
     const float* full_table;
     const float* const* cache_tables;
@@ -592,14 +603,6 @@ struct GatherParams {
                                     // sampled_ids); == hop for a plain single-op gather
 };
 void launch_gather(hipStream_t s, const GatherParams& g, const LanePtrs* d_lanes, int32_t n_lanes);
-// hand-over of a lane's finished batch to a trainer-visible pipe slot (kernels_gather.hip)
-struct DeliverParams {
-    int32_t* sampled_ids; int32_t* labels; int32_t* agg_src_off; int32_t* agg_dst_off;   // the slot's buffers
-    int32_t* node_counter; int32_t* edge_counter;
-    int32_t* mirror;          // device address of the slot's host-visible counter mirror [32], or null
-    int32_t num_ids;          // capacity of the id / edge arrays
-    int32_t batch_cap;        // capacity of labels
-};
 void launch_deliver(hipStream_t s, const LanePtrs* d_lane, const DeliverParams& d);
 // stand-alone form for tests / probes: explicit arrays, one lane
 void launch_gather_explicit(hipStream_t s, const GatherParams& g, const int32_t* sampled_ids,

@@ -60,6 +60,8 @@ struct LegionPipeline {
     bool use_graph;
     bool overlap = false;   // let kernels of different slots run concurrently (default: chained)
     bool split = false;     // sampler and gather phases on two streams (see the header comment)
+    bool sample_only = false;   // only the sampler phase runs here; the owner gathers each lane itself (GPURunner: straight
+                                // into a trainer-visible pipe slot)
     hipStream_t sample_stream = nullptr;
     bool gather_high = false;
     int32_t rr = 0;
@@ -88,6 +90,8 @@ extern "C" LegionPipeline* legion_pipeline_create(LegionGraphStorage* graph, Leg
     p->use_graph = (use_graph & 1) != 0;
     p->overlap = (use_graph & 2) != 0;
     p->split = (use_graph & 4) != 0;
+    p->sample_only = (use_graph & 8) != 0;
+    if (p->sample_only) p->split = false;
     if (p->split) p->overlap = false;
     SetGPUDevice(dev_id);
     if (p->split) {
@@ -151,17 +155,25 @@ static void slot_wait(LegionPipeline* p, Slot& sl)
 // and returns the slot index.  The slot's previous group must have been consumed: this call waits
 // for its completion first.
 extern "C" int32_t legion_pipeline_submit_n(LegionPipeline* p, int32_t counter0, int32_t mode, int32_t n_active);
+extern "C" int32_t legion_pipeline_submit_ex(LegionPipeline* p, int32_t counter0, int32_t mode, int32_t n_active, int32_t batch_size);
 extern "C" int32_t legion_pipeline_submit(LegionPipeline* p, int32_t counter0, int32_t mode)
 {
     return legion_pipeline_submit_n(p, counter0, mode, p ? p->group_size : 0);
 }
+extern "C" int32_t legion_pipeline_submit_n(LegionPipeline* p, int32_t counter0, int32_t mode, int32_t n_active)
+{
+    return legion_pipeline_submit_ex(p, counter0, mode, n_active, p ? p->batch_size : 0);
+}
+extern "C" legion_stream_t legion_pipeline_stream(LegionPipeline* p) { return p ? (legion_stream_t)p->slots[0].stream : nullptr; }
 
 // Same with only the first n_active lanes of the group working (the tail of a run whose length is
-// not a multiple of the group size).
-extern "C" int32_t legion_pipeline_submit_n(LegionPipeline* p, int32_t counter0, int32_t mode, int32_t n_active)
+// not a multiple of the group size) and an explicit batch size (validation / test batches differ from
+// training batches, SS/engine/ipc_service.cu:91-115; never larger than the pools were created for).
+extern "C" int32_t legion_pipeline_submit_ex(LegionPipeline* p, int32_t counter0, int32_t mode, int32_t n_active, int32_t batch_size)
 {
     if (!p) { printf("invalid pipeline ptr\n"); return -1; }
     if (n_active < 1 || n_active > p->group_size) n_active = p->group_size;
+    if (batch_size < 1 || batch_size > p->batch_size) batch_size = p->batch_size;
     SetGPUDevice(p->dev_id);
     const int32_t si = p->rr;
     p->rr = (p->rr + 1) % p->slots_n;
@@ -182,15 +194,15 @@ extern "C" int32_t legion_pipeline_submit_n(LegionPipeline* p, int32_t counter0,
     LegionFeatureStorage* f = reinterpret_cast<LegionFeatureStorage*>(p->feature);
     // split mode: phase 1 on the sampler stream, phase 2 on the slot's (gather) stream behind it
     hipStream_t s1 = p->split ? p->sample_stream : sl.stream;
-    const int32_t first_phase = p->split ? LG_PHASE_SAMPLE : LG_PHASE_ALL;
+    const int32_t first_phase = (p->split || p->sample_only) ? LG_PHASE_SAMPLE : LG_PHASE_ALL;
     if (!p->use_graph || p->profiling) {            // HIP cannot time events recorded by graph nodes
         legion_group_set_iter_state(sl.group, nullptr);     // eager: iteration by value
-        legion_enqueue_group_phase(s1, gr, f, p->cache_handle, sl.group, n_active, p->batch_size, counter0,
+        legion_enqueue_group_phase(s1, gr, f, p->cache_handle, sl.group, n_active, batch_size, counter0,
                                    p->dev_id, mode, p->fanout.data(), p->hop_num, first_phase);
         if (p->split) {
             HIP_CALL(hipEventRecord(sl.sampled, s1));
             HIP_CALL(hipStreamWaitEvent(sl.stream, sl.sampled, 0));
-            legion_enqueue_group_phase(sl.stream, gr, f, p->cache_handle, sl.group, n_active, p->batch_size, counter0,
+            legion_enqueue_group_phase(sl.stream, gr, f, p->cache_handle, sl.group, n_active, batch_size, counter0,
                                        p->dev_id, mode, p->fanout.data(), p->hop_num, LG_PHASE_GATHER);
         }
         sl.next_iter = -1;
@@ -204,14 +216,14 @@ extern "C" int32_t legion_pipeline_submit_n(LegionPipeline* p, int32_t counter0,
         }
         auto exec_of = [&](hipStream_t strm, int32_t phase) {
             const int64_t key = ((int64_t)phase << 48) | ((int64_t)mode << 40) | ((int64_t)n_active << 32) |
-                                (uint32_t)p->batch_size;
+                                (uint32_t)batch_size;
             auto it = sl.exec.find(key);
             if (it == sl.exec.end()) {
                 hipGraph_t graph = nullptr;
                 hipGraphExec_t exec = nullptr;
                 HIP_CALL(hipStreamSynchronize(strm));
                 HIP_CALL(hipStreamBeginCapture(strm, hipStreamCaptureModeThreadLocal));
-                legion_enqueue_group_phase(strm, gr, f, p->cache_handle, sl.group, n_active, p->batch_size, counter0,
+                legion_enqueue_group_phase(strm, gr, f, p->cache_handle, sl.group, n_active, batch_size, counter0,
                                            p->dev_id, mode, p->fanout.data(), p->hop_num, phase);
                 HIP_CALL(hipStreamEndCapture(strm, &graph));
                 HIP_CALL(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));

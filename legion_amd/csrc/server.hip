@@ -21,6 +21,7 @@
 
 #include <algorithm>
 #include <chrono>
+#include <atomic>
 #include <cstring>
 #include <map>
 #include <fstream>
@@ -264,10 +265,15 @@ private:
 };
 
 // =============================================================================================
-extern "C" void legion_enqueue_batch(legion_stream_t strm_hdl, LegionGraphStorage* graph, LegionFeatureStorage* feature,
-                                     LegionUnifiedCache* cache, LegionMemoryPool* memorypool, int32_t batch_size,
-                                     int32_t counter, int32_t dev_id, int32_t mode, bool is_presc,
-                                     const int32_t* fanout, int32_t hop_num);
+struct LegionPipeline;
+extern "C" LegionPipeline* legion_pipeline_create(LegionGraphStorage* graph, LegionFeatureStorage* feature,
+                                                  LegionUnifiedCache* cache, int32_t dev_id, int32_t batch_size,
+                                                  const int32_t* fanout, int32_t hop_num, int32_t group_size,
+                                                  int32_t slots, int64_t feature_rows, int32_t use_graph);
+extern "C" int32_t legion_pipeline_submit_ex(LegionPipeline* p, int32_t counter0, int32_t mode, int32_t n_active, int32_t batch_size);
+extern "C" legion_stream_t legion_pipeline_stream(LegionPipeline* p);
+extern "C" LegionMemoryPool* legion_pipeline_pool(LegionPipeline* p, int32_t slot, int32_t lane);
+extern "C" void legion_pipeline_destroy(LegionPipeline* p);
 
 class GPURunner : public Runner {
 public:
@@ -363,6 +369,8 @@ public:
         for (int i = 0; i < interbatch_concurrency_; i++)
             memorypool_->SetFloatFeatures(env->GetFloatFeatures(local_dev_id_, i), i);
         memorypool_->feature_rows = num_ids;
+        // from here on every batch's counters are also written to the slab's host-visible mirror (lane-group path)
+        if (use_groups_ && env->GetCounterMirror(local_dev_id_, 0) != nullptr) env->PublishMirror();
     }
 
     // SS/engine/server.cu:285-300
@@ -378,100 +386,231 @@ public:
         HIP_CALL(hipEventSynchronize(op_params_[op_num_ - 1]->event));
     }
 
-    // SS/engine/server.cu:302-332
+    // SS/engine/server.cu:302-332.  The reference produces ONE mini-batch per call, ~16 launches and three blocking
+    // read-backs each.  Here a call hands ONE batch over (same semaphores, same two pipe slots, same order), but the
+    // batches are PRODUCED in launch groups: the sampler phase of G consecutive batches runs as one hipGraph replay
+    // over G internal lanes (pipeline.hip, grid.y = G); per call the lane's ids / edges / labels / counters are copied
+    // into the free pipe slot and its feature rows are gathered straight into the slot's buffer (two launches).  A
+    // poster thread waits for the batch's event and posts it, so this thread never blocks on the GPU and a finished
+    // batch never waits for the trainer to release another slot.  LEGION_RUNNER_GRAPH=0: the operator-by-operator
+    // path of the reference (one batch per call, eager launches).
     void RunOnce(RunnerParams* params) override
     {
         SetGPUDevice(local_dev_id_);
         IPCEnv* env = (IPCEnv*)(params->env);
         const int32_t batch_id = params->global_batch_id;
-        mode_ = env->GetCurrentMode(batch_id);
-        memorypool_->SetCurrentMode(mode_);
-        memorypool_->SetIter(env->GetLocalBatchId(batch_id));
-        if (use_graph_ && pending_pipe_ >= 0 && hipEventQuery(batch_done_[pending_pipe_]) == hipSuccess)
-            FlushPending(env);                              // already finished: do not make the trainer wait for our wait
-        env->IPCWait(local_dev_id_, current_pipe_);
-        if (use_graph_) {
-            // the batch is only enqueued here; the previous one (other pipe slot) is handed over meanwhile
-            RunOnceGraph(params, env->GetLocalBatchId(batch_id), (int32_t)env->GetCurrentBatchsize(local_dev_id_, mode_));
-            FlushPending(env);
-            pending_pipe_ = current_pipe_;
-            if (batch_id % 1000 == 0 && local_dev_id_ == 0) std::cout << "batch id: " << batch_id << "\n";
-            current_pipe_ = (current_pipe_ + 1) % interbatch_concurrency_;
-            memorypool_->SetCurrentPipe(current_pipe_);
-            return;
-        } else {
+        if (!use_groups_) {
+            mode_ = env->GetCurrentMode(batch_id);
+            memorypool_->SetCurrentMode(mode_);
+            memorypool_->SetIter(env->GetLocalBatchId(batch_id));
+            env->IPCWait(local_dev_id_, current_pipe_);
             for (int i = 0; i < op_num_; i++) {
                 op_params_[i]->is_presc = false;
                 op_factory_[i]->run(op_params_[i]);
             }
             HIP_CALL(hipEventSynchronize(op_params_[op_num_ - 1]->event));   // every op is on this stream
+            ReportErrors(memorypool_);
+            env->IPCPost(local_dev_id_, current_pipe_);
+            if (batch_id % 1000 == 0 && local_dev_id_ == 0) std::cout << "batch id: " << batch_id << "\n";
+            current_pipe_ = (current_pipe_ + 1) % interbatch_concurrency_;
+            memorypool_->SetCurrentPipe(current_pipe_);
+            return;
         }
-        env->IPCPost(local_dev_id_, current_pipe_);
+        if (pipe_ == nullptr) CreateGroups(params);
+        if (pair_pending_) {                       // this batch went out together with the previous one (one launch, both slots)
+            pair_pending_ = false;
+            if (batch_id % 1000 == 0 && local_dev_id_ == 0) std::cout << "batch id: " << batch_id << "\n";
+            current_pipe_ = (current_pipe_ + 1) % interbatch_concurrency_;
+            return;
+        }
+        if (cur_slot_ < 0 || batch_id >= cur_first_ + cur_n_) {           // this call opens a new group
+            if (next_slot_ >= 0 && next_first_ == batch_id) {
+                cur_slot_ = next_slot_; cur_first_ = next_first_; cur_n_ = next_n_;
+                next_slot_ = -1;
+            } else {
+                SubmitGroup(env, batch_id, cur_slot_, cur_first_, cur_n_);
+            }
+        }
+        const int32_t lane = batch_id - cur_first_;
+        // the next group's sampler is queued while this group is still being handed over: the GPU never idles
+        // between groups, and by the time its first batch is due it has long finished
+        if (next_slot_ < 0 && lane >= cur_n_ / 2 && cur_first_ + cur_n_ < max_step_)
+            SubmitGroup(env, cur_first_ + cur_n_, next_slot_, next_first_, next_n_);
+        const auto t_a = std::chrono::steady_clock::now();
+        const int p = current_pipe_, p2 = (p + 1) % interbatch_concurrency_;
+        {   // the trainer has released this slot?  Poll for a short while (a futex wake costs more than a small batch's
+            // GPU time) before blocking
+            bool got = false;
+            for (int spin = 0; spin < 20000 && !got; spin++) got = env->IPCTryWait(local_dev_id_, p);
+            if (!got) env->IPCWait(local_dev_id_, p);
+        }
+        // A hand-over launch of one small batch is latency-bound (~18 us for 31 k rows, against 5.5 us per batch inside a
+        // 128-lane launch): when the next batch belongs to this group and ITS slot is free too, one launch serves both
+        int32_t n_out = 1;
+        if (pair_ && lane + 1 < cur_n_ && env->IPCTryWait(local_dev_id_, p2)) n_out = 2;
+        const auto t_b = std::chrono::steady_clock::now();
+        hipStream_t s = static_cast<hipStream_t>(legion_pipeline_stream(pipe_));
+        const int par = (p + lane) % interbatch_concurrency_;           // pipe of lane g = (par + g) % 2
+        const LanePtrs* desc = d_desc_ + ((size_t)par * 2 + cur_slot_) * lanes_ + lane;
+        UnifiedCache* cache = (UnifiedCache*)(params->cache);
+        const int64_t max_rows = std::min<int64_t>(memorypool_->feature_rows, memorypool_->num_ids);
+        if (float_feature_len_ > 0 && max_rows > 0)   // one launch: gather of every row of the batch(es) + the hand-over copies
+            cache->FeatCacheLookup(desc, n_out, INTRABATCH_CON * hop_num_ + 1, local_dev_id_, s, (int32_t)max_rows, true, 1);
+        else
+            for (int k = 0; k < n_out; k++) lg::launch_deliver(s, desc + k, deliver_[(p + k) % interbatch_concurrency_]);
+        for (int k = 0; k < n_out; k++) {
+            const int pk = (p + k) % interbatch_concurrency_;
+            HIP_CALL(hipEventRecord(batch_done_[pk], s));
+            // single producer (this thread), single consumer (the poster): at most INTERBATCH_CON jobs are outstanding
+            // (a slot is only reused after the trainer released it, i.e. after its previous job was posted)
+            const uint32_t t = q_tail_.load(std::memory_order_relaxed);
+            ring_[t % kRing] = {batch_done_[pk], pk, reinterpret_cast<MemoryPool*>(legion_pipeline_pool(pipe_, cur_slot_, lane + k)),
+                                std::chrono::steady_clock::now()};
+            q_tail_.store(t + 1, std::memory_order_release);
+        }
+        pair_pending_ = n_out == 2;
+        if (stats_) {
+            const auto t_c = std::chrono::steady_clock::now();
+            st_wait_ += std::chrono::duration<double>(t_b - t_a).count();
+            st_launch_ += std::chrono::duration<double>(t_c - t_b).count();
+            st_n_++;
+            st_pairs_ += n_out == 2;
+        }
         if (batch_id % 1000 == 0 && local_dev_id_ == 0) std::cout << "batch id: " << batch_id << "\n";
         current_pipe_ = (current_pipe_ + 1) % interbatch_concurrency_;
-        memorypool_->SetCurrentPipe(current_pipe_);
-    }
-
-    // The op list of one batch (the same kernels the operators launch, in the same order) captured once
-    // per (pipe slot, mode) into a hipGraph; the iteration is a device word written before every replay.
-    // One replay costs one launch instead of ~16 launches + 16 event records (LEGION_RUNNER_GRAPH=0: eager).
-    void RunOnceGraph(RunnerParams* params, int32_t local_batch_id, int32_t batch_size)
-    {
-        hipStream_t s = streams_[0];
-        if (d_iter_ == nullptr) {
-            d_iter_ = (int32_t*)d_alloc_space(2 * sizeof(int32_t));
-            HIP_CALL(hipHostMalloc((void**)&h_iter_, 2 * INTERBATCH_CON * sizeof(int32_t), hipHostMallocDefault));
-            for (int i = 0; i < INTERBATCH_CON; i++) HIP_CALL(hipEventCreateWithFlags(&batch_done_[i], hipEventDisableTiming));
-        }
-        int32_t* h = h_iter_ + 2 * current_pipe_;           // one staging pair per pipe slot: the copy is asynchronous
-        h[0] = local_batch_id;
-        h[1] = 0;                                           // the host positions the iteration every time
-        HIP_CALL(hipMemcpyAsync(d_iter_, h, 2 * sizeof(int32_t), hipMemcpyHostToDevice, s));
-        memorypool_->iter_state = d_iter_;
-        const int key = current_pipe_ * 4 + mode_;
-        auto it = graphs_.find(key);
-        if (it == graphs_.end()) {
-            std::vector<int32_t> fanout(params->fanout.begin(), params->fanout.end());
-            hipGraph_t graph = nullptr;
-            hipGraphExec_t exec = nullptr;
-            (void)memorypool_->DeviceLane();                // uploads the lane descriptors if they changed: not inside a capture
-            HIP_CALL(hipStreamSynchronize(s));
-            HIP_CALL(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
-            legion_enqueue_batch(s, (LegionGraphStorage*)params->graph, (LegionFeatureStorage*)params->feature,
-                                 (LegionUnifiedCache*)params->cache, (LegionMemoryPool*)memorypool_, batch_size,
-                                 local_batch_id, local_dev_id_, mode_, false, fanout.data(), (int32_t)fanout.size());
-            HIP_CALL(hipStreamEndCapture(s, &graph));
-            HIP_CALL(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
-            HIP_CALL(hipGraphDestroy(graph));
-            it = graphs_.emplace(key, exec).first;
-        }
-        HIP_CALL(hipGraphLaunch(it->second, s));
-        HIP_CALL(hipEventRecord(batch_done_[current_pipe_], s));
-        memorypool_->iter_state = nullptr;
-    }
-
-    // hands the batch enqueued by the previous RunOnce to the trainer once the GPU has finished it; by then
-    // the next batch is already queued behind it on the same stream (they share the scratch arrays, the
-    // trainer-visible buffers are per pipe slot)
-    void FlushPending(IPCEnv* env)
-    {
-        if (pending_pipe_ < 0) return;
-        HIP_CALL(hipEventSynchronize(batch_done_[pending_pipe_]));
-        env->IPCPost(local_dev_id_, pending_pipe_);
-        pending_pipe_ = -1;
     }
 
     void Finalize(RunnerParams* params) override
     {
         IPCEnv* env = (IPCEnv*)(params->env);
         SetGPUDevice(local_dev_id_);
-        FlushPending(env);
+        if (poster_.joinable()) {
+            stop_.store(true, std::memory_order_release);
+            poster_.join();                                                // every queued batch has been posted
+        }
         env->IPCWait(local_dev_id_, (current_pipe_ + 1) % interbatch_concurrency_);
         SetGPUDevice(local_dev_id_);
+        if (stats_ && st_n_ > 0)   // LEGION_RUNNER_STATS=1: where a hand-over's time goes, averages per batch
+            std::cout << "runner " << local_dev_id_ << ": " << st_n_ << " hand-over launches (" << st_pairs_ << " of two batches); waiting for a free slot " << st_wait_ / st_n_ * 1e6
+                      << " us, launch calls " << st_launch_ / st_n_ * 1e6 << " us, enqueue -> completion seen "
+                      << st_gpu_ / st_n_ * 1e6 << " us\n";
+        if (pipe_) {
+            legion_pipeline_destroy(pipe_);
+            pipe_ = nullptr;
+            d_free_space(d_desc_);
+            d_desc_ = nullptr;
+            d_free_space(d_deliver_);
+            d_deliver_ = nullptr;
+        }
         memorypool_->Finalize();
     }
 
 private:
+    struct Pending { hipEvent_t ev; int pipe; MemoryPool* lane; std::chrono::steady_clock::time_point enqueued; };
+
+    void ReportErrors(MemoryPool* mp)
+    {
+        const int32_t bits = mp->ErrorBits() & ~reported_;
+        if (bits == 0) return;
+        reported_ |= bits;
+        if (bits & LG_ERR_FEATURE_ROWS)
+            std::cout << "WARNING (gpu " << local_dev_id_ << "): a batch has more rows than the feature buffer ("
+                      << memorypool_->feature_rows << " rows = 1.2 x the PreSC maximum); its tail rows were not gathered\n";
+        if (bits & LG_ERR_TABLE_FULL) std::cout << "ERROR (gpu " << local_dev_id_ << "): position table overflow\n";
+        if (bits & LG_ERR_CHAIN) std::cout << "ERROR (gpu " << local_dev_id_ << "): unresolved first-touch chain\n";
+        std::cout << std::flush;
+    }
+
+    // G internal lanes x 2 groups in flight + the hand-over descriptors of every (group slot, lane, pipe slot)
+    void CreateGroups(RunnerParams* params)
+    {
+        IPCEnv* env = (IPCEnv*)(params->env);
+        hop_num_ = (int32_t)params->fanout.size();
+        max_step_ = env->GetMaxStep();
+        std::vector<int32_t> fanout(params->fanout.begin(), params->fanout.end());
+        lanes_ = std::max(1, std::min(128, 131072 / std::max(1, memorypool_->batch_size)));
+        if (const char* e = getenv("LEGION_RUNNER_LANES")) lanes_ = std::max(1, atoi(e));
+        // use_graph bits: 1 graph replay, 8 sampler phase only (the gathers go straight into the pipe slots)
+        pipe_ = legion_pipeline_create((LegionGraphStorage*)params->graph, (LegionFeatureStorage*)params->feature,
+                                       (LegionUnifiedCache*)params->cache, local_dev_id_, memorypool_->batch_size,
+                                       fanout.data(), hop_num_, lanes_, 2, 0, 1 | 8);
+        for (int p = 0; p < interbatch_concurrency_; p++) {
+            lg::DeliverParams& d = deliver_[p];
+            d.sampled_ids = env->GetIds(local_dev_id_, p);
+            d.labels = env->GetLabels(local_dev_id_, p);
+            d.agg_src_off = env->GetAggSrc(local_dev_id_, p);
+            d.agg_dst_off = env->GetAggDst(local_dev_id_, p);
+            d.node_counter = env->GetNodeCounter(local_dev_id_, p);
+            d.edge_counter = env->GetEdgeCounter(local_dev_id_, p);
+            d.mirror = env->GetCounterMirror(local_dev_id_, p);
+            d.num_ids = memorypool_->num_ids;
+            d.batch_cap = memorypool_->batch_size;
+            HIP_CALL(hipEventCreateWithFlags(&batch_done_[p], hipEventDisableTiming));
+        }
+        d_deliver_ = (lg::DeliverParams*)d_alloc_space(sizeof(deliver_));
+        HIP_CALL(hipMemcpy(d_deliver_, deliver_, sizeof(deliver_), hipMemcpyHostToDevice));
+        // hand-over descriptors [parity][group slot][lane]: the lane's own buffers as the source, the pipe slot
+        // (parity + lane) % 2 as the destination -- consecutive lanes alternate pipe slots like consecutive batches do,
+        // so two consecutive batches can be handed over by ONE launch (grid.y = 2) when both slots are free
+        std::vector<LanePtrs> h((size_t)interbatch_concurrency_ * 2 * lanes_);
+        for (int par = 0; par < interbatch_concurrency_; par++)
+            for (int sl = 0; sl < 2; sl++)
+                for (int g = 0; g < lanes_; g++) {
+                    MemoryPool* lp = reinterpret_cast<MemoryPool*>(legion_pipeline_pool(pipe_, sl, g));
+                    const int p = (par + g) % interbatch_concurrency_;
+                    LanePtrs d = lp->HostLane(0);
+                    d.float_features = env->GetFloatFeatures(local_dev_id_, p);
+                    d.feature_rows = (int32_t)std::min<int64_t>(memorypool_->feature_rows, memorypool_->num_ids);
+                    d.deliver = d_deliver_ + p;
+                    // counters stay the lane's: deliver_slice reads them there and writes the slot's (incl. [2..3])
+                    h[((size_t)par * 2 + sl) * lanes_ + g] = d;
+                }
+        d_desc_ = (LanePtrs*)d_alloc_space((int64_t)h.size() * sizeof(LanePtrs));
+        HIP_CALL(hipMemcpy(d_desc_, h.data(), h.size() * sizeof(LanePtrs), hipMemcpyHostToDevice));
+        poster_ = std::thread([this, env] {
+            // The poster polls (the reference's runner thread polls cudaEventQuery the same way, server.cu:319-324): one core
+            // per GPU buys a hand-over latency of about a microsecond instead of a condition-variable wake-up.
+            // (Measured and rejected, tools/micro/stream_wait_probe.hip + LEGION_RUNNER_STATS: queueing the hand-over ahead
+            // behind hipStreamWaitValue32 and signalling completion with hipStreamWriteValue32 -- 36 k batches/s against
+            // 44 k with events at B = 1024.)
+            SetGPUDevice(local_dev_id_);
+            uint32_t head = 0;
+            for (uint32_t idle = 0;;) {
+                if (q_tail_.load(std::memory_order_acquire) == head) {
+                    if (stop_.load(std::memory_order_acquire) && q_tail_.load(std::memory_order_acquire) == head) return;
+                    if ((++idle & 4095) == 0) std::this_thread::yield();
+                    continue;
+                }
+                const Pending job = ring_[head % kRing];
+                const hipError_t q = hipEventQuery(job.ev);
+                if (q == hipErrorNotReady) continue;
+                if (q != hipSuccess) {
+                    printf("HIP failure %s:%d: '%s'\n", __FILE__, __LINE__, hipGetErrorString(q));
+                    exit(EXIT_FAILURE);
+                }
+                if (stats_) st_gpu_ += std::chrono::duration<double>(std::chrono::steady_clock::now() - job.enqueued).count();
+                ReportErrors(job.lane);
+                env->IPCPost(local_dev_id_, job.pipe);
+                head++;
+                idle = 0;
+            }
+        });
+    }
+
+    // plans and enqueues the sampler phase of the group that starts at global batch `first`: consecutive batches of
+    // one mode with consecutive local ids (ipc_service.cu:213-253), at most `lanes_`
+    void SubmitGroup(IPCEnv* env, int32_t first, int& slot_out, int32_t& first_out, int32_t& n_out)
+    {
+        const int32_t mode = env->GetCurrentMode(first), local0 = env->GetLocalBatchId(first);
+        int32_t n = 1;
+        while (n < lanes_ && first + n < max_step_ && env->GetCurrentMode(first + n) == mode &&
+               env->GetLocalBatchId(first + n) == local0 + n)
+            n++;
+        slot_out = legion_pipeline_submit_ex(pipe_, local0, mode, n, env->GetCurrentBatchsize(local_dev_id_, mode));
+        first_out = first;
+        n_out = n;
+    }
+
     int32_t num_ids_ = 0;
     int32_t float_feature_len_ = 0;
     MemoryPool* memorypool_ = nullptr;
@@ -484,12 +623,28 @@ private:
     std::vector<hipEvent_t> events_;
     std::vector<Operator*> op_factory_;
     std::vector<OpParams*> op_params_;
-    bool use_graph_ = [] { const char* e = getenv("LEGION_RUNNER_GRAPH"); return e == nullptr || atoi(e) != 0; }();
-    std::map<int, hipGraphExec_t> graphs_;    // key: pipe slot * 4 + mode
-    int32_t* d_iter_ = nullptr;
-    int32_t* h_iter_ = nullptr;
+    bool use_groups_ = [] { const char* e = getenv("LEGION_RUNNER_GRAPH"); return e == nullptr || atoi(e) != 0; }();
+    // lane groups
+    LegionPipeline* pipe_ = nullptr;
+    int32_t lanes_ = 1, hop_num_ = 0, max_step_ = 0;
+    LanePtrs* d_desc_ = nullptr;
+    lg::DeliverParams deliver_[INTERBATCH_CON] = {};
+    lg::DeliverParams* d_deliver_ = nullptr;
     hipEvent_t batch_done_[INTERBATCH_CON] = {};
-    int pending_pipe_ = -1;                   // pipe slot whose batch is enqueued but not yet handed over
+    int cur_slot_ = -1, next_slot_ = -1;
+    int32_t cur_first_ = 0, cur_n_ = 0, next_first_ = 0, next_n_ = 0;
+    int32_t reported_ = 0;
+    std::thread poster_;
+    static constexpr uint32_t kRing = 8;
+    Pending ring_[kRing] = {};
+    std::atomic<uint32_t> q_tail_{0};
+    std::atomic<bool> stop_{false};
+    bool pair_pending_ = false;
+    bool pair_ = !(getenv("LEGION_RUNNER_PAIR") && atoi(getenv("LEGION_RUNNER_PAIR")) == 0);
+    int64_t st_pairs_ = 0;
+    bool stats_ = getenv("LEGION_RUNNER_STATS") != nullptr;
+    double st_wait_ = 0, st_launch_ = 0, st_gpu_ = 0;
+    int64_t st_n_ = 0;
 };
 
 Runner* NewGPURunner() { return new GPURunner(); }

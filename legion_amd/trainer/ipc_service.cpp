@@ -13,6 +13,7 @@
 #include <sys/mman.h>
 #include <unistd.h>
 
+#include <algorithm>
 #include <cerrno>
 #include <cstdint>
 #include <cstdio>
@@ -38,9 +39,17 @@
         }                                                                                     \
     }
 
+// The first two members are the reference's slab (TB/ipc_cuda_kernel.cu:30-33).  Behind them this build's server
+// publishes the counters of the batch in every (device, pipe slot) in host memory, written by the GPU before the
+// batch is posted: when ext_magic says so, get_next reads them there instead of making the reference's two blocking
+// 64-byte device-to-host copies per batch.
+#define LEGION_SHM_EXT_MAGIC 0x4C47494F
 typedef struct shmStruct_st {
     int32_t steps[3];
     hipIpcMemHandle_t memHandle[MAX_DEVICE][INTERBATCH_CON][MEMORY_USAGE];
+    int32_t ext_magic;
+    int32_t ext_reserved[3];
+    int32_t counters[MAX_DEVICE][INTERBATCH_CON][32];
 } shmStruct;
 static_assert(sizeof(hipIpcMemHandle_t) == 64, "IPC handle size is part of the wire format");
 
@@ -59,7 +68,7 @@ public:
         hipCheckError();
         const std::string shm_name = std::string("simpleIPCshm") + ipc_suffix();
         int fd = shm_open(shm_name.c_str(), O_RDWR | O_CREAT, 0777);
-        if (fd < 0 || ftruncate(fd, sizeof(shmStruct)) != 0) {
+        if (fd < 0 || ftruncate(fd, sizeof(shmStruct)) != 0) {     // never shrinks the server's slab: same size
             printf("Failed to create shared memory slab\n");
             exit(EXIT_FAILURE);
         }
@@ -106,7 +115,11 @@ public:
         }
         current_pipe_ = 0;
         device_ = central_device;
-        munmap(addr, sizeof(shmStruct));
+        if (shm->ext_magic == LEGION_SHM_EXT_MAGIC && !getenv("LEGION_NO_SHM_MIRROR")) {
+            mirror_ = shm;                                      // keep the slab mapped: counters are read from it
+        } else {
+            munmap(addr, sizeof(shmStruct));
+        }
         close(fd);
         return central_device;
     }
@@ -128,6 +141,9 @@ public:
     int32_t GetValidStep() { return valid_step_; }
     int32_t GetTestStep() { return test_step_; }
     int Device() const { return device_; }
+    int CurrentPipe() const { return current_pipe_; }
+    // host-visible counters of the batch in the current pipe slot, or null (then they are copied from the device)
+    const volatile int32_t* CounterMirror() const { return mirror_ ? &mirror_->counters[device_][current_pipe_][0] : nullptr; }
 
     void Finalize()
     {
@@ -146,11 +162,30 @@ private:
     int32_t train_step_ = 0, valid_step_ = 0, test_step_ = 0;
     int current_pipe_ = 0;
     int device_ = 0;
+    volatile shmStruct* mirror_ = nullptr;
 };
 
 static GPUIPCEnv* env = nullptr;
 static int32_t h_node_counter[16];
 static int32_t h_edge_counter[16];
+
+// Whole-buffer tensors over the seven IPC buffers of each pipe slot, wrapped once (torch::from_blob is the expensive
+// part of get_next: a TensorImpl + deleter context per call); a batch's tensors are as_strided views of them.
+struct SlotTensors { torch::Tensor ids, feats, labels, src, dst; };
+static SlotTensors slot_base[INTERBATCH_CON];
+static bool slot_base_ready[INTERBATCH_CON] = {false, false};
+// extent (in elements) of the device allocation behind an IPC-opened pointer
+static long long whole_buffer(void* p, size_t elem)
+{
+    hipDeviceptr_t base = nullptr;
+    size_t bytes = 0;
+    if (hipMemGetAddressRange(&base, &bytes, (hipDeviceptr_t)p) == hipSuccess && bytes >= elem) {
+        const size_t off = (size_t)((char*)p - (char*)base);
+        return (long long)((bytes - off) / elem);
+    }
+    (void)hipGetLastError();
+    return 1ll << 36;   // unknown: the server's extent bounds every view (views never exceed the batch's counts)
+}
 
 void InitializeIPC()
 {
@@ -158,28 +193,53 @@ void InitializeIPC()
     env->Initialize();
 }
 
-void FinalizeIPC() { env->Finalize(); }
+void FinalizeIPC()
+{
+    for (int i = 0; i < INTERBATCH_CON; i++) {
+        slot_base[i] = SlotTensors();
+        slot_base_ready[i] = false;
+    }
+    env->Finalize();
+}
 
 // training_backend/ipc_cuda_kernel.cu:177-235 + training_backend/ipc_service.cpp:44-59
 std::vector<torch::Tensor> get_next(int feature_dim)
 {
     env->Wait();
-    hipMemcpy(h_node_counter, env->GetNodeCounter(), 16 * sizeof(int32_t), hipMemcpyDeviceToHost);
-    hipMemcpy(h_edge_counter, env->GetEdgeCounter(), 16 * sizeof(int32_t), hipMemcpyDeviceToHost);
-    hipCheckError();
+    if (const volatile int32_t* m = env->CounterMirror()) {
+        for (int i = 0; i < 16; i++) {
+            h_node_counter[i] = m[i];
+            h_edge_counter[i] = m[16 + i];
+        }
+    } else {
+        hipMemcpy(h_node_counter, env->GetNodeCounter(), 16 * sizeof(int32_t), hipMemcpyDeviceToHost);
+        hipMemcpy(h_edge_counter, env->GetEdgeCounter(), 16 * sizeof(int32_t), hipMemcpyDeviceToHost);
+        hipCheckError();
+    }
     const int hop_num = h_node_counter[INTRABATCH_CON * 3 - 1];
-    const auto dev = torch::Device(torch::kCUDA, env->Device());
-    const auto i32 = torch::TensorOptions().dtype(torch::kI32).device(dev);
-    const auto f32 = torch::TensorOptions().dtype(torch::kF32).device(dev);
+    const int pipe = env->CurrentPipe();
+    SlotTensors& b = slot_base[pipe];
+    if (!slot_base_ready[pipe]) {
+        const auto dev = torch::Device(torch::kCUDA, env->Device());
+        const auto i32 = torch::TensorOptions().dtype(torch::kI32).device(dev);
+        const auto f32 = torch::TensorOptions().dtype(torch::kF32).device(dev);
+        b.ids = torch::from_blob(env->GetIds(), {whole_buffer(env->GetIds(), 4)}, i32);
+        b.feats = torch::from_blob(env->GetFloatFeatures(), {whole_buffer(env->GetFloatFeatures(), 4)}, f32);
+        b.labels = torch::from_blob(env->GetLabels(), {whole_buffer(env->GetLabels(), 4)}, i32);
+        b.src = torch::from_blob(env->GetAggSrc(), {whole_buffer(env->GetAggSrc(), 4)}, i32);
+        b.dst = torch::from_blob(env->GetAggDst(), {whole_buffer(env->GetAggDst(), 4)}, i32);
+        slot_base_ready[pipe] = true;
+    }
     std::vector<torch::Tensor> ret;
-    const long long n_total = h_node_counter[INTRABATCH_CON * 3 + hop_num];
-    ret.push_back(torch::from_blob(env->GetIds(), {n_total}, i32));
-    ret.push_back(torch::from_blob(env->GetFloatFeatures(), {n_total, (long long)feature_dim}, f32));
-    ret.push_back(torch::from_blob(env->GetLabels(), {(long long)h_node_counter[INTRABATCH_CON * 3]}, i32));
+    ret.reserve(3 + 2 * hop_num);
+    const long long n_total = std::max(h_node_counter[INTRABATCH_CON * 3 + hop_num], 0);
+    ret.push_back(b.ids.as_strided({n_total}, {1}));
+    ret.push_back(b.feats.as_strided({n_total, (long long)feature_dim}, {(long long)feature_dim, 1}));
+    ret.push_back(b.labels.as_strided({(long long)std::max(h_node_counter[INTRABATCH_CON * 3], 0)}, {1}));
     for (int i = hop_num; i > 0; i--) {   // cumulative edge prefixes, outermost block first
-        const long long n_edges = h_edge_counter[INTRABATCH_CON * 3 + i];
-        ret.push_back(torch::from_blob(env->GetAggSrc(), {n_edges}, i32));
-        ret.push_back(torch::from_blob(env->GetAggDst(), {n_edges}, i32));
+        const long long n_edges = std::max(h_edge_counter[INTRABATCH_CON * 3 + i], 0);
+        ret.push_back(b.src.as_strided({n_edges}, {1}));
+        ret.push_back(b.dst.as_strided({n_edges}, {1}));
     }
     return ret;
 }

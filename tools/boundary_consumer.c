@@ -1,0 +1,73 @@
+/* boundary_consumer.c -- the trainer end of the wire protocol with nothing else in it: waits for a batch
+ * (sem_w_<dev>_<pipe>), reads its counters from the slab's host-visible mirror, releases the slot (sem_r_...).
+ * Used by tools/server_throughput.py --consumer native to measure what the SERVER can hand over per second when
+ * the consumer costs nothing (the Python consumer adds ~15 us of tensor wrapping per batch).
+ *   gcc -O2 boundary_consumer.c -o boundary_consumer -lrt -lpthread
+ *   boundary_consumer <namespace-suffix> <device> <hops> <skip>     -> one JSON line
+ * Protocol: SS/engine/ipc_service.cu:28-31,181-192,283-291; TB/ipc_cuda_kernel.cu:75-106. */
+#include <fcntl.h>
+#include <semaphore.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <sys/mman.h>
+#include <time.h>
+#include <unistd.h>
+
+#define MAX_DEVICE 8
+#define INTERBATCH_CON 2
+#define MEMORY_USAGE 7
+#define MAGIC 0x4C47494F
+typedef struct {
+    int32_t steps[3];
+    char memHandle[MAX_DEVICE][INTERBATCH_CON][MEMORY_USAGE][64];
+    int32_t ext_magic;
+    int32_t ext_reserved[3];
+    int32_t counters[MAX_DEVICE][INTERBATCH_CON][32];
+} shmStruct;
+
+static double now(void) { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return t.tv_sec + 1e-9 * t.tv_nsec; }
+
+int main(int argc, char** argv)
+{
+    if (argc != 5) { fprintf(stderr, "usage: boundary_consumer <suffix> <device> <hops> <skip>\n"); return 2; }
+    const char* sfx = argv[1];
+    const int dev = atoi(argv[2]), hops = atoi(argv[3]), skip = atoi(argv[4]);
+    char name[128];
+    snprintf(name, sizeof name, "simpleIPCshm%s", sfx);
+    int fd = shm_open(name, O_RDWR, 0777);
+    if (fd < 0) { perror("shm_open"); return 1; }
+    volatile shmStruct* shm = (volatile shmStruct*)mmap(0, sizeof(shmStruct), PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+    if (shm == MAP_FAILED) { perror("mmap"); return 1; }
+    if (shm->ext_magic != MAGIC) { fprintf(stderr, "server does not publish the counter mirror\n"); return 1; }
+    sem_t *sr[2], *sw[2];
+    for (int i = 0; i < 2; i++) {
+        snprintf(name, sizeof name, "sem_r_%d_%d%s", dev, i, sfx);
+        sr[i] = sem_open(name, O_CREAT | O_RDWR, 0666, 0);
+        snprintf(name, sizeof name, "sem_w_%d_%d%s", dev, i, sfx);
+        sw[i] = sem_open(name, O_CREAT | O_RDWR, 0666, 0);
+        if (sr[i] == SEM_FAILED || sw[i] == SEM_FAILED) { perror("sem_open"); return 1; }
+        sem_post(sr[i]);                                   /* both pipe slots start free */
+    }
+    const int train = shm->steps[0], total = shm->steps[0] + shm->steps[1] + shm->steps[2];   /* epoch 1 */
+    long long edges = 0, nodes = 0;
+    int timed = 0, pipe = 0;
+    double t0 = 0, t1 = 0;
+    for (int i = 0; i < total; i++) {
+        sem_wait(sw[pipe]);
+        if (i == skip) { t0 = now(); edges = nodes = 0; timed = 0; }
+        if (i < train) {
+            edges += shm->counters[dev][pipe][16 + 9 + hops];
+            nodes += shm->counters[dev][pipe][9 + hops];
+            timed++;
+        }
+        sem_post(sr[pipe]);
+        pipe ^= 1;
+        if (i == train - 1) t1 = now();
+    }
+    printf("{\"consumer\": \"native (protocol only)\", \"batches_per_sec\": %.1f, \"edges_per_sec\": %.1f, \"timed_batches\": %d, "
+           "\"ms_per_batch\": %.6f, \"nodes_per_batch\": %.1f}\n", timed / (t1 - t0), edges / (t1 - t0), timed,
+           (t1 - t0) / timed * 1e3, (double)nodes / timed);
+    return 0;
+}

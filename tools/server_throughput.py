@@ -20,6 +20,9 @@ def main():
     ap.add_argument("--fanout", type=str, default="25,10")
     ap.add_argument("--train-batches", type=int, default=60)
     ap.add_argument("--cache-memory", type=int, default=1 << 30)
+    ap.add_argument("--consumer", type=str, default="python", choices=["python", "native"],
+                    help="python: the ipc_service extension as a trainer would use it (get_next -> synchronize); "
+                         "native: tools/boundary_consumer.c, the wire protocol with nothing else (what the server can hand over)")
     a = ap.parse_args()
     fanout = [int(x) for x in a.fanout.split(",")]
     dev = torch.device("cuda:0")
@@ -54,6 +57,20 @@ def main():
             assert server.poll() is None, open(os.path.join(work, "server.log")).read()
             assert time.time() < deadline
             time.sleep(0.2)
+        if a.consumer == "native":
+            exe = os.path.join(tmp, "boundary_consumer")
+            subprocess.check_call(["gcc", "-O2", os.path.join(ROOT, "tools", "boundary_consumer.c"), "-o", exe, "-lrt", "-lpthread"])
+            out = subprocess.check_output([exe, ns, "0", str(len(fanout)), "5"]).decode().strip().splitlines()[-1]
+            server.wait(timeout=120)
+            log.flush()
+            for line in open(os.path.join(work, "server.log")):
+                if line.startswith("runner "):
+                    print(line.strip(), file=sys.stderr)
+            res = json.loads(out)
+            res.update({"path": "sampling_server binary -> shm/semaphores -> protocol-only consumer (counters from the slab mirror)",
+                        "workload": f"RMAT-{a.scale} EF16, D={a.dim}, batch {a.batch}, fanout {fanout}, train mode, 1 GPU"})
+            print(json.dumps(res))
+            return
         import ipc_service
         torch.cuda.set_device(0)
         ipc_service.initialize()
