@@ -66,6 +66,10 @@ public:
         int central_device = -1;
         hipGetDevice(&central_device);
         hipCheckError();
+        const int physical_device = central_device;
+        // LEGION_IPC_DEVICE (testing): attach to the buffers / semaphores of this LOGICAL server GPU while staying on the
+        // current physical device (a server with more logical GPUs than the box has, see storage.hip SetGPUDevice)
+        if (const char* e = getenv("LEGION_IPC_DEVICE")) central_device = atoi(e);
         const std::string shm_name = std::string("simpleIPCshm") + ipc_suffix();
         int fd = shm_open(shm_name.c_str(), O_RDWR | O_CREAT, 0777);
         if (fd < 0 || ftruncate(fd, sizeof(shmStruct)) != 0) {     // never shrinks the server's slab: same size
@@ -114,7 +118,8 @@ public:
             sem_post(semr_[i]);   // both pipe slots start free (ipc_cuda_kernel.cu:91)
         }
         current_pipe_ = 0;
-        device_ = central_device;
+        device_ = physical_device;
+        slab_device_ = central_device;
         if (shm->ext_magic == LEGION_SHM_EXT_MAGIC && !getenv("LEGION_NO_SHM_MIRROR")) {
             mirror_ = shm;                                      // keep the slab mapped: counters are read from it
         } else {
@@ -143,7 +148,7 @@ public:
     int Device() const { return device_; }
     int CurrentPipe() const { return current_pipe_; }
     // host-visible counters of the batch in the current pipe slot, or null (then they are copied from the device)
-    const volatile int32_t* CounterMirror() const { return mirror_ ? &mirror_->counters[device_][current_pipe_][0] : nullptr; }
+    const volatile int32_t* CounterMirror() const { return mirror_ ? &mirror_->counters[slab_device_][current_pipe_][0] : nullptr; }
 
     void Finalize()
     {
@@ -161,7 +166,8 @@ private:
     std::vector<sem_t*> semw_, semr_;
     int32_t train_step_ = 0, valid_step_ = 0, test_step_ = 0;
     int current_pipe_ = 0;
-    int device_ = 0;
+    int device_ = 0;        // physical device the tensors live on
+    int slab_device_ = 0;   // index of this trainer's GPU in the server's slab / semaphore names
     volatile shmStruct* mirror_ = nullptr;
 };
 

@@ -1,0 +1,160 @@
+"""Everything about the first real multi-GPU run that a 1-GPU box CAN find out:
+  * the driver's own SCALE command line (`python -m torch.distributed.run ... bench.py --gpus 2 ...`) with both
+    ranks on the one GPU and gloo for the collectives -- default layout and --stripe (one clique over the ranks);
+  * the RCCL calls themselves, executed once at N = 1 (`--force-dist`, backend nccl);
+  * the reference's deployment -- ONE server process, a host thread per GPU (SS/engine/server.cu:95-103,122-130),
+    caches striped over a clique of two (cache_agg_mode 1) -- on two LOGICAL GPUs, serving two trainer processes,
+    every batch compared with the oracle."""
+import json
+import os
+import socket
+import subprocess
+import sys
+import time
+
+import numpy as np
+import pytest
+
+from tests.gpu_harness import CpuSide
+from tests.helpers import Workload
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SMALL = ["--scale", "18", "--group", "8", "--presc-steps", "8", "--cpu-seconds", "0", "--no-boundary", "--min-seconds", "0.1",
+         "--steps", "2", "--warmup", "1", "--cache-memory", str(64 << 20)]
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _last_json(text):
+    lines = [ln for ln in text.splitlines() if ln.startswith("{")]
+    assert lines, text[-3000:]
+    return json.loads(lines[-1])
+
+
+@pytest.mark.parametrize("stripe", [False, True], ids=["replicated-caches", "striped-clique"])
+def test_scale_command_line_two_ranks_on_one_gpu(hip, stripe):
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo",
+           "--force-device", "0"] + SMALL + (["--stripe"] if stripe else [])
+    res = subprocess.run(cmd, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+    assert res.returncode == 0, res.stderr[-4000:]
+    d = _last_json(res.stdout)
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["value"] > 0 and d["steps"] == 2
+    assert d["roofline"]["frac"] > 0 and d["roofline"]["launches"] == 2
+    assert ("striped" in d["config"]["parallelism"]) == stripe
+    assert "cpu_baseline" not in d                      # N = 1 only
+    one = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1"] + SMALL, cwd=ROOT,
+                         stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+    assert one.returncode == 0, one.stderr[-4000:]
+    d1 = _last_json(one.stdout)
+    assert d["batches_per_step"] == d1["batches_per_step"] == 8
+    # edges_per_step is rank 0's count: same batch shape as the 1-GPU run (different seeds, so only roughly equal)
+    assert 0.7 < d["edges_per_step"] / d1["edges_per_step"] < 1.4
+
+
+def test_rccl_calls_execute_at_n1(hip):
+    """bench.py --force-dist: torch.distributed over the nccl backend (= RCCL) with world size 1; the hotness all-reduce,
+    the MIN/MAX reductions and the barriers all go through RCCL once."""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--force-dist", "--backend", "nccl"] + SMALL,
+                         cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+    assert res.returncode == 0, res.stderr[-4000:]
+    d = _last_json(res.stdout)
+    assert d["n_gpus"] == 1 and d["value"] > 0
+
+
+def test_one_server_process_two_gpus_thread_per_gpu(hip, tmp_path):
+    """`sampling_server 2 1 5 3`: GPUServer with two runners (a host thread each), PreSC on both, hotness summed over the
+    clique, caches striped Kg = 2, two pipe-slot sets, two trainer processes.  Logical GPU 1 shares the box's one GPU."""
+    scale, D, B, fanout, epoch, cache_memory = 11, 24, 40, [5, 3], 2, 40_000
+    wl = Workload(scale=scale, edge_factor=8, dim=D, n_seeds=700, n_valid=130, n_test=70, partition_count=2)
+    N = wl.N
+    perm = np.random.RandomState(11).permutation(N).astype(np.int32)          # Workload's own split, unpartitioned
+    train, valid, test = perm[:700], perm[700:830], perm[830:900]
+    ds = str(tmp_path / "ds") + "/"
+    os.makedirs(ds)
+    wl.indptr.astype(np.int64).tofile(ds + "edge_src"); wl.col.astype(np.int32).tofile(ds + "edge_dst")
+    wl.features.astype(np.float32).tofile(ds + "features"); wl.labels_all.astype(np.int32).tofile(ds + "labels")
+    train.tofile(ds + "trainingset"); valid.tofile(ds + "validationset"); test.tofile(ds + "testingset")
+    work = tmp_path / "run"
+    work.mkdir()
+    (work / "meta_config").write_text("{} {} {} {} {} {} {} {} {} {}".format(
+        ds, B, N, wl.col.size, D, train.size, valid.size, test.size, cache_memory, epoch))
+    ns = f"_m{os.getpid()}"
+    env = dict(os.environ, LEGION_IPC_NAMESPACE=ns)
+    log = open(work / "server.log", "w")
+    server = subprocess.Popen([os.path.join(ROOT, "legion_amd", "bin", "sampling_server"), "2", "1"] + [str(f) for f in fanout],
+                              cwd=work, env=env, stdout=log, stderr=subprocess.STDOUT)
+    trainers = []
+    try:
+        deadline = time.time() + 400
+        while "System is ready for serving" not in open(work / "server.log").read():
+            assert server.poll() is None, open(work / "server.log").read()
+            assert time.time() < deadline, "server did not become ready"
+            time.sleep(0.1)
+        for dev in range(2):
+            trainers.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "fake_trainer.py"), str(dev), str(D),
+                                              str(epoch), str(tmp_path / f"t{dev}.npz")], env=env, cwd=ROOT,
+                                             stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+        for t in trainers:
+            out, _ = t.communicate(timeout=600)
+            assert t.returncode == 0, out[-3000:]
+        server.wait(timeout=120)
+        assert server.returncode == 0, open(work / "server.log").read()[-3000:]
+
+        # ---- the oracle: the same two-GPU server in one address space --------------------------------
+        from oracle import ffi
+        import ctypes
+        L = ffi.load()
+        st = ffi.Steps()
+        arr = lambda v: (ctypes.c_int32 * 2)(*v)
+        n_of = lambda mode: [wl.sets[(p, mode)][0].size for p in range(2)]
+        L.lgo_coordinate(ctypes.byref(st), 2, arr(n_of(0)), arr(n_of(1)), arr(n_of(2)), B, epoch)
+        max_bs = max([B] + [st.valid_bs[p] for p in range(2)] + [st.test_bs[p] for p in range(2)])
+        cpu = CpuSide(wl, max_bs, fanout)
+        for p in range(2):
+            for it in range(st.train_step):
+                cpu.run(p, it, 0, is_presc=True, batch_size=B)
+        cpu.build_cache(1, cache_memory=cache_memory, train_step=st.train_step)
+        total = L.lgo_max_step(ctypes.byref(st))
+        H = len(fanout)
+        hits = 0
+        for p in range(2):
+            got = np.load(tmp_path / f"t{p}.npz")
+            assert got["steps"].tolist() == [st.train_step, st.valid_step, st.test_step]
+            for gb in range(total):
+                mode = L.lgo_current_mode(ctypes.byref(st), gb)
+                it = L.lgo_local_batch_id(ctypes.byref(st), gb)
+                bs = L.lgo_current_batchsize(ctypes.byref(st), p, mode)
+                want = cpu.run(p, it, mode, batch_size=bs)
+                nc, ec = want["node_counter"], want["edge_counter"]
+                assert np.array_equal(got[f"b{gb}_ids"], want["sampled_ids"]), f"gpu {p} batch {gb}"
+                assert np.array_equal(got[f"b{gb}_labels"], want["labels"])
+                assert np.array_equal(got[f"b{gb}_feats"], want["float_features"].view(np.uint32)), f"gpu {p} batch {gb} rows"
+                for k, h in enumerate(range(H, 0, -1)):
+                    n_e = int(ec[9 + h])
+                    assert np.array_equal(got[f"b{gb}_src{k}"], want["agg_src_off"][:n_e])
+                    assert np.array_equal(got[f"b{gb}_dst{k}"], want["agg_dst_off"][:n_e])
+                exp = []
+                for h in range(H, 0, -1):
+                    exp += [int(nc[9 + h]), int(nc[9 + h - 1])]
+                assert got[f"b{gb}_sizes"].tolist() == exp
+                hits += int((want["cache_search_buffer"] >= 0).sum()) if "cache_search_buffer" in want else 0
+        cpu.close()
+    finally:
+        for t in trainers:
+            if t.poll() is None:
+                t.kill()
+        if server.poll() is None:
+            server.kill()
+        log.close()
+        for name in os.listdir("/dev/shm"):
+            if name.endswith(ns):
+                os.unlink(os.path.join("/dev/shm", name))
