@@ -542,6 +542,7 @@ public:
     virtual void RunPreSc(RunnerParams* params) = 0;
     virtual void RunOnce(RunnerParams* params) = 0;
     virtual void Finalize(RunnerParams* params) = 0;
+    virtual void PrepareServing(RunnerParams*) {}   // new: allocations / graph capture of the serving phase, before "ready"
 };
 Runner* NewGPURunner();
 

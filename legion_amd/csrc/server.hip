@@ -416,7 +416,7 @@ public:
             memorypool_->SetCurrentPipe(current_pipe_);
             return;
         }
-        if (pipe_ == nullptr) CreateGroups(params);
+        if (pipe_ == nullptr) PrepareServing(params);
         if (pair_pending_) {                       // this batch went out together with the previous one (one launch, both slots)
             pair_pending_ = false;
             if (batch_id % 1000 == 0 && local_dev_id_ == 0) std::cout << "batch id: " << batch_id << "\n";
@@ -478,6 +478,22 @@ public:
         }
         if (batch_id % 1000 == 0 && local_dev_id_ == 0) std::cout << "batch id: " << batch_id << "\n";
         current_pipe_ = (current_pipe_ + 1) % interbatch_concurrency_;
+    }
+
+    // Everything serving needs that allocates, captures or instantiates -- lanes, descriptors, the first group's graph and
+    // its sampler phase -- done BEFORE the server announces itself: while trainers attach to the IPC buffers the server
+    // process then only launches kernels (concurrent allocation in the exporting process made hipIpcOpenMemHandle fail
+    // now and then with two trainers attaching at once, ROCm 7.2), and the first batch is ready when the trainer asks.
+    void PrepareServing(RunnerParams* params) override
+    {
+        if (!use_groups_ || pipe_ != nullptr) return;
+        SetGPUDevice(local_dev_id_);
+        IPCEnv* env = (IPCEnv*)(params->env);
+        CreateGroups(params);
+        if (max_step_ > 0) {
+            SubmitGroup(env, 0, cur_slot_, cur_first_, cur_n_);
+            HIP_CALL(hipStreamSynchronize(static_cast<hipStream_t>(legion_pipeline_stream(pipe_))));
+        }
     }
 
     void Finalize(RunnerParams* params) override
@@ -733,6 +749,10 @@ public:
         cache_->CandidateSelection(cache_agg_mode, feature_, graph_);
         cache_->CostModel(cache_agg_mode, feature_, graph_, counters, train_step_);
         cache_->FillUp(cache_agg_mode, feature_, graph_);
+        for (int i = 0; i < shard_count_; i++) {
+            params_[i]->global_batch_id = 0;
+            runners_[i]->PrepareServing(params_[i]);
+        }
         std::cout << "Preprocessing cost: " << t << " s\n";
         std::cout << "System is ready for serving\n" << std::flush;
     }

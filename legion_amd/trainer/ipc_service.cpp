@@ -92,6 +92,15 @@ public:
             for (int k = 0; k < MEMORY_USAGE; k++) {
                 hipIpcMemHandle_t h = *(hipIpcMemHandle_t*)&shm->memHandle[central_device][i][k];
                 hipError_t e = hipIpcOpenMemHandle(&(*slots[k])[i], h, hipIpcMemLazyEnablePeerAccess);
+                // Observed on ROCm 7.2 (dmabuf IPC): while the exporting server process is busy allocating (its runners
+                // start right after "ready") and another trainer attaches at the same moment, an open can fail transiently
+                // with 'invalid device pointer'; the handle itself is fine.  Retry briefly before giving up.
+                for (int attempt = 0; e != hipSuccess && attempt < 10; attempt++) {
+                    (void)hipGetLastError();
+                    usleep(25000);
+                    e = hipIpcOpenMemHandle(&(*slots[k])[i], h, hipIpcMemLazyEnablePeerAccess);
+                    if (e == hipSuccess) printf("ipc_service: IPC handle (slot %d pipe %d) opened after %d retries\n", k, i, attempt + 1);
+                }
                 if (e != hipSuccess) {
                     printf("HIP failure %s:%d: '%s' (slot %d pipe %d)\n", __FILE__, __LINE__, hipGetErrorString(e), k, i);
                     exit(EXIT_FAILURE);

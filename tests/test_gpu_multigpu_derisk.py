@@ -91,7 +91,7 @@ def test_one_server_process_two_gpus_thread_per_gpu(hip, tmp_path):
     env = dict(os.environ, LEGION_IPC_NAMESPACE=ns)
     log = open(work / "server.log", "w")
     server = subprocess.Popen([os.path.join(ROOT, "legion_amd", "bin", "sampling_server"), "2", "1"] + [str(f) for f in fanout],
-                              cwd=work, env=env, stdout=log, stderr=subprocess.STDOUT)
+                              cwd=work, env=env, stdout=log, stderr=subprocess.STDOUT, stdin=subprocess.DEVNULL)
     trainers = []
     try:
         deadline = time.time() + 400
@@ -102,10 +102,11 @@ def test_one_server_process_two_gpus_thread_per_gpu(hip, tmp_path):
         for dev in range(2):
             trainers.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "fake_trainer.py"), str(dev), str(D),
                                               str(epoch), str(tmp_path / f"t{dev}.npz")], env=env, cwd=ROOT,
-                                             stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
-        for t in trainers:
-            out, _ = t.communicate(timeout=600)
-            assert t.returncode == 0, out[-3000:]
+                                             stdout=open(tmp_path / f"t{dev}.log", "w"), stderr=subprocess.STDOUT,
+                                             stdin=subprocess.DEVNULL))
+        for dev, t in enumerate(trainers):
+            t.wait(timeout=240)
+            assert t.returncode == 0, open(tmp_path / f"t{dev}.log").read()[-3000:]
         server.wait(timeout=120)
         assert server.returncode == 0, open(work / "server.log").read()[-3000:]
 
