@@ -77,9 +77,11 @@ def parse_args():
     ap.add_argument("--no-boundary", action="store_true",
                     help="skip the drop-in boundary leg (sampling_server binary -> shm/semaphores/IPC handles -> ipc_service "
                          "consumer on an RMAT-22 data set written in the reference's file formats; N = 1 only, ~15 s)")
-    ap.add_argument("--measured-counters", action="store_true",
-                    help="feed the cost model with the topology transactions the sampler counted during PreSC "
-                         "(default: {0,0} as the reference's v2 does)")
+    ap.add_argument("--measured-counters", action="store_true", help="same as --link-counters computed")
+    ap.add_argument("--link-counters", type=str, default="v2", choices=["v2", "computed", "smi"],
+                    help="what feeds CostModel's PCIe transaction counters: v2 = {0,0} as the reference's v2 does; computed = the "
+                         "64-byte topology transactions the sampler counted during PreSC; smi = what the PCIe link really carried "
+                         "during PreSC, from the driver's cumulative gpu_metrics counter (the paper's Intel-PCM reading)")
     ap.add_argument("--stripe", action="store_true",
                     help="N > 1: one clique of N GPUs, feature/topology caches striped over the ranks and read "
                          "through peer pointers over xGMI (default: every GPU caches for itself, no peer traffic)")
@@ -176,9 +178,17 @@ def main():
     pool = engine.MemoryPool(d, N, B, fanout, D, pipeline_depth=1)
 
     # ---- PreSC epoch (bounded) -> hotness -> all-reduce over ranks -> order -> cost model -> fills --
+    if args.measured_counters and args.link_counters == "v2":
+        args.link_counters = "computed"
+    torch.cuda.synchronize()
+    time.sleep(0.02)
+    lc0 = engine.link_counters(d)
     for it in range(train_step):
         engine.enqueue_batch(None, graph, feature, cache, pool, B, it, d, engine.TRAINMODE, True, fanout)
     torch.cuda.synchronize()
+    time.sleep(0.02)
+    lc1 = engine.link_counters(d)
+    pcie_tx = (lc1[0] - lc0[0]) // 64 if (lc0 is not None and lc1 is not None) else None
     if use_dist:    # the only collective of the path: RCCL all-reduce of the uint64 hotness counters
         dist.all_reduce(cache.array("node_access_time", d))
         dist.all_reduce(cache.array("edge_access_time", d))
@@ -188,7 +198,15 @@ def main():
         tt = torch.tensor([topo_tx], dtype=torch.int64, device=dev if args.backend == "nccl" else "cpu")
         dist.all_reduce(tt)
         topo_tx = int(tt.item())
-    counters = (topo_tx, 0) if args.measured_counters else (0, 0)
+    if args.link_counters == "smi" and pcie_tx is not None:
+        tt = torch.tensor([pcie_tx], dtype=torch.int64, device=dev if args.backend == "nccl" else "cpu")
+        if use_dist:
+            dist.all_reduce(tt)
+        counters = (int(tt.item()), 0)
+    elif args.link_counters in ("computed", "smi"):
+        counters = (topo_tx, 0)
+    else:
+        counters = (0, 0)
     if stripe:
         mids = [None] * world
         dist.all_gather_object(mids, max_ids)
@@ -383,6 +401,7 @@ def main():
                        "cache_memory_bytes": args.cache_memory,
                        "feature_cache_rows": cache.node_capacity(d), "topology_cache_vertices": cache.edge_capacity(d),
                        "presc_batches": train_step, "presc_topology_transactions": topo_tx,
+                       "presc_pcie_transactions_gpu_metrics": pcie_tx, "link_counters": args.link_counters,
                        "cost_model_counters": list(counters)},
             "feature_gather_GBps": payload_gbps * 1.0,
             "feature_gather_GBps_note": "payload bytes read (rows*D*4) / HIP-event time of all gather launches, rank 0",

@@ -268,6 +268,11 @@ void legion_draw_batch(legion_stream_t stream, const int32_t* idx, const int32_t
 void legion_pool_profile_begin(LegionMemoryPool* p, int32_t max_ops);
 int32_t legion_pool_profile_end(LegionMemoryPool* p, float* out_ms, int32_t* out_op, int32_t cap);
 
+/* Cumulative PCIe / xGMI byte counters of logical GPU dev_id from the driver's gpu_metrics table (the MI355X counterpart
+ * of the Intel-PCM PCIe counters that feed CostModel in the paper: SS/engine/server.cu:105-110, SS/engine/monitor.cuh).
+ * Returns 1 and fills the two totals, or 0 when the table is missing / has an unknown revision.  Host-only. */
+int32_t legion_link_counters(int32_t dev_id, uint64_t* pcie_bytes, uint64_t* xgmi_bytes);
+
 /* =====================================================================================
  * 5. Synthetic workload generators (RMAT + counter-hash features); device side.
  * ===================================================================================== */

@@ -30,12 +30,15 @@
 #include <thread>
 
 // ---------------------------------------------------------------------------------------------
-static bool read_file_into(const std::string& path, void* dst, size_t bytes)
+// Reads exactly `bytes` bytes.  A file that exists but is SHORTER than meta_config says is a corrupt or mismatched
+// data set: the reference mmaps it and reads past the end (storage_management_impl.cuh:46-159); here the server
+// says what is wrong and stops instead of sampling from zero-filled tables.
+static void read_file_into(const std::string& path, void* dst, size_t bytes)
 {
     int fd = open(path.c_str(), O_RDONLY);
     if (fd == -1) {
         std::cout << "cannout open file: " << path << "\n";
-        return false;
+        exit(EXIT_FAILURE);
     }
     size_t done = 0;
     char* p = (char*)dst;
@@ -45,8 +48,10 @@ static bool read_file_into(const std::string& path, void* dst, size_t bytes)
         done += (size_t)r;
     }
     close(fd);
-    if (done < bytes) memset(p + done, 0, bytes - done);
-    return done == bytes;
+    if (done < bytes) {
+        std::cout << "file too short: " << path << " holds " << done << " bytes, meta_config implies " << bytes << "\n" << std::flush;
+        exit(EXIT_FAILURE);
+    }
 }
 
 static int64_t file_size(const std::string& path)
@@ -62,20 +67,32 @@ struct Placement {
     bool in_hbm = false;
 };
 
-static Placement place_table(const std::string& path, size_t bytes, bool want_hbm, bool zero_if_missing)
+// HBM budget of the full tables (CSR + features): 70 % of what was free when loading started, shared by ALL of them --
+// three tables that each fit must not over-commit together; the rest stays for caches, pools and the trainer.
+static int64_t g_hbm_budget = -1;
+
+static Placement place_table(const std::string& path, size_t bytes, bool want_hbm, bool required)
 {
     Placement pl;
     void* pinned = nullptr;
     HIP_CALL(hipHostMalloc(&pinned, bytes ? bytes : 16, hipHostMallocMapped));
     const bool present = file_size(path) >= 0;
-    if (present)
+    if (present) {
         read_file_into(path, pinned, bytes);
-    else if (zero_if_missing)
-        memset(pinned, 0, bytes);
+    } else if (required) {
+        std::cout << "cannout open file: " << path << "\n" << std::flush;
+        exit(EXIT_FAILURE);
+    } else {
+        memset(pinned, 0, bytes);       // optional table absent (v2 of the reference reads neither features nor labels)
+    }
     if (want_hbm) {
-        size_t free_b = 0, total_b = 0;
-        HIP_CALL(hipMemGetInfo(&free_b, &total_b));
-        if (bytes < free_b / 10 * 7) {
+        if (g_hbm_budget < 0) {
+            size_t free_b = 0, total_b = 0;
+            HIP_CALL(hipMemGetInfo(&free_b, &total_b));
+            g_hbm_budget = (int64_t)(free_b / 10 * 7);
+        }
+        if ((int64_t)bytes <= g_hbm_budget) {
+            g_hbm_budget -= (int64_t)bytes;
             void* d = d_alloc_space((int64_t)bytes);
             HIP_CALL(hipMemcpy(d, pinned, bytes, hipMemcpyHostToDevice));
             HIP_CALL(hipHostFree(pinned));
@@ -156,6 +173,14 @@ public:
         const bool hbm = want_hbm();
         Placement ip = place_table(dataset_path_ + "edge_src", (size_t)(node_num_ + 1) * sizeof(int64_t), hbm, true);
         Placement ci = place_table(dataset_path_ + "edge_dst", (size_t)edge_num_ * sizeof(int32_t), hbm, true);
+        {   // the two files must describe one graph: indptr[N] is the edge count meta_config gives
+            int64_t last = 0;
+            HIP_CALL(hipMemcpy(&last, (int64_t*)ip.dev_ptr + node_num_, sizeof(int64_t), hipMemcpyDefault));
+            if (last != edge_num_) {
+                std::cout << "data set mismatch: edge_src[N] = " << last << " but meta_config says " << edge_num_ << " edges\n" << std::flush;
+                exit(EXIT_FAILURE);
+            }
+        }
         info->csr_node_index = (int64_t*)ip.dev_ptr;
         info->csr_dst_node_ids = (int32_t*)ci.dev_ptr;
         std::cout << "Topology placement: " << (ip.in_hbm && ci.in_hbm ? "HBM" : "pinned host") << "\n";
@@ -179,7 +204,7 @@ public:
         // v2 of the reference leaves features uninitialised and labels zero (:162,:164); this build
         // reads both files when they exist and zero-fills otherwise.
         Placement fp = place_table(dataset_path_ + "features", (size_t)node_num_ * float_feature_len_ * sizeof(float),
-                                   want_hbm(), true);
+                                   want_hbm(), false);
         if (file_size(dataset_path_ + "labels") >= 0)
             read_file_into(dataset_path_ + "labels", all_labels.data(), all_labels.size() * 4);
         const bool have_partition = file_size(dataset_path_ + "partition") >= (int64_t)node_num_ * 4;
@@ -190,6 +215,12 @@ public:
             std::cout << "cannout open file: " << dataset_path_ + "partition" << "\n";
         }
         std::cout << "Finish Reading All Files\n";
+        for (const std::vector<int32_t>* set : {&training_ids, &validation_ids, &testing_ids})
+            for (int32_t tid : *set)
+                if (tid < 0 || tid >= node_num_) {     // would index every table out of bounds on the device
+                    std::cout << "data set mismatch: seed id " << tid << " outside [0, " << node_num_ << ")\n" << std::flush;
+                    exit(EXIT_FAILURE);
+                }
         int trainingset_count = 0;
         for (int32_t tid : training_ids) {                                  // :171-184
             const int32_t part_id = have_partition ? partition_index[tid] : tid % partition_count;
@@ -721,9 +752,19 @@ public:
     void PreSc(int cache_agg_mode) override
     {
         std::chrono::steady_clock::time_point t1 = std::chrono::steady_clock::now();
+        const char* lc_mode = getenv("LEGION_LINK_COUNTERS");
+        const bool use_smi = lc_mode && strcmp(lc_mode, "smi") == 0;
+        uint64_t pcie_before = 0, pcie_after = 0;
+        bool smi_ok = use_smi;
+        if (use_smi) smi_ok = ReadPcieBytes(pcie_before);
         std::vector<std::thread> pool;
         for (int i = 0; i < shard_count_; i++) pool.emplace_back(&PreSCLoop, train_step_, runners_[i], params_[i]);
         for (auto& th : pool) th.join();
+        if (smi_ok) {
+            for (int i = 0; i < shard_count_; i++) { SetGPUDevice(i); HIP_CALL(hipDeviceSynchronize()); }
+            std::this_thread::sleep_for(std::chrono::milliseconds(20));   // the table is refreshed every millisecond or so
+            smi_ok = ReadPcieBytes(pcie_after);
+        }
         // PCIe/xGMI transaction counters of the PreSC epoch (Intel PCM in the paper, hard-wired to
         // {0,0} in v2, server.cu:105-106).  LEGION_LINK_COUNTERS="a,b" injects values;
         // LEGION_LINK_COUNTERS=measured uses what the sampler itself counted during this epoch
@@ -731,7 +772,13 @@ public:
         std::vector<uint64_t> counters(2, 0);
         if (const char* lc = getenv("LEGION_LINK_COUNTERS")) {
             unsigned long long a = 0, b = 0;
-            if (strcmp(lc, "measured") == 0) {
+            if (use_smi && smi_ok) {
+                // LEGION_LINK_COUNTERS=smi: what the PCIe link actually carried during the PreSC epoch, in 64-byte
+                // transactions, from the driver's cumulative counter (link_counters.hip) -- the paper's PCM reading
+                counters[0] = (pcie_after - pcie_before) / 64;
+                std::cout << "PCIe transactions (gpu_metrics): " << counters[0] << "\n";
+            } else if (strcmp(lc, "measured") == 0 || use_smi) {
+                if (use_smi) std::cout << "gpu_metrics link counters unavailable: using the sampler's own count\n";
                 for (int i = 0; i < shard_count_; i++) {
                     unsigned long long v = 0;
                     SetGPUDevice(i);
@@ -755,6 +802,19 @@ public:
         }
         std::cout << "Preprocessing cost: " << t << " s\n";
         std::cout << "System is ready for serving\n" << std::flush;
+    }
+
+    // sum of the cumulative PCIe byte counters of the (distinct physical) GPUs this server drives
+    bool ReadPcieBytes(uint64_t& total)
+    {
+        total = 0;
+        const int physical = std::max(1, legion_device_count());
+        for (int i = 0; i < std::min(shard_count_, physical); i++) {
+            uint64_t p = 0, x = 0;
+            if (!legion_link_counters(i, &p, &x)) return false;
+            total += p;
+        }
+        return true;
     }
 
     void Run() override

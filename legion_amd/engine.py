@@ -53,6 +53,14 @@ def set_local_device(dev):
     _libmod.load().legion_set_local_device(int(dev))
 
 
+def link_counters(dev_id=0):
+    """(PCIe bytes, xGMI bytes) moved by logical GPU dev_id since boot, from the driver's gpu_metrics table, or None
+    when the table is not readable / has an unknown revision (legion_hip.h: legion_link_counters)."""
+    a, b = ctypes.c_uint64(0), ctypes.c_uint64(0)
+    ok = _libmod.load().legion_link_counters(int(dev_id), ctypes.byref(a), ctypes.byref(b))
+    return (int(a.value), int(b.value)) if ok else None
+
+
 def _torch_device(dev_id):
     base = int(_libmod.load().legion_get_device_base())
     return torch.device("cuda", (base + int(dev_id)) % max(torch.cuda.device_count(), 1))

@@ -133,3 +133,41 @@ def test_server_binary_serves_fake_trainer(hip, tmp_path):
         for name in os.listdir("/dev/shm"):
             if name.endswith(ns):
                 os.unlink(os.path.join("/dev/shm", name))
+
+
+@pytest.mark.parametrize("damage,needle", [("short_edge_dst", "file too short"), ("edge_count", "data set mismatch"),
+                                           ("seed_range", "data set mismatch"), ("missing_edge_src", "cannout open file")])
+def test_server_rejects_a_mismatched_dataset(hip, tmp_path, damage, needle):
+    """A data set that does not match meta_config (truncated file, wrong edge count, seed ids beyond N, missing CSR) makes
+    the server say so and exit non-zero -- it neither zero-fills nor reads out of bounds (the reference mmaps and reads on)."""
+    scale, D, B = 10, 8, 32
+    indptr, col = synth.rmat_csr_numpy(scale, 8, 20231)
+    N = indptr.size - 1
+    feats = synth.features_numpy(0, N, D, 7)
+    labels = (np.arange(N) % 47).astype(np.int32)
+    perm = np.random.RandomState(3).permutation(N).astype(np.int32)
+    train, valid, test = perm[:200], perm[200:240], perm[240:260]
+    if damage == "seed_range":
+        train = train.copy(); train[17] = N + 5
+    ds = str(tmp_path / "ds") + "/"
+    write_dataset(ds, indptr, col, feats, labels, train, valid, test)
+    E = col.size
+    if damage == "short_edge_dst":
+        col[: E - 100].astype(np.int32).tofile(os.path.join(ds, "edge_dst"))
+    if damage == "edge_count":
+        E = E - 64                                      # meta_config disagrees with edge_src[N]
+    if damage == "missing_edge_src":
+        os.unlink(os.path.join(ds, "edge_src"))
+    work = tmp_path / "run"
+    work.mkdir()
+    (work / "meta_config").write_text("{} {} {} {} {} {} {} {} {} {}".format(
+        ds, B, N, E, D, train.size, valid.size, test.size, 50_000, 1))
+    ns = f"_r{os.getpid()}"
+    res = subprocess.run([os.path.join(ROOT, "legion_amd", "bin", "sampling_server"), "1", "0", "5", "3"], cwd=work,
+                         env=dict(os.environ, LEGION_IPC_NAMESPACE=ns), stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+                         stdin=subprocess.DEVNULL, text=True, timeout=300)
+    for name in os.listdir("/dev/shm"):
+        if name.endswith(ns):
+            os.unlink(os.path.join("/dev/shm", name))
+    assert res.returncode != 0 and needle in res.stdout, res.stdout[-2000:]
+    assert "System is ready for serving" not in res.stdout
