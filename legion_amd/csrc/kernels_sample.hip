@@ -31,6 +31,8 @@
 // not HBM bytes; no MFMA.
 #include "legion_core.h"
 
+#include <cstdlib>
+
 namespace lg {
 
 // ------------------------------------------------------------------------------------------
@@ -688,7 +690,9 @@ void launch_random_sample(hipStream_t s, const HopParams& p, const LanePtrs* d_l
     int32_t max_super = (p.max_slots + LG_SUPER - 1) / LG_SUPER;
     if (max_super < 1) max_super = 1;
     int32_t gx = max_super < 1024 ? max_super : 1024;
-    while (gx > 64 && (int64_t)gx * n_lanes > 4096) gx /= 2;    // keep the whole launch near 2 x resident capacity
+    static const int max_wg = [] { const char* e = getenv("LEGION_SAMPLE_MAX_WG"); return e ? atoi(e) : 4096; }();
+    while (gx > 64 && (int64_t)gx * n_lanes > max_wg) gx /= 2;  // keep the whole launch near 2 x resident capacity
+    while (gx > 1 && (int64_t)gx * n_lanes > max_wg && max_wg < 4096) gx /= 2;   // (experiments with fewer workgroups)
     const dim3 grid(gx, n_lanes);
     if (table_form)
         sample_kernel<true><<<grid, LG_TILE, 0, s>>>(p, d_lanes);

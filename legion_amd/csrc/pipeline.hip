@@ -20,6 +20,7 @@
 //     sampler(k+1) runs under gathers(k) and the two kinds of memory traffic share the machine.
 #include "legion_core.h"
 
+#include <algorithm>
 #include <map>
 
 struct LegionLaneGroup;
@@ -94,12 +95,33 @@ extern "C" LegionPipeline* legion_pipeline_create(LegionGraphStorage* graph, Leg
     if (p->sample_only) p->split = false;
     if (p->split) p->overlap = false;
     SetGPUDevice(dev_id);
+    // split mode with a CU partition (LEGION_SPLIT_SAMPLER_CUS = n): the sampler stream may only use n of the 256 CUs
+    // (every (256/n)-th bit of the mask), the gather stream the others.  The sampler is bound by the latency of scattered
+    // atomics, not by CUs; the gather needs every wave slot it can get to keep ~12 MB of loads in flight.
+    std::vector<uint32_t> mask_s, mask_g;
     if (p->split) {
+        const char* ce = getenv("LEGION_SPLIT_SAMPLER_CUS");
+        const int n_cu = ce ? atoi(ce) : 0;
+        if (n_cu > 0 && n_cu < 256) {
+            hipDeviceProp_t prop;
+            HIP_CALL(hipGetDeviceProperties(&prop, GetGPUDevice()));
+            const int total = prop.multiProcessorCount, words = (total + 31) / 32;
+            mask_s.assign(words, 0u);
+            mask_g.assign(words, 0u);
+            const int stride = std::max(1, total / n_cu);
+            for (int c = 0; c < total; c++) {
+                if (c % stride == 0 && (int)(c / stride) < n_cu) mask_s[c / 32] |= 1u << (c % 32);
+                else mask_g[c / 32] |= 1u << (c % 32);
+            }
+        }
         int lo = 0, hi = 0;                                  // hi is the numerically lowest = highest priority
         HIP_CALL(hipDeviceGetStreamPriorityRange(&lo, &hi));
         const char* pe = getenv("LEGION_SPLIT_PRIORITY");
         const int prio = pe ? atoi(pe) : 1;                  // 1: sampler first, 0: equal, -1: gathers first
-        HIP_CALL(hipStreamCreateWithPriority(&p->sample_stream, hipStreamNonBlocking, prio > 0 ? hi : lo));
+        if (!mask_s.empty())
+            HIP_CALL(hipExtStreamCreateWithCUMask(&p->sample_stream, (uint32_t)mask_s.size(), mask_s.data()))
+        else
+            HIP_CALL(hipStreamCreateWithPriority(&p->sample_stream, hipStreamNonBlocking, prio > 0 ? hi : lo));
         if (prio < 0) p->gather_high = true;
     }
     p->slots.resize(p->slots_n);
@@ -119,7 +141,9 @@ extern "C" LegionPipeline* legion_pipeline_create(LegionGraphStorage* graph, Leg
         HIP_CALL(hipHostMalloc((void**)&sl.h_iter, 2 * sizeof(int32_t), hipHostMallocDefault));
         // chained slots share one in-order stream (back-to-back graph launches, no event round trip);
         // overlapping slots get a stream each
-        if (p->gather_high && &sl == &p->slots[0]) {
+        if (!mask_g.empty() && &sl == &p->slots[0]) {
+            HIP_CALL(hipExtStreamCreateWithCUMask(&sl.stream, (uint32_t)mask_g.size(), mask_g.data()));
+        } else if (p->gather_high && &sl == &p->slots[0]) {
             int lo = 0, hi = 0;
             HIP_CALL(hipDeviceGetStreamPriorityRange(&lo, &hi));
             HIP_CALL(hipStreamCreateWithPriority(&sl.stream, hipStreamNonBlocking, hi));

@@ -1,31 +1,36 @@
 #!/bin/bash
-# PMC passes (one counter group per run, kernel-trace only) for the sampler kernels; output under gpurun_out/pmc_s/<group>
+# PMC passes (one counter group per run, kernel-trace only) for the sampler kernels, once per form of the position state:
+#   bash tools/pmc_sampler.sh direct|table [--scramble]     -> gpurun_out/pmc_s_<form>[_scr]/pmc_sampler_kernels.csv
+FORM=${1:-direct}
+SCR=$2
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
+TAG=pmc_s_$FORM$( [ -n "$SCR" ] && echo _scr )
 i=0
-for grp in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" "SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_VMEM SQ_INSTS_SALU" "FETCH_SIZE" "WRITE_SIZE" "MemUnitStalled LDSBankConflict" "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_WAIT_INST_LDS" "TCC_HIT_sum TCC_MISS_sum" "TCC_ATOMIC_sum TCC_REQ_sum"; do
+rm -f $R/gpurun_out/$TAG/pmc_sampler_kernels.csv
+mkdir -p $R/gpurun_out/$TAG
+for grp in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "TCC_ATOMIC_sum TCC_REQ_sum" "SQ_INSTS_VALU SQ_INSTS_VMEM SQ_INSTS_LDS SQ_INSTS_SALU"; do
   i=$((i+1))
-  out=$R/gpurun_out/pmc_s/g$i
-  mkdir -p $out
-  echo "$grp" > $out/group.txt
-  timeout 300 rocprofv3 --kernel-trace --pmc $grp --output-format csv -d $out -- python3 $R/bench.py --group 64 --steps 128 --warmup 64 --presc-steps 64 --cpu-seconds 0 --no-verify > $out/bench.json 2> $out/err.txt
-  echo "group $i rc=$?"
-  # keep only the folded summary (the raw csv is large)
-  python3 - "$out" <<'PY'
-import csv, glob, sys, collections, json
-d = sys.argv[1]
+  out=/tmp/$TAG/g$i
+  rm -rf $out; mkdir -p $out
+  timeout -k 5 600 rocprofv3 --kernel-trace --pmc $grp --output-format csv -d $out -- python3 $R/bench.py --dedup $FORM $SCR --steps 2 --warmup 1 --presc-steps 64 --cpu-seconds 0 --no-verify --no-boundary --min-seconds 0.01 > $out/bench.json 2> $out/err.txt < /dev/null
+  echo "group $i ($grp) rc=$?"
+  python3 - "$out" "$R/gpurun_out/$TAG/pmc_sampler_kernels.csv" "$FORM$SCR" <<'PY'
+import csv, glob, sys, collections, os
+d, dst, form = sys.argv[1], sys.argv[2], sys.argv[3]
 fs = glob.glob(d + '/*/*counter_collection.csv')
 if not fs: print("no csv"); sys.exit()
 acc = collections.defaultdict(lambda: [0.0, 0])
 for r in csv.DictReader(open(fs[0])):
-    k = (r['Kernel_Name'].split('(')[0][:40], r['Grid_Size'], r['Counter_Name'])
+    n = r['Kernel_Name']
+    if 'lg::' not in n: continue
+    k = (n.split('(')[0][:48], r['Grid_Size'], r['Counter_Name'])
     acc[k][0] += float(r['Counter_Value']); acc[k][1] += 1
-with open(d + '/summary.csv', 'w') as f:
-    f.write("kernel,grid,counter,avg,launches\n")
+new = not os.path.exists(dst)
+with open(dst, 'a') as f:
+    if new: f.write("position_state,kernel,grid_threads,counter,avg_per_launch,launches\n")
     for k, v in sorted(acc.items()):
-        f.write(f"{k[0]},{k[1]},{k[2]},{v[0]/v[1]:.1f},{v[1]}\n")
-import os
-for p in fs + glob.glob(d + '/*/*kernel_trace.csv') + glob.glob(d + '/*/*agent_info.csv'):
-    os.remove(p)
+        f.write(f"{form},{k[0]},{k[1]},{k[2]},{v[0]/v[1]:.1f},{v[1]}\n")
 PY
 done
+wc -l $R/gpurun_out/$TAG/pmc_sampler_kernels.csv
