@@ -74,6 +74,8 @@ def parse_args():
     ap.add_argument("--split", action="store_true",
                     help="sampler phase and gather phase of every group on two streams (sampler k+1 under gathers k)")
     ap.add_argument("--no-verify", action="store_true")
+    ap.add_argument("--no-overlap-leg", action="store_true",
+                    help="skip the extra timed region with sampler and gather phases overlapped on two streams")
     ap.add_argument("--no-boundary", action="store_true",
                     help="skip the drop-in boundary leg (sampling_server binary -> shm/semaphores/IPC handles -> ipc_service "
                          "consumer on an RMAT-22 data set written in the reference's file formats; N = 1 only, ~15 s)")
@@ -279,13 +281,14 @@ def main():
     pipe.run_range(0, n_warm)
     pipe.wait()
 
-    def timed_region():
+    def timed_region(p=None):
+        p = p or pipe
         if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        last = pipe.run_range(first, n_timed)
-        pipe.wait()
+        last = p.run_range(first, n_timed)
+        p.wait()
         torch.cuda.synchronize()
         if use_dist:
             dist.barrier()
@@ -336,6 +339,26 @@ def main():
     prof = pipe.profile_read()
     pipe.profile_end()
     prof = {op: (ms - warm.get(op, (0.0, 0))[0], cnt - warm.get(op, (0.0, 0))[1]) for op, (ms, cnt) in prof.items()}
+
+    # ---- the same K steps once more with every group's sampler phase and gather phase on two streams (sampler k+1 runs
+    #      under gathers k, pipeline.hip `split`): reported beside the headline as `overlapped`, not as `value`, because
+    #      two kernels sharing the machine make the per-kernel roofline of the timed region meaningless.  --split makes
+    #      this arrangement the headline instead. ------------------------------------------------------------------
+    overlapped = None
+    if not args.split and not args.no_overlap_leg:
+        pipe.close()
+        pipe = engine.Pipeline(graph, feature, cache, d, B, fanout, G, feature_rows, not args.no_graph, args.slots, False, True)
+        pipe.run_range(0, n_warm)
+        pipe.wait()
+        ov0, _ = timed_region(pipe)
+        reps2 = torch.tensor([max(1, min(args.max_repeats, int(np.ceil(0.5 * args.min_seconds / max(ov0, 1e-6)))))],
+                             dtype=torch.int64, device=dev)
+        if use_dist:
+            dist.all_reduce(reps2, op=dist.ReduceOp.MAX)
+        ov = torch.tensor([ov0] + [timed_region(pipe)[0] for _ in range(int(reps2.item()) - 1)], dtype=torch.float64, device=dev)
+        if use_dist:
+            dist.all_reduce(ov, op=dist.ReduceOp.MAX)
+        overlapped = float(np.median(ov.cpu().numpy())), int(ov.numel())
 
     tot_edges = torch.tensor([float(edges.sum())], dtype=torch.float64, device=dev)
     gather_bytes_t = torch.tensor([float(rows.sum() * D * 4)], dtype=torch.float64, device=dev)
@@ -424,6 +447,13 @@ def main():
                                      "hipGraph replay, timed region: %.4f)"
                                      % (H, args.steps, G, elapsed_profiled / args.steps * 1e3, elapsed_max / args.steps * 1e3)},
             "setup_seconds": setup_s,
+            "overlapped": None if overlapped is None else {
+                "value": float(tot_edges.item()) / overlapped[0], "unit": "edges/s", "ms_per_step": overlapped[0] / args.steps * 1e3,
+                "repeats": overlapped[1],
+                "note": "same K steps, same batches, with every group's sampler phase on one stream and its gathers on another "
+                        "(sampler k+1 runs under gathers k; `bench.py --split` makes this the headline).  Each kernel runs "
+                        "slower while sharing the machine (the gather at ~0.59 of peak instead of 0.76) but the group finishes "
+                        "sooner: at ~6.5 GB of HBM sector traffic per step the pipeline is then bound by total traffic."},
             "position_state": {"form": "table" if pipe.pools[0][0].uses_table() else "direct",
                                "bytes_per_lane": pipe.pools[0][0].state_bytes(), "lanes": G * args.slots},
             "feature_cache_hit_rate": feat_hit_rows / max(feat_hit_rows + feat_miss_rows, 1),

@@ -13,7 +13,7 @@ for grp in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" "FETCH_
   i=$((i+1))
   out=/tmp/$TAG/g$i
   rm -rf $out; mkdir -p $out
-  timeout -k 5 600 rocprofv3 --kernel-trace --pmc $grp --output-format csv -d $out -- python3 $R/bench.py --dedup $FORM $SCR --steps 2 --warmup 1 --presc-steps 64 --cpu-seconds 0 --no-verify --no-boundary --min-seconds 0.01 > $out/bench.json 2> $out/err.txt < /dev/null
+  timeout -k 5 600 rocprofv3 --kernel-trace --pmc $grp --output-format csv -d $out -- python3 $R/bench.py --dedup $FORM $SCR --steps 2 --warmup 1 --presc-steps 64 --cpu-seconds 0 --no-verify --no-boundary --no-overlap-leg --min-seconds 0.01 > $out/bench.json 2> $out/err.txt < /dev/null
   echo "group $i ($grp) rc=$?"
   python3 - "$out" "$R/gpurun_out/$TAG/pmc_sampler_kernels.csv" "$FORM$SCR" <<'PY'
 import csv, glob, sys, collections, os

@@ -11,7 +11,7 @@ timeout -k 5 600 python3 $R/bench.py --gpus 1 --steps 20 --warmup 5 2> $OUT/benc
 timeout -k 5 600 python3 $R/bench.py 2> $OUT/bench_default.err < /dev/null | tail -1 > $OUT/bench_default.json
 # 2. rocprofv3 --kernel-trace --stats of the same command (no boundary leg: that is another process)
 rm -rf /tmp/prof_stats
-timeout -k 5 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_stats -- python3 $R/bench.py --no-boundary --cpu-seconds 0 > $OUT/bench_default_under_rocprof.json 2> /tmp/prof_stats.err < /dev/null
+timeout -k 5 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_stats -- python3 $R/bench.py --no-boundary --no-overlap-leg --cpu-seconds 0 > $OUT/bench_default_under_rocprof.json 2> /tmp/prof_stats.err < /dev/null
 cp /tmp/prof_stats/*/*kernel_stats.csv $OUT/bench_default_kernel_stats.csv
 cp /tmp/prof_stats/*/*domain_stats.csv $OUT/bench_default_domain_stats.csv
 python3 - /tmp/prof_stats $OUT/bench_default_kernel_trace_by_grid.csv <<'PY'
@@ -31,7 +31,7 @@ PY
 # 3. HBM traffic of the dominant kernel: separate --pmc passes (kernel-trace only), gfx950 corrections in pmc_summary.py
 for c in FETCH_SIZE WRITE_SIZE; do
   rm -rf /tmp/pmc_$c; mkdir -p /tmp/pmc_$c
-  timeout -k 5 900 rocprofv3 --kernel-trace --pmc $c --output-format csv -d /tmp/pmc_$c -- python3 $R/bench.py --steps 4 --warmup 2 --presc-steps 64 --cpu-seconds 0 --no-verify --no-boundary --min-seconds 0.01 > /tmp/pmc_$c/bench.json 2> /tmp/pmc_$c/err.txt < /dev/null
+  timeout -k 5 900 rocprofv3 --kernel-trace --pmc $c --output-format csv -d /tmp/pmc_$c -- python3 $R/bench.py --steps 4 --warmup 2 --presc-steps 64 --cpu-seconds 0 --no-verify --no-boundary --no-overlap-leg --min-seconds 0.01 > /tmp/pmc_$c/bench.json 2> /tmp/pmc_$c/err.txt < /dev/null
 done
 python3 $R/tools/pmc_summary.py /tmp/pmc_FETCH_SIZE /tmp/pmc_WRITE_SIZE $OUT/pmc_gather_kernel.json > /dev/null
 cut -c1-300 $OUT/bench_default.json
