@@ -470,7 +470,8 @@ def main():
         if world == 1 and not args.no_boundary and args.placement == "hbm":
             out.update(boundary_leg(args, fanout))
         if args.cpu_seconds > 0 and world == 1:      # reported at N = 1 only
-            out["cpu_baseline"] = cpu_baseline(indptr, col, mine, N, B, fanout, first, args.cpu_seconds)
+            out["cpu_baseline"] = cpu_baseline(indptr, col, mine, N, B, fanout, first, args.cpu_seconds,
+                                               features if args.placement == "hbm" else None)
         json_out.write(json.dumps(out) + "\n")
         json_out.flush()
     if use_dist:
@@ -497,9 +498,9 @@ def boundary_leg(args, fanout):
         return {"boundary_batches_per_sec": None, "boundary": {"error": repr(e)[:300]}}
 
 
-def cpu_baseline(indptr, col, seeds, N, B, fanout, first_batch, target_s):
-    """The oracle's sampler (same Legion semantics, same batches) on the host cores; topology only
-    (a 34 GB host copy of the feature table is not worth the PCIe time), so the unit is edges/s."""
+def cpu_baseline(indptr, col, seeds, N, B, fanout, first_batch, target_s, features=None):
+    """The oracle's sampler (same Legion semantics, same batches) on the host cores: `value` is sampling only;
+    `with_gather` adds the oracle's feature gather over a host copy of the table when the host has the memory for it."""
     from oracle import ffi
     L = ffi.load()
     ip = indptr.cpu().numpy()
@@ -509,12 +510,14 @@ def cpu_baseline(indptr, col, seeds, N, B, fanout, first_batch, target_s):
     fan = np.asarray(fanout, dtype=np.int32)
     sd = np.ascontiguousarray(seeds, dtype=np.int32)
 
-    def timed(nb, threads=cores):
+    def timed(nb, threads=cores, feats=None):
         secs = ctypes.c_double(0)
         nodes = ctypes.c_int64(0)
         e = L.lgo_bench_batches(ctypes.byref(g.g), N, ffi._p(sd, ffi.P_I32), int(sd.size), B, ffi._p(fan, ffi.P_I32),
-                                len(fanout), first_batch, nb, threads, None, 0, ctypes.byref(secs), ctypes.byref(nodes))
-        return int(e), secs.value
+                                len(fanout), first_batch, nb, threads,
+                                feats.ctypes.data_as(ffi.P_F32) if feats is not None else None,
+                                int(feats.shape[1]) if feats is not None else 0, ctypes.byref(secs), ctypes.byref(nodes))
+        return int(e), secs.value, int(nodes.value)
 
     dgl_note = "DGL unavailable on this box (import dgl failed); the oracle's C sampler stands in (BASELINE.md 2.3)"
     try:
@@ -522,17 +525,32 @@ def cpu_baseline(indptr, col, seeds, N, B, fanout, first_batch, target_s):
         dgl_note = "dgl importable but not used: its sampler has different semantics (SURVEY.md A.9)"
     except Exception:
         pass
-    e, s = timed(cores)                       # calibration: one batch per thread
+    e, s, _ = timed(cores)                    # calibration: one batch per thread
     nb = int(max(cores, min(cores * 64, cores * target_s / max(s, 1e-3))))
     nb = min(nb, (sd.size - 1) // B - first_batch)
-    e, s = timed(nb)
-    e1, s1 = timed(4, 1)                      # the same sampler on one thread (SURVEY 8d asks for both)
-    e1, s1 = timed(int(max(4, min(256, 2.0 * 4 / max(s1, 1e-3)))), 1)
-    return {"value": e / s, "unit": "edges/s", "cores": cores, "kind": "port",
-            "single_thread_edges_per_sec": e1 / s1,
-            "sample": f"{nb} batches of {B} seeds (same RMAT graph, same fan-out, sampling only, no gather), "
-                      f"{s:.1f} s on {cores} threads",
-            "dgl": dgl_note}
+    e, s, _ = timed(nb)
+    e1, s1, _ = timed(4, 1)                   # the same sampler on one thread (SURVEY 8d asks for both)
+    e1, s1, _ = timed(int(max(4, min(256, 2.0 * 4 / max(s1, 1e-3)))), 1)
+    out = {"value": e / s, "unit": "edges/s", "cores": cores, "kind": "port",
+           "single_thread_edges_per_sec": e1 / s1,
+           "sample": f"{nb} batches of {B} seeds (same RMAT graph, same fan-out, sampling only, no gather), "
+                     f"{s:.1f} s on {cores} threads",
+           "dgl": dgl_note}
+    # the whole path on the CPU (sampling + the oracle's row gather) when a host copy of the table is affordable
+    try:
+        import psutil
+        table_bytes = int(features.numel()) * 4 if features is not None else 0
+        if features is not None and 0 < table_bytes <= 48 << 30 and psutil.virtual_memory().available > 2 * table_bytes + (32 << 30):
+            host = features.cpu().numpy()
+            nb2 = max(cores, nb // 4)
+            e2, s2, n2 = timed(nb2, cores, host)
+            out["with_gather"] = {"edges_per_sec": e2 / s2, "feature_gather_GBps": n2 * host.shape[1] * 4 / s2 / 1e9,
+                                  "sample": f"{nb2} batches, sampling + gather of {n2} rows from a host copy of the table, "
+                                            f"{s2:.1f} s on {cores} threads"}
+            del host
+    except Exception as ex:       # reported baseline only: never fail the bench over it
+        out["with_gather"] = {"error": repr(ex)[:200]}
+    return out
 
 
 if __name__ == "__main__":

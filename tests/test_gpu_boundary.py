@@ -28,8 +28,18 @@ def write_dataset(path, wl_indptr, wl_col, feats, labels, train, valid, test):
     test.astype(np.int32).tofile(os.path.join(path, "testingset"))
 
 
-def test_server_binary_serves_fake_trainer(hip, tmp_path):
+@pytest.mark.parametrize("server_env", [
+    {},                                                        # defaults: launch groups of up to 128 batches, counter mirror
+    {"LEGION_RUNNER_LANES": "3"},                              # many small groups: prefetch, partial groups, mode changes mid-run
+    {"LEGION_RUNNER_LANES": "4", "LEGION_DEDUP": "table"},     # compact position state inside the server
+    {"LEGION_RUNNER_LANES": "1", "LEGION_RUNNER_PAIR": "0"},   # one batch per group
+    {"LEGION_RUNNER_GRAPH": "0"},                              # the reference's operator-by-operator Runner
+    {"LEGION_NO_SHM_MIRROR": "1"},                             # counters copied from the device, as the reference's trainer end does
+], ids=["default", "lanes3", "lanes4-table", "lanes1", "operators", "no-mirror"])
+def test_server_binary_serves_fake_trainer(hip, tmp_path, server_env, monkeypatch):
     import torch
+    for k, v in server_env.items():
+        monkeypatch.setenv(k, v)
     sys.path.insert(0, os.path.join(ROOT, "legion_amd", "trainer"))
     import ipc_service
 
@@ -47,8 +57,8 @@ def test_server_binary_serves_fake_trainer(hip, tmp_path):
     (work / "meta_config").write_text("{} {} {} {} {} {} {} {} {} {}".format(
         ds, B, N, col.size, D, train.size, valid.size, test.size, cache_memory, epoch))
     ns = f"_t{os.getpid()}"
-    env = dict(os.environ, LEGION_IPC_NAMESPACE=ns)
-    os.environ["LEGION_IPC_NAMESPACE"] = ns
+    monkeypatch.setenv("LEGION_IPC_NAMESPACE", ns)
+    env = dict(os.environ)
     log = open(work / "server.log", "w")
     server = subprocess.Popen([os.path.join(ROOT, "legion_amd", "bin", "sampling_server"), "1", "0"] +
                               [str(f) for f in fanout], cwd=work, env=env, stdout=log, stderr=subprocess.STDOUT)
