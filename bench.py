@@ -67,7 +67,7 @@ def parse_args():
     ap.add_argument("--presc-steps", type=int, default=512, help="PreSC batches per GPU (bounded epoch)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU-baseline time; 0 disables")
     ap.add_argument("--group", type=int, default=0,
-                    help="mini-batches served by every launch (lanes of a group); 0 = 131072 // batch, at most 128")
+                    help="mini-batches served by every launch (lanes of a group); 0 = 262144 // batch, at most 256")
     ap.add_argument("--slots", type=int, default=2, help="groups in flight per GPU")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
     ap.add_argument("--overlap", action="store_true", help="let kernels of different slots share the GPU")
@@ -137,7 +137,7 @@ def main():
     N = 1 << args.scale
     D = args.dim
     B = args.batch
-    G = args.group if args.group > 0 else max(1, min(128, 131072 // B))   # mini-batches per step (launch group)
+    G = args.group if args.group > 0 else max(1, min(256, 262144 // B))   # mini-batches per step (launch group)
     n_warm, n_timed = args.warmup * G, args.steps * G                      # in mini-batches
     t_setup = time.time()
 
@@ -164,8 +164,11 @@ def main():
     need = max(need, (args.presc_steps + 2) * B * world)
     all_seeds = synth.seed_ids(N, min(max(need * 2, N // 10), N), 11)
     mine = np.ascontiguousarray(all_seeds[all_seeds % world == rank])      # storage_management.cu:178
-    assert mine.size > (n_warm + n_timed + 1) * B, \
-        f"not enough seeds for this rank: {mine.size} < {(n_warm + n_timed + 1) * B} (lower --steps/--warmup/--group)"
+    # an epoch = the whole groups this rank's seed set holds; a run longer than that starts another epoch over the same
+    # seeds (the reference's schedule wraps the same way: GetLocalBatchId, ipc_service.cu:213-228)
+    epoch_batches = ((mine.size - 1) // B) // G * G
+    assert epoch_batches >= G, f"the seed set of this rank ({mine.size} ids) holds less than one launch group of {G} x {B}"
+    wrap = epoch_batches if n_warm + n_timed > epoch_batches else None
 
     graph = engine.GraphStorage(P, indptr, col)
     feature = engine.FeatureStorage(P, features)
@@ -245,7 +248,7 @@ def main():
     feat_hit_rows = feat_miss_rows = 0           # over every timed batch (all hops)
     for k in range(n_timed):
         if k % G == 0:
-            slot = pipe.submit(first + k)
+            slot = pipe.submit((first + k) % wrap if wrap else first + k)
             pipe.wait(slot)
         pl = pipe.pools[slot][k % G]
         nc = pl.buffer("node_counter").cpu().numpy()
@@ -278,7 +281,7 @@ def main():
     #      barrier + synchronize brackets.  The region is repeated (same batches: an epoch over the same
     #      seeds, replays are deterministic) until --min-seconds have been timed; every rank runs the same
     #      number of repeats, per repeat the MAX over ranks counts, and the median repeat is reported. -------
-    pipe.run_range(0, n_warm)
+    pipe.run_range(0, n_warm, wrap=wrap)
     pipe.wait()
 
     def timed_region(p=None):
@@ -287,7 +290,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        last = p.run_range(first, n_timed)
+        last = p.run_range(first, n_timed, wrap=wrap)
         p.wait()
         torch.cuda.synchronize()
         if use_dist:
@@ -319,7 +322,7 @@ def main():
             pl = pipe.pools[slot][lane]
             nc = pl.buffer("node_counter").cpu().numpy()
             ec = pl.buffer("edge_counter").cpu().numpy()
-            k = k0 - first + lane
+            k = n_timed - n_lanes + lane          # the last group submitted holds the last n_lanes batches of the region
             assert ec[9 + H] == edges[k] and nc[9 + H] - nc[9] == rows[k, 1:].sum(), f"replayed batch {k0 + lane} differs"
         n = int(nc[9 + H])
         ids = pl.buffer("sampled_ids")[:n]
@@ -329,11 +332,11 @@ def main():
     # ---- the same K batches once more with HIP events around every gather launch (recorded on the
     #      lane's own stream).  Eager launches: HIP cannot time events recorded by graph nodes. ------
     pipe.profile_begin()
-    pipe.run_range(0, n_warm)
+    pipe.run_range(0, n_warm, wrap=wrap)
     pipe.wait()
     warm = pipe.profile_read()
     t1 = time.perf_counter()
-    pipe.run_range(first, n_timed)
+    pipe.run_range(first, n_timed, wrap=wrap)
     pipe.wait()
     elapsed_profiled = time.perf_counter() - t1
     prof = pipe.profile_read()
@@ -348,7 +351,7 @@ def main():
     if not args.split and not args.no_overlap_leg:
         pipe.close()
         pipe = engine.Pipeline(graph, feature, cache, d, B, fanout, G, feature_rows, not args.no_graph, args.slots, False, True)
-        pipe.run_range(0, n_warm)
+        pipe.run_range(0, n_warm, wrap=wrap)
         pipe.wait()
         ov0, _ = timed_region(pipe)
         reps2 = torch.tensor([max(1, min(args.max_repeats, int(np.ceil(0.5 * args.min_seconds / max(ov0, 1e-6)))))],
@@ -420,7 +423,8 @@ def main():
                        "parallelism": (f"seed-sharded x{world}, replicated graph+features, one clique of {world}: caches "
                                        f"striped over the ranks, peer reads over xGMI (cache_agg_mode {int(np.log2(world))})")
                        if stripe else f"seed-sharded x{world}, replicated graph+features, cache_agg_mode 0",
-                       "batches_per_launch_group": G, "groups_in_flight": args.slots, "hipgraph": not args.no_graph,
+                       "batches_per_launch_group": G, "groups_in_flight": args.slots, "epoch_batches": epoch_batches,
+                       "epochs_wrap": bool(wrap), "hipgraph": not args.no_graph,
                        "cache_memory_bytes": args.cache_memory,
                        "feature_cache_rows": cache.node_capacity(d), "topology_cache_vertices": cache.edge_capacity(d),
                        "presc_batches": train_step, "presc_topology_transactions": topo_tx,

@@ -301,13 +301,16 @@ class Pipeline:
             return int(self._lib.legion_pipeline_submit(self.handle, int(counter0), int(mode)))
         return int(self._lib.legion_pipeline_submit_n(self.handle, int(counter0), int(mode), int(n_active)))
 
-    def run_range(self, first, count, mode=TRAINMODE):
+    def run_range(self, first, count, mode=TRAINMODE, wrap=None):
         """Submits batches first .. first+count-1 as full groups plus, if needed, one partial group.
+        `wrap` (a number of batches): batch indices are taken modulo it -- another epoch over the same seed set, as
+        the reference's schedule does with GetLocalBatchId (ipc_service.cu:213-228); a group never straddles the wrap.
         Returns (slot, first batch, lanes) of the last group submitted."""
         k, last = 0, None
         while k < count:
-            n = min(self.group_size, count - k)
-            last = (self.submit(first + k, mode, n), first + k, n)
+            b = (first + k) % wrap if wrap else first + k
+            n = min(self.group_size, count - k, (wrap - b) if wrap else count)
+            last = (self.submit(b, mode, n), b, n)
             k += n
         return last
 
