@@ -125,6 +125,15 @@ LegionUnifiedCache* legion_cache_create(int64_t cache_memory, int32_t float_feat
                                         int32_t train_step, int32_t device_count,
                                         int32_t total_num_nodes);
 void legion_cache_init_controller(LegionUnifiedCache* c, int32_t dev_id);
+/* New in this build (no counterpart in the reference, whose GPUs had 16-80 GB): with caches striped over a clique of Kg
+ * GPUs (cache_impl.cuh:89-109) every member may ALSO keep a private copy of the clique's hottest rows, as many as
+ * `bytes` hold.  Lookup results (hit mask, global slot in cache_search_buffer) are unchanged; a hit whose hotness rank is
+ * below the replica size is read from local HBM instead of a peer over xGMI.  Call before legion_cache_fill_up*. */
+void legion_cache_set_replica_memory(LegionUnifiedCache* c, int64_t bytes);
+int32_t legion_cache_replica_rows(const LegionUnifiedCache* c, int32_t dev_id);
+/* Enables row-source statistics of the gathers on dev_id (Kg > 1) and returns the totals so far:
+ * out2[0] rows read through a stripe pointer (own or peer), out2[1] rows read from the local replica. */
+void legion_cache_gather_stats(LegionUnifiedCache* c, int32_t dev_id, uint64_t* out2);
 /* SS/cache/cache.cu:360-443.  Hotness is summed over the clique on the clique leader through
  * peer pointers (one process, several GPUs); when `world_reduced` is non-zero the caller has
  * already all-reduced the counters across processes with RCCL and they are used as they are. */

@@ -405,6 +405,21 @@ void UnifiedCache::FillUpLocal(FeatureStorage* feature, GraphStorage* graph)
                                  QF_[i], Kg_, j, N);
                 HIP_CALL(hipDeviceSynchronize());
                 float_feature_cache_[dev_id] = new_cache;
+                // hot-row replica: ranks 0 .. R-1 of the clique order, identical on every member (Kg = 1 addressing)
+                if ((int32_t)replica_.size() < device_count_) { replica_.resize(device_count_, nullptr); replica_rows_.resize(device_count_, 0); }
+                d_free_space(replica_[dev_id]);
+                replica_[dev_id] = nullptr;
+                replica_rows_[dev_id] = 0;
+                if (replica_bytes_ > 0 && Kg_ > 1) {
+                    int64_t rows = replica_bytes_ / ((int64_t)float_feature_len_ * sizeof(float));
+                    rows = std::min<int64_t>(rows, std::min<int64_t>((int64_t)node_capacity_[i] * Kg_, N));
+                    if (rows > 0) {
+                        replica_[dev_id] = (float*)d_alloc_space(rows * float_feature_len_ * sizeof(float));
+                        lg::feat_fill_up(nullptr, (int32_t)rows, float_feature_len_, replica_[dev_id], cpu_float_feature, QF_[i], 1, 0, N);
+                        HIP_CALL(hipDeviceSynchronize());
+                        replica_rows_[dev_id] = (int32_t)rows;
+                    }
+                }
             }
         }
     for (int32_t i = 0; i < Kc_; i++)
@@ -436,6 +451,17 @@ void UnifiedCache::FillUpLink(FeatureStorage* feature, GraphStorage* graph)
 
 int32_t UnifiedCache::MaxIdNum(int32_t dev_id) { return cache_controller_[dev_id]->MaxIdNum(); }
 
+unsigned long long* UnifiedCache::GatherStats(int32_t dev_id)
+{
+    if ((int32_t)gather_stats_.size() < device_count_) gather_stats_.resize(device_count_, nullptr);
+    if (gather_stats_[dev_id] == nullptr) {
+        SetGPUDevice(dev_id);
+        gather_stats_[dev_id] = (unsigned long long*)d_alloc_space(2 * sizeof(unsigned long long));
+        HIP_CALL(hipMemset(gather_stats_[dev_id], 0, 2 * sizeof(unsigned long long)));
+    }
+    return gather_stats_[dev_id];
+}
+
 unsigned long long int* UnifiedCache::GetEdgeAccessedMap(int32_t dev_id)
 {
     return cache_controller_[dev_id]->GetEdgeAccessedMap();
@@ -449,6 +475,10 @@ void UnifiedCache::FeatCacheLookup(const LanePtrs* d_lanes, int32_t n_lanes, int
                         cache_controller_[dev_id]->NodeMap() != nullptr;
     (void)op_id;
     lg::GatherParams g;
+    g.replica = (filled && dev_id < (int32_t)replica_.size()) ? replica_[dev_id] : nullptr;
+    g.replica_rows = g.replica ? replica_rows_[dev_id] : 0;
+    g.Kg = Kg_;
+    g.stats = (dev_id < (int32_t)gather_stats_.size()) ? gather_stats_[dev_id] : nullptr;
     g.full_table = cpu_float_features_;
     g.cache_tables = filled ? d_float_feature_cache_ptr_[dev_id] : nullptr;
     g.node_map = filled ? cache_controller_[dev_id]->NodeMap() : nullptr;
@@ -470,6 +500,28 @@ struct LegionCacheBox {   // the UnifiedCache plus what the C API needs to remem
 
 static UnifiedCache* as_cache(LegionUnifiedCache* c) { return c ? &reinterpret_cast<LegionCacheBox*>(c)->cache : nullptr; }
 static const UnifiedCache* as_cache(const LegionUnifiedCache* c) { return c ? &reinterpret_cast<const LegionCacheBox*>(c)->cache : nullptr; }
+
+extern "C" void legion_cache_set_replica_memory(LegionUnifiedCache* c, int64_t bytes)
+{
+    if (UnifiedCache* u = as_cache(c)) u->SetReplicaMemory(bytes);
+}
+extern "C" int32_t legion_cache_replica_rows(const LegionUnifiedCache* c, int32_t dev_id)
+{
+    const UnifiedCache* u = as_cache(c);
+    return u ? u->ReplicaRows(dev_id) : 0;
+}
+// enables the gather's row-source statistics for dev_id and returns {rows read from a peer's stripe, rows read from the
+// local replica} counted so far (device counters, read back here)
+extern "C" void legion_cache_gather_stats(LegionUnifiedCache* c, int32_t dev_id, uint64_t* out2)
+{
+    UnifiedCache* u = as_cache(c);
+    if (!u) return;
+    unsigned long long* d = u->GatherStats(dev_id);
+    unsigned long long h[2] = {0, 0};
+    HIP_CALL(hipDeviceSynchronize());
+    HIP_CALL(hipMemcpy(h, d, sizeof(h), hipMemcpyDeviceToHost));
+    if (out2) { out2[0] = h[0]; out2[1] = h[1]; }
+}
 
 extern "C" LegionUnifiedCache* legion_cache_create(int64_t cache_memory, int32_t float_feature_len,
                                                    int32_t train_step, int32_t device_count,

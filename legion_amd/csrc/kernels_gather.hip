@@ -142,7 +142,14 @@ __global__ __launch_bounds__(LG_GATHER_THREADS) void gather_kernel(GatherParams 
             if (id >= 0) p = LG_GPTR(const float, gp.full_table) + (int64_t)(id % gp.total_num_nodes) * D;   // :262-266
         } else {
             const int32_t didx = g / gp.node_capacity, fidx = g - didx * gp.node_capacity;   // :259-260
-            p = LG_GPTR(const float, gp.cache_tables[didx]) + (int64_t)fidx * D;                                   // :268
+            const int64_t rank = (int64_t)fidx * gp.Kg + didx;                               // hotness rank of the row (cache_impl.cuh:104-109)
+            const bool local_copy = gp.replica != nullptr && rank < gp.replica_rows;
+            if (local_copy)      // the clique's hottest rows are also kept locally: same row, no xGMI hop
+                p = LG_GPTR(const float, gp.replica) + rank * D;
+            else
+                p = LG_GPTR(const float, gp.cache_tables[didx]) + (int64_t)fidx * D;                               // :268
+            if (gp.stats != nullptr && gp.Kg > 1)      // tests / diagnostics: [0] rows read through a stripe pointer, [1] from the replica
+                atomicAdd(gp.stats + (local_copy ? 1 : 0), 1ull);
         }
         s_ptr[t] = p;
     }

@@ -418,6 +418,13 @@ public:
     void SetPeerFeatureCache(int32_t dev, float* ptr) { float_feature_cache_[dev] = ptr; }
     float* FeatureCachePtr(int32_t dev) const { return float_feature_cache_[dev]; }
     void SetPeerMaxIds(const int32_t* v, int32_t n) { peer_max_ids_.assign(v, v + n); }
+    // Hot-row replica (new; MI355X has 288 GB per GPU): besides its stripe of the clique's cache every member keeps a
+    // private copy of the clique's hottest rows, as many as `bytes` hold.  The lookup result (hit mask, global slot) is
+    // unchanged -- only where a hit row is READ changes: ranks below the replica size come from local HBM instead of a
+    // peer over xGMI.  Set before FillUp.
+    void SetReplicaMemory(int64_t bytes) { replica_bytes_ = bytes; }
+    int32_t ReplicaRows(int32_t dev_id) const { return replica_rows_.empty() ? 0 : replica_rows_[dev_id]; }
+    unsigned long long* GatherStats(int32_t dev_id);   // device {peer rows, replica rows}, allocated on first use
     int32_t MaxIdNum(int32_t dev_id);
     unsigned long long int* GetEdgeAccessedMap(int32_t dev_id);
     // the gather over a group of lanes (the reference's per-array arguments live in LanePtrs)
@@ -453,6 +460,10 @@ private:
     float* cpu_float_features_ = nullptr;
     bool is_presc_ = true;
     std::vector<int32_t> peer_max_ids_;   // MaxIdNum of every clique member when they live in other processes
+    int64_t replica_bytes_ = 0;
+    std::vector<float*> replica_;         // [device] hottest rows of its clique in rank order, or null
+    std::vector<int32_t> replica_rows_;
+    std::vector<unsigned long long*> gather_stats_;
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -592,6 +603,10 @@ struct DeliverParams {
 
 struct GatherParams {
     const float* full_table;
+    const float* replica;           // local copy of the clique's `replica_rows` hottest rows (hotness rank order), or null
+    int32_t replica_rows;
+    int32_t Kg;                     // GPUs per clique: rank t of a hit = (g % cap) * Kg + g / cap
+    unsigned long long* stats;      // optional {rows served from a peer's stripe, rows served from the local replica}
     const float* const* cache_tables;
     const int32_t* node_map;
     int32_t node_capacity;

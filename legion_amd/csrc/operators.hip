@@ -304,6 +304,10 @@ extern "C" void legion_gather_rows(legion_stream_t stream, const float* full_tab
                                    const int32_t* range_devptr, float* dst, int32_t max_rows)
 {
     lg::GatherParams g;
+    g.replica = nullptr;
+    g.replica_rows = 0;
+    g.Kg = 1;
+    g.stats = nullptr;
     g.full_table = full_table;
     g.cache_tables = cache_tables;
     g.node_map = node_map;

@@ -625,7 +625,9 @@ private:
             for (uint32_t idle = 0;;) {
                 if (q_tail_.load(std::memory_order_acquire) == head) {
                     if (stop_.load(std::memory_order_acquire) && q_tail_.load(std::memory_order_acquire) == head) return;
-                    if ((++idle & 4095) == 0) std::this_thread::yield();
+                    ++idle;
+                    if (idle > (1u << 18)) std::this_thread::sleep_for(std::chrono::microseconds(50));   // trainer is slow: stop burning the core
+                    else if ((idle & 4095) == 0) std::this_thread::yield();
                     continue;
                 }
                 const Pending job = ring_[head % kRing];

@@ -360,6 +360,19 @@ class UnifiedCache:
         cnt = (ctypes.c_uint64 * 2)(int(counters[0]), int(counters[1]))
         self._lib.legion_cache_cost_model(self.handle, feature.handle, graph.handle, cnt, int(train_step))
 
+    def set_replica_memory(self, nbytes):
+        """Every member of a striped clique also keeps the clique's hottest rows locally, as many as nbytes hold."""
+        self._lib.legion_cache_set_replica_memory(self.handle, int(nbytes))
+
+    def replica_rows(self, dev_id=0):
+        return int(self._lib.legion_cache_replica_rows(self.handle, int(dev_id)))
+
+    def gather_stats(self, dev_id=0):
+        """(rows read through a stripe pointer, rows read from the local replica) so far; the first call enables counting."""
+        out = (ctypes.c_uint64 * 2)()
+        self._lib.legion_cache_gather_stats(self.handle, int(dev_id), out)
+        return int(out[0]), int(out[1])
+
     def set_capacity(self, node_capacity, edge_capacity):
         self._lib.legion_cache_set_capacity(self.handle, int(node_capacity), int(edge_capacity))
 

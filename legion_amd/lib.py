@@ -42,6 +42,9 @@ SIGNATURES = {
     "legion_pool_error": (c_i32, [c_p]),
     "legion_cache_create": (c_p, [c_i64, c_i32, c_i32, c_i32, c_i32]),
     "legion_cache_init_controller": (None, [c_p, c_i32]),
+    "legion_cache_set_replica_memory": (None, [c_p, c_i64]),
+    "legion_cache_replica_rows": (c_i32, [c_p, c_i32]),
+    "legion_cache_gather_stats": (None, [c_p, c_i32, P_U64]),
     "legion_cache_candidate_selection": (None, [c_p, c_i32, c_p, c_i32]),
     "legion_cache_cost_model": (None, [c_p, c_p, c_p, P_U64, c_i32]),
     "legion_cache_set_capacity": (None, [c_p, c_i32, c_i32]),

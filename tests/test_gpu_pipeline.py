@@ -275,6 +275,47 @@ def test_wide_position_format(hip, dedup, monkeypatch):
         gpu.close(); cpu.close()
 
 
+@pytest.mark.parametrize("P,mode_bits,capacity,replica_rows", [(4, 2, (64, 33), 40), (8, 3, (40, 20), 100), (2, 1, (150, 90), 10_000)])
+def test_hot_row_replica_keeps_results_and_saves_peer_reads(hip, P, mode_bits, capacity, replica_rows):
+    """Striped clique + a local replica of the clique's hottest rows on every member: batches, hit masks and global slots
+    stay bit-identical to the oracle's striped clique (the replica only changes WHERE a hit row is read), and the rows of
+    rank < replica size are no longer read through a stripe pointer."""
+    wl = Workload(scale=11, edge_factor=8, dim=32, partition_count=P, n_seeds=1200)
+    fanout, batch = [5, 4], 64
+    gpu, cpu = GpuSide(wl, batch, fanout), CpuSide(wl, batch, fanout)
+    steps = min((wl.sets[(p, 0)][0].size - 1) // batch for p in range(P))
+    for p in range(P):
+        for it in range(steps):
+            gpu.run(p, it, 0, is_presc=True); cpu.run(p, it, 0, is_presc=True)
+    gpu.cache.candidate_selection(mode_bits, gpu.graph)
+    gpu.cache.set_capacity(*capacity)
+    gpu.cache.set_replica_memory(replica_rows * wl.D * 4)
+    gpu.cache.fill_up(gpu.feature, gpu.graph)
+    cpu.build_cache(mode_bits, capacity=capacity)
+    Kg = cpu.Kg
+    want_rows = min(replica_rows, capacity[0] * Kg)
+    for p in range(P):
+        assert gpu.cache.replica_rows(p) == want_rows
+        assert gpu.cache.gather_stats(p) == (0, 0)                 # enables the counters
+    for p in range(P):
+        hits = from_replica = 0
+        for it in range(2):
+            g, c = gpu.run(p, it, 0), cpu.run(p, it, 0)
+            compare_batches(g, c, f"replica gpu {p} batch {it}: ")
+            assert np.array_equal(g["cache_search_buffer"], c["cache_search_buffer"])
+        # hits and their hotness ranks over everything this GPU gathered (all hops of both batches): replay on the host
+        node_map = gpu.cache.array("node_map", p).cpu().numpy()
+        for it in range(2):
+            ids = cpu.run(p, it, 0)["sampled_ids"]
+            gslot = node_map[ids]
+            hit = gslot >= 0
+            rank = (gslot[hit] % capacity[0]) * Kg + gslot[hit] // capacity[0]
+            hits += int(hit.sum()); from_replica += int((rank < want_rows).sum())
+        stripe, replica = gpu.cache.gather_stats(p)
+        assert (stripe, replica) == (hits - from_replica, from_replica) and replica > 0
+    gpu.close(); cpu.close()
+
+
 def test_crowded_position_table(hip, monkeypatch):
     """The compact table under pressure: forced down to 2^10 words for batches of up to ~950 distinct vertices
     (load up to 0.93), so that claims walk long probe runs and displaced words are carried far.  Still bit-exact,
