@@ -87,6 +87,9 @@ def parse_args():
     ap.add_argument("--stripe", action="store_true",
                     help="N > 1: one clique of N GPUs, feature/topology caches striped over the ranks and read "
                          "through peer pointers over xGMI (default: every GPU caches for itself, no peer traffic)")
+    ap.add_argument("--replica-memory", type=int, default=0,
+                    help="with --stripe: bytes per GPU for a private copy of the clique's hottest rows (hits below that hotness "
+                         "rank are read from local HBM instead of a peer over xGMI; lookup results unchanged)")
     ap.add_argument("--backend", type=str, default="nccl", help="torch.distributed backend (nccl = RCCL)")
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise torch.distributed and run the collectives even at N = 1 (exercises the RCCL calls on a 1-GPU box)")
@@ -224,6 +227,8 @@ def main():
             dist.all_gather_object(out, b)
             return out
 
+        if args.replica_memory > 0:
+            cache.set_replica_memory(args.replica_memory)
         cache.fill_up_distributed(feature, graph, d, world, mids, all_gather_bytes)
         dist.barrier()
     else:
@@ -429,7 +434,8 @@ def main():
                        "feature_cache_rows": cache.node_capacity(d), "topology_cache_vertices": cache.edge_capacity(d),
                        "presc_batches": train_step, "presc_topology_transactions": topo_tx,
                        "presc_pcie_transactions_gpu_metrics": pcie_tx, "link_counters": args.link_counters,
-                       "cost_model_counters": list(counters)},
+                       "cost_model_counters": list(counters),
+                       "hot_row_replica_rows": cache.replica_rows(d)},
             "feature_gather_GBps": payload_gbps * 1.0,
             "feature_gather_GBps_note": "payload bytes read (rows*D*4) / HIP-event time of all gather launches, rank 0",
             "sampling_only": {"edges_per_sec": float(edges.sum()) / t_sampling, "algorithmic_GBps": samp_bytes / t_sampling / 1e9,
