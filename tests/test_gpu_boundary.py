@@ -181,3 +181,20 @@ def test_server_rejects_a_mismatched_dataset(hip, tmp_path, damage, needle):
             os.unlink(os.path.join("/dev/shm", name))
     assert res.returncode != 0 and needle in res.stdout, res.stdout[-2000:]
     assert "System is ready for serving" not in res.stdout
+
+
+@pytest.mark.parametrize("lanes", ["16", "5"])
+def test_boundary_soak_every_batch_verified(hip, lanes):
+    """600+ consecutive hand-overs through the binary and the two pipe slots with a consumer that checks EVERY batch on the
+    device (rows = the generator's rows of the batch's ids, unique ids, edge endpoints inside the batch, the seeds are the
+    training batch's): a wrong slot, a stale or half-copied batch, a lost or duplicated post shows up here."""
+    import json
+    env = dict(os.environ, LEGION_RUNNER_LANES=lanes)
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "server_throughput.py"), "--scale", "16", "--batch", "100",
+                          "--dim", "32", "--fanout", "6,4", "--train-batches", "620", "--verify-every", "1", "--watchdog", "150",
+                          "--cache-memory", str(1 << 20)], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
+                         stdin=subprocess.DEVNULL, timeout=400)
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+    assert res.returncode == 0 and lines, (res.stdout[-1500:], res.stderr[-3000:])
+    d = json.loads(lines[-1])
+    assert d["verified_batches"] >= 620 and d["batches_per_sec"] > 0

@@ -20,10 +20,18 @@ def main():
     ap.add_argument("--fanout", type=str, default="25,10")
     ap.add_argument("--train-batches", type=int, default=60)
     ap.add_argument("--cache-memory", type=int, default=1 << 30)
+    ap.add_argument("--verify-every", type=int, default=0,
+                    help="python consumer: every k-th batch, check on the device that the rows are the generator's rows of the "
+                         "batch's ids, that ids are unique and that every edge endpoint indexes a node of the batch (soak test "
+                         "of the hand-over: a wrong slot, a stale or half-copied batch fails here)")
     ap.add_argument("--consumer", type=str, default="python", choices=["python", "native"],
                     help="python: the ipc_service extension as a trainer would use it (get_next -> synchronize); "
                          "native: tools/boundary_consumer.c, the wire protocol with nothing else (what the server can hand over)")
+    ap.add_argument("--watchdog", type=int, default=0, help="seconds after which the tool dumps its stack and the server log and exits")
     a = ap.parse_args()
+    if a.watchdog:
+        import faulthandler
+        faulthandler.dump_traceback_later(a.watchdog, exit=False)
     fanout = [int(x) for x in a.fanout.split(",")]
     dev = torch.device("cuda:0")
     N = 1 << a.scale
@@ -76,14 +84,29 @@ def main():
         ipc_service.initialize()
         tr, va, te = ipc_service.get_steps()
         H = len(fanout)
-        edges, t0, n_timed = 0, None, 0
+        edges, t0, n_timed, verified = 0, None, 0, 0
+        t_start = time.time()
         for i in range(tr + va + te):
+            if a.watchdog and time.time() - t_start > a.watchdog:
+                raise RuntimeError(f"watchdog: stuck or too slow at batch {i} of {tr + va + te}")
             out = ipc_service.get_next(a.dim)
             if i < tr:
                 if i == 5:
                     torch.cuda.synchronize(); t0 = time.perf_counter(); edges = 0; n_timed = 0
                 edges += int(out[3].numel())          # outermost block = every edge of the batch
                 n_timed += 1
+            if a.verify_every and i % a.verify_every == 0:
+                ids, fts = out[0], out[1]
+                n = int(ids.numel())
+                assert n > 0 and tuple(fts.shape) == (n, a.dim)
+                assert synth.feature_check_device(fts.contiguous(), ids.contiguous(), a.dim, 7) == 0, f"batch {i}: rows differ"
+                assert int(torch.unique(ids).numel()) == n, f"batch {i}: duplicate ids"
+                sizes = ipc_service.get_block_size()
+                assert sizes[0] == n and int(out[3].max()) < n and int(out[4].max()) < sizes[1], f"batch {i}: edge endpoints"
+                seeds_expected = torch.from_numpy(train[i * a.batch:(i + 1) * a.batch]).cuda() if i < tr else None
+                if seeds_expected is not None:
+                    assert bool((ids[:a.batch] == seeds_expected).all()), f"batch {i}: not the seeds of training batch {i}"
+                verified += 1
             del out
             ipc_service.synchronize()
             if i == tr - 1:
@@ -94,11 +117,13 @@ def main():
         print(json.dumps({"path": "sampling_server binary -> shm/semaphores/IPC handles -> ipc_service consumer",
                           "workload": f"RMAT-{a.scale} EF16, D={a.dim}, batch {a.batch}, fanout {fanout}, train mode, 1 GPU",
                           "batches_per_sec": n_timed / dt, "edges_per_sec": edges / dt, "timed_batches": n_timed,
-                          "ms_per_batch": dt / n_timed * 1e3}))
+                          "ms_per_batch": dt / n_timed * 1e3, "verified_batches": verified}))
     finally:
         if server.poll() is None:
             server.kill()
         log.close()
+        if a.watchdog:
+            print("---- server log tail ----\n" + open(os.path.join(work, "server.log")).read()[-1500:], file=sys.stderr)
         for name in os.listdir("/dev/shm"):
             if name.endswith(ns):
                 os.unlink(os.path.join("/dev/shm", name))
