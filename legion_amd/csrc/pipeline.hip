@@ -175,6 +175,48 @@ static void slot_wait(LegionPipeline* p, Slot& sl)
     sl.prof_pairs = 0;
 }
 
+// The hipGraph of one phase of a group on a slot, captured on first use.  Nothing in it depends on host-side values: the
+// iteration lives in sl.d_iter on the device (the group's iter_state must be set), sizes are computed by the kernels.
+static hipGraphExec_t graph_of(LegionPipeline* p, Slot& sl, hipStream_t strm, int32_t phase, int32_t mode, int32_t n_active,
+                               int32_t batch_size)
+{
+    const int64_t key = ((int64_t)phase << 48) | ((int64_t)mode << 40) | ((int64_t)n_active << 32) | (uint32_t)batch_size;
+    auto it = sl.exec.find(key);
+    if (it == sl.exec.end()) {
+        hipGraph_t graph = nullptr;
+        hipGraphExec_t exec = nullptr;
+        HIP_CALL(hipStreamSynchronize(strm));
+        HIP_CALL(hipStreamBeginCapture(strm, hipStreamCaptureModeThreadLocal));
+        legion_enqueue_group_phase(strm, reinterpret_cast<LegionGraphStorage*>(p->graph), reinterpret_cast<LegionFeatureStorage*>(p->feature),
+                                   p->cache_handle, sl.group, n_active, batch_size, 0, p->dev_id, mode, p->fanout.data(),
+                                   p->hop_num, phase);
+        HIP_CALL(hipStreamEndCapture(strm, &graph));
+        HIP_CALL(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+        HIP_CALL(hipGraphDestroy(graph));
+        it = sl.exec.emplace(key, exec).first;
+    }
+    return it->second;
+}
+
+// Captures and instantiates, on EVERY slot, the graph(s) a later submit of (mode, n_active, batch_size) will replay, without
+// launching anything.  A server calls this for every group shape of its schedule before it starts serving: stream capture
+// and graph instantiation then never run beside another thread's HIP calls (GPURunner's poster polls events; a capture
+// concurrent with hipEventQuery on the same stream crashed inside the runtime about once in thirty starts, ROCm 7.2).
+extern "C" void legion_pipeline_prepare(LegionPipeline* p, int32_t mode, int32_t n_active, int32_t batch_size)
+{
+    if (!p || !p->use_graph) return;
+    if (n_active < 1 || n_active > p->group_size) n_active = p->group_size;
+    if (batch_size < 1 || batch_size > p->batch_size) batch_size = p->batch_size;
+    SetGPUDevice(p->dev_id);
+    const int32_t first_phase = (p->split || p->sample_only) ? LG_PHASE_SAMPLE : LG_PHASE_ALL;
+    for (Slot& sl : p->slots) {
+        slot_wait(p, sl);
+        legion_group_set_iter_state(sl.group, sl.d_iter);
+        (void)graph_of(p, sl, p->split ? p->sample_stream : sl.stream, first_phase, mode, n_active, batch_size);
+        if (p->split) (void)graph_of(p, sl, sl.stream, LG_PHASE_GATHER, mode, n_active, batch_size);
+    }
+}
+
 // Enqueues the group of batches counter0 .. counter0 + G - 1 of `mode` on the next slot (round robin)
 // and returns the slot index.  The slot's previous group must have been consumed: this call waits
 // for its completion first.
@@ -238,26 +280,8 @@ extern "C" int32_t legion_pipeline_submit_ex(LegionPipeline* p, int32_t counter0
             sl.h_iter[1] = p->group_size * p->slots_n;
             HIP_CALL(hipMemcpyAsync(sl.d_iter, sl.h_iter, 2 * sizeof(int32_t), hipMemcpyHostToDevice, s1));
         }
-        auto exec_of = [&](hipStream_t strm, int32_t phase) {
-            const int64_t key = ((int64_t)phase << 48) | ((int64_t)mode << 40) | ((int64_t)n_active << 32) |
-                                (uint32_t)batch_size;
-            auto it = sl.exec.find(key);
-            if (it == sl.exec.end()) {
-                hipGraph_t graph = nullptr;
-                hipGraphExec_t exec = nullptr;
-                HIP_CALL(hipStreamSynchronize(strm));
-                HIP_CALL(hipStreamBeginCapture(strm, hipStreamCaptureModeThreadLocal));
-                legion_enqueue_group_phase(strm, gr, f, p->cache_handle, sl.group, n_active, batch_size, counter0,
-                                           p->dev_id, mode, p->fanout.data(), p->hop_num, phase);
-                HIP_CALL(hipStreamEndCapture(strm, &graph));
-                HIP_CALL(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
-                HIP_CALL(hipGraphDestroy(graph));
-                it = sl.exec.emplace(key, exec).first;
-            }
-            return it->second;
-        };
-        hipGraphExec_t e1 = exec_of(s1, first_phase);
-        hipGraphExec_t e2 = p->split ? exec_of(sl.stream, LG_PHASE_GATHER) : nullptr;
+        hipGraphExec_t e1 = graph_of(p, sl, s1, first_phase, mode, n_active, batch_size);
+        hipGraphExec_t e2 = p->split ? graph_of(p, sl, sl.stream, LG_PHASE_GATHER, mode, n_active, batch_size) : nullptr;
         HIP_CALL(hipGraphLaunch(e1, s1));
         if (p->split) {
             HIP_CALL(hipEventRecord(sl.sampled, s1));

@@ -302,6 +302,7 @@ extern "C" LegionPipeline* legion_pipeline_create(LegionGraphStorage* graph, Leg
                                                   const int32_t* fanout, int32_t hop_num, int32_t group_size,
                                                   int32_t slots, int64_t feature_rows, int32_t use_graph);
 extern "C" int32_t legion_pipeline_submit_ex(LegionPipeline* p, int32_t counter0, int32_t mode, int32_t n_active, int32_t batch_size);
+extern "C" void legion_pipeline_prepare(LegionPipeline* p, int32_t mode, int32_t n_active, int32_t batch_size);
 extern "C" legion_stream_t legion_pipeline_stream(LegionPipeline* p);
 extern "C" LegionMemoryPool* legion_pipeline_pool(LegionPipeline* p, int32_t slot, int32_t lane);
 extern "C" void legion_pipeline_destroy(LegionPipeline* p);
@@ -521,6 +522,13 @@ public:
         SetGPUDevice(local_dev_id_);
         IPCEnv* env = (IPCEnv*)(params->env);
         CreateGroups(params);
+        // every group shape of the whole schedule gets its graph now: no stream capture while the poster thread polls events
+        for (int32_t first = 0; first < max_step_;) {
+            int32_t mode = 0, local0 = 0;
+            const int32_t n = PlanGroup(env, first, mode, local0);
+            legion_pipeline_prepare(pipe_, mode, n, env->GetCurrentBatchsize(local_dev_id_, mode));
+            first += n;
+        }
         if (max_step_ > 0) {
             SubmitGroup(env, 0, cur_slot_, cur_first_, cur_n_);
             HIP_CALL(hipStreamSynchronize(static_cast<hipStream_t>(legion_pipeline_stream(pipe_))));
@@ -648,13 +656,21 @@ private:
 
     // plans and enqueues the sampler phase of the group that starts at global batch `first`: consecutive batches of
     // one mode with consecutive local ids (ipc_service.cu:213-253), at most `lanes_`
-    void SubmitGroup(IPCEnv* env, int32_t first, int& slot_out, int32_t& first_out, int32_t& n_out)
+    int32_t PlanGroup(IPCEnv* env, int32_t first, int32_t& mode, int32_t& local0)
     {
-        const int32_t mode = env->GetCurrentMode(first), local0 = env->GetLocalBatchId(first);
+        mode = env->GetCurrentMode(first);
+        local0 = env->GetLocalBatchId(first);
         int32_t n = 1;
         while (n < lanes_ && first + n < max_step_ && env->GetCurrentMode(first + n) == mode &&
                env->GetLocalBatchId(first + n) == local0 + n)
             n++;
+        return n;
+    }
+
+    void SubmitGroup(IPCEnv* env, int32_t first, int& slot_out, int32_t& first_out, int32_t& n_out)
+    {
+        int32_t mode = 0, local0 = 0;
+        const int32_t n = PlanGroup(env, first, mode, local0);
         slot_out = legion_pipeline_submit_ex(pipe_, local0, mode, n, env->GetCurrentBatchsize(local_dev_id_, mode));
         first_out = first;
         n_out = n;

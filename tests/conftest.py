@@ -18,6 +18,16 @@ def pytest_configure(config):
     _ensure_built()
 
 
+def pytest_collection_modifyitems(config, items):
+    """No GPU test may hang the run: a server or trainer process that dies leaves its peer blocked on a semaphore.
+    pytest-timeout (installed in this image) turns that into a failure with a traceback."""
+    if not config.pluginmanager.hasplugin("timeout"):
+        return
+    for item in items:
+        if item.get_closest_marker("gpu") is not None and item.get_closest_marker("timeout") is None:
+            item.add_marker(pytest.mark.timeout(600))
+
+
 @pytest.fixture(scope="session")
 def oracle():
     from oracle import ffi
