@@ -421,9 +421,9 @@ public:
     // SS/engine/server.cu:302-332.  The reference produces ONE mini-batch per call, ~16 launches and three blocking
     // read-backs each.  Here a call hands ONE batch over (same semaphores, same two pipe slots, same order), but the
     // batches are PRODUCED in launch groups: the sampler phase of G consecutive batches runs as one hipGraph replay
-    // over G internal lanes (pipeline.hip, grid.y = G); per call the lane's ids / edges / labels / counters are copied
-    // into the free pipe slot and its feature rows are gathered straight into the slot's buffer (two launches).  A
-    // poster thread waits for the batch's event and posts it, so this thread never blocks on the GPU and a finished
+    // over G internal lanes (pipeline.hip, grid.y = G); per call ONE launch gathers the lane's feature rows straight into
+    // the free pipe slot's buffer and copies its ids / edges / labels / counters there (deliver_slice in gather_kernel).  A
+    // poster thread polls the batch's event and posts it, so this thread never blocks on the GPU and a finished
     // batch never waits for the trainer to release another slot.  LEGION_RUNNER_GRAPH=0: the operator-by-operator
     // path of the reference (one batch per call, eager launches).
     void RunOnce(RunnerParams* params) override
