@@ -73,6 +73,9 @@ def parse_args():
     ap.add_argument("--overlap", action="store_true", help="let kernels of different slots share the GPU")
     ap.add_argument("--split", action="store_true",
                     help="sampler phase and gather phase of every group on two streams (sampler k+1 under gathers k)")
+    ap.add_argument("--no-weave", action="store_true",
+                    help="everything of a group on ONE stream (default: the next group's head -- seeds + every hop but the last, small "
+                         "latency-bound kernels -- runs on a second stream under the current group's heavy kernels, pipeline.hip)")
     ap.add_argument("--no-verify", action="store_true")
     ap.add_argument("--no-overlap-leg", action="store_true",
                     help="skip the extra timed region with sampler and gather phases overlapped on two streams")
@@ -237,8 +240,9 @@ def main():
         cache.fill_up(feature, graph)
     feature_rows = int(max_ids * 1.2)                                        # server.cu:277
     pool.close()
+    weave = not (args.no_weave or args.split or args.overlap)
     pipe = engine.Pipeline(graph, feature, cache, d, B, fanout, G, feature_rows, not args.no_graph, args.slots,
-                           args.overlap, args.split)
+                           args.overlap, args.split, weave)
     torch.cuda.synchronize()
     setup_s = time.time() - t_setup
 
@@ -429,6 +433,8 @@ def main():
                                        f"striped over the ranks, peer reads over xGMI (cache_agg_mode {int(np.log2(world))})")
                        if stripe else f"seed-sharded x{world}, replicated graph+features, cache_agg_mode 0",
                        "batches_per_launch_group": G, "groups_in_flight": args.slots, "epoch_batches": epoch_batches,
+                       "streams": "weave: head of group k+1 on a second stream under the heavy kernels of group k" if weave else
+                                  ("split: sampler phase || gather phase" if args.split else "one"),
                        "epochs_wrap": bool(wrap), "hipgraph": not args.no_graph,
                        "cache_memory_bytes": args.cache_memory,
                        "feature_cache_rows": cache.node_capacity(d), "topology_cache_vertices": cache.edge_capacity(d),

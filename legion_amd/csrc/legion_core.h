@@ -145,6 +145,9 @@ enum HopScratch {
 #define LG_PHASE_ALL 0      // reference op order: gather right after the op that produced its rows
 #define LG_PHASE_SAMPLE 1   // BatchGenerate + every RandomSample + IOComplete
 #define LG_PHASE_GATHER 2   // every FeatureCacheLookup, from the per-op range snapshots
+// "weave" arrangement (pipeline.hip): the group cut where its character changes
+#define LG_PHASE_HEAD 3     // BatchGenerate + every hop but the last, complete: small, latency-bound kernels
+#define LG_PHASE_REST 4     // the last hop (sample .. localise) + IOComplete + every gather, in that order
 
 #define LG_TILE 256            // compaction tile == threads per workgroup in the sampler kernels
 #define LG_SLOTS_PER_LANE 4    // independent slots each lane keeps in flight

@@ -342,6 +342,23 @@ static void enqueue_lanes(hipStream_t s, GraphStorage* graph, FeatureStorage* fe
     // inside a whole-batch enqueue every gather reads the {offset, count} snapshot its producer left in
     // hop_scratch[HS_RANGE + 2h] (not overwritten by later hops), so the gathers may also run as a
     // phase of their own after the whole sampler (LG_PHASE_GATHER, on another stream: pipeline.hip)
+    const bool seeds_ride = hop_num >= 2;
+    if (phase >= LG_PHASE_HEAD) {          // the two pieces of the weave arrangement (serve mode only)
+        const int32_t last = hop_num - 1;
+        if (phase == LG_PHASE_HEAD) {
+            do_batch_generate(s, feature, d_lanes, n_lanes, pool0, batch_size, counter, dev_id, mode, hop_num, iter_state);
+            for (int32_t h = 0; h < last; h++)
+                do_random_sample(s, graph, cache, d_lanes, n_lanes, pool0, fanout[h], dev_id, INTRABATCH_CON * (h + 1), false);
+        } else {
+            if (last >= 0) do_random_sample(s, graph, cache, d_lanes, n_lanes, pool0, fanout[last], dev_id, INTRABATCH_CON * (last + 1), false);
+            lg::launch_end_of_batch(s, d_lanes, n_lanes, iter_state, pool_state_bytes(pool0));
+            if (!seeds_ride) do_feature_lookup(s, cache, d_lanes, n_lanes, pool0, 1, dev_id, true);
+            for (int32_t h = 0; h <= last; h++)
+                do_feature_lookup(s, cache, d_lanes, n_lanes, pool0, INTRABATCH_CON * (h + 1) + 1, dev_id, true,
+                                  (h == 0 && seeds_ride) ? 1 : -1);
+        }
+        return;
+    }
     const bool sampler = phase != LG_PHASE_GATHER, gathers = phase != LG_PHASE_SAMPLE && !is_presc;
     if (sampler) do_batch_generate(s, feature, d_lanes, n_lanes, pool0, batch_size, counter, dev_id, mode, hop_num, iter_state);
     // The seeds' rows (op 1) are few and directly in front of hop 1's: when a later gather follows (so that

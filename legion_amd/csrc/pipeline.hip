@@ -42,7 +42,7 @@ struct Slot {
     LegionLaneGroup* group = nullptr;
     hipStream_t stream = nullptr;
     hipEvent_t done = nullptr;
-    hipEvent_t sampled = nullptr;             // split mode: the group's sampler phase has finished
+    hipEvent_t sampled = nullptr;             // split mode: the group's sampler phase has finished (weave: its head)
     bool busy = false;
     std::map<int64_t, hipGraphExec_t> exec;   // key: (mode, active lanes, batch_size, phase)
     int32_t* d_iter = nullptr;                // device {next counter0, stride}
@@ -61,6 +61,7 @@ struct LegionPipeline {
     bool use_graph;
     bool overlap = false;   // let kernels of different slots run concurrently (default: chained)
     bool split = false;     // sampler and gather phases on two streams (see the header comment)
+    bool weave = false;     // head of group k+1 on a second stream under the heavy kernels of group k (see submit)
     bool sample_only = false;   // only the sampler phase runs here; the owner gathers each lane itself (GPURunner: straight
                                 // into a trainer-visible pipe slot)
     hipStream_t sample_stream = nullptr;
@@ -92,12 +93,15 @@ extern "C" LegionPipeline* legion_pipeline_create(LegionGraphStorage* graph, Leg
     p->overlap = (use_graph & 2) != 0;
     p->split = (use_graph & 4) != 0;
     p->sample_only = (use_graph & 8) != 0;
-    if (p->sample_only) p->split = false;
+    p->weave = (use_graph & 16) != 0;
+    if (p->sample_only) p->split = p->weave = false;
+    if (p->weave) p->split = false;
     if (p->split) p->overlap = false;
     SetGPUDevice(dev_id);
     // split mode with a CU partition (LEGION_SPLIT_SAMPLER_CUS = n): the sampler stream may only use n of the 256 CUs
     // (every (256/n)-th bit of the mask), the gather stream the others.  The sampler is bound by the latency of scattered
     // atomics, not by CUs; the gather needs every wave slot it can get to keep ~12 MB of loads in flight.
+    if (p->weave) HIP_CALL(hipStreamCreateWithFlags(&p->sample_stream, hipStreamNonBlocking));
     std::vector<uint32_t> mask_s, mask_g;
     if (p->split) {
         const char* ce = getenv("LEGION_SPLIT_SAMPLER_CUS");
@@ -212,6 +216,11 @@ extern "C" void legion_pipeline_prepare(LegionPipeline* p, int32_t mode, int32_t
     for (Slot& sl : p->slots) {
         slot_wait(p, sl);
         legion_group_set_iter_state(sl.group, sl.d_iter);
+        if (p->weave) {
+            (void)graph_of(p, sl, p->sample_stream, LG_PHASE_HEAD, mode, n_active, batch_size);
+            (void)graph_of(p, sl, sl.stream, LG_PHASE_REST, mode, n_active, batch_size);
+            continue;
+        }
         (void)graph_of(p, sl, p->split ? p->sample_stream : sl.stream, first_phase, mode, n_active, batch_size);
         if (p->split) (void)graph_of(p, sl, sl.stream, LG_PHASE_GATHER, mode, n_active, batch_size);
     }
@@ -258,6 +267,46 @@ extern "C" int32_t legion_pipeline_submit_ex(LegionPipeline* p, int32_t counter0
     p->last_slot = si;
     LegionGraphStorage* gr = reinterpret_cast<LegionGraphStorage*>(p->graph);
     LegionFeatureStorage* f = reinterpret_cast<LegionFeatureStorage*>(p->feature);
+    if (p->weave) {
+        // Weave: the group is cut where its character changes.  HEAD (seeds + every hop but the last: a dozen small,
+        // latency-bound kernels that cannot fill the chip) runs on the light stream Y; REST (the last hop -- scattered
+        // atomics at ~2 TB/s of sector traffic -- and every gather) runs on the heavy stream X:
+        //     X:  rest(k)                | rest(k+1)                 | ...
+        //     Y:      head(k+1)          |      head(k+2)            |
+        // The head of the next group hides under the current group's heavy kernels, which lose nothing measurable to it
+        // (the dominant gather keeps 0.78 of the HBM peak); the two heavy kinds of traffic never share the machine, which
+        // is what costs the plain two-stream split (sampler || gathers) a quarter of the gather's bandwidth.
+        // Measured (RMAT-26, B = 1024, 256 lanes): 4.25-4.31 G edges/s against 4.06-4.15 G on one stream.  Running the
+        // last hop's compaction kernels on Y beside the early gathers as well was measured too: no gain, gather at 0.75.
+        hipStream_t X = sl.stream, Y = p->sample_stream;
+        const bool eager = !p->use_graph || p->profiling;
+        legion_group_set_iter_state(sl.group, eager ? nullptr : sl.d_iter);
+        if (!eager && sl.next_iter != counter0) {
+            sl.h_iter[0] = counter0;
+            sl.h_iter[1] = p->group_size * p->slots_n;
+            HIP_CALL(hipMemcpyAsync(sl.d_iter, sl.h_iter, 2 * sizeof(int32_t), hipMemcpyHostToDevice, Y));
+        }
+        auto run = [&](hipStream_t strm, int32_t phase) {
+            if (eager)
+                legion_enqueue_group_phase(strm, gr, f, p->cache_handle, sl.group, n_active, batch_size, counter0, p->dev_id, mode,
+                                           p->fanout.data(), p->hop_num, phase);
+            else
+                HIP_CALL(hipGraphLaunch(graph_of(p, sl, strm, phase, mode, n_active, batch_size), strm));
+        };
+        run(Y, LG_PHASE_HEAD);
+        HIP_CALL(hipEventRecord(sl.sampled, Y));
+        HIP_CALL(hipStreamWaitEvent(X, sl.sampled, 0));
+        run(X, LG_PHASE_REST);
+        if (eager) {
+            sl.next_iter = -1;
+            sl.prof_pairs = sl.pools[0]->prof_used;
+        } else {
+            sl.next_iter = n_active == p->group_size ? counter0 + p->group_size * p->slots_n : -1;
+        }
+        HIP_CALL(hipEventRecord(sl.done, X));
+        sl.busy = true;
+        return si;
+    }
     // split mode: phase 1 on the sampler stream, phase 2 on the slot's (gather) stream behind it
     hipStream_t s1 = p->split ? p->sample_stream : sl.stream;
     const int32_t first_phase = (p->split || p->sample_only) ? LG_PHASE_SAMPLE : LG_PHASE_ALL;

@@ -283,14 +283,15 @@ class Pipeline:
     hipGraph (pipeline.hip).  submit(counter0) enqueues batches counter0 .. counter0+group_size-1."""
 
     def __init__(self, graph, feature, cache, dev_id, batch_size, fanout, group_size, feature_rows, use_graph=True,
-                 slots=2, overlap=False, split=False):
+                 slots=2, overlap=False, split=False, weave=False):
         self._lib = _libmod.load()
         self.group_size, self.slots = int(group_size), int(slots)
         self.fanout = [int(f) for f in fanout]
         self.handle = self._lib.legion_pipeline_create(graph.handle, feature.handle, cache.handle, int(dev_id),
                                                        int(batch_size), _i32_array(self.fanout), len(self.fanout),
                                                        self.group_size, self.slots, int(feature_rows),
-                                                       (1 if use_graph else 0) | (2 if overlap else 0) | (4 if split else 0))
+                                                       (1 if use_graph else 0) | (2 if overlap else 0) | (4 if split else 0) |
+                                                       (16 if weave else 0))
         self.pools = [[MemoryPool._borrowed(self._lib.legion_pipeline_pool(self.handle, s, g), dev_id,
                                             feature.total_num_nodes, batch_size, fanout, feature.float_feature_len,
                                             feature_rows) for g in range(self.group_size)]

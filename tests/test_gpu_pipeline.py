@@ -168,7 +168,9 @@ def test_presc_topology_transactions_feed_cost_model(hip):
 
 @pytest.mark.parametrize("group,slots,use_graph,split", [(1, 1, True, False), (3, 2, True, False), (4, 2, False, False),
                                                          (2, 3, True, False), (8, 2, True, False), (3, 2, True, True),
-                                                         (4, 2, False, True), (2, 3, True, True), (1, 1, True, True)])
+                                                         (4, 2, False, True), (2, 3, True, True), (1, 1, True, True),
+                                                         (3, 2, True, "weave"), (4, 2, False, "weave"), (2, 3, True, "weave"),
+                                                         (1, 1, True, "weave"), (8, 2, True, "weave")])
 def test_pipeline_groups_and_graph_replay(hip, dedup, group, slots, use_graph, split):
     """Grouped launches (grid.y = lanes) + hipGraph replay produce exactly the batches the one-lane
     eager path does: every batch of a short run -- including the clamped last batch and the empty
@@ -186,7 +188,7 @@ def test_pipeline_groups_and_graph_replay(hip, dedup, group, slots, use_graph, s
     gpu.cache.fill_up(gpu.feature, gpu.graph)
     cpu.build_cache(0, capacity=(150, 80))
     pipe = engine.Pipeline(gpu.graph, gpu.feature, gpu.cache, 0, batch, fanout, group, gpu.pools[0].num_ids, use_graph, slots,
-                           split=split)
+                           split=split is True, weave=split == "weave")
     n_batches = (wl.sets[(0, 0)][0].size + batch - 1) // batch     # the last one is partial
     n_groups = (n_batches + group - 1) // group                    # the last group may reach past the set
     for rep in range(2):                                          # the second epoch re-positions the device iteration
