@@ -446,9 +446,10 @@ def main():
             "feature_gather_GBps_note": "payload bytes read (rows*D*4) / HIP-event time of all gather launches, rank 0",
             "sampling_only": {"edges_per_sec": float(edges.sum()) / t_sampling, "algorithmic_GBps": samp_bytes / t_sampling / 1e9,
                               "frac_of_hbm_peak": samp_bytes / t_sampling / 1e9 / HBM_PEAK_GBPS,
-                              "note": "rank 0; time = timed region minus the HIP-event time of all gather launches; the "
-                                      "sampler is bound by scattered 4-byte atomics (~17-19 G/s beyond the Infinity Cache) and loads (~47 G/s), "
-                                      "see tools/micro/random_access.hip"},
+                              "note": "rank 0; time = timed region minus the HIP-event time of all gather launches (with the weave "
+                                      "arrangement the head of the next group runs hidden under this group's heavy kernels, so this is the "
+                                      "sampler time that is NOT hidden); the sampler is bound by memory-side atomics (~13-19 G claims/s) and "
+                                      "scattered loads (~47 G/s), see tools/micro/dedup_tables.hip"},
             "edges_per_step": float(edges.sum()) / args.steps, "rows_per_step": float(rows.sum()) / args.steps,
             "edges_per_batch": float(edges.mean()), "rows_per_batch": float(rows.sum(axis=1).mean()),
             "seed_feature_cache_hits_step0": hits,
