@@ -50,7 +50,7 @@ def parse_args():
     ap.add_argument("--min-seconds", type=float, default=1.5,
                     help="repeat the K-step timed region until this much time has been measured (median reported)")
     ap.add_argument("--max-repeats", type=int, default=400)
-    ap.add_argument("--dedup", type=str, default="auto", choices=["auto", "direct", "table"],
+    ap.add_argument("--dedup", type=str, default="auto", choices=["auto", "direct", "table", "lds"],
                     help="form of the per-lane first-touch/position state: direct uint32[N] array, compact open-addressing "
                          "table, or auto (table when the arrays of all lanes in flight would exceed a quarter of HBM)")
     ap.add_argument("--placement", type=str, default="hbm", choices=["hbm", "pinned"],
@@ -471,7 +471,7 @@ def main():
                         "(sampler k+1 runs under gathers k; `bench.py --split` makes this the headline).  Each kernel runs "
                         "slower while sharing the machine (the gather at ~0.59 of peak instead of 0.76) but the group finishes "
                         "sooner: at ~6.5 GB of HBM sector traffic per step the pipeline is then bound by total traffic."},
-            "position_state": {"form": "table" if pipe.pools[0][0].uses_table() else "direct",
+            "position_state": {"form": pipe.pools[0][0].dedup_form(),
                                "bytes_per_lane": pipe.pools[0][0].state_bytes(), "lanes": G * args.slots},
             "feature_cache_hit_rate": feat_hit_rows / max(feat_hit_rows + feat_miss_rows, 1),
             "feature_cache_hit_rate_over": "every timed batch" if args.placement == "pinned" else "the first timed step",

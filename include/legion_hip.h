@@ -113,6 +113,9 @@ void* legion_pool_buffer(LegionMemoryPool* p, int32_t which);
  * open-addressing table sized by num_ids (LEGION_DEDUP=direct|table|auto, auto = table when the arrays of all
  * pools in flight would exceed a quarter of HBM).  Both give bit-identical batches. */
 int32_t legion_pool_uses_table(const LegionMemoryPool* p);
+/* 0 direct array, 1 compact table, 2 "lds": no per-vertex state, a hop's claims are de-duplicated bucket by bucket in LDS
+ * (LEGION_DEDUP=lds; pools whose largest hop has at most 2^19 slots) */
+int32_t legion_pool_dedup_form(const LegionMemoryPool* p);
 int64_t legion_pool_state_bytes(const LegionMemoryPool* p);
 /* Sticky error bits raised on the device for this pool (0 = none): 1 position table full, 2 batch larger than the
  * feature buffer (gather stopped at its end; the reference overruns, SS/engine/server.cu:277), 4 internal.  The

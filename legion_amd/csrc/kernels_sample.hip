@@ -204,7 +204,7 @@ __global__ void batch_generate_kernel(SeedParams p, const LanePtrs* __restrict__
             const PosFmt pf = lg_pos_fmt(L.hop_scratch[HS_EPOCH], L.hop_scratch[HS_VALUE_BITS]);
             if (L.pos_table != nullptr)
                 table_claim(L.pos_table, L.pos_mask, pf, src_id, (uint32_t)idx, nullptr, nullptr, 0, L.hop_scratch, L.err_flag);
-            else
+            else if (L.position_map != nullptr)       // (lds form: no per-vertex state, the seeds are re-read from sampled_ids)
                 __hip_atomic_fetch_min(L.position_map + src_id, pf.hi | (uint32_t)idx,
                                        __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // seeds are unique (":26 assume no duplicate")
             L.labels[idx] = p.all_labels[at % p.total_cap];
@@ -236,6 +236,7 @@ struct SampleArgs {
     LG_G int32_t* slot_dst; LG_G int32_t* slot_pos; LG_G int32_t* slot_mark; LG_G int32_t* tile_counts; LG_G int32_t* tile_prefix; LG_G int32_t* hop_scratch;
     LG_G RowHdr* fh_edge;
     LG_G unsigned long long* pos_table; uint32_t pos_mask; LG_G int32_t* err_flag;
+    LG_G unsigned long long* claim_pairs; LG_G int32_t* run_base; LG_G int32_t* run_cnt;
     PosFmt pf;
     int32_t mark_tag;   // (epoch, hop): what slot_mark holds for a slot that lost its first touch in THIS hop
 };
@@ -280,6 +281,8 @@ __device__ __forceinline__ SampleArgs lane_args(const HopParams& p, const LanePt
     a.fh_edge = LG_GPTR(RowHdr, L.fh_edge);
     a.pos_table = LG_GPTR(unsigned long long, L.pos_table); a.pos_mask = L.pos_table_mask;
     a.err_flag = LG_GPTR(int32_t, L.err_flag);
+    a.claim_pairs = LG_GPTR(unsigned long long, L.claim_pairs);
+    a.run_base = LG_GPTR(int32_t, L.run_base); a.run_cnt = LG_GPTR(int32_t, L.run_cnt);
     a.pf = lg_pos_fmt(a.hop_scratch[HS_EPOCH], a.hop_scratch[HS_VALUE_BITS]);
     a.mark_tag = (a.hop_scratch[HS_EPOCH] << 8) | (p.op_id / INTRABATCH_CON);
     return a;
@@ -323,11 +326,13 @@ __device__ __forceinline__ HopGeom hop_geometry(const SampleArgs& a)
 // coalesced 16-byte load per frontier entry), for hop 1 they are looked up in the per-vertex
 // header table here.
 // ------------------------------------------------------------------------------------------
-template <bool TABLE>
+template <int FORM>      // 0 direct array, 1 table, 2 lds
 __global__ __launch_bounds__(LG_TILE) void sample_kernel(HopParams hp, const LanePtrs* __restrict__ lanes)
 {
+    constexpr bool TABLE = FORM == 1;
     const SampleArgs a = lane_args(hp, lanes);
     __shared__ RowHdr s_hdr[LG_SUPER];
+    __shared__ int32_t s_bcnt[LG_LDS_BUCKETS], s_boff[LG_LDS_BUCKETS], s_base;
 
     const HopGeom g = hop_geometry(a);
     const int32_t tid = threadIdx.x;
@@ -376,6 +381,7 @@ __global__ __launch_bounds__(LG_TILE) void sample_kernel(HopParams hp, const Lan
         }
         __syncthreads();
 
+        if (FORM == 2 && tid < LG_LDS_BUCKETS) s_bcnt[tid] = 0;     // (made visible by the barrier above the loads' use below)
         int32_t dst[LG_SLOTS_PER_LANE];
 #pragma unroll
         for (int u = 0; u < LG_SLOTS_PER_LANE; u++) {
@@ -395,7 +401,13 @@ __global__ __launch_bounds__(LG_TILE) void sample_kernel(HopParams hp, const Lan
         for (int u = 0; u < LG_SLOTS_PER_LANE; u++) {
             const int32_t idx = idx0 + u * LG_TILE + tid;
             if (idx < g.total) {
-                if (dst[u] >= 0) {                                         // :244
+                if (FORM == 2) {
+                    // lds form: no claim here; the pair goes to its hash bucket below
+                    if (dst[u] >= 0 && a.edge_access_time)
+                        __hip_atomic_fetch_add(a.edge_access_time + g.frontier[idx / count], 1ull, __ATOMIC_RELAXED,
+                                               __HIP_MEMORY_SCOPE_AGENT);
+                    if (dst[u] < 0) dst[u] = -1;
+                } else if (dst[u] >= 0) {                                  // :244
                     // First touch goes to the LOWEST slot that sampled the vertex.  The atomic returns what
                     // it replaced, so every loser is known without a second look at the state array:
                     //   old < key : the vertex is already in the batch (final position) or a lower slot of this
@@ -430,8 +442,148 @@ __global__ __launch_bounds__(LG_TILE) void sample_kernel(HopParams hp, const Lan
                 a.slot_dst[idx] = dst[u];
             }
         }
+        if (FORM == 2) {
+            // the super tile's claims, grouped by hash bucket, into one run of the lane's pair array: ranks by LDS atomics
+            // (the order inside a bucket does not matter), ONE global reservation per super tile
+            int32_t rank[LG_SLOTS_PER_LANE], bkt[LG_SLOTS_PER_LANE];
+            __syncthreads();                                   // s_bcnt zeroed by every wave's view
+#pragma unroll
+            for (int u = 0; u < LG_SLOTS_PER_LANE; u++) {
+                bkt[u] = -1;
+                if (dst[u] >= 0) {
+                    bkt[u] = (int32_t)(lg_tab_hash(dst[u]) & (LG_LDS_BUCKETS - 1));
+                    rank[u] = atomicAdd(&s_bcnt[bkt[u]], 1);
+                }
+            }
+            __syncthreads();
+            if (tid == 0) {
+                int32_t tot = 0;
+                for (int b = 0; b < LG_LDS_BUCKETS; b++) { s_boff[b] = tot; tot += s_bcnt[b]; }
+                s_base = tot > 0 ? __hip_atomic_fetch_add(a.hop_scratch + HS_PAIR_CURSOR, tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+                a.run_base[st] = s_base;
+            }
+            __syncthreads();
+            if (tid < LG_LDS_BUCKETS) a.run_cnt[st * LG_LDS_BUCKETS + tid] = s_bcnt[tid];
+#pragma unroll
+            for (int u = 0; u < LG_SLOTS_PER_LANE; u++)
+                if (bkt[u] >= 0)
+                    a.claim_pairs[s_base + s_boff[bkt[u]] + rank[u]] =
+                        ((unsigned long long)(uint32_t)dst[u] << 32) | (uint32_t)(idx0 + u * LG_TILE + tid);
+        }
         __syncthreads();
     }
+}
+
+// ------------------------------------------------------------------------------------------
+// K1b (lds form): de-duplication of a hop's claims, one workgroup per (bucket, lane), entirely in LDS.
+//   table word = [ vertex : 32 | pending : 1 | value : 31 ], empty = all ones, ordered linear probing with atomicMin.
+//   1. the batch's known vertices that hash into this bucket (sampled_ids[0 .. nodes so far)) go in with their position;
+//   2. the bucket's claims go in as pending | slot: per vertex the lowest value survives -- a known position beats any
+//      slot, a lower slot beats a higher one;
+//   3. every claim looks its vertex up: the claim that IS the surviving word is a first touch and stays unmarked; every
+//      other claim gets the hop's mark and, in slot_pos, the final position or -2 - (the winning slot) -- exactly what
+//      the atomics of the other two forms leave (here the chain of losers always has length one).
+// A bucket whose vertices cannot fit the table is processed in P passes over sub-buckets (further hash bits), so the
+// result never depends on how the hash spreads the batch.  Nothing survives the hop: nothing to clear, no state that
+// scales with the graph.
+// ------------------------------------------------------------------------------------------
+#define LG_DEDUP_THREADS 1024
+__device__ __forceinline__ uint32_t lds_slot_of(uint32_t h) { return (h * 0x9E3779B1u) >> (32 - 13); }   // LG_LDS_TABLE = 2^13
+static_assert(LG_LDS_TABLE == (1 << 13), "lds_slot_of assumes a 2^13-word table");
+
+__global__ __launch_bounds__(LG_DEDUP_THREADS) void dedup_lds_kernel(HopParams hp, const LanePtrs* __restrict__ lanes)
+{
+    const SampleArgs a = lane_args(hp, lanes);
+    __shared__ unsigned long long s_tab[LG_LDS_TABLE];
+    __shared__ int32_t s_pref[LG_LDS_MAX_SLOTS / LG_SUPER + 2];    // exclusive prefix of the bucket's segment lengths
+    __shared__ int32_t s_seg[LG_LDS_MAX_SLOTS / LG_SUPER + 2];     // where the bucket's segment of super tile t starts in claim_pairs
+    __shared__ int32_t s_known, s_total;
+    const HopGeom g = hop_geometry(a);
+    const int32_t tid = threadIdx.x, b = blockIdx.x;
+    const int32_t n_known = a.node_counter[0] + a.node_counter[1];          // nodes of the batch before this hop
+    constexpr uint32_t PENDING = 0x80000000u;
+
+    // the bucket's segments, one per super tile: exclusive prefix of their lengths
+    if (tid == 0) { s_known = 0; s_total = 0; }
+    for (int32_t t = tid; t < g.nsuper; t += LG_DEDUP_THREADS) {
+        s_pref[t + 1] = a.run_cnt[t * LG_LDS_BUCKETS + b];
+        int32_t off = a.run_base[t];
+        for (int bb = 0; bb < b; bb++) off += a.run_cnt[t * LG_LDS_BUCKETS + bb];
+        s_seg[t] = off;
+    }
+    __syncthreads();
+    if (tid == 0) {                                    // <= 512 entries: a serial scan costs less than its barriers
+        int32_t acc = 0;
+        s_pref[0] = 0;
+        for (int32_t t = 0; t < g.nsuper; t++) { acc += s_pref[t + 1]; s_pref[t + 1] = acc; }
+        s_total = acc;
+    }
+    int32_t known_here = 0;
+    for (int32_t i = tid; i < n_known; i += LG_DEDUP_THREADS) {
+        const int32_t id = a.sampled_ids[i];
+        if (id >= 0 && (lg_tab_hash(id) & (LG_LDS_BUCKETS - 1)) == (uint32_t)b) known_here++;
+    }
+    if (known_here) atomicAdd(&s_known, known_here);
+    __syncthreads();
+    const int32_t total = s_total;
+    // passes: distinct vertices <= known + claims; keep the expected load of a pass at or below half the table
+    int32_t passes = 1;
+    while ((int64_t)(s_known + total) > (int64_t)passes * (LG_LDS_TABLE / 2)) passes <<= 1;
+    const uint32_t pmask = (uint32_t)passes - 1u;
+
+    auto segment_of = [&](int32_t k) {                 // claim k of the bucket -> index into claim_pairs
+        int32_t lo = 0, hi = g.nsuper;                 // s_pref[lo] <= k < s_pref[hi]
+        while (hi - lo > 1) { const int32_t mid = (lo + hi) >> 1; if (s_pref[mid] <= k) lo = mid; else hi = mid; }
+        return s_seg[lo] + (k - s_pref[lo]);
+    };
+    auto insert = [&](unsigned long long w, uint32_t h) {
+        uint32_t p = lds_slot_of(h);
+        for (int it = 0; it < LG_LDS_TABLE; it++) {
+            const unsigned long long old = __hip_atomic_fetch_min(&s_tab[p], w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (old == ~0ull || (uint32_t)(old >> 32) == (uint32_t)(w >> 32)) return;    // placed, or merged with the same vertex
+            if (old > w) w = old;                                                          // displaced a larger word: carry it on
+            p = (p + 1) & (LG_LDS_TABLE - 1);
+        }
+        raise_error(a.hop_scratch, a.err_flag, LG_ERR_TABLE_FULL);
+    };
+
+    for (uint32_t pass = 0; pass <= pmask; pass++) {
+        for (int32_t i = tid; i < LG_LDS_TABLE; i += LG_DEDUP_THREADS) s_tab[i] = ~0ull;
+        __syncthreads();
+        for (int32_t i = tid; i < n_known; i += LG_DEDUP_THREADS) {
+            const int32_t id = a.sampled_ids[i];
+            if (id < 0) continue;
+            const uint32_t h = lg_tab_hash(id);
+            if ((h & (LG_LDS_BUCKETS - 1)) != (uint32_t)b || ((h >> 3) & pmask) != pass) continue;
+            insert(((unsigned long long)(uint32_t)id << 32) | (uint32_t)i, h);
+        }
+        for (int32_t k = tid; k < total; k += LG_DEDUP_THREADS) {
+            const unsigned long long pr = a.claim_pairs[segment_of(k)];
+            const uint32_t h = lg_tab_hash((int32_t)(pr >> 32));
+            if (((h >> 3) & pmask) != pass) continue;
+            insert((pr & 0xFFFFFFFF00000000ull) | PENDING | (uint32_t)pr, h);
+        }
+        __syncthreads();
+        for (int32_t k = tid; k < total; k += LG_DEDUP_THREADS) {
+            const unsigned long long pr = a.claim_pairs[segment_of(k)];
+            const uint32_t id = (uint32_t)(pr >> 32), slot = (uint32_t)pr;
+            const uint32_t h = lg_tab_hash((int32_t)id);
+            if (((h >> 3) & pmask) != pass) continue;
+            uint32_t p = lds_slot_of(h);
+            uint32_t v = 0xFFFFFFFFu;
+            for (int it = 0; it < LG_LDS_TABLE; it++) {
+                const unsigned long long w = s_tab[p];
+                if ((uint32_t)(w >> 32) == id) { v = (uint32_t)w; break; }
+                p = (p + 1) & (LG_LDS_TABLE - 1);
+            }
+            if (v != (PENDING | slot)) {          // not the lowest slot of a new vertex
+                a.slot_mark[slot] = a.mark_tag;
+                a.slot_pos[slot] = (v & PENDING) ? -2 - (int32_t)(v & ~PENDING) : (int32_t)v;
+            }
+        }
+        __syncthreads();
+    }
+    if (b == 0 && tid == 0) a.hop_scratch[HS_PAIR_CURSOR] = 0;      // the next hop's sampling starts a new pair array
 }
 
 // ------------------------------------------------------------------------------------------
@@ -635,9 +787,9 @@ __global__ __launch_bounds__(LG_TILE) void scatter_kernel(HopParams hp, const La
                 // :271 -- later hops look the position up in the state array; after the last hop nobody
                 // does, and same-hop duplicates resolve through slot_pos (a small, cache-resident array)
                 if (!a.last_hop) {
-                    if (a.pos_table == nullptr)
-                        a.position_map[dst] = (int32_t)(a.pf.hi | (uint32_t)n);
-                    else if (tab_at[u] != 0xFFFFFFFFu)
+                    if (a.pos_table == nullptr) {
+                        if (a.position_map != nullptr) a.position_map[dst] = (int32_t)(a.pf.hi | (uint32_t)n);   // (lds form: none)
+                    } else if (tab_at[u] != 0xFFFFFFFFu)
                         a.pos_table[tab_at[u]] = lg_tab_word(a.pf, dst, (uint32_t)n);
                     else
                         raise_error(a.hop_scratch, a.err_flag, LG_ERR_TABLE_FULL);
@@ -684,7 +836,7 @@ __global__ __launch_bounds__(LG_TILE) void localise_kernel(HopParams hp, const L
     }
 }
 
-void launch_random_sample(hipStream_t s, const HopParams& p, const LanePtrs* d_lanes, int32_t n_lanes, bool table_form)
+void launch_random_sample(hipStream_t s, const HopParams& p, const LanePtrs* d_lanes, int32_t n_lanes, int32_t form)
 {
     // Fixed grids that stride over super tiles; grid.y = lanes (independent mini-batches of a group).
     int32_t max_super = (p.max_slots + LG_SUPER - 1) / LG_SUPER;
@@ -694,10 +846,15 @@ void launch_random_sample(hipStream_t s, const HopParams& p, const LanePtrs* d_l
     while (gx > 64 && (int64_t)gx * n_lanes > max_wg) gx /= 2;  // keep the whole launch near 2 x resident capacity
     while (gx > 1 && (int64_t)gx * n_lanes > max_wg && max_wg < 4096) gx /= 2;   // (experiments with fewer workgroups)
     const dim3 grid(gx, n_lanes);
-    if (table_form)
-        sample_kernel<true><<<grid, LG_TILE, 0, s>>>(p, d_lanes);
-    else
-        sample_kernel<false><<<grid, LG_TILE, 0, s>>>(p, d_lanes);
+    if (form == 2) {
+        sample_kernel<2><<<grid, LG_TILE, 0, s>>>(p, d_lanes);
+        hipCheckError();
+        dedup_lds_kernel<<<dim3(LG_LDS_BUCKETS, n_lanes), LG_DEDUP_THREADS, 0, s>>>(p, d_lanes);
+    } else if (form == 1) {
+        sample_kernel<1><<<grid, LG_TILE, 0, s>>>(p, d_lanes);
+    } else {
+        sample_kernel<0><<<grid, LG_TILE, 0, s>>>(p, d_lanes);
+    }
     hipCheckError();
     flag_count_kernel<<<grid, LG_TILE, 0, s>>>(p, d_lanes);
     hipCheckError();
@@ -777,7 +934,7 @@ __global__ void end_of_batch_kernel(const LanePtrs* __restrict__ lanes, int32_t*
         if (L.pos_table != nullptr) {
             for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i <= (int64_t)L.pos_mask; i += (int64_t)gridDim.x * blockDim.x)
                 L.pos_table[i] = ~0ull;
-        } else {
+        } else if (L.position_map != nullptr) {
             LG_G uint32_t* pm = L.position_map;
             for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < L.total_num_nodes; i += (int64_t)gridDim.x * blockDim.x)
                 pm[i] = 0xFFFFFFFFu;

@@ -78,6 +78,18 @@
 // merged away exactly once -- by the thread that observes it -- which keeps "one writer per loser mark".
 // Same epochs, same refill rule (T x 8 B instead of N x 4 B).  Selected per pool: LEGION_DEDUP=direct|table|auto
 // (auto: table when the direct arrays of all lanes in flight would take more than a quarter of HBM).
+//
+// The LDS form (round 2) issues no memory-side atomic per claim at all.  A hop's claims (vertex, slot) are written, by
+// the sampling kernel, into 8 hash buckets per lane (one reservation per 1024-slot super tile, ranks by LDS atomics); a
+// second kernel gives every (lane, bucket) a workgroup that builds an open-addressing table of the bucket's vertices IN
+// LDS -- the batch's known vertices of that bucket re-inserted from sampled_ids with their positions, then the claims with
+// atomicMin on (vertex, pending | slot) -- and writes, for every claim that is not the lowest slot of a new vertex, the
+// same loser mark the other forms leave.  No per-vertex state survives the hop, nothing to clear, nothing that scales
+// with N.  Used when a hop's slots per lane are few enough (<= 2^19: B = 1024-class batches); a bucket whose vertices
+// do not fit the table is handled in several passes over sub-buckets, so the result never depends on the hash.
+#define LG_LDS_BUCKETS 8
+#define LG_LDS_TABLE 8192          // 64-bit words of LDS per (lane, bucket) workgroup
+#define LG_LDS_MAX_SLOTS (1 << 19)
 #define LG_POS_VALUE_BITS_MIN 16
 #define LG_POS_VALUE_BITS_MAX 28
 struct PosFmt {
@@ -124,6 +136,7 @@ enum HopScratch {
     HS_EPOCH = 8,          // this lane's current epoch of the position-state array
     HS_TICKET = 9,         // last-workgroup ticket of the end-of-batch kernel
     HS_VALUE_BITS = 30,    // vb of the position-state format (fixed at pool creation)
+    HS_PAIR_CURSOR = 27,   // lds form: pairs reserved so far in the hop being sampled (reset by the de-duplication kernel)
     HS_ERROR = 29,         // sticky error bits of the lane (LG_ERR_*), also mirrored to the pool's host-visible flag
     HS_RANGE = 10,         // [HS_RANGE + 2h], [+1]: {offset, count} of the new nodes of op 3h, kept for its gather
     HS_WORDS = 32
@@ -194,6 +207,11 @@ struct LanePtrs {
     int32_t* position_map;             // direct form: uint32[N]; null in table form
     unsigned long long* pos_table;     // table form: uint64[pos_table_mask + 1]; null in direct form
     uint32_t pos_table_mask;
+    // lds form of the first-touch state (no per-vertex state at all, legion_core.h "LDS form"): the hop's claims,
+    // partitioned by hash bucket inside the run of every 1024-slot super tile
+    unsigned long long* claim_pairs;   // [max_slots] (vertex << 32 | slot)
+    int32_t* run_base;                 // [super tiles] where the super tile's run starts in claim_pairs
+    int32_t* run_cnt;                  // [super tiles][LG_LDS_BUCKETS] claims of each bucket in that run
     int32_t* err_flag;                 // mapped pinned host word: kernels OR LG_ERR_* bits into it
     const void* deliver;               // lg::DeliverParams* (device) or null: the gather of this lane also hands its batch
                                        // over to that trainer-visible pipe slot (GPURunner's hand-over descriptors)
@@ -268,6 +286,10 @@ public:
     int32_t* tile_prefix = nullptr;    // [2 * max_tiles] exclusive prefixes
     RowHdr* fh_edge = nullptr;         // [num_ids] frontier row headers written by scatter
     int32_t* hop_scratch = nullptr;    // [HS_WORDS]
+    unsigned long long* claim_pairs = nullptr; // lds form: see LanePtrs
+    int32_t* run_base = nullptr;
+    int32_t* run_cnt = nullptr;
+    bool lds_form = false;
     unsigned long long* pos_table = nullptr;   // compact position state (table form), else null
     uint32_t pos_table_mask = 0;
     int32_t* err_host = nullptr;       // host-visible error word (mapped pinned), err_dev = its device address
@@ -593,7 +615,8 @@ struct HopParams {                  // what every lane of a launch shares
     unsigned long long* edge_access_time;  // presample only (single lane), else null
     unsigned long long* topo_transactions; // presample only: 64-byte transactions the hop's topology reads amount to
 };
-void launch_random_sample(hipStream_t s, const HopParams& p, const LanePtrs* d_lanes, int32_t n_lanes, bool table_form);
+// form: 0 direct array, 1 table, 2 lds
+void launch_random_sample(hipStream_t s, const HopParams& p, const LanePtrs* d_lanes, int32_t n_lanes, int32_t form);
 
 // hand-over of a lane's finished batch to a trainer-visible pipe slot (kernels_gather.hip)
 struct DeliverParams {

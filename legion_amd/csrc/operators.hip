@@ -37,8 +37,9 @@ struct LegionLaneGroup {
     int32_t* iter_state = nullptr;    // device {next iteration of lane 0, stride} for graph replay, or null
 };
 
-static inline int64_t pool_state_bytes(const MemoryPool* mp)
+static inline int64_t pool_state_bytes(const MemoryPool* mp)     // what an epoch wrap refills
 {
+    if (mp->lds_form) return 4;
     return mp->pos_table ? ((int64_t)mp->pos_table_mask + 1) * 8 : (int64_t)mp->total_num_nodes * 4;
 }
 
@@ -116,7 +117,7 @@ static void do_random_sample(hipStream_t s, GraphStorage* graph, UnifiedCache* c
     p.max_slots = (int32_t)(hop < pool0->max_new.size() ? pool0->max_new[hop] : pool0->max_slots);
     p.edge_access_time = (is_presc && cache) ? cache->GetEdgeAccessedMap(dev_id) : nullptr;   // :473
     p.topo_transactions = (is_presc && cache) ? cache->Controller(dev_id)->GetTopoTransactions() : nullptr;
-    lg::launch_random_sample(s, p, d_lanes, n_lanes, pool0->pos_table != nullptr);
+    lg::launch_random_sample(s, p, d_lanes, n_lanes, pool0->lds_form ? 2 : (pool0->pos_table != nullptr ? 1 : 0));
 }
 
 static void do_feature_lookup(hipStream_t s, UnifiedCache* cache, const LanePtrs* d_lanes, int32_t n_lanes,

@@ -339,6 +339,9 @@ LanePtrs MemoryPool::HostLane(int32_t pipe) const
     h.pos_table = pos_table;
     h.pos_table_mask = pos_table_mask;
     h.err_flag = err_dev;
+    h.claim_pairs = claim_pairs;
+    h.run_base = run_base;
+    h.run_cnt = run_cnt;
     h.node_counter = node_counter_[pipe];
     h.edge_counter = edge_counter_[pipe];
     h.slot_dst = slot_dst;
@@ -380,6 +383,11 @@ void MemoryPool::Finalize()
     d_free_space(position_map_);
     d_free_space(pos_table);
     pos_table = nullptr;
+    d_free_space(claim_pairs);
+    d_free_space(run_base);
+    d_free_space(run_cnt);
+    claim_pairs = nullptr;
+    run_base = run_cnt = nullptr;
     if (err_host) HIP_CALL(hipHostFree(err_host));
     err_host = err_dev = nullptr;
     d_free_space(agg_src_ids_);
@@ -416,15 +424,26 @@ void MemoryPool::Finalize()
 }
 
 // ---- direct array or compact table for the position state (legion_core.h) ------------------------
+static bool lg_use_pos_table(int64_t total_num_nodes);
 static thread_local int32_t g_pool_lanes_hint = 0;
 void lg_set_pool_lanes_hint(int32_t lanes) { g_pool_lanes_hint = lanes; }
 
-static bool lg_use_pos_table(int64_t total_num_nodes)
+// 0 direct array, 1 table, 2 lds (legion_core.h)
+static int lg_dedup_form(int64_t total_num_nodes, int64_t max_slots)
 {
     if (const char* e = getenv("LEGION_DEDUP")) {
-        if (strcmp(e, "table") == 0) return true;
-        if (strcmp(e, "direct") == 0) return false;
+        if (strcmp(e, "table") == 0) return 1;
+        if (strcmp(e, "direct") == 0) return 0;
+        if (strcmp(e, "lds") == 0) return max_slots <= LG_LDS_MAX_SLOTS ? 2 : 1;
     }
+    // auto: the LDS form wherever a hop's slots per lane allow it (12 % more edges/s at B = 1024 than either atomics form and
+    // no per-vertex state); otherwise the direct array while it fits a quarter of HBM over all lanes in flight, else the table
+    if (max_slots <= LG_LDS_MAX_SLOTS) return 2;
+    return lg_use_pos_table(total_num_nodes) ? 1 : 0;
+}
+
+static bool lg_use_pos_table(int64_t total_num_nodes)
+{
     size_t free_b = 0, total_b = 0;
     HIP_CALL(hipMemGetInfo(&free_b, &total_b));
     const int64_t lanes = g_pool_lanes_hint > 0 ? g_pool_lanes_hint : 1;
@@ -454,7 +473,17 @@ void lg_pool_alloc_private(MemoryPool* mp, int32_t dev_id, int32_t total_num_nod
     mp->batch_size = batch_size;
     mp->float_feature_len = float_feature_len;
     mp->SetCacheSearchBuffer((int32_t*)d_alloc_space(num_ids * sizeof(int32_t)));
-    if (lg_use_pos_table(total_num_nodes)) {
+    const int form = lg_dedup_form(total_num_nodes, hop_num > 0 ? per : batch_size);
+    if (form == 2) {
+        // lds form: no per-vertex state; the hop's claim pairs + the runs of every super tile
+        const int64_t slots = hop_num > 0 ? per : batch_size;
+        const int64_t n_super = (slots + LG_SUPER - 1) / LG_SUPER + 1;
+        mp->lds_form = true;
+        mp->claim_pairs = (unsigned long long*)d_alloc_space(slots * sizeof(unsigned long long));
+        mp->run_base = (int32_t*)d_alloc_space(n_super * sizeof(int32_t));
+        mp->run_cnt = (int32_t*)d_alloc_space(n_super * LG_LDS_BUCKETS * sizeof(int32_t));
+        mp->SetPositionMap(nullptr);
+    } else if (form == 1) {
         // compact form: at least 1.5 x the pool's worst-case id count, so a free word always exists
         uint32_t bits = 10;
         while (((int64_t)1 << bits) < num_ids + num_ids / 2) bits++;
@@ -639,10 +668,19 @@ extern "C" int32_t legion_pool_uses_table(const LegionMemoryPool* p_)
     return (mp && mp->pos_table != nullptr) ? 1 : 0;
 }
 
+// 0 direct uint32[N] array, 1 compact table, 2 lds (no per-vertex state)
+extern "C" int32_t legion_pool_dedup_form(const LegionMemoryPool* p_)
+{
+    const MemoryPool* mp = reinterpret_cast<const MemoryPool*>(p_);
+    if (!mp) return -1;
+    return mp->lds_form ? 2 : (mp->pos_table != nullptr ? 1 : 0);
+}
+
 extern "C" int64_t legion_pool_state_bytes(const LegionMemoryPool* p_)
 {
     const MemoryPool* mp = reinterpret_cast<const MemoryPool*>(p_);
     if (!mp) return 0;
+    if (mp->lds_form) return (int64_t)mp->max_slots * 8;      // the claim pairs of one hop
     return mp->pos_table ? ((int64_t)mp->pos_table_mask + 1) * 8 : (int64_t)mp->total_num_nodes * 4;
 }
 

@@ -235,6 +235,10 @@ class MemoryPool:
         """True if the pool's first-touch/position state is the compact table form (LEGION_DEDUP)."""
         return bool(self._lib.legion_pool_uses_table(self.handle))
 
+    def dedup_form(self):
+        """'direct', 'table' or 'lds' (legion_hip.h: legion_pool_dedup_form)."""
+        return ("direct", "table", "lds")[int(self._lib.legion_pool_dedup_form(self.handle))]
+
     def state_bytes(self):
         return int(self._lib.legion_pool_state_bytes(self.handle))
 

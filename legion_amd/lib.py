@@ -38,6 +38,7 @@ SIGNATURES = {
     "legion_pool_buffer": (c_p, [c_p, c_i32]),
     "legion_pool_destroy": (None, [c_p]),
     "legion_pool_uses_table": (c_i32, [c_p]),
+    "legion_pool_dedup_form": (c_i32, [c_p]),
     "legion_pool_state_bytes": (c_i64, [c_p]),
     "legion_pool_error": (c_i32, [c_p]),
     "legion_cache_create": (c_p, [c_i64, c_i32, c_i32, c_i32, c_i32]),

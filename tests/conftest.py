@@ -45,9 +45,10 @@ def hip():
     return L
 
 
-@pytest.fixture(params=["direct", "table"])
+@pytest.fixture(params=["direct", "table", "lds"])
 def dedup(request, monkeypatch):
-    """Runs a GPU test once per form of the first-touch/position state (legion_core.h): the direct
-    uint32[N] array and the compact open-addressing table.  Both must give bit-identical batches."""
+    """Runs a GPU test once per form of the first-touch state (legion_core.h): the direct uint32[N] array, the compact
+    open-addressing table, and the LDS form (no per-vertex state; pools whose largest hop exceeds 2^19 slots fall back to
+    the table).  All must give bit-identical batches."""
     monkeypatch.setenv("LEGION_DEDUP", request.param)
     return request.param

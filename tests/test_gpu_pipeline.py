@@ -21,7 +21,7 @@ pytestmark = pytest.mark.gpu
 def test_serve_batches_no_cache(hip, dedup, scale, ef, fanout, batch, dim):
     wl = Workload(scale=scale, edge_factor=ef, dim=dim)
     gpu, cpu = GpuSide(wl, batch, fanout), CpuSide(wl, batch, fanout)
-    assert gpu.pools[0].uses_table() == (dedup == "table")
+    assert gpu.pools[0].dedup_form() == dedup
     n_train = wl.sets[(0, 0)][0].size
     for mode, counters in ((0, range(min(3, (n_train - 1) // batch))), (1, range(2)), (2, range(1))):
         bs = batch if mode == 0 else min(batch, 100)
@@ -315,6 +315,36 @@ def test_hot_row_replica_keeps_results_and_saves_peer_reads(hip, P, mode_bits, c
             hits += int(hit.sum()); from_replica += int((rank < want_rows).sum())
         stripe, replica = gpu.cache.gather_stats(p)
         assert (stripe, replica) == (hits - from_replica, from_replica) and replica > 0
+    gpu.close(); cpu.close()
+
+
+def test_lds_dedup_multi_pass_buckets(hip, monkeypatch):
+    """The LDS form when a bucket's vertices do not fit its table: batches of up to ~100 k claims per lane make every
+    (lane, bucket) workgroup run 2-4 passes over sub-buckets; still bit-exact, no error raised.  Also a graph with hubs
+    sampled thousands of times in one batch (every duplicate lands in the same bucket)."""
+    monkeypatch.setenv("LEGION_DEDUP", "lds")
+    wl = Workload(scale=15, edge_factor=16, dim=4, n_seeds=9000)
+    fanout, batch = [10, 10], 2000                         # hop 2: up to 200 k slots per lane
+    gpu, cpu = GpuSide(wl, batch, fanout), CpuSide(wl, batch, fanout)
+    assert gpu.pools[0].dedup_form() == "lds"
+    for it in range(3):
+        g, c = gpu.run(0, it, 0), cpu.run(0, it, 0)
+        compare_batches(g, c, f"multi-pass lds batch {it}: ")
+        assert int(g["edge_counter"][11] - g["edge_counter"][10]) > 8 * 4096      # more claims than 8 half-full tables hold
+    assert gpu.pools[0].error() == 0
+    gpu.close(); cpu.close()
+    # a star-heavy graph: vertex 0 is everybody's neighbour many times over
+    N = 4096
+    deg = np.full(N, 24, dtype=np.int64)
+    indptr = np.zeros(N + 1, dtype=np.int64); np.cumsum(deg, out=indptr[1:])
+    rng = np.random.RandomState(9)
+    col = rng.randint(0, N, indptr[-1]).astype(np.int32)
+    col[rng.rand(col.size) < 0.5] = 0
+    wl = Workload(dim=4, n_seeds=2000, indptr=indptr, col=col)
+    gpu, cpu = GpuSide(wl, 512, [12, 6]), CpuSide(wl, 512, [12, 6])
+    for it in range(3):
+        compare_batches(gpu.run(0, it, 0), cpu.run(0, it, 0), f"hub graph lds batch {it}: ")
+    assert gpu.pools[0].error() == 0
     gpu.close(); cpu.close()
 
 
