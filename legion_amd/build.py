@@ -20,7 +20,7 @@ ARCH = "gfx950"
 SOURCES = ["kernels_sample.hip", "kernels_gather.hip", "kernels_cache.hip", "kernels_synth.hip",
            "storage.hip", "link_counters.hip", "cache.hip", "operators.hip", "pipeline.hip", "ipc_env.hip", "server.hip"]
 FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-fno-fast-math", "-Wall",
-         "-Wno-unused-result", "-Wno-unused-function"]
+         "-Wno-unused-result", "-Wno-unused-function"] + os.environ.get("LEGION_EXTRA_HIPCC_FLAGS", "").split()
 
 
 def _newer(target, deps):

@@ -487,9 +487,10 @@ __global__ __launch_bounds__(LG_TILE) void sample_kernel(HopParams hp, const Lan
 // result never depends on how the hash spreads the batch.  Nothing survives the hop: nothing to clear, no state that
 // scales with the graph.
 // ------------------------------------------------------------------------------------------
+#ifndef LG_DEDUP_THREADS
 #define LG_DEDUP_THREADS 1024
-__device__ __forceinline__ uint32_t lds_slot_of(uint32_t h) { return (h * 0x9E3779B1u) >> (32 - 13); }   // LG_LDS_TABLE = 2^13
-static_assert(LG_LDS_TABLE == (1 << 13), "lds_slot_of assumes a 2^13-word table");
+#endif
+__device__ __forceinline__ uint32_t lds_slot_of(uint32_t h) { return (h * 0x9E3779B1u) >> (32 - LG_LDS_TABLE_BITS); }
 
 __global__ __launch_bounds__(LG_DEDUP_THREADS) void dedup_lds_kernel(HopParams hp, const LanePtrs* __restrict__ lanes)
 {
@@ -554,13 +555,13 @@ __global__ __launch_bounds__(LG_DEDUP_THREADS) void dedup_lds_kernel(HopParams h
             const int32_t id = a.sampled_ids[i];
             if (id < 0) continue;
             const uint32_t h = lg_tab_hash(id);
-            if ((h & (LG_LDS_BUCKETS - 1)) != (uint32_t)b || ((h >> 3) & pmask) != pass) continue;
+            if ((h & (LG_LDS_BUCKETS - 1)) != (uint32_t)b || ((h >> LG_LDS_BUCKET_BITS) & pmask) != pass) continue;
             insert(((unsigned long long)(uint32_t)id << 32) | (uint32_t)i, h);
         }
         for (int32_t k = tid; k < total; k += LG_DEDUP_THREADS) {
             const unsigned long long pr = a.claim_pairs[segment_of(k)];
             const uint32_t h = lg_tab_hash((int32_t)(pr >> 32));
-            if (((h >> 3) & pmask) != pass) continue;
+            if (((h >> LG_LDS_BUCKET_BITS) & pmask) != pass) continue;
             insert((pr & 0xFFFFFFFF00000000ull) | PENDING | (uint32_t)pr, h);
         }
         __syncthreads();
@@ -568,7 +569,7 @@ __global__ __launch_bounds__(LG_DEDUP_THREADS) void dedup_lds_kernel(HopParams h
             const unsigned long long pr = a.claim_pairs[segment_of(k)];
             const uint32_t id = (uint32_t)(pr >> 32), slot = (uint32_t)pr;
             const uint32_t h = lg_tab_hash((int32_t)id);
-            if (((h >> 3) & pmask) != pass) continue;
+            if (((h >> LG_LDS_BUCKET_BITS) & pmask) != pass) continue;
             uint32_t p = lds_slot_of(h);
             uint32_t v = 0xFFFFFFFFu;
             for (int it = 0; it < LG_LDS_TABLE; it++) {

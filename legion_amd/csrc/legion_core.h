@@ -87,8 +87,14 @@
 // same loser mark the other forms leave.  No per-vertex state survives the hop, nothing to clear, nothing that scales
 // with N.  Used when a hop's slots per lane are few enough (<= 2^19: B = 1024-class batches); a bucket whose vertices
 // do not fit the table is handled in several passes over sub-buckets, so the result never depends on the hash.
-#define LG_LDS_BUCKETS 8
-#define LG_LDS_TABLE 8192          // 64-bit words of LDS per (lane, bucket) workgroup
+#ifndef LG_LDS_BUCKET_BITS
+#define LG_LDS_BUCKET_BITS 3
+#endif
+#ifndef LG_LDS_TABLE_BITS
+#define LG_LDS_TABLE_BITS 13
+#endif
+#define LG_LDS_BUCKETS (1 << LG_LDS_BUCKET_BITS)
+#define LG_LDS_TABLE (1 << LG_LDS_TABLE_BITS)   // 64-bit words of LDS per (lane, bucket) workgroup
 #define LG_LDS_MAX_SLOTS (1 << 19)
 #define LG_POS_VALUE_BITS_MIN 16
 #define LG_POS_VALUE_BITS_MAX 28

@@ -1,6 +1,6 @@
 #!/bin/bash
 # PMC passes (one counter group per run, kernel-trace only) for the sampler kernels, once per form of the position state:
-#   bash tools/pmc_sampler.sh direct|table [--scramble]     -> gpurun_out/pmc_s_<form>[_scr]/pmc_sampler_kernels.csv
+#   bash tools/pmc_sampler.sh direct|table|lds [--scramble]     -> gpurun_out/pmc_s_<form>[_scr]/pmc_sampler_kernels.csv
 FORM=${1:-direct}
 SCR=$2
 cd /tmp && export TMPDIR=/tmp
