@@ -110,7 +110,7 @@ int32_t legion_pool_num_ids(const LegionMemoryPool* p);
 void* legion_pool_buffer(LegionMemoryPool* p, int32_t which);
 /* New in this build.  The first-touch/position state of a pool (the reference's accessed_map + position_map,
  * SS/engine/memorypool.cuh:120-135) is either a direct uint32[N] array (fastest; N x 4 B per pool) or a compact
- * open-addressing table sized by num_ids (LEGION_DEDUP=direct|table|auto, auto = table when the arrays of all
+ * open-addressing table sized by num_ids, or (form "lds") nothing at all per vertex: see legion_pool_dedup_form (LEGION_DEDUP=direct|table|lds|auto, auto = lds for small hops, else table when the arrays of all
  * pools in flight would exceed a quarter of HBM).  Both give bit-identical batches. */
 int32_t legion_pool_uses_table(const LegionMemoryPool* p);
 /* 0 direct array, 1 compact table, 2 "lds": no per-vertex state, a hop's claims are de-duplicated bucket by bucket in LDS
