@@ -1,3 +1,5 @@
+"""Per-position average kernel durations of one launch group from a rocprofv3 --kernel-trace csv directory
+(`bench.py --no-weave` on one stream: the op list repeats every 16 kernels).  Usage: python tools/trace_group.py <dir>"""
 import csv, glob, collections, sys
 f = glob.glob(sys.argv[1] + "/*/*kernel_trace.csv")[0]
 rows = [r for r in csv.DictReader(open(f)) if "lg::" in r["Kernel_Name"] and r["Grid_Size_Y"] == "256"]
