@@ -11,7 +11,7 @@ KEYS_EXACT = ["node_counter", "edge_counter", "sampled_ids", "labels", "agg_src_
 
 class Workload:
     def __init__(self, scale=10, edge_factor=8, dim=16, seed=20231, n_seeds=None, n_valid=300, n_test=200,
-                 partition_count=1, indptr=None, col=None):
+                 partition_count=1, indptr=None, col=None, partition=None):
         if indptr is None:
             indptr, col = synth.rmat_csr_numpy(scale, edge_factor, seed)
         self.indptr, self.col = indptr, col
@@ -26,11 +26,14 @@ class Workload:
         valid = perm[n_seeds:n_seeds + n_valid]
         test = perm[n_seeds + n_valid:n_seeds + n_valid + n_test]
         self.labels_all = (np.arange(self.N, dtype=np.int64) * 2654435761 % 47).astype(np.int32)
-        # storage_management.cu:171-203: id % partition_count
+        # storage_management.cu:171-203: id % partition_count; with a `partition` file the TRAINING ids go where the
+        # file says (an entry >= partition_count drops the id), validation and testing ids stay on id % partition_count
+        self.train, self.valid, self.test = train, valid, test
         self.sets = {}
         for mode, ids in ((0, train), (1, valid), (2, test)):
+            part_of = partition[ids] if (partition is not None and mode == 0) else ids % partition_count
             for p in range(partition_count):
-                mine = ids[ids % partition_count == p]
+                mine = ids[part_of == p]
                 self.sets[(p, mode)] = (np.ascontiguousarray(mine), np.ascontiguousarray(self.labels_all[mine]))
 
 

@@ -71,16 +71,25 @@ def test_rccl_calls_execute_at_n1(hip):
     assert d["n_gpus"] == 1 and d["value"] > 0
 
 
-def test_one_server_process_two_gpus_thread_per_gpu(hip, tmp_path):
+@pytest.mark.parametrize("partition_file", [False, True], ids=["modulo", "partition-file"])
+def test_one_server_process_two_gpus_thread_per_gpu(hip, tmp_path, partition_file):
     """`sampling_server 2 1 5 3`: GPUServer with two runners (a host thread each), PreSC on both, hotness summed over the
-    clique, caches striped Kg = 2, two pipe-slot sets, two trainer processes.  Logical GPU 1 shares the box's one GPU."""
+    clique, caches striped Kg = 2, two pipe-slot sets, two trainer processes.  Logical GPU 1 shares the box's one GPU.
+    With a `partition` file in the dataset directory (the reference's xtrapulp output, storage_management.cu:165-183)
+    training seeds go to the GPU the file names -- an uneven split, entries >= 2 dropped -- while validation and testing
+    seeds stay on id % 2."""
     scale, D, B, fanout, epoch, cache_memory = 11, 24, 40, [5, 3], 2, 40_000
-    wl = Workload(scale=scale, edge_factor=8, dim=D, n_seeds=700, n_valid=130, n_test=70, partition_count=2)
+    part = None
+    if partition_file:
+        part = np.random.RandomState(5).choice(3, size=1 << scale, p=[0.55, 0.35, 0.10]).astype(np.int32)
+    wl = Workload(scale=scale, edge_factor=8, dim=D, n_seeds=700, n_valid=130, n_test=70, partition_count=2, partition=part)
     N = wl.N
-    perm = np.random.RandomState(11).permutation(N).astype(np.int32)          # Workload's own split, unpartitioned
-    train, valid, test = perm[:700], perm[700:830], perm[830:900]
+    train, valid, test = wl.train, wl.valid, wl.test                           # the split before it is partitioned
     ds = str(tmp_path / "ds") + "/"
     os.makedirs(ds)
+    if partition_file:
+        part.tofile(ds + "partition")
+        assert wl.sets[(0, 0)][0].size != wl.sets[(1, 0)][0].size and wl.sets[(0, 0)][0].size + wl.sets[(1, 0)][0].size < 700
     wl.indptr.astype(np.int64).tofile(ds + "edge_src"); wl.col.astype(np.int32).tofile(ds + "edge_dst")
     wl.features.astype(np.float32).tofile(ds + "features"); wl.labels_all.astype(np.int32).tofile(ds + "labels")
     train.tofile(ds + "trainingset"); valid.tofile(ds + "validationset"); test.tofile(ds + "testingset")
