@@ -469,8 +469,9 @@ def main():
                 "repeats": overlapped[1],
                 "note": "same K steps, same batches, with every group's sampler phase on one stream and its gathers on another "
                         "(sampler k+1 runs under gathers k; `bench.py --split` makes this the headline).  Each kernel runs "
-                        "slower while sharing the machine (the gather at ~0.59 of peak instead of 0.76) but the group finishes "
-                        "sooner: at ~6.5 GB of HBM sector traffic per step the pipeline is then bound by total traffic."},
+                        "slower while sharing the machine (the gather at ~0.59 of peak instead of 0.78).  With the atomics forms "
+                        "of the first-touch state this finishes a group 8-12 % sooner than one stream; with the LDS form and "
+                        "the weave default it does not (DESIGN.md section 4.5)."},
             "position_state": {"form": pipe.pools[0][0].dedup_form(),
                                "bytes_per_lane": pipe.pools[0][0].state_bytes(), "lanes": G * args.slots},
             "feature_cache_hit_rate": feat_hit_rows / max(feat_hit_rows + feat_miss_rows, 1),

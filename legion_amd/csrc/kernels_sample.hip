@@ -102,6 +102,7 @@ struct BracketLane {
     LG_G int32_t* sampled_ids; LG_G int32_t* labels; LG_G int32_t* node_counter; LG_G int32_t* edge_counter;
     LG_G int32_t* hop_scratch; LG_G uint32_t* position_map; LG_G int32_t* slot_mark;
     LG_G unsigned long long* pos_table; uint32_t pos_mask; LG_G int32_t* err_flag;
+    LG_G int32_t* known_cnt;
     int32_t total_num_nodes, max_slots;
 };
 __device__ __forceinline__ BracketLane bracket_lane(const LanePtrs& P)
@@ -113,6 +114,7 @@ __device__ __forceinline__ BracketLane bracket_lane(const LanePtrs& P)
     L.slot_mark = LG_GPTR(int32_t, P.slot_mark);
     L.pos_table = LG_GPTR(unsigned long long, P.pos_table); L.pos_mask = P.pos_table_mask;
     L.err_flag = LG_GPTR(int32_t, P.err_flag);
+    L.known_cnt = LG_GPTR(int32_t, P.known_cnt);
     L.total_num_nodes = P.total_num_nodes; L.max_slots = P.max_slots;
     return L;
 }
@@ -181,6 +183,7 @@ __global__ void batch_generate_kernel(SeedParams p, const LanePtrs* __restrict__
     // operator_impl.cu:159 -- the clamped last batch (may be <= 0: nothing is sampled)
     const int32_t size = ((int64_t)p.batch_size * (counter + 1) >= p.total_cap)
                              ? (p.total_cap - p.batch_size * counter) : p.batch_size;
+    if (L.known_cnt != nullptr && idx < LG_LDS_BUCKETS) L.known_cnt[idx] = 0;    // lds form: the batch's known lists start empty
     if (idx < 16) {                    // memset of both counter blocks, operator_impl.cu:155-156,
         int32_t v = 0;                 // then counter_update(op 0), :64-68
         if (idx == 1) v = size;
@@ -237,6 +240,7 @@ struct SampleArgs {
     LG_G RowHdr* fh_edge;
     LG_G unsigned long long* pos_table; uint32_t pos_mask; LG_G int32_t* err_flag;
     LG_G unsigned long long* claim_pairs; LG_G int32_t* run_base; LG_G int32_t* run_cnt;
+    LG_G unsigned long long* known_pairs; LG_G int32_t* known_cnt; int32_t known_cap;
     PosFmt pf;
     int32_t mark_tag;   // (epoch, hop): what slot_mark holds for a slot that lost its first touch in THIS hop
 };
@@ -283,6 +287,7 @@ __device__ __forceinline__ SampleArgs lane_args(const HopParams& p, const LanePt
     a.err_flag = LG_GPTR(int32_t, L.err_flag);
     a.claim_pairs = LG_GPTR(unsigned long long, L.claim_pairs);
     a.run_base = LG_GPTR(int32_t, L.run_base); a.run_cnt = LG_GPTR(int32_t, L.run_cnt);
+    a.known_pairs = LG_GPTR(unsigned long long, L.known_pairs); a.known_cnt = LG_GPTR(int32_t, L.known_cnt); a.known_cap = L.known_cap;
     a.pf = lg_pos_fmt(a.hop_scratch[HS_EPOCH], a.hop_scratch[HS_VALUE_BITS]);
     a.mark_tag = (a.hop_scratch[HS_EPOCH] << 8) | (p.op_id / INTRABATCH_CON);
     return a;
@@ -487,6 +492,10 @@ __global__ __launch_bounds__(LG_TILE) void sample_kernel(HopParams hp, const Lan
 // result never depends on how the hash spreads the batch.  Nothing survives the hop: nothing to clear, no state that
 // scales with the graph.
 // ------------------------------------------------------------------------------------------
+#ifndef LG_LDS_FILL_16THS
+#define LG_LDS_FILL_16THS 14         // a pass may fill its table up to this many sixteenths (bound: known + claims of the pass)
+#endif
+#define LG_DEDUP_BATCH 4             // claims a thread loads before it works on them (their loads are in flight together)
 #ifndef LG_DEDUP_THREADS
 #define LG_DEDUP_THREADS 1024
 #endif
@@ -513,23 +522,37 @@ __global__ __launch_bounds__(LG_DEDUP_THREADS) void dedup_lds_kernel(HopParams h
         s_seg[t] = off;
     }
     __syncthreads();
-    if (tid == 0) {                                    // <= 512 entries: a serial scan costs less than its barriers
-        int32_t acc = 0;
-        s_pref[0] = 0;
-        for (int32_t t = 0; t < g.nsuper; t++) { acc += s_pref[t + 1]; s_pref[t + 1] = acc; }
-        s_total = acc;
+    if (tid < 64) {                                    // <= 513 entries: wave 0 scans them, a few consecutive entries per lane
+        const int32_t per = (g.nsuper + 63) / 64;
+        const int32_t lo = min(tid * per, g.nsuper), hi = min(lo + per, g.nsuper);
+        int32_t sum = 0;
+        for (int32_t t = lo; t < hi; t++) sum += s_pref[t + 1];
+        int32_t inc = sum;
+        for (int d = 1; d < 64; d <<= 1) { const int32_t o = __shfl_up(inc, d); if (tid >= d) inc += o; }
+        int32_t acc = inc - sum;
+        for (int32_t t = lo; t < hi; t++) { acc += s_pref[t + 1]; s_pref[t + 1] = acc; }
+        if (tid == 0) s_pref[0] = 0;
+        if (tid == 63) s_total = inc;
     }
+    // the batch's vertices before this hop: the seeds are read from sampled_ids, the nodes earlier hops added from the
+    // bucket's list (scatter_kernel) -- or from sampled_ids too when there is no list or it outgrew its capacity
+    const int32_t n_seed = min(max(a.node_counter[INTRABATCH_CON * 3], 0), n_known);
+    const int32_t n_listed = a.known_pairs != nullptr ? a.known_cnt[b] : 0;
+    const bool listed = a.known_pairs != nullptr && n_listed <= a.known_cap;
+    const int32_t n_scan = listed ? n_seed : n_known;
+    const LG_G unsigned long long* klist = a.known_pairs + (int64_t)b * a.known_cap;
     int32_t known_here = 0;
-    for (int32_t i = tid; i < n_known; i += LG_DEDUP_THREADS) {
+    for (int32_t i = tid; i < n_scan; i += LG_DEDUP_THREADS) {
         const int32_t id = a.sampled_ids[i];
         if (id >= 0 && (lg_tab_hash(id) & (LG_LDS_BUCKETS - 1)) == (uint32_t)b) known_here++;
     }
+    if (tid == 0 && listed) known_here += n_listed;
     if (known_here) atomicAdd(&s_known, known_here);
     __syncthreads();
     const int32_t total = s_total;
     // passes: distinct vertices <= known + claims; keep the expected load of a pass at or below half the table
     int32_t passes = 1;
-    while ((int64_t)(s_known + total) > (int64_t)passes * (LG_LDS_TABLE / 2)) passes <<= 1;
+    while ((int64_t)(s_known + total) > (int64_t)passes * (LG_LDS_TABLE / 16 * LG_LDS_FILL_16THS)) passes <<= 1;
     const uint32_t pmask = (uint32_t)passes - 1u;
 
     auto segment_of = [&](int32_t k) {                 // claim k of the bucket -> index into claim_pairs
@@ -551,35 +574,60 @@ __global__ __launch_bounds__(LG_DEDUP_THREADS) void dedup_lds_kernel(HopParams h
     for (uint32_t pass = 0; pass <= pmask; pass++) {
         for (int32_t i = tid; i < LG_LDS_TABLE; i += LG_DEDUP_THREADS) s_tab[i] = ~0ull;
         __syncthreads();
-        for (int32_t i = tid; i < n_known; i += LG_DEDUP_THREADS) {
+        for (int32_t i = tid; i < n_scan; i += LG_DEDUP_THREADS) {
             const int32_t id = a.sampled_ids[i];
             if (id < 0) continue;
             const uint32_t h = lg_tab_hash(id);
             if ((h & (LG_LDS_BUCKETS - 1)) != (uint32_t)b || ((h >> LG_LDS_BUCKET_BITS) & pmask) != pass) continue;
             insert(((unsigned long long)(uint32_t)id << 32) | (uint32_t)i, h);
         }
-        for (int32_t k = tid; k < total; k += LG_DEDUP_THREADS) {
-            const unsigned long long pr = a.claim_pairs[segment_of(k)];
-            const uint32_t h = lg_tab_hash((int32_t)(pr >> 32));
-            if (((h >> LG_LDS_BUCKET_BITS) & pmask) != pass) continue;
-            insert((pr & 0xFFFFFFFF00000000ull) | PENDING | (uint32_t)pr, h);
+        if (listed)
+            for (int32_t i = tid; i < n_listed; i += LG_DEDUP_THREADS) {
+                const unsigned long long pr = klist[i];
+                const uint32_t h = lg_tab_hash((int32_t)(pr >> 32));
+                if (((h >> LG_LDS_BUCKET_BITS) & pmask) != pass) continue;
+                insert(pr, h);
+            }
+        for (int32_t k0 = 0; k0 < total; k0 += LG_DEDUP_BATCH * LG_DEDUP_THREADS) {
+            unsigned long long pr[LG_DEDUP_BATCH];
+#pragma unroll
+            for (int u = 0; u < LG_DEDUP_BATCH; u++) {
+                const int32_t k = k0 + u * LG_DEDUP_THREADS + tid;
+                pr[u] = k < total ? a.claim_pairs[segment_of(k)] : ~0ull;
+            }
+#pragma unroll
+            for (int u = 0; u < LG_DEDUP_BATCH; u++) {
+                if (pr[u] == ~0ull) continue;
+                const uint32_t h = lg_tab_hash((int32_t)(pr[u] >> 32));
+                if (((h >> LG_LDS_BUCKET_BITS) & pmask) != pass) continue;
+                insert((pr[u] & 0xFFFFFFFF00000000ull) | PENDING | (uint32_t)pr[u], h);
+            }
         }
         __syncthreads();
-        for (int32_t k = tid; k < total; k += LG_DEDUP_THREADS) {
-            const unsigned long long pr = a.claim_pairs[segment_of(k)];
-            const uint32_t id = (uint32_t)(pr >> 32), slot = (uint32_t)pr;
-            const uint32_t h = lg_tab_hash((int32_t)id);
-            if (((h >> LG_LDS_BUCKET_BITS) & pmask) != pass) continue;
-            uint32_t p = lds_slot_of(h);
-            uint32_t v = 0xFFFFFFFFu;
-            for (int it = 0; it < LG_LDS_TABLE; it++) {
-                const unsigned long long w = s_tab[p];
-                if ((uint32_t)(w >> 32) == id) { v = (uint32_t)w; break; }
-                p = (p + 1) & (LG_LDS_TABLE - 1);
+        for (int32_t k0 = 0; k0 < total; k0 += LG_DEDUP_BATCH * LG_DEDUP_THREADS) {
+            unsigned long long pr[LG_DEDUP_BATCH];
+#pragma unroll
+            for (int u = 0; u < LG_DEDUP_BATCH; u++) {
+                const int32_t k = k0 + u * LG_DEDUP_THREADS + tid;
+                pr[u] = k < total ? a.claim_pairs[segment_of(k)] : ~0ull;
             }
-            if (v != (PENDING | slot)) {          // not the lowest slot of a new vertex
-                a.slot_mark[slot] = a.mark_tag;
-                a.slot_pos[slot] = (v & PENDING) ? -2 - (int32_t)(v & ~PENDING) : (int32_t)v;
+#pragma unroll
+            for (int u = 0; u < LG_DEDUP_BATCH; u++) {
+                if (pr[u] == ~0ull) continue;
+                const uint32_t id = (uint32_t)(pr[u] >> 32), slot = (uint32_t)pr[u];
+                const uint32_t h = lg_tab_hash((int32_t)id);
+                if (((h >> LG_LDS_BUCKET_BITS) & pmask) != pass) continue;
+                uint32_t p = lds_slot_of(h);
+                uint32_t v = 0xFFFFFFFFu;
+                for (int it = 0; it < LG_LDS_TABLE; it++) {
+                    const unsigned long long w = s_tab[p];
+                    if ((uint32_t)(w >> 32) == id) { v = (uint32_t)w; break; }
+                    p = (p + 1) & (LG_LDS_TABLE - 1);
+                }
+                if (v != (PENDING | slot)) {          // not the lowest slot of a new vertex
+                    a.slot_mark[slot] = a.mark_tag;
+                    a.slot_pos[slot] = (v & PENDING) ? -2 - (int32_t)(v & ~PENDING) : (int32_t)v;
+                }
             }
         }
         __syncthreads();
@@ -707,10 +755,13 @@ __global__ __launch_bounds__(LG_SCAN_THREADS) void scan_kernel(HopParams hp, con
 // edges and the new nodes it writes, next to every edge, the row header of the sampled
 // neighbour: the next hop's frontier then needs no dependent lookup.
 // ------------------------------------------------------------------------------------------
+template <bool LISTING>     // lds form, not the last hop: later hops must recognise the nodes this one adds
 __global__ __launch_bounds__(LG_TILE) void scatter_kernel(HopParams hp, const LanePtrs* __restrict__ lanes)
 {
     const SampleArgs a = lane_args(hp, lanes);
     __shared__ int32_t s_cnt[LG_SLOTS_PER_LANE][2][LG_TILE / 64];
+    __shared__ int32_t s_kcnt[LISTING ? LG_LDS_BUCKETS : 1], s_kbase[LISTING ? LG_LDS_BUCKETS : 1];
+    constexpr bool listing = LISTING;
     const LG_G int32_t* hs = a.hop_scratch;
     const int32_t total = hs[HS_SLOTS];
     const int32_t ntiles = (total + LG_TILE - 1) / LG_TILE;
@@ -743,6 +794,7 @@ __global__ __launch_bounds__(LG_TILE) void scatter_kernel(HopParams hp, const La
                 s_cnt[u][1][wave] = __popcll(mf[u]);
             }
         }
+        if (listing && tid < LG_LDS_BUCKETS) s_kcnt[tid] = 0;
         __syncthreads();
         // phase 1: every load of the thread's four slots (nothing is stored in between, so they are all
         // in flight together: the buffers may alias as far as the compiler knows)
@@ -769,6 +821,27 @@ __global__ __launch_bounds__(LG_TILE) void scatter_kernel(HopParams hp, const La
                 if (!a.last_hop) nh[u] = load_hdr(a.row_hdr + dst);      // next hop's frontier header
                 lost_pos[u] = first ? 0 : a.slot_pos[idx];               // final already, or -2 - (slot it lost to)
                 tab_at[u] = (first && !a.last_hop && a.pos_table != nullptr) ? table_find(a.pos_table, a.pos_mask, a.pf, dst) : 0u;
+            }
+        }
+        if (listing && a.known_pairs != nullptr) {      // the super tile's new nodes, appended to their buckets' lists: one global atomic per bucket
+            int32_t kr[LG_SLOTS_PER_LANE];
+#pragma unroll
+            for (int u = 0; u < LG_SLOTS_PER_LANE; u++) {
+                kr[u] = -1;
+                if (e_at[u] >= 0 && n_at[u] >= 0)
+                    kr[u] = atomicAdd(&s_kcnt[lg_tab_hash(v[u] & 0x7FFFFFFF) & (LG_LDS_BUCKETS - 1)], 1);
+            }
+            __syncthreads();
+            if (tid < LG_LDS_BUCKETS) s_kbase[tid] = s_kcnt[tid] ? __hip_atomic_fetch_add(a.known_cnt + tid, s_kcnt[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+            __syncthreads();
+#pragma unroll
+            for (int u = 0; u < LG_SLOTS_PER_LANE; u++) {
+                if (kr[u] < 0) continue;
+                const int32_t dst = v[u] & 0x7FFFFFFF;
+                const int32_t bk = (int32_t)(lg_tab_hash(dst) & (LG_LDS_BUCKETS - 1));
+                const int32_t at = s_kbase[bk] + kr[u];
+                if (at < a.known_cap)       // (a list that overflows is not used: its count says so)
+                    a.known_pairs[(int64_t)bk * a.known_cap + at] = ((unsigned long long)(uint32_t)dst << 32) | (uint32_t)n_at[u];
             }
         }
         // phase 2: the stores
@@ -861,7 +934,8 @@ void launch_random_sample(hipStream_t s, const HopParams& p, const LanePtrs* d_l
     hipCheckError();
     scan_kernel<<<dim3(1, n_lanes), LG_SCAN_THREADS, 0, s>>>(p, d_lanes);
     hipCheckError();
-    scatter_kernel<<<grid, LG_TILE, 0, s>>>(p, d_lanes);
+    if (form == 2 && !p.last_hop) scatter_kernel<true><<<grid, LG_TILE, 0, s>>>(p, d_lanes);    // (pools without lists: known_pairs is null)
+    else scatter_kernel<false><<<grid, LG_TILE, 0, s>>>(p, d_lanes);
     hipCheckError();
     localise_kernel<<<grid, LG_TILE, 0, s>>>(p, d_lanes);
     hipCheckError();

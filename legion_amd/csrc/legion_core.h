@@ -218,6 +218,11 @@ struct LanePtrs {
     unsigned long long* claim_pairs;   // [max_slots] (vertex << 32 | slot)
     int32_t* run_base;                 // [super tiles] where the super tile's run starts in claim_pairs
     int32_t* run_cnt;                  // [super tiles][LG_LDS_BUCKETS] claims of each bucket in that run
+    // ... and the batch's vertices that later hops must recognise (every node but the seeds and the last hop's), one list
+    // per bucket: scatter appends (vertex << 32 | position), the next hop's workgroup of that bucket reads only its list
+    unsigned long long* known_pairs;   // [LG_LDS_BUCKETS][known_cap]
+    int32_t* known_cnt;                // [LG_LDS_BUCKETS] entries appended (may exceed known_cap: then the list is not used)
+    int32_t known_cap;
     int32_t* err_flag;                 // mapped pinned host word: kernels OR LG_ERR_* bits into it
     const void* deliver;               // lg::DeliverParams* (device) or null: the gather of this lane also hands its batch
                                        // over to that trainer-visible pipe slot (GPURunner's hand-over descriptors)
@@ -295,6 +300,9 @@ public:
     unsigned long long* claim_pairs = nullptr; // lds form: see LanePtrs
     int32_t* run_base = nullptr;
     int32_t* run_cnt = nullptr;
+    unsigned long long* known_pairs = nullptr;
+    int32_t* known_cnt = nullptr;
+    int32_t known_cap = 0;
     bool lds_form = false;
     unsigned long long* pos_table = nullptr;   // compact position state (table form), else null
     uint32_t pos_table_mask = 0;

@@ -342,6 +342,9 @@ LanePtrs MemoryPool::HostLane(int32_t pipe) const
     h.claim_pairs = claim_pairs;
     h.run_base = run_base;
     h.run_cnt = run_cnt;
+    h.known_pairs = known_pairs;
+    h.known_cnt = known_cnt;
+    h.known_cap = known_cap;
     h.node_counter = node_counter_[pipe];
     h.edge_counter = edge_counter_[pipe];
     h.slot_dst = slot_dst;
@@ -386,6 +389,10 @@ void MemoryPool::Finalize()
     d_free_space(claim_pairs);
     d_free_space(run_base);
     d_free_space(run_cnt);
+    d_free_space(known_pairs);
+    d_free_space(known_cnt);
+    known_pairs = nullptr;
+    known_cnt = nullptr;
     claim_pairs = nullptr;
     run_base = run_cnt = nullptr;
     if (err_host) HIP_CALL(hipHostFree(err_host));
@@ -482,6 +489,17 @@ void lg_pool_alloc_private(MemoryPool* mp, int32_t dev_id, int32_t total_num_nod
         mp->claim_pairs = (unsigned long long*)d_alloc_space(slots * sizeof(unsigned long long));
         mp->run_base = (int32_t*)d_alloc_space(n_super * sizeof(int32_t));
         mp->run_cnt = (int32_t*)d_alloc_space(n_super * LG_LDS_BUCKETS * sizeof(int32_t));
+        // per-bucket lists of the nodes hops 1 .. H-1 add (later hops must recognise them): twice an even share each;
+        // a bucket that outgrows its list is served by scanning sampled_ids instead (kernels_sample.hip)
+        int64_t listed = 0;
+        for (int i = 1; i < hop_num; i++) listed += mp->max_new[i];
+        if (listed > 0) {
+            mp->known_cap = (int32_t)(2 * ((listed + LG_LDS_BUCKETS - 1) / LG_LDS_BUCKETS) + 256);
+            if (const char* e = getenv("LEGION_LDS_KNOWN_CAP")) mp->known_cap = std::max(1, atoi(e));   // tests: force the scan
+            mp->known_pairs = (unsigned long long*)d_alloc_space((int64_t)LG_LDS_BUCKETS * mp->known_cap * sizeof(unsigned long long));
+            mp->known_cnt = (int32_t*)d_alloc_space(LG_LDS_BUCKETS * sizeof(int32_t));
+            HIP_CALL(hipMemset(mp->known_cnt, 0, LG_LDS_BUCKETS * sizeof(int32_t)));
+        }
         mp->SetPositionMap(nullptr);
     } else if (form == 1) {
         // compact form: at least 1.5 x the pool's worst-case id count, so a free word always exists
@@ -680,7 +698,7 @@ extern "C" int64_t legion_pool_state_bytes(const LegionMemoryPool* p_)
 {
     const MemoryPool* mp = reinterpret_cast<const MemoryPool*>(p_);
     if (!mp) return 0;
-    if (mp->lds_form) return (int64_t)mp->max_slots * 8;      // the claim pairs of one hop
+    if (mp->lds_form) return (int64_t)mp->max_slots * 8 + (int64_t)LG_LDS_BUCKETS * mp->known_cap * 8;   // one hop's claim pairs + the known lists
     return mp->pos_table ? ((int64_t)mp->pos_table_mask + 1) * 8 : (int64_t)mp->total_num_nodes * 4;
 }
 

@@ -330,7 +330,7 @@ def test_lds_dedup_multi_pass_buckets(hip, monkeypatch):
     for it in range(3):
         g, c = gpu.run(0, it, 0), cpu.run(0, it, 0)
         compare_batches(g, c, f"multi-pass lds batch {it}: ")
-        assert int(g["edge_counter"][11] - g["edge_counter"][10]) > 8 * 4096      # more claims than 8 half-full tables hold
+        assert int(g["edge_counter"][11] - g["edge_counter"][10]) > 8 * 7168      # more claims than 8 tables filled to 14/16 hold
     assert gpu.pools[0].error() == 0
     gpu.close(); cpu.close()
     # a star-heavy graph: vertex 0 is everybody's neighbour many times over
@@ -344,6 +344,24 @@ def test_lds_dedup_multi_pass_buckets(hip, monkeypatch):
     gpu, cpu = GpuSide(wl, 512, [12, 6]), CpuSide(wl, 512, [12, 6])
     for it in range(3):
         compare_batches(gpu.run(0, it, 0), cpu.run(0, it, 0), f"hub graph lds batch {it}: ")
+    assert gpu.pools[0].error() == 0
+    gpu.close(); cpu.close()
+
+
+@pytest.mark.parametrize("known_cap", [None, "1", "80"], ids=["lists", "no-room", "some-buckets-overflow"])
+def test_lds_dedup_known_lists(hip, monkeypatch, known_cap):
+    """LDS form, three hops: hops 2 and 3 recognise the nodes hops 1 and 2 added through the per-bucket lists scatter
+    appends to.  A list that outgrows its capacity is not used (that bucket's workgroup scans sampled_ids instead):
+    forced for every bucket (capacity 1) and for some of them (capacity 80 against ~75 nodes per bucket)."""
+    monkeypatch.setenv("LEGION_DEDUP", "lds")
+    if known_cap is not None:
+        monkeypatch.setenv("LEGION_LDS_KNOWN_CAP", known_cap)
+    wl = Workload(scale=12, edge_factor=8, dim=4, n_seeds=600)
+    fanout, batch = [4, 3, 3], 48
+    gpu, cpu = GpuSide(wl, batch, fanout), CpuSide(wl, batch, fanout)
+    assert gpu.pools[0].dedup_form() == "lds"
+    for it in range(6):
+        compare_batches(gpu.run(0, it, 0), cpu.run(0, it, 0), f"known lists ({known_cap}) batch {it}: ")
     assert gpu.pools[0].error() == 0
     gpu.close(); cpu.close()
 
