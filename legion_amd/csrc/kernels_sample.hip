@@ -102,7 +102,7 @@ struct BracketLane {
     LG_G int32_t* sampled_ids; LG_G int32_t* labels; LG_G int32_t* node_counter; LG_G int32_t* edge_counter;
     LG_G int32_t* hop_scratch; LG_G uint32_t* position_map; LG_G int32_t* slot_mark;
     LG_G unsigned long long* pos_table; uint32_t pos_mask; LG_G int32_t* err_flag;
-    LG_G int32_t* known_cnt;
+    LG_G int32_t* known_cnt; int32_t lds_buckets;
     int32_t total_num_nodes, max_slots;
 };
 __device__ __forceinline__ BracketLane bracket_lane(const LanePtrs& P)
@@ -114,7 +114,7 @@ __device__ __forceinline__ BracketLane bracket_lane(const LanePtrs& P)
     L.slot_mark = LG_GPTR(int32_t, P.slot_mark);
     L.pos_table = LG_GPTR(unsigned long long, P.pos_table); L.pos_mask = P.pos_table_mask;
     L.err_flag = LG_GPTR(int32_t, P.err_flag);
-    L.known_cnt = LG_GPTR(int32_t, P.known_cnt);
+    L.known_cnt = LG_GPTR(int32_t, P.known_cnt); L.lds_buckets = P.lds_buckets;
     L.total_num_nodes = P.total_num_nodes; L.max_slots = P.max_slots;
     return L;
 }
@@ -183,7 +183,7 @@ __global__ void batch_generate_kernel(SeedParams p, const LanePtrs* __restrict__
     // operator_impl.cu:159 -- the clamped last batch (may be <= 0: nothing is sampled)
     const int32_t size = ((int64_t)p.batch_size * (counter + 1) >= p.total_cap)
                              ? (p.total_cap - p.batch_size * counter) : p.batch_size;
-    if (L.known_cnt != nullptr && idx < LG_LDS_BUCKETS) L.known_cnt[idx] = 0;    // lds form: the batch's known lists start empty
+    if (L.known_cnt != nullptr && idx < L.lds_buckets) L.known_cnt[idx] = 0;    // lds form: the batch's known lists start empty
     if (idx < 16) {                    // memset of both counter blocks, operator_impl.cu:155-156,
         int32_t v = 0;                 // then counter_update(op 0), :64-68
         if (idx == 1) v = size;
@@ -239,7 +239,7 @@ struct SampleArgs {
     LG_G int32_t* slot_dst; LG_G int32_t* slot_pos; LG_G int32_t* slot_mark; LG_G int32_t* tile_counts; LG_G int32_t* tile_prefix; LG_G int32_t* hop_scratch;
     LG_G RowHdr* fh_edge;
     LG_G unsigned long long* pos_table; uint32_t pos_mask; LG_G int32_t* err_flag;
-    LG_G unsigned long long* claim_pairs; LG_G int32_t* run_base; LG_G int32_t* run_cnt;
+    LG_G unsigned long long* claim_pairs; LG_G int32_t* run_off;
     LG_G unsigned long long* known_pairs; LG_G int32_t* known_cnt; int32_t known_cap;
     PosFmt pf;
     int32_t mark_tag;   // (epoch, hop): what slot_mark holds for a slot that lost its first touch in THIS hop
@@ -286,7 +286,7 @@ __device__ __forceinline__ SampleArgs lane_args(const HopParams& p, const LanePt
     a.pos_table = LG_GPTR(unsigned long long, L.pos_table); a.pos_mask = L.pos_table_mask;
     a.err_flag = LG_GPTR(int32_t, L.err_flag);
     a.claim_pairs = LG_GPTR(unsigned long long, L.claim_pairs);
-    a.run_base = LG_GPTR(int32_t, L.run_base); a.run_cnt = LG_GPTR(int32_t, L.run_cnt);
+    a.run_off = LG_GPTR(int32_t, L.run_off);
     a.known_pairs = LG_GPTR(unsigned long long, L.known_pairs); a.known_cnt = LG_GPTR(int32_t, L.known_cnt); a.known_cap = L.known_cap;
     a.pf = lg_pos_fmt(a.hop_scratch[HS_EPOCH], a.hop_scratch[HS_VALUE_BITS]);
     a.mark_tag = (a.hop_scratch[HS_EPOCH] << 8) | (p.op_id / INTRABATCH_CON);
@@ -331,13 +331,16 @@ __device__ __forceinline__ HopGeom hop_geometry(const SampleArgs& a)
 // coalesced 16-byte load per frontier entry), for hop 1 they are looked up in the per-vertex
 // header table here.
 // ------------------------------------------------------------------------------------------
-template <int FORM>      // 0 direct array, 1 table, 2 lds
+template <int FORM, int BB, bool SINGLE>      // 0 direct array, 1 table, 2 lds with 2^BB buckets per lane; SINGLE: partition tile = super tile
 __global__ __launch_bounds__(LG_TILE) void sample_kernel(HopParams hp, const LanePtrs* __restrict__ lanes)
 {
     constexpr bool TABLE = FORM == 1;
+    constexpr int NB = 1 << BB;
+    const int32_t K = SINGLE ? 1 : hp.lds_k;      // super tiles per partition tile
+    static_assert(NB <= LG_TILE, "one thread per bucket in the prefix");
     const SampleArgs a = lane_args(hp, lanes);
     __shared__ RowHdr s_hdr[LG_SUPER];
-    __shared__ int32_t s_bcnt[LG_LDS_BUCKETS], s_boff[LG_LDS_BUCKETS], s_base;
+    __shared__ int32_t s_bcnt[NB], s_boff[NB], s_base, s_wtot[LG_TILE / 64];
 
     const HopGeom g = hop_geometry(a);
     const int32_t tid = threadIdx.x;
@@ -345,137 +348,200 @@ __global__ __launch_bounds__(LG_TILE) void sample_kernel(HopParams hp, const Lan
     const bool seeds = (a.op_id == INTRABATCH_CON);
     const LG_G RowHdr* fh = a.fh_edge + g.frontier_off;
 
-    for (int32_t st = blockIdx.x; st < g.nsuper; st += gridDim.x) {
-        const int32_t idx0 = st * LG_SUPER;
-        const int32_t last = min(idx0 + LG_SUPER - 1, g.total - 1);
-        const int32_t j0 = idx0 / count;
-        const int32_t nsrc = last / count - j0 + 1;          // <= LG_SUPER
+    // lds form: the claims of K consecutive super tiles (a partition tile) go, grouped by bucket, into ONE run of the lane's
+    // pair array.  SINGLE (K = 1): ranks are taken while the super tile is sampled.  Otherwise (many buckets: a run must stay long
+    // enough per bucket to be read in whole sectors): the first sweep samples and counts, the second re-reads slot_dst
+    // (this workgroup's own stores) and places the pairs.
+    const int32_t nparts = (g.nsuper + K - 1) / K;
+    for (int32_t m = blockIdx.x; m < nparts; m += gridDim.x) {
+        if (FORM == 2 && !SINGLE && tid < NB) s_bcnt[tid] = 0;      // (visible after the first barrier of the first super tile)
+        for (int32_t sub = 0; sub < K; sub++) {
+            const int32_t st = m * K + sub;
+            if (st >= g.nsuper) break;
+            const int32_t idx0 = st * LG_SUPER;
+            const int32_t last = min(idx0 + LG_SUPER - 1, g.total - 1);
+            const int32_t j0 = idx0 / count;
+            const int32_t nsrc = last / count - j0 + 1;          // <= LG_SUPER
 
-        // the draws do not depend on the frontier: start their table loads first
-        uint32_t x[LG_SLOTS_PER_LANE];
+            // the draws do not depend on the frontier: start their table loads first
+            uint32_t x[LG_SLOTS_PER_LANE];
 #pragma unroll
-        for (int u = 0; u < LG_SLOTS_PER_LANE; u++) x[u] = minstd_pow((uint32_t)(idx0 + u * LG_TILE + tid) + 1u);
+            for (int u = 0; u < LG_SLOTS_PER_LANE; u++) x[u] = minstd_pow((uint32_t)(idx0 + u * LG_TILE + tid) + 1u);
 
-        unsigned long long tx = 0;
-        for (int32_t t = tid; t < nsrc; t += LG_TILE) {
-            RowHdr h;
-            bool real = true;
-            if (seeds) {
-                const int32_t src = g.frontier[j0 + t];
-                if (src >= 0) {
-                    h = load_hdr(a.row_hdr + src);
-                } else {
-                    h.start = 0; h.deg = 0; h.slot = a.partition_count;
-                    real = false;
-                }
-            } else {
-                h = load_hdr(fh + j0 + t);
-            }
-            s_hdr[t] = h;
-            // PreSC: what this row's topology reads cost in 64-byte transactions (row-pointer pair + the
-            // sectors its picks can touch); a row is counted by the super tile its first slot falls in
-            if (a.topo_transactions && real && (int64_t)(j0 + t) * count >= idx0)
-                tx += 1ull + (unsigned long long)min(count, (h.deg * 4 + 63) / 64);
-            if (!a.is_presc)   // FindTopo's hit mask: owner device of the cached row, or -2 (cache.cu:217-225)
-                a.tmp_part_ind[j0 + t] = (char)(h.slot == a.partition_count ? CACHEMISS_FLAG : h.slot);
-        }
-        if (a.topo_transactions) {               // wave sum, one atomic per wave
-            for (int off = 32; off > 0; off >>= 1) tx += __shfl_down(tx, off);
-            if ((tid & 63) == 0 && tx != 0)
-                __hip_atomic_fetch_add(a.topo_transactions, tx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        __syncthreads();
-
-        if (FORM == 2 && tid < LG_LDS_BUCKETS) s_bcnt[tid] = 0;     // (made visible by the barrier above the loads' use below)
-        int32_t dst[LG_SLOTS_PER_LANE];
-#pragma unroll
-        for (int u = 0; u < LG_SLOTS_PER_LANE; u++) {
-            const int32_t idx = idx0 + u * LG_TILE + tid;
-            dst[u] = -1;
-            if (idx < g.total) {
-                const int32_t q = idx / count;
-                const int32_t k = idx - q * count;
-                const RowHdr h = s_hdr[q - j0];
-                if (k < h.deg) {                                           // :232-233 (src < 0 has deg 0)
-                    const int32_t pick = draw_from_x(x[u], h.deg);         // :235-238
-                    dst[u] = LG_GPTR(const int32_t, a.csr_dst_node_ids[h.slot])[h.start + (int64_t)pick];   // :239-243
-                }
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < LG_SLOTS_PER_LANE; u++) {
-            const int32_t idx = idx0 + u * LG_TILE + tid;
-            if (idx < g.total) {
-                if (FORM == 2) {
-                    // lds form: no claim here; the pair goes to its hash bucket below
-                    if (dst[u] >= 0 && a.edge_access_time)
-                        __hip_atomic_fetch_add(a.edge_access_time + g.frontier[idx / count], 1ull, __ATOMIC_RELAXED,
-                                               __HIP_MEMORY_SCOPE_AGENT);
-                    if (dst[u] < 0) dst[u] = -1;
-                } else if (dst[u] >= 0) {                                  // :244
-                    // First touch goes to the LOWEST slot that sampled the vertex.  The atomic returns what
-                    // it replaced, so every loser is known without a second look at the state array:
-                    //   old < key : the vertex is already in the batch (final position) or a lower slot of this
-                    //               hop holds it -> this slot lost, and knows to whom;
-                    //   old > key, this epoch : old is a higher slot that held it until now -> THAT slot lost to
-                    //               this one (it wrote nothing itself, so the two stores below have one writer);
-                    //   otherwise : untouched so far; this slot holds it unless a lower one shows up.
-                    // A loser gets the hop's tag in slot_mark and, in slot_pos, the final position or -2 - (the
-                    // slot it lost to); the chain of losers ends at the winner (localise follows it).
-                    if (TABLE) {      // compact form: the same outcome through the lane's open-addressing table
-                        table_claim(a.pos_table, a.pos_mask, a.pf, dst[u], a.pf.pending | (uint32_t)idx, a.slot_mark, a.slot_pos,
-                                    a.mark_tag, a.hop_scratch, a.err_flag);
+            unsigned long long tx = 0;
+            for (int32_t t = tid; t < nsrc; t += LG_TILE) {
+                RowHdr h;
+                bool real = true;
+                if (seeds) {
+                    const int32_t src = g.frontier[j0 + t];
+                    if (src >= 0) {
+                        h = load_hdr(a.row_hdr + src);
                     } else {
-                        const uint32_t key = a.pf.hi | a.pf.pending | (uint32_t)idx;
-                        const uint32_t old = __hip_atomic_fetch_min(a.position_map + dst[u], key, __ATOMIC_RELAXED,
-                                                                    __HIP_MEMORY_SCOPE_AGENT);
-                        if (old < key) {
-                            a.slot_mark[idx] = a.mark_tag;
-                            a.slot_pos[idx] = (old & a.pf.pending) ? -2 - (int32_t)(old & a.pf.vmask) : (int32_t)(old & a.pf.vmask);
-                        } else if ((old & ~(a.pf.pending | a.pf.vmask)) == a.pf.hi) {
-                            const int32_t loser = (int32_t)(old & a.pf.vmask);
-                            a.slot_mark[loser] = a.mark_tag;
-                            a.slot_pos[loser] = -2 - idx;
-                        }
+                        h.start = 0; h.deg = 0; h.slot = a.partition_count;
+                        real = false;
                     }
-                    if (a.edge_access_time)                                // :358
-                        __hip_atomic_fetch_add(a.edge_access_time + g.frontier[idx / count], 1ull, __ATOMIC_RELAXED,
-                                               __HIP_MEMORY_SCOPE_AGENT);
                 } else {
-                    dst[u] = -1;
+                    h = load_hdr(fh + j0 + t);
                 }
-                a.slot_dst[idx] = dst[u];
+                s_hdr[t] = h;
+                // PreSC: what this row's topology reads cost in 64-byte transactions (row-pointer pair + the
+                // sectors its picks can touch); a row is counted by the super tile its first slot falls in
+                if (a.topo_transactions && real && (int64_t)(j0 + t) * count >= idx0)
+                    tx += 1ull + (unsigned long long)min(count, (h.deg * 4 + 63) / 64);
+                if (!a.is_presc)   // FindTopo's hit mask: owner device of the cached row, or -2 (cache.cu:217-225)
+                    a.tmp_part_ind[j0 + t] = (char)(h.slot == a.partition_count ? CACHEMISS_FLAG : h.slot);
             }
-        }
-        if (FORM == 2) {
-            // the super tile's claims, grouped by hash bucket, into one run of the lane's pair array: ranks by LDS atomics
-            // (the order inside a bucket does not matter), ONE global reservation per super tile
-            int32_t rank[LG_SLOTS_PER_LANE], bkt[LG_SLOTS_PER_LANE];
-            __syncthreads();                                   // s_bcnt zeroed by every wave's view
+            if (a.topo_transactions) {               // wave sum, one atomic per wave
+                for (int off = 32; off > 0; off >>= 1) tx += __shfl_down(tx, off);
+                if ((tid & 63) == 0 && tx != 0)
+                    __hip_atomic_fetch_add(a.topo_transactions, tx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            __syncthreads();
+
+            if (FORM == 2 && SINGLE && tid < NB) s_bcnt[tid] = 0;     // (made visible by the barrier above the loads' use below)
+            int32_t dst[LG_SLOTS_PER_LANE];
 #pragma unroll
             for (int u = 0; u < LG_SLOTS_PER_LANE; u++) {
-                bkt[u] = -1;
-                if (dst[u] >= 0) {
-                    bkt[u] = (int32_t)(lg_tab_hash(dst[u]) & (LG_LDS_BUCKETS - 1));
-                    rank[u] = atomicAdd(&s_bcnt[bkt[u]], 1);
+                const int32_t idx = idx0 + u * LG_TILE + tid;
+                dst[u] = -1;
+                if (idx < g.total) {
+                    const int32_t q = idx / count;
+                    const int32_t k = idx - q * count;
+                    const RowHdr h = s_hdr[q - j0];
+                    if (k < h.deg) {                                           // :232-233 (src < 0 has deg 0)
+                        const int32_t pick = draw_from_x(x[u], h.deg);         // :235-238
+                        dst[u] = LG_GPTR(const int32_t, a.csr_dst_node_ids[h.slot])[h.start + (int64_t)pick];   // :239-243
+                    }
                 }
             }
-            __syncthreads();
-            if (tid == 0) {
-                int32_t tot = 0;
-                for (int b = 0; b < LG_LDS_BUCKETS; b++) { s_boff[b] = tot; tot += s_bcnt[b]; }
-                s_base = tot > 0 ? __hip_atomic_fetch_add(a.hop_scratch + HS_PAIR_CURSOR, tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
-                a.run_base[st] = s_base;
+#pragma unroll
+            for (int u = 0; u < LG_SLOTS_PER_LANE; u++) {
+                const int32_t idx = idx0 + u * LG_TILE + tid;
+                if (idx < g.total) {
+                    if (FORM == 2) {
+                        // lds form: no claim here; the pair goes to its hash bucket below
+                        if (dst[u] >= 0 && a.edge_access_time)
+                            __hip_atomic_fetch_add(a.edge_access_time + g.frontier[idx / count], 1ull, __ATOMIC_RELAXED,
+                                                   __HIP_MEMORY_SCOPE_AGENT);
+                        if (dst[u] < 0) dst[u] = -1;
+                    } else if (dst[u] >= 0) {                                  // :244
+                        // First touch goes to the LOWEST slot that sampled the vertex.  The atomic returns what
+                        // it replaced, so every loser is known without a second look at the state array:
+                        //   old < key : the vertex is already in the batch (final position) or a lower slot of this
+                        //               hop holds it -> this slot lost, and knows to whom;
+                        //   old > key, this epoch : old is a higher slot that held it until now -> THAT slot lost to
+                        //               this one (it wrote nothing itself, so the two stores below have one writer);
+                        //   otherwise : untouched so far; this slot holds it unless a lower one shows up.
+                        // A loser gets the hop's tag in slot_mark and, in slot_pos, the final position or -2 - (the
+                        // slot it lost to); the chain of losers ends at the winner (localise follows it).
+                        if (TABLE) {      // compact form: the same outcome through the lane's open-addressing table
+                            table_claim(a.pos_table, a.pos_mask, a.pf, dst[u], a.pf.pending | (uint32_t)idx, a.slot_mark, a.slot_pos,
+                                        a.mark_tag, a.hop_scratch, a.err_flag);
+                        } else {
+                            const uint32_t key = a.pf.hi | a.pf.pending | (uint32_t)idx;
+                            const uint32_t old = __hip_atomic_fetch_min(a.position_map + dst[u], key, __ATOMIC_RELAXED,
+                                                                        __HIP_MEMORY_SCOPE_AGENT);
+                            if (old < key) {
+                                a.slot_mark[idx] = a.mark_tag;
+                                a.slot_pos[idx] = (old & a.pf.pending) ? -2 - (int32_t)(old & a.pf.vmask) : (int32_t)(old & a.pf.vmask);
+                            } else if ((old & ~(a.pf.pending | a.pf.vmask)) == a.pf.hi) {
+                                const int32_t loser = (int32_t)(old & a.pf.vmask);
+                                a.slot_mark[loser] = a.mark_tag;
+                                a.slot_pos[loser] = -2 - idx;
+                            }
+                        }
+                        if (a.edge_access_time)                                // :358
+                            __hip_atomic_fetch_add(a.edge_access_time + g.frontier[idx / count], 1ull, __ATOMIC_RELAXED,
+                                                   __HIP_MEMORY_SCOPE_AGENT);
+                    } else {
+                        dst[u] = -1;
+                    }
+                    a.slot_dst[idx] = dst[u];
+                }
+            }
+            if (FORM == 2 && SINGLE) {
+                // the super tile's claims, grouped by hash bucket, into one run of the lane's pair array: ranks by LDS atomics
+                // (the order inside a bucket does not matter), ONE global reservation per super tile
+                int32_t rank[LG_SLOTS_PER_LANE], bkt[LG_SLOTS_PER_LANE];
+                __syncthreads();                                   // s_bcnt zeroed by every wave's view
+#pragma unroll
+                for (int u = 0; u < LG_SLOTS_PER_LANE; u++) {
+                    bkt[u] = -1;
+                    if (dst[u] >= 0) {
+                        bkt[u] = (int32_t)(lg_tab_hash(dst[u]) & (NB - 1));
+                        rank[u] = atomicAdd(&s_bcnt[bkt[u]], 1);
+                    }
+                }
+                __syncthreads();
+                if (NB <= 8) {
+                    if (tid == 0) {
+                        int32_t tot = 0;
+                        for (int b = 0; b < NB; b++) { s_boff[b] = tot; tot += s_bcnt[b]; }
+                        s_base = tot > 0 ? __hip_atomic_fetch_add(a.hop_scratch + HS_PAIR_CURSOR, tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+                        a.run_off[(int64_t)st * (NB + 1) + NB] = s_base + tot;
+                    }
+                } else if (tid < 64) {                             // NB <= 64: wave 0 scans the bucket counts
+                    const int32_t c = tid < NB ? s_bcnt[tid] : 0;
+                    int32_t inc = c;
+                    for (int d = 1; d < 64; d <<= 1) { const int32_t o = __shfl_up(inc, d); if (tid >= d) inc += o; }
+                    if (tid < NB) s_boff[tid] = inc - c;
+                    if (tid == 63) {
+                        s_base = inc > 0 ? __hip_atomic_fetch_add(a.hop_scratch + HS_PAIR_CURSOR, inc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+                        a.run_off[(int64_t)st * (NB + 1) + NB] = s_base + inc;
+                    }
+                }
+                __syncthreads();
+                if (tid < NB) a.run_off[(int64_t)st * (NB + 1) + tid] = s_base + s_boff[tid];
+#pragma unroll
+                for (int u = 0; u < LG_SLOTS_PER_LANE; u++)
+                    if (bkt[u] >= 0)
+                        a.claim_pairs[s_base + s_boff[bkt[u]] + rank[u]] =
+                            ((unsigned long long)(uint32_t)dst[u] << 32) | (uint32_t)(idx0 + u * LG_TILE + tid);
+            }
+
+            if (FORM == 2 && !SINGLE) {
+#pragma unroll
+                for (int u = 0; u < LG_SLOTS_PER_LANE; u++)
+                    if (dst[u] >= 0) atomicAdd(&s_bcnt[lg_tab_hash(dst[u]) & (NB - 1)], 1);
             }
             __syncthreads();
-            if (tid < LG_LDS_BUCKETS) a.run_cnt[st * LG_LDS_BUCKETS + tid] = s_bcnt[tid];
-#pragma unroll
-            for (int u = 0; u < LG_SLOTS_PER_LANE; u++)
-                if (bkt[u] >= 0)
-                    a.claim_pairs[s_base + s_boff[bkt[u]] + rank[u]] =
-                        ((unsigned long long)(uint32_t)dst[u] << 32) | (uint32_t)(idx0 + u * LG_TILE + tid);
         }
-        __syncthreads();
+        if (FORM == 2 && !SINGLE) {
+            // exclusive prefix of the bucket counts over the workgroup, one global reservation, then the second sweep
+            const int32_t c = tid < NB ? s_bcnt[tid] : 0;
+            int32_t inc = c;
+            for (int d = 1; d < 64; d <<= 1) { const int32_t o = __shfl_up(inc, d); if ((tid & 63) >= d) inc += o; }
+            if ((tid & 63) == 63) s_wtot[tid >> 6] = inc;
+            __syncthreads();
+            int32_t wbase = 0, tot = 0;
+            for (int w = 0; w < LG_TILE / 64; w++) { if (w < (tid >> 6)) wbase += s_wtot[w]; tot += s_wtot[w]; }
+            if (tid < NB) { s_boff[tid] = wbase + inc - c; s_bcnt[tid] = 0; }
+            if (tid == 0) {
+                s_base = tot > 0 ? __hip_atomic_fetch_add(a.hop_scratch + HS_PAIR_CURSOR, tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+                a.run_off[(int64_t)m * (NB + 1) + NB] = s_base + tot;
+            }
+            __syncthreads();
+            if (tid < NB) a.run_off[(int64_t)m * (NB + 1) + tid] = s_base + s_boff[tid];
+            for (int32_t sub = 0; sub < K; sub++) {
+                const int32_t idx0 = (m * K + sub) * LG_SUPER;
+                if (idx0 >= g.total) break;
+                int32_t d[LG_SLOTS_PER_LANE];
+#pragma unroll
+                for (int u = 0; u < LG_SLOTS_PER_LANE; u++) {
+                    const int32_t idx = idx0 + u * LG_TILE + tid;
+                    d[u] = idx < g.total ? a.slot_dst[idx] : -1;
+                }
+#pragma unroll
+                for (int u = 0; u < LG_SLOTS_PER_LANE; u++) {
+                    if (d[u] < 0) continue;
+                    const int32_t bk = (int32_t)(lg_tab_hash(d[u]) & (NB - 1));
+                    const int32_t r = atomicAdd(&s_bcnt[bk], 1);
+                    a.claim_pairs[s_base + s_boff[bk] + r] =
+                        ((unsigned long long)(uint32_t)d[u] << 32) | (uint32_t)(idx0 + u * LG_TILE + tid);
+                }
+            }
+            __syncthreads();                       // the next partition tile zeroes s_bcnt
+        }
     }
 }
 
@@ -501,30 +567,35 @@ __global__ __launch_bounds__(LG_TILE) void sample_kernel(HopParams hp, const Lan
 #endif
 __device__ __forceinline__ uint32_t lds_slot_of(uint32_t h) { return (h * 0x9E3779B1u) >> (32 - LG_LDS_TABLE_BITS); }
 
+template <int BB>
 __global__ __launch_bounds__(LG_DEDUP_THREADS) void dedup_lds_kernel(HopParams hp, const LanePtrs* __restrict__ lanes)
 {
+    constexpr int NB = 1 << BB;
+    const int32_t K = hp.lds_k;                           // super tiles per partition tile (1 in the 8-bucket class)
+    constexpr int MAX_PARTS = LG_LDS_MAX_PARTS + 2;       // partition tiles of a hop (sample_kernel's K super tiles each)
     const SampleArgs a = lane_args(hp, lanes);
     __shared__ unsigned long long s_tab[LG_LDS_TABLE];
-    __shared__ int32_t s_pref[LG_LDS_MAX_SLOTS / LG_SUPER + 2];    // exclusive prefix of the bucket's segment lengths
-    __shared__ int32_t s_seg[LG_LDS_MAX_SLOTS / LG_SUPER + 2];     // where the bucket's segment of super tile t starts in claim_pairs
+    __shared__ int32_t s_pref[MAX_PARTS];                  // exclusive prefix of the bucket's segment lengths
+    __shared__ int32_t s_seg[MAX_PARTS];                   // where the bucket's segment of partition tile t starts in claim_pairs
     __shared__ int32_t s_known, s_total;
     const HopGeom g = hop_geometry(a);
+    const int32_t nparts = (g.nsuper + K - 1) / K;
     const int32_t tid = threadIdx.x, b = blockIdx.x;
     const int32_t n_known = a.node_counter[0] + a.node_counter[1];          // nodes of the batch before this hop
     constexpr uint32_t PENDING = 0x80000000u;
+    const LG_G int32_t* roff = a.run_off + b;              // roff[t * (NB + 1)]: start of this bucket's segment of partition tile t
 
-    // the bucket's segments, one per super tile: exclusive prefix of their lengths
+    // the bucket's segments, one per partition tile: exclusive prefix of their lengths
     if (tid == 0) { s_known = 0; s_total = 0; }
-    for (int32_t t = tid; t < g.nsuper; t += LG_DEDUP_THREADS) {
-        s_pref[t + 1] = a.run_cnt[t * LG_LDS_BUCKETS + b];
-        int32_t off = a.run_base[t];
-        for (int bb = 0; bb < b; bb++) off += a.run_cnt[t * LG_LDS_BUCKETS + bb];
+    for (int32_t t = tid; t < nparts; t += LG_DEDUP_THREADS) {
+        const int32_t off = roff[(int64_t)t * (NB + 1)];
+        s_pref[t + 1] = roff[(int64_t)t * (NB + 1) + 1] - off;
         s_seg[t] = off;
     }
     __syncthreads();
     if (tid < 64) {                                    // <= 513 entries: wave 0 scans them, a few consecutive entries per lane
-        const int32_t per = (g.nsuper + 63) / 64;
-        const int32_t lo = min(tid * per, g.nsuper), hi = min(lo + per, g.nsuper);
+        const int32_t per = (nparts + 63) / 64;
+        const int32_t lo = min(tid * per, nparts), hi = min(lo + per, nparts);
         int32_t sum = 0;
         for (int32_t t = lo; t < hi; t++) sum += s_pref[t + 1];
         int32_t inc = sum;
@@ -544,7 +615,7 @@ __global__ __launch_bounds__(LG_DEDUP_THREADS) void dedup_lds_kernel(HopParams h
     int32_t known_here = 0;
     for (int32_t i = tid; i < n_scan; i += LG_DEDUP_THREADS) {
         const int32_t id = a.sampled_ids[i];
-        if (id >= 0 && (lg_tab_hash(id) & (LG_LDS_BUCKETS - 1)) == (uint32_t)b) known_here++;
+        if (id >= 0 && (lg_tab_hash(id) & (NB - 1)) == (uint32_t)b) known_here++;
     }
     if (tid == 0 && listed) known_here += n_listed;
     if (known_here) atomicAdd(&s_known, known_here);
@@ -556,7 +627,7 @@ __global__ __launch_bounds__(LG_DEDUP_THREADS) void dedup_lds_kernel(HopParams h
     const uint32_t pmask = (uint32_t)passes - 1u;
 
     auto segment_of = [&](int32_t k) {                 // claim k of the bucket -> index into claim_pairs
-        int32_t lo = 0, hi = g.nsuper;                 // s_pref[lo] <= k < s_pref[hi]
+        int32_t lo = 0, hi = nparts;                   // s_pref[lo] <= k < s_pref[hi]
         while (hi - lo > 1) { const int32_t mid = (lo + hi) >> 1; if (s_pref[mid] <= k) lo = mid; else hi = mid; }
         return s_seg[lo] + (k - s_pref[lo]);
     };
@@ -578,14 +649,14 @@ __global__ __launch_bounds__(LG_DEDUP_THREADS) void dedup_lds_kernel(HopParams h
             const int32_t id = a.sampled_ids[i];
             if (id < 0) continue;
             const uint32_t h = lg_tab_hash(id);
-            if ((h & (LG_LDS_BUCKETS - 1)) != (uint32_t)b || ((h >> LG_LDS_BUCKET_BITS) & pmask) != pass) continue;
+            if ((h & (NB - 1)) != (uint32_t)b || ((h >> BB) & pmask) != pass) continue;
             insert(((unsigned long long)(uint32_t)id << 32) | (uint32_t)i, h);
         }
         if (listed)
             for (int32_t i = tid; i < n_listed; i += LG_DEDUP_THREADS) {
                 const unsigned long long pr = klist[i];
                 const uint32_t h = lg_tab_hash((int32_t)(pr >> 32));
-                if (((h >> LG_LDS_BUCKET_BITS) & pmask) != pass) continue;
+                if (((h >> BB) & pmask) != pass) continue;
                 insert(pr, h);
             }
         for (int32_t k0 = 0; k0 < total; k0 += LG_DEDUP_BATCH * LG_DEDUP_THREADS) {
@@ -599,7 +670,7 @@ __global__ __launch_bounds__(LG_DEDUP_THREADS) void dedup_lds_kernel(HopParams h
             for (int u = 0; u < LG_DEDUP_BATCH; u++) {
                 if (pr[u] == ~0ull) continue;
                 const uint32_t h = lg_tab_hash((int32_t)(pr[u] >> 32));
-                if (((h >> LG_LDS_BUCKET_BITS) & pmask) != pass) continue;
+                if (((h >> BB) & pmask) != pass) continue;
                 insert((pr[u] & 0xFFFFFFFF00000000ull) | PENDING | (uint32_t)pr[u], h);
             }
         }
@@ -616,7 +687,7 @@ __global__ __launch_bounds__(LG_DEDUP_THREADS) void dedup_lds_kernel(HopParams h
                 if (pr[u] == ~0ull) continue;
                 const uint32_t id = (uint32_t)(pr[u] >> 32), slot = (uint32_t)pr[u];
                 const uint32_t h = lg_tab_hash((int32_t)id);
-                if (((h >> LG_LDS_BUCKET_BITS) & pmask) != pass) continue;
+                if (((h >> BB) & pmask) != pass) continue;
                 uint32_t p = lds_slot_of(h);
                 uint32_t v = 0xFFFFFFFFu;
                 for (int it = 0; it < LG_LDS_TABLE; it++) {
@@ -755,13 +826,10 @@ __global__ __launch_bounds__(LG_SCAN_THREADS) void scan_kernel(HopParams hp, con
 // edges and the new nodes it writes, next to every edge, the row header of the sampled
 // neighbour: the next hop's frontier then needs no dependent lookup.
 // ------------------------------------------------------------------------------------------
-template <bool LISTING>     // lds form, not the last hop: later hops must recognise the nodes this one adds
 __global__ __launch_bounds__(LG_TILE) void scatter_kernel(HopParams hp, const LanePtrs* __restrict__ lanes)
 {
     const SampleArgs a = lane_args(hp, lanes);
     __shared__ int32_t s_cnt[LG_SLOTS_PER_LANE][2][LG_TILE / 64];
-    __shared__ int32_t s_kcnt[LISTING ? LG_LDS_BUCKETS : 1], s_kbase[LISTING ? LG_LDS_BUCKETS : 1];
-    constexpr bool listing = LISTING;
     const LG_G int32_t* hs = a.hop_scratch;
     const int32_t total = hs[HS_SLOTS];
     const int32_t ntiles = (total + LG_TILE - 1) / LG_TILE;
@@ -794,7 +862,6 @@ __global__ __launch_bounds__(LG_TILE) void scatter_kernel(HopParams hp, const La
                 s_cnt[u][1][wave] = __popcll(mf[u]);
             }
         }
-        if (listing && tid < LG_LDS_BUCKETS) s_kcnt[tid] = 0;
         __syncthreads();
         // phase 1: every load of the thread's four slots (nothing is stored in between, so they are all
         // in flight together: the buffers may alias as far as the compiler knows)
@@ -821,27 +888,6 @@ __global__ __launch_bounds__(LG_TILE) void scatter_kernel(HopParams hp, const La
                 if (!a.last_hop) nh[u] = load_hdr(a.row_hdr + dst);      // next hop's frontier header
                 lost_pos[u] = first ? 0 : a.slot_pos[idx];               // final already, or -2 - (slot it lost to)
                 tab_at[u] = (first && !a.last_hop && a.pos_table != nullptr) ? table_find(a.pos_table, a.pos_mask, a.pf, dst) : 0u;
-            }
-        }
-        if (listing && a.known_pairs != nullptr) {      // the super tile's new nodes, appended to their buckets' lists: one global atomic per bucket
-            int32_t kr[LG_SLOTS_PER_LANE];
-#pragma unroll
-            for (int u = 0; u < LG_SLOTS_PER_LANE; u++) {
-                kr[u] = -1;
-                if (e_at[u] >= 0 && n_at[u] >= 0)
-                    kr[u] = atomicAdd(&s_kcnt[lg_tab_hash(v[u] & 0x7FFFFFFF) & (LG_LDS_BUCKETS - 1)], 1);
-            }
-            __syncthreads();
-            if (tid < LG_LDS_BUCKETS) s_kbase[tid] = s_kcnt[tid] ? __hip_atomic_fetch_add(a.known_cnt + tid, s_kcnt[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
-            __syncthreads();
-#pragma unroll
-            for (int u = 0; u < LG_SLOTS_PER_LANE; u++) {
-                if (kr[u] < 0) continue;
-                const int32_t dst = v[u] & 0x7FFFFFFF;
-                const int32_t bk = (int32_t)(lg_tab_hash(dst) & (LG_LDS_BUCKETS - 1));
-                const int32_t at = s_kbase[bk] + kr[u];
-                if (at < a.known_cap)       // (a list that overflows is not used: its count says so)
-                    a.known_pairs[(int64_t)bk * a.known_cap + at] = ((unsigned long long)(uint32_t)dst << 32) | (uint32_t)n_at[u];
             }
         }
         // phase 2: the stores
@@ -873,6 +919,47 @@ __global__ __launch_bounds__(LG_TILE) void scatter_kernel(HopParams hp, const La
             } else {
                 a.agg_src_off[e] = lost_pos[u];
             }
+        }
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// K4b (lds form, every hop but the last): the nodes this hop added, appended as (vertex << 32 | position) to the lane's
+// per-bucket lists -- the next hops' de-duplication workgroups read only their bucket's list.  A chunk of new nodes is
+// counted per bucket in LDS, ONE global atomicAdd per non-empty bucket reserves its entries, a second sweep places them.
+// A list that outgrows its capacity is not used (its count says so; that bucket's workgroup scans sampled_ids instead).
+// ------------------------------------------------------------------------------------------
+#define LG_LIST_CHUNK 8192
+template <int BB>
+__global__ __launch_bounds__(LG_TILE) void list_known_kernel(HopParams hp, const LanePtrs* __restrict__ lanes)
+{
+    constexpr int NB = 1 << BB;
+    const SampleArgs a = lane_args(hp, lanes);
+    __shared__ int32_t s_kcnt[NB], s_kbase[NB];
+    if (a.known_pairs == nullptr) return;
+    const int32_t tid = threadIdx.x;
+    const int32_t h = a.op_id / INTRABATCH_CON;
+    const int32_t base = a.hop_scratch[HS_RANGE + 2 * h], n_new = a.hop_scratch[HS_RANGE + 2 * h + 1];   // this hop's range of sampled_ids
+    for (int32_t c0 = blockIdx.x * LG_LIST_CHUNK; c0 < n_new; c0 += gridDim.x * LG_LIST_CHUNK) {
+        const int32_t c1 = min(c0 + LG_LIST_CHUNK, n_new);
+        for (int32_t i = tid; i < NB; i += LG_TILE) s_kcnt[i] = 0;
+        __syncthreads();
+        for (int32_t i = c0 + tid; i < c1; i += LG_TILE)
+            atomicAdd(&s_kcnt[lg_tab_hash(a.sampled_ids[base + i]) & (NB - 1)], 1);
+        __syncthreads();
+        for (int32_t i = tid; i < NB; i += LG_TILE) {
+            const int32_t c = s_kcnt[i];
+            s_kbase[i] = c ? __hip_atomic_fetch_add(a.known_cnt + i, c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+            s_kcnt[i] = 0;
+        }
+        __syncthreads();
+        for (int32_t i = c0 + tid; i < c1; i += LG_TILE) {
+            const int32_t id = a.sampled_ids[base + i];
+            const int32_t bk = (int32_t)(lg_tab_hash(id) & (NB - 1));
+            const int32_t at = s_kbase[bk] + atomicAdd(&s_kcnt[bk], 1);
+            if (at < a.known_cap)
+                a.known_pairs[(int64_t)bk * a.known_cap + at] = ((unsigned long long)(uint32_t)id << 32) | (uint32_t)(base + i);
         }
         __syncthreads();
     }
@@ -921,22 +1008,50 @@ void launch_random_sample(hipStream_t s, const HopParams& p, const LanePtrs* d_l
     while (gx > 1 && (int64_t)gx * n_lanes > max_wg && max_wg < 4096) gx /= 2;   // (experiments with fewer workgroups)
     const dim3 grid(gx, n_lanes);
     if (form == 2) {
-        sample_kernel<2><<<grid, LG_TILE, 0, s>>>(p, d_lanes);
-        hipCheckError();
-        dedup_lds_kernel<<<dim3(LG_LDS_BUCKETS, n_lanes), LG_DEDUP_THREADS, 0, s>>>(p, d_lanes);
+        // buckets per lane follow the pool's largest hop (legion_core.h); super tiles per partition tile follow THIS hop: at
+        // most LG_LDS_MAX_PARTS partition tiles, and no larger than leaves the launch a couple of thousand workgroups
+        HopParams q = p;
+        const int32_t k_hi = p.lds_bucket_bits == LG_LDS_BITS_SMALL ? 1 : (p.lds_bucket_bits == LG_LDS_BITS_MEDIUM ? LG_LDS_K_MEDIUM : LG_LDS_K_LARGE);
+        int32_t k_lo = p.lds_bucket_bits == LG_LDS_BITS_LARGE ? 4 : 1;
+        while (max_super > LG_LDS_MAX_PARTS * k_lo) k_lo *= 2;
+        int32_t k = k_hi > k_lo ? k_hi : k_lo;
+        while (k > k_lo && (int64_t)(max_super / k) * n_lanes < 2048) k /= 2;
+        q.lds_k = k;
+        int32_t gp = (max_super + k - 1) / k;                  // one workgroup per partition tile ...
+        while (gp > 16 && (int64_t)gp * n_lanes > 8192) gp = (gp + 1) / 2;   // ... within reason
+        if (p.lds_bucket_bits == LG_LDS_BITS_SMALL) {
+            sample_kernel<2, LG_LDS_BITS_SMALL, true><<<grid, LG_TILE, 0, s>>>(q, d_lanes);
+            hipCheckError();
+            dedup_lds_kernel<LG_LDS_BITS_SMALL><<<dim3(1 << LG_LDS_BITS_SMALL, n_lanes), LG_DEDUP_THREADS, 0, s>>>(q, d_lanes);
+        } else if (p.lds_bucket_bits == LG_LDS_BITS_MEDIUM) {
+            sample_kernel<2, LG_LDS_BITS_MEDIUM, false><<<dim3(gp, n_lanes), LG_TILE, 0, s>>>(q, d_lanes);
+            hipCheckError();
+            dedup_lds_kernel<LG_LDS_BITS_MEDIUM><<<dim3(1 << LG_LDS_BITS_MEDIUM, n_lanes), LG_DEDUP_THREADS, 0, s>>>(q, d_lanes);
+        } else {
+            sample_kernel<2, LG_LDS_BITS_LARGE, false><<<dim3(gp, n_lanes), LG_TILE, 0, s>>>(q, d_lanes);
+            hipCheckError();
+            dedup_lds_kernel<LG_LDS_BITS_LARGE><<<dim3(1 << LG_LDS_BITS_LARGE, n_lanes), LG_DEDUP_THREADS, 0, s>>>(q, d_lanes);
+        }
     } else if (form == 1) {
-        sample_kernel<1><<<grid, LG_TILE, 0, s>>>(p, d_lanes);
+        sample_kernel<1, 0, true><<<grid, LG_TILE, 0, s>>>(p, d_lanes);
     } else {
-        sample_kernel<0><<<grid, LG_TILE, 0, s>>>(p, d_lanes);
+        sample_kernel<0, 0, true><<<grid, LG_TILE, 0, s>>>(p, d_lanes);
     }
     hipCheckError();
     flag_count_kernel<<<grid, LG_TILE, 0, s>>>(p, d_lanes);
     hipCheckError();
     scan_kernel<<<dim3(1, n_lanes), LG_SCAN_THREADS, 0, s>>>(p, d_lanes);
     hipCheckError();
-    if (form == 2 && !p.last_hop) scatter_kernel<true><<<grid, LG_TILE, 0, s>>>(p, d_lanes);    // (pools without lists: known_pairs is null)
-    else scatter_kernel<false><<<grid, LG_TILE, 0, s>>>(p, d_lanes);
+    scatter_kernel<<<grid, LG_TILE, 0, s>>>(p, d_lanes);
     hipCheckError();
+    if (form == 2 && !p.last_hop) {       // later hops must recognise the nodes this one added: their buckets' lists
+        int32_t chunks = (p.max_slots + LG_LIST_CHUNK - 1) / LG_LIST_CHUNK;
+        if (chunks > 256) chunks = 256;
+        if (p.lds_bucket_bits == LG_LDS_BITS_SMALL) list_known_kernel<LG_LDS_BITS_SMALL><<<dim3(chunks, n_lanes), LG_TILE, 0, s>>>(p, d_lanes);
+        else if (p.lds_bucket_bits == LG_LDS_BITS_MEDIUM) list_known_kernel<LG_LDS_BITS_MEDIUM><<<dim3(chunks, n_lanes), LG_TILE, 0, s>>>(p, d_lanes);
+        else list_known_kernel<LG_LDS_BITS_LARGE><<<dim3(chunks, n_lanes), LG_TILE, 0, s>>>(p, d_lanes);
+        hipCheckError();
+    }
     localise_kernel<<<grid, LG_TILE, 0, s>>>(p, d_lanes);
     hipCheckError();
 }

@@ -87,15 +87,23 @@
 // same loser mark the other forms leave.  No per-vertex state survives the hop, nothing to clear, nothing that scales
 // with N.  Used when a hop's slots per lane are few enough (<= 2^19: B = 1024-class batches); a bucket whose vertices
 // do not fit the table is handled in several passes over sub-buckets, so the result never depends on the hash.
-#ifndef LG_LDS_BUCKET_BITS
-#define LG_LDS_BUCKET_BITS 3
-#endif
+// Buckets per lane and the partition tile follow the pool's largest hop, so that a bucket sees at most ~64 k slots and
+// a bucket's share of a partition tile stays a few sectors long: 8 buckets / 1024-slot tiles up to 2^19 slots per lane
+// (B = 1024-class batches), 64 / 8192 up to 2^22 (B = 8000 with [25,10]), 256 / 32768 up to 2^24 (B = 8000 with
+// [15,10,5]); at most 512 partition tiles per hop in each class.  The kernels are instantiated for the three classes.
+#define LG_LDS_BITS_SMALL 3
+#define LG_LDS_BITS_MEDIUM 6
+#define LG_LDS_BITS_LARGE 8
+#define LG_LDS_K_MEDIUM 8                       // super tiles (1024 slots) per partition tile
+#define LG_LDS_K_LARGE 32
+#define LG_LDS_SLOTS_SMALL (1 << 19)
+#define LG_LDS_SLOTS_MEDIUM (1 << 22)
+#define LG_LDS_MAX_PARTS 512
 #ifndef LG_LDS_TABLE_BITS
 #define LG_LDS_TABLE_BITS 13
 #endif
-#define LG_LDS_BUCKETS (1 << LG_LDS_BUCKET_BITS)
 #define LG_LDS_TABLE (1 << LG_LDS_TABLE_BITS)   // 64-bit words of LDS per (lane, bucket) workgroup
-#define LG_LDS_MAX_SLOTS (1 << 19)
+#define LG_LDS_MAX_SLOTS (1 << 24)
 #define LG_POS_VALUE_BITS_MIN 16
 #define LG_POS_VALUE_BITS_MAX 28
 struct PosFmt {
@@ -216,12 +224,12 @@ struct LanePtrs {
     // lds form of the first-touch state (no per-vertex state at all, legion_core.h "LDS form"): the hop's claims,
     // partitioned by hash bucket inside the run of every 1024-slot super tile
     unsigned long long* claim_pairs;   // [max_slots] (vertex << 32 | slot)
-    int32_t* run_base;                 // [super tiles] where the super tile's run starts in claim_pairs
-    int32_t* run_cnt;                  // [super tiles][LG_LDS_BUCKETS] claims of each bucket in that run
+    int32_t* run_off;                  // [super tiles][buckets + 1] where each bucket's claims of that super tile start in claim_pairs
+    int32_t lds_buckets;               // 8 or 64 (0: not the lds form)
     // ... and the batch's vertices that later hops must recognise (every node but the seeds and the last hop's), one list
     // per bucket: scatter appends (vertex << 32 | position), the next hop's workgroup of that bucket reads only its list
-    unsigned long long* known_pairs;   // [LG_LDS_BUCKETS][known_cap]
-    int32_t* known_cnt;                // [LG_LDS_BUCKETS] entries appended (may exceed known_cap: then the list is not used)
+    unsigned long long* known_pairs;   // [buckets][known_cap]
+    int32_t* known_cnt;                // [buckets] entries appended (may exceed known_cap: then the list is not used)
     int32_t known_cap;
     int32_t* err_flag;                 // mapped pinned host word: kernels OR LG_ERR_* bits into it
     const void* deliver;               // lg::DeliverParams* (device) or null: the gather of this lane also hands its batch
@@ -298,8 +306,8 @@ public:
     RowHdr* fh_edge = nullptr;         // [num_ids] frontier row headers written by scatter
     int32_t* hop_scratch = nullptr;    // [HS_WORDS]
     unsigned long long* claim_pairs = nullptr; // lds form: see LanePtrs
-    int32_t* run_base = nullptr;
-    int32_t* run_cnt = nullptr;
+    int32_t* run_off = nullptr;
+    int32_t lds_bucket_bits = 0;
     unsigned long long* known_pairs = nullptr;
     int32_t* known_cnt = nullptr;
     int32_t known_cap = 0;
@@ -628,6 +636,8 @@ struct HopParams {                  // what every lane of a launch shares
     int32_t max_slots;              // capacity of slot_dst for this hop
     unsigned long long* edge_access_time;  // presample only (single lane), else null
     unsigned long long* topo_transactions; // presample only: 64-byte transactions the hop's topology reads amount to
+    int32_t lds_bucket_bits;        // lds form: LG_LDS_BITS_SMALL / MEDIUM / LARGE (the pool's)
+    int32_t lds_k;                  // lds form: super tiles per partition tile in this hop (set by launch_random_sample)
 };
 // form: 0 direct array, 1 table, 2 lds
 void launch_random_sample(hipStream_t s, const HopParams& p, const LanePtrs* d_lanes, int32_t n_lanes, int32_t form);

@@ -340,8 +340,8 @@ LanePtrs MemoryPool::HostLane(int32_t pipe) const
     h.pos_table_mask = pos_table_mask;
     h.err_flag = err_dev;
     h.claim_pairs = claim_pairs;
-    h.run_base = run_base;
-    h.run_cnt = run_cnt;
+    h.run_off = run_off;
+    h.lds_buckets = lds_form ? (1 << lds_bucket_bits) : 0;
     h.known_pairs = known_pairs;
     h.known_cnt = known_cnt;
     h.known_cap = known_cap;
@@ -387,14 +387,13 @@ void MemoryPool::Finalize()
     d_free_space(pos_table);
     pos_table = nullptr;
     d_free_space(claim_pairs);
-    d_free_space(run_base);
-    d_free_space(run_cnt);
+    d_free_space(run_off);
     d_free_space(known_pairs);
     d_free_space(known_cnt);
     known_pairs = nullptr;
     known_cnt = nullptr;
     claim_pairs = nullptr;
-    run_base = run_cnt = nullptr;
+    run_off = nullptr;
     if (err_host) HIP_CALL(hipHostFree(err_host));
     err_host = err_dev = nullptr;
     d_free_space(agg_src_ids_);
@@ -443,8 +442,9 @@ static int lg_dedup_form(int64_t total_num_nodes, int64_t max_slots)
         if (strcmp(e, "direct") == 0) return 0;
         if (strcmp(e, "lds") == 0) return max_slots <= LG_LDS_MAX_SLOTS ? 2 : 1;
     }
-    // auto: the LDS form wherever a hop's slots per lane allow it (12 % more edges/s at B = 1024 than either atomics form and
-    // no per-vertex state); otherwise the direct array while it fits a quarter of HBM over all lanes in flight, else the table
+    // auto: the LDS form wherever a hop's slots per lane allow it (no per-vertex state; measured against either atomics form:
+    // +14 % edges/s at B = 1024 with 8 buckets per lane, +5.5 % at B = 8000 [25,10] with 64); otherwise the direct array
+    // while it fits a quarter of HBM over all lanes in flight, else the table
     if (max_slots <= LG_LDS_MAX_SLOTS) return 2;
     return lg_use_pos_table(total_num_nodes) ? 1 : 0;
 }
@@ -487,18 +487,20 @@ void lg_pool_alloc_private(MemoryPool* mp, int32_t dev_id, int32_t total_num_nod
         const int64_t n_super = (slots + LG_SUPER - 1) / LG_SUPER + 1;
         mp->lds_form = true;
         mp->claim_pairs = (unsigned long long*)d_alloc_space(slots * sizeof(unsigned long long));
-        mp->run_base = (int32_t*)d_alloc_space(n_super * sizeof(int32_t));
-        mp->run_cnt = (int32_t*)d_alloc_space(n_super * LG_LDS_BUCKETS * sizeof(int32_t));
+        mp->lds_bucket_bits = slots <= LG_LDS_SLOTS_SMALL ? LG_LDS_BITS_SMALL : (slots <= LG_LDS_SLOTS_MEDIUM ? LG_LDS_BITS_MEDIUM : LG_LDS_BITS_LARGE);
+        const int64_t n_buckets = (int64_t)1 << mp->lds_bucket_bits;
+        const int64_t n_parts = std::min<int64_t>(n_super, LG_LDS_MAX_PARTS) + 2;    // launch_random_sample keeps every hop within LG_LDS_MAX_PARTS
+        mp->run_off = (int32_t*)d_alloc_space(n_parts * (n_buckets + 1) * sizeof(int32_t));
         // per-bucket lists of the nodes hops 1 .. H-1 add (later hops must recognise them): twice an even share each;
         // a bucket that outgrows its list is served by scanning sampled_ids instead (kernels_sample.hip)
         int64_t listed = 0;
         for (int i = 1; i < hop_num; i++) listed += mp->max_new[i];
         if (listed > 0) {
-            mp->known_cap = (int32_t)(2 * ((listed + LG_LDS_BUCKETS - 1) / LG_LDS_BUCKETS) + 256);
+            mp->known_cap = (int32_t)(2 * ((listed + n_buckets - 1) / n_buckets) + 256);
             if (const char* e = getenv("LEGION_LDS_KNOWN_CAP")) mp->known_cap = std::max(1, atoi(e));   // tests: force the scan
-            mp->known_pairs = (unsigned long long*)d_alloc_space((int64_t)LG_LDS_BUCKETS * mp->known_cap * sizeof(unsigned long long));
-            mp->known_cnt = (int32_t*)d_alloc_space(LG_LDS_BUCKETS * sizeof(int32_t));
-            HIP_CALL(hipMemset(mp->known_cnt, 0, LG_LDS_BUCKETS * sizeof(int32_t)));
+            mp->known_pairs = (unsigned long long*)d_alloc_space(n_buckets * mp->known_cap * sizeof(unsigned long long));
+            mp->known_cnt = (int32_t*)d_alloc_space(n_buckets * sizeof(int32_t));
+            HIP_CALL(hipMemset(mp->known_cnt, 0, n_buckets * sizeof(int32_t)));
         }
         mp->SetPositionMap(nullptr);
     } else if (form == 1) {
@@ -698,7 +700,7 @@ extern "C" int64_t legion_pool_state_bytes(const LegionMemoryPool* p_)
 {
     const MemoryPool* mp = reinterpret_cast<const MemoryPool*>(p_);
     if (!mp) return 0;
-    if (mp->lds_form) return (int64_t)mp->max_slots * 8 + (int64_t)LG_LDS_BUCKETS * mp->known_cap * 8;   // one hop's claim pairs + the known lists
+    if (mp->lds_form) return (int64_t)mp->max_slots * 8 + ((int64_t)mp->known_cap << mp->lds_bucket_bits) * 8;   // one hop's claim pairs + the known lists
     return mp->pos_table ? ((int64_t)mp->pos_table_mask + 1) * 8 : (int64_t)mp->total_num_nodes * 4;
 }
 

@@ -18,7 +18,7 @@ for r in csv.DictReader(open(f)):
     if 'lg::' not in n: continue
     key = (n.split('(')[0][:40], r['Grid_Size_X'], r['Grid_Size_Y'])
     acc[key].append((int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3)
-for k, v in sorted(acc.items(), key=lambda kv: -sum(kv[1]))[:9]:
+for k, v in sorted(acc.items(), key=lambda kv: -sum(kv[1]))[:22]:
     v = sorted(v)
     print(k, len(v), "median %.1f" % v[len(v)//2])
 PY
