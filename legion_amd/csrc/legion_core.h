@@ -80,13 +80,14 @@
 // (auto: table when the direct arrays of all lanes in flight would take more than a quarter of HBM).
 //
 // The LDS form (round 2) issues no memory-side atomic per claim at all.  A hop's claims (vertex, slot) are written, by
-// the sampling kernel, into 8 hash buckets per lane (one reservation per 1024-slot super tile, ranks by LDS atomics); a
+// the sampling kernel, into hash buckets of their lane (one reservation per partition tile, ranks by LDS atomics); a
 // second kernel gives every (lane, bucket) a workgroup that builds an open-addressing table of the bucket's vertices IN
-// LDS -- the batch's known vertices of that bucket re-inserted from sampled_ids with their positions, then the claims with
-// atomicMin on (vertex, pending | slot) -- and writes, for every claim that is not the lowest slot of a new vertex, the
-// same loser mark the other forms leave.  No per-vertex state survives the hop, nothing to clear, nothing that scales
-// with N.  Used when a hop's slots per lane are few enough (<= 2^19: B = 1024-class batches); a bucket whose vertices
-// do not fit the table is handled in several passes over sub-buckets, so the result never depends on the hash.
+// LDS -- the batch's known vertices of that bucket (the seeds from sampled_ids, the nodes earlier hops added from the
+// bucket's list, which list_known_kernel keeps) with their positions, then the claims with atomicMin on
+// (vertex, pending | slot) -- and writes, for every claim that is not the lowest slot of a new vertex, the same loser
+// mark the other forms leave.  No per-vertex state survives the hop, nothing to clear, nothing that scales with N.  A
+// bucket whose vertices do not fit the table is handled in several passes over sub-buckets, so the result never depends
+// on the hash.  Used for hops of up to 2^24 slots per lane (every shape of legion_server.py; beyond: the atomics forms).
 // Buckets per lane and the partition tile follow the pool's largest hop, so that a bucket sees at most ~64 k slots and
 // a bucket's share of a partition tile stays a few sectors long: 8 buckets / 1024-slot tiles up to 2^19 slots per lane
 // (B = 1024-class batches), 64 / 8192 up to 2^22 (B = 8000 with [25,10]), 256 / 32768 up to 2^24 (B = 8000 with
@@ -225,7 +226,7 @@ struct LanePtrs {
     // partitioned by hash bucket inside the run of every 1024-slot super tile
     unsigned long long* claim_pairs;   // [max_slots] (vertex << 32 | slot)
     int32_t* run_off;                  // [super tiles][buckets + 1] where each bucket's claims of that super tile start in claim_pairs
-    int32_t lds_buckets;               // 8 or 64 (0: not the lds form)
+    int32_t lds_buckets;               // 8, 64 or 256 (0: not the lds form)
     // ... and the batch's vertices that later hops must recognise (every node but the seeds and the last hop's), one list
     // per bucket: scatter appends (vertex << 32 | position), the next hop's workgroup of that bucket reads only its list
     unsigned long long* known_pairs;   // [buckets][known_cap]

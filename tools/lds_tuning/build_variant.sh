@@ -3,8 +3,8 @@
 #   tools/lds_tuning/build_variant.sh v16 -DLG_LDS_BUCKET_BITS=4 -DLG_LDS_FILL_16THS=8
 # -> tools/lds_tuning/variants/v16/liblegion_hip.so (git-ignored; travels to the GPU box with the snapshot)
 NAME=$1; shift
-R=/root/repo
-O=$R/tools/lds_tuning/variants/$NAME
+R=${SRC_ROOT:-/root/repo}
+O=/root/repo/tools/lds_tuning/variants/$NAME
 mkdir -p $O
 for f in kernels_sample kernels_gather kernels_cache kernels_synth storage link_counters cache operators pipeline ipc_env server; do
   /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -fno-fast-math -w "$@" -c $R/legion_amd/csrc/$f.hip -o $O/$f.o &
