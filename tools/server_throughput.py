@@ -20,6 +20,7 @@ def main():
     ap.add_argument("--fanout", type=str, default="25,10")
     ap.add_argument("--train-batches", type=int, default=60)
     ap.add_argument("--cache-memory", type=int, default=1 << 30)
+    ap.add_argument("--epochs", type=int, default=1, help="epochs the server runs (python consumer: the timed window spans them all)")
     ap.add_argument("--verify-every", type=int, default=0,
                     help="python consumer: every k-th batch, check on the device that the rows are the generator's rows of the "
                          "batch's ids, that ids are unique and that every edge endpoint indexes a node of the batch (soak test "
@@ -53,7 +54,7 @@ def main():
     work = os.path.join(tmp, "run")
     os.makedirs(work)
     open(os.path.join(work, "meta_config"), "w").write("{} {} {} {} {} {} {} {} {} {}".format(
-        ds, a.batch, N, E, a.dim, train.size, valid.size, test.size, a.cache_memory, 1))
+        ds, a.batch, N, E, a.dim, train.size, valid.size, test.size, a.cache_memory, a.epochs))
     ns = f"_b{os.getpid()}"
     os.environ["LEGION_IPC_NAMESPACE"] = ns
     log = open(os.path.join(work, "server.log"), "w")
@@ -86,11 +87,13 @@ def main():
         H = len(fanout)
         edges, t0, n_timed, verified = 0, None, 0, 0
         t_start = time.time()
-        for i in range(tr + va + te):
+        n_all = (tr + va) * a.epochs + te                # the reference's schedule (ipc_service.cu:130-132)
+        last_timed = (tr + va) * (a.epochs - 1) + tr - 1     # last training batch of the last epoch
+        for i in range(n_all):
             if a.watchdog and time.time() - t_start > a.watchdog:
-                raise RuntimeError(f"watchdog: stuck or too slow at batch {i} of {tr + va + te}")
+                raise RuntimeError(f"watchdog: stuck or too slow at batch {i} of {n_all}")
             out = ipc_service.get_next(a.dim)
-            if i < tr:
+            if i <= last_timed:
                 if i == 5:
                     torch.cuda.synchronize(); t0 = time.perf_counter(); edges = 0; n_timed = 0
                 edges += int(out[3].numel())          # outermost block = every edge of the batch
@@ -103,13 +106,13 @@ def main():
                 assert int(torch.unique(ids).numel()) == n, f"batch {i}: duplicate ids"
                 sizes = ipc_service.get_block_size()
                 assert sizes[0] == n and int(out[3].max()) < n and int(out[4].max()) < sizes[1], f"batch {i}: edge endpoints"
-                seeds_expected = torch.from_numpy(train[i * a.batch:(i + 1) * a.batch]).cuda() if i < tr else None
+                seeds_expected = torch.from_numpy(train[i * a.batch:(i + 1) * a.batch]).cuda() if (i < tr and a.epochs == 1) else None
                 if seeds_expected is not None:
                     assert bool((ids[:a.batch] == seeds_expected).all()), f"batch {i}: not the seeds of training batch {i}"
                 verified += 1
             del out
             ipc_service.synchronize()
-            if i == tr - 1:
+            if i == last_timed:
                 torch.cuda.synchronize(); t1 = time.perf_counter()
         ipc_service.finalize()
         server.wait(timeout=120)
