@@ -1009,16 +1009,18 @@ void launch_random_sample(hipStream_t s, const HopParams& p, const LanePtrs* d_l
     const dim3 grid(gx, n_lanes);
     if (form == 2) {
         // buckets per lane follow the pool's largest hop (legion_core.h); super tiles per partition tile follow THIS hop: at
-        // most LG_LDS_MAX_PARTS partition tiles, and no larger than leaves the launch a couple of thousand workgroups
+        // most LG_LDS_MAX_PARTS partition tiles, and no larger than leaves the launch ~8 k workgroups by the hop's capacity
+        // (a hop typically fills a quarter of it: ~2 k active ones; measured at B = 8000: 2 k -> 8 k +1...2 %, beyond: the same)
         HopParams q = p;
         const int32_t k_hi = p.lds_bucket_bits == LG_LDS_BITS_SMALL ? 1 : (p.lds_bucket_bits == LG_LDS_BITS_MEDIUM ? LG_LDS_K_MEDIUM : LG_LDS_K_LARGE);
         int32_t k_lo = p.lds_bucket_bits == LG_LDS_BITS_LARGE ? 4 : 1;
         while (max_super > LG_LDS_MAX_PARTS * k_lo) k_lo *= 2;
         int32_t k = k_hi > k_lo ? k_hi : k_lo;
-        while (k > k_lo && (int64_t)(max_super / k) * n_lanes < 2048) k /= 2;
+        static const int want_wg = [] { const char* e = getenv("LEGION_LDS_PART_WG"); return e ? atoi(e) : 8192; }();
+        while (k > k_lo && (int64_t)(max_super / k) * n_lanes < want_wg) k /= 2;
         q.lds_k = k;
         int32_t gp = (max_super + k - 1) / k;                  // one workgroup per partition tile ...
-        while (gp > 16 && (int64_t)gp * n_lanes > 8192) gp = (gp + 1) / 2;   // ... within reason
+        while (gp > 16 && (int64_t)gp * n_lanes > 16384) gp = (gp + 1) / 2;  // ... within reason
         if (p.lds_bucket_bits == LG_LDS_BITS_SMALL) {
             sample_kernel<2, LG_LDS_BITS_SMALL, true><<<grid, LG_TILE, 0, s>>>(q, d_lanes);
             hipCheckError();

@@ -91,7 +91,7 @@
 // Buckets per lane and the partition tile follow the pool's largest hop, so that a bucket sees at most ~64 k slots and
 // a bucket's share of a partition tile stays a few sectors long: 8 buckets / 1024-slot tiles up to 2^19 slots per lane
 // (B = 1024-class batches), 64 / 8192 up to 2^22 (B = 8000 with [25,10]), 256 / 32768 up to 2^24 (B = 8000 with
-// [15,10,5]); at most 512 partition tiles per hop in each class.  The kernels are instantiated for the three classes.
+// [15,10,5]); at most 1024 partition tiles per hop.  The kernels are instantiated for the three classes.
 #define LG_LDS_BITS_SMALL 3
 #define LG_LDS_BITS_MEDIUM 6
 #define LG_LDS_BITS_LARGE 8
@@ -99,7 +99,7 @@
 #define LG_LDS_K_LARGE 32
 #define LG_LDS_SLOTS_SMALL (1 << 19)
 #define LG_LDS_SLOTS_MEDIUM (1 << 22)
-#define LG_LDS_MAX_PARTS 512
+#define LG_LDS_MAX_PARTS 1024
 #ifndef LG_LDS_TABLE_BITS
 #define LG_LDS_TABLE_BITS 13
 #endif
