@@ -13,7 +13,7 @@ far too short to time (launch latency, clock ramp), the same region is repeated 
 GPU work have been timed and the MEDIAN region (max over ranks per repeat) gives `value`.
 Workload: synthetic RMAT-26 (N = 2^26, E = 2^30), float32[N x 128] counter-hash
 features, B = 1024, seeds = a seeded permutation, GPU p of P takes seeds with id % P == p.
-Mini-batches are served in groups: every kernel launch covers --group (default 131072 / B, at most 128) independent
+Mini-batches are served in groups: every kernel launch covers --group (default 262144 / B, at most 256) independent
 batches (grid.y = lanes) and a group's op list is one hipGraph replay (legion_amd/csrc/pipeline.hip).
 
 One process per GPU.  The path shards by seeds with no per-batch exchange; the only collective is

@@ -583,7 +583,7 @@ private:
         hop_num_ = (int32_t)params->fanout.size();
         max_step_ = env->GetMaxStep();
         std::vector<int32_t> fanout(params->fanout.begin(), params->fanout.end());
-        lanes_ = std::max(1, std::min(128, 131072 / std::max(1, memorypool_->batch_size)));
+        lanes_ = std::max(1, std::min(128, 262144 / std::max(1, memorypool_->batch_size)));
         if (const char* e = getenv("LEGION_RUNNER_LANES")) lanes_ = std::max(1, atoi(e));
         // use_graph bits: 1 graph replay, 8 sampler phase only (the gathers go straight into the pipe slots)
         pipe_ = legion_pipeline_create((LegionGraphStorage*)params->graph, (LegionFeatureStorage*)params->feature,
