@@ -1016,7 +1016,8 @@ void launch_random_sample(hipStream_t s, const HopParams& p, const LanePtrs* d_l
         int32_t k_lo = p.lds_bucket_bits == LG_LDS_BITS_LARGE ? 4 : 1;
         while (max_super > LG_LDS_MAX_PARTS * k_lo) k_lo *= 2;
         int32_t k = k_hi > k_lo ? k_hi : k_lo;
-        static const int want_wg = [] { const char* e = getenv("LEGION_LDS_PART_WG"); return e ? atoi(e) : 8192; }();
+        const char* want_env = getenv("LEGION_LDS_PART_WG");        // (read per launch: tests vary it inside one process)
+        const int want_wg = want_env ? atoi(want_env) : 8192;
         while (k > k_lo && (int64_t)(max_super / k) * n_lanes < want_wg) k /= 2;
         q.lds_k = k;
         int32_t gp = (max_super + k - 1) / k;                  // one workgroup per partition tile ...
