@@ -448,8 +448,9 @@ def main():
                               "frac_of_hbm_peak": samp_bytes / t_sampling / 1e9 / HBM_PEAK_GBPS,
                               "note": "rank 0; time = timed region minus the HIP-event time of all gather launches (with the weave "
                                       "arrangement the head of the next group runs hidden under this group's heavy kernels, so this is the "
-                                      "sampler time that is NOT hidden); the sampler is bound by memory-side atomics (~13-19 G claims/s) and "
-                                      "scattered loads (~47 G/s), see tools/micro/dedup_tables.hip"},
+                                      "sampler time that is NOT hidden); the sampler is bound by scattered 4-byte column loads (~43-47 G sector "
+                                      "misses/s, tools/micro/random_access.hip) and, in the atomics forms of the first-touch state, by "
+                                      "memory-side atomics (~13-19 G claims/s, tools/micro/dedup_tables.hip): DESIGN.md section 4.2"},
             "edges_per_step": float(edges.sum()) / args.steps, "rows_per_step": float(rows.sum()) / args.steps,
             "edges_per_batch": float(edges.mean()), "rows_per_batch": float(rows.sum(axis=1).mean()),
             "seed_feature_cache_hits_step0": hits,
