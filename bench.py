@@ -76,6 +76,9 @@ def parse_args():
     ap.add_argument("--no-weave", action="store_true",
                     help="everything of a group on ONE stream (default: the next group's head -- seeds + every hop but the last, small "
                          "latency-bound kernels -- runs on a second stream under the current group's heavy kernels, pipeline.hip)")
+    ap.add_argument("--capacity", type=str, default="",
+                    help="NODE,EDGE: cache capacities per GPU set by hand after the cost model has run (its choice is logged): e.g. a "
+                         "topology cache of the EDGE hottest vertices' adjacency beside a pinned-host CSR (SURVEY section 8 N1)")
     ap.add_argument("--no-verify", action="store_true")
     ap.add_argument("--no-overlap-leg", action="store_true",
                     help="skip the extra timed region with sampler and gather phases overlapped on two streams")
@@ -237,6 +240,8 @@ def main():
     else:
         cache.candidate_selection(0, graph, world_reduced=use_dist)
         cache.cost_model(feature, graph, counters, train_step)
+        if args.capacity:
+            cache.set_capacity(*[int(x) for x in args.capacity.split(",")])
         cache.fill_up(feature, graph)
     feature_rows = int(max_ids * 1.2)                                        # server.cu:277
     pool.close()
