@@ -240,6 +240,11 @@ extern "C" int32_t legion_pipeline_submit_n(LegionPipeline* p, int32_t counter0,
     return legion_pipeline_submit_ex(p, counter0, mode, n_active, p ? p->batch_size : 0);
 }
 extern "C" legion_stream_t legion_pipeline_stream(LegionPipeline* p) { return p ? (legion_stream_t)p->slots[0].stream : nullptr; }
+// (GPURunner) the event recorded behind the last submitted group of a slot: another stream may wait for it
+extern "C" void* legion_pipeline_slot_done_event(LegionPipeline* p, int32_t slot)
+{
+    return (p && slot >= 0 && slot < p->slots_n) ? (void*)p->slots[slot].done : nullptr;
+}
 
 // Same with only the first n_active lanes of the group working (the tail of a run whose length is
 // not a multiple of the group size) and an explicit batch size (validation / test batches differ from

@@ -304,6 +304,7 @@ extern "C" LegionPipeline* legion_pipeline_create(LegionGraphStorage* graph, Leg
 extern "C" int32_t legion_pipeline_submit_ex(LegionPipeline* p, int32_t counter0, int32_t mode, int32_t n_active, int32_t batch_size);
 extern "C" void legion_pipeline_prepare(LegionPipeline* p, int32_t mode, int32_t n_active, int32_t batch_size);
 extern "C" legion_stream_t legion_pipeline_stream(LegionPipeline* p);
+extern "C" void* legion_pipeline_slot_done_event(LegionPipeline* p, int32_t slot);
 extern "C" LegionMemoryPool* legion_pipeline_pool(LegionPipeline* p, int32_t slot, int32_t lane);
 extern "C" void legion_pipeline_destroy(LegionPipeline* p);
 
@@ -462,6 +463,9 @@ public:
             } else {
                 SubmitGroup(env, batch_id, cur_slot_, cur_first_, cur_n_);
             }
+            // the hand-over stream may touch this group's lanes once its sampler phase has finished
+            if (ho_stream_ != nullptr)
+                HIP_CALL(hipStreamWaitEvent(ho_stream_, (hipEvent_t)legion_pipeline_slot_done_event(pipe_, cur_slot_), 0));
         }
         const int32_t lane = batch_id - cur_first_;
         // the next group's sampler is queued while this group is still being handed over: the GPU never idles
@@ -481,7 +485,9 @@ public:
         int32_t n_out = 1;
         if (pair_ && lane + 1 < cur_n_ && env->IPCTryWait(local_dev_id_, p2)) n_out = 2;
         const auto t_b = std::chrono::steady_clock::now();
-        hipStream_t s = static_cast<hipStream_t>(legion_pipeline_stream(pipe_));
+        // hand-overs run on their own (high-priority) stream: queued behind the next group's sampler phase on ONE stream
+        // they stalled for its whole duration once per group, the trainer starving meanwhile
+        hipStream_t s = ho_stream_ != nullptr ? ho_stream_ : static_cast<hipStream_t>(legion_pipeline_stream(pipe_));
         const int par = (p + lane) % interbatch_concurrency_;           // pipe of lane g = (par + g) % 2
         const LanePtrs* desc = d_desc_ + ((size_t)par * 2 + cur_slot_) * lanes_ + lane;
         UnifiedCache* cache = (UnifiedCache*)(params->cache);
@@ -501,6 +507,10 @@ public:
             q_tail_.store(t + 1, std::memory_order_release);
         }
         pair_pending_ = n_out == 2;
+        if (ho_stream_ != nullptr && lane + n_out >= cur_n_) {       // the group's lanes are free again once this has run
+            HIP_CALL(hipEventRecord(ho_done_[cur_slot_], ho_stream_));
+            ho_done_valid_[cur_slot_] = true;
+        }
         if (stats_) {
             const auto t_c = std::chrono::steady_clock::now();
             st_wait_ += std::chrono::duration<double>(t_b - t_a).count();
@@ -549,6 +559,11 @@ public:
             std::cout << "runner " << local_dev_id_ << ": " << st_n_ << " hand-over launches (" << st_pairs_ << " of two batches); waiting for a free slot " << st_wait_ / st_n_ * 1e6
                       << " us, launch calls " << st_launch_ / st_n_ * 1e6 << " us, enqueue -> completion seen "
                       << st_gpu_ / st_n_ * 1e6 << " us\n";
+        if (ho_stream_ != nullptr) {
+            HIP_CALL(hipStreamSynchronize(ho_stream_));
+            HIP_CALL(hipStreamDestroy(ho_stream_));
+            ho_stream_ = nullptr;
+        }
         if (pipe_) {
             legion_pipeline_destroy(pipe_);
             pipe_ = nullptr;
@@ -589,6 +604,12 @@ private:
         pipe_ = legion_pipeline_create((LegionGraphStorage*)params->graph, (LegionFeatureStorage*)params->feature,
                                        (LegionUnifiedCache*)params->cache, local_dev_id_, memorypool_->batch_size,
                                        fanout.data(), hop_num_, lanes_, 2, 0, 1 | 8);
+        if (!(getenv("LEGION_RUNNER_HO_STREAM") && atoi(getenv("LEGION_RUNNER_HO_STREAM")) == 0)) {
+            int lo = 0, hi = 0;
+            HIP_CALL(hipDeviceGetStreamPriorityRange(&lo, &hi));
+            HIP_CALL(hipStreamCreateWithPriority(&ho_stream_, hipStreamNonBlocking, hi));
+            for (int i = 0; i < 2; i++) HIP_CALL(hipEventCreateWithFlags(&ho_done_[i], hipEventDisableTiming));
+        }
         for (int p = 0; p < interbatch_concurrency_; p++) {
             lg::DeliverParams& d = deliver_[p];
             d.sampled_ids = env->GetIds(local_dev_id_, p);
@@ -671,7 +692,13 @@ private:
     {
         int32_t mode = 0, local0 = 0;
         const int32_t n = PlanGroup(env, first, mode, local0);
+        // the pipeline hands its two slots out in turn: the sampler may overwrite the lanes of the slot it gets now only
+        // after every batch of the group that used them before has been handed over
+        const int target = submit_count_++ % 2;
+        if (ho_stream_ != nullptr && ho_done_valid_[target])
+            HIP_CALL(hipStreamWaitEvent(static_cast<hipStream_t>(legion_pipeline_stream(pipe_)), ho_done_[target], 0));
         slot_out = legion_pipeline_submit_ex(pipe_, local0, mode, n, env->GetCurrentBatchsize(local_dev_id_, mode));
+        if (slot_out != target) { printf("legion_hip: runner lost track of the pipeline's slots\n"); exit(EXIT_FAILURE); }
         first_out = first;
         n_out = n;
     }
@@ -705,6 +732,10 @@ private:
     std::atomic<uint32_t> q_tail_{0};
     std::atomic<bool> stop_{false};
     bool pair_pending_ = false;
+    hipStream_t ho_stream_ = nullptr;                   // hand-over launches (LEGION_RUNNER_HO_STREAM=0: the sampler's stream)
+    hipEvent_t ho_done_[2] = {nullptr, nullptr};        // behind the last hand-over of the group in pipeline slot 0 / 1
+    bool ho_done_valid_[2] = {false, false};
+    int submit_count_ = 0;
     bool pair_ = !(getenv("LEGION_RUNNER_PAIR") && atoi(getenv("LEGION_RUNNER_PAIR")) == 0);
     int64_t st_pairs_ = 0;
     bool stats_ = getenv("LEGION_RUNNER_STATS") != nullptr;

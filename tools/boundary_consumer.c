@@ -31,9 +31,9 @@ static double now(void) { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t);
 
 int main(int argc, char** argv)
 {
-    if (argc != 5) { fprintf(stderr, "usage: boundary_consumer <suffix> <device> <hops> <skip>\n"); return 2; }
+    if (argc != 5 && argc != 6) { fprintf(stderr, "usage: boundary_consumer <suffix> <device> <hops> <skip> [epochs]\n"); return 2; }
     const char* sfx = argv[1];
-    const int dev = atoi(argv[2]), hops = atoi(argv[3]), skip = atoi(argv[4]);
+    const int dev = atoi(argv[2]), hops = atoi(argv[3]), skip = atoi(argv[4]), epochs = argc == 6 ? atoi(argv[5]) : 1;
     char name[128];
     snprintf(name, sizeof name, "simpleIPCshm%s", sfx);
     int fd = shm_open(name, O_RDWR, 0777);
@@ -50,7 +50,9 @@ int main(int argc, char** argv)
         if (sr[i] == SEM_FAILED || sw[i] == SEM_FAILED) { perror("sem_open"); return 1; }
         sem_post(sr[i]);                                   /* both pipe slots start free */
     }
-    const int train = shm->steps[0], total = shm->steps[0] + shm->steps[1] + shm->steps[2];   /* epoch 1 */
+    /* the reference's schedule: (train + valid) x epochs + test; timed up to the last training batch of the last epoch */
+    const int per_epoch = shm->steps[0] + shm->steps[1];
+    const int total = per_epoch * epochs + shm->steps[2], train = per_epoch * (epochs - 1) + shm->steps[0];
     long long edges = 0, nodes = 0;
     int timed = 0, pipe = 0;
     double t0 = 0, t1 = 0;

@@ -69,7 +69,7 @@ def main():
         if a.consumer == "native":
             exe = os.path.join(tmp, "boundary_consumer")
             subprocess.check_call(["gcc", "-O2", os.path.join(ROOT, "tools", "boundary_consumer.c"), "-o", exe, "-lrt", "-lpthread"])
-            out = subprocess.check_output([exe, ns, "0", str(len(fanout)), "5"]).decode().strip().splitlines()[-1]
+            out = subprocess.check_output([exe, ns, "0", str(len(fanout)), "5", str(a.epochs)]).decode().strip().splitlines()[-1]
             server.wait(timeout=120)
             log.flush()
             for line in open(os.path.join(work, "server.log")):
