@@ -35,7 +35,8 @@ def write_dataset(path, wl_indptr, wl_col, feats, labels, train, valid, test):
     {"LEGION_RUNNER_LANES": "1", "LEGION_RUNNER_PAIR": "0"},   # one batch per group
     {"LEGION_RUNNER_GRAPH": "0"},                              # the reference's operator-by-operator Runner
     {"LEGION_NO_SHM_MIRROR": "1"},                             # counters copied from the device, as the reference's trainer end does
-], ids=["default", "lanes3", "lanes4-table", "lanes1", "operators", "no-mirror"])
+    {"LEGION_RUNNER_LANES": "5", "LEGION_RUNNER_HO_STREAM": "0"},   # hand-overs on the sampler's own stream
+], ids=["default", "lanes3", "lanes4-table", "lanes1", "operators", "no-mirror", "lanes5-one-stream"])
 def test_server_binary_serves_fake_trainer(hip, tmp_path, server_env, monkeypatch):
     import torch
     for k, v in server_env.items():
