@@ -693,9 +693,9 @@ extern "C" void legion_cache_export(LegionUnifiedCache* c, LegionGraphStorage* g
     if (!u || !g || !handles192) { printf("invalid cache/graph ptr\n"); return; }
     SetGPUDevice(dev_id);
     LegionStripeHandles* h = reinterpret_cast<LegionStripeHandles*>(handles192);
-    HIP_CALL(hipIpcGetMemHandle(&h->feat_cache, u->FeatureCachePtr(dev_id)));
-    HIP_CALL(hipIpcGetMemHandle(&h->topo_index, g->CachedCSRIndex(dev_id)));
-    HIP_CALL(hipIpcGetMemHandle(&h->topo_col, g->CachedCSRDst(dev_id)));
+    lg_ipc_export(&h->feat_cache, (void*)u->FeatureCachePtr(dev_id), __FILE__, __LINE__);
+    lg_ipc_export(&h->topo_index, (void*)g->CachedCSRIndex(dev_id), __FILE__, __LINE__);
+    lg_ipc_export(&h->topo_col, (void*)g->CachedCSRDst(dev_id), __FILE__, __LINE__);
 }
 
 extern "C" void legion_cache_import_peer(LegionUnifiedCache* c, LegionGraphStorage* graph, int32_t local_dev,

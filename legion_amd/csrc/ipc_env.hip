@@ -172,12 +172,12 @@ public:
             void* new_edge_counter = d_alloc_space(16 * sizeof(int32_t));
             HIP_CALL(hipMemset(new_node_counter, 0, 64));
             HIP_CALL(hipMemset(new_edge_counter, 0, 64));
-            HIP_CALL(hipIpcGetMemHandle((hipIpcMemHandle_t*)&shm_->memHandle[device_id][i][0], new_ids));
-            HIP_CALL(hipIpcGetMemHandle((hipIpcMemHandle_t*)&shm_->memHandle[device_id][i][2], new_labels));
-            HIP_CALL(hipIpcGetMemHandle((hipIpcMemHandle_t*)&shm_->memHandle[device_id][i][3], new_agg_src));
-            HIP_CALL(hipIpcGetMemHandle((hipIpcMemHandle_t*)&shm_->memHandle[device_id][i][4], new_agg_dst));
-            HIP_CALL(hipIpcGetMemHandle((hipIpcMemHandle_t*)&shm_->memHandle[device_id][i][5], new_node_counter));
-            HIP_CALL(hipIpcGetMemHandle((hipIpcMemHandle_t*)&shm_->memHandle[device_id][i][6], new_edge_counter));
+            lg_ipc_export((void*)&shm_->memHandle[device_id][i][0], new_ids, __FILE__, __LINE__);
+            lg_ipc_export((void*)&shm_->memHandle[device_id][i][2], new_labels, __FILE__, __LINE__);
+            lg_ipc_export((void*)&shm_->memHandle[device_id][i][3], new_agg_src, __FILE__, __LINE__);
+            lg_ipc_export((void*)&shm_->memHandle[device_id][i][4], new_agg_dst, __FILE__, __LINE__);
+            lg_ipc_export((void*)&shm_->memHandle[device_id][i][5], new_node_counter, __FILE__, __LINE__);
+            lg_ipc_export((void*)&shm_->memHandle[device_id][i][6], new_edge_counter, __FILE__, __LINE__);
             ids_[device_id].push_back(new_ids);
             labels_[device_id].push_back(new_labels);
             agg_src_[device_id].push_back(new_agg_src);
@@ -214,7 +214,7 @@ public:
         SetGPUDevice(device_id);
         for (int32_t i = 0; i < pipeline_depth; i++) {
             void* new_features = d_alloc_space((int64_t)num_ids * feature_dim * sizeof(float));
-            HIP_CALL(hipIpcGetMemHandle((hipIpcMemHandle_t*)&shm_->memHandle[device_id][i][1], new_features));
+            lg_ipc_export((void*)&shm_->memHandle[device_id][i][1], new_features, __FILE__, __LINE__);
             float_features_[device_id].push_back(new_features);
         }
     }

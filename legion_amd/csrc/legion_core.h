@@ -621,6 +621,9 @@ extern "C" void d_free_space(void* d_ptr);
 extern "C" void* host_alloc_space(int64_t num_bytes);
 extern "C" void SetGPUDevice(int32_t shard_id);
 extern "C" int32_t GetGPUDevice();
+// hipIpcGetMemHandle with a few retries: on this pool's driver (dmabuf IPC) an export now and then fails with
+// 'invalid argument' for a fresh, valid allocation and succeeds a moment later; a persistent failure is fatal as before
+void lg_ipc_export(void* handle64, void* dev_ptr, const char* file, int line);
 
 // ---------------------------------------------------------------------------------------------
 // kernel launchers (kernels_*.hip)

@@ -9,6 +9,7 @@
 // device-dereferenceable pointers; the caller places them in HBM when they fit and in mapped
 // pinned memory otherwise.  Nothing here assumes which.
 #include "legion_core.h"
+#include <unistd.h>
 
 #include <cstring>
 
@@ -52,6 +53,19 @@ extern "C" void* d_alloc_space(int64_t num_bytes)
     void* ret = nullptr;
     HIP_CALL(hipMalloc(&ret, num_bytes > 0 ? (size_t)num_bytes : 16));
     return ret;
+}
+
+void lg_ipc_export(void* handle64, void* dev_ptr, const char* file, int line)
+{
+    hipError_t e = hipSuccess;
+    for (int attempt = 0; attempt < 20; attempt++) {
+        e = hipIpcGetMemHandle((hipIpcMemHandle_t*)handle64, dev_ptr);
+        if (e == hipSuccess) return;
+        (void)hipGetLastError();
+        usleep(25000);
+    }
+    printf("HIP failure %s:%d: '%s' (hipIpcGetMemHandle, 20 attempts)\n", file, line, hipGetErrorString(e));
+    exit(EXIT_FAILURE);
 }
 
 extern "C" void d_free_space(void* d_ptr)
