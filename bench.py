@@ -356,6 +356,12 @@ def main():
     prof = pipe.profile_read()
     pipe.profile_end()
     prof = {op: (ms - warm.get(op, (0.0, 0))[0], cnt - warm.get(op, (0.0, 0))[1]) for op, (ms, cnt) in prof.items()}
+    err_bits = 0                              # LG_ERR_* bits a kernel raised for any lane (table full, feature rows, chain)
+    for row in pipe.pools:
+        for pl in row:
+            err_bits |= pl.error()
+    if err_bits:
+        raise RuntimeError(f"a kernel raised error bits {err_bits:#x} during the run (legion_core.h LG_ERR_*)")
 
     # ---- the same K steps once more with every group's sampler phase and gather phase on two streams (sampler k+1 runs
     #      under gathers k, pipeline.hip `split`): reported beside the headline as `overlapped`, not as `value`, because
