@@ -548,7 +548,9 @@ __global__ __launch_bounds__(LG_TILE) void sample_kernel(HopParams hp, const Lan
 // ------------------------------------------------------------------------------------------
 // K1b (lds form): de-duplication of a hop's claims, one workgroup per (bucket, lane), entirely in LDS.
 //   table word = [ vertex : 32 | pending : 1 | value : 31 ], empty = all ones, ordered linear probing with atomicMin.
-//   1. the batch's known vertices that hash into this bucket (sampled_ids[0 .. nodes so far)) go in with their position;
+//   1. the batch's known vertices that hash into this bucket go in with their position: the seeds from sampled_ids, the
+//      nodes earlier hops added from the bucket's list (list_known_kernel) -- or all of them from sampled_ids when the
+//      list outgrew its capacity;
 //   2. the bucket's claims go in as pending | slot: per vertex the lowest value survives -- a known position beats any
 //      slot, a lower slot beats a higher one;
 //   3. every claim looks its vertex up: the claim that IS the surviving word is a first touch and stays unmarked; every
@@ -556,7 +558,8 @@ __global__ __launch_bounds__(LG_TILE) void sample_kernel(HopParams hp, const Lan
 //      the atomics of the other two forms leave (here the chain of losers always has length one).
 // A bucket whose vertices cannot fit the table is processed in P passes over sub-buckets (further hash bits), so the
 // result never depends on how the hash spreads the batch.  Nothing survives the hop: nothing to clear, no state that
-// scales with the graph.
+// scales with the graph.  The claims arrive as one segment per partition tile of the sampling kernel (run_off); a
+// workgroup addresses claim k of its bucket through the prefix of the segment lengths.
 // ------------------------------------------------------------------------------------------
 #ifndef LG_LDS_FILL_16THS
 #define LG_LDS_FILL_16THS 14         // a pass may fill its table up to this many sixteenths (bound: known + claims of the pass)
