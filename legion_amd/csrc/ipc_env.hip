@@ -164,20 +164,15 @@ public:
         semr_[device_id].resize(pipeline_depth);
         semw_[device_id].resize(pipeline_depth);
         for (int32_t i = 0; i < pipeline_depth; i++) {
-            void* new_ids = d_alloc_space((int64_t)num_ids * sizeof(int32_t));
-            void* new_labels = d_alloc_space((int64_t)batch_size * sizeof(int32_t));
-            void* new_agg_src = d_alloc_space((int64_t)num_ids * sizeof(int32_t));
-            void* new_agg_dst = d_alloc_space((int64_t)num_ids * sizeof(int32_t));
-            void* new_node_counter = d_alloc_space(16 * sizeof(int32_t));
-            void* new_edge_counter = d_alloc_space(16 * sizeof(int32_t));
+            auto slot = [&](int k) { return (void*)&shm_->memHandle[device_id][i][k]; };
+            void* new_ids = lg_alloc_exported((int64_t)num_ids * sizeof(int32_t), slot(0), __FILE__, __LINE__);
+            void* new_labels = lg_alloc_exported((int64_t)batch_size * sizeof(int32_t), slot(2), __FILE__, __LINE__);
+            void* new_agg_src = lg_alloc_exported((int64_t)num_ids * sizeof(int32_t), slot(3), __FILE__, __LINE__);
+            void* new_agg_dst = lg_alloc_exported((int64_t)num_ids * sizeof(int32_t), slot(4), __FILE__, __LINE__);
+            void* new_node_counter = lg_alloc_exported(16 * sizeof(int32_t), slot(5), __FILE__, __LINE__);
+            void* new_edge_counter = lg_alloc_exported(16 * sizeof(int32_t), slot(6), __FILE__, __LINE__);
             HIP_CALL(hipMemset(new_node_counter, 0, 64));
             HIP_CALL(hipMemset(new_edge_counter, 0, 64));
-            lg_ipc_export((void*)&shm_->memHandle[device_id][i][0], new_ids, __FILE__, __LINE__);
-            lg_ipc_export((void*)&shm_->memHandle[device_id][i][2], new_labels, __FILE__, __LINE__);
-            lg_ipc_export((void*)&shm_->memHandle[device_id][i][3], new_agg_src, __FILE__, __LINE__);
-            lg_ipc_export((void*)&shm_->memHandle[device_id][i][4], new_agg_dst, __FILE__, __LINE__);
-            lg_ipc_export((void*)&shm_->memHandle[device_id][i][5], new_node_counter, __FILE__, __LINE__);
-            lg_ipc_export((void*)&shm_->memHandle[device_id][i][6], new_edge_counter, __FILE__, __LINE__);
             ids_[device_id].push_back(new_ids);
             labels_[device_id].push_back(new_labels);
             agg_src_[device_id].push_back(new_agg_src);
@@ -213,8 +208,8 @@ public:
         (void)batch_size;
         SetGPUDevice(device_id);
         for (int32_t i = 0; i < pipeline_depth; i++) {
-            void* new_features = d_alloc_space((int64_t)num_ids * feature_dim * sizeof(float));
-            lg_ipc_export((void*)&shm_->memHandle[device_id][i][1], new_features, __FILE__, __LINE__);
+            void* new_features = lg_alloc_exported((int64_t)num_ids * feature_dim * sizeof(float),
+                                                   (void*)&shm_->memHandle[device_id][i][1], __FILE__, __LINE__);
             float_features_[device_id].push_back(new_features);
         }
     }

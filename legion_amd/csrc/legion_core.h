@@ -624,6 +624,7 @@ extern "C" int32_t GetGPUDevice();
 // hipIpcGetMemHandle with a few retries: on this pool's driver (dmabuf IPC) an export now and then fails with
 // 'invalid argument' for a fresh, valid allocation and succeeds a moment later; a persistent failure is fatal as before
 void lg_ipc_export(void* handle64, void* dev_ptr, const char* file, int line);
+void* lg_alloc_exported(int64_t num_bytes, void* handle64, const char* file, int line);   // fresh buffer + its handle; tries other blocks
 
 // ---------------------------------------------------------------------------------------------
 // kernel launchers (kernels_*.hip)

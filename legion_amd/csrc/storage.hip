@@ -10,6 +10,7 @@
 // pinned memory otherwise.  Nothing here assumes which.
 #include "legion_core.h"
 #include <unistd.h>
+#include <algorithm>
 
 #include <cstring>
 
@@ -55,16 +56,56 @@ extern "C" void* d_alloc_space(int64_t num_bytes)
     return ret;
 }
 
-void lg_ipc_export(void* handle64, void* dev_ptr, const char* file, int line)
+static bool lg_ipc_try_export(void* handle64, void* dev_ptr, int attempts, hipError_t* last)
 {
-    hipError_t e = hipSuccess;
-    for (int attempt = 0; attempt < 20; attempt++) {
-        e = hipIpcGetMemHandle((hipIpcMemHandle_t*)handle64, dev_ptr);
-        if (e == hipSuccess) return;
+    for (int attempt = 0; attempt < attempts; attempt++) {
+        *last = hipIpcGetMemHandle((hipIpcMemHandle_t*)handle64, dev_ptr);
+        if (*last == hipSuccess) return true;
         (void)hipGetLastError();
         usleep(25000);
     }
-    printf("HIP failure %s:%d: '%s' (hipIpcGetMemHandle, 20 attempts)\n", file, line, hipGetErrorString(e));
+    return false;
+}
+
+static void lg_ipc_diagnose(void* dev_ptr, hipError_t e, const char* file, int line)
+{
+    hipPointerAttribute_t at;
+    memset(&at, 0, sizeof(at));
+    const hipError_t pe = hipPointerGetAttributes(&at, dev_ptr);
+    (void)hipGetLastError();
+    const char* legacy = getenv("HSA_ENABLE_IPC_MODE_LEGACY");
+    printf("HIP failure %s:%d: '%s' (hipIpcGetMemHandle of %p; attributes %s: device %d, type %d, base %p; "
+           "HSA_ENABLE_IPC_MODE_LEGACY=%s)\n", file, line, hipGetErrorString(e), dev_ptr, hipGetErrorString(pe), at.device,
+           (int)at.type, at.devicePointer, legacy ? legacy : "(unset)");
+    fflush(stdout);
+}
+
+void lg_ipc_export(void* handle64, void* dev_ptr, const char* file, int line)
+{
+    hipError_t e = hipSuccess;
+    if (lg_ipc_try_export(handle64, dev_ptr, 20, &e)) return;
+    lg_ipc_diagnose(dev_ptr, e, file, line);
+    exit(EXIT_FAILURE);
+}
+
+// A fresh device buffer together with its IPC handle.  About one server start in a hundred on this pool (ROCm 7.2, dmabuf
+// IPC) finds EVERY small block of the process unexportable ('invalid argument', pointer attributes fine, mode variable
+// set) while other starts export the same sizes without trouble -- small allocations are fragments of a shared runtime
+// block there.  A block that keeps failing is set aside (not freed: the allocator would hand it out again) and a block of
+// its own (>= 2 MiB, not a fragment) is tried instead.
+void* lg_alloc_exported(int64_t num_bytes, void* handle64, const char* file, int line)
+{
+    hipError_t e = hipSuccess;
+    void* p = nullptr;
+    for (int block = 0; block < 4; block++) {
+        const int64_t bytes = block == 0 ? num_bytes : std::max<int64_t>(num_bytes, ((int64_t)2 << 20) * block + 4096);
+        p = d_alloc_space(bytes);
+        if (lg_ipc_try_export(handle64, p, block == 0 ? 3 : 6, &e)) {
+            if (block > 0) { printf("legion_hip: IPC export succeeded with a block of %lld bytes\n", (long long)bytes); fflush(stdout); }
+            return p;
+        }
+        lg_ipc_diagnose(p, e, file, line);
+    }
     exit(EXIT_FAILURE);
 }
 

@@ -12,6 +12,7 @@ import pytest
 
 from legion_amd import synth
 from oracle import ffi
+from tests.server_proc import start_server
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -36,7 +37,8 @@ def write_dataset(path, wl_indptr, wl_col, feats, labels, train, valid, test):
     {"LEGION_RUNNER_GRAPH": "0"},                              # the reference's operator-by-operator Runner
     {"LEGION_NO_SHM_MIRROR": "1"},                             # counters copied from the device, as the reference's trainer end does
     {"LEGION_RUNNER_LANES": "5", "LEGION_RUNNER_HO_STREAM": "0"},   # hand-overs on the sampler's own stream
-], ids=["default", "lanes3", "lanes4-table", "lanes1", "operators", "no-mirror", "lanes5-one-stream"])
+    {"LEGION_RUNNER_LANES": "6", "LEGION_RUNNER_HO_STREAM": "1"},   # one hand-over stream for both pipe slots
+], ids=["default", "lanes3", "lanes4-table", "lanes1", "operators", "no-mirror", "lanes5-one-stream", "lanes6-shared-ho-stream"])
 def test_server_binary_serves_fake_trainer(hip, tmp_path, server_env, monkeypatch):
     import torch
     for k, v in server_env.items():
@@ -60,16 +62,9 @@ def test_server_binary_serves_fake_trainer(hip, tmp_path, server_env, monkeypatc
     ns = f"_t{os.getpid()}"
     monkeypatch.setenv("LEGION_IPC_NAMESPACE", ns)
     env = dict(os.environ)
-    log = open(work / "server.log", "w")
-    server = subprocess.Popen([os.path.join(ROOT, "legion_amd", "bin", "sampling_server"), "1", "0"] +
-                              [str(f) for f in fanout], cwd=work, env=env, stdout=log, stderr=subprocess.STDOUT)
+    server, log = start_server([os.path.join(ROOT, "legion_amd", "bin", "sampling_server"), "1", "0"] + [str(f) for f in fanout],
+                               work, env, work / "server.log")
     try:
-        deadline = time.time() + 400      # a cold box pages the ROCm libraries in first
-        while "System is ready for serving" not in open(work / "server.log").read():
-            assert server.poll() is None, open(work / "server.log").read()
-            assert time.time() < deadline, "server did not become ready"
-            time.sleep(0.1)
-
         # ---- oracle replay of the whole server life: PreSC -> cache -> schedule ------------------
         g = ffi.OracleGraph(1, indptr, col)
         st = ffi.Steps()

@@ -17,6 +17,7 @@ import pytest
 
 from tests.gpu_harness import CpuSide
 from tests.helpers import Workload
+from tests.server_proc import start_server
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -99,16 +100,10 @@ def test_one_server_process_two_gpus_thread_per_gpu(hip, tmp_path, partition_fil
         ds, B, N, wl.col.size, D, train.size, valid.size, test.size, cache_memory, epoch))
     ns = f"_m{os.getpid()}"
     env = dict(os.environ, LEGION_IPC_NAMESPACE=ns)
-    log = open(work / "server.log", "w")
-    server = subprocess.Popen([os.path.join(ROOT, "legion_amd", "bin", "sampling_server"), "2", "1"] + [str(f) for f in fanout],
-                              cwd=work, env=env, stdout=log, stderr=subprocess.STDOUT, stdin=subprocess.DEVNULL)
+    server, log = start_server([os.path.join(ROOT, "legion_amd", "bin", "sampling_server"), "2", "1"] + [str(f) for f in fanout],
+                               work, env, work / "server.log")
     trainers = []
     try:
-        deadline = time.time() + 400
-        while "System is ready for serving" not in open(work / "server.log").read():
-            assert server.poll() is None, open(work / "server.log").read()
-            assert time.time() < deadline, "server did not become ready"
-            time.sleep(0.1)
         for dev in range(2):
             trainers.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "fake_trainer.py"), str(dev), str(D),
                                               str(epoch), str(tmp_path / f"t{dev}.npz")], env=env, cwd=ROOT,

@@ -45,16 +45,11 @@ def test_graphsage_learns_a_neighbour_only_task_through_the_boundary(hip, tmp_pa
         ds, B, N, col.size, D, train.size, valid.size, test.size, 100_000, epoch))
     ns = f"_g{os.getpid()}"
     env = dict(os.environ, LEGION_IPC_NAMESPACE=ns)
-    log = open(work / "server.log", "w")
-    server = subprocess.Popen([os.path.join(ROOT, "legion_amd", "bin", "sampling_server"), "1", "0"] + [str(f) for f in fanout],
-                              cwd=work, env=env, stdout=log, stderr=subprocess.STDOUT, stdin=subprocess.DEVNULL)
+    from tests.server_proc import start_server
+    server, log = start_server([os.path.join(ROOT, "legion_amd", "bin", "sampling_server"), "1", "0"] + [str(f) for f in fanout],
+                               work, env, work / "server.log")
     trainer = None
     try:
-        deadline = time.time() + 300
-        while "System is ready for serving" not in open(work / "server.log").read():
-            assert server.poll() is None, open(work / "server.log").read()
-            assert time.time() < deadline, "server did not become ready"
-            time.sleep(0.1)
         report = tmp_path / "report.json"
         trainer = subprocess.Popen([sys.executable, os.path.join(ROOT, "examples", "graphsage_torch.py"), "--device", "0",
                                     "--features_num", str(D), "--hidden_dim", "32", "--class_num", str(C), "--hops_num", "2",
