@@ -87,11 +87,11 @@
 // (vertex, pending | slot) -- and writes, for every claim that is not the lowest slot of a new vertex, the same loser
 // mark the other forms leave.  No per-vertex state survives the hop, nothing to clear, nothing that scales with N.  A
 // bucket whose vertices do not fit the table is handled in several passes over sub-buckets, so the result never depends
-// on the hash.  Used for hops of up to 2^24 slots per lane (every shape of legion_server.py; beyond: the atomics forms).
+// on the hash.  Used for hops of up to 2^25 slots per lane (every shape of legion_server.py; beyond: the atomics forms).
 // Buckets per lane and the partition tile follow the pool's largest hop, so that a bucket sees at most ~64 k slots and
 // a bucket's share of a partition tile stays a few sectors long: 8 buckets / 1024-slot tiles up to 2^19 slots per lane
-// (B = 1024-class batches), 64 / 8192 up to 2^22 (B = 8000 with [25,10]), 256 / 32768 up to 2^24 (B = 8000 with
-// [15,10,5]); at most 1024 partition tiles per hop.  The kernels are instantiated for the three classes.
+// (B = 1024-class batches), 64 / 8192 up to 2^22 (B = 8000 with [25,10]), 256 up to 2^25 (B = 8000 with [15,10,5] has 6 M,
+// with [25,10,10] 20 M); at most 1024 partition tiles per hop.  The kernels are instantiated for the three classes.
 #define LG_LDS_BITS_SMALL 3
 #define LG_LDS_BITS_MEDIUM 6
 #define LG_LDS_BITS_LARGE 8
@@ -104,7 +104,7 @@
 #define LG_LDS_TABLE_BITS 13
 #endif
 #define LG_LDS_TABLE (1 << LG_LDS_TABLE_BITS)   // 64-bit words of LDS per (lane, bucket) workgroup
-#define LG_LDS_MAX_SLOTS (1 << 24)
+#define LG_LDS_MAX_SLOTS (1 << 25)
 #define LG_POS_VALUE_BITS_MIN 16
 #define LG_POS_VALUE_BITS_MAX 28
 struct PosFmt {

@@ -367,11 +367,11 @@ def test_lds_dedup_known_lists(hip, monkeypatch, known_cap):
 
 
 @pytest.mark.parametrize("part_wg", [None, "1", "100000000"], ids=["default-tiles", "largest-tiles", "smallest-tiles"])
-@pytest.mark.parametrize("batch,fanout", [(6000, [10, 10]), (5000, [5, 5, 5]), (6000, [10, 10, 8])],
-                         ids=["b6000-10x10-64buckets", "b5000-5x5x5-64buckets", "b6000-10x10x8-256buckets"])
+@pytest.mark.parametrize("batch,fanout", [(6000, [10, 10]), (5000, [5, 5, 5]), (6000, [10, 10, 8]), (8000, [13, 13, 13])],
+                         ids=["b6000-10x10-64buckets", "b5000-5x5x5-64buckets", "b6000-10x10x8-256buckets", "b8000-13x13x13-17Mslots"])
 def test_lds_dedup_large_batches(hip, monkeypatch, batch, fanout, part_wg):
     """LDS form for hops of more than 2^19 slots per lane (Legion's default B = 8000 class): 64 buckets per lane and
-    partition tiles of 8 super tiles up to 2^22 slots, 256 buckets and 32 super tiles beyond (here 4.8 M slots); the
+    partition tiles of 8 super tiles up to 2^22 slots, 256 buckets and 32 super tiles beyond (here 4.8 M and 17.6 M slots); the
     sampling kernel places the pairs in a second sweep; bit-exact like the 8-bucket form."""
     monkeypatch.setenv("LEGION_DEDUP", "lds")
     if part_wg is not None:                              # partition tiles of 8 / 32 super tiles, or as few as the hop allows
