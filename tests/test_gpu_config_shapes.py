@@ -178,7 +178,8 @@ def test_config4_shape_2pow28_vertices(hip):
     groups + hipGraph.  D = 128 here: the 256-wide table of 2^28 rows is 275 GB and exists only striped over
     eight GPUs; D = 256 at B = 8000 is covered by test_config4_shape_oracle_replay and the config-3 full-size
     case.  What this run pins down is everything that scales with N: int32 ids up to 2^28, int64 row starts up
-    to 2^30, the position state in BOTH forms (1 GB per lane as a direct array, 128 MB as a compact table)."""
+    to 2^30, the first-touch state in ALL THREE forms (1 GB per lane as a direct array, 128 MB as a compact table, nothing
+    per vertex in the LDS form -- 256 buckets per lane at this batch size -- which is what `auto` picks here)."""
     import os
     scale, D, fanout, batch, group = 28, 128, [15, 10, 5], 8000, 4
     N = 1 << scale
@@ -204,14 +205,15 @@ def test_config4_shape_2pow28_vertices(hip):
     pool.close()
     deg = indptr[1:] - indptr[:-1]
     seen = {}
-    for form in ("direct", "table"):
+    for form in ("direct", "table", "lds"):
         os.environ["LEGION_DEDUP"] = form
         try:
             pipe = engine.Pipeline(graph, feature, cache, 0, batch, fanout, group, rows, True, 2)
         finally:
             del os.environ["LEGION_DEDUP"]
-        assert pipe.pools[0][0].uses_table() == (form == "table")
-        assert pipe.pools[0][0].state_bytes() == (N * 4 if form == "direct" else (1 << 24) * 8)
+        assert pipe.pools[0][0].uses_table() == (form == "table") and pipe.pools[0][0].dedup_form() == form
+        if form != "lds":
+            assert pipe.pools[0][0].state_bytes() == (N * 4 if form == "direct" else (1 << 24) * 8)
         for c0 in (0, group):
             slot = pipe.submit(c0)
             pipe.wait(slot)
@@ -220,7 +222,7 @@ def test_config4_shape_2pow28_vertices(hip):
                 n, e, nc, ec = _check_lane(pl, seeds[(c0 + lane) * batch:(c0 + lane + 1) * batch], indptr, col, deg, fanout, D, rows)
                 key = (c0, lane)
                 sig = (n, e, int(pl.buffer("sampled_ids")[:n].long().sum()), int(pl.buffer("agg_src_off")[:e].long().sum()))
-                assert seen.setdefault(key, sig) == sig                 # both forms produce the same batch
+                assert seen.setdefault(key, sig) == sig                 # every form produces the same batch
                 assert int(pl.buffer("sampled_ids")[:n].max()) > N // 2
         pipe.close()
     cache.close(); feature.close(); graph.close()
