@@ -93,8 +93,12 @@
 // (B = 1024-class batches), 64 / 8192 up to 2^22 (B = 8000 with [25,10]), 256 up to 2^25 (B = 8000 with [15,10,5] has 6 M,
 // with [25,10,10] 20 M); at most 1024 partition tiles per hop.  The kernels are instantiated for the three classes.
 #define LG_LDS_BITS_SMALL 3
+#ifndef LG_LDS_BITS_MEDIUM
 #define LG_LDS_BITS_MEDIUM 6
+#endif
+#ifndef LG_LDS_BITS_LARGE
 #define LG_LDS_BITS_LARGE 8
+#endif
 #define LG_LDS_K_MEDIUM 8                       // super tiles (1024 slots) per partition tile
 #define LG_LDS_K_LARGE 32
 #define LG_LDS_SLOTS_SMALL (1 << 19)
