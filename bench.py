@@ -79,6 +79,10 @@ def parse_args():
     ap.add_argument("--capacity", type=str, default="",
                     help="NODE,EDGE: cache capacities per GPU set by hand after the cost model has run (its choice is logged): e.g. a "
                          "topology cache of the EDGE hottest vertices' adjacency beside a pinned-host CSR (SURVEY section 8 N1)")
+    ap.add_argument("--no-cache", action="store_true",
+                    help="experiment: no feature/topology cache at all (no FillUp): every row comes from the full table and the "
+                         "gather makes no node_map lookup -- what the lookup's 128-byte line per row costs the gather")
+    ap.add_argument("--gather-rows", type=int, default=0, help="experiment: rows per gather workgroup (LegionTuning.gather_rows_per_wg)")
     ap.add_argument("--no-verify", action="store_true")
     ap.add_argument("--no-overlap-leg", action="store_true",
                     help="skip the extra timed region with sampler and gather phases overlapped on two streams")
@@ -153,6 +157,8 @@ def main():
     # ---- workload, resident in HBM --------------------------------------------------------------
     if args.dedup != "auto":
         os.environ["LEGION_DEDUP"] = args.dedup
+    if args.gather_rows > 0:
+        os.environ["LEGION_GATHER_ROWS"] = str(args.gather_rows)
     indptr, col = synth.rmat_csr_device(args.scale, args.edge_factor, 20231, dev, scramble=args.scramble)
     torch.cuda.empty_cache()
     pinned = []
@@ -242,7 +248,8 @@ def main():
         cache.cost_model(feature, graph, counters, train_step)
         if args.capacity:
             cache.set_capacity(*[int(x) for x in args.capacity.split(",")])
-        cache.fill_up(feature, graph)
+        if not args.no_cache:
+            cache.fill_up(feature, graph)
     feature_rows = int(max_ids * 1.2)                                        # server.cu:277
     pool.close()
     weave = not (args.no_weave or args.split or args.overlap)
@@ -258,7 +265,7 @@ def main():
     hop_edges = np.zeros((n_timed, H), dtype=np.int64)
     hop_slots = np.zeros((n_timed, H), dtype=np.int64)
     hits = 0
-    node_map = cache.array("node_map", d) if cache.node_capacity(d) > 0 else torch.empty(0, dtype=torch.int32, device=dev)
+    node_map = cache.array("node_map", d) if (cache.node_capacity(d) > 0 and not args.no_cache) else torch.empty(0, dtype=torch.int32, device=dev)
     feat_hit_rows = feat_miss_rows = 0           # over every timed batch (all hops)
     for k in range(n_timed):
         if k % G == 0:

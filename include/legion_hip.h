@@ -137,6 +137,8 @@ int32_t legion_cache_replica_rows(const LegionUnifiedCache* c, int32_t dev_id);
 /* Enables row-source statistics of the gathers on dev_id (Kg > 1) and returns the totals so far:
  * out2[0] rows read through a stripe pointer (own or peer), out2[1] rows read from the local replica. */
 void legion_cache_gather_stats(LegionUnifiedCache* c, int32_t dev_id, uint64_t* out2);
+/* same with out3[2] = the part of out3[0] that came from ANOTHER member's stripe (over xGMI between physical GPUs) */
+void legion_cache_gather_stats3(LegionUnifiedCache* c, int32_t dev_id, uint64_t* out3);
 /* SS/cache/cache.cu:360-443.  Hotness is summed over the clique on the clique leader through
  * peer pointers (one process, several GPUs); when `world_reduced` is non-zero the caller has
  * already all-reduced the counters across processes with RCCL and they are used as they are. */
@@ -284,6 +286,23 @@ int32_t legion_pool_profile_end(LegionMemoryPool* p, float* out_ms, int32_t* out
  * of the Intel-PCM PCIe counters that feed CostModel in the paper: SS/engine/server.cu:105-110, SS/engine/monitor.cuh).
  * Returns 1 and fills the two totals, or 0 when the table is missing / has an unknown revision.  Host-only. */
 int32_t legion_link_counters(int32_t dev_id, uint64_t* pcie_bytes, uint64_t* xgmi_bytes);
+/* The same table in full: PCIe total, xGMI bytes READ and WRITTEN by this GPU in total and per link (8 links; 7 populated
+ * on an 8-GPU MI355X node), the table revision that was found (known: 1.8) and the GPU's PCI bus id.  CostModel's second
+ * counter (counters[1]) is fed with the xGMI bytes the clique's members READ during the PreSC epoch / 64
+ * (SS/engine/server.cu:105-106: the two PCM counters are summed into "transactions of topology", cache.cu:459). */
+typedef struct LegionLinkCounters {
+    uint64_t pcie_bytes;
+    uint64_t xgmi_read_bytes, xgmi_write_bytes;
+    uint64_t xgmi_read_bytes_link[8], xgmi_write_bytes_link[8];
+    int32_t format_revision, content_revision;
+    char pci_bus_id[32];
+} LegionLinkCounters;
+int32_t legion_link_counters_ex(int32_t dev_id, LegionLinkCounters* out);
+/* 64-byte transactions the gathers of dev_id have so far read from OTHER members' stripes of a striped feature cache
+ * (rows read through a peer's pointer x row bytes / 64; enables the row-source statistics like
+ * legion_cache_gather_stats).  The computed stand-in for the xGMI counter where the driver's table is unavailable or
+ * cannot move (one physical GPU). */
+uint64_t legion_cache_peer_transactions(LegionUnifiedCache* c, int32_t dev_id);
 
 /* =====================================================================================
  * 5. Synthetic workload generators (RMAT + counter-hash features); device side.
@@ -309,6 +328,43 @@ void legion_host_free(void* host_ptr);
  * Call once before creating any object (bench.py passes LOCAL_RANK). */
 void legion_set_device_base(int32_t base);
 int32_t legion_get_device_base(void);
+
+/* =====================================================================================
+ * 6. Tuning.  Every switch that changes how the path runs (never what it computes) lives in ONE
+ *    struct.  The library keeps one process-wide copy; it is (re)filled from the LEGION_* environment
+ *    variables named below by legion_tuning_from_env(), which the library itself calls whenever a
+ *    MemoryPool, a Pipeline or a Server is created -- never inside a launch path.  A host program may
+ *    instead fill the struct and call legion_tuning_set(): values set that way are kept (the
+ *    environment is then only read again after legion_tuning_from_env() is called explicitly).
+ *    No reference counterpart (the reference has compile-time constants only, system_config.cuh).
+ *    Not tuning and therefore still plain environment: LEGION_IPC_NAMESPACE, LEGION_IPC_LOCAL,
+ *    LEGION_IPC_DEVICE (deployment: which shm names / which GPU a trainer attaches to).
+ * ===================================================================================== */
+typedef struct LegionTuning {
+    int32_t dedup_form;          /* LEGION_DEDUP=auto|direct|table|lds -> -1|0|1|2.  auto: lds when the pool's largest hop has
+                                    <= 2^25 slots, else direct while N*4 B x lanes in flight fit a quarter of HBM, else table */
+    int32_t pos_value_bits;      /* LEGION_POS_VALUE_BITS  (0): minimum width of the position-state value field (tests) */
+    int32_t pos_table_bits;      /* LEGION_POS_TABLE_BITS  (0 = sized by num_ids): log2 words of the compact table (tests) */
+    int32_t lds_known_cap;       /* LEGION_LDS_KNOWN_CAP   (0 = 2 x an even share): entries per known-node list (tests) */
+    int32_t lds_part_wg;         /* LEGION_LDS_PART_WG     (8192): workgroups a partitioning sample launch aims for */
+    int32_t sample_max_wg;       /* LEGION_SAMPLE_MAX_WG   (4096): workgroup cap of the strided sampler grids */
+    int32_t gather_small_tiles;  /* LEGION_GATHER_SMALL_TILES (1): 16-row tiles for launches of fewer than 4096 tiles */
+    int32_t gather_rows_per_wg;  /* LEGION_GATHER_ROWS     (0 = by row width): rows per gather workgroup, 16|32|64|128|256 */
+    int32_t split_sampler_cus;   /* LEGION_SPLIT_SAMPLER_CUS (0 = no CU mask): CUs of the sampler stream in split mode */
+    int32_t split_priority;      /* LEGION_SPLIT_PRIORITY  (1): split mode, 1 sampler stream first, 0 equal, -1 gathers first */
+    int32_t runner_graph;        /* LEGION_RUNNER_GRAPH    (1): Runner serves from lane groups + hipGraph; 0 = operator by operator */
+    int32_t runner_lanes;        /* LEGION_RUNNER_LANES    (0 = min(128, 262144 / batch)): lanes of a Runner group */
+    int32_t runner_pair;         /* LEGION_RUNNER_PAIR     (1): one hand-over launch for two batches when both pipe slots are free */
+    int32_t runner_ho_stream;    /* LEGION_RUNNER_HO_STREAM (2): hand-over streams: 0 the sampler's, 1 one shared, 2 one per pipe slot */
+    int32_t runner_stats;        /* LEGION_RUNNER_STATS    (0): print where a hand-over's time went at Finalize */
+    int32_t table_placement;     /* LEGION_TABLE_PLACEMENT=hbm|pinned -> 0|1: where the server puts the full CSR / feature table */
+    int32_t shm_mirror;          /* LEGION_NO_SHM_MIRROR unset -> 1: counters also go to a host-visible mirror (no D2H copy per batch) */
+    int32_t link_counters;       /* LEGION_LINK_COUNTERS=v2|measured|smi|"a,b" -> 0|1|2|3: what feeds CostModel's counters */
+    uint64_t link_counter_values[2];   /* the injected pair of LEGION_LINK_COUNTERS="a,b" */
+} LegionTuning;
+void legion_tuning_from_env(void);
+void legion_tuning_get(LegionTuning* out);
+void legion_tuning_set(const LegionTuning* in);
 
 /* library / device info */
 const char* legion_version(void);

@@ -18,7 +18,7 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 ARCH = "gfx950"
 
 SOURCES = ["kernels_sample.hip", "kernels_gather.hip", "kernels_cache.hip", "kernels_synth.hip",
-           "storage.hip", "link_counters.hip", "cache.hip", "operators.hip", "pipeline.hip", "ipc_env.hip", "server.hip"]
+           "storage.hip", "tuning.hip", "link_counters.hip", "cache.hip", "operators.hip", "pipeline.hip", "ipc_env.hip", "server.hip"]
 FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-fno-fast-math", "-Wall",
          "-Wno-unused-result", "-Wno-unused-function"] + os.environ.get("LEGION_EXTRA_HIPCC_FLAGS", "").split()
 
@@ -77,7 +77,36 @@ def build_trainer(verbose=True, force=False):
     subprocess.check_call(cmd, cwd=tdir, env=env)
 
 
+def build_variant(name, extra_flags, verbose=True):
+    """liblegion_hip.so with other compile-time constants, for tuning sweeps:
+        python -m legion_amd.build --variant v16 -DLG_LDS_BUCKET_BITS=4 ...
+    -> tools/lds_tuning/variants/<name>/liblegion_hip.so (git-ignored; travels to the GPU box).  Select it at run time with
+    LEGION_HIP_LIB=<path> (legion_amd/lib.py); the library in place is never overwritten."""
+    out = os.path.join(HERE, "..", "tools", "lds_tuning", "variants", name)
+    os.makedirs(out, exist_ok=True)
+    objs, procs = [], []
+    for src in SOURCES:
+        o = os.path.join(out, src + ".o")
+        objs.append(o)
+        cmd = [HIPCC] + FLAGS + ["-w"] + list(extra_flags) + ["-c", os.path.join(CSRC, src), "-o", o]
+        procs.append((src, subprocess.Popen(cmd)))
+    failed = [src for src, p in procs if p.wait() != 0]
+    if failed:
+        raise RuntimeError(f"hipcc failed for {failed}")
+    lib = os.path.join(out, "liblegion_hip.so")
+    subprocess.check_call([HIPCC, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", lib] + objs + ["-lpthread", "-lrt"])
+    for o in objs:
+        os.unlink(o)
+    if verbose:
+        print(lib)
+    return lib
+
+
 if __name__ == "__main__":
+    if "--variant" in sys.argv:
+        i = sys.argv.index("--variant")
+        build_variant(sys.argv[i + 1], sys.argv[i + 2:])
+        sys.exit(0)
     build_lib(force="--force" in sys.argv)
     if "--trainer" in sys.argv:
         build_trainer()

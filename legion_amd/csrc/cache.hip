@@ -456,8 +456,8 @@ unsigned long long* UnifiedCache::GatherStats(int32_t dev_id)
     if ((int32_t)gather_stats_.size() < device_count_) gather_stats_.resize(device_count_, nullptr);
     if (gather_stats_[dev_id] == nullptr) {
         SetGPUDevice(dev_id);
-        gather_stats_[dev_id] = (unsigned long long*)d_alloc_space(2 * sizeof(unsigned long long));
-        HIP_CALL(hipMemset(gather_stats_[dev_id], 0, 2 * sizeof(unsigned long long)));
+        gather_stats_[dev_id] = (unsigned long long*)d_alloc_space(4 * sizeof(unsigned long long));
+        HIP_CALL(hipMemset(gather_stats_[dev_id], 0, 4 * sizeof(unsigned long long)));
     }
     return gather_stats_[dev_id];
 }
@@ -478,6 +478,7 @@ void UnifiedCache::FeatCacheLookup(const LanePtrs* d_lanes, int32_t n_lanes, int
     g.replica = (filled && dev_id < (int32_t)replica_.size()) ? replica_[dev_id] : nullptr;
     g.replica_rows = g.replica ? replica_rows_[dev_id] : 0;
     g.Kg = Kg_;
+    g.member = dev_id % (Kg_ > 0 ? Kg_ : 1);
     g.stats = (dev_id < (int32_t)gather_stats_.size()) ? gather_stats_[dev_id] : nullptr;
     g.full_table = cpu_float_features_;
     g.cache_tables = filled ? d_float_feature_cache_ptr_[dev_id] : nullptr;
@@ -521,6 +522,27 @@ extern "C" void legion_cache_gather_stats(LegionUnifiedCache* c, int32_t dev_id,
     HIP_CALL(hipDeviceSynchronize());
     HIP_CALL(hipMemcpy(h, d, sizeof(h), hipMemcpyDeviceToHost));
     if (out2) { out2[0] = h[0]; out2[1] = h[1]; }
+}
+
+extern "C" void legion_cache_gather_stats3(LegionUnifiedCache* c, int32_t dev_id, uint64_t* out3)
+{
+    UnifiedCache* u = as_cache(c);
+    if (!u) return;
+    unsigned long long* d = u->GatherStats(dev_id);
+    unsigned long long h[3] = {0, 0, 0};
+    HIP_CALL(hipDeviceSynchronize());
+    HIP_CALL(hipMemcpy(h, d, sizeof(h), hipMemcpyDeviceToHost));
+    if (out3) { out3[0] = h[0]; out3[1] = h[1]; out3[2] = h[2]; }
+}
+
+// rows read from other members' stripes so far, as 64-byte transactions (the unit of CostModel's counters)
+extern "C" uint64_t legion_cache_peer_transactions(LegionUnifiedCache* c, int32_t dev_id)
+{
+    UnifiedCache* u = as_cache(c);
+    if (!u) return 0;
+    uint64_t h[3] = {0, 0, 0};
+    legion_cache_gather_stats3(c, dev_id, h);
+    return h[2] * (uint64_t)u->FloatFeatureLen() * sizeof(float) / 64;
 }
 
 extern "C" LegionUnifiedCache* legion_cache_create(int64_t cache_memory, int32_t float_feature_len,

@@ -2,7 +2,7 @@
 //
 // Reference: SS/engine/ipc_service.cu (CUDAIPCEnv :33-349), SS/engine/helper_multiprocess.cu
 // (only sharedMemoryCreate/Open/Close are used).  The protocol is kept bit-for-bit:
-//   * POSIX shm "simpleIPCshm" = struct { int32 steps[3]; IpcMemHandle(64 B) memHandle[8][2][7]; }
+//   * POSIX shm "simpleIPCshm" = struct { int32 steps[3]; IpcMemHandle(64 B) memHandle[8][2][7]; }, exactly that size
 //     slot order: 0 ids, 1 features, 2 labels, 3 agg_src, 4 agg_dst, 5 node_counter, 6 edge_counter
 //   * named semaphores sem_r_<dev>_<pipe> (trainer -> server, buffer free) and
 //     sem_w_<dev>_<pipe> (server -> trainer, batch ready), created with value 0
@@ -24,21 +24,24 @@
 
 static_assert(sizeof(hipIpcMemHandle_t) == 64, "IPC handle size is part of the wire format");
 
-// The reference's slab (SS/engine/ipc_service.cu:28-31) is the PREFIX of this one, byte for byte: a trainer
-// built from the reference maps only that prefix.  Behind it this build publishes, per (device, pipe slot), the
-// 16 + 16 counters of the batch in that slot in HOST memory: the slab is registered with HIP and the GPU writes
-// them itself, so the trainer end needs no device-to-host copy per batch (the reference does two blocking
-// 64-byte cudaMemcpy per get_next, TB/ipc_cuda_kernel.cu:186-187).
+// The slab is the reference's, byte for byte and no larger (SS/engine/ipc_service.cu:28-31): a trainer built from the
+// reference opens it with shm_open + ftruncate(sizeof(its struct)) (TB/helper_multiprocess.cpp:30-37), which must not
+// change its size.  This build's extra -- per (device, pipe slot) the 16 + 16 counters of the batch in that slot in
+// HOST memory, so the trainer end needs no device-to-host copy per batch (the reference does two blocking 64-byte
+// cudaMemcpy per get_next, TB/ipc_cuda_kernel.cu:186-187) -- lives in a shm object of its own, "legionIPCext<suffix>":
+// registered with HIP, written by the GPU, opened by this build's ipc_service when it exists.
 #define LEGION_SHM_EXT_MAGIC 0x4C47494F   /* "LGIO" */
 typedef struct shmStruct_st {
     int32_t steps[3];
     hipIpcMemHandle_t memHandle[MAX_DEVICE][INTERBATCH_CON][MEMORY_USAGE];
+} shmStruct;
+static_assert(offsetof(shmStruct, memHandle) == 12 && sizeof(shmStruct) == 12 + MAX_DEVICE * INTERBATCH_CON * MEMORY_USAGE * 64,
+              "the reference's slab layout is the wire format");
+typedef struct shmExt_st {
     int32_t ext_magic;                                         // LEGION_SHM_EXT_MAGIC once the mirror below is live
     int32_t ext_reserved[3];
     int32_t counters[MAX_DEVICE][INTERBATCH_CON][32];          // [0..15] node_counter, [16..31] edge_counter
-} shmStruct;
-static_assert(offsetof(shmStruct, memHandle) == 12 && offsetof(shmStruct, ext_magic) == 12 + MAX_DEVICE * INTERBATCH_CON * MEMORY_USAGE * 64,
-              "the reference's slab layout is the wire format");
+} shmExt;
 
 typedef struct sharedMemoryInfo_st {
     void* addr;
@@ -86,18 +89,27 @@ public:
             }
             shm_ = (volatile shmStruct*)info_.addr;
             memset((void*)shm_, 0, sizeof(*shm_));
-            // let the GPUs write the per-slot counter mirror straight into the slab
-            if (!getenv("LEGION_NO_SHM_MIRROR") &&
-                hipHostRegister(info_.addr, sizeof(shmStruct), hipHostRegisterPortable | hipHostRegisterMapped) == hipSuccess) {
-                void* dptr = nullptr;
-                if (hipHostGetDevicePointer(&dptr, info_.addr, 0) == hipSuccess && dptr != nullptr) {
-                    shm_dev_ = (shmStruct*)dptr;
-                    registered_ = true;
-                } else {
-                    (void)hipHostUnregister(info_.addr);
+            // the counter mirror: a shm object of its own that the GPUs write straight into
+            ext_info_.addr = nullptr;
+            ext_info_.shmFd = -1;
+            ext_name_ = std::string("legionIPCext") + ipc_suffix();
+            if (lg::tuning().shm_mirror && sharedMemoryCreate(ext_name_.c_str(), sizeof(shmExt), &ext_info_) == 0) {
+                ext_ = (volatile shmExt*)ext_info_.addr;
+                memset((void*)ext_, 0, sizeof(shmExt));
+                if (hipHostRegister(ext_info_.addr, sizeof(shmExt), hipHostRegisterPortable | hipHostRegisterMapped) == hipSuccess) {
+                    void* dptr = nullptr;
+                    if (hipHostGetDevicePointer(&dptr, ext_info_.addr, 0) == hipSuccess && dptr != nullptr) {
+                        ext_dev_ = (shmExt*)dptr;
+                        registered_ = true;
+                    } else {
+                        (void)hipHostUnregister(ext_info_.addr);
+                    }
                 }
+                (void)hipGetLastError();
+            } else {
+                shm_unlink(ext_name_.c_str());      // no mirror: never leave an older run's object for a trainer to find
+                ext_name_.clear();
             }
-            (void)hipGetLastError();
         } else {
             local_ = new shmStruct();
             memset(local_, 0, sizeof(*local_));
@@ -259,9 +271,9 @@ public:
     // registered (then the trainer end falls back to copying the counters from the device buffers)
     int32_t* GetCounterMirror(int32_t d, int32_t p) override
     {
-        return shm_dev_ ? &shm_dev_->counters[d][p % pipeline_depth_][0] : nullptr;
+        return ext_dev_ ? &ext_dev_->counters[d][p % pipeline_depth_][0] : nullptr;
     }
-    void PublishMirror() override { if (shm_dev_) shm_->ext_magic = LEGION_SHM_EXT_MAGIC; }
+    void PublishMirror() override { if (ext_dev_) ext_->ext_magic = LEGION_SHM_EXT_MAGIC; }
     bool IPCTryWait(int32_t dev_id, int32_t current_pipe) override { return sem_trywait(semr_[dev_id][current_pipe]) == 0; }
 
     void IPCPost(int32_t dev_id, int32_t current_pipe) override { sem_post(semw_[dev_id][current_pipe]); }
@@ -295,11 +307,16 @@ public:
             delete local_;
             local_ = nullptr;
         } else {
-            if (registered_) (void)hipHostUnregister(info_.addr);
+            if (registered_) (void)hipHostUnregister(ext_info_.addr);
             registered_ = false;
-            shm_dev_ = nullptr;
+            ext_dev_ = nullptr;
+            ext_ = nullptr;
             sharedMemoryClose(&info_);
             if (!shm_name_.empty()) shm_unlink(shm_name_.c_str());
+            if (!ext_name_.empty()) {
+                sharedMemoryClose(&ext_info_);
+                shm_unlink(ext_name_.c_str());
+            }
         }
         shm_ = nullptr;
     }
@@ -308,11 +325,12 @@ public:
 
 private:
     volatile shmStruct* shm_ = nullptr;
-    shmStruct* shm_dev_ = nullptr;      // the slab as the GPUs see it (registered host memory)
+    volatile shmExt* ext_ = nullptr;    // the counter mirror (its own shm object) ...
+    shmExt* ext_dev_ = nullptr;         // ... as the GPUs see it (registered host memory)
     bool registered_ = false;
     shmStruct* local_ = nullptr;
-    sharedMemoryInfo info_;
-    std::string shm_name_;
+    sharedMemoryInfo info_, ext_info_ = {nullptr, 0, -1};
+    std::string shm_name_, ext_name_;
     std::vector<std::vector<void*>> ids_, float_features_, labels_, agg_src_, agg_dst_, node_counter_, edge_counter_;
     std::vector<std::vector<sem_t*>> semr_, semw_;
     int32_t raw_batch_size_ = 0;

@@ -148,8 +148,10 @@ __global__ __launch_bounds__(LG_GATHER_THREADS) void gather_kernel(GatherParams 
                 p = LG_GPTR(const float, gp.replica) + rank * D;
             else
                 p = LG_GPTR(const float, gp.cache_tables[didx]) + (int64_t)fidx * D;                               // :268
-            if (gp.stats != nullptr && gp.Kg > 1)      // tests / diagnostics: [0] rows read through a stripe pointer, [1] from the replica
-                atomicAdd(gp.stats + (local_copy ? 1 : 0), 1ull);
+            if (gp.stats != nullptr && gp.Kg > 1) {    // tests / diagnostics / the computed xGMI count: [0] rows read through a stripe
+                atomicAdd(gp.stats + (local_copy ? 1 : 0), 1ull);   // pointer, [1] from the replica, [2] the part of [0] from a peer's stripe
+                if (!local_copy && didx != gp.member) atomicAdd(gp.stats + 2, 1ull);
+            }
         }
         s_ptr[t] = p;
     }
@@ -189,23 +191,35 @@ __global__ __launch_bounds__(LG_GATHER_THREADS) void gather_kernel(GatherParams 
     }
 }
 
+template <int ROWS>
+static void launch_gather_v4(hipStream_t s, const GatherParams& g, const LanePtrs* d_lanes, int32_t n_lanes, bool copy_range)
+{
+    typedef float v4 __attribute__((ext_vector_type(4)));
+    const dim3 grid((g.max_rows + ROWS - 1) / ROWS, n_lanes);
+    gather_kernel<v4, ROWS><<<grid, LG_GATHER_THREADS, 0, s>>>(g, d_lanes, copy_range);
+}
+
 static void launch_gather_impl(hipStream_t s, GatherParams g, const LanePtrs* d_lanes, int32_t n_lanes, bool copy_range)
 {
     if (g.D <= 0 || g.max_rows <= 0) return;            // :256 float_feature_len > 0
     if (g.node_capacity < 1) g.node_capacity = 1;
     const dim3 grid((g.max_rows + LG_GATHER_ROWS - 1) / LG_GATHER_ROWS, n_lanes);
-    typedef float v4 __attribute__((ext_vector_type(4)));
     typedef float v2 __attribute__((ext_vector_type(2)));
-    // a launch of one or a few lanes (the Runner's per-batch hand-over) has too few 64-row tiles to keep 256 CUs
-    // busy: 16-row tiles give it 4 x the workgroups (a full lane group is indifferent to the tile size)
-    constexpr int kSmallRows = 16;
-    const int env_small = [] { const char* e = getenv("LEGION_GATHER_SMALL_TILES"); return e ? atoi(e) : 1; }();
-    if (g.D % 4 == 0 && env_small && (int64_t)grid.x * n_lanes < 4096) {
-        const dim3 grid_s((g.max_rows + kSmallRows - 1) / kSmallRows, n_lanes);
-        gather_kernel<v4, kSmallRows><<<grid_s, LG_GATHER_THREADS, 0, s>>>(g, d_lanes, copy_range);
-    } else if (g.D % 4 == 0)
-        gather_kernel<v4><<<grid, LG_GATHER_THREADS, 0, s>>>(g, d_lanes, copy_range);
-    else if (g.D % 2 == 0)
+    const LegionTuning& tune = tuning();
+    if (g.D % 4 == 0) {
+        // rows per workgroup (LegionTuning.gather_rows_per_wg; 0 = the default below).  A launch of one or a few lanes (the
+        // Runner's per-batch hand-over) has too few 64-row tiles to keep 256 CUs busy: 16-row tiles give it 4 x the
+        // workgroups; a full lane group is indifferent to the tile size at D = 128
+        int rows = tune.gather_rows_per_wg;
+        if (rows <= 0) rows = (tune.gather_small_tiles && (int64_t)grid.x * n_lanes < 4096) ? 16 : LG_GATHER_ROWS;
+        switch (rows) {
+            case 16: launch_gather_v4<16>(s, g, d_lanes, n_lanes, copy_range); break;
+            case 32: launch_gather_v4<32>(s, g, d_lanes, n_lanes, copy_range); break;
+            case 128: launch_gather_v4<128>(s, g, d_lanes, n_lanes, copy_range); break;
+            case 256: launch_gather_v4<256>(s, g, d_lanes, n_lanes, copy_range); break;
+            default: launch_gather_v4<64>(s, g, d_lanes, n_lanes, copy_range); break;
+        }
+    } else if (g.D % 2 == 0)
         gather_kernel<v2><<<grid, LG_GATHER_THREADS, 0, s>>>(g, d_lanes, copy_range);
     else
         gather_kernel<float><<<grid, LG_GATHER_THREADS, 0, s>>>(g, d_lanes, copy_range);

@@ -1006,7 +1006,7 @@ void launch_random_sample(hipStream_t s, const HopParams& p, const LanePtrs* d_l
     int32_t max_super = (p.max_slots + LG_SUPER - 1) / LG_SUPER;
     if (max_super < 1) max_super = 1;
     int32_t gx = max_super < 1024 ? max_super : 1024;
-    static const int max_wg = [] { const char* e = getenv("LEGION_SAMPLE_MAX_WG"); return e ? atoi(e) : 4096; }();
+    const int max_wg = tuning().sample_max_wg;
     while (gx > 64 && (int64_t)gx * n_lanes > max_wg) gx /= 2;  // keep the whole launch near 2 x resident capacity
     while (gx > 1 && (int64_t)gx * n_lanes > max_wg && max_wg < 4096) gx /= 2;   // (experiments with fewer workgroups)
     const dim3 grid(gx, n_lanes);
@@ -1019,8 +1019,7 @@ void launch_random_sample(hipStream_t s, const HopParams& p, const LanePtrs* d_l
         int32_t k_lo = p.lds_bucket_bits == LG_LDS_BITS_LARGE ? 4 : 1;
         while (max_super > LG_LDS_MAX_PARTS * k_lo) k_lo *= 2;
         int32_t k = k_hi > k_lo ? k_hi : k_lo;
-        const char* want_env = getenv("LEGION_LDS_PART_WG");        // (read per launch: tests vary it inside one process)
-        const int want_wg = want_env ? atoi(want_env) : 8192;
+        const int want_wg = tuning().lds_part_wg;
         while (k > k_lo && (int64_t)(max_super / k) * n_lanes < want_wg) k /= 2;
         q.lds_k = k;
         int32_t gp = (max_super + k - 1) / k;                  // one workgroup per partition tile ...

@@ -476,7 +476,8 @@ public:
     // peer over xGMI.  Set before FillUp.
     void SetReplicaMemory(int64_t bytes) { replica_bytes_ = bytes; }
     int32_t ReplicaRows(int32_t dev_id) const { return replica_rows_.empty() ? 0 : replica_rows_[dev_id]; }
-    unsigned long long* GatherStats(int32_t dev_id);   // device {peer rows, replica rows}, allocated on first use
+    int32_t FloatFeatureLen() const { return float_feature_len_; }
+    unsigned long long* GatherStats(int32_t dev_id);   // device {stripe rows, replica rows, peer-stripe rows}, allocated on first use
     int32_t MaxIdNum(int32_t dev_id);
     unsigned long long int* GetEdgeAccessedMap(int32_t dev_id);
     // the gather over a group of lanes (the reference's per-array arguments live in LanePtrs)
@@ -634,6 +635,12 @@ void* lg_alloc_exported(int64_t num_bytes, void* handle64, const char* file, int
 // kernel launchers (kernels_*.hip)
 namespace lg {
 
+// the process-wide LegionTuning (include/legion_hip.h section 6, tuning.hip): launch paths read it here, nothing else
+// parses LEGION_* tuning variables.  tuning_refresh() re-reads the environment (unless a host program installed its own
+// values with legion_tuning_set); pools, pipelines and servers call it when they are created.
+const LegionTuning& tuning();
+void tuning_refresh();
+
 struct HopParams {                  // what every lane of a launch shares
     int32_t op_id;
     int32_t count;                  // fan-out of this hop
@@ -665,7 +672,8 @@ struct GatherParams {
     const float* replica;           // local copy of the clique's `replica_rows` hottest rows (hotness rank order), or null
     int32_t replica_rows;
     int32_t Kg;                     // GPUs per clique: rank t of a hit = (g % cap) * Kg + g / cap
-    unsigned long long* stats;      // optional {rows served from a peer's stripe, rows served from the local replica}
+    int32_t member;                 // this GPU's index inside its clique (dev_id % Kg)
+    unsigned long long* stats;      // optional {rows read through a stripe pointer, rows from the local replica, rows from a PEER's stripe}
     const float* const* cache_tables;
     const int32_t* node_map;
     int32_t node_capacity;

@@ -310,6 +310,7 @@ extern "C" void legion_gather_rows(legion_stream_t stream, const float* full_tab
     g.replica = nullptr;
     g.replica_rows = 0;
     g.Kg = 1;
+    g.member = 0;
     g.stats = nullptr;
     g.full_table = full_table;
     g.cache_tables = cache_tables;

@@ -98,14 +98,14 @@ extern "C" LegionPipeline* legion_pipeline_create(LegionGraphStorage* graph, Leg
     if (p->weave) p->split = false;
     if (p->split) p->overlap = false;
     SetGPUDevice(dev_id);
+    lg::tuning_refresh();
     // split mode with a CU partition (LEGION_SPLIT_SAMPLER_CUS = n): the sampler stream may only use n of the 256 CUs
     // (every (256/n)-th bit of the mask), the gather stream the others.  The sampler is bound by the latency of scattered
     // atomics, not by CUs; the gather needs every wave slot it can get to keep ~12 MB of loads in flight.
     if (p->weave) HIP_CALL(hipStreamCreateWithFlags(&p->sample_stream, hipStreamNonBlocking));
     std::vector<uint32_t> mask_s, mask_g;
     if (p->split) {
-        const char* ce = getenv("LEGION_SPLIT_SAMPLER_CUS");
-        const int n_cu = ce ? atoi(ce) : 0;
+        const int n_cu = lg::tuning().split_sampler_cus;
         if (n_cu > 0 && n_cu < 256) {
             hipDeviceProp_t prop;
             HIP_CALL(hipGetDeviceProperties(&prop, GetGPUDevice()));
@@ -120,8 +120,7 @@ extern "C" LegionPipeline* legion_pipeline_create(LegionGraphStorage* graph, Leg
         }
         int lo = 0, hi = 0;                                  // hi is the numerically lowest = highest priority
         HIP_CALL(hipDeviceGetStreamPriorityRange(&lo, &hi));
-        const char* pe = getenv("LEGION_SPLIT_PRIORITY");
-        const int prio = pe ? atoi(pe) : 1;                  // 1: sampler first, 0: equal, -1: gathers first
+        const int prio = lg::tuning().split_priority;        // 1: sampler first, 0: equal, -1: gathers first
         if (!mask_s.empty())
             HIP_CALL(hipExtStreamCreateWithCUMask(&p->sample_stream, (uint32_t)mask_s.size(), mask_s.data()))
         else
@@ -202,6 +201,21 @@ static hipGraphExec_t graph_of(LegionPipeline* p, Slot& sl, hipStream_t strm, in
     return it->second;
 }
 
+// A batch larger than the lanes were created for cannot be served: shrinking it silently would drop part of a validation
+// or test set (their batches are sized from a raw 512, SS/engine/ipc_service.cu:91-115, whatever the training batch is)
+// while the schedule's step counts stay the same.  The owner must size the pipeline for the largest batch of any mode
+// (GPURunner::Initialize does); anything else is a bug and ends the process like every other error here.
+static int32_t checked_batch_size(const LegionPipeline* p, int32_t batch_size)
+{
+    if (batch_size < 1) return p->batch_size;            // "the pipeline's own"
+    if (batch_size > p->batch_size) {
+        printf("legion_hip: batch size %d exceeds the %d the pipeline's lanes were created for\n", batch_size, p->batch_size);
+        fflush(stdout);
+        exit(EXIT_FAILURE);
+    }
+    return batch_size;
+}
+
 // Captures and instantiates, on EVERY slot, the graph(s) a later submit of (mode, n_active, batch_size) will replay, without
 // launching anything.  A server calls this for every group shape of its schedule before it starts serving: stream capture
 // and graph instantiation then never run beside another thread's HIP calls (GPURunner's poster polls events; a capture
@@ -210,7 +224,7 @@ extern "C" void legion_pipeline_prepare(LegionPipeline* p, int32_t mode, int32_t
 {
     if (!p || !p->use_graph) return;
     if (n_active < 1 || n_active > p->group_size) n_active = p->group_size;
-    if (batch_size < 1 || batch_size > p->batch_size) batch_size = p->batch_size;
+    batch_size = checked_batch_size(p, batch_size);
     SetGPUDevice(p->dev_id);
     const int32_t first_phase = (p->split || p->sample_only) ? LG_PHASE_SAMPLE : LG_PHASE_ALL;
     for (Slot& sl : p->slots) {
@@ -253,7 +267,7 @@ extern "C" int32_t legion_pipeline_submit_ex(LegionPipeline* p, int32_t counter0
 {
     if (!p) { printf("invalid pipeline ptr\n"); return -1; }
     if (n_active < 1 || n_active > p->group_size) n_active = p->group_size;
-    if (batch_size < 1 || batch_size > p->batch_size) batch_size = p->batch_size;
+    batch_size = checked_batch_size(p, batch_size);
     SetGPUDevice(p->dev_id);
     const int32_t si = p->rr;
     p->rr = (p->rr + 1) % p->slots_n;

@@ -279,11 +279,7 @@ public:
     IPCEnv* GetIPCEnv() { return env_; }
 
 private:
-    static bool want_hbm()
-    {
-        const char* p = getenv("LEGION_TABLE_PLACEMENT");   // "hbm" (default) | "pinned"
-        return !(p && strcmp(p, "pinned") == 0);
-    }
+    static bool want_hbm() { return lg::tuning().table_placement == 0; }   // LegionTuning: "hbm" (default) | "pinned"
     std::string dataset_path_;
     int32_t raw_batch_size_ = 0, node_num_ = 0, float_feature_len_ = 0;
     int64_t edge_num_ = 0, cache_memory_ = 0;
@@ -388,6 +384,9 @@ public:
     // SS/engine/server.cu:275-283
     void InitializeFeaturesBuffer(RunnerParams* params) override
     {
+        SetGPUDevice(local_dev_id_);
+        HIP_CALL(hipDeviceSynchronize());
+        ReportErrors(memorypool_);          // a PreSC epoch over corrupt batches would size the caches from garbage: stop here
         UnifiedCache* cache = (UnifiedCache*)(params->cache);
         int32_t num_ids = int32_t((cache->MaxIdNum(local_dev_id_)) * 1.2);
         // MaxIdNum was measured on training batches; validation/test batches can be larger than the
@@ -591,6 +590,14 @@ private:
         if (bits & LG_ERR_TABLE_FULL) std::cout << "ERROR (gpu " << local_dev_id_ << "): position table overflow\n";
         if (bits & LG_ERR_CHAIN) std::cout << "ERROR (gpu " << local_dev_id_ << "): unresolved first-touch chain\n";
         std::cout << std::flush;
+        // A full table or an unresolved chain means positions in this batch are garbage: it must not reach a trainer.
+        // Same convention as every other device-side failure at this boundary (include/legion_hip.h, the reference's
+        // cudaCheckError): say what happened and end the process -- the caller is about to IPCPost.  A truncated feature
+        // buffer (above) stays a warning: ids, edges and the rows that fit are correct.
+        if (bits & (LG_ERR_TABLE_FULL | LG_ERR_CHAIN)) {
+            std::cout << "legion_hip: corrupt batch on gpu " << local_dev_id_ << ", not posted; stopping the server\n" << std::flush;
+            _exit(EXIT_FAILURE);     // (from the poster thread too: no destructors, the trainer sees the server gone)
+        }
     }
 
     // G internal lanes x 2 groups in flight + the hand-over descriptors of every (group slot, lane, pipe slot)
@@ -601,19 +608,20 @@ private:
         max_step_ = env->GetMaxStep();
         std::vector<int32_t> fanout(params->fanout.begin(), params->fanout.end());
         lanes_ = std::max(1, std::min(128, 262144 / std::max(1, memorypool_->batch_size)));
-        if (const char* e = getenv("LEGION_RUNNER_LANES")) lanes_ = std::max(1, atoi(e));
+        if (lg::tuning().runner_lanes > 0) lanes_ = lg::tuning().runner_lanes;
         // use_graph bits: 1 graph replay, 8 sampler phase only (the gathers go straight into the pipe slots)
         pipe_ = legion_pipeline_create((LegionGraphStorage*)params->graph, (LegionFeatureStorage*)params->feature,
                                        (LegionUnifiedCache*)params->cache, local_dev_id_, memorypool_->batch_size,
                                        fanout.data(), hop_num_, lanes_, 2, 0, 1 | 8);
-        if (!(getenv("LEGION_RUNNER_HO_STREAM") && atoi(getenv("LEGION_RUNNER_HO_STREAM")) == 0)) {
+        const int32_t ho_mode = lg::tuning().runner_ho_stream;    // 0 the sampler's stream, 1 one shared, 2 one per pipe slot
+        if (ho_mode != 0) {
             int lo = 0, hi = 0;
             HIP_CALL(hipDeviceGetStreamPriorityRange(&lo, &hi));
             HIP_CALL(hipStreamCreateWithPriority(&ho_streams_[0], hipStreamNonBlocking, hi));
             // one stream per pipe slot: the two hand-overs in flight then overlap on the GPU (the tail of one small launch
             // under the head of the next) instead of queueing -- 57.9 k against 47.9 k batches/s at B = 1024, 15.5 k against
-            // 13.2 k at B = 8000 (LEGION_RUNNER_HO_STREAM=1: one stream for both)
-            if (getenv("LEGION_RUNNER_HO_STREAM") && atoi(getenv("LEGION_RUNNER_HO_STREAM")) == 1)
+            // 13.2 k at B = 8000 (runner_ho_stream = 1: one stream for both)
+            if (ho_mode == 1)
                 ho_streams_[1] = ho_streams_[0];
             else
                 HIP_CALL(hipStreamCreateWithPriority(&ho_streams_[1], hipStreamNonBlocking, hi));
@@ -726,7 +734,7 @@ private:
     std::vector<hipEvent_t> events_;
     std::vector<Operator*> op_factory_;
     std::vector<OpParams*> op_params_;
-    bool use_groups_ = [] { const char* e = getenv("LEGION_RUNNER_GRAPH"); return e == nullptr || atoi(e) != 0; }();
+    bool use_groups_ = lg::tuning().runner_graph != 0;
     // lane groups
     LegionPipeline* pipe_ = nullptr;
     int32_t lanes_ = 1, hop_num_ = 0, max_step_ = 0;
@@ -747,9 +755,9 @@ private:
     hipEvent_t ho_done_[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};   // [pipeline slot][stream]: behind the group's last hand-over
     bool ho_done_valid_[2] = {false, false};
     int submit_count_ = 0;
-    bool pair_ = !(getenv("LEGION_RUNNER_PAIR") && atoi(getenv("LEGION_RUNNER_PAIR")) == 0);
+    bool pair_ = lg::tuning().runner_pair != 0;
     int64_t st_pairs_ = 0;
-    bool stats_ = getenv("LEGION_RUNNER_STATS") != nullptr;
+    bool stats_ = lg::tuning().runner_stats != 0;
     double st_wait_ = 0, st_launch_ = 0, st_gpu_ = 0;
     int64_t st_n_ = 0;
 };
@@ -779,6 +787,7 @@ public:
     void Initialize(int global_shard_count, std::vector<int> fanout, int in_memory_mode) override
     {
         shard_count_ = global_shard_count;
+        lg::tuning_refresh();           // the environment as it is when the server starts (or what the host program installed)
         if (in_memory_mode) std::cout << "In Memory Mode\n";
         else std::cout << "In Disk Mode\n";
         StorageManagement* storage_management = new StorageManagement();
@@ -812,45 +821,54 @@ public:
     void PreSc(int cache_agg_mode) override
     {
         std::chrono::steady_clock::time_point t1 = std::chrono::steady_clock::now();
-        const char* lc_mode = getenv("LEGION_LINK_COUNTERS");
-        const bool use_smi = lc_mode && strcmp(lc_mode, "smi") == 0;
-        uint64_t pcie_before = 0, pcie_after = 0;
-        bool smi_ok = use_smi;
-        if (use_smi) smi_ok = ReadPcieBytes(pcie_before);
+        const LegionTuning& tune = lg::tuning();
+        const bool use_smi = tune.link_counters == 2;
+        LinkTotals before, after;
+        if (use_smi && !ReadLinkTotals(before, true)) {
+            // the link's own counters were asked for: a table this build cannot decode is an error, not a reason to
+            // quietly size the caches from something else
+            std::cout << "legion_hip: LEGION_LINK_COUNTERS=smi but the driver's gpu_metrics table is missing or has an unknown "
+                         "revision (known: 1.8); use LEGION_LINK_COUNTERS=measured for the counts the kernels compute\n" << std::flush;
+            exit(EXIT_FAILURE);
+        }
         std::vector<std::thread> pool;
         for (int i = 0; i < shard_count_; i++) pool.emplace_back(&PreSCLoop, train_step_, runners_[i], params_[i]);
         for (auto& th : pool) th.join();
-        if (smi_ok) {
+        if (use_smi) {
             for (int i = 0; i < shard_count_; i++) { SetGPUDevice(i); HIP_CALL(hipDeviceSynchronize()); }
             std::this_thread::sleep_for(std::chrono::milliseconds(20));   // the table is refreshed every millisecond or so
-            smi_ok = ReadPcieBytes(pcie_after);
+            if (!ReadLinkTotals(after, false)) { std::cout << "legion_hip: gpu_metrics table vanished during PreSC\n" << std::flush; exit(EXIT_FAILURE); }
         }
-        // PCIe/xGMI transaction counters of the PreSC epoch (Intel PCM in the paper, hard-wired to
-        // {0,0} in v2, server.cu:105-106).  LEGION_LINK_COUNTERS="a,b" injects values;
-        // LEGION_LINK_COUNTERS=measured uses what the sampler itself counted during this epoch
-        // (legion_cache_topo_transactions: 64-byte transactions of the topology reads, summed over the GPUs).
+        // PCIe/xGMI transaction counters of the PreSC epoch (Intel PCM in the paper, hard-wired to {0,0} in v2,
+        // server.cu:105-106; CostModel sums the two into "transactions of topology", cache.cu:459).  LegionTuning.link_counters:
+        //   v2       {0, 0}
+        //   smi      [0] what the PCIe links of the server's GPUs carried during the epoch, [1] what those GPUs READ over
+        //            their xGMI links, both in 64-byte transactions from the driver's cumulative counters (link_counters.hip)
+        //   measured [0] the 64-byte topology transactions the sampler itself counted (legion_cache_topo_transactions),
+        //            [1] the rows the gathers read from other members' stripes x row bytes / 64
+        //            (legion_cache_peer_transactions; 0 in a fresh server -- PreSC runs no gathers -- non-zero when the
+        //            cost model is re-run over a served epoch through the C API)
+        //   "a,b"    injected values
         std::vector<uint64_t> counters(2, 0);
-        if (const char* lc = getenv("LEGION_LINK_COUNTERS")) {
-            unsigned long long a = 0, b = 0;
-            if (use_smi && smi_ok) {
-                // LEGION_LINK_COUNTERS=smi: what the PCIe link actually carried during the PreSC epoch, in 64-byte
-                // transactions, from the driver's cumulative counter (link_counters.hip) -- the paper's PCM reading
-                counters[0] = (pcie_after - pcie_before) / 64;
-                std::cout << "PCIe transactions (gpu_metrics): " << counters[0] << "\n";
-            } else if (strcmp(lc, "measured") == 0 || use_smi) {
-                if (use_smi) std::cout << "gpu_metrics link counters unavailable: using the sampler's own count\n";
-                for (int i = 0; i < shard_count_; i++) {
-                    unsigned long long v = 0;
-                    SetGPUDevice(i);
-                    HIP_CALL(hipDeviceSynchronize());
-                    HIP_CALL(hipMemcpy(&v, cache_->Controller(i)->GetTopoTransactions(), sizeof(v), hipMemcpyDeviceToHost));
-                    counters[0] += v;
-                }
-                std::cout << "Topology transactions: " << counters[0] << "\n";
-            } else if (sscanf(lc, "%llu,%llu", &a, &b) == 2) {
-                counters[0] = a;
-                counters[1] = b;
+        if (use_smi) {
+            counters[0] = (after.pcie - before.pcie) / 64;
+            counters[1] = (after.xgmi_read - before.xgmi_read) / 64;
+            std::cout << "PCIe transactions (gpu_metrics): " << counters[0] << "\n";
+            std::cout << "xGMI read transactions (gpu_metrics): " << counters[1] << "\n";
+        } else if (tune.link_counters == 1) {
+            for (int i = 0; i < shard_count_; i++) {
+                unsigned long long v = 0;
+                SetGPUDevice(i);
+                HIP_CALL(hipDeviceSynchronize());
+                HIP_CALL(hipMemcpy(&v, cache_->Controller(i)->GetTopoTransactions(), sizeof(v), hipMemcpyDeviceToHost));
+                counters[0] += v;
+                counters[1] += legion_cache_peer_transactions((LegionUnifiedCache*)cache_, i);
             }
+            std::cout << "Topology transactions: " << counters[0] << "\n";
+            std::cout << "Peer-stripe transactions: " << counters[1] << "\n";
+        } else if (tune.link_counters == 3) {
+            counters[0] = tune.link_counter_values[0];
+            counters[1] = tune.link_counter_values[1];
         }
         double t = std::chrono::duration_cast<std::chrono::duration<double>>(std::chrono::steady_clock::now() - t1).count();
         cache_->CandidateSelection(cache_agg_mode, feature_, graph_);
@@ -864,15 +882,21 @@ public:
         std::cout << "System is ready for serving\n" << std::flush;
     }
 
-    // sum of the cumulative PCIe byte counters of the (distinct physical) GPUs this server drives
-    bool ReadPcieBytes(uint64_t& total)
+    // sums of the cumulative link counters of the (distinct physical) GPUs this server drives
+    struct LinkTotals { uint64_t pcie = 0, xgmi_read = 0; };
+    bool ReadLinkTotals(LinkTotals& t, bool log)
     {
-        total = 0;
+        t = LinkTotals();
         const int physical = std::max(1, legion_device_count());
         for (int i = 0; i < std::min(shard_count_, physical); i++) {
-            uint64_t p = 0, x = 0;
-            if (!legion_link_counters(i, &p, &x)) return false;
-            total += p;
+            LegionLinkCounters c;
+            const int32_t ok = legion_link_counters_ex(i, &c);
+            if (log)
+                std::cout << "gpu_metrics of gpu " << i << " (" << c.pci_bus_id << "): revision " << c.format_revision << "."
+                          << c.content_revision << (ok ? "" : " -- not a layout this build knows") << "\n";
+            if (!ok) return false;
+            t.pcie += c.pcie_bytes;
+            t.xgmi_read += c.xgmi_read_bytes;
         }
         return true;
     }

@@ -492,11 +492,10 @@ void lg_set_pool_lanes_hint(int32_t lanes) { g_pool_lanes_hint = lanes; }
 // 0 direct array, 1 table, 2 lds (legion_core.h)
 static int lg_dedup_form(int64_t total_num_nodes, int64_t max_slots)
 {
-    if (const char* e = getenv("LEGION_DEDUP")) {
-        if (strcmp(e, "table") == 0) return 1;
-        if (strcmp(e, "direct") == 0) return 0;
-        if (strcmp(e, "lds") == 0) return max_slots <= LG_LDS_MAX_SLOTS ? 2 : 1;
-    }
+    const int32_t want = lg::tuning().dedup_form;
+    if (want == 1) return 1;
+    if (want == 0) return 0;
+    if (want == 2) return max_slots <= LG_LDS_MAX_SLOTS ? 2 : 1;
     // auto: the LDS form wherever a hop's slots per lane allow it (no per-vertex state; measured against either atomics form:
     // +14 % edges/s at B = 1024 with 8 buckets per lane, +5.5 % at B = 8000 [25,10] with 64); otherwise the direct array
     // while it fits a quarter of HBM over all lanes in flight, else the table
@@ -517,11 +516,13 @@ void lg_pool_alloc_private(MemoryPool* mp, int32_t dev_id, int32_t total_num_nod
                            const int32_t* fanout, int32_t hop_num, int32_t float_feature_len)
 {
     SetGPUDevice(dev_id);
+    lg::tuning_refresh();
+    const LegionTuning& tune = lg::tuning();
     int64_t num_ids = batch_size, per = batch_size;         // server.cu:187-199
     mp->max_new.assign(1, batch_size);
     for (int i = 0; i < hop_num; i++) { per *= fanout[i]; num_ids += per; mp->max_new.push_back(per); }
     int32_t value_bits = LG_POS_VALUE_BITS_MIN;          // position-state format, see legion_core.h
-    if (const char* e = getenv("LEGION_POS_VALUE_BITS")) value_bits = std::max(value_bits, atoi(e));
+    value_bits = std::max(value_bits, tune.pos_value_bits);
     while (value_bits <= LG_POS_VALUE_BITS_MAX && (num_ids >> value_bits) != 0) value_bits++;
     if (value_bits > LG_POS_VALUE_BITS_MAX) {
         printf("legion_hip: batch %d with this fan-out needs %lld slots / %lld ids; limit is 2^%d\n", batch_size,
@@ -552,7 +553,7 @@ void lg_pool_alloc_private(MemoryPool* mp, int32_t dev_id, int32_t total_num_nod
         for (int i = 1; i < hop_num; i++) listed += mp->max_new[i];
         if (listed > 0) {
             mp->known_cap = (int32_t)(2 * ((listed + n_buckets - 1) / n_buckets) + 256);
-            if (const char* e = getenv("LEGION_LDS_KNOWN_CAP")) mp->known_cap = std::max(1, atoi(e));   // tests: force the scan
+            if (tune.lds_known_cap > 0) mp->known_cap = tune.lds_known_cap;   // tests: force the scan
             mp->known_pairs = (unsigned long long*)d_alloc_space(n_buckets * mp->known_cap * sizeof(unsigned long long));
             mp->known_cnt = (int32_t*)d_alloc_space(n_buckets * sizeof(int32_t));
             HIP_CALL(hipMemset(mp->known_cnt, 0, n_buckets * sizeof(int32_t)));
@@ -562,7 +563,7 @@ void lg_pool_alloc_private(MemoryPool* mp, int32_t dev_id, int32_t total_num_nod
         // compact form: at least 1.5 x the pool's worst-case id count, so a free word always exists
         uint32_t bits = 10;
         while (((int64_t)1 << bits) < num_ids + num_ids / 2) bits++;
-        if (const char* e = getenv("LEGION_POS_TABLE_BITS")) bits = (uint32_t)atoi(e);   // tests: force a crowded table
+        if (tune.pos_table_bits > 0) bits = (uint32_t)tune.pos_table_bits;   // tests: force a crowded table
         mp->pos_table_mask = (1u << bits) - 1u;
         mp->pos_table = (unsigned long long*)d_alloc_space(((int64_t)1 << bits) * sizeof(unsigned long long));
         HIP_CALL(hipMemset(mp->pos_table, 0xFF, ((size_t)1 << bits) * sizeof(unsigned long long)));

@@ -1,0 +1,113 @@
+// tuning.hip -- the one place where the LEGION_* tuning environment is parsed (include/legion_hip.h section 6).
+//
+// The reference has compile-time constants only (SS/include/system_config.cuh); this build grew run-time switches
+// while its kernels were measured.  They select HOW the path runs (which form of the first-touch state, tile counts,
+// stream layout of the Runner), never WHAT it computes -- every combination is parity-tested against the oracle.
+// The library keeps one process-wide LegionTuning; launch paths read it through lg::tuning() and never call getenv.
+#include "legion_core.h"
+
+#include <cstring>
+#include <mutex>
+
+namespace {
+LegionTuning g_tuning;
+bool g_tuning_valid = false;     // parsed at least once
+bool g_tuning_pinned = false;    // set programmatically: creation-time refreshes keep it
+std::mutex g_tuning_mu;
+
+int env_int(const char* name, int dflt)
+{
+    const char* e = getenv(name);
+    return (e && *e) ? atoi(e) : dflt;
+}
+
+void parse_env(LegionTuning& t)
+{
+    memset(&t, 0, sizeof(t));
+    t.dedup_form = -1;
+    if (const char* e = getenv("LEGION_DEDUP")) {
+        if (strcmp(e, "direct") == 0) t.dedup_form = 0;
+        else if (strcmp(e, "table") == 0) t.dedup_form = 1;
+        else if (strcmp(e, "lds") == 0) t.dedup_form = 2;
+        else if (strcmp(e, "auto") != 0 && *e) {
+            printf("legion_hip: LEGION_DEDUP=%s is not one of auto|direct|table|lds\n", e);
+            exit(EXIT_FAILURE);
+        }
+    }
+    t.pos_value_bits = env_int("LEGION_POS_VALUE_BITS", 0);
+    t.pos_table_bits = env_int("LEGION_POS_TABLE_BITS", 0);
+    t.lds_known_cap = env_int("LEGION_LDS_KNOWN_CAP", 0);
+    t.lds_part_wg = env_int("LEGION_LDS_PART_WG", 8192);
+    t.sample_max_wg = env_int("LEGION_SAMPLE_MAX_WG", 4096);
+    t.gather_small_tiles = env_int("LEGION_GATHER_SMALL_TILES", 1);
+    t.gather_rows_per_wg = env_int("LEGION_GATHER_ROWS", 0);
+    t.split_sampler_cus = env_int("LEGION_SPLIT_SAMPLER_CUS", 0);
+    t.split_priority = env_int("LEGION_SPLIT_PRIORITY", 1);
+    t.runner_graph = env_int("LEGION_RUNNER_GRAPH", 1);
+    t.runner_lanes = env_int("LEGION_RUNNER_LANES", 0);
+    t.runner_pair = env_int("LEGION_RUNNER_PAIR", 1);
+    t.runner_ho_stream = env_int("LEGION_RUNNER_HO_STREAM", 2);
+    t.runner_stats = getenv("LEGION_RUNNER_STATS") != nullptr ? 1 : 0;
+    t.table_placement = 0;
+    if (const char* e = getenv("LEGION_TABLE_PLACEMENT")) t.table_placement = strcmp(e, "pinned") == 0 ? 1 : 0;
+    t.shm_mirror = getenv("LEGION_NO_SHM_MIRROR") != nullptr ? 0 : 1;
+    t.link_counters = 0;
+    if (const char* e = getenv("LEGION_LINK_COUNTERS")) {
+        unsigned long long a = 0, b = 0;
+        if (strcmp(e, "measured") == 0) t.link_counters = 1;
+        else if (strcmp(e, "smi") == 0) t.link_counters = 2;
+        else if (sscanf(e, "%llu,%llu", &a, &b) == 2) {
+            t.link_counters = 3;
+            t.link_counter_values[0] = a;
+            t.link_counter_values[1] = b;
+        } else if (strcmp(e, "v2") != 0 && *e) {
+            printf("legion_hip: LEGION_LINK_COUNTERS=%s is not one of v2|measured|smi|<a>,<b>\n", e);
+            exit(EXIT_FAILURE);
+        }
+    }
+}
+}  // namespace
+
+namespace lg {
+const LegionTuning& tuning()
+{
+    std::lock_guard<std::mutex> lk(g_tuning_mu);
+    if (!g_tuning_valid) {
+        parse_env(g_tuning);
+        g_tuning_valid = true;
+    }
+    return g_tuning;
+}
+
+// called where objects are created (pool, pipeline, server): the environment as it is NOW decides, unless a host program
+// installed its own values
+void tuning_refresh()
+{
+    std::lock_guard<std::mutex> lk(g_tuning_mu);
+    if (g_tuning_pinned) return;
+    parse_env(g_tuning);
+    g_tuning_valid = true;
+}
+}  // namespace lg
+
+extern "C" void legion_tuning_from_env(void)
+{
+    std::lock_guard<std::mutex> lk(g_tuning_mu);
+    parse_env(g_tuning);
+    g_tuning_valid = true;
+    g_tuning_pinned = false;
+}
+
+extern "C" void legion_tuning_get(LegionTuning* out)
+{
+    if (out) *out = lg::tuning();
+}
+
+extern "C" void legion_tuning_set(const LegionTuning* in)
+{
+    if (!in) return;
+    std::lock_guard<std::mutex> lk(g_tuning_mu);
+    g_tuning = *in;
+    g_tuning_valid = true;
+    g_tuning_pinned = true;
+}

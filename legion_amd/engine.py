@@ -61,6 +61,44 @@ def link_counters(dev_id=0):
     return (int(a.value), int(b.value)) if ok else None
 
 
+def link_counters_ex(dev_id=0):
+    """The whole table as a dict (legion_hip.h: LegionLinkCounters) plus 'supported': PCIe bytes, xGMI bytes read / written
+    in total and per link, the gpu_metrics revision found and the GPU's PCI bus id."""
+    c = _libmod.LinkCounters()
+    ok = _libmod.load().legion_link_counters_ex(int(dev_id), ctypes.byref(c))
+    return {"supported": bool(ok), "pcie_bytes": int(c.pcie_bytes), "xgmi_read_bytes": int(c.xgmi_read_bytes),
+            "xgmi_write_bytes": int(c.xgmi_write_bytes), "xgmi_read_bytes_link": [int(x) for x in c.xgmi_read_bytes_link],
+            "xgmi_write_bytes_link": [int(x) for x in c.xgmi_write_bytes_link],
+            "gpu_metrics_revision": f"{int(c.format_revision)}.{int(c.content_revision)}",
+            "pci_bus_id": c.pci_bus_id.decode(errors="replace")}
+
+
+def tuning():
+    """The library's current LegionTuning as a dict."""
+    t = _libmod.Tuning()
+    _libmod.load().legion_tuning_get(ctypes.byref(t))
+    return {n: (list(getattr(t, n)) if n == "link_counter_values" else int(getattr(t, n))) for n, _ in t._fields_}
+
+
+def set_tuning(**fields):
+    """Installs programmatic tuning values (kept until tuning_from_env() is called): set_tuning(dedup_form=1, ...)."""
+    t = _libmod.Tuning()
+    L = _libmod.load()
+    L.legion_tuning_get(ctypes.byref(t))
+    for k, v in fields.items():
+        if k == "link_counter_values":
+            t.link_counter_values[0], t.link_counter_values[1] = int(v[0]), int(v[1])
+        else:
+            if not hasattr(t, k):
+                raise KeyError(k)
+            setattr(t, k, int(v))
+    L.legion_tuning_set(ctypes.byref(t))
+
+
+def tuning_from_env():
+    _libmod.load().legion_tuning_from_env()
+
+
 def _torch_device(dev_id):
     base = int(_libmod.load().legion_get_device_base())
     return torch.device("cuda", (base + int(dev_id)) % max(torch.cuda.device_count(), 1))
@@ -377,6 +415,16 @@ class UnifiedCache:
         out = (ctypes.c_uint64 * 2)()
         self._lib.legion_cache_gather_stats(self.handle, int(dev_id), out)
         return int(out[0]), int(out[1])
+
+    def gather_stats3(self, dev_id=0):
+        """(rows through a stripe pointer, rows from the local replica, rows from a PEER's stripe) so far."""
+        out = (ctypes.c_uint64 * 3)()
+        self._lib.legion_cache_gather_stats3(self.handle, int(dev_id), out)
+        return int(out[0]), int(out[1]), int(out[2])
+
+    def peer_transactions(self, dev_id=0):
+        """64-byte transactions read from other members' stripes so far (the computed stand-in for the xGMI counter)."""
+        return int(self._lib.legion_cache_peer_transactions(self.handle, int(dev_id)))
 
     def set_capacity(self, node_capacity, edge_capacity):
         self._lib.legion_cache_set_capacity(self.handle, int(node_capacity), int(edge_capacity))

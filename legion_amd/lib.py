@@ -8,7 +8,9 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "liblegion_hip.so")
+# LEGION_HIP_LIB=<path>: load another build of the same library (tuning sweeps with other compile-time constants,
+# tools/lds_tuning/); the library in place is never replaced
+LIB_PATH = os.environ.get("LEGION_HIP_LIB") or os.path.join(_HERE, "liblegion_hip.so")
 
 c_i32, c_i64, c_u64 = ctypes.c_int32, ctypes.c_int64, ctypes.c_uint64
 c_p, c_bool = ctypes.c_void_p, ctypes.c_bool
@@ -105,6 +107,13 @@ SIGNATURES = {
     "legion_synth_features": (None, [c_p, c_p, c_i64, c_i64, c_i32, c_u64]),
     "legion_synth_feature_check": (None, [c_p, c_p, c_p, c_i64, c_i32, c_u64, c_p]),
     "legion_link_counters": (c_i32, [c_i32, P_U64, P_U64]),
+    "legion_link_counters_ex": (c_i32, [c_i32, c_p]),
+    "legion_cache_peer_transactions": (ctypes.c_uint64, [c_p, c_i32]),
+    "legion_cache_gather_stats3": (None, [c_p, c_i32, P_U64]),
+    # 6. tuning
+    "legion_tuning_from_env": (None, []),
+    "legion_tuning_get": (None, [c_p]),
+    "legion_tuning_set": (None, [c_p]),
     "legion_host_alloc": (c_p, [c_i64, ctypes.POINTER(c_p)]),
     "legion_host_free": (None, [c_p]),
     "legion_set_device_base": (None, [c_i32]),
@@ -112,6 +121,22 @@ SIGNATURES = {
     "legion_version": (ctypes.c_char_p, []),
     "legion_device_count": (c_i32, []),
 }
+
+
+
+class LinkCounters(ctypes.Structure):          # LegionLinkCounters
+    _fields_ = [("pcie_bytes", c_u64), ("xgmi_read_bytes", c_u64), ("xgmi_write_bytes", c_u64),
+                ("xgmi_read_bytes_link", c_u64 * 8), ("xgmi_write_bytes_link", c_u64 * 8),
+                ("format_revision", c_i32), ("content_revision", c_i32), ("pci_bus_id", ctypes.c_char * 32)]
+
+
+class Tuning(ctypes.Structure):                # LegionTuning (include/legion_hip.h section 6)
+    _fields_ = [(n, c_i32) for n in (
+        "dedup_form", "pos_value_bits", "pos_table_bits", "lds_known_cap", "lds_part_wg", "sample_max_wg",
+        "gather_small_tiles", "gather_rows_per_wg", "split_sampler_cus", "split_priority", "runner_graph", "runner_lanes",
+        "runner_pair", "runner_ho_stream", "runner_stats", "table_placement", "shm_mirror", "link_counters")] + \
+        [("link_counter_values", c_u64 * 2)]
+
 
 _lib = None
 

@@ -39,18 +39,20 @@
         }                                                                                     \
     }
 
-// The first two members are the reference's slab (TB/ipc_cuda_kernel.cu:30-33).  Behind them this build's server
-// publishes the counters of the batch in every (device, pipe slot) in host memory, written by the GPU before the
-// batch is posted: when ext_magic says so, get_next reads them there instead of making the reference's two blocking
-// 64-byte device-to-host copies per batch.
+// The slab is the reference's (TB/ipc_cuda_kernel.cu:30-33), same size.  This build's server also publishes, in a shm
+// object of its own ("legionIPCext<suffix>"), the counters of the batch in every (device, pipe slot) in host memory,
+// written by the GPU before the batch is posted: when that object exists and its magic says so, get_next reads them
+// there instead of making the reference's two blocking 64-byte device-to-host copies per batch.
 #define LEGION_SHM_EXT_MAGIC 0x4C47494F
 typedef struct shmStruct_st {
     int32_t steps[3];
     hipIpcMemHandle_t memHandle[MAX_DEVICE][INTERBATCH_CON][MEMORY_USAGE];
+} shmStruct;
+typedef struct shmExt_st {
     int32_t ext_magic;
     int32_t ext_reserved[3];
     int32_t counters[MAX_DEVICE][INTERBATCH_CON][32];
-} shmStruct;
+} shmExt;
 static_assert(sizeof(hipIpcMemHandle_t) == 64, "IPC handle size is part of the wire format");
 
 static std::string ipc_suffix()
@@ -72,7 +74,7 @@ public:
         if (const char* e = getenv("LEGION_IPC_DEVICE")) central_device = atoi(e);
         const std::string shm_name = std::string("simpleIPCshm") + ipc_suffix();
         int fd = shm_open(shm_name.c_str(), O_RDWR | O_CREAT, 0777);
-        if (fd < 0 || ftruncate(fd, sizeof(shmStruct)) != 0) {     // never shrinks the server's slab: same size
+        if (fd < 0 || ftruncate(fd, sizeof(shmStruct)) != 0) {     // the reference's call; the slab has exactly this size
             printf("Failed to create shared memory slab\n");
             exit(EXIT_FAILURE);
         }
@@ -129,12 +131,18 @@ public:
         current_pipe_ = 0;
         device_ = physical_device;
         slab_device_ = central_device;
-        if (shm->ext_magic == LEGION_SHM_EXT_MAGIC && !getenv("LEGION_NO_SHM_MIRROR")) {
-            mirror_ = shm;                                      // keep the slab mapped: counters are read from it
-        } else {
-            munmap(addr, sizeof(shmStruct));
-        }
+        munmap(addr, sizeof(shmStruct));
         close(fd);
+        if (!getenv("LEGION_NO_SHM_MIRROR")) {                  // this build's server: counters in host memory (never created here)
+            const std::string ext_name = std::string("legionIPCext") + ipc_suffix();
+            const int efd = shm_open(ext_name.c_str(), O_RDONLY, 0);
+            if (efd >= 0) {
+                void* ea = mmap(0, sizeof(shmExt), PROT_READ, MAP_SHARED, efd, 0);
+                if (ea != MAP_FAILED && ((volatile shmExt*)ea)->ext_magic == LEGION_SHM_EXT_MAGIC) mirror_ = (volatile shmExt*)ea;
+                else if (ea != MAP_FAILED) munmap(ea, sizeof(shmExt));
+                close(efd);
+            }
+        }
         return central_device;
     }
 
@@ -177,7 +185,7 @@ private:
     int current_pipe_ = 0;
     int device_ = 0;        // physical device the tensors live on
     int slab_device_ = 0;   // index of this trainer's GPU in the server's slab / semaphore names
-    volatile shmStruct* mirror_ = nullptr;
+    volatile shmExt* mirror_ = nullptr;
 };
 
 static GPUIPCEnv* env = nullptr;

@@ -179,6 +179,48 @@ def test_server_rejects_a_mismatched_dataset(hip, tmp_path, damage, needle):
     assert "System is ready for serving" not in res.stdout
 
 
+def test_server_stops_instead_of_posting_a_corrupt_batch(hip, tmp_path):
+    """Device-side corruption ends the server before IPCPost (include/legion_hip.h error convention; the reference's
+    cudaCheckError).  Forced here: the compact position table is held at 2^9 words (LEGION_POS_TABLE_BITS), enough for every
+    training batch (16 seeds, <= 336 ids) but not for the one validation batch (400 seeds, thousands of ids): the PreSC epoch
+    and the training batches are served, the validation batch raises LG_ERR_TABLE_FULL and the server exits non-zero without
+    posting it."""
+    scale, D, B, fanout = 14, 8, 16, [5, 3]
+    indptr, col = synth.rmat_csr_numpy(scale, 8, 20231)
+    N = indptr.size - 1
+    feats = synth.features_numpy(0, N, D, 7)
+    labels = (np.arange(N) % 47).astype(np.int32)
+    perm = np.random.RandomState(5).permutation(N).astype(np.int32)
+    train, valid, test = perm[:100], perm[100:500], perm[500:520]
+    ds = str(tmp_path / "ds") + "/"
+    write_dataset(ds, indptr, col, feats, labels, train, valid, test)
+    work = tmp_path / "run"
+    work.mkdir()
+    (work / "meta_config").write_text("{} {} {} {} {} {} {} {} {} {}".format(
+        ds, B, N, col.size, D, train.size, valid.size, test.size, 50_000, 1))
+    ns = f"_c{os.getpid()}"
+    env = dict(os.environ, LEGION_IPC_NAMESPACE=ns, LEGION_DEDUP="table", LEGION_POS_TABLE_BITS="9", LEGION_RUNNER_LANES="4")
+    server, log = start_server([os.path.join(ROOT, "legion_amd", "bin", "sampling_server"), "1", "0"] + [str(f) for f in fanout],
+                               work, env, work / "server.log")
+    trainer = subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "fake_trainer.py"), "0", str(D), "1", str(work / "out.npz")],
+                               env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, stdin=subprocess.DEVNULL)
+    try:
+        server.wait(timeout=240)
+        text = open(work / "server.log").read()
+        assert server.returncode not in (0, None), text[-2000:]
+        assert "position table overflow" in text and "not posted" in text and "Server Stopped" not in text, text[-2000:]
+        assert not os.path.exists(work / "out.npz")          # the trainer never got the whole schedule
+    finally:
+        if server.poll() is None:
+            server.kill()
+        trainer.kill()                                       # it is blocked on the semaphore of the batch that never came
+        trainer.wait()
+        log.close()
+        for name in os.listdir("/dev/shm"):
+            if name.endswith(ns):
+                os.unlink(os.path.join("/dev/shm", name))
+
+
 @pytest.mark.parametrize("lanes", ["16", "5"])
 def test_boundary_soak_every_batch_verified(hip, lanes):
     """600+ consecutive hand-overs through the binary and the two pipe slots with a consumer that checks EVERY batch on the

@@ -315,6 +315,16 @@ def test_hot_row_replica_keeps_results_and_saves_peer_reads(hip, P, mode_bits, c
             hits += int(hit.sum()); from_replica += int((rank < want_rows).sum())
         stripe, replica = gpu.cache.gather_stats(p)
         assert (stripe, replica) == (hits - from_replica, from_replica) and replica > 0
+        # the computed stand-in for the xGMI counter (CostModel's counters[1], SS/engine/server.cu:105-106): of the rows read
+        # through a stripe pointer, the ones whose owner g / cap is ANOTHER member of the clique, as 64-byte transactions
+        from_peer = 0
+        for it in range(2):
+            gslot = node_map[cpu.run(p, it, 0)["sampled_ids"]]
+            hit = gslot[gslot >= 0]
+            rank = (hit % capacity[0]) * Kg + hit // capacity[0]
+            from_peer += int(((hit // capacity[0] != p % Kg) & (rank >= want_rows)).sum())
+        assert gpu.cache.gather_stats3(p) == (stripe, replica, from_peer) and 0 < from_peer <= stripe
+        assert gpu.cache.peer_transactions(p) == from_peer * wl.D * 4 // 64
     gpu.close(); cpu.close()
 
 

@@ -1,0 +1,63 @@
+"""LegionTuning (include/legion_hip.h section 6): one struct, filled from the LEGION_* environment by one function, or set
+by the host program.  Host-only: no GPU needed."""
+import ctypes
+
+import pytest
+
+from legion_amd import engine, lib
+
+
+@pytest.fixture(autouse=True)
+def _restore():
+    yield
+    engine.tuning_from_env()
+
+
+def test_defaults_and_environment(monkeypatch):
+    for k in ("LEGION_DEDUP", "LEGION_POS_TABLE_BITS", "LEGION_RUNNER_LANES", "LEGION_LINK_COUNTERS", "LEGION_NO_SHM_MIRROR",
+              "LEGION_TABLE_PLACEMENT", "LEGION_RUNNER_HO_STREAM", "LEGION_GATHER_ROWS"):
+        monkeypatch.delenv(k, raising=False)
+    engine.tuning_from_env()
+    t = engine.tuning()
+    assert t["dedup_form"] == -1 and t["lds_part_wg"] == 8192 and t["sample_max_wg"] == 4096 and t["runner_graph"] == 1
+    assert t["runner_ho_stream"] == 2 and t["shm_mirror"] == 1 and t["link_counters"] == 0 and t["table_placement"] == 0
+    assert t["gather_rows_per_wg"] == 0 and t["gather_small_tiles"] == 1
+    monkeypatch.setenv("LEGION_DEDUP", "table")
+    monkeypatch.setenv("LEGION_POS_TABLE_BITS", "10")
+    monkeypatch.setenv("LEGION_RUNNER_LANES", "3")
+    monkeypatch.setenv("LEGION_LINK_COUNTERS", "123,45")
+    monkeypatch.setenv("LEGION_NO_SHM_MIRROR", "1")
+    monkeypatch.setenv("LEGION_TABLE_PLACEMENT", "pinned")
+    engine.tuning_from_env()
+    t = engine.tuning()
+    assert (t["dedup_form"], t["pos_table_bits"], t["runner_lanes"], t["shm_mirror"], t["table_placement"]) == (1, 10, 3, 0, 1)
+    assert t["link_counters"] == 3 and t["link_counter_values"] == [123, 45]
+    for word, code in (("v2", 0), ("measured", 1), ("smi", 2)):
+        monkeypatch.setenv("LEGION_LINK_COUNTERS", word)
+        engine.tuning_from_env()
+        assert engine.tuning()["link_counters"] == code
+
+
+def test_programmatic_values_survive_until_the_environment_is_asked_again(monkeypatch):
+    monkeypatch.delenv("LEGION_DEDUP", raising=False)
+    engine.tuning_from_env()
+    engine.set_tuning(dedup_form=2, runner_lanes=7)
+    t = engine.tuning()
+    assert t["dedup_form"] == 2 and t["runner_lanes"] == 7 and t["lds_part_wg"] == 8192     # the rest untouched
+    monkeypatch.setenv("LEGION_DEDUP", "direct")
+    assert engine.tuning()["dedup_form"] == 2                   # installed values are kept ...
+    engine.tuning_from_env()
+    assert engine.tuning()["dedup_form"] == 0                   # ... until the environment is asked for explicitly
+
+
+def test_struct_mirror_matches_the_header():
+    """The ctypes mirror has the header's field order and size: 18 int32 + 2 uint64."""
+    assert ctypes.sizeof(lib.Tuning) == 18 * 4 + 16
+    assert [n for n, _ in lib.Tuning._fields_][:3] == ["dedup_form", "pos_value_bits", "pos_table_bits"]
+    assert ctypes.sizeof(lib.LinkCounters) == 8 * 3 + 8 * 16 + 8 + 32
+
+
+def test_link_counters_without_a_gpu_report_unsupported():
+    c = engine.link_counters_ex(0)
+    assert set(c) >= {"supported", "pcie_bytes", "xgmi_read_bytes", "xgmi_read_bytes_link", "gpu_metrics_revision", "pci_bus_id"}
+    assert len(c["xgmi_read_bytes_link"]) == 8

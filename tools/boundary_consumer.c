@@ -1,5 +1,5 @@
 /* boundary_consumer.c -- the trainer end of the wire protocol with nothing else in it: waits for a batch
- * (sem_w_<dev>_<pipe>), reads its counters from the slab's host-visible mirror, releases the slot (sem_r_...).
+ * (sem_w_<dev>_<pipe>), reads its counters from the server's host-visible mirror, releases the slot (sem_r_...).
  * Used by tools/server_throughput.py --consumer native to measure what the SERVER can hand over per second when
  * the consumer costs nothing (the Python consumer adds ~15 us of tensor wrapping per batch).
  *   gcc -O2 boundary_consumer.c -o boundary_consumer -lrt -lpthread
@@ -22,10 +22,12 @@
 typedef struct {
     int32_t steps[3];
     char memHandle[MAX_DEVICE][INTERBATCH_CON][MEMORY_USAGE][64];
+} shmStruct;
+typedef struct {            /* "legionIPCext<suffix>": the server's host-visible counter mirror (ipc_env.hip) */
     int32_t ext_magic;
     int32_t ext_reserved[3];
     int32_t counters[MAX_DEVICE][INTERBATCH_CON][32];
-} shmStruct;
+} shmExt;
 
 static double now(void) { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return t.tv_sec + 1e-9 * t.tv_nsec; }
 
@@ -40,7 +42,11 @@ int main(int argc, char** argv)
     if (fd < 0) { perror("shm_open"); return 1; }
     volatile shmStruct* shm = (volatile shmStruct*)mmap(0, sizeof(shmStruct), PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
     if (shm == MAP_FAILED) { perror("mmap"); return 1; }
-    if (shm->ext_magic != MAGIC) { fprintf(stderr, "server does not publish the counter mirror\n"); return 1; }
+    snprintf(name, sizeof name, "legionIPCext%s", sfx);
+    int efd = shm_open(name, O_RDONLY, 0);
+    if (efd < 0) { fprintf(stderr, "server does not publish the counter mirror\n"); return 1; }
+    volatile shmExt* ext = (volatile shmExt*)mmap(0, sizeof(shmExt), PROT_READ, MAP_SHARED, efd, 0);
+    if (ext == MAP_FAILED || ext->ext_magic != MAGIC) { fprintf(stderr, "server does not publish the counter mirror\n"); return 1; }
     sem_t *sr[2], *sw[2];
     for (int i = 0; i < 2; i++) {
         snprintf(name, sizeof name, "sem_r_%d_%d%s", dev, i, sfx);
@@ -60,8 +66,8 @@ int main(int argc, char** argv)
         sem_wait(sw[pipe]);
         if (i == skip) { t0 = now(); edges = nodes = 0; timed = 0; }
         if (i < train) {
-            edges += shm->counters[dev][pipe][16 + 9 + hops];
-            nodes += shm->counters[dev][pipe][9 + hops];
+            edges += ext->counters[dev][pipe][16 + 9 + hops];
+            nodes += ext->counters[dev][pipe][9 + hops];
             timed++;
         }
         sem_post(sr[pipe]);
