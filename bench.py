@@ -31,6 +31,7 @@ import json
 import os
 import sys
 import time
+import types
 
 import numpy as np
 import torch
@@ -65,7 +66,8 @@ def parse_args():
     ap.add_argument("--fanout", type=str, default="25,10")
     ap.add_argument("--cache-memory", type=int, default=8 << 30, help="bytes per GPU fed to the cost model")
     ap.add_argument("--presc-steps", type=int, default=512, help="PreSC batches per GPU (bounded epoch)")
-    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU-baseline time; 0 disables")
+    ap.add_argument("--cpu-seconds", type=float, default=16.0,
+                    help="target time of EACH CPU-baseline leg (Legion-semantics port, DGL-semantics port); 0 disables")
     ap.add_argument("--group", type=int, default=0,
                     help="mini-batches served by every launch (lanes of a group); 0 = 262144 // batch, at most 256")
     ap.add_argument("--slots", type=int, default=2, help="groups in flight per GPU")
@@ -100,6 +102,11 @@ def parse_args():
     ap.add_argument("--replica-memory", type=int, default=0,
                     help="with --stripe: bytes per GPU for a private copy of the clique's hottest rows (hits below that hotness "
                          "rank are read from local HBM instead of a peer over xGMI; lookup results unchanged)")
+    ap.add_argument("--no-striped-leg", action="store_true",
+                    help="N > 1 without --stripe: skip the two extra timed legs with the caches striped over one clique of N "
+                         "(plain, and with a hot-row replica of --striped-replica-memory bytes)")
+    ap.add_argument("--striped-replica-memory", type=int, default=4 << 30,
+                    help="bytes per GPU of the hot-row replica in the `striped_replica` leg")
     ap.add_argument("--backend", type=str, default="nccl", help="torch.distributed backend (nccl = RCCL)")
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise torch.distributed and run the collectives even at N = 1 (exercises the RCCL calls on a 1-GPU box)")
@@ -138,36 +145,32 @@ def main():
     if use_dist:
         dist.barrier()
     from legion_amd import engine, synth
-    stripe = args.stripe and world > 1
-    P = world if stripe else 1              # logical GPUs the objects know about
-    d = rank if stripe else 0               # the one this process owns
-    engine.set_device_base(max(local_rank - d, 0))   # logical GPU d of this process = physical GPU LOCAL_RANK
-    if stripe:
-        engine.set_local_device(d)
 
-    fanout = [int(x) for x in args.fanout.split(",")]
-    H = len(fanout)
-    N = 1 << args.scale
-    D = args.dim
-    B = args.batch
-    G = args.group if args.group > 0 else max(1, min(256, 262144 // B))   # mini-batches per step (launch group)
-    n_warm, n_timed = args.warmup * G, args.steps * G                      # in mini-batches
-    t_setup = time.time()
+    c = types.SimpleNamespace(args=args, world=world, rank=rank, local_rank=local_rank, dev=dev, use_dist=use_dist)
+    c.fanout = [int(x) for x in args.fanout.split(",")]
+    c.H = len(c.fanout)
+    c.N = N = 1 << args.scale
+    c.D = D = args.dim
+    c.B = B = args.batch
+    c.G = G = args.group if args.group > 0 else max(1, min(256, 262144 // B))   # mini-batches per step (launch group)
+    c.n_warm, c.n_timed = args.warmup * G, args.steps * G                      # in mini-batches
+    c.t_setup = time.time()
 
     # ---- workload, resident in HBM --------------------------------------------------------------
     if args.dedup != "auto":
         os.environ["LEGION_DEDUP"] = args.dedup
     if args.gather_rows > 0:
         os.environ["LEGION_GATHER_ROWS"] = str(args.gather_rows)
+    engine.set_device_base(local_rank)
     indptr, col = synth.rmat_csr_device(args.scale, args.edge_factor, 20231, dev, scramble=args.scramble)
     torch.cuda.empty_cache()
-    pinned = []
+    c.pinned = []
     if args.placement == "pinned":
         # generate on the device, park in mapped pinned host memory; the device copies of the CSR stay for the checks
         indptr_hbm, col_hbm = indptr, col
-        pinned = [engine.PinnedArray.empty((N + 1,), np.int64), engine.PinnedArray.empty((int(col.numel()),), np.int32),
-                  engine.PinnedArray.empty((N, D), np.float32)]
-        indptr, col, features = (p.tensor(dev) for p in pinned)
+        c.pinned = [engine.PinnedArray.empty((N + 1,), np.int64), engine.PinnedArray.empty((int(col.numel()),), np.int32),
+                    engine.PinnedArray.empty((N, D), np.float32)]
+        indptr, col, features = (p.tensor(dev) for p in c.pinned)
         indptr.copy_(indptr_hbm)
         col.copy_(col_hbm)
         for r0 in range(0, N, 1 << 22):
@@ -175,18 +178,58 @@ def main():
         torch.cuda.synchronize()
     else:
         features = synth.features_device(N, D, 7, dev)
-    need = (n_warm + n_timed + 2) * B * world + B
+    c.indptr, c.col, c.features = indptr, col, features
+    need = (c.n_warm + c.n_timed + 2) * B * world + B
     need = max(need, (args.presc_steps + 2) * B * world)
     all_seeds = synth.seed_ids(N, min(max(need * 2, N // 10), N), 11)
-    mine = np.ascontiguousarray(all_seeds[all_seeds % world == rank])      # storage_management.cu:178
+    c.mine = np.ascontiguousarray(all_seeds[all_seeds % world == rank])      # storage_management.cu:178
     # an epoch = the whole groups this rank's seed set holds; a run longer than that starts another epoch over the same
     # seeds (the reference's schedule wraps the same way: GetLocalBatchId, ipc_service.cu:213-228)
-    epoch_batches = ((mine.size - 1) // B) // G * G
-    assert epoch_batches >= G, f"the seed set of this rank ({mine.size} ids) holds less than one launch group of {G} x {B}"
-    wrap = epoch_batches if n_warm + n_timed > epoch_batches else None
+    c.epoch_batches = ((c.mine.size - 1) // B) // G * G
+    assert c.epoch_batches >= G, f"the seed set of this rank ({c.mine.size} ids) holds less than one launch group of {G} x {B}"
+    c.wrap = c.epoch_batches if c.n_warm + c.n_timed > c.epoch_batches else None
 
-    graph = engine.GraphStorage(P, indptr, col)
-    feature = engine.FeatureStorage(P, features)
+    # ---- the headline leg, then (N > 1) the same workload with the caches striped over one clique of N ------------
+    stripe = args.stripe and world > 1
+    head = run_leg(c, engine, synth, stripe, args.replica_memory if stripe else 0, headline=True)
+    extra = {}
+    if world > 1 and not stripe and not args.no_striped_leg:
+        extra["striped"] = run_leg(c, engine, synth, True, 0, headline=False)
+        if args.striped_replica_memory > 0:
+            extra["striped_replica"] = run_leg(c, engine, synth, True, args.striped_replica_memory, headline=False)
+
+    if rank == 0:
+        out = head["json"]
+        for k, leg in extra.items():
+            out[k] = leg["json"]
+        if world == 1 and not args.no_boundary and args.placement == "hbm":
+            out.update(boundary_leg(args, c.fanout))
+        if args.cpu_seconds > 0 and world == 1:      # reported at N = 1 only
+            out["cpu_baseline"] = cpu_baseline(indptr, col, c.mine, N, B, c.fanout, c.n_warm, args.cpu_seconds,
+                                               features if args.placement == "hbm" else None)
+        json_out.write(json.dumps(out) + "\n")
+        json_out.flush()
+    if use_dist:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def run_leg(c, engine, synth, stripe, replica_memory, headline):
+    """One cache layout over the resident workload: objects -> PreSC -> hotness all-reduce -> cost model -> fills -> pipeline ->
+    counting pass -> warm-up -> timed regions -> eager pass with HIP events around the gathers.  Returns {"json": rank 0's
+    report of the leg}.  The headline leg also verifies, and runs the `overlapped` arrangement; the extra legs are shorter."""
+    args, world, rank, dev, use_dist = c.args, c.world, c.rank, c.dev, c.use_dist
+    fanout, H, N, D, B, G = c.fanout, c.H, c.N, c.D, c.B, c.G
+    n_warm, n_timed, wrap, mine = c.n_warm, c.n_timed, c.wrap, c.mine
+    t_leg = time.time()
+    P = world if stripe else 1              # logical GPUs the objects know about
+    d = rank if stripe else 0               # the one this process owns
+    engine.set_device_base(max(c.local_rank - d, 0))   # logical GPU d of this process = physical GPU LOCAL_RANK
+    engine.set_local_device(d if stripe else -1)
+    red_dev = dev if args.backend == "nccl" else "cpu"
+
+    graph = engine.GraphStorage(P, c.indptr, c.col)
+    feature = engine.FeatureStorage(P, c.features)
     feature.set_ids(d, engine.TRAINMODE, mine, None)
     train_step = min((mine.size - 1) // B, args.presc_steps)
     if use_dist:                            # train_step = min over partitions (ipc_service.cu:73-82)
@@ -209,20 +252,36 @@ def main():
     time.sleep(0.02)
     lc1 = engine.link_counters(d)
     pcie_tx = (lc1[0] - lc0[0]) // 64 if (lc0 is not None and lc1 is not None) else None
+    xgmi_tx = (lc1[1] - lc0[1]) // 64 if (lc0 is not None and lc1 is not None) else None
+    collective = None
     if use_dist:    # the only collective of the path: RCCL all-reduce of the uint64 hotness counters
+        ones = torch.ones(1, dtype=torch.int64, device=red_dev)
+        dist.all_reduce(ones)                                   # the world size as the collective itself sees it
+        torch.cuda.synchronize()
+        dist.barrier()
+        t0 = time.perf_counter()
         dist.all_reduce(cache.array("node_access_time", d))
         dist.all_reduce(cache.array("edge_access_time", d))
+        torch.cuda.synchronize()
+        ar_ms = (time.perf_counter() - t0) * 1e3
+        ar_t = torch.tensor([ar_ms], dtype=torch.float64, device=red_dev)
+        dist.all_reduce(ar_t, op=dist.ReduceOp.MAX)
+        collective = {"backend": dist.get_backend(), "world_size_seen_by_all_reduce": int(ones.item()),
+                      "hotness_all_reduce_ms": float(ar_t.item()), "hotness_all_reduce_bytes": 2 * N * 8,
+                      "hotness_all_reduce_GBps_algorithmic": 2 * N * 8 / max(float(ar_t.item()), 1e-6) / 1e6,
+                      "note": "two uint64[N] arrays (node and edge access counts), all-reduced in place once before CandidateSelection; "
+                              "time = max over ranks, wall clock around both calls incl. synchronize"}
     max_ids = cache.max_id_num(d)
     topo_tx = cache.topo_transactions(d)
     if use_dist:
-        tt = torch.tensor([topo_tx], dtype=torch.int64, device=dev if args.backend == "nccl" else "cpu")
+        tt = torch.tensor([topo_tx], dtype=torch.int64, device=red_dev)
         dist.all_reduce(tt)
         topo_tx = int(tt.item())
     if args.link_counters == "smi" and pcie_tx is not None:
-        tt = torch.tensor([pcie_tx], dtype=torch.int64, device=dev if args.backend == "nccl" else "cpu")
+        tt = torch.tensor([pcie_tx, xgmi_tx], dtype=torch.int64, device=red_dev)
         if use_dist:
             dist.all_reduce(tt)
-        counters = (int(tt.item()), 0)
+        counters = (int(tt[0].item()), int(tt[1].item()))
     elif args.link_counters in ("computed", "smi"):
         counters = (topo_tx, 0)
     else:
@@ -239,8 +298,8 @@ def main():
             dist.all_gather_object(out, b)
             return out
 
-        if args.replica_memory > 0:
-            cache.set_replica_memory(args.replica_memory)
+        if replica_memory > 0:
+            cache.set_replica_memory(replica_memory)
         cache.fill_up_distributed(feature, graph, d, world, mids, all_gather_bytes)
         dist.barrier()
     else:
@@ -256,7 +315,7 @@ def main():
     pipe = engine.Pipeline(graph, feature, cache, d, B, fanout, G, feature_rows, not args.no_graph, args.slots,
                            args.overlap, args.split, weave)
     torch.cuda.synchronize()
-    setup_s = time.time() - t_setup
+    setup_s = time.time() - (c.t_setup if headline else t_leg)
 
     # ---- untimed counting pass over exactly the timed batches (deterministic) --------------------
     first = n_warm
@@ -265,8 +324,11 @@ def main():
     hop_edges = np.zeros((n_timed, H), dtype=np.int64)
     hop_slots = np.zeros((n_timed, H), dtype=np.int64)
     hits = 0
-    node_map = cache.array("node_map", d) if (cache.node_capacity(d) > 0 and not args.no_cache) else torch.empty(0, dtype=torch.int32, device=dev)
+    have_map = cache.node_capacity(d) > 0 and not args.no_cache
+    node_map = cache.array("node_map", d) if have_map else torch.empty(0, dtype=torch.int32, device=dev)
     feat_hit_rows = feat_miss_rows = 0           # over every timed batch (all hops)
+    if stripe:
+        cache.gather_stats3(d)                   # arms the row-source counters for this (untimed) pass only
     for k in range(n_timed):
         if k % G == 0:
             slot = pipe.submit((first + k) % wrap if wrap else first + k)
@@ -284,7 +346,7 @@ def main():
             rows[k, h + 1] = nc[9 + h + 1] - nc[9 + h]
             hop_edges[k, h] = ec[9 + h + 1] - ec[9 + h]
             hop_slots[k, h] = (nc[9] if h == 0 else ec[9 + h] - ec[9 + h - 1]) * fanout[h]
-        if k == 0 and not args.no_verify:
+        if k == 0 and headline and not args.no_verify:
             # size-independent parity properties at full size: every gathered row is byte-identical to
             # the generator's value for its id; ids are unique; positions localise the edge endpoints
             n = int(nc[9 + H])
@@ -297,6 +359,10 @@ def main():
             src_g = pl.buffer("agg_src_ids")[:e].long()
             assert bool((ids.long()[pl.buffer("agg_src_off")[:e].long()] == src_g).all())
             hits = int((pl.buffer("cache_search_buffer")[:int(nc[1])] >= 0).sum())
+    source_rows = None
+    if stripe:                                   # where this rank's gathers read the timed batches' hit rows from
+        source_rows = cache.gather_stats3(d)
+        cache.gather_stats_enable(False)         # counting costs an atomic per hit row: off before anything is timed
 
     # ---- warm-up, then the timed region: exactly K steps (K hipGraph replays of G batches each) between
     #      barrier + synchronize brackets.  The region is repeated (same batches: an epoch over the same
@@ -319,8 +385,11 @@ def main():
         torch.cuda.synchronize()
         return time.perf_counter() - t0, last
 
+    min_seconds = args.min_seconds if headline else 0.5 * args.min_seconds
+    time.sleep(0.005)
+    lk0, t_lk0 = engine.link_counters_ex(d), time.perf_counter()
     el0, last_group = timed_region()
-    reps_t = torch.tensor([max(1, min(args.max_repeats, int(np.ceil(args.min_seconds / max(el0, 1e-6)))))],
+    reps_t = torch.tensor([max(1, min(args.max_repeats, int(np.ceil(min_seconds / max(el0, 1e-6)))))],
                           dtype=torch.int64, device=dev)
     if use_dist:
         dist.all_reduce(reps_t, op=dist.ReduceOp.MAX)
@@ -329,13 +398,16 @@ def main():
     for _ in range(repeats - 1):
         el, last_group = timed_region()
         region_s.append(el)
+    time.sleep(0.005)
+    lk1, t_lk1 = engine.link_counters_ex(d), time.perf_counter()
+    own_region = float(np.median(np.asarray(region_s)))                     # this rank's own clock (brackets include the barriers)
     region_t = torch.tensor(region_s, dtype=torch.float64, device=dev)
     if use_dist:
         dist.all_reduce(region_t, op=dist.ReduceOp.MAX)              # per repeat: the slowest rank
     region_s = region_t.cpu().numpy()
     elapsed_max = float(np.median(region_s))
-    elapsed = float(np.median(np.asarray(region_s)))                 # used for the rank-0 sampler/gather split below
-    if not args.no_verify and last_group is not None:
+    elapsed = elapsed_max                                            # used for the rank-0 sampler/gather split below
+    if headline and not args.no_verify and last_group is not None:
         # the last group of the timed region is still in its slot: its batches must be the ones the counting
         # pass saw (replays are deterministic), and its last lane passes the full-size property checks
         slot, k0, n_lanes = last_group
@@ -369,14 +441,15 @@ def main():
             err_bits |= pl.error()
     if err_bits:
         raise RuntimeError(f"a kernel raised error bits {err_bits:#x} during the run (legion_core.h LG_ERR_*)")
+    dedup_form, state_bytes = pipe.pools[0][0].dedup_form(), pipe.pools[0][0].state_bytes()
 
     # ---- the same K steps once more with every group's sampler phase and gather phase on two streams (sampler k+1 runs
     #      under gathers k, pipeline.hip `split`): reported beside the headline as `overlapped`, not as `value`, because
     #      two kernels sharing the machine make the per-kernel roofline of the timed region meaningless.  --split makes
     #      this arrangement the headline instead. ------------------------------------------------------------------
     overlapped = None
-    if not args.split and not args.no_overlap_leg:
-        pipe.close()
+    pipe.close()
+    if headline and not args.split and not args.no_overlap_leg:
         pipe = engine.Pipeline(graph, feature, cache, d, B, fanout, G, feature_rows, not args.no_graph, args.slots, False, True)
         pipe.run_range(0, n_warm, wrap=wrap)
         pipe.wait()
@@ -389,6 +462,7 @@ def main():
         if use_dist:
             dist.all_reduce(ov, op=dist.ReduceOp.MAX)
         overlapped = float(np.median(ov.cpu().numpy())), int(ov.numel())
+        pipe.close()
 
     tot_edges = torch.tensor([float(edges.sum())], dtype=torch.float64, device=dev)
     gather_bytes_t = torch.tensor([float(rows.sum() * D * 4)], dtype=torch.float64, device=dev)
@@ -410,6 +484,32 @@ def main():
                      float(rows[:, h + 1].sum()) * 8.0 for h in range(H))
     t_sampling = max(elapsed - t_all_gathers, 1e-9)
 
+    # ---- N > 1: what every rank saw, so that one SCALE invocation is its own evidence ------------------------------
+    per_rank = None
+    if use_dist:
+        window_s = t_lk1 - t_lk0
+        mine_info = {"rank": rank, "pci_bus_id": lk1["pci_bus_id"], "gpu_metrics_revision": lk1["gpu_metrics_revision"],
+                     "edges_per_sec": float(edges.sum()) / max(own_region, 1e-9),
+                     "gather_roofline_frac": achieved / HBM_PEAK_GBPS, "gather_avg_launch_us": t_last / max(n_last, 1) * 1e6}
+        if lk0["supported"] and lk1["supported"]:
+            xr = lk1["xgmi_read_bytes"] - lk0["xgmi_read_bytes"]
+            mine_info.update({"xgmi_read_bytes": xr, "xgmi_write_bytes": lk1["xgmi_write_bytes"] - lk0["xgmi_write_bytes"],
+                              "xgmi_read_GBps": xr / max(window_s, 1e-9) / 1e9,
+                              "xgmi_read_bytes_link": [b - a for a, b in zip(lk0["xgmi_read_bytes_link"], lk1["xgmi_read_bytes_link"])],
+                              "pcie_bytes": lk1["pcie_bytes"] - lk0["pcie_bytes"], "window_s": window_s,
+                              "window": f"{repeats} timed regions incl. their barriers"})
+        if source_rows is not None:
+            # rows of ONE timed region by where the gather read them: computed by the kernel in the untimed counting pass
+            stripe_rows, replica_rows_read, peer_rows = source_rows
+            mine_info.update({"rows_from_own_stripe": stripe_rows - peer_rows, "rows_from_peer_stripes": peer_rows,
+                              "rows_from_local_replica": replica_rows_read, "rows_gathered": int(rows.sum()),
+                              "peer_bytes_per_region_computed": peer_rows * D * 4,
+                              "peer_read_GBps_computed": peer_rows * D * 4 / max(own_region, 1e-9) / 1e9})
+            if "xgmi_read_bytes" in mine_info:
+                mine_info["xgmi_read_bytes_per_region_measured"] = mine_info["xgmi_read_bytes"] / repeats
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, mine_info)
+
     # HBM traffic of that kernel cannot be read live: it comes from the committed PMC summary
     # (profiles/rNN/pmc_gather_kernel.json: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of
     # this same command, gfx950 corrections applied), used only when it was taken on this configuration
@@ -426,111 +526,150 @@ def main():
             traffic_src = os.path.relpath(f, ROOT)
             break
 
+    out = None
     if rank == 0:
-        out = {
-            "metric": "sampled_edges_per_sec",
-            "value": float(tot_edges.item()) / elapsed_max,
-            "unit": "edges/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed_max / args.steps * 1e3,
-            "batches_per_step": G, "ms_per_batch": elapsed_max / n_timed * 1e3,
-            "timed_region": {"steps": args.steps, "repeats": repeats, "median_s": elapsed_max,
-                             "min_s": float(region_s.min()), "max_s": float(region_s.max()),
-                             "total_timed_s": float(region_s.sum()),
-                             "note": "exactly K steps per region between barrier+synchronize brackets; region repeated over the "
-                                     "same batches until --min-seconds; per repeat the max over ranks; value uses the median"},
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "int32+f32(copy)", "data": "synthetic",
-            "config": {"workload": f"RMAT-{args.scale} EF{args.edge_factor} (N={N}, E={N * args.edge_factor}), "
-                                   f"float32[N x {D}] features, batch {B}, fanout {fanout}, " +
-                                   ("all tables resident in HBM" if args.placement == "hbm" else
-                                    "full CSR + full feature table in mapped pinned host memory (read over PCIe on a miss), "
-                                    "hotness-ranked feature/topology caches in HBM")
-                                   + (", vertex labels scrambled" if args.scramble else ""),
-                       "parallelism": (f"seed-sharded x{world}, replicated graph+features, one clique of {world}: caches "
-                                       f"striped over the ranks, peer reads over xGMI (cache_agg_mode {int(np.log2(world))})")
-                       if stripe else f"seed-sharded x{world}, replicated graph+features, cache_agg_mode 0",
-                       "batches_per_launch_group": G, "groups_in_flight": args.slots, "epoch_batches": epoch_batches,
-                       "streams": "weave: head of group k+1 on a second stream under the heavy kernels of group k" if weave else
-                                  ("split: sampler phase || gather phase" if args.split else "one"),
-                       "epochs_wrap": bool(wrap), "hipgraph": not args.no_graph,
-                       "cache_memory_bytes": args.cache_memory,
-                       "feature_cache_rows": cache.node_capacity(d), "topology_cache_vertices": cache.edge_capacity(d),
-                       "presc_batches": train_step, "presc_topology_transactions": topo_tx,
-                       "presc_pcie_transactions_gpu_metrics": pcie_tx, "link_counters": args.link_counters,
-                       "cost_model_counters": list(counters),
-                       "hot_row_replica_rows": cache.replica_rows(d)},
-            "feature_gather_GBps": payload_gbps * 1.0,
-            "feature_gather_GBps_note": "payload bytes read (rows*D*4) / HIP-event time of all gather launches, rank 0",
-            "sampling_only": {"edges_per_sec": float(edges.sum()) / t_sampling, "algorithmic_GBps": samp_bytes / t_sampling / 1e9,
-                              "frac_of_hbm_peak": samp_bytes / t_sampling / 1e9 / HBM_PEAK_GBPS,
-                              "note": "rank 0; time = timed region minus the HIP-event time of all gather launches (with the weave "
-                                      "arrangement the head of the next group runs hidden under this group's heavy kernels, so this is the "
-                                      "sampler time that is NOT hidden); the sampler is bound by scattered 4-byte column loads (~43-47 G sector "
-                                      "misses/s, tools/micro/random_access.hip) and, in the atomics forms of the first-touch state, by "
-                                      "memory-side atomics (~13-19 G claims/s, tools/micro/dedup_tables.hip): DESIGN.md section 4.2"},
-            "edges_per_step": float(edges.sum()) / args.steps, "rows_per_step": float(rows.sum()) / args.steps,
-            "edges_per_batch": float(edges.mean()), "rows_per_batch": float(rows.sum(axis=1).mean()),
-            "seed_feature_cache_hits_step0": hits,
-            "roofline": {"bound": "hbm", "kernel": "gather_kernel<float4> (hop-%d gather, op %d)" % (H, last_op),
-                         "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_unit": "bytes per launch",
-                         "traffic_source": traffic_src, "algorithmic_bytes_per_launch": rows_last / max(n_last, 1) * bytes_per_row,
-                         "bytes_per_row": bytes_per_row, "rows_per_launch": rows_last / max(n_last, 1),
-                         "launches": n_last, "avg_launch_us": t_last / max(n_last, 1) * 1e6,
-                         "measured": "HIP events on the launch stream around each hop-%d gather launch over the same %d "
-                                     "steps, %d batches per launch, eager launches (wall clock of that pass: ms_per_step %.4f; "
-                                     "hipGraph replay, timed region: %.4f)"
-                                     % (H, args.steps, G, elapsed_profiled / args.steps * 1e3, elapsed_max / args.steps * 1e3)},
-            "setup_seconds": setup_s,
-            "overlapped": None if overlapped is None else {
-                "value": float(tot_edges.item()) / overlapped[0], "unit": "edges/s", "ms_per_step": overlapped[0] / args.steps * 1e3,
-                "repeats": overlapped[1],
-                "note": "same K steps, same batches, with every group's sampler phase on one stream and its gathers on another "
-                        "(sampler k+1 runs under gathers k; `bench.py --split` makes this the headline).  Each kernel runs "
-                        "slower while sharing the machine (the gather at ~0.59 of peak instead of 0.78).  With the atomics forms "
-                        "of the first-touch state this finishes a group 8-12 % sooner than one stream; with the LDS form and "
-                        "the weave default it does not (DESIGN.md section 4.5)."},
-            "position_state": {"form": pipe.pools[0][0].dedup_form(),
-                               "bytes_per_lane": pipe.pools[0][0].state_bytes(), "lanes": G * args.slots},
-            "feature_cache_hit_rate": feat_hit_rows / max(feat_hit_rows + feat_miss_rows, 1),
-            "feature_cache_hit_rate_over": "every timed batch" if args.placement == "pinned" else "the first timed step",
-        }
-        if args.placement == "pinned":
-            miss_frac = feat_miss_rows / max(feat_hit_rows + feat_miss_rows, 1)
-            miss_gbps = float(rows.sum() * D * 4) * miss_frac / t_all_gathers / 1e9 if t_all_gathers > 0 else 0.0
-            out["miss_path"] = {"feature_rows_missed_frac": miss_frac, "pcie_feature_GBps": miss_gbps,
-                                "pcie_peak_GBps": 64.0, "frac_of_pcie_peak": miss_gbps / 64.0,
-                                "note": "missed rows x D x 4 bytes / HIP-event time of all gather launches (hits are served from "
-                                        "HBM inside the same launches); PCIe Gen5 x16 = 64 GB/s per direction; topology misses "
-                                        "(4-byte column reads) cross the same link during the sampler kernels"}
-        if world == 1 and not args.no_boundary and args.placement == "hbm":
-            out.update(boundary_leg(args, fanout))
-        if args.cpu_seconds > 0 and world == 1:      # reported at N = 1 only
-            out["cpu_baseline"] = cpu_baseline(indptr, col, mine, N, B, fanout, first, args.cpu_seconds,
-                                               features if args.placement == "hbm" else None)
-        json_out.write(json.dumps(out) + "\n")
-        json_out.flush()
+        layout = (f"seed-sharded x{world}, replicated graph+features, one clique of {world}: caches striped over the ranks, peer reads "
+                  f"over xGMI (cache_agg_mode {int(np.log2(world))})" + (f", hot-row replica of {replica_memory} bytes per GPU" if replica_memory else "")
+                  if stripe else f"seed-sharded x{world}, replicated graph+features, cache_agg_mode 0")
+        roof = {"bound": "hbm", "kernel": "gather_kernel<float4> (hop-%d gather, op %d)" % (H, last_op),
+                "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_unit": "bytes per launch",
+                "traffic_source": traffic_src, "algorithmic_bytes_per_launch": rows_last / max(n_last, 1) * bytes_per_row,
+                "bytes_per_row": bytes_per_row, "rows_per_launch": rows_last / max(n_last, 1),
+                "launches": n_last, "avg_launch_us": t_last / max(n_last, 1) * 1e6,
+                "measured": "HIP events on the launch stream around each hop-%d gather launch over the same %d "
+                            "steps, %d batches per launch, eager launches (wall clock of that pass: ms_per_step %.4f; "
+                            "hipGraph replay, timed region: %.4f)"
+                            % (H, args.steps, G, elapsed_profiled / args.steps * 1e3, elapsed_max / args.steps * 1e3)}
+        timed = {"steps": args.steps, "repeats": repeats, "median_s": elapsed_max,
+                 "min_s": float(region_s.min()), "max_s": float(region_s.max()), "total_timed_s": float(region_s.sum()),
+                 "note": "exactly K steps per region between barrier+synchronize brackets; region repeated over the "
+                         "same batches until --min-seconds; per repeat the max over ranks; value uses the median"}
+        if not headline:
+            out = {"value": float(tot_edges.item()) / elapsed_max, "unit": "edges/s", "ms_per_step": elapsed_max / args.steps * 1e3,
+                   "parallelism": layout, "timed_region": timed, "roofline": roof,
+                   "feature_gather_GBps": payload_gbps, "feature_cache_rows": cache.node_capacity(d),
+                   "topology_cache_vertices": cache.edge_capacity(d), "hot_row_replica_rows": cache.replica_rows(d),
+                   "collective": collective, "per_rank": per_rank, "setup_seconds": setup_s,
+                   "xgmi_ingest_peak_GBps_per_gpu": 7 * 153.0 / 2,
+                   "note": "same workload, same seed batches, same K steps as the headline; the feature and topology caches striped over "
+                           "one clique of all ranks (hotness rank t on GPU t % N), remote rows and adjacency read with direct peer loads "
+                           "over xGMI; per_rank[].rows_from_* were counted by the gather itself in an untimed pass over the timed batches, "
+                           "xgmi_* are deltas of the driver's cumulative gpu_metrics counters over the timed regions"}
+        else:
+            out = {
+                "metric": "sampled_edges_per_sec",
+                "value": float(tot_edges.item()) / elapsed_max,
+                "unit": "edges/s",
+                "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                "ms_per_step": elapsed_max / args.steps * 1e3,
+                "batches_per_step": G, "ms_per_batch": elapsed_max / n_timed * 1e3,
+                "timed_region": timed,
+                "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                "dtype": "int32+f32(copy)", "data": "synthetic",
+                "config": {"workload": f"RMAT-{args.scale} EF{args.edge_factor} (N={N}, E={N * args.edge_factor}), "
+                                       f"float32[N x {D}] features, batch {B}, fanout {fanout}, " +
+                                       ("all tables resident in HBM" if args.placement == "hbm" else
+                                        "full CSR + full feature table in mapped pinned host memory (read over PCIe on a miss), "
+                                        "hotness-ranked feature/topology caches in HBM")
+                                       + (", vertex labels scrambled" if args.scramble else ""),
+                           "parallelism": layout,
+                           "batches_per_launch_group": G, "groups_in_flight": args.slots, "epoch_batches": c.epoch_batches,
+                           "streams": "weave: head of group k+1 on a second stream under the heavy kernels of group k" if weave else
+                                      ("split: sampler phase || gather phase" if args.split else "one"),
+                           "epochs_wrap": bool(wrap), "hipgraph": not args.no_graph,
+                           "cache_memory_bytes": args.cache_memory,
+                           "feature_cache_rows": cache.node_capacity(d), "topology_cache_vertices": cache.edge_capacity(d),
+                           "presc_batches": train_step, "presc_topology_transactions": topo_tx,
+                           "presc_pcie_transactions_gpu_metrics": pcie_tx, "presc_xgmi_transactions_gpu_metrics": xgmi_tx,
+                           "link_counters": args.link_counters,
+                           "cost_model_counters": list(counters),
+                           "hot_row_replica_rows": cache.replica_rows(d)},
+                "feature_gather_GBps": payload_gbps * 1.0,
+                "feature_gather_GBps_note": "payload bytes read (rows*D*4) / HIP-event time of all gather launches, rank 0",
+                "sampling_only": {"edges_per_sec": float(edges.sum()) / t_sampling, "algorithmic_GBps": samp_bytes / t_sampling / 1e9,
+                                  "frac_of_hbm_peak": samp_bytes / t_sampling / 1e9 / HBM_PEAK_GBPS,
+                                  "note": "rank 0; time = timed region minus the HIP-event time of all gather launches (with the weave "
+                                          "arrangement the head of the next group runs hidden under this group's heavy kernels, so this is the "
+                                          "sampler time that is NOT hidden); the sampler is bound by scattered 4-byte column loads (~43-47 G sector "
+                                          "misses/s, tools/micro/random_access.hip) and, in the atomics forms of the first-touch state, by "
+                                          "memory-side atomics (~13-19 G claims/s, tools/micro/dedup_tables.hip): DESIGN.md section 4.2"},
+                "edges_per_step": float(edges.sum()) / args.steps, "rows_per_step": float(rows.sum()) / args.steps,
+                "edges_per_batch": float(edges.mean()), "rows_per_batch": float(rows.sum(axis=1).mean()),
+                "seed_feature_cache_hits_step0": hits,
+                "roofline": roof,
+                "setup_seconds": setup_s,
+                "overlapped": None if overlapped is None else {
+                    "value": float(tot_edges.item()) / overlapped[0], "unit": "edges/s", "ms_per_step": overlapped[0] / args.steps * 1e3,
+                    "repeats": overlapped[1],
+                    "note": "same K steps, same batches, with every group's sampler phase on one stream and its gathers on another "
+                            "(sampler k+1 runs under gathers k; `bench.py --split` makes this the headline).  Each kernel runs "
+                            "slower while sharing the machine (the gather at ~0.59 of peak instead of 0.78).  With the atomics forms "
+                            "of the first-touch state this finishes a group 8-12 % sooner than one stream; with the LDS form and "
+                            "the weave default it does not (DESIGN.md section 4.5)."},
+                "position_state": {"form": dedup_form, "bytes_per_lane": state_bytes, "lanes": G * args.slots},
+                "feature_cache_hit_rate": feat_hit_rows / max(feat_hit_rows + feat_miss_rows, 1),
+                "feature_cache_hit_rate_over": "every timed batch" if args.placement == "pinned" else "the first timed step",
+            }
+            if collective is not None:
+                out["collective"] = collective
+                out["per_rank"] = per_rank
+            if args.placement == "pinned":
+                miss_frac = feat_miss_rows / max(feat_hit_rows + feat_miss_rows, 1)
+                miss_gbps = float(rows.sum() * D * 4) * miss_frac / t_all_gathers / 1e9 if t_all_gathers > 0 else 0.0
+                out["miss_path"] = {"feature_rows_missed_frac": miss_frac, "pcie_feature_GBps": miss_gbps,
+                                    "pcie_peak_GBps": 64.0, "frac_of_pcie_peak": miss_gbps / 64.0,
+                                    "note": "missed rows x D x 4 bytes / HIP-event time of all gather launches (hits are served from "
+                                            "HBM inside the same launches); PCIe Gen5 x16 = 64 GB/s per direction; topology misses "
+                                            "(4-byte column reads) cross the same link during the sampler kernels"}
+    # this leg's objects go before the next leg builds its own (other logical-GPU numbering, other cache layout)
+    cache.close()
+    feature.close()
+    graph.close()
+    torch.cuda.synchronize()
     if use_dist:
         dist.barrier()
-        dist.destroy_process_group()
+    return {"json": out}
 
 
 def boundary_leg(args, fanout):
     """The same kernels behind the reference's own server <-> trainer protocol (tools/server_throughput.py): the
     `sampling_server` binary serving a Python `ipc_service` consumer one mini-batch per semaphore hand-off into one of two
-    pipe slots.  Reported beside the headline, never as `value`."""
+    pipe slots -- on the bench's own graph (RMAT-26) at the bench's batch size AND at Legion's default B = 8000, where the
+    per-batch hand-over latency no longer hides the GPU.  Reported beside the headline, never as `value`.  The data set is
+    written to /tmp in the reference's file formats (CSR 4.8 GB at RMAT-26; no `features` file: the server serves a zero-filled
+    table of the same shape, as v2 of the reference does, storage_management.cu:162); without room there the leg falls back
+    to RMAT-22 and says so."""
+    import shutil
     import subprocess
-    cmd = [sys.executable, os.path.join(ROOT, "tools", "server_throughput.py"), "--scale", str(min(args.scale, 22)),
-           "--batch", str(args.batch), "--dim", str(args.dim), "--fanout", ",".join(str(f) for f in fanout),
-           "--train-batches", str(max(64, min(3000, (3 << 20) // args.batch)))]
+    scale = args.scale
+    need = (1 << scale) * (8 + 4 * args.edge_factor + 4) + (2 << 30)
+    note = None
     try:
-        res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
-        line = [ln for ln in res.stdout.splitlines() if ln.startswith("{")][-1]
-        r = json.loads(line)
-        return {"boundary_batches_per_sec": r["batches_per_sec"], "boundary_edges_per_sec": r["edges_per_sec"],
-                "boundary": {"path": r["path"], "workload": r["workload"], "ms_per_batch": r["ms_per_batch"],
-                             "timed_batches": r["timed_batches"]}}
+        free = shutil.disk_usage("/tmp").free
+    except OSError:
+        free = 0
+    if free < need:
+        note = f"/tmp has {free >> 20} MiB free, the RMAT-{scale} data set needs {need >> 20}: boundary leg run at RMAT-22 instead"
+        scale = min(scale, 22)
+    batches = [args.batch] + ([8000] if args.batch != 8000 else [])
+    cmd = [sys.executable, os.path.join(ROOT, "tools", "server_throughput.py"), "--scale", str(scale), "--edge-factor", str(args.edge_factor),
+           "--batch", ",".join(str(b) for b in batches), "--dim", str(args.dim), "--fanout", ",".join(str(f) for f in fanout),
+           "--train-batches", str(max(64, min(3000, (3 << 20) // args.batch))), "--no-features-file", "--cache-memory", str(args.cache_memory)]
+    try:
+        res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+        lines = [json.loads(ln) for ln in res.stdout.splitlines() if ln.startswith("{")]
+        if not lines:
+            raise RuntimeError(res.stderr[-300:])
+        legs = [{"batch": r["batch"], "batches_per_sec": r["batches_per_sec"], "edges_per_sec": r["edges_per_sec"], "path": r["path"],
+                 "workload": r["workload"], "ms_per_batch": r["ms_per_batch"], "timed_batches": r["timed_batches"]} for r in lines]
+        first = legs[0]
+        out = {"boundary_batches_per_sec": first["batches_per_sec"], "boundary_edges_per_sec": first["edges_per_sec"],
+               "boundary": {"path": first["path"], "workload": first["workload"], "ms_per_batch": first["ms_per_batch"],
+                            "timed_batches": first["timed_batches"], "by_batch_size": legs}}
+        if note:
+            out["boundary"]["note"] = note
+        return out
     except Exception as e:            # the headline must not depend on this leg
         return {"boundary_batches_per_sec": None, "boundary": {"error": repr(e)[:300]}}
 
@@ -556,23 +695,52 @@ def cpu_baseline(indptr, col, seeds, N, B, fanout, first_batch, target_s, featur
                                 int(feats.shape[1]) if feats is not None else 0, ctypes.byref(secs), ctypes.byref(nodes))
         return int(e), secs.value, int(nodes.value)
 
-    dgl_note = "DGL unavailable on this box (import dgl failed); the oracle's C sampler stands in (BASELINE.md 2.3)"
+    dgl_note = "DGL unavailable on this box (import dgl failed): oracle/dgl_semantics.c restates its sampler's semantics (SURVEY.md A.9)"
     try:
         import dgl  # noqa: F401
-        dgl_note = "dgl importable but not used: its sampler has different semantics (SURVEY.md A.9)"
+        dgl_note = "dgl importable but not used here; oracle/dgl_semantics.c restates its sampler's semantics (SURVEY.md A.9)"
     except Exception:
         pass
-    e, s, _ = timed(cores)                    # calibration: one batch per thread
-    nb = int(max(cores, min(cores * 64, cores * target_s / max(s, 1e-3))))
-    nb = min(nb, (sd.size - 1) // B - first_batch)
-    e, s, _ = timed(nb)
+    avail = (sd.size - 1) // B - first_batch
+
+    def sized(run_nb, budget_s):
+        """calibrate on one batch per thread, then size the sample for budget_s seconds (bounded by the seed set)"""
+        e0, s0 = run_nb(min(cores, avail))
+        nb_ = int(max(cores, cores * budget_s / max(s0, 1e-3)))
+        nb_ = max(1, min(nb_, avail))
+        e_, s_ = run_nb(nb_)
+        return e_, s_, nb_
+
+    e, s, nb = sized(lambda n: timed(n)[:2], target_s)
     e1, s1, _ = timed(4, 1)                   # the same sampler on one thread (SURVEY 8d asks for both)
     e1, s1, _ = timed(int(max(4, min(256, 2.0 * 4 / max(s1, 1e-3)))), 1)
     out = {"value": e / s, "unit": "edges/s", "cores": cores, "kind": "port",
            "single_thread_edges_per_sec": e1 / s1,
-           "sample": f"{nb} batches of {B} seeds (same RMAT graph, same fan-out, sampling only, no gather), "
-                     f"{s:.1f} s on {cores} threads",
+           "sample": f"{nb} batches of {B} seeds (same RMAT graph, same fan-out, Legion semantics = the parity oracle's sampler, "
+                     f"sampling only, no gather), {s:.1f} s on {cores} threads",
            "dgl": dgl_note}
+
+    # DGL NeighborSampler semantics (without replacement, de-duplicated frontier, per-hop blocks) on the same seed batches:
+    # the baseline north_star names; its edge count is its own (SURVEY A.9), so is its edges/s
+    def timed_dgl(nb_, threads=cores):
+        secs = ctypes.c_double(0)
+        nodes = ctypes.c_int64(0)
+        ed_ = L.lgo_dgl_bench_batches(ffi._p(ip, ffi.P_I64), ffi._p(cl, ffi.P_I32), ffi._p(sd, ffi.P_I32), int(sd.size), B,
+                                      ffi._p(fan, ffi.P_I32), len(fanout), first_batch, nb_, threads, ctypes.byref(secs), ctypes.byref(nodes))
+        return int(ed_), secs.value, int(nodes.value)
+
+    try:
+        ed, sdg, nbd = sized(lambda n: timed_dgl(n)[:2], target_s)
+        ed1, sd1, _ = timed_dgl(int(max(4, min(256, 2.0 * 4 / max(timed_dgl(4, 1)[1], 1e-3)))), 1)
+        out["dgl_semantics"] = {"value": ed / sdg, "unit": "edges/s", "cores": cores, "kind": "dgl-semantics port",
+                                "single_thread_edges_per_sec": ed1 / sd1, "edges_per_batch": ed / nbd,
+                                "sample": f"{nbd} batches of {B} seeds (same graph, same seed batches, fan-out {fanout} from the seeds outward, "
+                                          f"uniform WITHOUT replacement over the de-duplicated frontier, per-hop blocks; sampling only), "
+                                          f"{sdg:.1f} s on {cores} threads",
+                                "note": "oracle/dgl_semantics.c: a restatement of dgl.dataloading.NeighborSampler's semantics, not DGL's "
+                                        "code (not installable here); a throughput reference, never a parity oracle"}
+    except Exception as ex:       # reported baseline only: never fail the bench over it
+        out["dgl_semantics"] = {"error": repr(ex)[:200]}
     # the whole path on the CPU (sampling + the oracle's row gather) when a host copy of the table is affordable
     try:
         import psutil

@@ -139,6 +139,8 @@ int32_t legion_cache_replica_rows(const LegionUnifiedCache* c, int32_t dev_id);
 void legion_cache_gather_stats(LegionUnifiedCache* c, int32_t dev_id, uint64_t* out2);
 /* same with out3[2] = the part of out3[0] that came from ANOTHER member's stripe (over xGMI between physical GPUs) */
 void legion_cache_gather_stats3(LegionUnifiedCache* c, int32_t dev_id, uint64_t* out3);
+/* pauses (0) / resumes (1) the counting: it costs the gather an atomic per hit row, so measurements count in an untimed pass */
+void legion_cache_gather_stats_enable(LegionUnifiedCache* c, int32_t on);
 /* SS/cache/cache.cu:360-443.  Hotness is summed over the clique on the clique leader through
  * peer pointers (one process, several GPUs); when `world_reduced` is non-zero the caller has
  * already all-reduced the counters across processes with RCCL and they are used as they are. */

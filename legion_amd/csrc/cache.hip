@@ -479,7 +479,7 @@ void UnifiedCache::FeatCacheLookup(const LanePtrs* d_lanes, int32_t n_lanes, int
     g.replica_rows = g.replica ? replica_rows_[dev_id] : 0;
     g.Kg = Kg_;
     g.member = dev_id % (Kg_ > 0 ? Kg_ : 1);
-    g.stats = (dev_id < (int32_t)gather_stats_.size()) ? gather_stats_[dev_id] : nullptr;
+    g.stats = (gather_stats_on_ && dev_id < (int32_t)gather_stats_.size()) ? gather_stats_[dev_id] : nullptr;
     g.full_table = cpu_float_features_;
     g.cache_tables = filled ? d_float_feature_cache_ptr_[dev_id] : nullptr;
     g.node_map = filled ? cache_controller_[dev_id]->NodeMap() : nullptr;
@@ -522,6 +522,12 @@ extern "C" void legion_cache_gather_stats(LegionUnifiedCache* c, int32_t dev_id,
     HIP_CALL(hipDeviceSynchronize());
     HIP_CALL(hipMemcpy(h, d, sizeof(h), hipMemcpyDeviceToHost));
     if (out2) { out2[0] = h[0]; out2[1] = h[1]; }
+}
+
+// counting costs the gather an atomic per hit row: a measurement switches it off again before anything is timed
+extern "C" void legion_cache_gather_stats_enable(LegionUnifiedCache* c, int32_t on)
+{
+    if (UnifiedCache* u = as_cache(c)) u->gather_stats_on_ = on != 0;
 }
 
 extern "C" void legion_cache_gather_stats3(LegionUnifiedCache* c, int32_t dev_id, uint64_t* out3)

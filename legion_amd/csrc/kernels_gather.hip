@@ -84,7 +84,10 @@ void launch_deliver(hipStream_t s, const LanePtrs* d_lane, const DeliverParams& 
     hipCheckError();
 }
 
-template <typename VecT, int ROWS = LG_GATHER_ROWS, int UNROLL = LG_GATHER_UNROLL>
+// VecT: float4 for rows that are multiples of 16 bytes; `v4u` -- the same 16 bytes per lane at 4-byte alignment -- for every other
+// width of at least 4 floats (gfx950 global loads / stores of 16 bytes need dword alignment only; the compiler emits
+// global_load_dwordx4 for both), with the D % 4 trailing floats of each row moved by a scalar pass (TAIL); float below that.
+template <typename VecT, int ROWS = LG_GATHER_ROWS, int UNROLL = LG_GATHER_UNROLL, bool TAIL = false>
 __global__ __launch_bounds__(LG_GATHER_THREADS) void gather_kernel(GatherParams gp, const LanePtrs* __restrict__ lanes,
                                                                    bool copy_range)
 {
@@ -189,6 +192,14 @@ __global__ __launch_bounds__(LG_GATHER_THREADS) void gather_kernel(GatherParams 
                 __builtin_nontemporal_store(v[u], (LG_G VecT*)(dst_tile + (int64_t)rr[u] * D) + cc[u]);
         }
     }
+    if (TAIL) {            // the last D % VEC floats of every row
+        const int32_t tail = D - C * VEC;
+        for (int32_t i = tid; i < nr * tail; i += LG_GATHER_THREADS) {
+            const int32_t tr = i / tail, k = C * VEC + (i - tr * tail);
+            const LG_G float* p = s_ptr[tr];
+            if (p != nullptr) dst_tile[(int64_t)tr * D + k] = p[k];
+        }
+    }
 }
 
 template <int ROWS>
@@ -203,15 +214,21 @@ static void launch_gather_impl(hipStream_t s, GatherParams g, const LanePtrs* d_
 {
     if (g.D <= 0 || g.max_rows <= 0) return;            // :256 float_feature_len > 0
     if (g.node_capacity < 1) g.node_capacity = 1;
-    const dim3 grid((g.max_rows + LG_GATHER_ROWS - 1) / LG_GATHER_ROWS, n_lanes);
-    typedef float v2 __attribute__((ext_vector_type(2)));
+    const dim3 grid((g.max_rows + LG_GATHER_ROWS - 1) / LG_GATHER_ROWS, n_lanes);     // (the 8- and 4-byte vector paths)
     const LegionTuning& tune = tuning();
     if (g.D % 4 == 0) {
         // rows per workgroup (LegionTuning.gather_rows_per_wg; 0 = the default below).  A launch of one or a few lanes (the
         // Runner's per-batch hand-over) has too few 64-row tiles to keep 256 CUs busy: 16-row tiles give it 4 x the
         // workgroups; a full lane group is indifferent to the tile size at D = 128
+        // Default for a full group: the tile whose payload is 32 KB (measured, profiles/r03/gather_experiments.txt: D = 256 with
+        // 32 rows 0.758 of peak against 0.727 with 64 and 0.720 with 128; D = 64 with 128 rows 0.710 against 0.685 with 64;
+        // D = 128 with 64 or 128 rows 0.776 / 0.777, with 32 rows 0.751)
         int rows = tune.gather_rows_per_wg;
-        if (rows <= 0) rows = (tune.gather_small_tiles && (int64_t)grid.x * n_lanes < 4096) ? 16 : LG_GATHER_ROWS;
+        if (rows <= 0) {
+            rows = 16;
+            while (rows < 256 && (int64_t)rows * 2 * g.D * 4 <= 32768 + 8192) rows *= 2;       // D = 100 -> 64, D = 602 -> 16
+            if (tune.gather_small_tiles && (int64_t)((g.max_rows + rows - 1) / rows) * n_lanes < 4096) rows = 16;
+        }
         switch (rows) {
             case 16: launch_gather_v4<16>(s, g, d_lanes, n_lanes, copy_range); break;
             case 32: launch_gather_v4<32>(s, g, d_lanes, n_lanes, copy_range); break;
@@ -219,9 +236,16 @@ static void launch_gather_impl(hipStream_t s, GatherParams g, const LanePtrs* d_
             case 256: launch_gather_v4<256>(s, g, d_lanes, n_lanes, copy_range); break;
             default: launch_gather_v4<64>(s, g, d_lanes, n_lanes, copy_range); break;
         }
-    } else if (g.D % 2 == 0)
-        gather_kernel<v2><<<grid, LG_GATHER_THREADS, 0, s>>>(g, d_lanes, copy_range);
-    else
+    } else if (g.D > 4) {
+        // rows that are not multiples of 16 bytes (D = 602: 2408-byte rows): 16-byte chunks at dword alignment + a scalar
+        // tail, instead of the 8- / 4-byte vector paths of rounds 1-2 (0.65 of peak at D = 602)
+        typedef float v4u __attribute__((ext_vector_type(4), aligned(4)));
+        const bool small = tune.gather_small_tiles && (int64_t)grid.x * n_lanes < 4096;
+        if (small || (int64_t)g.D * 4 * 64 > 65536)
+            gather_kernel<v4u, 16, LG_GATHER_UNROLL, true><<<dim3((g.max_rows + 15) / 16, n_lanes), LG_GATHER_THREADS, 0, s>>>(g, d_lanes, copy_range);
+        else
+            gather_kernel<v4u, LG_GATHER_ROWS, LG_GATHER_UNROLL, true><<<grid, LG_GATHER_THREADS, 0, s>>>(g, d_lanes, copy_range);
+    } else
         gather_kernel<float><<<grid, LG_GATHER_THREADS, 0, s>>>(g, d_lanes, copy_range);
     hipCheckError();
 }

@@ -477,6 +477,7 @@ public:
     void SetReplicaMemory(int64_t bytes) { replica_bytes_ = bytes; }
     int32_t ReplicaRows(int32_t dev_id) const { return replica_rows_.empty() ? 0 : replica_rows_[dev_id]; }
     int32_t FloatFeatureLen() const { return float_feature_len_; }
+    bool gather_stats_on_ = true;        // GatherStats() arms the counters; this pauses them (legion_cache_gather_stats_enable)
     unsigned long long* GatherStats(int32_t dev_id);   // device {stripe rows, replica rows, peer-stripe rows}, allocated on first use
     int32_t MaxIdNum(int32_t dev_id);
     unsigned long long int* GetEdgeAccessedMap(int32_t dev_id);

@@ -422,6 +422,9 @@ class UnifiedCache:
         self._lib.legion_cache_gather_stats3(self.handle, int(dev_id), out)
         return int(out[0]), int(out[1]), int(out[2])
 
+    def gather_stats_enable(self, on):
+        self._lib.legion_cache_gather_stats_enable(self.handle, 1 if on else 0)
+
     def peer_transactions(self, dev_id=0):
         """64-byte transactions read from other members' stripes so far (the computed stand-in for the xGMI counter)."""
         return int(self._lib.legion_cache_peer_transactions(self.handle, int(dev_id)))

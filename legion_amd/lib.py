@@ -110,6 +110,7 @@ SIGNATURES = {
     "legion_link_counters_ex": (c_i32, [c_i32, c_p]),
     "legion_cache_peer_transactions": (ctypes.c_uint64, [c_p, c_i32]),
     "legion_cache_gather_stats3": (None, [c_p, c_i32, P_U64]),
+    "legion_cache_gather_stats_enable": (None, [c_p, c_i32]),
     # 6. tuning
     "legion_tuning_from_env": (None, []),
     "legion_tuning_get": (None, [c_p]),

@@ -65,7 +65,8 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
-    if not os.path.exists(LIB_PATH):
+    srcs = [os.path.join(HERE, f) for f in ("legion_oracle.c", "dgl_semantics.c", "legion_oracle.h")]
+    if not os.path.exists(LIB_PATH) or any(os.path.getmtime(f) > os.path.getmtime(LIB_PATH) for f in srcs):
         build()
     L = ctypes.CDLL(LIB_PATH)
     PP, PG, PC = ctypes.POINTER(Pool), ctypes.POINTER(Graph), ctypes.POINTER(Cache)
@@ -97,6 +98,10 @@ def load():
         "lgo_current_batchsize": (c_i32, [ctypes.POINTER(Steps), c_i32, c_i32]),
         "lgo_bench_batches": (c_i64, [PG, c_i32, P_I32, c_i32, c_i32, P_I32, c_i32, c_i32, c_i32, c_i32, P_F32,
                                       c_i32, ctypes.POINTER(ctypes.c_double), P_I64]),
+        # dgl_semantics.c: the DGL-semantics throughput baseline (no parity role)
+        "lgo_dgl_sample_batch": (c_i64, [P_I64, P_I32, P_I32, c_i32, P_I32, c_i32, c_u64, P_I64, P_I32, P_I32, P_I32, P_I32]),
+        "lgo_dgl_bench_batches": (c_i64, [P_I64, P_I32, P_I32, c_i32, c_i32, P_I32, c_i32, c_i32, c_i32, c_i32,
+                                          ctypes.POINTER(ctypes.c_double), P_I64]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(L, name)

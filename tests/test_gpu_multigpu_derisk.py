@@ -52,6 +52,28 @@ def test_scale_command_line_two_ranks_on_one_gpu(hip, stripe):
     assert ("striped" in d["config"]["parallelism"]) == stripe
     assert "cpu_baseline" not in d                      # N = 1 only
     assert (d["overlapped"] is None) == stripe and (stripe or d["overlapped"]["value"] > 0)
+    # the line is its own evidence of what ran on how many ranks: the world size as an all-reduce of
+    # ones saw it, the one collective of the path timed, and what every rank measured for itself
+    col = d["collective"]
+    assert col["backend"] == "gloo" and col["world_size_seen_by_all_reduce"] == 2
+    assert col["hotness_all_reduce_ms"] > 0 and col["hotness_all_reduce_bytes"] == 2 * (1 << 18) * 8
+    assert [r["rank"] for r in d["per_rank"]] == [0, 1]
+    for r in d["per_rank"]:
+        assert r["pci_bus_id"] and r["edges_per_sec"] > 0 and 0 < r["gather_roofline_frac"] < 1
+    assert abs(sum(r["edges_per_sec"] for r in d["per_rank"]) / d["value"] - 1) < 0.5      # (own clocks vs the slowest rank's)
+    legs = [d] if stripe else [d["striped"], d["striped_replica"]]
+    for leg in legs:                                     # the striped clique: rows by where the gather read them
+        assert "striped" in (leg["config"]["parallelism"] if stripe else leg["parallelism"]) and leg["value"] > 0
+        assert leg["roofline"]["frac"] > 0
+        for r in leg["per_rank"]:
+            assert r["rows_from_peer_stripes"] + r["rows_from_own_stripe"] + r["rows_from_local_replica"] <= r["rows_gathered"]
+            assert r["peer_bytes_per_region_computed"] == r["rows_from_peer_stripes"] * 128 * 4
+    if not stripe:
+        plain, repl = d["striped"]["per_rank"], d["striped_replica"]["per_rank"]
+        assert d["striped_replica"]["hot_row_replica_rows"] > 0 and d["striped"]["hot_row_replica_rows"] == 0
+        for a, b in zip(plain, repl):                    # the replica takes hit rows away from the stripes, peers' included
+            assert a["rows_from_peer_stripes"] > 0 and a["rows_from_local_replica"] == 0 and b["rows_from_local_replica"] > 0
+            assert b["rows_from_peer_stripes"] < a["rows_from_peer_stripes"]
     one = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1"] + SMALL, cwd=ROOT,
                          stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
     assert one.returncode == 0, one.stderr[-4000:]

@@ -323,7 +323,8 @@ def test_hot_row_replica_keeps_results_and_saves_peer_reads(hip, P, mode_bits, c
             hit = gslot[gslot >= 0]
             rank = (hit % capacity[0]) * Kg + hit // capacity[0]
             from_peer += int(((hit // capacity[0] != p % Kg) & (rank >= want_rows)).sum())
-        assert gpu.cache.gather_stats3(p) == (stripe, replica, from_peer) and 0 < from_peer <= stripe
+        assert gpu.cache.gather_stats3(p) == (stripe, replica, from_peer) and from_peer <= stripe
+        assert from_peer > 0 or want_rows >= capacity[0] * Kg          # (everything replicated: nothing left to read from a peer)
         assert gpu.cache.peer_transactions(p) == from_peer * wl.D * 4 // 64
     gpu.close(); cpu.close()
 

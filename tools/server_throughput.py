@@ -15,7 +15,7 @@ from legion_amd import synth  # noqa: E402
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--scale", type=int, default=22)
-    ap.add_argument("--batch", type=int, default=8000)
+    ap.add_argument("--batch", type=str, default="8000", help="one batch size or a comma list (one server run and one JSON line each, same data set)")
     ap.add_argument("--dim", type=int, default=128)
     ap.add_argument("--fanout", type=str, default="25,10")
     ap.add_argument("--train-batches", type=int, default=60)
@@ -28,35 +28,55 @@ def main():
     ap.add_argument("--consumer", type=str, default="python", choices=["python", "native"],
                     help="python: the ipc_service extension as a trainer would use it (get_next -> synchronize); "
                          "native: tools/boundary_consumer.c, the wire protocol with nothing else (what the server can hand over)")
+    ap.add_argument("--no-features-file", action="store_true",
+                    help="do not write the `features` file: the server then serves a zero-filled table of the same shape (v2 of the "
+                         "reference reads no features either, storage_management.cu:162); a 34 GB file is too slow to write for a "
+                         "throughput run at RMAT-26, the traffic is the same")
+    ap.add_argument("--edge-factor", type=int, default=16)
     ap.add_argument("--watchdog", type=int, default=0, help="seconds after which the tool dumps its stack and the server log and exits")
     a = ap.parse_args()
     if a.watchdog:
         import faulthandler
         faulthandler.dump_traceback_later(a.watchdog, exit=False)
     fanout = [int(x) for x in a.fanout.split(",")]
+    batches = [int(x) for x in a.batch.split(",")]
     dev = torch.device("cuda:0")
     N = 1 << a.scale
-    indptr, col = synth.rmat_csr_device(a.scale, 16, 20231, dev)
-    feats = synth.features_device(N, a.dim, 7, dev)
-    train = synth.seed_ids(N, a.batch * a.train_batches + 1, 11).astype(np.int32)
-    valid, test = train[:a.batch], train[:a.batch]
+    indptr, col = synth.rmat_csr_device(a.scale, a.edge_factor, 20231, dev)
+    tb = {b: (a.train_batches if len(batches) == 1 else max(64, min(a.train_batches, a.train_batches * batches[0] // b))) for b in batches}
+    train = synth.seed_ids(N, max(b * tb[b] for b in batches) + 1, 11).astype(np.int32)
     tmp = tempfile.mkdtemp(prefix="legion_srv_", dir="/tmp")
     ds = os.path.join(tmp, "ds") + "/"
     os.makedirs(ds)
     indptr.cpu().numpy().astype(np.int64).tofile(ds + "edge_src")
     col.cpu().numpy().astype(np.int32).tofile(ds + "edge_dst")
-    feats.cpu().numpy().tofile(ds + "features")
+    if not a.no_features_file:
+        feats = synth.features_device(N, a.dim, 7, dev)
+        feats.cpu().numpy().tofile(ds + "features")
+        del feats
     (np.arange(N) % 47).astype(np.int32).tofile(ds + "labels")
-    train.tofile(ds + "trainingset"); valid.tofile(ds + "validationset"); test.tofile(ds + "testingset")
+    train.tofile(ds + "trainingset")
     E = int(col.numel())
-    del indptr, col, feats
+    del indptr, col
     torch.cuda.empty_cache()
-    work = os.path.join(tmp, "run")
+    try:
+        for b in batches:
+            n_train = b * tb[b] + 1
+            train[:b].tofile(ds + "validationset"); train[:b].tofile(ds + "testingset")
+            run_one(a, ds, tmp, b, n_train, train, fanout, N, E)
+    finally:
+        subprocess.call(["rm", "-rf", tmp])
+
+
+def run_one(a, ds, tmp, batch, n_train, train, fanout, N, E):
+    work = os.path.join(tmp, f"run_b{batch}")
     os.makedirs(work)
     open(os.path.join(work, "meta_config"), "w").write("{} {} {} {} {} {} {} {} {} {}".format(
-        ds, a.batch, N, E, a.dim, train.size, valid.size, test.size, a.cache_memory, a.epochs))
+        ds, batch, N, E, a.dim, n_train, batch, batch, a.cache_memory, a.epochs))
     ns = f"_b{os.getpid()}"
     os.environ["LEGION_IPC_NAMESPACE"] = ns
+    workload = f"RMAT-{a.scale} EF{a.edge_factor}, D={a.dim}, batch {batch}, fanout {fanout}, train mode, 1 GPU" + \
+               (", zero-filled feature table (no `features` file)" if a.no_features_file else "")
     log = open(os.path.join(work, "server.log"), "w")
     server = subprocess.Popen([os.path.join(ROOT, "legion_amd", "bin", "sampling_server"), "1", "0"] + [str(f) for f in fanout],
                               cwd=work, env=dict(os.environ), stdout=log, stderr=subprocess.STDOUT)
@@ -76,9 +96,9 @@ def main():
                 if line.startswith("runner "):
                     print(line.strip(), file=sys.stderr)
             res = json.loads(out)
-            res.update({"path": "sampling_server binary -> shm/semaphores -> protocol-only consumer (counters from the slab mirror)",
-                        "workload": f"RMAT-{a.scale} EF16, D={a.dim}, batch {a.batch}, fanout {fanout}, train mode, 1 GPU"})
-            print(json.dumps(res))
+            res.update({"path": "sampling_server binary -> shm/semaphores -> protocol-only consumer (counters from the server's host-visible mirror)",
+                        "workload": workload, "batch": batch})
+            print(json.dumps(res), flush=True)
             return
         import ipc_service
         torch.cuda.set_device(0)
@@ -102,13 +122,14 @@ def main():
                 ids, fts = out[0], out[1]
                 n = int(ids.numel())
                 assert n > 0 and tuple(fts.shape) == (n, a.dim)
-                assert synth.feature_check_device(fts.contiguous(), ids.contiguous(), a.dim, 7) == 0, f"batch {i}: rows differ"
+                if not a.no_features_file:
+                    assert synth.feature_check_device(fts.contiguous(), ids.contiguous(), a.dim, 7) == 0, f"batch {i}: rows differ"
                 assert int(torch.unique(ids).numel()) == n, f"batch {i}: duplicate ids"
                 sizes = ipc_service.get_block_size()
                 assert sizes[0] == n and int(out[3].max()) < n and int(out[4].max()) < sizes[1], f"batch {i}: edge endpoints"
-                seeds_expected = torch.from_numpy(train[i * a.batch:(i + 1) * a.batch]).cuda() if (i < tr and a.epochs == 1) else None
+                seeds_expected = torch.from_numpy(train[i * batch:(i + 1) * batch]).cuda() if (i < tr and a.epochs == 1) else None
                 if seeds_expected is not None:
-                    assert bool((ids[:a.batch] == seeds_expected).all()), f"batch {i}: not the seeds of training batch {i}"
+                    assert bool((ids[:batch] == seeds_expected).all()), f"batch {i}: not the seeds of training batch {i}"
                 verified += 1
             del out
             ipc_service.synchronize()
@@ -118,9 +139,9 @@ def main():
         server.wait(timeout=120)
         dt = t1 - t0
         print(json.dumps({"path": "sampling_server binary -> shm/semaphores/IPC handles -> ipc_service consumer",
-                          "workload": f"RMAT-{a.scale} EF16, D={a.dim}, batch {a.batch}, fanout {fanout}, train mode, 1 GPU",
+                          "workload": workload, "batch": batch,
                           "batches_per_sec": n_timed / dt, "edges_per_sec": edges / dt, "timed_batches": n_timed,
-                          "ms_per_batch": dt / n_timed * 1e3, "verified_batches": verified}))
+                          "ms_per_batch": dt / n_timed * 1e3, "verified_batches": verified}), flush=True)
     finally:
         if server.poll() is None:
             server.kill()
@@ -130,7 +151,6 @@ def main():
         for name in os.listdir("/dev/shm"):
             if name.endswith(ns):
                 os.unlink(os.path.join("/dev/shm", name))
-        subprocess.call(["rm", "-rf", tmp])
 
 
 if __name__ == "__main__":
