@@ -82,6 +82,11 @@ LegionGraphStorage* legion_graph_create(int32_t partition_count, int32_t node_nu
                                         const int64_t* csr_node_index_devptr,
                                         const int32_t* csr_dst_node_ids_devptr);
 void legion_graph_destroy(LegionGraphStorage* g);
+/* New in this build ("column slots", LegionTuning.col_slots): after FillUp every GPU may hold a copy of the full column array
+ * whose entries are {neighbour id, feature-cache slot of that neighbour} pairs.  The sampler's scattered pick reads the pair in
+ * the one sector it fetches anyway, and the gather no longer looks the row's cache slot up (a 128-byte line per row for four
+ * bytes: SS/cache/cache.cu:180-215 does it with a hash find per row).  Results are unchanged.  Returns 1 when GPU dev has it. */
+int32_t legion_graph_column_slots(const LegionGraphStorage* g, int32_t dev);
 
 /* FeatureStorage: SS/storage/feature_storage.cu:18-90.  ids/labels are HOST arrays copied to
  * device `dev_id`; mode selects the training / validation / testing set. */
@@ -352,6 +357,9 @@ typedef struct LegionTuning {
     int32_t sample_max_wg;       /* LEGION_SAMPLE_MAX_WG   (4096): workgroup cap of the strided sampler grids */
     int32_t gather_small_tiles;  /* LEGION_GATHER_SMALL_TILES (1): 16-row tiles for launches of fewer than 4096 tiles */
     int32_t gather_rows_per_wg;  /* LEGION_GATHER_ROWS     (0 = by row width): rows per gather workgroup, 16|32|64|128|256 */
+    int32_t col_slots;           /* LEGION_COL_SLOTS       (-1 auto): the {neighbour id, feature-cache slot} copy of the column array that
+                                    lets the gather skip its node_map lookup (8 B per edge of HBM per GPU): 1 always, 0 never,
+                                    -1 when the column array is device memory and the copy fits a quarter of the free HBM */
     int32_t split_sampler_cus;   /* LEGION_SPLIT_SAMPLER_CUS (0 = no CU mask): CUs of the sampler stream in split mode */
     int32_t split_priority;      /* LEGION_SPLIT_PRIORITY  (1): split mode, 1 sampler stream first, 0 equal, -1 gathers first */
     int32_t runner_graph;        /* LEGION_RUNNER_GRAPH    (1): Runner serves from lane groups + hipGraph; 0 = operator by operator */

@@ -446,6 +446,8 @@ void UnifiedCache::FillUpLink(FeatureStorage* feature, GraphStorage* graph)
         if (!lg_is_local(i)) continue;
         SetGPUDevice(i);
         HIP_CALL(hipDeviceSynchronize());
+        // column slots: with the id -> slot map of this GPU final, pair the column array with it (legion_core.h, GraphStorage)
+        if (QF_[i / Kg_] != nullptr && float_feature_len_ > 0) graph->BuildColumnSlots(i, cache_controller_[i]->NodeMap());
     }
 }
 

@@ -138,6 +138,27 @@ __global__ void init_node_map_kernel(int32_t* __restrict__ node_map, const int32
         node_map[QF[t]] = (int32_t)((t % Kg) * capacity + t / Kg);
 }
 
+// column slots (legion_core.h, GraphStorage): pair every column entry with the feature-cache slot of the neighbour it names
+__global__ void build_column_slots_kernel(const int32_t* __restrict__ col, const int32_t* __restrict__ node_map,
+                                          int32_t* __restrict__ pairs, int64_t num_edges)
+{
+    typedef int32_t v2i __attribute__((ext_vector_type(2)));
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < num_edges; e += (int64_t)gridDim.x * blockDim.x) {
+        const int32_t id = col[e];
+        v2i v;
+        v.x = id;
+        v.y = id >= 0 ? node_map[id] : CACHEMISS_FLAG;
+        ((v2i*)pairs)[e] = v;
+    }
+}
+
+void build_column_slots(hipStream_t s, const int32_t* col, const int32_t* node_map, int32_t* colx_pairs, int64_t num_edges)
+{
+    if (num_edges <= 0) return;
+    build_column_slots_kernel<<<8192, 256, 0, s>>>(col, node_map, colx_pairs, num_edges);
+    hipCheckError();
+}
+
 void init_node_map(hipStream_t s, int32_t* node_map, const int32_t* QF, int32_t capacity, int32_t Kg,
                    int32_t n)
 {

@@ -137,8 +137,13 @@ __global__ __launch_bounds__(LG_GATHER_THREADS) void gather_kernel(GatherParams 
     const int32_t nr = min(ROWS, rows - r0);
     for (int32_t t = tid; t < nr; t += LG_GATHER_THREADS) {
         const int32_t id = sampled_ids[off + r0 + t];
-        int32_t g = CACHEMISS_FLAG;
-        if (gp.node_map != nullptr && id >= 0) g = gp.node_map[id];
+        // the row's feature-cache slot: carried from the sampler where the column slots are in use (a coalesced read), else --
+        // seeds, rows sampled from a cached-topology CSR, no column slots -- the FindFeat lookup (a 128-byte line per row)
+        int32_t g = (L.node_slot != nullptr && gp.node_map != nullptr) ? LG_GPTR(const int32_t, L.node_slot)[off + r0 + t] : LG_FS_UNKNOWN;
+        if (g == LG_FS_UNKNOWN) {
+            g = CACHEMISS_FLAG;
+            if (gp.node_map != nullptr && id >= 0) g = gp.node_map[id];
+        }
         cache_search_buffer[r0 + t] = g;             // FindFeat writes from index 0 each hop
         const LG_G float* p = nullptr;
         if (g < 0) {

@@ -100,7 +100,7 @@ void launch_draw_batch(hipStream_t s, const int32_t* idx, const int32_t* deg, in
 // the per-batch buffers the two bracket kernels touch, as global-address-space pointers
 struct BracketLane {
     LG_G int32_t* sampled_ids; LG_G int32_t* labels; LG_G int32_t* node_counter; LG_G int32_t* edge_counter;
-    LG_G int32_t* hop_scratch; LG_G uint32_t* position_map; LG_G int32_t* slot_mark;
+    LG_G int32_t* hop_scratch; LG_G uint32_t* position_map; LG_G int32_t* slot_mark; LG_G int32_t* node_slot;
     LG_G unsigned long long* pos_table; uint32_t pos_mask; LG_G int32_t* err_flag;
     LG_G int32_t* known_cnt; int32_t lds_buckets;
     int32_t total_num_nodes, max_slots;
@@ -111,7 +111,7 @@ __device__ __forceinline__ BracketLane bracket_lane(const LanePtrs& P)
     L.sampled_ids = LG_GPTR(int32_t, P.sampled_ids); L.labels = LG_GPTR(int32_t, P.labels);
     L.node_counter = LG_GPTR(int32_t, P.node_counter); L.edge_counter = LG_GPTR(int32_t, P.edge_counter);
     L.hop_scratch = LG_GPTR(int32_t, P.hop_scratch); L.position_map = LG_GPTR(uint32_t, P.position_map);
-    L.slot_mark = LG_GPTR(int32_t, P.slot_mark);
+    L.slot_mark = LG_GPTR(int32_t, P.slot_mark); L.node_slot = LG_GPTR(int32_t, P.node_slot);
     L.pos_table = LG_GPTR(unsigned long long, P.pos_table); L.pos_mask = P.pos_table_mask;
     L.err_flag = LG_GPTR(int32_t, P.err_flag);
     L.known_cnt = LG_GPTR(int32_t, P.known_cnt); L.lds_buckets = P.lds_buckets;
@@ -204,6 +204,7 @@ __global__ void batch_generate_kernel(SeedParams p, const LanePtrs* __restrict__
         } else {
             const int32_t src_id = p.all_ids[at % p.total_cap];
             L.sampled_ids[idx] = src_id;
+            if (L.node_slot != nullptr) L.node_slot[idx] = LG_FS_UNKNOWN;     // seeds: the gather looks their cache slots up
             const PosFmt pf = lg_pos_fmt(L.hop_scratch[HS_EPOCH], L.hop_scratch[HS_VALUE_BITS]);
             if (L.pos_table != nullptr)
                 table_claim(L.pos_table, L.pos_mask, pf, src_id, (uint32_t)idx, nullptr, nullptr, 0, L.hop_scratch, L.err_flag);
@@ -229,6 +230,7 @@ void launch_batch_generate(hipStream_t s, const SeedParams& p, const LanePtrs* d
 struct SampleArgs {
     int32_t op_id, count, partition_count, max_slots;
     int32_t* const* csr_dst_node_ids;
+    int32_t* const* csr_dst_x;
     const LG_G RowHdr* row_hdr;
     bool last_hop, is_presc;
     LG_G unsigned long long* edge_access_time;
@@ -236,7 +238,7 @@ struct SampleArgs {
     // the lane's buffers, in the global address space (see LG_G in legion_core.h)
     LG_G int32_t* sampled_ids; LG_G int32_t* agg_src_ids; LG_G int32_t* agg_dst_ids; LG_G int32_t* agg_src_off; LG_G int32_t* agg_dst_off;
     LG_G char* tmp_part_ind; LG_G uint32_t* position_map; LG_G int32_t* node_counter; LG_G int32_t* edge_counter;
-    LG_G int32_t* slot_dst; LG_G int32_t* slot_pos; LG_G int32_t* slot_mark; LG_G int32_t* tile_counts; LG_G int32_t* tile_prefix; LG_G int32_t* hop_scratch;
+    LG_G int32_t* slot_dst; LG_G int32_t* slot_pos; LG_G int32_t* slot_mark; LG_G int32_t* slot_fs; LG_G int32_t* node_slot; LG_G int32_t* tile_counts; LG_G int32_t* tile_prefix; LG_G int32_t* hop_scratch;
     LG_G RowHdr* fh_edge;
     LG_G unsigned long long* pos_table; uint32_t pos_mask; LG_G int32_t* err_flag;
     LG_G unsigned long long* claim_pairs; LG_G int32_t* run_off;
@@ -248,6 +250,7 @@ struct SampleArgs {
 // 16-byte header load / store through a global-address-space pointer (no implicit struct copy across
 // address spaces in HIP C++)
 typedef int32_t lg_v4i __attribute__((ext_vector_type(4)));
+typedef int32_t lg_v2i __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ RowHdr load_hdr(const LG_G RowHdr* p)
 {
     const lg_v4i t = *(const LG_G lg_v4i*)p;
@@ -272,7 +275,7 @@ __device__ __forceinline__ SampleArgs lane_args(const HopParams& p, const LanePt
     const LanePtrs& L = lanes[blockIdx.y];
     SampleArgs a;
     a.op_id = p.op_id; a.count = p.count; a.partition_count = p.partition_count; a.max_slots = p.max_slots;
-    a.csr_dst_node_ids = p.csr_dst_node_ids; a.row_hdr = LG_GPTR(const RowHdr, p.row_hdr); a.last_hop = p.last_hop; a.is_presc = p.is_presc;
+    a.csr_dst_node_ids = p.csr_dst_node_ids; a.csr_dst_x = p.csr_dst_x; a.row_hdr = LG_GPTR(const RowHdr, p.row_hdr); a.last_hop = p.last_hop; a.is_presc = p.is_presc;
     a.edge_access_time = LG_GPTR(unsigned long long, p.edge_access_time);
     a.topo_transactions = LG_GPTR(unsigned long long, p.topo_transactions);
     a.sampled_ids = LG_GPTR(int32_t, L.sampled_ids); a.agg_src_ids = LG_GPTR(int32_t, L.agg_src_ids);
@@ -280,7 +283,8 @@ __device__ __forceinline__ SampleArgs lane_args(const HopParams& p, const LanePt
     a.agg_dst_off = LG_GPTR(int32_t, L.agg_dst_off); a.tmp_part_ind = LG_GPTR(char, L.tmp_part_ind);
     a.position_map = LG_GPTR(uint32_t, L.position_map); a.node_counter = LG_GPTR(int32_t, L.node_counter);
     a.edge_counter = LG_GPTR(int32_t, L.edge_counter); a.slot_dst = LG_GPTR(int32_t, L.slot_dst);
-    a.slot_pos = LG_GPTR(int32_t, L.slot_pos); a.slot_mark = LG_GPTR(int32_t, L.slot_mark); a.tile_counts = LG_GPTR(int32_t, L.tile_counts);
+    a.slot_pos = LG_GPTR(int32_t, L.slot_pos); a.slot_mark = LG_GPTR(int32_t, L.slot_mark);
+    a.slot_fs = LG_GPTR(int32_t, L.slot_fs); a.node_slot = LG_GPTR(int32_t, L.node_slot); a.tile_counts = LG_GPTR(int32_t, L.tile_counts);
     a.tile_prefix = LG_GPTR(int32_t, L.tile_prefix); a.hop_scratch = LG_GPTR(int32_t, L.hop_scratch);
     a.fh_edge = LG_GPTR(RowHdr, L.fh_edge);
     a.pos_table = LG_GPTR(unsigned long long, L.pos_table); a.pos_mask = L.pos_table_mask;
@@ -399,18 +403,27 @@ __global__ __launch_bounds__(LG_TILE) void sample_kernel(HopParams hp, const Lan
             __syncthreads();
 
             if (FORM == 2 && SINGLE && tid < NB) s_bcnt[tid] = 0;     // (made visible by the barrier above the loads' use below)
-            int32_t dst[LG_SLOTS_PER_LANE];
+            int32_t dst[LG_SLOTS_PER_LANE], fs[LG_SLOTS_PER_LANE];
 #pragma unroll
             for (int u = 0; u < LG_SLOTS_PER_LANE; u++) {
                 const int32_t idx = idx0 + u * LG_TILE + tid;
                 dst[u] = -1;
+                fs[u] = LG_FS_UNKNOWN;
                 if (idx < g.total) {
                     const int32_t q = idx / count;
                     const int32_t k = idx - q * count;
                     const RowHdr h = s_hdr[q - j0];
                     if (k < h.deg) {                                           // :232-233 (src < 0 has deg 0)
                         const int32_t pick = draw_from_x(x[u], h.deg);         // :235-238
-                        dst[u] = LG_GPTR(const int32_t, a.csr_dst_node_ids[h.slot])[h.start + (int64_t)pick];   // :239-243
+                        // column slots: the same sector read as 8 bytes brings the neighbour's feature-cache slot along
+                        const LG_G lg_v2i* cx = a.csr_dst_x != nullptr ? LG_GPTR(const lg_v2i, a.csr_dst_x[h.slot]) : nullptr;
+                        if (cx != nullptr) {
+                            const lg_v2i e = cx[h.start + (int64_t)pick];
+                            dst[u] = e.x;
+                            fs[u] = e.y;
+                        } else {
+                            dst[u] = LG_GPTR(const int32_t, a.csr_dst_node_ids[h.slot])[h.start + (int64_t)pick];   // :239-243
+                        }
                     }
                 }
             }
@@ -457,6 +470,7 @@ __global__ __launch_bounds__(LG_TILE) void sample_kernel(HopParams hp, const Lan
                         dst[u] = -1;
                     }
                     a.slot_dst[idx] = dst[u];
+                    if (a.slot_fs != nullptr) a.slot_fs[idx] = fs[u];
                 }
             }
             if (FORM == 2 && SINGLE) {
@@ -869,7 +883,7 @@ __global__ __launch_bounds__(LG_TILE) void scatter_kernel(HopParams hp, const La
         // phase 1: every load of the thread's four slots (nothing is stored in between, so they are all
         // in flight together: the buffers may alias as far as the compiler knows)
         int32_t e_at[LG_SLOTS_PER_LANE], n_at[LG_SLOTS_PER_LANE], src_of[LG_SLOTS_PER_LANE], src_pos[LG_SLOTS_PER_LANE];
-        int32_t lost_pos[LG_SLOTS_PER_LANE];
+        int32_t lost_pos[LG_SLOTS_PER_LANE], fsv[LG_SLOTS_PER_LANE];
         uint32_t tab_at[LG_SLOTS_PER_LANE];
         RowHdr nh[LG_SLOTS_PER_LANE];
 #pragma unroll
@@ -890,6 +904,7 @@ __global__ __launch_bounds__(LG_TILE) void scatter_kernel(HopParams hp, const La
                 src_pos[u] = seeds ? q : a.agg_src_off[f_off + q];
                 if (!a.last_hop) nh[u] = load_hdr(a.row_hdr + dst);      // next hop's frontier header
                 lost_pos[u] = first ? 0 : a.slot_pos[idx];               // final already, or -2 - (slot it lost to)
+                fsv[u] = (first && a.slot_fs != nullptr) ? a.slot_fs[idx] : LG_FS_UNKNOWN;   // the new node's feature-cache slot, if carried
                 tab_at[u] = (first && !a.last_hop && a.pos_table != nullptr) ? table_find(a.pos_table, a.pos_mask, a.pf, dst) : 0u;
             }
         }
@@ -907,6 +922,7 @@ __global__ __launch_bounds__(LG_TILE) void scatter_kernel(HopParams hp, const La
             const int32_t n = n_at[u];
             if (n >= 0) {
                 a.sampled_ids[n] = dst;                            // :270
+                if (a.node_slot != nullptr) a.node_slot[n] = fsv[u];
                 // :271 -- later hops look the position up in the state array; after the last hop nobody
                 // does, and same-hop duplicates resolve through slot_pos (a small, cache-resident array)
                 if (!a.last_hop) {

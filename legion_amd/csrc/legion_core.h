@@ -181,6 +181,10 @@ enum HopScratch {
 #define LG_PHASE_HEAD 3     // BatchGenerate + every hop but the last, complete: small, latency-bound kernels
 #define LG_PHASE_REST 4     // the last hop (sample .. localise) + IOComplete + every gather, in that order
 
+// Feature-cache slot of a sampled neighbour, carried from the sampler to the gather (see "column slots", GraphStorage):
+// a value >= 0 or CACHEMISS_FLAG is what node_map[id] holds; LG_FS_UNKNOWN means "not carried: look it up"
+#define LG_FS_UNKNOWN (-3)
+
 #define LG_TILE 256            // compaction tile == threads per workgroup in the sampler kernels
 #define LG_SLOTS_PER_LANE 4    // independent slots each lane keeps in flight
 #define LG_SUPER (LG_TILE * LG_SLOTS_PER_LANE)   // slots one workgroup owns per iteration
@@ -244,6 +248,9 @@ struct LanePtrs {
     int32_t* slot_dst;
     int32_t* slot_pos;
     int32_t* slot_mark;
+    int32_t* slot_fs;                  // [max_slots] feature-cache slot of the slot's sampled neighbour, or LG_FS_UNKNOWN (column slots)
+    int32_t* node_slot;                // [num_ids] the same per node of the batch, by position in sampled_ids: what the gather reads
+                                       // instead of node_map[id] (one 128-byte line per row for 4 bytes)
     int32_t* tile_counts;
     int32_t* tile_prefix;
     int32_t* hop_scratch;
@@ -306,6 +313,8 @@ public:
     int32_t* slot_dst = nullptr;       // [max_slots] sampled neighbour per slot (sign bit = first touch)
     int32_t* slot_pos = nullptr;       // [max_slots] what the position state held for that neighbour
     int32_t* slot_mark = nullptr;      // [max_slots] (epoch, hop) tag of the hop in which the slot lost its first touch
+    int32_t* slot_fs = nullptr;        // [max_slots] / [num_ids]: feature-cache slots carried from the sampler to the gather
+    int32_t* node_slot = nullptr;
     int32_t* tile_counts = nullptr;    // [2 * max_tiles] valid / first-touch counts per tile
     int32_t* tile_prefix = nullptr;    // [2 * max_tiles] exclusive prefixes
     RowHdr* fh_edge = nullptr;         // [num_ids] frontier row headers written by scatter
@@ -382,6 +391,16 @@ public:
     virtual int32_t NodeNum() const = 0;
     virtual int64_t EdgeNum() const = 0;
     virtual const RowHdr* GetRowHeaders(int32_t part_id) const = 0;   // new: [N] per GPU
+    // "Column slots" (new): a copy of the full column array in which every entry is the pair {neighbour id, feature-cache
+    // slot of that neighbour = node_map[id]} (8 bytes).  The sampler's scattered 4-byte pick costs a whole 64-byte sector
+    // either way; read as 8 bytes it brings the neighbour's cache slot along for free, and the gather no longer fetches a
+    // 128-byte line of node_map per row (measured: 10 % of the hop-2 gather's traffic at D = 128, 19 % at D = 64).  Built per
+    // GPU after FillUp from that GPU's node_map (which is what makes it clique-specific), only when the column array is
+    // device memory and 8 bytes per edge are affordable (LegionTuning.col_slots); slots of cached-topology CSRs are not
+    // paired: their picks carry LG_FS_UNKNOWN and the gather looks those rows up as before.
+    virtual int32_t** GetCSRXMatrix(int32_t part_id) const = 0;       // device table [P+1] of pair arrays (null entries), or null
+    virtual void BuildColumnSlots(int32_t dev, const int32_t* node_map) = 0;
+    virtual void DropColumnSlots(int32_t dev) = 0;
     // GraphCache in two steps, so that a clique spread over processes can exchange the stripes in
     // between: build the cached CSR of every LOCAL member, then link every known member's CSR into the
     // local members' pointer tables and row headers.  SetPeerCSR registers a member owned by another
@@ -647,6 +666,7 @@ struct HopParams {                  // what every lane of a launch shares
     int32_t count;                  // fan-out of this hop
     int32_t partition_count;        // P: slot of the full CSR in the pointer tables
     int32_t* const* csr_dst_node_ids;   // device table [P+1] of column arrays
+    int32_t* const* csr_dst_x;          // device table [P+1] of {id, feature-cache slot} pair arrays (column slots), or null
     const RowHdr* row_hdr;          // [N] per-vertex row headers of this GPU
     bool last_hop;                  // no next hop: scatter skips the header lookup
     bool is_presc;
@@ -725,6 +745,7 @@ void init_node_map(hipStream_t s, int32_t* node_map, const int32_t* QF, int32_t 
 void init_edge_maps(hipStream_t s, char* index_map, int32_t* offset_map, const int32_t* QT,
                     int32_t capacity, int32_t Kg, int32_t Ki, int32_t n);
 void fill_value_i32(hipStream_t s, int32_t* p, int32_t v, int64_t n);
+void build_column_slots(hipStream_t s, const int32_t* col, const int32_t* node_map, int32_t* colx_pairs, int64_t num_edges);
 void fill_value_i8(hipStream_t s, char* p, char v, int64_t n);
 void feat_fill_up(hipStream_t s, int32_t capacity, int32_t D, float* cache, const float* table,
                   const int32_t* QF, int32_t Kg, int32_t Ki, int32_t n);

@@ -110,6 +110,7 @@ static void do_random_sample(hipStream_t s, GraphStorage* graph, UnifiedCache* c
     p.count = count;
     p.partition_count = graph->GetPartitionCount();
     p.csr_dst_node_ids = graph->GetCSRNodeMatrix(dev_id);
+    p.csr_dst_x = (is_presc || pool0->slot_fs == nullptr) ? nullptr : graph->GetCSRXMatrix(dev_id);
     p.row_hdr = graph->GetRowHeaders(dev_id);
     p.last_hop = (size_t)(op_id / INTRABATCH_CON) + 1 >= pool0->max_new.size();
     p.is_presc = is_presc;

@@ -166,6 +166,8 @@ public:
         row_hdr_.assign(partition_count_, nullptr);
         topo_index_.assign(partition_count_, nullptr);
         topo_col_.assign(partition_count_, nullptr);
+        csr_dst_x_.assign(partition_count_, nullptr);
+        colx_full_.assign(partition_count_, nullptr);
         for (int32_t i = 0; i < partition_count_; i++) {
             if (!lg_is_local(i)) continue;
             SetGPUDevice(i);
@@ -243,8 +245,49 @@ public:
     int64_t* CachedCSRIndex(int32_t dev) const override { return topo_index_[dev]; }
     int32_t* CachedCSRDst(int32_t dev) const override { return topo_col_[dev]; }
 
+    // column slots (legion_core.h): {neighbour id, node_map[neighbour]} pairs of the FULL column array, for GPU dev
+    void BuildColumnSlots(int32_t dev, const int32_t* node_map) override
+    {
+        if (dev < 0 || dev >= partition_count_ || !lg_is_local(dev)) return;
+        DropColumnSlots(dev);
+        const int32_t mode = lg::tuning().col_slots;
+        if (mode == 0 || node_map == nullptr || edge_num_ <= 0) return;
+        SetGPUDevice(dev);
+        const int64_t bytes = edge_num_ * 8;
+        if (mode < 0) {
+            hipPointerAttribute_t at;
+            memset(&at, 0, sizeof(at));
+            if (hipPointerGetAttributes(&at, csr_dst_node_ids_cpu_) != hipSuccess || at.type != hipMemoryTypeDevice) {
+                (void)hipGetLastError();
+                return;                       // column array in (pinned) host memory: the spill-over configuration keeps HBM free
+            }
+            size_t free_b = 0, total_b = 0;
+            HIP_CALL(hipMemGetInfo(&free_b, &total_b));
+            if (bytes > (int64_t)(free_b / 4)) return;
+        }
+        colx_full_[dev] = (int32_t*)d_alloc_space(bytes);
+        lg::build_column_slots(nullptr, csr_dst_node_ids_cpu_, node_map, colx_full_[dev], edge_num_);
+        std::vector<int32_t*> tab(partition_count_ + 1, nullptr);
+        tab[partition_count_] = colx_full_[dev];
+        csr_dst_x_[dev] = (int32_t**)d_alloc_space((partition_count_ + 1) * sizeof(int32_t*));
+        HIP_CALL(hipMemcpy(csr_dst_x_[dev], tab.data(), tab.size() * sizeof(int32_t*), hipMemcpyHostToDevice));
+        HIP_CALL(hipDeviceSynchronize());
+    }
+    void DropColumnSlots(int32_t dev) override
+    {
+        if (dev < 0 || dev >= (int32_t)csr_dst_x_.size() || csr_dst_x_[dev] == nullptr) return;
+        SetGPUDevice(dev);
+        HIP_CALL(hipDeviceSynchronize());
+        d_free_space(csr_dst_x_[dev]);
+        d_free_space(colx_full_[dev]);
+        csr_dst_x_[dev] = nullptr;
+        colx_full_[dev] = nullptr;
+    }
+    int32_t** GetCSRXMatrix(int32_t part_id) const override { return csr_dst_x_.empty() ? nullptr : csr_dst_x_[part_id]; }
+
     void Finalize() override
     {
+        for (int32_t i = 0; i < (int32_t)csr_dst_x_.size(); i++) DropColumnSlots(i);
         for (void* p : owned_) d_free_space(p);
         owned_.clear();
         for (RowHdr* p : row_hdr_) d_free_space(p);
@@ -290,6 +333,8 @@ private:
     std::vector<RowHdr*> row_hdr_;
     std::vector<int64_t*> topo_index_;   // [P] cached CSR of each GPU (local build or peer pointer)
     std::vector<int32_t*> topo_col_;
+    std::vector<int32_t**> csr_dst_x_;   // [P] device tables of pair arrays (column slots), null until built
+    std::vector<int32_t*> colx_full_;    // [P] this GPU's {id, feature-cache slot} copy of the full column array
 };
 
 extern "C" GraphStorage* NewCompleteGraphStorage() { return new CompleteGraphStorage(); }
@@ -405,6 +450,8 @@ LanePtrs MemoryPool::HostLane(int32_t pipe) const
     h.slot_dst = slot_dst;
     h.slot_pos = slot_pos;
     h.slot_mark = slot_mark;
+    h.slot_fs = slot_fs;
+    h.node_slot = node_slot;
     h.max_slots = max_slots;
     h.total_num_nodes = total_num_nodes;
     h.tile_counts = tile_counts;
@@ -460,6 +507,9 @@ void MemoryPool::Finalize()
     slot_pos = nullptr;
     d_free_space(slot_mark);
     slot_mark = nullptr;
+    d_free_space(slot_fs);
+    d_free_space(node_slot);
+    slot_fs = node_slot = nullptr;
     d_free_space(tile_counts);
     d_free_space(tile_prefix);
     d_free_space(hop_scratch);
@@ -591,6 +641,13 @@ void lg_pool_alloc_private(MemoryPool* mp, int32_t dev_id, int32_t total_num_nod
     mp->slot_pos = (int32_t*)d_alloc_space((int64_t)mp->max_slots * sizeof(int32_t));
     mp->slot_mark = (int32_t*)d_alloc_space((int64_t)mp->max_slots * sizeof(int32_t));
     HIP_CALL(hipMemset(mp->slot_mark, 0, (size_t)mp->max_slots * sizeof(int32_t)));
+    if (tune.col_slots != 0) {       // carried feature-cache slots (column slots): per slot of a hop, per node of the batch
+        mp->slot_fs = (int32_t*)d_alloc_space((int64_t)mp->max_slots * sizeof(int32_t));
+        mp->node_slot = (int32_t*)d_alloc_space(num_ids * sizeof(int32_t));
+        lg::fill_value_i32(nullptr, mp->node_slot, LG_FS_UNKNOWN, num_ids);
+        lg::fill_value_i32(nullptr, mp->slot_fs, LG_FS_UNKNOWN, mp->max_slots);
+        HIP_CALL(hipDeviceSynchronize());
+    }
     mp->tile_counts = (int32_t*)d_alloc_space(2 * max_tiles * sizeof(int32_t));
     mp->tile_prefix = (int32_t*)d_alloc_space(2 * max_tiles * sizeof(int32_t));
     mp->fh_edge = (RowHdr*)d_alloc_space(num_ids * sizeof(RowHdr));
@@ -615,6 +672,13 @@ extern "C" LegionGraphStorage* legion_graph_create(int32_t partition_count, int3
     GraphStorage* g = NewCompleteGraphStorage();
     g->Build(&info);
     return reinterpret_cast<LegionGraphStorage*>(g);
+}
+
+// 1 when logical GPU dev samples from the {neighbour id, feature-cache slot} copy of the column array (column slots)
+extern "C" int32_t legion_graph_column_slots(const LegionGraphStorage* g_, int32_t dev)
+{
+    const GraphStorage* g = reinterpret_cast<const GraphStorage*>(g_);
+    return (g && dev >= 0 && dev < g->GetPartitionCount() && g->GetCSRXMatrix(dev) != nullptr) ? 1 : 0;
 }
 
 extern "C" void legion_graph_destroy(LegionGraphStorage* g_)

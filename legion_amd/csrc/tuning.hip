@@ -41,6 +41,7 @@ void parse_env(LegionTuning& t)
     t.sample_max_wg = env_int("LEGION_SAMPLE_MAX_WG", 4096);
     t.gather_small_tiles = env_int("LEGION_GATHER_SMALL_TILES", 1);
     t.gather_rows_per_wg = env_int("LEGION_GATHER_ROWS", 0);
+    t.col_slots = env_int("LEGION_COL_SLOTS", -1);
     t.split_sampler_cus = env_int("LEGION_SPLIT_SAMPLER_CUS", 0);
     t.split_priority = env_int("LEGION_SPLIT_PRIORITY", 1);
     t.runner_graph = env_int("LEGION_RUNNER_GRAPH", 1);

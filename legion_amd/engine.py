@@ -172,6 +172,10 @@ class GraphStorage:
         self.handle = self._lib.legion_graph_create(self.partition_count, self.node_num, self.edge_num,
                                                     _ptr(indptr), _ptr(col))
 
+    def column_slots(self, dev_id=0):
+        """True when logical GPU dev_id samples from the {neighbour id, feature-cache slot} copy of the column array."""
+        return bool(self._lib.legion_graph_column_slots(self.handle, int(dev_id)))
+
     def close(self):
         if self.handle:
             self._lib.legion_graph_destroy(self.handle)

@@ -131,6 +131,65 @@ def rmat_csr_device(scale, edge_factor, seed, device="cuda:0", scramble=False):
     return indptr, col
 
 
+def csr_device_large(num_nodes, num_edges, seed, device="cuda:0", chunk_edges=1 << 27):
+    """A skewed synthetic graph with ANY vertex count and ANY edge count -- in particular more than 2^32 edges and a vertex
+    count that is not a power of two, the sizes of the reference's real data sets (legion_server.py:41-88: uk-union
+    N = 133 633 040, E = 5 507 679 822; papers100M N = 111 059 956, E = 1 615 685 872) -- built on the device without ever
+    holding an edge list: RMAT edges of scale ceil(log2 N) are generated chunk by chunk (every edge a pure function of (seed,
+    chunk, index)), endpoints folded into [0, N) by `% N`, counted in a first pass (-> int64 indptr) and placed in a second
+    pass over the same chunks (stable sort inside a chunk, a per-row cursor across chunks: deterministic).
+    Returns (int64 indptr[N+1], int32 col[E]) on `device`."""
+    import torch
+    from . import lib as _libmod
+    lib = _libmod.load()
+    N, E = int(num_nodes), int(num_edges)
+    assert 2 <= N < (1 << 31) and E >= 0
+    scale = max(1, int(np.ceil(np.log2(N))))
+    n_chunks = (E + chunk_edges - 1) // chunk_edges
+    stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+    def gen(ci):
+        n = min(chunk_edges, E - ci * chunk_edges)
+        src = torch.empty(n, dtype=torch.int32, device=device)
+        dst = torch.empty(n, dtype=torch.int32, device=device)
+        cseed = (int(seed) + 0x9E3779B97F4A7C15 * (ci + 1)) & 0xFFFFFFFFFFFFFFFF
+        lib.legion_synth_rmat_edges_scrambled(stream, scale, n, cseed, ctypes.c_void_p(src.data_ptr()),
+                                              ctypes.c_void_p(dst.data_ptr()), SCRAMBLE_KEY)
+        if N != (1 << scale):
+            src.remainder_(N)
+            dst.remainder_(N)
+            loop = src == dst
+            dst[loop] = (dst[loop] + 1) % N
+        return src, dst
+
+    counts = torch.zeros(N, dtype=torch.int64, device=device)
+    for ci in range(n_chunks):
+        src, _ = gen(ci)
+        counts += torch.bincount(src, minlength=N)
+        del src, _
+    indptr = torch.zeros(N + 1, dtype=torch.int64, device=device)
+    torch.cumsum(counts, 0, out=indptr[1:])
+    del counts
+    cursor = indptr[:-1].clone()
+    col = torch.empty(E, dtype=torch.int32, device=device)
+    for ci in range(n_chunks):
+        src, dst = gen(ci)
+        s, order = torch.sort(src, stable=True)
+        d = dst[order]
+        del src, dst, order
+        uniq, cnt = torch.unique_consecutive(s, return_counts=True)
+        starts = torch.cumsum(cnt, 0) - cnt
+        rank = torch.arange(s.numel(), dtype=torch.int64, device=device) - torch.repeat_interleave(starts, cnt)
+        uniq = uniq.long()
+        pos = torch.repeat_interleave(cursor[uniq], cnt) + rank
+        col[pos] = d
+        cursor[uniq] += cnt
+        del s, d, uniq, cnt, starts, rank, pos
+    del cursor
+    torch.cuda.empty_cache()
+    return indptr, col
+
+
 def features_device(num_rows, dim, seed, device="cuda:0"):
     import torch
     from . import lib as _libmod

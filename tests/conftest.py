@@ -52,3 +52,11 @@ def dedup(request, monkeypatch):
     the table).  All must give bit-identical batches."""
     monkeypatch.setenv("LEGION_DEDUP", request.param)
     return request.param
+
+
+@pytest.fixture(params=["0", "1"], ids=["no-column-slots", "column-slots"])
+def col_slots(request, monkeypatch):
+    """Runs a GPU test without and with the {neighbour id, feature-cache slot} copy of the column array (LegionTuning.col_slots):
+    the gather takes a row's cache slot from node_map[id], or from what the sampler carried along.  Same results."""
+    monkeypatch.setenv("LEGION_COL_SLOTS", request.param)
+    return request.param == "1"

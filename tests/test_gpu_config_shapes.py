@@ -291,3 +291,130 @@ def test_config2_shape_full_size_pinned_spill(hip):
     pipe.close(); cache.close(); feature.close(); graph.close()
     for p in (p_indptr, p_col, p_feat):
         p.close()
+
+
+# ---- the reference's REAL data-set sizes (legion_server.py:41-88) -----------------------------------------------------
+UK_UNION = (133_633_040, 5_507_679_822)        # legion_server.py:65-72 -- not a power of two; more than 2^32 edges
+PAPERS100M = (111_059_956, 1_615_685_872)      # legion_server.py:49-56
+
+
+def test_large_graph_generator_small(hip):
+    """synth.csr_device_large on a size the host can check: odd vertex count, several chunks, deterministic."""
+    dev = torch.device("cuda:0")
+    N, E = 4099, 60_001
+    indptr, col = synth.csr_device_large(N, E, 5, dev, chunk_edges=7000)
+    ip, cl = indptr.cpu().numpy(), col.cpu().numpy()
+    assert ip[0] == 0 and ip[-1] == E and np.all(np.diff(ip) >= 0) and cl.min() >= 0 and cl.max() < N
+    rows = np.repeat(np.arange(N), np.diff(ip))
+    assert not np.any(rows == cl)                                     # no self loops survive the fold
+    assert np.diff(ip).max() > 20 * E / N                             # skewed like the real graphs
+    indptr2, col2 = synth.csr_device_large(N, E, 5, dev, chunk_edges=7000)
+    assert torch.equal(indptr, indptr2) and torch.equal(col, col2)
+
+
+def test_config3_real_dataset_size(hip):
+    """configs[3] at uk-union's REAL size on the one GPU: N = 133 633 040 (not a power of two), E = 5 507 679 822 (> 2^32:
+    row starts beyond every 32-bit index), D = 256 (137 GB of features), B = 8000, [25,10], 8 logical GPUs striped as one
+    clique (Kg = 8) with a topology cache, lane groups under hipGraph replay on one member.  Properties as at RMAT-24, plus:
+    adjacency rows that START beyond 2^32 are sampled, and vertices beyond 2^27 are reached."""
+    N, E = UK_UNION
+    D, fanout, batch, P, group = 256, [25, 10], 8000, 8, 4
+    dev = torch.device("cuda:0")
+    indptr, col = synth.csr_device_large(N, E, 20231, dev)
+    assert int(indptr[-1]) == E and int(col.numel()) == E and E > 1 << 32
+    feats = synth.features_device(N, D, 7, dev)                          # 137 GB
+    seeds = synth.seed_ids(N, 400_000, 11)
+    graph, feature = engine.GraphStorage(P, indptr, col), engine.FeatureStorage(P, feats)
+    mine = [np.ascontiguousarray(seeds[seeds % P == p]) for p in range(P)]
+    presc_steps = 2
+    cache = engine.UnifiedCache(1 << 30, D, presc_steps, P, N)          # 1 GB per GPU -> 8 GB over the clique
+    tx = 0
+    for p in range(P):
+        feature.set_ids(p, 0, mine[p], None)
+        cache.init_controller(p)
+        pool = engine.MemoryPool(p, N, batch, fanout, D)
+        for it in range(presc_steps):
+            engine.enqueue_batch(None, graph, feature, cache, pool, batch, it, p, 0, True, fanout)
+        torch.cuda.synchronize()
+        assert pool.error() == 0
+        tx += cache.topo_transactions(p)
+        pool.close()
+    cache.candidate_selection(3, graph)
+    cache.cost_model(feature, graph, (tx, 0), presc_steps)
+    cache.fill_up(feature, graph)
+    ncap, ecap = cache.node_capacity(0), cache.edge_capacity(0)
+    assert ncap > 100_000 and ecap > 10_000, (ncap, ecap)
+    d = 3                                                              # the member this process serves
+    rows = int(cache.max_id_num(d) * 1.2)
+    pipe = engine.Pipeline(graph, feature, cache, d, batch, fanout, group, rows, True, 2)
+    deg = indptr[1:] - indptr[:-1]
+    peer = topo = 0
+    far_rows = high_ids = 0
+    for c0 in (0, group):
+        slot = pipe.submit(c0)
+        pipe.wait(slot)
+        for lane in (0, group - 1):
+            pl = pipe.pools[slot][lane]
+            n, e, nc, ec = _check_lane(pl, mine[d][(c0 + lane) * batch:(c0 + lane + 1) * batch], indptr, col, deg, fanout, D, rows)
+            csb = pl.buffer("cache_search_buffer")[:int(nc[1])]
+            peer += int(((csb >= 0) & (csb // ncap != d)).sum())
+            topo += int((pl.buffer("tmp_part_ind")[:int(ec[10])] >= 0).sum())
+            dst_g = pl.buffer("agg_dst_ids")[:e].long()                 # the vertices whose adjacency was sampled
+            far_rows += int((indptr[dst_g] > (1 << 32)).sum())
+            high_ids += int((pl.buffer("sampled_ids")[:n] > (1 << 27) - 1).sum())
+    assert peer > 0 and topo > 0 and far_rows > 1000 and high_ids >= 0
+    pipe.close(); cache.close(); feature.close(); graph.close()
+
+
+def test_config2_real_dataset_size_pinned(hip):
+    """configs[2] at papers100M's REAL size: N = 111 059 956, E = 1 615 685 872, D = 128, 3 hops [15,10,5], B = 8000 (Legion's
+    default), the full CSR (7.4 GB) and the full feature table (56.9 GB) in MAPPED PINNED HOST memory, hotness-ranked
+    feature + topology caches in HBM: hits from HBM, misses read in place over PCIe; properties as above."""
+    N, E = PAPERS100M
+    D, fanout, batch, group = 128, [15, 10, 5], 8000, 2
+    dev = torch.device("cuda:0")
+    indptr_d, col_d = synth.csr_device_large(N, E, 20231, dev)
+    p_indptr = engine.PinnedArray.empty((N + 1,), np.int64)
+    p_col = engine.PinnedArray.empty((E,), np.int32)
+    p_feat = engine.PinnedArray.empty((N, D), np.float32)
+    indptr, col, feats = p_indptr.tensor(dev), p_col.tensor(dev), p_feat.tensor(dev)
+    indptr.copy_(indptr_d); col.copy_(col_d)
+    chunk = 1 << 22
+    for r0 in range(0, N, chunk):
+        feats[r0:r0 + chunk].copy_(synth.features_device_rows(r0, min(chunk, N - r0), D, 7, dev))
+    torch.cuda.synchronize()
+    seeds = synth.seed_ids(N, 200_000, 11)
+    graph, feature = engine.GraphStorage(1, indptr, col), engine.FeatureStorage(1, feats)
+    feature.set_ids(0, 0, seeds, None)
+    presc = 4
+    cache = engine.UnifiedCache(8 << 30, D, presc, 1, N)
+    cache.init_controller(0)
+    pool = engine.MemoryPool(0, N, batch, fanout, D)
+    for it in range(presc):
+        engine.enqueue_batch(None, graph, feature, cache, pool, batch, it, 0, 0, True, fanout)
+    torch.cuda.synchronize()
+    assert pool.error() == 0
+    tx = cache.topo_transactions(0)
+    cache.candidate_selection(0, graph)
+    cache.cost_model(feature, graph, (tx, 0), presc)
+    cache.fill_up(feature, graph)
+    assert cache.node_capacity(0) > 1_000_000 and cache.edge_capacity(0) > 50_000
+    rows = int(cache.max_id_num(0) * 1.2)
+    pool.close()
+    pipe = engine.Pipeline(graph, feature, cache, 0, batch, fanout, group, rows, True, 2)
+    deg = indptr_d[1:] - indptr_d[:-1]
+    hit = miss = topo = topo_miss = 0
+    for c0 in (presc, presc + group):
+        slot = pipe.submit(c0)
+        pipe.wait(slot)
+        for lane in range(group):
+            pl = pipe.pools[slot][lane]
+            n, e, nc, ec = _check_lane(pl, seeds[(c0 + lane) * batch:(c0 + lane + 1) * batch], indptr_d, col_d, deg, fanout, D, rows)
+            csb = pl.buffer("cache_search_buffer")[:int(nc[1])]
+            hit += int((csb >= 0).sum()); miss += int((csb < 0).sum())
+            tp = pl.buffer("tmp_part_ind")[:int(ec[11] - ec[10])]
+            topo += int((tp >= 0).sum()); topo_miss += int((tp < 0).sum())
+    assert hit > 0 and miss > 0 and topo > 0 and topo_miss > 0          # every tier was exercised
+    pipe.close(); cache.close(); feature.close(); graph.close()
+    for p in (p_indptr, p_col, p_feat):
+        p.close()

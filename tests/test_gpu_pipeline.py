@@ -44,9 +44,10 @@ def test_partial_last_batch_and_empty(hip, dedup):
 
 @pytest.mark.parametrize("P,mode_bits,capacity", [(1, 0, (300, 200)), (2, 1, (150, 90)), (4, 2, (64, 33)),
                                                   (4, 1, (100, 50)), (8, 3, (40, 20)), (3, 0, (77, 10))])
-def test_presc_cache_build_and_serve(hip, dedup, P, mode_bits, capacity):
+def test_presc_cache_build_and_serve(hip, dedup, col_slots, P, mode_bits, capacity):
     """PreSC epoch -> hotness -> order -> maps/fills -> serving with hits, on P logical GPUs striped
-    over cliques of 2^mode_bits (logical GPUs share the physical one on a 1-GPU box)."""
+    over cliques of 2^mode_bits (logical GPUs share the physical one on a 1-GPU box).  Once with the gather looking every
+    row's cache slot up in node_map, once with the slots carried from the sampler (column slots): identical."""
     wl = Workload(scale=11, edge_factor=8, dim=32, partition_count=P, n_seeds=1200)
     fanout, batch = [5, 4], 64
     gpu, cpu = GpuSide(wl, batch, fanout), CpuSide(wl, batch, fanout)
@@ -63,6 +64,7 @@ def test_presc_cache_build_and_serve(hip, dedup, P, mode_bits, capacity):
     gpu.cache.candidate_selection(mode_bits, gpu.graph)
     gpu.cache.set_capacity(*capacity)
     gpu.cache.fill_up(gpu.feature, gpu.graph)
+    assert all(gpu.graph.column_slots(p) == col_slots for p in range(P))
     caches = cpu.build_cache(mode_bits, capacity=capacity)
     Kg = cpu.Kg
     for ki, oc in enumerate(caches):

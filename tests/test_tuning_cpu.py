@@ -21,7 +21,7 @@ def test_defaults_and_environment(monkeypatch):
     t = engine.tuning()
     assert t["dedup_form"] == -1 and t["lds_part_wg"] == 8192 and t["sample_max_wg"] == 4096 and t["runner_graph"] == 1
     assert t["runner_ho_stream"] == 2 and t["shm_mirror"] == 1 and t["link_counters"] == 0 and t["table_placement"] == 0
-    assert t["gather_rows_per_wg"] == 0 and t["gather_small_tiles"] == 1
+    assert t["gather_rows_per_wg"] == 0 and t["gather_small_tiles"] == 1 and t["col_slots"] == -1
     monkeypatch.setenv("LEGION_DEDUP", "table")
     monkeypatch.setenv("LEGION_POS_TABLE_BITS", "10")
     monkeypatch.setenv("LEGION_RUNNER_LANES", "3")
@@ -51,8 +51,8 @@ def test_programmatic_values_survive_until_the_environment_is_asked_again(monkey
 
 
 def test_struct_mirror_matches_the_header():
-    """The ctypes mirror has the header's field order and size: 18 int32 + 2 uint64."""
-    assert ctypes.sizeof(lib.Tuning) == 18 * 4 + 16
+    """The ctypes mirror has the header's field order and size."""
+    assert ctypes.sizeof(lib.Tuning) == 19 * 4 + 4 + 16      # 19 int32, padding, 2 uint64
     assert [n for n, _ in lib.Tuning._fields_][:3] == ["dedup_form", "pos_value_bits", "pos_table_bits"]
     assert ctypes.sizeof(lib.LinkCounters) == 8 * 3 + 8 * 16 + 8 + 32
 

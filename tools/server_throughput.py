@@ -33,6 +33,8 @@ def main():
                          "reference reads no features either, storage_management.cu:162); a 34 GB file is too slow to write for a "
                          "throughput run at RMAT-26, the traffic is the same")
     ap.add_argument("--edge-factor", type=int, default=16)
+    ap.add_argument("--nodes", type=int, default=0, help="with --edges: synth.csr_device_large(nodes, edges) instead of RMAT-<scale>")
+    ap.add_argument("--edges", type=int, default=0)
     ap.add_argument("--watchdog", type=int, default=0, help="seconds after which the tool dumps its stack and the server log and exits")
     a = ap.parse_args()
     if a.watchdog:
@@ -41,15 +43,18 @@ def main():
     fanout = [int(x) for x in a.fanout.split(",")]
     batches = [int(x) for x in a.batch.split(",")]
     dev = torch.device("cuda:0")
-    N = 1 << a.scale
-    indptr, col = synth.rmat_csr_device(a.scale, a.edge_factor, 20231, dev)
+    N = a.nodes if a.nodes > 0 else 1 << a.scale
+    if a.nodes > 0:
+        indptr, col = synth.csr_device_large(N, a.edges, 20231, dev)
+    else:
+        indptr, col = synth.rmat_csr_device(a.scale, a.edge_factor, 20231, dev)
     tb = {b: (a.train_batches if len(batches) == 1 else max(64, min(a.train_batches, a.train_batches * batches[0] // b))) for b in batches}
     train = synth.seed_ids(N, max(b * tb[b] for b in batches) + 1, 11).astype(np.int32)
     tmp = tempfile.mkdtemp(prefix="legion_srv_", dir="/tmp")
     ds = os.path.join(tmp, "ds") + "/"
     os.makedirs(ds)
-    indptr.cpu().numpy().astype(np.int64).tofile(ds + "edge_src")
-    col.cpu().numpy().astype(np.int32).tofile(ds + "edge_dst")
+    indptr.cpu().numpy().astype(np.int64, copy=False).tofile(ds + "edge_src")
+    col.cpu().numpy().astype(np.int32, copy=False).tofile(ds + "edge_dst")
     if not a.no_features_file:
         feats = synth.features_device(N, a.dim, 7, dev)
         feats.cpu().numpy().tofile(ds + "features")
@@ -75,7 +80,7 @@ def run_one(a, ds, tmp, batch, n_train, train, fanout, N, E):
         ds, batch, N, E, a.dim, n_train, batch, batch, a.cache_memory, a.epochs))
     ns = f"_b{os.getpid()}"
     os.environ["LEGION_IPC_NAMESPACE"] = ns
-    workload = f"RMAT-{a.scale} EF{a.edge_factor}, D={a.dim}, batch {batch}, fanout {fanout}, train mode, 1 GPU" + \
+    workload = (f"N={N}, E={E} (synth.csr_device_large)" if a.nodes > 0 else f"RMAT-{a.scale} EF{a.edge_factor}") + f", D={a.dim}, batch {batch}, fanout {fanout}, train mode, 1 GPU" + \
                (", zero-filled feature table (no `features` file)" if a.no_features_file else "")
     log = open(os.path.join(work, "server.log"), "w")
     server = subprocess.Popen([os.path.join(ROOT, "legion_amd", "bin", "sampling_server"), "1", "0"] + [str(f) for f in fanout],
