@@ -239,6 +239,7 @@ struct SampleArgs {
     LG_G int32_t* sampled_ids; LG_G int32_t* agg_src_ids; LG_G int32_t* agg_dst_ids; LG_G int32_t* agg_src_off; LG_G int32_t* agg_dst_off;
     LG_G char* tmp_part_ind; LG_G uint32_t* position_map; LG_G int32_t* node_counter; LG_G int32_t* edge_counter;
     LG_G int32_t* slot_dst; LG_G int32_t* slot_pos; LG_G int32_t* slot_mark; LG_G int32_t* slot_fs; LG_G int32_t* node_slot; LG_G int32_t* tile_counts; LG_G int32_t* tile_prefix; LG_G int32_t* hop_scratch;
+    LG_G unsigned long long* first_masks;
     LG_G RowHdr* fh_edge;
     LG_G unsigned long long* pos_table; uint32_t pos_mask; LG_G int32_t* err_flag;
     LG_G unsigned long long* claim_pairs; LG_G int32_t* run_off;
@@ -287,6 +288,7 @@ __device__ __forceinline__ SampleArgs lane_args(const HopParams& p, const LanePt
     a.slot_fs = LG_GPTR(int32_t, L.slot_fs); a.node_slot = LG_GPTR(int32_t, L.node_slot); a.tile_counts = LG_GPTR(int32_t, L.tile_counts);
     a.tile_prefix = LG_GPTR(int32_t, L.tile_prefix); a.hop_scratch = LG_GPTR(int32_t, L.hop_scratch);
     a.fh_edge = LG_GPTR(RowHdr, L.fh_edge);
+    a.first_masks = LG_GPTR(unsigned long long, L.first_masks);
     a.pos_table = LG_GPTR(unsigned long long, L.pos_table); a.pos_mask = L.pos_table_mask;
     a.err_flag = LG_GPTR(int32_t, L.err_flag);
     a.claim_pairs = LG_GPTR(unsigned long long, L.claim_pairs);
@@ -755,6 +757,8 @@ __global__ __launch_bounds__(LG_TILE) void flag_count_kernel(HopParams hp, const
             if (lane == 0) {
                 s_cnt[u][0][wave] = __popcll(mv);
                 s_cnt[u][1][wave] = __popcll(mf);
+                const int32_t tile = st * LG_SLOTS_PER_LANE + u;
+                if (a.first_masks != nullptr && tile < g.ntiles) a.first_masks[(int64_t)tile * (LG_TILE / 64) + wave] = mf;
             }
         }
         __syncthreads();
@@ -904,6 +908,17 @@ __global__ __launch_bounds__(LG_TILE) void scatter_kernel(HopParams hp, const La
                 src_pos[u] = seeds ? q : a.agg_src_off[f_off + q];
                 if (!a.last_hop) nh[u] = load_hdr(a.row_hdr + dst);      // next hop's frontier header
                 lost_pos[u] = first ? 0 : a.slot_pos[idx];               // final already, or -2 - (slot it lost to)
+                if (a.first_masks != nullptr && lost_pos[u] < -1) {
+                    // lds form: the slot it lost to IS the winner (chains have length one); its new position follows from the
+                    // first-touch prefix of its tile and the ballots flag_count kept -- no localise pass over the edges
+                    const int32_t w = -2 - lost_pos[u];
+                    const int32_t tw = w / LG_TILE, ww = (w % LG_TILE) >> 6, lw = w & 63;
+                    const LG_G unsigned long long* mk = a.first_masks + (int64_t)tw * (LG_TILE / 64);
+                    int32_t nw = node_base + a.tile_prefix[2 * tw + 1];
+                    for (int j = 0; j < ww; j++) nw += __popcll(mk[j]);
+                    nw += __popcll(mk[ww] & (lw == 0 ? 0ull : (~0ull >> (64 - lw))));
+                    lost_pos[u] = nw;
+                }
                 fsv[u] = (first && a.slot_fs != nullptr) ? a.slot_fs[idx] : LG_FS_UNKNOWN;   // the new node's feature-cache slot, if carried
                 tab_at[u] = (first && !a.last_hop && a.pos_table != nullptr) ? table_find(a.pos_table, a.pos_mask, a.pf, dst) : 0u;
             }
@@ -933,7 +948,7 @@ __global__ __launch_bounds__(LG_TILE) void scatter_kernel(HopParams hp, const La
                     else
                         raise_error(a.hop_scratch, a.err_flag, LG_ERR_TABLE_FULL);
                 }
-                a.slot_pos[idx] = n;
+                if (a.first_masks == nullptr) a.slot_pos[idx] = n;   // (what localise follows; the lds form needs no localise)
                 a.agg_src_off[e] = n;                              // construct_graph's neighbour side, known here
             } else {
                 a.agg_src_off[e] = lost_pos[u];
@@ -1073,8 +1088,10 @@ void launch_random_sample(hipStream_t s, const HopParams& p, const LanePtrs* d_l
         else list_known_kernel<LG_LDS_BITS_LARGE><<<dim3(chunks, n_lanes), LG_TILE, 0, s>>>(p, d_lanes);
         hipCheckError();
     }
-    localise_kernel<<<grid, LG_TILE, 0, s>>>(p, d_lanes);
-    hipCheckError();
+    if (form != 2) {      // (lds form: scatter placed every loser itself from the first-touch ballots)
+        localise_kernel<<<grid, LG_TILE, 0, s>>>(p, d_lanes);
+        hipCheckError();
+    }
 }
 
 // ------------------------------------------------------------------------------------------

@@ -253,6 +253,8 @@ struct LanePtrs {
                                        // instead of node_map[id] (one 128-byte line per row for 4 bytes)
     int32_t* tile_counts;
     int32_t* tile_prefix;
+    unsigned long long* first_masks;   // lds form: [tiles][4] ballot of the first-touch slots of every wave of a 256-slot tile (flag_count):
+                                       // with tile_prefix it gives ANY winner's final position, so scatter localises losers itself
     int32_t* hop_scratch;
     RowHdr* fh_edge;
     int32_t* cache_search_buffer;
@@ -316,6 +318,7 @@ public:
     int32_t* slot_fs = nullptr;        // [max_slots] / [num_ids]: feature-cache slots carried from the sampler to the gather
     int32_t* node_slot = nullptr;
     int32_t* tile_counts = nullptr;    // [2 * max_tiles] valid / first-touch counts per tile
+    unsigned long long* first_masks = nullptr;   // lds form: [max_tiles][4] first-touch ballots (LanePtrs)
     int32_t* tile_prefix = nullptr;    // [2 * max_tiles] exclusive prefixes
     RowHdr* fh_edge = nullptr;         // [num_ids] frontier row headers written by scatter
     int32_t* hop_scratch = nullptr;    // [HS_WORDS]

@@ -323,9 +323,10 @@ def test_config3_real_dataset_size(hip):
     indptr, col = synth.csr_device_large(N, E, 20231, dev)
     assert int(indptr[-1]) == E and int(col.numel()) == E and E > 1 << 32
     feats = synth.features_device(N, D, 7, dev)                          # 137 GB
-    seeds = synth.seed_ids(N, 400_000, 11)
+    seeds = synth.seed_ids(N, 1_000_000, 11)                             # ~125 k per logical GPU: 15 batches of 8000
     graph, feature = engine.GraphStorage(P, indptr, col), engine.FeatureStorage(P, feats)
     mine = [np.ascontiguousarray(seeds[seeds % P == p]) for p in range(P)]
+    assert min(m.size for m in mine) > 2 * group * batch
     presc_steps = 2
     cache = engine.UnifiedCache(1 << 30, D, presc_steps, P, N)          # 1 GB per GPU -> 8 GB over the clique
     tx = 0
