@@ -484,6 +484,7 @@ void UnifiedCache::FeatCacheLookup(const LanePtrs* d_lanes, int32_t n_lanes, int
     g.stats = (gather_stats_on_ && dev_id < (int32_t)gather_stats_.size()) ? gather_stats_[dev_id] : nullptr;
     g.full_table = cpu_float_features_;
     g.cache_tables = filled ? d_float_feature_cache_ptr_[dev_id] : nullptr;
+    g.local_table = filled ? float_feature_cache_[dev_id] : nullptr;
     g.node_map = filled ? cache_controller_[dev_id]->NodeMap() : nullptr;
     g.node_capacity = filled ? NodeCapacity(dev_id) : 1;
     g.D = float_feature_len_;

@@ -147,13 +147,17 @@ __global__ __launch_bounds__(LG_GATHER_THREADS) void gather_kernel(GatherParams 
         cache_search_buffer[r0 + t] = g;             // FindFeat writes from index 0 each hop
         const LG_G float* p = nullptr;
         if (g < 0) {
-            if (id >= 0) p = LG_GPTR(const float, gp.full_table) + (int64_t)(id % gp.total_num_nodes) * D;   // :262-266
+            if (id >= 0)     // :262-266 (the modulo only where it does anything)
+                p = LG_GPTR(const float, gp.full_table) + (int64_t)(id < gp.total_num_nodes ? id : id % gp.total_num_nodes) * D;
         } else {
-            const int32_t didx = g / gp.node_capacity, fidx = g - didx * gp.node_capacity;   // :259-260
+            int32_t didx = 0, fidx = g;                                                      // :259-260 (one division, and
+            if (gp.Kg > 1) { didx = g / gp.node_capacity; fidx = g - didx * gp.node_capacity; }   // none without striping)
             const int64_t rank = (int64_t)fidx * gp.Kg + didx;                               // hotness rank of the row (cache_impl.cuh:104-109)
             const bool local_copy = gp.replica != nullptr && rank < gp.replica_rows;
             if (local_copy)      // the clique's hottest rows are also kept locally: same row, no xGMI hop
                 p = LG_GPTR(const float, gp.replica) + rank * D;
+            else if (didx == gp.member && gp.local_table != nullptr)     // own stripe: its address came with the launch
+                p = LG_GPTR(const float, gp.local_table) + (int64_t)fidx * D;
             else
                 p = LG_GPTR(const float, gp.cache_tables[didx]) + (int64_t)fidx * D;                               // :268
             if (gp.stats != nullptr && gp.Kg > 1) {    // tests / diagnostics / the computed xGMI count: [0] rows read through a stripe

@@ -239,7 +239,7 @@ struct SampleArgs {
     LG_G int32_t* sampled_ids; LG_G int32_t* agg_src_ids; LG_G int32_t* agg_dst_ids; LG_G int32_t* agg_src_off; LG_G int32_t* agg_dst_off;
     LG_G char* tmp_part_ind; LG_G uint32_t* position_map; LG_G int32_t* node_counter; LG_G int32_t* edge_counter;
     LG_G int32_t* slot_dst; LG_G int32_t* slot_pos; LG_G int32_t* slot_mark; LG_G int32_t* slot_fs; LG_G int32_t* node_slot; LG_G int32_t* tile_counts; LG_G int32_t* tile_prefix; LG_G int32_t* hop_scratch;
-    LG_G unsigned long long* first_masks;
+    LG_G FirstRec* first_rec;
     LG_G RowHdr* fh_edge;
     LG_G unsigned long long* pos_table; uint32_t pos_mask; LG_G int32_t* err_flag;
     LG_G unsigned long long* claim_pairs; LG_G int32_t* run_off;
@@ -288,7 +288,7 @@ __device__ __forceinline__ SampleArgs lane_args(const HopParams& p, const LanePt
     a.slot_fs = LG_GPTR(int32_t, L.slot_fs); a.node_slot = LG_GPTR(int32_t, L.node_slot); a.tile_counts = LG_GPTR(int32_t, L.tile_counts);
     a.tile_prefix = LG_GPTR(int32_t, L.tile_prefix); a.hop_scratch = LG_GPTR(int32_t, L.hop_scratch);
     a.fh_edge = LG_GPTR(RowHdr, L.fh_edge);
-    a.first_masks = LG_GPTR(unsigned long long, L.first_masks);
+    a.first_rec = LG_GPTR(FirstRec, L.first_rec);
     a.pos_table = LG_GPTR(unsigned long long, L.pos_table); a.pos_mask = L.pos_table_mask;
     a.err_flag = LG_GPTR(int32_t, L.err_flag);
     a.claim_pairs = LG_GPTR(unsigned long long, L.claim_pairs);
@@ -472,7 +472,7 @@ __global__ __launch_bounds__(LG_TILE) void sample_kernel(HopParams hp, const Lan
                         dst[u] = -1;
                     }
                     a.slot_dst[idx] = dst[u];
-                    if (a.slot_fs != nullptr) a.slot_fs[idx] = fs[u];
+                    if (a.slot_fs != nullptr && dst[u] >= 0) a.slot_fs[idx] = fs[u];     // (read for first-touch slots only)
                 }
             }
             if (FORM == 2 && SINGLE) {
@@ -596,7 +596,7 @@ __global__ __launch_bounds__(LG_DEDUP_THREADS) void dedup_lds_kernel(HopParams h
     __shared__ unsigned long long s_tab[LG_LDS_TABLE];
     __shared__ int32_t s_pref[MAX_PARTS];                  // exclusive prefix of the bucket's segment lengths
     __shared__ int32_t s_seg[MAX_PARTS];                   // where the bucket's segment of partition tile t starts in claim_pairs
-    __shared__ int32_t s_known, s_total;
+    __shared__ int32_t s_known, s_total, s_full;
     const HopGeom g = hop_geometry(a);
     const int32_t nparts = (g.nsuper + K - 1) / K;
     const int32_t tid = threadIdx.x, b = blockIdx.x;
@@ -640,10 +640,12 @@ __global__ __launch_bounds__(LG_DEDUP_THREADS) void dedup_lds_kernel(HopParams h
     if (known_here) atomicAdd(&s_known, known_here);
     __syncthreads();
     const int32_t total = s_total;
-    // passes: distinct vertices <= known + claims; keep the expected load of a pass at or below half the table
+    // passes: distinct vertices <= known + claims; keep the expected load of a pass at or below LG_LDS_FILL_16THS / 16 of the
+    // table.  That bound assumes the hash spreads the bucket evenly over its sub-buckets; when it does not (s_full: an insert
+    // found no free word) the whole bucket is redone with twice the passes -- every claim's outcome is the same under any
+    // partition, so what finished passes already wrote is simply written again.
     int32_t passes = 1;
     while ((int64_t)(s_known + total) > (int64_t)passes * (LG_LDS_TABLE / 16 * LG_LDS_FILL_16THS)) passes <<= 1;
-    const uint32_t pmask = (uint32_t)passes - 1u;
 
     auto segment_of = [&](int32_t k) {                 // claim k of the bucket -> index into claim_pairs
         int32_t lo = 0, hi = nparts;                   // s_pref[lo] <= k < s_pref[hi]
@@ -658,11 +660,15 @@ __global__ __launch_bounds__(LG_DEDUP_THREADS) void dedup_lds_kernel(HopParams h
             if (old > w) w = old;                                                          // displaced a larger word: carry it on
             p = (p + 1) & (LG_LDS_TABLE - 1);
         }
-        raise_error(a.hop_scratch, a.err_flag, LG_ERR_TABLE_FULL);
+        s_full = 1;
     };
 
+  for (;;) {
+    const uint32_t pmask = (uint32_t)passes - 1u;
+    bool overflow = false;
     for (uint32_t pass = 0; pass <= pmask; pass++) {
         for (int32_t i = tid; i < LG_LDS_TABLE; i += LG_DEDUP_THREADS) s_tab[i] = ~0ull;
+        if (tid == 0) s_full = 0;
         __syncthreads();
         for (int32_t i = tid; i < n_scan; i += LG_DEDUP_THREADS) {
             const int32_t id = a.sampled_ids[i];
@@ -694,6 +700,7 @@ __global__ __launch_bounds__(LG_DEDUP_THREADS) void dedup_lds_kernel(HopParams h
             }
         }
         __syncthreads();
+        if (s_full != 0) { overflow = true; break; }       // (uniform: read behind the barrier, reset behind the next one)
         for (int32_t k0 = 0; k0 < total; k0 += LG_DEDUP_BATCH * LG_DEDUP_THREADS) {
             unsigned long long pr[LG_DEDUP_BATCH];
 #pragma unroll
@@ -722,6 +729,14 @@ __global__ __launch_bounds__(LG_DEDUP_THREADS) void dedup_lds_kernel(HopParams h
         }
         __syncthreads();
     }
+    if (!overflow) break;
+    if (passes >= (1 << 14)) {                             // 2^14 sub-buckets of one bucket still too full: not a hash problem
+        if (tid == 0) raise_error(a.hop_scratch, a.err_flag, LG_ERR_TABLE_FULL);
+        break;
+    }
+    passes <<= 1;
+    __syncthreads();
+  }
     if (b == 0 && tid == 0) a.hop_scratch[HS_PAIR_CURSOR] = 0;      // the next hop's sampling starts a new pair array
 }
 
@@ -740,6 +755,7 @@ __global__ __launch_bounds__(LG_TILE) void flag_count_kernel(HopParams hp, const
     for (int32_t st = blockIdx.x; st < g.nsuper; st += gridDim.x) {
         const int32_t idx0 = st * LG_SUPER;
         int32_t v[LG_SLOTS_PER_LANE], mk[LG_SLOTS_PER_LANE];
+        unsigned long long mfk[LG_SLOTS_PER_LANE];
 #pragma unroll
         for (int u = 0; u < LG_SLOTS_PER_LANE; u++) {
             const int32_t idx = idx0 + u * LG_TILE + tid;
@@ -754,14 +770,28 @@ __global__ __launch_bounds__(LG_TILE) void flag_count_kernel(HopParams hp, const
             if (first) a.slot_dst[idx] = v[u] | (int32_t)0x80000000;
             const unsigned long long mv = __ballot(valid);
             const unsigned long long mf = __ballot(first);
+            mfk[u] = mf;
             if (lane == 0) {
                 s_cnt[u][0][wave] = __popcll(mv);
                 s_cnt[u][1][wave] = __popcll(mf);
-                const int32_t tile = st * LG_SLOTS_PER_LANE + u;
-                if (a.first_masks != nullptr && tile < g.ntiles) a.first_masks[(int64_t)tile * (LG_TILE / 64) + wave] = mf;
             }
         }
         __syncthreads();
+        if (a.first_rec != nullptr && lane == 0) {       // lds form: the wave's first-touch ballot + its offset inside the tile
+#pragma unroll
+            for (int u = 0; u < LG_SLOTS_PER_LANE; u++) {
+                const int32_t tile = st * LG_SLOTS_PER_LANE + u;
+                if (tile >= g.ntiles) continue;
+                int32_t before = 0;
+                for (int w = 0; w < wave; w++) before += s_cnt[u][1][w];
+                lg_v4i r;
+                r.x = (int32_t)(uint32_t)mfk[u];
+                r.y = (int32_t)(uint32_t)(mfk[u] >> 32);
+                r.z = before;
+                r.w = 0;
+                *(LG_G lg_v4i*)(a.first_rec + (int64_t)tile * (LG_TILE / 64) + wave) = r;
+            }
+        }
         if (tid < 2 * LG_SLOTS_PER_LANE) {
             const int u = tid >> 1, which = tid & 1;
             const int32_t tile = st * LG_SLOTS_PER_LANE + u;
@@ -810,6 +840,8 @@ __global__ __launch_bounds__(LG_SCAN_THREADS) void scan_kernel(HopParams hp, con
     for (int32_t t = lo; t < hi; t++) {
         a.tile_prefix[2 * t] = pe;
         a.tile_prefix[2 * t + 1] = pn;
+        if (a.first_rec != nullptr)        // lds form: every wave's record gets the absolute position of its first new node
+            for (int w = 0; w < LG_TILE / 64; w++) a.first_rec[(int64_t)t * (LG_TILE / 64) + w].base += nc0 + nc1 + pn;
         pe += a.tile_counts[2 * t];
         pn += a.tile_counts[2 * t + 1];
     }
@@ -908,16 +940,14 @@ __global__ __launch_bounds__(LG_TILE) void scatter_kernel(HopParams hp, const La
                 src_pos[u] = seeds ? q : a.agg_src_off[f_off + q];
                 if (!a.last_hop) nh[u] = load_hdr(a.row_hdr + dst);      // next hop's frontier header
                 lost_pos[u] = first ? 0 : a.slot_pos[idx];               // final already, or -2 - (slot it lost to)
-                if (a.first_masks != nullptr && lost_pos[u] < -1) {
+                if (a.first_rec != nullptr && lost_pos[u] < -1) {
                     // lds form: the slot it lost to IS the winner (chains have length one); its new position follows from the
-                    // first-touch prefix of its tile and the ballots flag_count kept -- no localise pass over the edges
+                    // record of the winner's wave -- no localise pass over the edges
                     const int32_t w = -2 - lost_pos[u];
-                    const int32_t tw = w / LG_TILE, ww = (w % LG_TILE) >> 6, lw = w & 63;
-                    const LG_G unsigned long long* mk = a.first_masks + (int64_t)tw * (LG_TILE / 64);
-                    int32_t nw = node_base + a.tile_prefix[2 * tw + 1];
-                    for (int j = 0; j < ww; j++) nw += __popcll(mk[j]);
-                    nw += __popcll(mk[ww] & (lw == 0 ? 0ull : (~0ull >> (64 - lw))));
-                    lost_pos[u] = nw;
+                    const lg_v4i r = *(const LG_G lg_v4i*)(a.first_rec + (w >> 6));       // (tile * 4 + wave) == slot / 64
+                    const unsigned long long m = ((unsigned long long)(uint32_t)r.y << 32) | (uint32_t)r.x;
+                    const int32_t lw = w & 63;
+                    lost_pos[u] = r.z + __popcll(m & (lw == 0 ? 0ull : (~0ull >> (64 - lw))));
                 }
                 fsv[u] = (first && a.slot_fs != nullptr) ? a.slot_fs[idx] : LG_FS_UNKNOWN;   // the new node's feature-cache slot, if carried
                 tab_at[u] = (first && !a.last_hop && a.pos_table != nullptr) ? table_find(a.pos_table, a.pos_mask, a.pf, dst) : 0u;
@@ -948,7 +978,7 @@ __global__ __launch_bounds__(LG_TILE) void scatter_kernel(HopParams hp, const La
                     else
                         raise_error(a.hop_scratch, a.err_flag, LG_ERR_TABLE_FULL);
                 }
-                if (a.first_masks == nullptr) a.slot_pos[idx] = n;   // (what localise follows; the lds form needs no localise)
+                if (a.first_rec == nullptr) a.slot_pos[idx] = n;     // (what localise follows; the lds form needs no localise)
                 a.agg_src_off[e] = n;                              // construct_graph's neighbour side, known here
             } else {
                 a.agg_src_off[e] = lost_pos[u];

@@ -199,6 +199,15 @@ struct alignas(16) RowHdr {
     int32_t slot;
 };
 
+// lds form: what flag_count + scan leave per wave of every 256-slot tile of a hop -- the ballot of its first-touch slots and
+// the position in sampled_ids of the first of them.  ANY winner's final position is then base + popcount(mask below its
+// lane): scatter places a loser's edge with one 16-byte load instead of a localise pass over all edges.
+struct alignas(16) FirstRec {
+    unsigned long long mask;
+    int32_t base;       // flag_count: first touches in the tile's earlier waves; scan adds node_base + the tile's prefix
+    int32_t pad;
+};
+
 struct BuildInfo {  // SS/include/buildinfo.h (only the fields of the in-memory path)
     int32_t partition_count = 0;
     std::vector<int32_t> training_set_num, validation_set_num, testing_set_num;
@@ -253,8 +262,7 @@ struct LanePtrs {
                                        // instead of node_map[id] (one 128-byte line per row for 4 bytes)
     int32_t* tile_counts;
     int32_t* tile_prefix;
-    unsigned long long* first_masks;   // lds form: [tiles][4] ballot of the first-touch slots of every wave of a 256-slot tile (flag_count):
-                                       // with tile_prefix it gives ANY winner's final position, so scatter localises losers itself
+    FirstRec* first_rec;               // lds form: [tiles][4], see FirstRec
     int32_t* hop_scratch;
     RowHdr* fh_edge;
     int32_t* cache_search_buffer;
@@ -318,7 +326,7 @@ public:
     int32_t* slot_fs = nullptr;        // [max_slots] / [num_ids]: feature-cache slots carried from the sampler to the gather
     int32_t* node_slot = nullptr;
     int32_t* tile_counts = nullptr;    // [2 * max_tiles] valid / first-touch counts per tile
-    unsigned long long* first_masks = nullptr;   // lds form: [max_tiles][4] first-touch ballots (LanePtrs)
+    FirstRec* first_rec = nullptr;     // lds form: [max_tiles][4] (LanePtrs)
     int32_t* tile_prefix = nullptr;    // [2 * max_tiles] exclusive prefixes
     RowHdr* fh_edge = nullptr;         // [num_ids] frontier row headers written by scatter
     int32_t* hop_scratch = nullptr;    // [HS_WORDS]
@@ -699,6 +707,7 @@ struct GatherParams {
     int32_t member;                 // this GPU's index inside its clique (dev_id % Kg)
     unsigned long long* stats;      // optional {rows read through a stripe pointer, rows from the local replica, rows from a PEER's stripe}
     const float* const* cache_tables;
+    const float* local_table;       // this member's own stripe by value (cache_tables[member]): no dependent pointer load for local rows
     const int32_t* node_map;
     int32_t node_capacity;
     int32_t D;

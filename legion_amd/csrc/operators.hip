@@ -315,6 +315,7 @@ extern "C" void legion_gather_rows(legion_stream_t stream, const float* full_tab
     g.stats = nullptr;
     g.full_table = full_table;
     g.cache_tables = cache_tables;
+    g.local_table = nullptr;
     g.node_map = node_map;
     g.node_capacity = node_capacity;
     g.D = float_feature_len;

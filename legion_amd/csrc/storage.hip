@@ -455,7 +455,7 @@ LanePtrs MemoryPool::HostLane(int32_t pipe) const
     h.max_slots = max_slots;
     h.total_num_nodes = total_num_nodes;
     h.tile_counts = tile_counts;
-    h.first_masks = first_masks;
+    h.first_rec = first_rec;
     h.tile_prefix = tile_prefix;
     h.hop_scratch = hop_scratch;
     h.fh_edge = fh_edge;
@@ -512,8 +512,8 @@ void MemoryPool::Finalize()
     d_free_space(node_slot);
     slot_fs = node_slot = nullptr;
     d_free_space(tile_counts);
-    d_free_space(first_masks);
-    first_masks = nullptr;
+    d_free_space(first_rec);
+    first_rec = nullptr;
     d_free_space(tile_prefix);
     d_free_space(hop_scratch);
     d_free_space(fh_edge);
@@ -652,7 +652,7 @@ void lg_pool_alloc_private(MemoryPool* mp, int32_t dev_id, int32_t total_num_nod
         HIP_CALL(hipDeviceSynchronize());
     }
     mp->tile_counts = (int32_t*)d_alloc_space(2 * max_tiles * sizeof(int32_t));
-    if (mp->lds_form) mp->first_masks = (unsigned long long*)d_alloc_space(4 * max_tiles * sizeof(unsigned long long));
+    if (mp->lds_form) mp->first_rec = (FirstRec*)d_alloc_space(4 * max_tiles * sizeof(FirstRec));
     mp->tile_prefix = (int32_t*)d_alloc_space(2 * max_tiles * sizeof(int32_t));
     mp->fh_edge = (RowHdr*)d_alloc_space(num_ids * sizeof(RowHdr));
     mp->hop_scratch = (int32_t*)d_alloc_space(HS_WORDS * sizeof(int32_t));

@@ -361,6 +361,37 @@ def test_lds_dedup_multi_pass_buckets(hip, monkeypatch):
     gpu.close(); cpu.close()
 
 
+def test_lds_dedup_skewed_sub_bucket(hip, monkeypatch):
+    """The LDS form when the hash does NOT spread a bucket over its sub-buckets: every neighbour of every seed hashes to the
+    same low 10 bits, so the passes the kernel plans from the claim count (sub-buckets by hash bits 3, 4) all land in one
+    sub-bucket of ~11 k distinct vertices -- more than the 8192-word table.  The kernel notices the failed insert and redoes
+    the bucket with more passes until the sub-buckets fit: bit-exact, no error (this used to raise
+    LG_ERR_TABLE_FULL and leave garbage positions)."""
+    monkeypatch.setenv("LEGION_DEDUP", "lds")
+    N = 1 << 24
+    x = np.arange(N, dtype=np.uint32)
+    x ^= x >> np.uint32(16); x *= np.uint32(0x7feb352d); x ^= x >> np.uint32(15); x *= np.uint32(0x846ca68b); x ^= x >> np.uint32(16)
+    S = np.nonzero((x & np.uint32(0x3FF)) == 5)[0].astype(np.int32)              # ~16 k vertices, one bucket, one sub-bucket
+    assert S.size > 14_000
+    seeds = np.setdiff1d(np.arange(6000, dtype=np.int32), S)[:4096]
+    deg = np.zeros(N, dtype=np.int64)
+    deg[seeds] = 24
+    deg[S] = 24
+    indptr = np.zeros(N + 1, dtype=np.int64); np.cumsum(deg, out=indptr[1:])
+    col = S[np.random.RandomState(3).randint(0, S.size, int(indptr[-1]))].astype(np.int32)
+    wl = Workload(dim=4, n_seeds=16, n_valid=0, n_test=0, indptr=indptr, col=col)
+    wl.sets[(0, 0)] = (np.ascontiguousarray(seeds), np.ascontiguousarray(wl.labels_all[seeds]))
+    fanout, batch = [20, 3], 1024
+    gpu, cpu = GpuSide(wl, batch, fanout), CpuSide(wl, batch, fanout)
+    assert gpu.pools[0].dedup_form() == "lds"
+    for it in range(2):
+        g, c = gpu.run(0, it, 0), cpu.run(0, it, 0)
+        compare_batches(g, c, f"skewed sub-bucket batch {it}: ")
+        assert int(g["node_counter"][10] - g["node_counter"][9]) > 8192          # hop 1 alone adds more vertices than a table holds
+    assert gpu.pools[0].error() == 0
+    gpu.close(); cpu.close()
+
+
 @pytest.mark.parametrize("known_cap", [None, "1", "80"], ids=["lists", "no-room", "some-buckets-overflow"])
 def test_lds_dedup_known_lists(hip, monkeypatch, known_cap):
     """LDS form, three hops: hops 2 and 3 recognise the nodes hops 1 and 2 added through the per-bucket lists scatter
