@@ -481,6 +481,7 @@ void UnifiedCache::FeatCacheLookup(const LanePtrs* d_lanes, int32_t n_lanes, int
     g.replica_rows = g.replica ? replica_rows_[dev_id] : 0;
     g.Kg = Kg_;
     g.member = dev_id % (Kg_ > 0 ? Kg_ : 1);
+    g.striped = Kg_ > 1;
     g.stats = (gather_stats_on_ && dev_id < (int32_t)gather_stats_.size()) ? gather_stats_[dev_id] : nullptr;
     g.full_table = cpu_float_features_;
     g.cache_tables = filled ? d_float_feature_cache_ptr_[dev_id] : nullptr;

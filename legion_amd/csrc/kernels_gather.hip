@@ -87,8 +87,11 @@ void launch_deliver(hipStream_t s, const LanePtrs* d_lane, const DeliverParams& 
 // VecT: float4 for rows that are multiples of 16 bytes; `v4u` -- the same 16 bytes per lane at 4-byte alignment -- for every other
 // width of at least 4 floats (gfx950 global loads / stores of 16 bytes need dword alignment only; the compiler emits
 // global_load_dwordx4 for both), with the D % 4 trailing floats of each row moved by a scalar pass (TAIL); float below that.
+#ifndef LG_GATHER_MIN_WAVES
+#define LG_GATHER_MIN_WAVES 8        // waves per SIMD the register allocation must leave room for (68 VGPRs would allow 7)
+#endif
 template <typename VecT, int ROWS = LG_GATHER_ROWS, int UNROLL = LG_GATHER_UNROLL, bool TAIL = false>
-__global__ __launch_bounds__(LG_GATHER_THREADS) void gather_kernel(GatherParams gp, const LanePtrs* __restrict__ lanes,
+__global__ __launch_bounds__(LG_GATHER_THREADS, LG_GATHER_MIN_WAVES) void gather_kernel(GatherParams gp, const LanePtrs* __restrict__ lanes,
                                                                    bool copy_range)
 {
     constexpr int VEC = sizeof(VecT) / sizeof(float);
@@ -151,7 +154,7 @@ __global__ __launch_bounds__(LG_GATHER_THREADS) void gather_kernel(GatherParams 
                 p = LG_GPTR(const float, gp.full_table) + (int64_t)(id < gp.total_num_nodes ? id : id % gp.total_num_nodes) * D;
         } else {
             int32_t didx = 0, fidx = g;                                                      // :259-260 (one division, and
-            if (gp.Kg > 1) { didx = g / gp.node_capacity; fidx = g - didx * gp.node_capacity; }   // none without striping)
+            if (gp.striped) { didx = g / gp.node_capacity; fidx = g - didx * gp.node_capacity; }  // none without striping)
             const int64_t rank = (int64_t)fidx * gp.Kg + didx;                               // hotness rank of the row (cache_impl.cuh:104-109)
             const bool local_copy = gp.replica != nullptr && rank < gp.replica_rows;
             if (local_copy)      // the clique's hottest rows are also kept locally: same row, no xGMI hop

@@ -227,10 +227,13 @@ void launch_batch_generate(hipStream_t s, const SeedParams& p, const LanePtrs* d
 // hop geometry shared by the three pre-scan kernels: read from the live counters
 // ------------------------------------------------------------------------------------------
 // the kernels' view of one lane: the launch-wide hop parameters + that lane's buffers
+typedef int32_t lg_v4i __attribute__((ext_vector_type(4)));
+typedef int32_t lg_v2i __attribute__((ext_vector_type(2)));
 struct SampleArgs {
     int32_t op_id, count, partition_count, max_slots;
     int32_t* const* csr_dst_node_ids;
     int32_t* const* csr_dst_x;
+    const LG_G int32_t* col_full; const LG_G lg_v2i* colx_full;
     const LG_G RowHdr* row_hdr;
     bool last_hop, is_presc;
     LG_G unsigned long long* edge_access_time;
@@ -250,8 +253,7 @@ struct SampleArgs {
 
 // 16-byte header load / store through a global-address-space pointer (no implicit struct copy across
 // address spaces in HIP C++)
-typedef int32_t lg_v4i __attribute__((ext_vector_type(4)));
-typedef int32_t lg_v2i __attribute__((ext_vector_type(2)));
+
 __device__ __forceinline__ RowHdr load_hdr(const LG_G RowHdr* p)
 {
     const lg_v4i t = *(const LG_G lg_v4i*)p;
@@ -276,7 +278,8 @@ __device__ __forceinline__ SampleArgs lane_args(const HopParams& p, const LanePt
     const LanePtrs& L = lanes[blockIdx.y];
     SampleArgs a;
     a.op_id = p.op_id; a.count = p.count; a.partition_count = p.partition_count; a.max_slots = p.max_slots;
-    a.csr_dst_node_ids = p.csr_dst_node_ids; a.csr_dst_x = p.csr_dst_x; a.row_hdr = LG_GPTR(const RowHdr, p.row_hdr); a.last_hop = p.last_hop; a.is_presc = p.is_presc;
+    a.csr_dst_node_ids = p.csr_dst_node_ids; a.csr_dst_x = p.csr_dst_x;
+    a.col_full = LG_GPTR(const int32_t, p.col_full); a.colx_full = LG_GPTR(const lg_v2i, p.colx_full); a.row_hdr = LG_GPTR(const RowHdr, p.row_hdr); a.last_hop = p.last_hop; a.is_presc = p.is_presc;
     a.edge_access_time = LG_GPTR(unsigned long long, p.edge_access_time);
     a.topo_transactions = LG_GPTR(unsigned long long, p.topo_transactions);
     a.sampled_ids = LG_GPTR(int32_t, L.sampled_ids); a.agg_src_ids = LG_GPTR(int32_t, L.agg_src_ids);
@@ -337,8 +340,11 @@ __device__ __forceinline__ HopGeom hop_geometry(const SampleArgs& a)
 // coalesced 16-byte load per frontier entry), for hop 1 they are looked up in the per-vertex
 // header table here.
 // ------------------------------------------------------------------------------------------
+#ifndef LG_SAMPLE_SGPRS
+#define LG_SAMPLE_SGPRS 80           // 8 workgroups of 256 threads per CU need <= 80 SGPRs (MI355X_MICROARCH.md, residency); 90-106 give 6-7
+#endif
 template <int FORM, int BB, bool SINGLE>      // 0 direct array, 1 table, 2 lds with 2^BB buckets per lane; SINGLE: partition tile = super tile
-__global__ __launch_bounds__(LG_TILE) void sample_kernel(HopParams hp, const LanePtrs* __restrict__ lanes)
+__global__ __launch_bounds__(LG_TILE) __attribute__((amdgpu_num_sgpr(LG_SAMPLE_SGPRS))) void sample_kernel(HopParams hp, const LanePtrs* __restrict__ lanes)
 {
     constexpr bool TABLE = FORM == 1;
     constexpr int NB = 1 << BB;
@@ -417,14 +423,27 @@ __global__ __launch_bounds__(LG_TILE) void sample_kernel(HopParams hp, const Lan
                     const RowHdr h = s_hdr[q - j0];
                     if (k < h.deg) {                                           // :232-233 (src < 0 has deg 0)
                         const int32_t pick = draw_from_x(x[u], h.deg);         // :235-238
-                        // column slots: the same sector read as 8 bytes brings the neighbour's feature-cache slot along
-                        const LG_G lg_v2i* cx = a.csr_dst_x != nullptr ? LG_GPTR(const lg_v2i, a.csr_dst_x[h.slot]) : nullptr;
-                        if (cx != nullptr) {
-                            const lg_v2i e = cx[h.start + (int64_t)pick];
-                            dst[u] = e.x;
-                            fs[u] = e.y;
+                        // column slots: the same sector read as 8 bytes brings the neighbour's feature-cache slot along.  Picks
+                        // from the full CSR (slot P: all but the cached-topology rows) address it through pointers that came
+                        // with the launch; only a cached row's pick loads its column array's address from the table first
+                        const int64_t at = h.start + (int64_t)pick;
+                        if (h.slot == a.partition_count) {
+                            if (a.colx_full != nullptr) {
+                                const lg_v2i e = a.colx_full[at];
+                                dst[u] = e.x;
+                                fs[u] = e.y;
+                            } else {
+                                dst[u] = a.col_full[at];                        // :239-243
+                            }
                         } else {
-                            dst[u] = LG_GPTR(const int32_t, a.csr_dst_node_ids[h.slot])[h.start + (int64_t)pick];   // :239-243
+                            const LG_G lg_v2i* cx = a.csr_dst_x != nullptr ? LG_GPTR(const lg_v2i, a.csr_dst_x[h.slot]) : nullptr;
+                            if (cx != nullptr) {
+                                const lg_v2i e = cx[at];
+                                dst[u] = e.x;
+                                fs[u] = e.y;
+                            } else {
+                                dst[u] = LG_GPTR(const int32_t, a.csr_dst_node_ids[h.slot])[at];
+                            }
                         }
                     }
                 }
@@ -586,8 +605,11 @@ __global__ __launch_bounds__(LG_TILE) void sample_kernel(HopParams hp, const Lan
 #endif
 __device__ __forceinline__ uint32_t lds_slot_of(uint32_t h) { return (h * 0x9E3779B1u) >> (32 - LG_LDS_TABLE_BITS); }
 
+// (SGPR cap: two of these 16-wave workgroups share a CU only while the kernel stays within 80 SGPRs -- 82..96 admit 28 waves
+// per CU, i.e. ONE workgroup, and the kernel takes 150 us instead of 94 at hop 2 of a 256-lane group; measured, round 3)
 template <int BB>
-__global__ __launch_bounds__(LG_DEDUP_THREADS) void dedup_lds_kernel(HopParams hp, const LanePtrs* __restrict__ lanes)
+__global__ __launch_bounds__(LG_DEDUP_THREADS) __attribute__((amdgpu_num_sgpr(80)))
+void dedup_lds_kernel(HopParams hp, const LanePtrs* __restrict__ lanes)
 {
     constexpr int NB = 1 << BB;
     const int32_t K = hp.lds_k;                           // super tiles per partition tile (1 in the 8-bucket class)
@@ -700,7 +722,9 @@ __global__ __launch_bounds__(LG_DEDUP_THREADS) void dedup_lds_kernel(HopParams h
             }
         }
         __syncthreads();
+#ifndef LG_LDS_NO_RETRY
         if (s_full != 0) { overflow = true; break; }       // (uniform: read behind the barrier, reset behind the next one)
+#endif
         for (int32_t k0 = 0; k0 < total; k0 += LG_DEDUP_BATCH * LG_DEDUP_THREADS) {
             unsigned long long pr[LG_DEDUP_BATCH];
 #pragma unroll
@@ -879,7 +903,11 @@ __global__ __launch_bounds__(LG_SCAN_THREADS) void scan_kernel(HopParams hp, con
 // edges and the new nodes it writes, next to every edge, the row header of the sampled
 // neighbour: the next hop's frontier then needs no dependent lookup.
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(LG_TILE) void scatter_kernel(HopParams hp, const LanePtrs* __restrict__ lanes)
+#ifndef LG_SCATTER_MIN_WAVES
+#define LG_SCATTER_MIN_WAVES 6
+#endif
+__global__ __launch_bounds__(LG_TILE, LG_SCATTER_MIN_WAVES) __attribute__((amdgpu_num_sgpr(80)))
+void scatter_kernel(HopParams hp, const LanePtrs* __restrict__ lanes)
 {
     const SampleArgs a = lane_args(hp, lanes);
     __shared__ int32_t s_cnt[LG_SLOTS_PER_LANE][2][LG_TILE / 64];

@@ -410,6 +410,7 @@ public:
     // device memory and 8 bytes per edge are affordable (LegionTuning.col_slots); slots of cached-topology CSRs are not
     // paired: their picks carry LG_FS_UNKNOWN and the gather looks those rows up as before.
     virtual int32_t** GetCSRXMatrix(int32_t part_id) const = 0;       // device table [P+1] of pair arrays (null entries), or null
+    virtual const int32_t* GetColumnSlotsFull(int32_t part_id) const = 0;   // that GPU's pair copy of the full column array, or null
     virtual void BuildColumnSlots(int32_t dev, const int32_t* node_map) = 0;
     virtual void DropColumnSlots(int32_t dev) = 0;
     // GraphCache in two steps, so that a clique spread over processes can exchange the stripes in
@@ -678,6 +679,8 @@ struct HopParams {                  // what every lane of a launch shares
     int32_t partition_count;        // P: slot of the full CSR in the pointer tables
     int32_t* const* csr_dst_node_ids;   // device table [P+1] of column arrays
     int32_t* const* csr_dst_x;          // device table [P+1] of {id, feature-cache slot} pair arrays (column slots), or null
+    const int32_t* col_full;            // the full CSR's column array and its pair copy BY VALUE: a pick from slot P (nearly all of
+    const int32_t* colx_full;           // them) then needs no dependent load of a table entry before the column load itself
     const RowHdr* row_hdr;          // [N] per-vertex row headers of this GPU
     bool last_hop;                  // no next hop: scatter skips the header lookup
     bool is_presc;
@@ -705,6 +708,7 @@ struct GatherParams {
     int32_t replica_rows;
     int32_t Kg;                     // GPUs per clique: rank t of a hit = (g % cap) * Kg + g / cap
     int32_t member;                 // this GPU's index inside its clique (dev_id % Kg)
+    bool striped;                   // slots encode (owner, row) = (g / capacity, g % capacity); false: one table, row = g (no division)
     unsigned long long* stats;      // optional {rows read through a stripe pointer, rows from the local replica, rows from a PEER's stripe}
     const float* const* cache_tables;
     const float* local_table;       // this member's own stripe by value (cache_tables[member]): no dependent pointer load for local rows

@@ -111,6 +111,8 @@ static void do_random_sample(hipStream_t s, GraphStorage* graph, UnifiedCache* c
     p.partition_count = graph->GetPartitionCount();
     p.csr_dst_node_ids = graph->GetCSRNodeMatrix(dev_id);
     p.csr_dst_x = (is_presc || pool0->slot_fs == nullptr) ? nullptr : graph->GetCSRXMatrix(dev_id);
+    p.col_full = graph->GetCSRNodeMatrixCPU();
+    p.colx_full = p.csr_dst_x != nullptr ? graph->GetColumnSlotsFull(dev_id) : nullptr;
     p.row_hdr = graph->GetRowHeaders(dev_id);
     p.last_hop = (size_t)(op_id / INTRABATCH_CON) + 1 >= pool0->max_new.size();
     p.is_presc = is_presc;
@@ -312,6 +314,7 @@ extern "C" void legion_gather_rows(legion_stream_t stream, const float* full_tab
     g.replica_rows = 0;
     g.Kg = 1;
     g.member = 0;
+    g.striped = true;               // the caller's node_map may address several tables: always decode (owner, row)
     g.stats = nullptr;
     g.full_table = full_table;
     g.cache_tables = cache_tables;

@@ -284,6 +284,7 @@ public:
         colx_full_[dev] = nullptr;
     }
     int32_t** GetCSRXMatrix(int32_t part_id) const override { return csr_dst_x_.empty() ? nullptr : csr_dst_x_[part_id]; }
+    const int32_t* GetColumnSlotsFull(int32_t part_id) const override { return colx_full_.empty() ? nullptr : colx_full_[part_id]; }
 
     void Finalize() override
     {

@@ -236,3 +236,25 @@ def test_boundary_soak_every_batch_verified(hip, lanes):
     assert res.returncode == 0 and lines, (res.stdout[-1500:], res.stderr[-3000:])
     d = json.loads(lines[-1])
     assert d["verified_batches"] >= 620 and d["batches_per_sec"] > 0
+
+
+@pytest.mark.timeout(1500)
+def test_server_loads_a_uk_union_sized_dataset(hip):
+    """The reference's file formats at uk-union's REAL size through the server's own loaders (SS/storage/
+    storage_management_impl.cuh:46-159; legion_server.py:65-72): N = 133 633 040, E = 5 507 679 822 -- an `edge_dst` file of
+    22 GB (> 16 GiB, > 2^32 entries), `edge_src` offsets beyond 2^32 -- written to /tmp, loaded into HBM by `sampling_server`,
+    PreSC + cache set-up, then every served batch verified on the device by the consumer (rows = the generator's rows of
+    the batch's ids, unique ids, edge endpoints inside the batch, the seeds are the training batch's).  D = 4 keeps the
+    features file at 2 GB; what is under test is everything that scales with E."""
+    import json
+    import shutil
+    if shutil.disk_usage("/tmp").free < (40 << 30):
+        pytest.skip("needs 40 GB of free space in /tmp for the data set files")
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "server_throughput.py"), "--nodes", "133633040",
+                          "--edges", "5507679822", "--batch", "8000", "--dim", "4", "--fanout", "25,10", "--train-batches", "12",
+                          "--verify-every", "1", "--watchdog", "1200", "--cache-memory", str(1 << 30)],
+                         stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, stdin=subprocess.DEVNULL, timeout=1400)
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+    assert res.returncode == 0 and lines, (res.stdout[-1500:], res.stderr[-3000:])
+    d = json.loads(lines[-1])
+    assert d["verified_batches"] >= 12 and d["edges_per_sec"] > 0 and "E=5507679822" in d["workload"]

@@ -1,0 +1,23 @@
+#!/bin/bash
+# Bench lines at the reference's REAL data-set sizes on one MI355X (legion_server.py:41-88):  bash tools/real_size_runs.sh r03
+#   uk-union   N = 133 633 040, E = 5 507 679 822, D = 256, B = 8000, [25,10]   (configs[3]'s data set; all resident: 160 GB)
+#   papers100M N = 111 059 956, E = 1 615 685 872, D = 128, B = 8000, [15,10,5], CSR + features in pinned host memory (configs[2])
+RND=${1:-r03}
+R=$GRAFT_REPO_ROOT; OUT=$R/gpurun_out/real_$RND; mkdir -p $OUT
+COMMON="--cpu-seconds 0 --no-boundary --no-overlap-leg --presc-steps 64 --steps 8 --warmup 2 --group 8"
+run() { name=$1; shift; ( time timeout -k 5 1200 python3 $R/bench.py $COMMON "$@" > $OUT/$name.json 2> $OUT/$name.err < /dev/null ) 2>&1 | grep real
+  python3 - $OUT/$name.json $name <<'PY'
+import json, sys
+try:
+    d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
+    print(sys.argv[2], "value %.3f G edges/s" % (d["value"] / 1e9), "ms/step %.3f" % d["ms_per_step"], "gather frac %.3f" % d["roofline"]["frac"],
+          "rows/launch %.0f" % d["roofline"]["rows_per_launch"], "sampler-only %.2f G" % (d["sampling_only"]["edges_per_sec"] / 1e9),
+          "cache rows", d["config"]["feature_cache_rows"], "hit rate %.3f" % d["feature_cache_hit_rate"], d.get("miss_path", {}).get("pcie_feature_GBps"))
+except Exception as e:
+    print(sys.argv[2], "FAILED", e); print(open(sys.argv[1].replace(".json", ".err")).read()[-1500:])
+PY
+}
+run uk_union_size_d256_b8000 --nodes 133633040 --edges 5507679822 --dim 256 --batch 8000
+LEGION_COL_SLOTS=1 run uk_union_size_d256_b8000_column_slots --nodes 133633040 --edges 5507679822 --dim 256 --batch 8000
+run papers100m_size_3hop_pinned --nodes 111059956 --edges 1615685872 --dim 128 --batch 8000 --fanout 15,10,5 --placement pinned --link-counters smi
+run papers100m_size_3hop_hbm --nodes 111059956 --edges 1615685872 --dim 128 --batch 8000 --fanout 15,10,5
