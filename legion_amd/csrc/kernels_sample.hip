@@ -241,8 +241,7 @@ struct SampleArgs {
     // the lane's buffers, in the global address space (see LG_G in legion_core.h)
     LG_G int32_t* sampled_ids; LG_G int32_t* agg_src_ids; LG_G int32_t* agg_dst_ids; LG_G int32_t* agg_src_off; LG_G int32_t* agg_dst_off;
     LG_G char* tmp_part_ind; LG_G uint32_t* position_map; LG_G int32_t* node_counter; LG_G int32_t* edge_counter;
-    LG_G int32_t* slot_dst; LG_G int32_t* slot_pos; LG_G int32_t* slot_mark; LG_G int32_t* slot_fs; LG_G int32_t* node_slot; LG_G int32_t* tile_counts; LG_G int32_t* tile_prefix; LG_G int32_t* hop_scratch;
-    LG_G FirstRec* first_rec;
+    LG_G int32_t* slot_dst; LG_G int32_t* slot_pos; LG_G int32_t* slot_mark; LG_G int32_t* slot_fs; LG_G int32_t* node_slot; LG_G unsigned long long* tile_state; LG_G int32_t* hop_scratch;
     LG_G RowHdr* fh_edge;
     LG_G unsigned long long* pos_table; uint32_t pos_mask; LG_G int32_t* err_flag;
     LG_G unsigned long long* claim_pairs; LG_G int32_t* run_off;
@@ -288,10 +287,8 @@ __device__ __forceinline__ SampleArgs lane_args(const HopParams& p, const LanePt
     a.position_map = LG_GPTR(uint32_t, L.position_map); a.node_counter = LG_GPTR(int32_t, L.node_counter);
     a.edge_counter = LG_GPTR(int32_t, L.edge_counter); a.slot_dst = LG_GPTR(int32_t, L.slot_dst);
     a.slot_pos = LG_GPTR(int32_t, L.slot_pos); a.slot_mark = LG_GPTR(int32_t, L.slot_mark);
-    a.slot_fs = LG_GPTR(int32_t, L.slot_fs); a.node_slot = LG_GPTR(int32_t, L.node_slot); a.tile_counts = LG_GPTR(int32_t, L.tile_counts);
-    a.tile_prefix = LG_GPTR(int32_t, L.tile_prefix); a.hop_scratch = LG_GPTR(int32_t, L.hop_scratch);
+    a.slot_fs = LG_GPTR(int32_t, L.slot_fs); a.node_slot = LG_GPTR(int32_t, L.node_slot); a.tile_state = LG_GPTR(unsigned long long, L.tile_state); a.hop_scratch = LG_GPTR(int32_t, L.hop_scratch);
     a.fh_edge = LG_GPTR(RowHdr, L.fh_edge);
-    a.first_rec = LG_GPTR(FirstRec, L.first_rec);
     a.pos_table = LG_GPTR(unsigned long long, L.pos_table); a.pos_mask = L.pos_table_mask;
     a.err_flag = LG_GPTR(int32_t, L.err_flag);
     a.claim_pairs = LG_GPTR(unsigned long long, L.claim_pairs);
@@ -491,6 +488,7 @@ __global__ __launch_bounds__(LG_TILE) __attribute__((amdgpu_num_sgpr(LG_SAMPLE_S
                         dst[u] = -1;
                     }
                     a.slot_dst[idx] = dst[u];
+                    if (FORM == 2) a.slot_pos[idx] = -1;      // "no position yet": compact_kernel publishes a first touch's position here
                     if (a.slot_fs != nullptr && dst[u] >= 0) a.slot_fs[idx] = fs[u];     // (read for first-touch slots only)
                 }
             }
@@ -618,7 +616,7 @@ void dedup_lds_kernel(HopParams hp, const LanePtrs* __restrict__ lanes)
     __shared__ unsigned long long s_tab[LG_LDS_TABLE];
     __shared__ int32_t s_pref[MAX_PARTS];                  // exclusive prefix of the bucket's segment lengths
     __shared__ int32_t s_seg[MAX_PARTS];                   // where the bucket's segment of partition tile t starts in claim_pairs
-    __shared__ int32_t s_known, s_total, s_full;
+    __shared__ int32_t s_total, s_full;
     const HopGeom g = hop_geometry(a);
     const int32_t nparts = (g.nsuper + K - 1) / K;
     const int32_t tid = threadIdx.x, b = blockIdx.x;
@@ -627,7 +625,7 @@ void dedup_lds_kernel(HopParams hp, const LanePtrs* __restrict__ lanes)
     const LG_G int32_t* roff = a.run_off + b;              // roff[t * (NB + 1)]: start of this bucket's segment of partition tile t
 
     // the bucket's segments, one per partition tile: exclusive prefix of their lengths
-    if (tid == 0) { s_known = 0; s_total = 0; }
+    if (tid == 0) s_total = 0;
     for (int32_t t = tid; t < nparts; t += LG_DEDUP_THREADS) {
         const int32_t off = roff[(int64_t)t * (NB + 1)];
         s_pref[t + 1] = roff[(int64_t)t * (NB + 1) + 1] - off;
@@ -653,21 +651,16 @@ void dedup_lds_kernel(HopParams hp, const LanePtrs* __restrict__ lanes)
     const bool listed = a.known_pairs != nullptr && n_listed <= a.known_cap;
     const int32_t n_scan = listed ? n_seed : n_known;
     const LG_G unsigned long long* klist = a.known_pairs + (int64_t)b * a.known_cap;
-    int32_t known_here = 0;
-    for (int32_t i = tid; i < n_scan; i += LG_DEDUP_THREADS) {
-        const int32_t id = a.sampled_ids[i];
-        if (id >= 0 && (lg_tab_hash(id) & (NB - 1)) == (uint32_t)b) known_here++;
-    }
-    if (tid == 0 && listed) known_here += n_listed;
-    if (known_here) atomicAdd(&s_known, known_here);
     __syncthreads();
     const int32_t total = s_total;
     // passes: distinct vertices <= known + claims; keep the expected load of a pass at or below LG_LDS_FILL_16THS / 16 of the
-    // table.  That bound assumes the hash spreads the bucket evenly over its sub-buckets; when it does not (s_full: an insert
-    // found no free word) the whole bucket is redone with twice the passes -- every claim's outcome is the same under any
-    // partition, so what finished passes already wrote is simply written again.
+    // table.  The bucket's share of the scanned ids is ESTIMATED (an even spread + a quarter; counting it would cost every
+    // workgroup one more round trip to memory), and the hash is assumed to spread the bucket evenly over its sub-buckets: when
+    // either is wrong (s_full: an insert found no free word) the whole bucket is redone with twice the passes -- every claim's
+    // outcome is the same under any partition, so what finished passes already wrote is simply written again.
+    const int32_t known_est = (listed ? n_listed : 0) + n_scan / NB + n_scan / (4 * NB) + 32;
     int32_t passes = 1;
-    while ((int64_t)(s_known + total) > (int64_t)passes * (LG_LDS_TABLE / 16 * LG_LDS_FILL_16THS)) passes <<= 1;
+    while ((int64_t)known_est + total > (int64_t)passes * (LG_LDS_TABLE / 16 * LG_LDS_FILL_16THS)) passes <<= 1;
 
     auto segment_of = [&](int32_t k) {                 // claim k of the bucket -> index into claim_pairs
         int32_t lo = 0, hi = nparts;                   // s_pref[lo] <= k < s_pref[hi]
@@ -684,6 +677,19 @@ void dedup_lds_kernel(HopParams hp, const LanePtrs* __restrict__ lanes)
         }
         s_full = 1;
     };
+
+    // a bucket of at most LG_DEDUP_BATCH claims per thread (the usual case) keeps them in registers: one trip to memory for both
+    // sweeps of every pass
+    const bool resident = total <= LG_DEDUP_BATCH * LG_DEDUP_THREADS;
+    unsigned long long rp[LG_DEDUP_BATCH];
+    auto fetch = [&](int32_t k0, unsigned long long (&pr)[LG_DEDUP_BATCH]) {
+#pragma unroll
+        for (int u = 0; u < LG_DEDUP_BATCH; u++) {
+            const int32_t k = k0 + u * LG_DEDUP_THREADS + tid;
+            pr[u] = k < total ? a.claim_pairs[segment_of(k)] : ~0ull;
+        }
+    };
+    if (resident) fetch(0, rp);
 
   for (;;) {
     const uint32_t pmask = (uint32_t)passes - 1u;
@@ -708,11 +714,11 @@ void dedup_lds_kernel(HopParams hp, const LanePtrs* __restrict__ lanes)
             }
         for (int32_t k0 = 0; k0 < total; k0 += LG_DEDUP_BATCH * LG_DEDUP_THREADS) {
             unsigned long long pr[LG_DEDUP_BATCH];
+            if (resident) {
 #pragma unroll
-            for (int u = 0; u < LG_DEDUP_BATCH; u++) {
-                const int32_t k = k0 + u * LG_DEDUP_THREADS + tid;
-                pr[u] = k < total ? a.claim_pairs[segment_of(k)] : ~0ull;
-            }
+                for (int u = 0; u < LG_DEDUP_BATCH; u++) pr[u] = rp[u];
+            } else
+                fetch(k0, pr);
 #pragma unroll
             for (int u = 0; u < LG_DEDUP_BATCH; u++) {
                 if (pr[u] == ~0ull) continue;
@@ -727,11 +733,11 @@ void dedup_lds_kernel(HopParams hp, const LanePtrs* __restrict__ lanes)
 #endif
         for (int32_t k0 = 0; k0 < total; k0 += LG_DEDUP_BATCH * LG_DEDUP_THREADS) {
             unsigned long long pr[LG_DEDUP_BATCH];
+            if (resident) {
 #pragma unroll
-            for (int u = 0; u < LG_DEDUP_BATCH; u++) {
-                const int32_t k = k0 + u * LG_DEDUP_THREADS + tid;
-                pr[u] = k < total ? a.claim_pairs[segment_of(k)] : ~0ull;
-            }
+                for (int u = 0; u < LG_DEDUP_BATCH; u++) pr[u] = rp[u];
+            } else
+                fetch(k0, pr);
 #pragma unroll
             for (int u = 0; u < LG_DEDUP_BATCH; u++) {
                 if (pr[u] == ~0ull) continue;
@@ -765,229 +771,200 @@ void dedup_lds_kernel(HopParams hp, const LanePtrs* __restrict__ lanes)
 }
 
 // ------------------------------------------------------------------------------------------
-// K2: per-256-slot-tile counts of valid edges and first touches (coalesced reads only: the sample
-//     kernel left a mark on every slot that lost its first touch)
-// ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(LG_TILE) void flag_count_kernel(HopParams hp, const LanePtrs* __restrict__ lanes)
-{
-    const SampleArgs a = lane_args(hp, lanes);
-    __shared__ int32_t s_cnt[LG_SLOTS_PER_LANE][2][LG_TILE / 64];
-    const HopGeom g = hop_geometry(a);
-    const int32_t tid = threadIdx.x;
-    const int32_t wave = tid >> 6, lane = tid & 63;
-
-    for (int32_t st = blockIdx.x; st < g.nsuper; st += gridDim.x) {
-        const int32_t idx0 = st * LG_SUPER;
-        int32_t v[LG_SLOTS_PER_LANE], mk[LG_SLOTS_PER_LANE];
-        unsigned long long mfk[LG_SLOTS_PER_LANE];
-#pragma unroll
-        for (int u = 0; u < LG_SLOTS_PER_LANE; u++) {
-            const int32_t idx = idx0 + u * LG_TILE + tid;
-            v[u] = idx < g.total ? a.slot_dst[idx] : -1;
-            mk[u] = idx < g.total ? a.slot_mark[idx] : 0;
-        }
-#pragma unroll
-        for (int u = 0; u < LG_SLOTS_PER_LANE; u++) {
-            const int32_t idx = idx0 + u * LG_TILE + tid;
-            const bool valid = v[u] >= 0;
-            const bool first = valid && mk[u] != a.mark_tag;     // nobody marked it a loser in this hop
-            if (first) a.slot_dst[idx] = v[u] | (int32_t)0x80000000;
-            const unsigned long long mv = __ballot(valid);
-            const unsigned long long mf = __ballot(first);
-            mfk[u] = mf;
-            if (lane == 0) {
-                s_cnt[u][0][wave] = __popcll(mv);
-                s_cnt[u][1][wave] = __popcll(mf);
-            }
-        }
-        __syncthreads();
-        if (a.first_rec != nullptr && lane == 0) {       // lds form: the wave's first-touch ballot + its offset inside the tile
-#pragma unroll
-            for (int u = 0; u < LG_SLOTS_PER_LANE; u++) {
-                const int32_t tile = st * LG_SLOTS_PER_LANE + u;
-                if (tile >= g.ntiles) continue;
-                int32_t before = 0;
-                for (int w = 0; w < wave; w++) before += s_cnt[u][1][w];
-                lg_v4i r;
-                r.x = (int32_t)(uint32_t)mfk[u];
-                r.y = (int32_t)(uint32_t)(mfk[u] >> 32);
-                r.z = before;
-                r.w = 0;
-                *(LG_G lg_v4i*)(a.first_rec + (int64_t)tile * (LG_TILE / 64) + wave) = r;
-            }
-        }
-        if (tid < 2 * LG_SLOTS_PER_LANE) {
-            const int u = tid >> 1, which = tid & 1;
-            const int32_t tile = st * LG_SLOTS_PER_LANE + u;
-            if (tile < g.ntiles) {
-                int32_t c = 0;
-                for (int w = 0; w < LG_TILE / 64; w++) c += s_cnt[u][which][w];
-                a.tile_counts[2 * tile + which] = c;
-            }
-        }
-        __syncthreads();
-    }
-}
-
-// ------------------------------------------------------------------------------------------
-// K3: one workgroup: exclusive prefix over tiles, hop scratch, counter_update(op) and the
-//     copy the following gather op would make (counter_update(op+1)).
-// ------------------------------------------------------------------------------------------
-#define LG_SCAN_THREADS 1024
-__global__ __launch_bounds__(LG_SCAN_THREADS) void scan_kernel(HopParams hp, const LanePtrs* __restrict__ lanes)
-{
-    const SampleArgs a = lane_args(hp, lanes);
-    __shared__ int32_t s_e[LG_SCAN_THREADS];
-    __shared__ int32_t s_n[LG_SCAN_THREADS];
-    const HopGeom g = hop_geometry(a);
-    LG_G int32_t* nc = a.node_counter;
-    LG_G int32_t* ec = a.edge_counter;
-    const int32_t nc0 = nc[0], nc1 = nc[1], ec0 = ec[0], ec1 = ec[1];
-    const int32_t tid = threadIdx.x;
-
-    const int32_t per = (g.ntiles + LG_SCAN_THREADS - 1) / LG_SCAN_THREADS;
-    const int32_t lo = min(tid * per, g.ntiles), hi = min(lo + per, g.ntiles);
-    int32_t se = 0, sn = 0;
-    for (int32_t t = lo; t < hi; t++) { se += a.tile_counts[2 * t]; sn += a.tile_counts[2 * t + 1]; }
-    s_e[tid] = se;
-    s_n[tid] = sn;
-    __syncthreads();
-    for (int32_t d = 1; d < LG_SCAN_THREADS; d <<= 1) {        // inclusive Hillis-Steele
-        int32_t ve = 0, vn = 0;
-        if (tid >= d) { ve = s_e[tid - d]; vn = s_n[tid - d]; }
-        __syncthreads();
-        s_e[tid] += ve;
-        s_n[tid] += vn;
-        __syncthreads();
-    }
-    int32_t pe = s_e[tid] - se, pn = s_n[tid] - sn;            // exclusive prefix of this chunk
-    for (int32_t t = lo; t < hi; t++) {
-        a.tile_prefix[2 * t] = pe;
-        a.tile_prefix[2 * t + 1] = pn;
-        if (a.first_rec != nullptr)        // lds form: every wave's record gets the absolute position of its first new node
-            for (int w = 0; w < LG_TILE / 64; w++) a.first_rec[(int64_t)t * (LG_TILE / 64) + w].base += nc0 + nc1 + pn;
-        pe += a.tile_counts[2 * t];
-        pn += a.tile_counts[2 * t + 1];
-    }
-    if (tid == 0) {
-        const int32_t n_edge = s_e[LG_SCAN_THREADS - 1];
-        const int32_t n_new = s_n[LG_SCAN_THREADS - 1];
-        LG_G int32_t* hs = a.hop_scratch;
-        hs[HS_FRONTIER_IS_SEEDS] = (a.op_id == INTRABATCH_CON) ? 1 : 0;
-        hs[HS_FRONTIER_OFF] = (a.op_id == INTRABATCH_CON) ? 0 : ec0;
-        hs[HS_FRONTIER_LEN] = g.frontier_len;
-        hs[HS_NODE_BASE] = nc0 + nc1;                          // operator_impl.cu:268
-        hs[HS_EDGE_BASE] = ec0 + ec1;                          // :275
-        hs[HS_N_NEW] = n_new;
-        hs[HS_N_EDGE] = n_edge;
-        hs[HS_SLOTS] = g.total;
-        hs[HS_RANGE + 2 * (a.op_id / INTRABATCH_CON)] = nc0 + nc1;     // range snapshot for this hop's gather
-        hs[HS_RANGE + 2 * (a.op_id / INTRABATCH_CON) + 1] = n_new;
-        // counter_update(op_id), op_id % 3 == 0: operator_impl.cu:69-82, with nc[6] = n_new and
-        // ec[2] = n_edge being what the reference's atomicAdds (:263-264) leave there
-        const int32_t h = a.op_id / INTRABATCH_CON;
-        nc[0] = nc0 + nc1;
-        nc[1] = n_new;
-        nc[INTRABATCH_CON * 2] = 0;
-        nc[INTRABATCH_CON * 2 + 1] = nc0 + nc1 + n_new;
-        ec[0] = ec0 + ec1;
-        ec[1] = n_edge;
-        ec[2] = 0;
-        nc[INTRABATCH_CON * 3 + h] = nc0 + nc1 + n_new;
-        ec[INTRABATCH_CON * 3 + h] = ec0 + ec1 + n_edge;
-    }
-}
-
-// ------------------------------------------------------------------------------------------
-// K4: slot-ordered compaction (ballot + mbcnt prefix inside each 256-slot tile).  Besides the
-// edges and the new nodes it writes, next to every edge, the row header of the sampled
-// neighbour: the next hop's frontier then needs no dependent lookup.
+// K2: compaction in ONE pass over the hop's slots (rounds 1-2 took three: per-tile counts, a one-workgroup prefix with
+// counter_update, the scatter).  A workgroup takes the next 1024-slot super tile by ticket, counts its valid edges and first
+// touches (wave ballots: the sample / de-duplication kernels left a mark on every slot that lost its first touch), and gets
+// what the earlier super tiles hold by decoupled look-back over one 64-bit word per super tile
+//     [ status : 2 | edges : 31 | nodes : 31 ]   status 1 = this tile's own counts, 2 = inclusive prefix
+// (tickets are handed out in order, so every tile a workgroup waits for belongs to a workgroup that is already running).
+// Then the slot-ordered compaction itself: ballot + mbcnt prefix inside the tile -> edges (global ids + both local
+// positions when known), new nodes and, next to every edge, the row header of the sampled neighbour, so that the next
+// hop's frontier needs no dependent lookup.
+// lds form: a slot that lost to ANOTHER slot of the hop needs that winner's new position.  sample_kernel left -1 in slot_pos
+// of every slot and the de-duplication kernel wrote the losers' entries only, so a winner's entry still holds -1 when this
+// kernel starts: the winner publishes its position there and the loser -- whose winner is always the LOWER slot, in this
+// super tile or an earlier one, so its position is on its way -- polls that one word.  No pass over the edges afterwards.
+// Everything that crosses workgroups here (status words, published positions, tickets) is a single self-contained word moved
+// with relaxed agent-scope atomics: no acquire / release fences, which on this part write back and invalidate a whole XCD's
+// L2 (measured: with fences the kernel took 1.1 ms per 256-lane group instead of ~0.1).
+// The workgroup that finishes last does what counter_update(op) does (operator_impl.cu:69-82), leaves the hop scratch for
+// the kernels that follow, and zeroes the status words and tickets for the next hop.
 // ------------------------------------------------------------------------------------------
 #ifndef LG_SCATTER_MIN_WAVES
-#define LG_SCATTER_MIN_WAVES 6
+#define LG_SCATTER_MIN_WAVES 5
 #endif
-__global__ __launch_bounds__(LG_TILE, LG_SCATTER_MIN_WAVES) __attribute__((amdgpu_num_sgpr(80)))
-void scatter_kernel(HopParams hp, const LanePtrs* __restrict__ lanes)
+#define LG_ST_AGG (1ull << 62)
+#define LG_ST_PREF (2ull << 62)
+__device__ __forceinline__ unsigned long long st_word(unsigned long long status, int32_t e, int32_t n)
 {
+    return status | ((unsigned long long)(uint32_t)e << 31) | (unsigned long long)(uint32_t)n;
+}
+__device__ __forceinline__ int32_t st_edges(unsigned long long w) { return (int32_t)((w >> 31) & 0x7FFFFFFFull); }
+__device__ __forceinline__ int32_t st_nodes(unsigned long long w) { return (int32_t)(w & 0x7FFFFFFFull); }
+
+__global__ __launch_bounds__(LG_TILE, LG_SCATTER_MIN_WAVES) __attribute__((amdgpu_num_sgpr(80)))
+void compact_kernel(HopParams hp, const LanePtrs* __restrict__ lanes)
+{
+    constexpr int NW = LG_SLOTS_PER_LANE * (LG_TILE / 64);     // waves' worth of slots in a super tile (16)
+    static_assert(NW <= 64, "one lane of wave 0 per (u, wave)");
     const SampleArgs a = lane_args(hp, lanes);
-    __shared__ int32_t s_cnt[LG_SLOTS_PER_LANE][2][LG_TILE / 64];
-    const LG_G int32_t* hs = a.hop_scratch;
-    const int32_t total = hs[HS_SLOTS];
-    const int32_t ntiles = (total + LG_TILE - 1) / LG_TILE;
-    const int32_t nsuper = (total + LG_SUPER - 1) / LG_SUPER;
-    const bool seeds = hs[HS_FRONTIER_IS_SEEDS] != 0;
-    const int32_t f_off = hs[HS_FRONTIER_OFF];
-    const int32_t node_base = hs[HS_NODE_BASE], edge_base = hs[HS_EDGE_BASE];
-    const LG_G int32_t* frontier = seeds ? a.sampled_ids : a.agg_src_ids + f_off;
+    __shared__ int32_t s_cnt[2][NW];               // [valid | first touch][u * 4 + wave]
+    __shared__ int32_t s_pre[2][NW];               // exclusive prefix of s_cnt inside the super tile
+    __shared__ unsigned long long s_mf[NW];        // first-touch ballots
+    __shared__ int32_t s_st, s_ex[2], s_last, s_tot[2];
+    const HopGeom g = hop_geometry(a);
+    LG_G int32_t* hs = a.hop_scratch;
+    LG_G int32_t* nc = a.node_counter;
+    LG_G int32_t* ec = a.edge_counter;
+    const int32_t nc0 = nc[0], nc1 = nc[1], ec0 = ec[0], ec1 = ec[1];     // (rewritten by the LAST workgroup only)
+    const int32_t total = g.total, nsuper = g.nsuper;
+    const bool seeds = a.op_id == INTRABATCH_CON;
+    const int32_t f_off = g.frontier_off;
+    const int32_t node_base = nc0 + nc1, edge_base = ec0 + ec1;           // operator_impl.cu:268, :275
+    const LG_G int32_t* frontier = g.frontier;
+    LG_G unsigned long long* state = a.tile_state;
+    const bool lds = a.claim_pairs != nullptr;                            // the lds form of the first-touch state
     const int32_t tid = threadIdx.x;
     const int32_t wave = tid >> 6, lane = tid & 63;
     const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
 
-    for (int32_t st = blockIdx.x; st < nsuper; st += gridDim.x) {
+    for (;;) {
+        if (tid == 0) s_st = __hip_atomic_fetch_add(hs + HS_CTICKET, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        const int32_t st = s_st;
+        if (st >= nsuper) break;                                          // (uniform)
         const int32_t idx0 = st * LG_SUPER;
-        int32_t v[LG_SLOTS_PER_LANE];
+        int32_t v[LG_SLOTS_PER_LANE], mk[LG_SLOTS_PER_LANE];
         unsigned long long mv[LG_SLOTS_PER_LANE], mf[LG_SLOTS_PER_LANE];
 #pragma unroll
         for (int u = 0; u < LG_SLOTS_PER_LANE; u++) {
             const int32_t idx = idx0 + u * LG_TILE + tid;
             v[u] = idx < total ? a.slot_dst[idx] : -1;
+            mk[u] = idx < total ? a.slot_mark[idx] : 0;
         }
 #pragma unroll
         for (int u = 0; u < LG_SLOTS_PER_LANE; u++) {
-            const bool valid = v[u] != -1;
-            const bool first = valid && v[u] < 0;
+            const bool valid = v[u] >= 0;
+            const bool first = valid && mk[u] != a.mark_tag;              // nobody marked it a loser in this hop
             mv[u] = __ballot(valid);
             mf[u] = __ballot(first);
             if (lane == 0) {
-                s_cnt[u][0][wave] = __popcll(mv[u]);
-                s_cnt[u][1][wave] = __popcll(mf[u]);
+                s_cnt[0][u * (LG_TILE / 64) + wave] = __popcll(mv[u]);
+                s_cnt[1][u * (LG_TILE / 64) + wave] = __popcll(mf[u]);
+                s_mf[u * (LG_TILE / 64) + wave] = mf[u];
             }
         }
         __syncthreads();
-        // phase 1: every load of the thread's four slots (nothing is stored in between, so they are all
-        // in flight together: the buffers may alias as far as the compiler knows)
-        int32_t e_at[LG_SLOTS_PER_LANE], n_at[LG_SLOTS_PER_LANE], src_of[LG_SLOTS_PER_LANE], src_pos[LG_SLOTS_PER_LANE];
-        int32_t lost_pos[LG_SLOTS_PER_LANE], fsv[LG_SLOTS_PER_LANE];
+        // wave 0: this super tile's counts, for everybody behind it
+        int32_t te = 0, tn = 0;
+        if (wave == 0) {
+            const int32_t ce = lane < NW ? s_cnt[0][lane] : 0, cn = lane < NW ? s_cnt[1][lane] : 0;
+            int32_t ie = ce, in = cn;
+            for (int d = 1; d < NW; d <<= 1) {
+                const int32_t oe = __shfl_up(ie, d), on = __shfl_up(in, d);
+                if (lane >= d) { ie += oe; in += on; }
+            }
+            te = __shfl(ie, NW - 1);
+            tn = __shfl(in, NW - 1);
+            if (lane < NW) {
+                s_pre[0][lane] = ie - ce;
+                s_pre[1][lane] = in - cn;
+            }
+            if (st > 0 && lane == 0)
+                __hip_atomic_store(state + st, st_word(LG_ST_AGG, te, tn), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        // phase 1: every load of the thread's four slots that does not need the prefix -- in flight while wave 0 looks back
+        // (nothing is stored in between: the buffers may alias as far as the compiler knows)
+        int32_t src_of[LG_SLOTS_PER_LANE], src_pos[LG_SLOTS_PER_LANE], lost_pos[LG_SLOTS_PER_LANE], fsv[LG_SLOTS_PER_LANE];
         uint32_t tab_at[LG_SLOTS_PER_LANE];
         RowHdr nh[LG_SLOTS_PER_LANE];
 #pragma unroll
         for (int u = 0; u < LG_SLOTS_PER_LANE; u++) {
             const int32_t idx = idx0 + u * LG_TILE + tid;
-            const int32_t tile = st * LG_SLOTS_PER_LANE + u;
-            e_at[u] = -1;
-            if (v[u] != -1 && tile < ntiles) {
-                const bool first = v[u] < 0;
-                const int32_t dst = v[u] & 0x7FFFFFFF;
-                int32_t we = 0, wn = 0;
-                for (int w = 0; w < wave; w++) { we += s_cnt[u][0][w]; wn += s_cnt[u][1][w]; }
-                e_at[u] = edge_base + a.tile_prefix[2 * tile] + we + __popcll(mv[u] & lt);
-                n_at[u] = first ? node_base + a.tile_prefix[2 * tile + 1] + wn + __popcll(mf[u] & lt) : -1;
+            if (v[u] >= 0) {
+                const bool first = (mf[u] >> lane) & 1ull;
+                const int32_t dst = v[u];
                 const int32_t q = idx / a.count;
                 src_of[u] = frontier[q];
                 // position of the node sampled for == construct_graph's position_map[agg_dst_ids[e]]
                 src_pos[u] = seeds ? q : a.agg_src_off[f_off + q];
                 if (!a.last_hop) nh[u] = load_hdr(a.row_hdr + dst);      // next hop's frontier header
                 lost_pos[u] = first ? 0 : a.slot_pos[idx];               // final already, or -2 - (slot it lost to)
-                if (a.first_rec != nullptr && lost_pos[u] < -1) {
-                    // lds form: the slot it lost to IS the winner (chains have length one); its new position follows from the
-                    // record of the winner's wave -- no localise pass over the edges
-                    const int32_t w = -2 - lost_pos[u];
-                    const lg_v4i r = *(const LG_G lg_v4i*)(a.first_rec + (w >> 6));       // (tile * 4 + wave) == slot / 64
-                    const unsigned long long m = ((unsigned long long)(uint32_t)r.y << 32) | (uint32_t)r.x;
-                    const int32_t lw = w & 63;
-                    lost_pos[u] = r.z + __popcll(m & (lw == 0 ? 0ull : (~0ull >> (64 - lw))));
-                }
                 fsv[u] = (first && a.slot_fs != nullptr) ? a.slot_fs[idx] : LG_FS_UNKNOWN;   // the new node's feature-cache slot, if carried
                 tab_at[u] = (first && !a.last_hop && a.pos_table != nullptr) ? table_find(a.pos_table, a.pos_mask, a.pf, dst) : 0u;
+            }
+        }
+        if (wave == 0) {
+            int32_t xe = 0, xn = 0;
+            if (st > 0) {
+                int32_t j = st - 1;                                       // nearest earlier tile not yet accounted for
+                for (;;) {
+                    const int32_t me = j - lane;
+                    unsigned long long w = LG_ST_PREF;                    // below tile 0: an inclusive prefix of nothing
+                    if (me >= 0) {
+                        w = __hip_atomic_load(state + me, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        while ((w >> 62) == 0) {
+                            __builtin_amdgcn_s_sleep(1);
+                            w = __hip_atomic_load(state + me, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        }
+                    }
+                    const unsigned long long pm = __ballot((w >> 62) == 2);
+                    const int first_p = pm ? __builtin_ctzll(pm) : 64;   // lanes up to the nearest inclusive prefix count
+                    if (lane <= first_p) { xe += st_edges(w); xn += st_nodes(w); }
+                    if (pm) break;
+                    j -= 64;
+                }
+                for (int off = 32; off > 0; off >>= 1) { xe += __shfl_down(xe, off); xn += __shfl_down(xn, off); }
+                xe = __shfl(xe, 0);
+                xn = __shfl(xn, 0);
+            }
+            if (lane == 0) {
+                s_ex[0] = xe;
+                s_ex[1] = xn;
+                __hip_atomic_store(state + st, st_word(LG_ST_PREF, xe + te, xn + tn), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        __syncthreads();
+        const int32_t xe = s_ex[0], xn = s_ex[1];
+        // lds form: the first touches' positions are known now -- publish them before anything else, later super tiles' losers
+        // are waiting for nothing but this (publishing with the other stores below would chain every tile's loads behind the
+        // stores of the tiles before it)
+        int32_t n_at[LG_SLOTS_PER_LANE];
+#pragma unroll
+        for (int u = 0; u < LG_SLOTS_PER_LANE; u++) {
+            n_at[u] = -1;
+            if ((mf[u] >> lane) & 1ull) {
+                n_at[u] = node_base + xn + s_pre[1][u * (LG_TILE / 64) + wave] + __popcll(mf[u] & lt);
+                if (lds) __hip_atomic_store(a.slot_pos + idx0 + u * LG_TILE + tid, n_at[u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        if (lds) {
+            // a slot that lost to ANOTHER slot of the hop: that slot IS the winner (chains have length one), and it is a LOWER slot
+#pragma unroll
+            for (int u = 0; u < LG_SLOTS_PER_LANE; u++) {
+                if (v[u] < 0 || lost_pos[u] >= -1) continue;
+                const int32_t w = -2 - lost_pos[u];
+                if (w >= idx0) {            // of this super tile: its position follows from the ballots at hand
+                    const int32_t ww = (w - idx0) >> 6, lw = w & 63;
+                    lost_pos[u] = node_base + xn + s_pre[1][ww] + __popcll(s_mf[ww] & (lw == 0 ? 0ull : (~0ull >> (64 - lw))));
+                } else {                    // of an earlier one: wait for the position its workgroup publishes
+                    const LG_G int32_t* wp = a.slot_pos + w;
+                    int32_t np = __hip_atomic_load(wp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    while (np < 0) {
+                        __builtin_amdgcn_s_sleep(1);
+                        np = __hip_atomic_load(wp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                    lost_pos[u] = np;
+                }
             }
         }
         // phase 2: the stores
 #pragma unroll
         for (int u = 0; u < LG_SLOTS_PER_LANE; u++) {
             const int32_t idx = idx0 + u * LG_TILE + tid;
-            const int32_t e = e_at[u];
-            if (e < 0) continue;
-            const int32_t dst = v[u] & 0x7FFFFFFF;
+            if (v[u] < 0) continue;
+            const int32_t dst = v[u];
+            const int32_t e = edge_base + xe + s_pre[0][u * (LG_TILE / 64) + wave] + __popcll(mv[u] & lt);
             a.agg_src_ids[e] = dst;                                // :256, :276
             a.agg_dst_ids[e] = src_of[u];                          // :257, :277
             a.agg_dst_off[e] = src_pos[u];
@@ -1006,13 +983,52 @@ void scatter_kernel(HopParams hp, const LanePtrs* __restrict__ lanes)
                     else
                         raise_error(a.hop_scratch, a.err_flag, LG_ERR_TABLE_FULL);
                 }
-                if (a.first_rec == nullptr) a.slot_pos[idx] = n;     // (what localise follows; the lds form needs no localise)
+                if (!lds) a.slot_pos[idx] = n;                     // (atomics forms: what localise follows)
                 a.agg_src_off[e] = n;                              // construct_graph's neighbour side, known here
             } else {
                 a.agg_src_off[e] = lost_pos[u];
             }
         }
         __syncthreads();
+    }
+
+    // the workgroup that finishes last: counter_update(op_id), op_id % 3 == 0 (operator_impl.cu:69-82), with nc[6] = n_new and
+    // ec[2] = n_edge being what the reference's atomicAdds (:263-264) leave there; hop scratch; status words back to zero
+    if (tid == 0)
+        s_last = (__hip_atomic_fetch_add(hs + HS_CDONE, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (int32_t)gridDim.x - 1) ? 1 : 0;
+    __syncthreads();
+    if (!s_last) return;
+    if (tid == 0) {
+        const unsigned long long tw = nsuper > 0 ? __hip_atomic_load(state + nsuper - 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+        s_tot[0] = st_edges(tw);
+        s_tot[1] = st_nodes(tw);
+    }
+    __syncthreads();
+    for (int32_t t = tid; t < nsuper; t += LG_TILE) state[t] = 0ull;
+    if (tid == 0) {
+        const int32_t n_edge = s_tot[0], n_new = s_tot[1];
+        hs[HS_CTICKET] = 0;
+        hs[HS_CDONE] = 0;
+        hs[HS_FRONTIER_IS_SEEDS] = seeds ? 1 : 0;
+        hs[HS_FRONTIER_OFF] = f_off;
+        hs[HS_FRONTIER_LEN] = g.frontier_len;
+        hs[HS_NODE_BASE] = node_base;
+        hs[HS_EDGE_BASE] = edge_base;
+        hs[HS_N_NEW] = n_new;
+        hs[HS_N_EDGE] = n_edge;
+        hs[HS_SLOTS] = total;
+        const int32_t h = a.op_id / INTRABATCH_CON;
+        hs[HS_RANGE + 2 * h] = node_base;                  // range snapshot for this hop's gather
+        hs[HS_RANGE + 2 * h + 1] = n_new;
+        nc[0] = node_base;
+        nc[1] = n_new;
+        nc[INTRABATCH_CON * 2] = 0;
+        nc[INTRABATCH_CON * 2 + 1] = node_base + n_new;
+        ec[0] = edge_base;
+        ec[1] = n_edge;
+        ec[2] = 0;
+        nc[INTRABATCH_CON * 3 + h] = node_base + n_new;
+        ec[INTRABATCH_CON * 3 + h] = edge_base + n_edge;
     }
 }
 
@@ -1132,11 +1148,7 @@ void launch_random_sample(hipStream_t s, const HopParams& p, const LanePtrs* d_l
         sample_kernel<0, 0, true><<<grid, LG_TILE, 0, s>>>(p, d_lanes);
     }
     hipCheckError();
-    flag_count_kernel<<<grid, LG_TILE, 0, s>>>(p, d_lanes);
-    hipCheckError();
-    scan_kernel<<<dim3(1, n_lanes), LG_SCAN_THREADS, 0, s>>>(p, d_lanes);
-    hipCheckError();
-    scatter_kernel<<<grid, LG_TILE, 0, s>>>(p, d_lanes);
+    compact_kernel<<<grid, LG_TILE, 0, s>>>(p, d_lanes);
     hipCheckError();
     if (form == 2 && !p.last_hop) {       // later hops must recognise the nodes this one added: their buckets' lists
         int32_t chunks = (p.max_slots + LG_LIST_CHUNK - 1) / LG_LIST_CHUNK;

@@ -154,6 +154,8 @@ enum HopScratch {
     HS_SLOTS = 7,
     HS_EPOCH = 8,          // this lane's current epoch of the position-state array
     HS_TICKET = 9,         // last-workgroup ticket of the end-of-batch kernel
+    HS_CTICKET = 24,       // compact_kernel: next super tile to hand out / workgroups that finished (both zero between hops)
+    HS_CDONE = 25,
     HS_VALUE_BITS = 30,    // vb of the position-state format (fixed at pool creation)
     HS_PAIR_CURSOR = 27,   // lds form: pairs reserved so far in the hop being sampled (reset by the de-duplication kernel)
     HS_ERROR = 29,         // sticky error bits of the lane (LG_ERR_*), also mirrored to the pool's host-visible flag
@@ -197,15 +199,6 @@ struct alignas(16) RowHdr {
     int64_t start;
     int32_t deg;
     int32_t slot;
-};
-
-// lds form: what flag_count + scan leave per wave of every 256-slot tile of a hop -- the ballot of its first-touch slots and
-// the position in sampled_ids of the first of them.  ANY winner's final position is then base + popcount(mask below its
-// lane): scatter places a loser's edge with one 16-byte load instead of a localise pass over all edges.
-struct alignas(16) FirstRec {
-    unsigned long long mask;
-    int32_t base;       // flag_count: first touches in the tile's earlier waves; scan adds node_base + the tile's prefix
-    int32_t pad;
 };
 
 struct BuildInfo {  // SS/include/buildinfo.h (only the fields of the in-memory path)
@@ -260,9 +253,7 @@ struct LanePtrs {
     int32_t* slot_fs;                  // [max_slots] feature-cache slot of the slot's sampled neighbour, or LG_FS_UNKNOWN (column slots)
     int32_t* node_slot;                // [num_ids] the same per node of the batch, by position in sampled_ids: what the gather reads
                                        // instead of node_map[id] (one 128-byte line per row for 4 bytes)
-    int32_t* tile_counts;
-    int32_t* tile_prefix;
-    FirstRec* first_rec;               // lds form: [tiles][4], see FirstRec
+    unsigned long long* tile_state;    // [super tiles] look-back status words of compact_kernel (zero between hops)
     int32_t* hop_scratch;
     RowHdr* fh_edge;
     int32_t* cache_search_buffer;
@@ -320,14 +311,12 @@ public:
     void SetIter(int32_t iter) { iter_ = iter; }
 
     // new in this build: sampler scratch (all device memory, private to the server)
-    int32_t* slot_dst = nullptr;       // [max_slots] sampled neighbour per slot (sign bit = first touch)
+    int32_t* slot_dst = nullptr;       // [max_slots] sampled neighbour per slot
     int32_t* slot_pos = nullptr;       // [max_slots] what the position state held for that neighbour
     int32_t* slot_mark = nullptr;      // [max_slots] (epoch, hop) tag of the hop in which the slot lost its first touch
     int32_t* slot_fs = nullptr;        // [max_slots] / [num_ids]: feature-cache slots carried from the sampler to the gather
     int32_t* node_slot = nullptr;
-    int32_t* tile_counts = nullptr;    // [2 * max_tiles] valid / first-touch counts per tile
-    FirstRec* first_rec = nullptr;     // lds form: [max_tiles][4] (LanePtrs)
-    int32_t* tile_prefix = nullptr;    // [2 * max_tiles] exclusive prefixes
+    unsigned long long* tile_state = nullptr;   // [max_tiles / 4 + 1] (LanePtrs)
     RowHdr* fh_edge = nullptr;         // [num_ids] frontier row headers written by scatter
     int32_t* hop_scratch = nullptr;    // [HS_WORDS]
     unsigned long long* claim_pairs = nullptr; // lds form: see LanePtrs

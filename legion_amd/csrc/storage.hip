@@ -455,9 +455,7 @@ LanePtrs MemoryPool::HostLane(int32_t pipe) const
     h.node_slot = node_slot;
     h.max_slots = max_slots;
     h.total_num_nodes = total_num_nodes;
-    h.tile_counts = tile_counts;
-    h.first_rec = first_rec;
-    h.tile_prefix = tile_prefix;
+    h.tile_state = tile_state;
     h.hop_scratch = hop_scratch;
     h.fh_edge = fh_edge;
     h.cache_search_buffer = cache_search_buffer_;
@@ -512,16 +510,14 @@ void MemoryPool::Finalize()
     d_free_space(slot_fs);
     d_free_space(node_slot);
     slot_fs = node_slot = nullptr;
-    d_free_space(tile_counts);
-    d_free_space(first_rec);
-    first_rec = nullptr;
-    d_free_space(tile_prefix);
+    d_free_space(tile_state);
     d_free_space(hop_scratch);
     d_free_space(fh_edge);
     fh_edge = nullptr;
     cache_search_buffer_ = position_map_ = agg_src_ids_ = agg_dst_ids_ = tmp_part_off_ = nullptr;
     tmp_part_ind_ = nullptr;
-    slot_dst = tile_counts = tile_prefix = hop_scratch = nullptr;
+    slot_dst = hop_scratch = nullptr;
+    tile_state = nullptr;
     if (owns_buffers) {
         for (int i = 0; i < pipeline_depth_; i++) {
             d_free_space(float_features_[i]);
@@ -652,9 +648,8 @@ void lg_pool_alloc_private(MemoryPool* mp, int32_t dev_id, int32_t total_num_nod
         lg::fill_value_i32(nullptr, mp->slot_fs, LG_FS_UNKNOWN, mp->max_slots);
         HIP_CALL(hipDeviceSynchronize());
     }
-    mp->tile_counts = (int32_t*)d_alloc_space(2 * max_tiles * sizeof(int32_t));
-    if (mp->lds_form) mp->first_rec = (FirstRec*)d_alloc_space(4 * max_tiles * sizeof(FirstRec));
-    mp->tile_prefix = (int32_t*)d_alloc_space(2 * max_tiles * sizeof(int32_t));
+    mp->tile_state = (unsigned long long*)d_alloc_space((max_tiles / LG_SLOTS_PER_LANE + 2) * sizeof(unsigned long long));
+    HIP_CALL(hipMemset(mp->tile_state, 0, (size_t)(max_tiles / LG_SLOTS_PER_LANE + 2) * sizeof(unsigned long long)));
     mp->fh_edge = (RowHdr*)d_alloc_space(num_ids * sizeof(RowHdr));
     mp->hop_scratch = (int32_t*)d_alloc_space(HS_WORDS * sizeof(int32_t));
     HIP_CALL(hipMemset(mp->hop_scratch, 0, HS_WORDS * sizeof(int32_t)));
