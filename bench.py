@@ -29,7 +29,9 @@ import argparse
 import ctypes
 import json
 import os
+import signal
 import sys
+import threading
 import time
 import types
 
@@ -41,6 +43,50 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0   # MI355X_MICROARCH.md: 8 TB/s spec
+
+
+class OneLine:
+    """The ONE JSON line of rank 0, written exactly once.  At N > 1 the extra legs (striped caches over peer pointers) run after
+    the headline leg and have never met more than one physical GPU before the driver's SCALE run: whatever ends this process
+    while they run -- a Python error (caught by the caller), a native exit() of the library (libc atexit hook), SIGTERM from
+    the launcher after another rank died (wake-up fd + watcher thread: works while the main thread is blocked inside a HIP or
+    RCCL call) -- the headline leg's line, already measured, still goes out, with a note on what happened."""
+
+    def __init__(self, fd):
+        self.fd, self.line, self.done, self.lock = fd, None, False, threading.Lock()
+        self._hook = None
+
+    def emit(self, obj):
+        with self.lock:
+            if self.done:
+                return
+            self.done = True
+        os.write(self.fd, (json.dumps(obj) + "\n").encode())
+
+    def arm(self, headline_obj):
+        """From here on a dying process still prints `headline_obj`."""
+        self.line = dict(headline_obj)
+
+        def fallback(why):
+            if self.line is not None and not self.done:
+                self.line["extra_legs_error"] = why
+                self.emit(self.line)
+
+        # (glibc exports __cxa_atexit; plain atexit lives in its static part)
+        self._hook = ctypes.CFUNCTYPE(None, ctypes.c_void_p)(lambda _: fallback("the process exited inside an extra leg (native exit)"))
+        getattr(ctypes.CDLL(None), "__cxa_atexit")(self._hook, None, None)
+        rfd, wfd = os.pipe()
+        os.set_blocking(wfd, False)
+        signal.set_wakeup_fd(wfd, warn_on_full_buffer=False)
+        signal.signal(signal.SIGTERM, lambda *_: None)       # (the C-level handler writes the signal number to wfd)
+
+        def watch():
+            os.read(rfd, 1)
+            fallback("SIGTERM while an extra leg was running (another rank failed?)")
+            os._exit(1)
+
+        threading.Thread(target=watch, daemon=True).start()
+        return fallback
 
 
 def parse_args():
@@ -115,6 +161,8 @@ def parse_args():
     ap.add_argument("--backend", type=str, default="nccl", help="torch.distributed backend (nccl = RCCL)")
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise torch.distributed and run the collectives even at N = 1 (exercises the RCCL calls on a 1-GPU box)")
+    ap.add_argument("--fail-extra-leg", type=str, default="", choices=["", "raise", "exit", "sigterm"],
+                    help="testing: make rank 0 fail this way when the first extra leg starts (the headline line must still go out)")
     ap.add_argument("--force-device", type=int, default=-1,
                     help="put every rank on this GPU (testing the N > 1 code path on a 1-GPU box, with --backend gloo)")
     return ap.parse_args()
@@ -125,7 +173,7 @@ def main():
     # the library logs the reference's lines ("Alpha: ...", "Feat capacity: ...") on stdout from every
     # rank; keep the real stdout for the one JSON line and send everything else to stderr
     sys.stdout.flush()
-    json_out = os.fdopen(os.dup(1), "w")
+    one_line = OneLine(os.dup(1))
     os.dup2(2, 1)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -203,26 +251,37 @@ def main():
     # ---- the headline leg, then (N > 1) the same workload with the caches striped over one clique of N ------------
     stripe = args.stripe and world > 1
     head = run_leg(c, engine, synth, stripe, args.replica_memory if stripe else 0, headline=True)
-    extra = {}
+    out = head["json"] if rank == 0 else None
     if world > 1 and not stripe and not args.no_striped_leg:
-        extra["striped"] = run_leg(c, engine, synth, True, 0, headline=False)
-        if args.striped_replica_memory > 0:
-            extra["striped_replica"] = run_leg(c, engine, synth, True, args.striped_replica_memory, headline=False)
+        if rank == 0:
+            one_line.arm(out)
+        try:
+            out_striped = run_leg(c, engine, synth, True, 0, headline=False)
+            if rank == 0:
+                out["striped"] = out_striped["json"]
+            if args.striped_replica_memory > 0:
+                out_rep = run_leg(c, engine, synth, True, args.striped_replica_memory, headline=False)
+                if rank == 0:
+                    out["striped_replica"] = out_rep["json"]
+        except Exception as e:      # the headline stands; say what the extra leg did
+            if rank == 0:
+                out["extra_legs_error"] = f"{type(e).__name__}: {e}"[:600]
+                one_line.emit(out)
+            raise
 
     if rank == 0:
-        out = head["json"]
-        for k, leg in extra.items():
-            out[k] = leg["json"]
         if world == 1 and not args.no_boundary and args.placement == "hbm":
             out.update(boundary_leg(args, c.fanout))
         if args.cpu_seconds > 0 and world == 1:      # reported at N = 1 only
             out["cpu_baseline"] = cpu_baseline(indptr, col, c.mine, N, B, c.fanout, c.n_warm, args.cpu_seconds,
                                                features if args.placement == "hbm" else None)
-        json_out.write(json.dumps(out) + "\n")
-        json_out.flush()
+        one_line.emit(out)
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
+    if one_line.line is not None:     # armed: the libc exit hook is a Python callable and must not outlive the interpreter
+        sys.stderr.flush()
+        os._exit(0)
 
 
 def run_leg(c, engine, synth, stripe, replica_memory, headline):
@@ -230,6 +289,13 @@ def run_leg(c, engine, synth, stripe, replica_memory, headline):
     counting pass -> warm-up -> timed regions -> eager pass with HIP events around the gathers.  Returns {"json": rank 0's
     report of the leg}.  The headline leg also verifies, and runs the `overlapped` arrangement; the extra legs are shorter."""
     args, world, rank, dev, use_dist = c.args, c.world, c.rank, c.dev, c.use_dist
+    if not headline and args.fail_extra_leg and rank == 0:        # (tests of OneLine)
+        if args.fail_extra_leg == "raise":
+            raise RuntimeError("requested by --fail-extra-leg")
+        if args.fail_extra_leg == "exit":
+            ctypes.CDLL(None).exit(3)
+        os.kill(os.getpid(), signal.SIGTERM)
+        time.sleep(60)
     fanout, H, N, D, B, G = c.fanout, c.H, c.N, c.D, c.B, c.G
     n_warm, n_timed, wrap, mine = c.n_warm, c.n_timed, c.wrap, c.mine
     t_leg = time.time()

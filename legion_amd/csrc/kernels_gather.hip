@@ -87,20 +87,33 @@ void launch_deliver(hipStream_t s, const LanePtrs* d_lane, const DeliverParams& 
 // VecT: float4 for rows that are multiples of 16 bytes; `v4u` -- the same 16 bytes per lane at 4-byte alignment -- for every other
 // width of at least 4 floats (gfx950 global loads / stores of 16 bytes need dword alignment only; the compiler emits
 // global_load_dwordx4 for both), with the D % 4 trailing floats of each row moved by a scalar pass (TAIL); float below that.
+//
+// A workgroup walks the tiles blockIdx.x, blockIdx.x + gridDim.x, ... of its lane and keeps the walk software-pipelined: while
+// tile t is being copied, the first ROWS threads already hold the ids of tile t+1 (loaded one step earlier), have its
+// slot lookups (node_map[id], the one scattered read of the resolve) in flight together with the copy's loads, and fetch the
+// ids of tile t+2.  The copy of a tile therefore never waits for its own resolve chain (id -> slot -> pointer): with one tile
+// per workgroup that chain was 40 % of a workgroup's life during which it streamed nothing.  Loads of the copy loop are
+// unconditional (a missing row reads the destination instead, chunks past the tile's end re-read its last chunk), so no
+// branch sits between the prefetch and the copy and all of them are in flight together; only the stores are predicated.
 #ifndef LG_GATHER_MIN_WAVES
-#define LG_GATHER_MIN_WAVES 8        // waves per SIMD the register allocation must leave room for (68 VGPRs would allow 7)
+#define LG_GATHER_MIN_WAVES 8        // waves per SIMD the register allocation must leave room for
+#endif
+#ifndef LG_GATHER_TARGET_WG
+#define LG_GATHER_TARGET_WG 8192     // workgroups of a full launch: four rounds of what is resident, so the dispatcher evens out lanes of different length
 #endif
 template <typename VecT, int ROWS = LG_GATHER_ROWS, int UNROLL = LG_GATHER_UNROLL, bool TAIL = false>
 __global__ __launch_bounds__(LG_GATHER_THREADS, LG_GATHER_MIN_WAVES) void gather_kernel(GatherParams gp, const LanePtrs* __restrict__ lanes,
                                                                    bool copy_range)
 {
     constexpr int VEC = sizeof(VecT) / sizeof(float);
-    __shared__ const LG_G float* s_ptr[ROWS];
+    static_assert(ROWS <= LG_GATHER_THREADS, "one resolving thread per row of a tile");
+    __shared__ const LG_G float* s_ptr[2][ROWS];
 
     const LanePtrs& L = lanes[blockIdx.y];
     // {offset, count} of the new-node range: the live counters, or the per-hop snapshot
     const LG_G int32_t* range = LG_GPTR(const int32_t, gp.hop >= 0 ? L.hop_scratch + HS_RANGE + 2 * gp.hop : L.node_counter);
     const LG_G int32_t* sampled_ids = LG_GPTR(const int32_t, L.sampled_ids);
+    const LG_G int32_t* node_slot = (L.node_slot != nullptr && gp.node_map != nullptr) ? LG_GPTR(const int32_t, L.node_slot) : nullptr;
     LG_G int32_t* cache_search_buffer = LG_GPTR(int32_t, L.cache_search_buffer);
     int32_t off = range[0];
     int32_t rows = range[1];
@@ -122,32 +135,19 @@ __global__ __launch_bounds__(LG_GATHER_THREADS, LG_GATHER_MIN_WAVES) void gather
         }
     }
     const int32_t ntiles = (rows + ROWS - 1) / ROWS;
-    if (L.deliver != nullptr) {      // this lane's gather also hands the batch over to a pipe slot: every active workgroup a slice
-        const int32_t parts = ntiles > 0 ? ntiles : 1;
-        if ((int32_t)blockIdx.x < parts) deliver_slice(L, *static_cast<const DeliverParams*>(L.deliver), blockIdx.x, parts);
-    }
+    const int32_t step = gridDim.x;
+    if (L.deliver != nullptr)        // this lane's gather also hands the batch over to a pipe slot: every workgroup a slice
+        deliver_slice(L, *static_cast<const DeliverParams*>(L.deliver), blockIdx.x, step);
     const int32_t tid = threadIdx.x;
     const int32_t D = gp.D;
     const int32_t C = D / VEC;                         // chunks per row
     const int32_t dr = LG_GATHER_THREADS / C;          // row / chunk advance per 256-chunk step
     const int32_t dc = LG_GATHER_THREADS - dr * C;
+    int32_t tile = blockIdx.x;
+    if (tile >= ntiles) return;                        // (surplus workgroups of a short lane)
 
-    // one tile per workgroup: the grid covers the largest range the op can have, surplus workgroups
-    // leave here, and the hardware dispatcher balances the rest
-    const int32_t tile = blockIdx.x;
-    if (tile >= ntiles) return;
-    const int32_t r0 = tile * ROWS;
-    const int32_t nr = min(ROWS, rows - r0);
-    for (int32_t t = tid; t < nr; t += LG_GATHER_THREADS) {
-        const int32_t id = sampled_ids[off + r0 + t];
-        // the row's feature-cache slot: carried from the sampler where the column slots are in use (a coalesced read), else --
-        // seeds, rows sampled from a cached-topology CSR, no column slots -- the FindFeat lookup (a 128-byte line per row)
-        int32_t g = (L.node_slot != nullptr && gp.node_map != nullptr) ? LG_GPTR(const int32_t, L.node_slot)[off + r0 + t] : LG_FS_UNKNOWN;
-        if (g == LG_FS_UNKNOWN) {
-            g = CACHEMISS_FLAG;
-            if (gp.node_map != nullptr && id >= 0) g = gp.node_map[id];
-        }
-        cache_search_buffer[r0 + t] = g;             // FindFeat writes from index 0 each hop
+    // a row's source: FindFeat (cache.cu:180-215) + the address arithmetic of cache_impl.cuh:259-268
+    auto source_of = [&](int32_t id, int32_t g) -> const LG_G float* {
         const LG_G float* p = nullptr;
         if (g < 0) {
             if (id >= 0)     // :262-266 (the modulo only where it does anything)
@@ -168,57 +168,115 @@ __global__ __launch_bounds__(LG_GATHER_THREADS, LG_GATHER_MIN_WAVES) void gather
                 if (!local_copy && didx != gp.member) atomicAdd(gp.stats + 2, 1ull);
             }
         }
-        s_ptr[t] = p;
+        return p;
+    };
+    // the row's feature-cache slot: carried from the sampler where the column slots are in use (a coalesced read), else --
+    // seeds, rows sampled from a cached-topology CSR, no column slots -- the FindFeat lookup (a 128-byte line per row)
+    auto lookup = [&](int32_t id, int32_t carried) -> int32_t {
+        if (carried != LG_FS_UNKNOWN) return carried;
+        return (gp.node_map != nullptr && id >= 0) ? gp.node_map[id] : CACHEMISS_FLAG;
+    };
+
+    // prologue: this workgroup's first tile resolved, the second tile's ids in hand
+    int32_t id_n = -1, fs_n = LG_FS_UNKNOWN;           // ids / carried slots of the NEXT tile (threads < ROWS)
+    bool have_n = false;
+    if (tid < ROWS) {
+        const int32_t r = tile * ROWS + tid;
+        if (r < rows) {
+            const int32_t id = sampled_ids[off + r];
+            const int32_t g = lookup(id, node_slot != nullptr ? node_slot[off + r] : LG_FS_UNKNOWN);
+            cache_search_buffer[r] = g;                // FindFeat writes from index 0 each hop
+            s_ptr[0][tid] = source_of(id, g);
+        }
+        const int32_t rn = (tile + step) * ROWS + tid;
+        have_n = tile + step < ntiles && rn < rows;
+        if (have_n) {
+            id_n = sampled_ids[off + rn];
+            if (node_slot != nullptr) fs_n = node_slot[off + rn];
+        }
     }
     __syncthreads();
 
-    const int32_t nchunks = nr * C;
-    LG_G float* dst_tile = LG_GPTR(float, L.float_features) + (int64_t)(off + r0) * D;
-    int32_t q = tid;
-    int32_t r = q / C;
-    int32_t c = q - r * C;
-    while (q < nchunks) {
-        VecT v[UNROLL];
-        int32_t rr[UNROLL], cc[UNROLL];
-        bool ok[UNROLL];
-#pragma unroll
-        for (int u = 0; u < UNROLL; u++) {
-            rr[u] = r;
-            cc[u] = c;
-            ok[u] = false;
-            if (q < nchunks) {
-                const LG_G float* p = s_ptr[r];
-                if (p != nullptr) {
-                    v[u] = ((const LG_G VecT*)p)[c];     // plain loads: measured 74% of HBM peak vs 63% nontemporal
-                    ok[u] = true;
-                }
+    int buf = 0;
+    for (; tile < ntiles; tile += step) {
+        const int32_t r0 = tile * ROWS;
+        const int32_t nr = min(ROWS, rows - r0);
+        // resolve of the next tile: its one scattered read goes out before the copy's loads; the ids of the tile after it too
+        int32_t g_n = CACHEMISS_FLAG, id_nn = -1, fs_nn = LG_FS_UNKNOWN;
+        bool have_nn = false;
+        if (tid < ROWS) {
+            if (have_n) g_n = lookup(id_n, fs_n);
+            const int32_t rnn = (tile + 2 * step) * ROWS + tid;
+            have_nn = tile + 2 * step < ntiles && rnn < rows;
+            if (have_nn) {
+                id_nn = sampled_ids[off + rnn];
+                if (node_slot != nullptr) fs_nn = node_slot[off + rnn];
             }
-            q += LG_GATHER_THREADS;
-            r += dr;
-            c += dc;
-            if (c >= C) { c -= C; r += 1; }
         }
+
+        const int32_t nchunks = nr * C;
+        LG_G float* dst_tile = LG_GPTR(float, L.float_features) + (int64_t)(off + r0) * D;
+        int32_t q = tid;
+        int32_t r = q / C;
+        int32_t c = q - r * C;
+        while (q < nchunks) {
+            VecT v[UNROLL];
+            int32_t rr[UNROLL], cc[UNROLL];
+            bool ok[UNROLL];
 #pragma unroll
-        for (int u = 0; u < UNROLL; u++) {
-            if (ok[u])     // write-once output: nontemporal stores
-                __builtin_nontemporal_store(v[u], (LG_G VecT*)(dst_tile + (int64_t)rr[u] * D) + cc[u]);
+            for (int u = 0; u < UNROLL; u++) {
+                const bool in = q < nchunks;
+                rr[u] = in ? r : nr - 1;               // past the end: the tile's last chunk again (loaded, not stored)
+                cc[u] = in ? c : C - 1;
+                const LG_G float* p = s_ptr[buf][rr[u]];
+                ok[u] = in && p != nullptr;
+                if (p == nullptr) p = dst_tile + (int64_t)rr[u] * D;     // id < 0: nothing to fetch; read what is there
+                v[u] = ((const LG_G VecT*)p)[cc[u]];   // plain loads: measured 74% of HBM peak vs 63% nontemporal
+                q += LG_GATHER_THREADS;
+                r += dr;
+                c += dc;
+                if (c >= C) { c -= C; r += 1; }
+            }
+#pragma unroll
+            for (int u = 0; u < UNROLL; u++) {
+                if (ok[u])     // write-once output: nontemporal stores
+                    __builtin_nontemporal_store(v[u], (LG_G VecT*)(dst_tile + (int64_t)rr[u] * D) + cc[u]);
+            }
         }
-    }
-    if (TAIL) {            // the last D % VEC floats of every row
-        const int32_t tail = D - C * VEC;
-        for (int32_t i = tid; i < nr * tail; i += LG_GATHER_THREADS) {
-            const int32_t tr = i / tail, k = C * VEC + (i - tr * tail);
-            const LG_G float* p = s_ptr[tr];
-            if (p != nullptr) dst_tile[(int64_t)tr * D + k] = p[k];
+        if (TAIL) {            // the last D % VEC floats of every row
+            const int32_t tail = D - C * VEC;
+            for (int32_t i = tid; i < nr * tail; i += LG_GATHER_THREADS) {
+                const int32_t tr = i / tail, k = C * VEC + (i - tr * tail);
+                const LG_G float* p = s_ptr[buf][tr];
+                if (p != nullptr) dst_tile[(int64_t)tr * D + k] = p[k];
+            }
         }
+        if (tid < ROWS && have_n) {
+            cache_search_buffer[(tile + step) * ROWS + tid] = g_n;
+            s_ptr[buf ^ 1][tid] = source_of(id_n, g_n);
+        }
+        id_n = id_nn;
+        fs_n = fs_nn;
+        have_n = have_nn;
+        __syncthreads();
+        buf ^= 1;
     }
+}
+
+// tiles of a lane are walked by gx workgroups: about LG_GATHER_TARGET_WG workgroups per launch, never more than tiles
+static inline int32_t gather_grid_x(int32_t max_rows, int32_t rows_per_tile, int32_t n_lanes)
+{
+    const int32_t tiles = (max_rows + rows_per_tile - 1) / rows_per_tile;
+    int32_t gx = (LG_GATHER_TARGET_WG + n_lanes - 1) / n_lanes;
+    if (gx > tiles) gx = tiles;
+    return gx < 1 ? 1 : gx;
 }
 
 template <int ROWS>
 static void launch_gather_v4(hipStream_t s, const GatherParams& g, const LanePtrs* d_lanes, int32_t n_lanes, bool copy_range)
 {
     typedef float v4 __attribute__((ext_vector_type(4)));
-    const dim3 grid((g.max_rows + ROWS - 1) / ROWS, n_lanes);
+    const dim3 grid(gather_grid_x(g.max_rows, ROWS, n_lanes), n_lanes);
     gather_kernel<v4, ROWS><<<grid, LG_GATHER_THREADS, 0, s>>>(g, d_lanes, copy_range);
 }
 
@@ -226,7 +284,7 @@ static void launch_gather_impl(hipStream_t s, GatherParams g, const LanePtrs* d_
 {
     if (g.D <= 0 || g.max_rows <= 0) return;            // :256 float_feature_len > 0
     if (g.node_capacity < 1) g.node_capacity = 1;
-    const dim3 grid((g.max_rows + LG_GATHER_ROWS - 1) / LG_GATHER_ROWS, n_lanes);     // (the 8- and 4-byte vector paths)
+    const dim3 grid(gather_grid_x(g.max_rows, LG_GATHER_ROWS, n_lanes), n_lanes);     // (the 4-byte vector path, and 64-row tiles at dword alignment)
     const LegionTuning& tune = tuning();
     if (g.D % 4 == 0) {
         // rows per workgroup (LegionTuning.gather_rows_per_wg; 0 = the default below).  A launch of one or a few lanes (the
@@ -252,9 +310,9 @@ static void launch_gather_impl(hipStream_t s, GatherParams g, const LanePtrs* d_
         // rows that are not multiples of 16 bytes (D = 602: 2408-byte rows): 16-byte chunks at dword alignment + a scalar
         // tail, instead of the 8- / 4-byte vector paths of rounds 1-2 (0.65 of peak at D = 602)
         typedef float v4u __attribute__((ext_vector_type(4), aligned(4)));
-        const bool small = tune.gather_small_tiles && (int64_t)grid.x * n_lanes < 4096;
+        const bool small = tune.gather_small_tiles && (int64_t)((g.max_rows + LG_GATHER_ROWS - 1) / LG_GATHER_ROWS) * n_lanes < 4096;
         if (small || (int64_t)g.D * 4 * 64 > 65536)
-            gather_kernel<v4u, 16, LG_GATHER_UNROLL, true><<<dim3((g.max_rows + 15) / 16, n_lanes), LG_GATHER_THREADS, 0, s>>>(g, d_lanes, copy_range);
+            gather_kernel<v4u, 16, LG_GATHER_UNROLL, true><<<dim3(gather_grid_x(g.max_rows, 16, n_lanes), n_lanes), LG_GATHER_THREADS, 0, s>>>(g, d_lanes, copy_range);
         else
             gather_kernel<v4u, LG_GATHER_ROWS, LG_GATHER_UNROLL, true><<<grid, LG_GATHER_THREADS, 0, s>>>(g, d_lanes, copy_range);
     } else

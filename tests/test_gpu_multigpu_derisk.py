@@ -83,6 +83,21 @@ def test_scale_command_line_two_ranks_on_one_gpu(hip, stripe):
     assert 0.7 < d["edges_per_step"] / d1["edges_per_step"] < 1.4
 
 
+@pytest.mark.parametrize("how", ["raise", "exit", "sigterm"])
+def test_headline_line_survives_a_failing_extra_leg(hip, how):
+    """N > 1: the striped legs run after the headline leg; if one of them ends rank 0 -- a Python error, a native exit() of the
+    library, SIGTERM from the launcher -- the headline leg's ONE line must still be printed, with a note (bench.py OneLine)."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo",
+           "--force-device", "0", "--fail-extra-leg", how] + SMALL
+    res = subprocess.run(cmd, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, (res.stdout[-2000:], res.stderr[-2000:])
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["value"] > 0 and d["roofline"]["frac"] > 0
+    assert "extra_legs_error" in d and "striped" not in d
+
+
 def test_rccl_calls_execute_at_n1(hip):
     """bench.py --force-dist: torch.distributed over the nccl backend (= RCCL) with world size 1; the hotness all-reduce,
     the MIN/MAX reductions and the barriers all go through RCCL once."""
