@@ -793,6 +793,9 @@ void dedup_lds_kernel(HopParams hp, const LanePtrs* __restrict__ lanes)
 #ifndef LG_SCATTER_MIN_WAVES
 #define LG_SCATTER_MIN_WAVES 5
 #endif
+#ifndef LG_SCATTER_MIN_WAVES_LAST
+#define LG_SCATTER_MIN_WAVES_LAST 8
+#endif
 #define LG_ST_AGG (1ull << 62)
 #define LG_ST_PREF (2ull << 62)
 __device__ __forceinline__ unsigned long long st_word(unsigned long long status, int32_t e, int32_t n)
@@ -802,7 +805,8 @@ __device__ __forceinline__ unsigned long long st_word(unsigned long long status,
 __device__ __forceinline__ int32_t st_edges(unsigned long long w) { return (int32_t)((w >> 31) & 0x7FFFFFFFull); }
 __device__ __forceinline__ int32_t st_nodes(unsigned long long w) { return (int32_t)(w & 0x7FFFFFFFull); }
 
-__global__ __launch_bounds__(LG_TILE, LG_SCATTER_MIN_WAVES) __attribute__((amdgpu_num_sgpr(80)))
+template <bool LAST>       // the last hop writes no frontier headers and no position state: fewer registers, more waves per SIMD
+__global__ __launch_bounds__(LG_TILE, LAST ? LG_SCATTER_MIN_WAVES_LAST : LG_SCATTER_MIN_WAVES) __attribute__((amdgpu_num_sgpr(80)))
 void compact_kernel(HopParams hp, const LanePtrs* __restrict__ lanes)
 {
     constexpr int NW = LG_SLOTS_PER_LANE * (LG_TILE / 64);     // waves' worth of slots in a super tile (16)
@@ -888,10 +892,10 @@ void compact_kernel(HopParams hp, const LanePtrs* __restrict__ lanes)
                 src_of[u] = frontier[q];
                 // position of the node sampled for == construct_graph's position_map[agg_dst_ids[e]]
                 src_pos[u] = seeds ? q : a.agg_src_off[f_off + q];
-                if (!a.last_hop) nh[u] = load_hdr(a.row_hdr + dst);      // next hop's frontier header
+                if (!LAST) nh[u] = load_hdr(a.row_hdr + dst);      // next hop's frontier header
                 lost_pos[u] = first ? 0 : a.slot_pos[idx];               // final already, or -2 - (slot it lost to)
                 fsv[u] = (first && a.slot_fs != nullptr) ? a.slot_fs[idx] : LG_FS_UNKNOWN;   // the new node's feature-cache slot, if carried
-                tab_at[u] = (first && !a.last_hop && a.pos_table != nullptr) ? table_find(a.pos_table, a.pos_mask, a.pf, dst) : 0u;
+                tab_at[u] = (first && !LAST && a.pos_table != nullptr) ? table_find(a.pos_table, a.pos_mask, a.pf, dst) : 0u;
             }
         }
         if (wave == 0) {
@@ -968,14 +972,14 @@ void compact_kernel(HopParams hp, const LanePtrs* __restrict__ lanes)
             a.agg_src_ids[e] = dst;                                // :256, :276
             a.agg_dst_ids[e] = src_of[u];                          // :257, :277
             a.agg_dst_off[e] = src_pos[u];
-            if (!a.last_hop) store_hdr(a.fh_edge + e, nh[u]);
+            if (!LAST) store_hdr(a.fh_edge + e, nh[u]);
             const int32_t n = n_at[u];
             if (n >= 0) {
                 a.sampled_ids[n] = dst;                            // :270
                 if (a.node_slot != nullptr) a.node_slot[n] = fsv[u];
                 // :271 -- later hops look the position up in the state array; after the last hop nobody
                 // does, and same-hop duplicates resolve through slot_pos (a small, cache-resident array)
-                if (!a.last_hop) {
+                if (!LAST) {
                     if (a.pos_table == nullptr) {
                         if (a.position_map != nullptr) a.position_map[dst] = (int32_t)(a.pf.hi | (uint32_t)n);   // (lds form: none)
                     } else if (tab_at[u] != 0xFFFFFFFFu)
@@ -1148,7 +1152,8 @@ void launch_random_sample(hipStream_t s, const HopParams& p, const LanePtrs* d_l
         sample_kernel<0, 0, true><<<grid, LG_TILE, 0, s>>>(p, d_lanes);
     }
     hipCheckError();
-    compact_kernel<<<grid, LG_TILE, 0, s>>>(p, d_lanes);
+    if (p.last_hop) compact_kernel<true><<<grid, LG_TILE, 0, s>>>(p, d_lanes);
+    else compact_kernel<false><<<grid, LG_TILE, 0, s>>>(p, d_lanes);
     hipCheckError();
     if (form == 2 && !p.last_hop) {       // later hops must recognise the nodes this one added: their buckets' lists
         int32_t chunks = (p.max_slots + LG_LIST_CHUNK - 1) / LG_LIST_CHUNK;

@@ -1,0 +1,25 @@
+#!/bin/bash
+# duration of every sampler kernel by launch order inside a group (hop 1 and hop 2 share a grid for some of them)
+R=$GRAFT_REPO_ROOT
+cd /tmp && export TMPDIR=/tmp
+rm -rf /tmp/px_h
+timeout -k 5 400 rocprofv3 --kernel-trace --output-format csv -d /tmp/px_h -- python3 $R/bench.py --no-boundary --no-overlap-leg --cpu-seconds 0 --no-weave --no-verify --steps 8 --warmup 2 --min-seconds 0.3 $EXTRA > /dev/null 2> /dev/null < /dev/null
+python3 - /tmp/px_h <<'PY'
+import csv, glob, sys, collections
+f = glob.glob(sys.argv[1] + '/*/*kernel_trace.csv')[0]
+rows = sorted((int(r['Start_Timestamp']), r['Kernel_Name'].split('(')[0][-40:], int(r['Grid_Size_Y']) if r['Grid_Size_Y'].isdigit() else 0, (int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3, int(r['Start_Timestamp']), int(r['End_Timestamp'])) for r in csv.DictReader(open(f)) if 'lg::' in r['Kernel_Name'])
+rows = [r for r in rows if r[2] >= 32]
+# the last complete group: from the last batch_generate onwards
+starts = [i for i, r in enumerate(rows) if 'batch_generate' in r[1]]
+seq = collections.defaultdict(list)
+for a, b in zip(starts[-40:-1], starts[-39:]):
+    for j, r in enumerate(rows[a:b]):
+        gap = (r[4] - rows[a + j - 1][5]) / 1e3 if j else 0.0
+        seq[(j, r[1])].append((r[3], gap))
+tot = 0
+for (j, name), v in sorted(seq.items()):
+    d = sorted(x[0] for x in v); g = sorted(x[1] for x in v)
+    print(f"{j:2d} {name:42s} n={len(v):3d} median {d[len(d)//2]:8.1f} us   gap before {g[len(g)//2]:6.1f} us")
+    tot += d[len(d)//2] + g[len(g)//2]
+print("sum of medians + gaps %.1f us" % tot)
+PY

@@ -9,7 +9,7 @@ TAG=pmc_s_$FORM$( [ -n "$SCR" ] && echo _scr )
 i=0
 rm -f $R/gpurun_out/$TAG/pmc_sampler_kernels.csv
 mkdir -p $R/gpurun_out/$TAG
-for grp in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "TCC_ATOMIC_sum TCC_REQ_sum" "SQ_INSTS_VALU SQ_INSTS_VMEM SQ_INSTS_LDS SQ_INSTS_SALU"; do
+for grp in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "TCC_ATOMIC_sum TCC_REQ_sum" "SQ_INSTS_VALU SQ_INSTS_VMEM SQ_INSTS_LDS SQ_INSTS_SALU" "SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVE_CYCLES" "SQ_INST_CYCLES_VMEM SQ_WAIT_ANY SQ_LDS_ADDR_CONFLICT SQ_LDS_ATOMIC_RETURN"; do
   i=$((i+1))
   out=/tmp/$TAG/g$i
   rm -rf $out; mkdir -p $out
