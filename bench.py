@@ -608,7 +608,7 @@ def run_leg(c, engine, synth, stripe, replica_memory, headline):
         layout = (f"seed-sharded x{world}, replicated graph+features, one clique of {world}: caches striped over the ranks, peer reads "
                   f"over xGMI (cache_agg_mode {int(np.log2(world))})" + (f", hot-row replica of {replica_memory} bytes per GPU" if replica_memory else "")
                   if stripe else f"seed-sharded x{world}, replicated graph+features, cache_agg_mode 0")
-        roof = {"bound": "hbm", "kernel": "gather_kernel<float4> (hop-%d gather, op %d)" % (H, last_op),
+        roof = {"bound": "hbm", "kernel": "lg::gather_kernel<..., LASTOP = true> (hop-%d gather, op %d: the instance launched for a batch's last op)" % (H, last_op),
                 "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_unit": "bytes per launch",
                 "traffic_source": traffic_src, "algorithmic_bytes_per_launch": rows_last / max(n_last, 1) * bytes_per_row,

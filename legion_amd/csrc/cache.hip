@@ -471,7 +471,7 @@ unsigned long long int* UnifiedCache::GetEdgeAccessedMap(int32_t dev_id)
 
 // SS/cache/cache.cu:726-748 -- lookup (FindFeat) fused into the gather
 void UnifiedCache::FeatCacheLookup(const LanePtrs* d_lanes, int32_t n_lanes, int32_t op_id, int32_t dev_id,
-                                   hipStream_t strm_hdl, int32_t max_rows, bool use_snapshot, int32_t first_op_id)
+                                   hipStream_t strm_hdl, int32_t max_rows, bool use_snapshot, int32_t first_op_id, bool last_op)
 {
     const bool filled = !node_capacity_.empty() && d_float_feature_cache_ptr_[dev_id] != nullptr &&
                         cache_controller_[dev_id]->NodeMap() != nullptr;
@@ -493,6 +493,7 @@ void UnifiedCache::FeatCacheLookup(const LanePtrs* d_lanes, int32_t n_lanes, int
     g.max_rows = max_rows;
     g.hop = use_snapshot ? op_id / INTRABATCH_CON : -1;
     g.first_hop = (use_snapshot && first_op_id >= 0 && first_op_id < op_id) ? first_op_id / INTRABATCH_CON : g.hop;
+    g.last_op = last_op;
     lg::launch_gather(strm_hdl, g, d_lanes, n_lanes);
 }
 

@@ -101,7 +101,9 @@ void launch_deliver(hipStream_t s, const LanePtrs* d_lane, const DeliverParams& 
 #ifndef LG_GATHER_TARGET_WG
 #define LG_GATHER_TARGET_WG 8192     // workgroups of a full launch: four rounds of what is resident, so the dispatcher evens out lanes of different length
 #endif
-template <typename VecT, int ROWS = LG_GATHER_ROWS, int UNROLL = LG_GATHER_UNROLL, bool TAIL = false>
+// LASTOP: the gather of a batch's last op (the dominant launch; traces and counters tell it from the early hops' gathers by
+// name) -- the only one that can carry a hand-over to a trainer-visible pipe slot.
+template <typename VecT, int ROWS = LG_GATHER_ROWS, int UNROLL = LG_GATHER_UNROLL, bool TAIL = false, bool LASTOP = true>
 __global__ __launch_bounds__(LG_GATHER_THREADS, LG_GATHER_MIN_WAVES) void gather_kernel(GatherParams gp, const LanePtrs* __restrict__ lanes,
                                                                    bool copy_range)
 {
@@ -136,7 +138,7 @@ __global__ __launch_bounds__(LG_GATHER_THREADS, LG_GATHER_MIN_WAVES) void gather
     }
     const int32_t ntiles = (rows + ROWS - 1) / ROWS;
     const int32_t step = gridDim.x;
-    if (L.deliver != nullptr)        // this lane's gather also hands the batch over to a pipe slot: every workgroup a slice
+    if (LASTOP && L.deliver != nullptr)        // this lane's gather also hands the batch over to a pipe slot: every workgroup a slice
         deliver_slice(L, *static_cast<const DeliverParams*>(L.deliver), blockIdx.x, step);
     const int32_t tid = threadIdx.x;
     const int32_t D = gp.D;
@@ -277,7 +279,8 @@ static void launch_gather_v4(hipStream_t s, const GatherParams& g, const LanePtr
 {
     typedef float v4 __attribute__((ext_vector_type(4)));
     const dim3 grid(gather_grid_x(g.max_rows, ROWS, n_lanes), n_lanes);
-    gather_kernel<v4, ROWS><<<grid, LG_GATHER_THREADS, 0, s>>>(g, d_lanes, copy_range);
+    if (g.last_op) gather_kernel<v4, ROWS, LG_GATHER_UNROLL, false, true><<<grid, LG_GATHER_THREADS, 0, s>>>(g, d_lanes, copy_range);
+    else gather_kernel<v4, ROWS, LG_GATHER_UNROLL, false, false><<<grid, LG_GATHER_THREADS, 0, s>>>(g, d_lanes, copy_range);
 }
 
 static void launch_gather_impl(hipStream_t s, GatherParams g, const LanePtrs* d_lanes, int32_t n_lanes, bool copy_range)
@@ -311,12 +314,16 @@ static void launch_gather_impl(hipStream_t s, GatherParams g, const LanePtrs* d_
         // tail, instead of the 8- / 4-byte vector paths of rounds 1-2 (0.65 of peak at D = 602)
         typedef float v4u __attribute__((ext_vector_type(4), aligned(4)));
         const bool small = tune.gather_small_tiles && (int64_t)((g.max_rows + LG_GATHER_ROWS - 1) / LG_GATHER_ROWS) * n_lanes < 4096;
-        if (small || (int64_t)g.D * 4 * 64 > 65536)
-            gather_kernel<v4u, 16, LG_GATHER_UNROLL, true><<<dim3(gather_grid_x(g.max_rows, 16, n_lanes), n_lanes), LG_GATHER_THREADS, 0, s>>>(g, d_lanes, copy_range);
-        else
-            gather_kernel<v4u, LG_GATHER_ROWS, LG_GATHER_UNROLL, true><<<grid, LG_GATHER_THREADS, 0, s>>>(g, d_lanes, copy_range);
-    } else
+        const bool r16 = small || (int64_t)g.D * 4 * 64 > 65536;
+        const dim3 gr = r16 ? dim3(gather_grid_x(g.max_rows, 16, n_lanes), n_lanes) : grid;
+        if (r16 && g.last_op) gather_kernel<v4u, 16, LG_GATHER_UNROLL, true, true><<<gr, LG_GATHER_THREADS, 0, s>>>(g, d_lanes, copy_range);
+        else if (r16) gather_kernel<v4u, 16, LG_GATHER_UNROLL, true, false><<<gr, LG_GATHER_THREADS, 0, s>>>(g, d_lanes, copy_range);
+        else if (g.last_op) gather_kernel<v4u, LG_GATHER_ROWS, LG_GATHER_UNROLL, true, true><<<gr, LG_GATHER_THREADS, 0, s>>>(g, d_lanes, copy_range);
+        else gather_kernel<v4u, LG_GATHER_ROWS, LG_GATHER_UNROLL, true, false><<<gr, LG_GATHER_THREADS, 0, s>>>(g, d_lanes, copy_range);
+    } else if (g.last_op)
         gather_kernel<float><<<grid, LG_GATHER_THREADS, 0, s>>>(g, d_lanes, copy_range);
+    else
+        gather_kernel<float, LG_GATHER_ROWS, LG_GATHER_UNROLL, false, false><<<grid, LG_GATHER_THREADS, 0, s>>>(g, d_lanes, copy_range);
     hipCheckError();
 }
 
@@ -341,6 +348,7 @@ void launch_gather_explicit(hipStream_t s, const GatherParams& g, const int32_t*
     GatherParams ge = g;
     ge.hop = -1;
     ge.first_hop = -1;
+    ge.last_op = true;
     HIP_CALL(hipMemcpyAsync(d_lane, &h, sizeof(h), hipMemcpyHostToDevice, s));   // pageable source: staged before return
     launch_gather_impl(s, ge, d_lane, 1, false);
 }

@@ -504,7 +504,7 @@ public:
     // the gather over a group of lanes (the reference's per-array arguments live in LanePtrs)
     // first_op_id < op_id: one launch also covers the new-node ranges of the earlier ops first_op_id, +3, ...
     void FeatCacheLookup(const LanePtrs* d_lanes, int32_t n_lanes, int32_t op_id, int32_t dev_id,
-                         hipStream_t strm_hdl, int32_t max_rows, bool use_snapshot, int32_t first_op_id = -1);
+                         hipStream_t strm_hdl, int32_t max_rows, bool use_snapshot, int32_t first_op_id = -1, bool last_op = true);
 
     // new / exposed for the C API and the fused kernels
     void SetCapacity(int32_t node_capacity, int32_t edge_capacity);
@@ -710,6 +710,7 @@ struct GatherParams {
                                     // hops do not overwrite, so the gather may run beside the next hop); < 0: node_counter[0..1]
     int32_t first_hop;              // with hop >= 0: also gather the ranges of hops first_hop .. hop-1 (they are adjacent in
                                     // sampled_ids); == hop for a plain single-op gather
+    bool last_op;                   // the gather of the batch's last op (kernel instance of its own: hand-over, traces)
 };
 void launch_gather(hipStream_t s, const GatherParams& g, const LanePtrs* d_lanes, int32_t n_lanes);
 void launch_deliver(hipStream_t s, const LanePtrs* d_lane, const DeliverParams& d);

@@ -147,7 +147,8 @@ static void do_feature_lookup(hipStream_t s, UnifiedCache* cache, const LanePtrs
     MemoryPool* pp = pool0;
     const bool prof = pp->prof_on && (size_t)(2 * pp->prof_used + 1) < pp->prof_events.size();
     if (prof) HIP_CALL(hipEventRecord(pp->prof_events[2 * pp->prof_used], s));
-    cache->FeatCacheLookup(d_lanes, n_lanes, op_id, dev_id, s, (int32_t)max_rows, use_snapshot, first_op_id);
+    cache->FeatCacheLookup(d_lanes, n_lanes, op_id, dev_id, s, (int32_t)max_rows, use_snapshot, first_op_id,
+                           hop + 1 >= pool0->max_new.size());
     if (prof) {
         HIP_CALL(hipEventRecord(pp->prof_events[2 * pp->prof_used + 1], s));
         pp->prof_op[pp->prof_used] = op_id;

@@ -14,13 +14,18 @@ import os
 import sys
 
 
+def last_op(n):
+    """gather_kernel<..., true>(...): the instance launched for a batch's last op (kernels_gather.hip LASTOP)."""
+    return "gather_kernel" in n and n[:n.rfind("(")].rstrip().endswith("true>")
+
+
 def fold(src, dst, group):
     os.makedirs(dst, exist_ok=True)
     out = {"group": group.split(), "counters": {}, "launches": 0}
     cc = glob.glob(src + "/*/*counter_collection.csv")
     kt = glob.glob(src + "/*/*kernel_trace.csv")
     if cc:
-        rows = [r for r in csv.DictReader(open(cc[0])) if "gather_kernel" in r["Kernel_Name"]]
+        rows = [r for r in csv.DictReader(open(cc[0])) if last_op(r["Kernel_Name"])]
         if rows:
             mx = max(int(r["Grid_Size"]) for r in rows)
             acc = collections.defaultdict(list)
@@ -34,7 +39,7 @@ def fold(src, dst, group):
             out["counters"] = {k: (lambda big: sum(big) / len(big))([x for x in v if x >= 0.75 * max(v)]) for k, v in acc.items()}
             out["launches"] = max(len([x for x in v if x >= 0.75 * max(v)]) for v in acc.values())
     if kt:
-        rows = [r for r in csv.DictReader(open(kt[0])) if "gather_kernel" in r["Kernel_Name"]]
+        rows = [r for r in csv.DictReader(open(kt[0])) if last_op(r["Kernel_Name"])]
         if rows:
             gx = max(int(r["Grid_Size_X"]) * int(r["Grid_Size_Y"]) for r in rows)
             d = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in rows

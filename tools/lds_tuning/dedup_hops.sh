@@ -7,7 +7,7 @@ timeout -k 5 400 rocprofv3 --kernel-trace --output-format csv -d /tmp/px_h -- py
 python3 - /tmp/px_h <<'PY'
 import csv, glob, sys, collections
 f = glob.glob(sys.argv[1] + '/*/*kernel_trace.csv')[0]
-rows = sorted((int(r['Start_Timestamp']), r['Kernel_Name'].split('(')[0][-40:], int(r['Grid_Size_Y']) if r['Grid_Size_Y'].isdigit() else 0, (int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3, int(r['Start_Timestamp']), int(r['End_Timestamp'])) for r in csv.DictReader(open(f)) if 'lg::' in r['Kernel_Name'])
+rows = sorted((int(r['Start_Timestamp']), r['Kernel_Name'][:r['Kernel_Name'].rfind('(')].replace('float __vector(4)', 'float4').replace(' ', '')[-44:], int(r['Grid_Size_Y']) if r['Grid_Size_Y'].isdigit() else 0, (int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3, int(r['Start_Timestamp']), int(r['End_Timestamp'])) for r in csv.DictReader(open(f)) if 'lg::' in r['Kernel_Name'])
 rows = [r for r in rows if r[2] >= 32]
 # the last complete group: from the last batch_generate onwards
 starts = [i for i, r in enumerate(rows) if 'batch_generate' in r[1]]

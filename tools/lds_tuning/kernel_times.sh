@@ -16,7 +16,7 @@ acc = collections.defaultdict(list)
 for r in csv.DictReader(open(f)):
     n = r['Kernel_Name']
     if 'lg::' not in n: continue
-    key = (n.split('(')[0][:40], r['Grid_Size_X'], r['Grid_Size_Y'])
+    key = (n[:n.rfind('(')].replace('float __vector(4)', 'float4').replace(' ', '')[:56], r['Grid_Size_X'], r['Grid_Size_Y'])
     acc[key].append((int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3)
 for k, v in sorted(acc.items(), key=lambda kv: -sum(kv[1]))[:22]:
     v = sorted(v)

@@ -9,8 +9,10 @@ fetch_dir, write_dir, out = sys.argv[1], sys.argv[2], sys.argv[3]
 
 def per_launch(d, name):
     f = glob.glob(d + '/*/*counter_collection.csv')[0]
-    rows = [r for r in csv.DictReader(open(f)) if 'gather_kernel' in r['Kernel_Name'] and r['Counter_Name'] == name]
-    mx = max(int(r['Grid_Size']) for r in rows)                   # the hop-2 gather of a full group
+    def last_op(n):         # gather_kernel<..., true>(...): the instance launched for a batch's last op (kernels_gather.hip LASTOP)
+        return 'gather_kernel' in n and n[:n.rfind('(')].rstrip().endswith('true>')
+    rows = [r for r in csv.DictReader(open(f)) if last_op(r['Kernel_Name']) and r['Counter_Name'] == name]
+    mx = max(int(r['Grid_Size']) for r in rows)                   # ... of a full group
     sel = [float(r['Counter_Value']) for r in rows if int(r['Grid_Size']) == mx]
     return sum(sel) / len(sel), len(sel), mx
 
@@ -19,7 +21,7 @@ f, nf, grid = per_launch(fetch_dir, 'FETCH_SIZE')
 w, nw, _ = per_launch(write_dir, 'WRITE_SIZE')
 bench = json.loads(open(fetch_dir + '/bench.json').read().strip().splitlines()[-1])
 rows = bench['roofline']['rows_per_launch']
-res = {"kernel": "lg::gather_kernel<float4,64,4> (hop-2 gather of a full lane group)", "grid_threads": grid,
+res = {"kernel": "lg::gather_kernel<float4, ROWS, 4, false, true> (the last hop's gather of a full lane group)", "grid_threads": grid,
        "launches_sampled": {"FETCH_SIZE": nf, "WRITE_SIZE": nw},
        "FETCH_SIZE_KiB_raw_per_launch": f, "WRITE_SIZE_KiB_per_launch": w,
        "read_bytes_per_launch_corrected": 2 * f * 1024, "write_bytes_per_launch": w * 1024,

@@ -21,7 +21,7 @@ acc = collections.defaultdict(list)
 for r in csv.DictReader(open(f)):
     n = r['Kernel_Name']
     if not (n.startswith('lg::') or 'lg::' in n): continue
-    key = (n.split('(')[0][:56], r['Grid_Size_X'], r['Grid_Size_Y'], r['Workgroup_Size_X'], r.get('VGPR_Count', r.get('Arch_VGPR_Count', '')), r.get('LDS_Block_Size', ''))
+    key = (n[:n.rfind('(')].replace('float __vector(4)', 'float4').replace(' ', '')[:64], r['Grid_Size_X'], r['Grid_Size_Y'], r['Workgroup_Size_X'], r.get('VGPR_Count', r.get('Arch_VGPR_Count', '')), r.get('LDS_Block_Size', ''))
     acc[key].append((int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3)
 with open(sys.argv[2], 'w') as o:
     o.write("kernel,grid_x_threads,grid_y,workgroup,vgpr,lds_bytes,launches,avg_us,min_us,max_us,total_us\n")
