@@ -15,13 +15,12 @@
 //     atomicMin(position_state[dst], PENDING + slot) so that the LOWEST slot owns a first touch
 //     (deterministic, unlike atomicOr on a bitmap), and the value the atomic returns tells which slot
 //     lost (slot_mark / slot_pos), so nothing re-reads the state array;
-//   * flag_count_kernel: first touch = valid and not marked a loser; wave ballots count valid edges /
-//     first touches per 256-slot tile;
-//   * scan_kernel (one workgroup per lane): exclusive prefix over tiles + the whole counter_update
-//     state machine, so no host round trip and no <<<1,1>>> launches;
-//   * scatter_kernel: ballot + mbcnt prefix inside the tile -> slot-ordered compaction of edges
-//     (global ids + both local positions when known) and of new nodes, + the next hop's row headers;
-//   * localise_kernel: agg_src_off[e] of the edges whose neighbour another slot of the hop owns.
+//   * dedup_lds_kernel (lds form of the first-touch state, the default): a hop's claims de-duplicated bucket by bucket in LDS;
+//   * compact_kernel: ONE pass -- tiles handed out by ticket, counts of valid edges / first touches by wave ballots, the
+//     prefix over a lane's tiles by decoupled look-back, then the slot-ordered compaction of edges (global ids + both local
+//     positions) and of new nodes, + the next hop's row headers; its last workgroup does the counter_update state machine,
+//     so there is no host round trip and no <<<1,1>>> launch;
+//   * localise_kernel (atomics forms only): agg_src_off[e] of the edges whose neighbour another slot of the hop owns.
 // Every kernel runs with grid.y = lanes (independent mini-batches, LanePtrs) and takes its pointers
 // from the lane descriptor as global-address-space pointers.
 // Every kernel is a fixed-size grid that strides over tiles and reads the frontier length from
@@ -645,7 +644,7 @@ void dedup_lds_kernel(HopParams hp, const LanePtrs* __restrict__ lanes)
         if (tid == 63) s_total = inc;
     }
     // the batch's vertices before this hop: the seeds are read from sampled_ids, the nodes earlier hops added from the
-    // bucket's list (scatter_kernel) -- or from sampled_ids too when there is no list or it outgrew its capacity
+    // bucket's list (list_known_kernel) -- or from sampled_ids too when there is no list or it outgrew its capacity
     const int32_t n_seed = min(max(a.node_counter[INTRABATCH_CON * 3], 0), n_known);
     const int32_t n_listed = a.known_pairs != nullptr ? a.known_cnt[b] : 0;
     const bool listed = a.known_pairs != nullptr && n_listed <= a.known_cap;
@@ -796,6 +795,7 @@ void dedup_lds_kernel(HopParams hp, const LanePtrs* __restrict__ lanes)
 #ifndef LG_SCATTER_MIN_WAVES_LAST
 #define LG_SCATTER_MIN_WAVES_LAST 8
 #endif
+#define LG_SPIN_LIMIT (1 << 24)       // polls of one word before a waiter gives up with LG_ERR_CHAIN (seconds; a wait is microseconds)
 #define LG_ST_AGG (1ull << 62)
 #define LG_ST_PREF (2ull << 62)
 __device__ __forceinline__ unsigned long long st_word(unsigned long long status, int32_t e, int32_t n)
@@ -907,7 +907,12 @@ void compact_kernel(HopParams hp, const LanePtrs* __restrict__ lanes)
                     unsigned long long w = LG_ST_PREF;                    // below tile 0: an inclusive prefix of nothing
                     if (me >= 0) {
                         w = __hip_atomic_load(state + me, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        while ((w >> 62) == 0) {
+                        for (int32_t spin = 0; (w >> 62) == 0; spin++) {
+                            if (spin == LG_SPIN_LIMIT) {       // cannot happen (the tile's workgroup is running): give up, never hang
+                                raise_error(a.hop_scratch, a.err_flag, LG_ERR_CHAIN);
+                                w = LG_ST_AGG;
+                                break;
+                            }
                             __builtin_amdgcn_s_sleep(1);
                             w = __hip_atomic_load(state + me, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         }
@@ -954,7 +959,12 @@ void compact_kernel(HopParams hp, const LanePtrs* __restrict__ lanes)
                 } else {                    // of an earlier one: wait for the position its workgroup publishes
                     const LG_G int32_t* wp = a.slot_pos + w;
                     int32_t np = __hip_atomic_load(wp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    while (np < 0) {
+                    for (int32_t spin = 0; np < 0; spin++) {
+                        if (spin == LG_SPIN_LIMIT) {           // (as above: an error bit instead of a hung GPU)
+                            raise_error(a.hop_scratch, a.err_flag, LG_ERR_CHAIN);
+                            np = 0;
+                            break;
+                        }
                         __builtin_amdgcn_s_sleep(1);
                         np = __hip_atomic_load(wp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     }
