@@ -99,7 +99,9 @@ def parse_args():
     ap.add_argument("--max-repeats", type=int, default=400)
     ap.add_argument("--dedup", type=str, default="auto", choices=["auto", "direct", "table", "lds"],
                     help="form of the per-lane first-touch/position state: direct uint32[N] array, compact open-addressing "
-                         "table, or auto (table when the arrays of all lanes in flight would exceed a quarter of HBM)")
+                         "table, lds (no per-vertex state: a hop's claims are de-duplicated bucket by bucket in LDS), or auto "
+                         "(lds up to 2^25 slots per hop and lane; beyond: direct, or table when the arrays of all lanes in "
+                         "flight would exceed a quarter of HBM)")
     ap.add_argument("--placement", type=str, default="hbm", choices=["hbm", "pinned"],
                     help="pinned: full CSR and full feature table in mapped pinned host memory (the reference's only tier; "
                          "BASELINE configs[2]): cache hits come from HBM, misses are read in place over PCIe")

@@ -114,12 +114,14 @@ int32_t legion_pool_num_ids(const LegionMemoryPool* p);
  *        12 position_map.  Returns the device pointer of the CURRENT pipe slot. */
 void* legion_pool_buffer(LegionMemoryPool* p, int32_t which);
 /* New in this build.  The first-touch/position state of a pool (the reference's accessed_map + position_map,
- * SS/engine/memorypool.cuh:120-135) is either a direct uint32[N] array (fastest; N x 4 B per pool) or a compact
- * open-addressing table sized by num_ids, or (form "lds") nothing at all per vertex: see legion_pool_dedup_form (LEGION_DEDUP=direct|table|lds|auto, auto = lds for small hops, else table when the arrays of all
- * pools in flight would exceed a quarter of HBM).  Both give bit-identical batches. */
+ * SS/engine/memorypool.cuh:120-135) takes one of three forms: a direct uint32[N] array (N x 4 B per pool), a compact
+ * open-addressing table sized by num_ids, or (form "lds", the default wherever it applies) nothing at all per vertex.
+ * LEGION_DEDUP=direct|table|lds|auto; auto = lds for pools whose largest hop has at most 2^25 slots per lane (every shape
+ * of legion_server.py), beyond that direct, or table when the arrays of all pools in flight would exceed a quarter of
+ * HBM.  All three give bit-identical batches. */
 int32_t legion_pool_uses_table(const LegionMemoryPool* p);
 /* 0 direct array, 1 compact table, 2 "lds": no per-vertex state, a hop's claims are de-duplicated bucket by bucket in LDS
- * (LEGION_DEDUP=lds; pools whose largest hop has at most 2^19 slots) */
+ * (hops of up to 2^25 slots per lane; a pool beyond that falls back to the table) */
 int32_t legion_pool_dedup_form(const LegionMemoryPool* p);
 int64_t legion_pool_state_bytes(const LegionMemoryPool* p);
 /* Sticky error bits raised on the device for this pool (0 = none): 1 position table full, 2 batch larger than the

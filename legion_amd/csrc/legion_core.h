@@ -76,8 +76,9 @@
 // position, a smaller one sends the claim itself on.  Words only ever decrease at a position within an
 // epoch, so a vertex has one home however the claims interleave, and every word that is merged away is
 // merged away exactly once -- by the thread that observes it -- which keeps "one writer per loser mark".
-// Same epochs, same refill rule (T x 8 B instead of N x 4 B).  Selected per pool: LEGION_DEDUP=direct|table|auto
-// (auto: table when the direct arrays of all lanes in flight would take more than a quarter of HBM).
+// Same epochs, same refill rule (T x 8 B instead of N x 4 B).  Selected per pool: LEGION_DEDUP=direct|table|lds|auto
+// (auto: the LDS form below for pools whose largest hop has at most 2^25 slots per lane -- every shape of legion_server.py --
+// beyond that direct, or table when the direct arrays of all lanes in flight would take more than a quarter of HBM).
 //
 // The LDS form (round 2) issues no memory-side atomic per claim at all.  A hop's claims (vertex, slot) are written, by
 // the sampling kernel, into hash buckets of their lane (one reservation per partition tile, ranks by LDS atomics); a
