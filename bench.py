@@ -50,7 +50,8 @@ class OneLine:
     the headline leg and have never met more than one physical GPU before the driver's SCALE run: whatever ends this process
     while they run -- a Python error (caught by the caller), a native exit() of the library (libc atexit hook), SIGTERM from
     the launcher after another rank died (wake-up fd + watcher thread: works while the main thread is blocked inside a HIP or
-    RCCL call) -- the headline leg's line, already measured, still goes out, with a note on what happened."""
+    RCCL call), or nothing at all for `deadline_s` seconds (a hang) -- the headline leg's line, already measured, still goes
+    out, with a note on what happened."""
 
     def __init__(self, fd):
         self.fd, self.line, self.done, self.lock = fd, None, False, threading.Lock()
@@ -63,8 +64,8 @@ class OneLine:
             self.done = True
         os.write(self.fd, (json.dumps(obj) + "\n").encode())
 
-    def arm(self, headline_obj):
-        """From here on a dying process still prints `headline_obj`."""
+    def arm(self, headline_obj, deadline_s=900):
+        """From here on a dying -- or, after `deadline_s`, a hung -- process still prints `headline_obj`."""
         self.line = dict(headline_obj)
 
         def fallback(why):
@@ -81,8 +82,10 @@ class OneLine:
         signal.signal(signal.SIGTERM, lambda *_: None)       # (the C-level handler writes the signal number to wfd)
 
         def watch():
-            os.read(rfd, 1)
-            fallback("SIGTERM while an extra leg was running (another rank failed?)")
+            import select
+            got, _, _ = select.select([rfd], [], [], deadline_s)
+            fallback("SIGTERM while an extra leg was running (another rank failed?)" if got else
+                     "the extra legs did not finish within %d s (hung peer load or collective?)" % deadline_s)
             os._exit(1)
 
         threading.Thread(target=watch, daemon=True).start()
@@ -163,7 +166,9 @@ def parse_args():
     ap.add_argument("--backend", type=str, default="nccl", help="torch.distributed backend (nccl = RCCL)")
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise torch.distributed and run the collectives even at N = 1 (exercises the RCCL calls on a 1-GPU box)")
-    ap.add_argument("--fail-extra-leg", type=str, default="", choices=["", "raise", "exit", "sigterm"],
+    ap.add_argument("--extra-legs-deadline", type=int, default=600,
+                    help="N > 1: seconds the extra (striped) legs may take together before rank 0 prints the headline line alone and exits")
+    ap.add_argument("--fail-extra-leg", type=str, default="", choices=["", "raise", "exit", "sigterm", "hang"],
                     help="testing: make rank 0 fail this way when the first extra leg starts (the headline line must still go out)")
     ap.add_argument("--force-device", type=int, default=-1,
                     help="put every rank on this GPU (testing the N > 1 code path on a 1-GPU box, with --backend gloo)")
@@ -256,7 +261,7 @@ def main():
     out = head["json"] if rank == 0 else None
     if world > 1 and not stripe and not args.no_striped_leg:
         if rank == 0:
-            one_line.arm(out)
+            one_line.arm(out, args.extra_legs_deadline)
         try:
             out_striped = run_leg(c, engine, synth, True, 0, headline=False)
             if rank == 0:
@@ -296,8 +301,10 @@ def run_leg(c, engine, synth, stripe, replica_memory, headline):
             raise RuntimeError("requested by --fail-extra-leg")
         if args.fail_extra_leg == "exit":
             ctypes.CDLL(None).exit(3)
-        os.kill(os.getpid(), signal.SIGTERM)
-        time.sleep(60)
+        if args.fail_extra_leg == "sigterm":
+            os.kill(os.getpid(), signal.SIGTERM)
+        while True:
+            ctypes.CDLL(None).sleep(5)      # (a main thread that never comes back from a C call)
     fanout, H, N, D, B, G = c.fanout, c.H, c.N, c.D, c.B, c.G
     n_warm, n_timed, wrap, mine = c.n_warm, c.n_timed, c.wrap, c.mine
     t_leg = time.time()

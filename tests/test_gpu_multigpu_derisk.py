@@ -83,13 +83,13 @@ def test_scale_command_line_two_ranks_on_one_gpu(hip, stripe):
     assert 0.7 < d["edges_per_step"] / d1["edges_per_step"] < 1.4
 
 
-@pytest.mark.parametrize("how", ["raise", "exit", "sigterm"])
+@pytest.mark.parametrize("how", ["raise", "exit", "sigterm", "hang"])
 def test_headline_line_survives_a_failing_extra_leg(hip, how):
     """N > 1: the striped legs run after the headline leg; if one of them ends rank 0 -- a Python error, a native exit() of the
-    library, SIGTERM from the launcher -- the headline leg's ONE line must still be printed, with a note (bench.py OneLine)."""
+    library, SIGTERM from the launcher, a hang -- the headline leg's ONE line must still be printed, with a note (bench.py OneLine)."""
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo",
-           "--force-device", "0", "--fail-extra-leg", how] + SMALL
+           "--force-device", "0", "--fail-extra-leg", how, "--extra-legs-deadline", "8"] + SMALL
     res = subprocess.run(cmd, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
     lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, (res.stdout[-2000:], res.stderr[-2000:])
