@@ -97,6 +97,41 @@ def test_gather_rows(hip, D):
     assert np.array_equal(dst.cpu().numpy().view(np.uint32), want.view(np.uint32))
 
 
+@pytest.mark.parametrize("rows_per_wg,D,cnt", [(16, 4, 300_017), (64, 7, 1_200_003), (32, 128, 530_001)])
+def test_gather_rows_workgroups_walk_several_tiles(hip, monkeypatch, rows_per_wg, D, cnt):
+    """More tiles than workgroups (the grid is capped at ~8192 workgroups per launch): a workgroup then walks tiles
+    blockIdx.x, + gridDim.x, ... with the NEXT tile's ids and slot lookups prefetched while it copies (kernels_gather.hip) --
+    two and three tiles per workgroup, a partial last tile, hits / misses / skipped rows mixed."""
+    monkeypatch.setenv("LEGION_GATHER_ROWS", str(rows_per_wg))
+    hip.legion_tuning_from_env()
+    try:
+        N, cap = 40_000, 9_000
+        rng = np.random.RandomState(cnt % 1000)
+        table = synth.features_numpy(0, N, D, 7)
+        node_map = np.full(N, -2, dtype=np.int32)
+        cached = rng.permutation(N)[:cap]
+        node_map[cached] = np.arange(cap, dtype=np.int32)
+        cache = table[cached] + np.float32(1000.0)                      # make hits distinguishable
+        ids = rng.randint(0, N, size=cnt).astype(np.int32)
+        ids[::101] = -1                                                  # skipped rows
+        t_table, t_cache = torch.from_numpy(table).cuda(), torch.from_numpy(cache).cuda()
+        ptrs = torch.tensor([t_cache.data_ptr()], dtype=torch.int64).cuda()
+        t_map, t_ids = torch.from_numpy(node_map).cuda(), torch.from_numpy(ids).cuda()
+        t_range = torch.tensor([0, cnt], dtype=torch.int32).cuda()
+        dst = torch.full((cnt, D), -7.0, dtype=torch.float32).cuda()
+        cidx = torch.full((cnt,), 99, dtype=torch.int32).cuda()
+        hip.legion_gather_rows(_stream(), _p(t_table), _p(ptrs), _p(t_map), cap, D, N, _p(t_ids), _p(cidx), _p(t_range), _p(dst), cnt)
+        torch.cuda.synchronize()
+        g = np.where(ids >= 0, node_map[np.maximum(ids, 0)], -2).astype(np.int32)
+        want = np.where((g >= 0)[:, None], cache[np.maximum(g, 0)], table[np.maximum(ids, 0)])
+        want[ids < 0] = -7.0
+        assert np.array_equal(cidx.cpu().numpy(), g)
+        assert np.array_equal(dst.cpu().numpy().view(np.uint32), want.astype(np.float32).view(np.uint32))
+    finally:
+        monkeypatch.delenv("LEGION_GATHER_ROWS")
+        hip.legion_tuning_from_env()
+
+
 def test_gather_no_map_all_miss_and_zero_rows(hip):
     N, D = 1000, 128
     table = torch.from_numpy(synth.features_numpy(0, N, D, 7)).cuda()
