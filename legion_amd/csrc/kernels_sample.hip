@@ -623,6 +623,28 @@ void dedup_lds_kernel(HopParams hp, const LanePtrs* __restrict__ lanes)
     constexpr uint32_t PENDING = 0x80000000u;
     const LG_G int32_t* roff = a.run_off + b;              // roff[t * (NB + 1)]: start of this bucket's segment of partition tile t
 
+    // the batch's vertices before this hop: the seeds are read from sampled_ids, the nodes earlier hops added from the
+    // bucket's list (list_known_kernel) -- or from sampled_ids too when there is no list or it outgrew its capacity
+    const int32_t n_seed = min(max(a.node_counter[INTRABATCH_CON * 3], 0), n_known);
+    const int32_t n_listed = a.known_pairs != nullptr ? a.known_cnt[b] : 0;
+    const bool listed = a.known_pairs != nullptr && n_listed <= a.known_cap;
+    const int32_t n_scan = listed ? n_seed : n_known;
+    const LG_G unsigned long long* klist = a.known_pairs + (int64_t)b * a.known_cap;
+    // Nothing below depends on the segment table: the first LG_DEDUP_BATCH known ids / list entries of the thread are loaded
+    // now (the usual bucket has no more) and the table is cleared now, while the segment table is being built -- the
+    // workgroup's life is a chain of dependent round trips, these two leave it
+    int32_t kid[LG_DEDUP_BATCH];
+    unsigned long long kl[LG_DEDUP_BATCH];
+#pragma unroll
+    for (int u = 0; u < LG_DEDUP_BATCH; u++) {
+        const int32_t i = u * LG_DEDUP_THREADS + tid;
+        kid[u] = i < n_scan ? a.sampled_ids[i] : -1;
+        kl[u] = (listed && i < n_listed) ? klist[i] : ~0ull;
+    }
+    for (int32_t i = tid; i < LG_LDS_TABLE; i += LG_DEDUP_THREADS) s_tab[i] = ~0ull;
+    if (tid == 0) s_full = 0;
+    bool cleared = true;
+
     // the bucket's segments, one per partition tile: exclusive prefix of their lengths
     if (tid == 0) s_total = 0;
     for (int32_t t = tid; t < nparts; t += LG_DEDUP_THREADS) {
@@ -643,13 +665,6 @@ void dedup_lds_kernel(HopParams hp, const LanePtrs* __restrict__ lanes)
         if (tid == 0) s_pref[0] = 0;
         if (tid == 63) s_total = inc;
     }
-    // the batch's vertices before this hop: the seeds are read from sampled_ids, the nodes earlier hops added from the
-    // bucket's list (list_known_kernel) -- or from sampled_ids too when there is no list or it outgrew its capacity
-    const int32_t n_seed = min(max(a.node_counter[INTRABATCH_CON * 3], 0), n_known);
-    const int32_t n_listed = a.known_pairs != nullptr ? a.known_cnt[b] : 0;
-    const bool listed = a.known_pairs != nullptr && n_listed <= a.known_cap;
-    const int32_t n_scan = listed ? n_seed : n_known;
-    const LG_G unsigned long long* klist = a.known_pairs + (int64_t)b * a.known_cap;
     __syncthreads();
     const int32_t total = s_total;
     // passes: distinct vertices <= known + claims; keep the expected load of a pass at or below LG_LDS_FILL_16THS / 16 of the
@@ -694,22 +709,34 @@ void dedup_lds_kernel(HopParams hp, const LanePtrs* __restrict__ lanes)
     const uint32_t pmask = (uint32_t)passes - 1u;
     bool overflow = false;
     for (uint32_t pass = 0; pass <= pmask; pass++) {
-        for (int32_t i = tid; i < LG_LDS_TABLE; i += LG_DEDUP_THREADS) s_tab[i] = ~0ull;
-        if (tid == 0) s_full = 0;
-        __syncthreads();
-        for (int32_t i = tid; i < n_scan; i += LG_DEDUP_THREADS) {
-            const int32_t id = a.sampled_ids[i];
-            if (id < 0) continue;
-            const uint32_t h = lg_tab_hash(id);
-            if ((h & (NB - 1)) != (uint32_t)b || ((h >> BB) & pmask) != pass) continue;
-            insert(((unsigned long long)(uint32_t)id << 32) | (uint32_t)i, h);
+        if (!cleared) {
+            for (int32_t i = tid; i < LG_LDS_TABLE; i += LG_DEDUP_THREADS) s_tab[i] = ~0ull;
+            if (tid == 0) s_full = 0;
+            __syncthreads();
+        }
+        cleared = false;
+        for (int32_t i0 = 0; i0 < n_scan; i0 += LG_DEDUP_BATCH * LG_DEDUP_THREADS) {
+#pragma unroll
+            for (int u = 0; u < LG_DEDUP_BATCH; u++) {
+                const int32_t i = i0 + u * LG_DEDUP_THREADS + tid;
+                const int32_t id = i0 == 0 ? kid[u] : (i < n_scan ? a.sampled_ids[i] : -1);      // (the first chunk came early)
+                if (id < 0) continue;
+                const uint32_t h = lg_tab_hash(id);
+                if ((h & (NB - 1)) != (uint32_t)b || ((h >> BB) & pmask) != pass) continue;
+                insert(((unsigned long long)(uint32_t)id << 32) | (uint32_t)i, h);
+            }
         }
         if (listed)
-            for (int32_t i = tid; i < n_listed; i += LG_DEDUP_THREADS) {
-                const unsigned long long pr = klist[i];
-                const uint32_t h = lg_tab_hash((int32_t)(pr >> 32));
-                if (((h >> BB) & pmask) != pass) continue;
-                insert(pr, h);
+            for (int32_t i0 = 0; i0 < n_listed; i0 += LG_DEDUP_BATCH * LG_DEDUP_THREADS) {
+#pragma unroll
+                for (int u = 0; u < LG_DEDUP_BATCH; u++) {
+                    const int32_t i = i0 + u * LG_DEDUP_THREADS + tid;
+                    const unsigned long long pr = i0 == 0 ? kl[u] : (i < n_listed ? klist[i] : ~0ull);
+                    if (pr == ~0ull) continue;
+                    const uint32_t h = lg_tab_hash((int32_t)(pr >> 32));
+                    if (((h >> BB) & pmask) != pass) continue;
+                    insert(pr, h);
+                }
             }
         for (int32_t k0 = 0; k0 < total; k0 += LG_DEDUP_BATCH * LG_DEDUP_THREADS) {
             unsigned long long pr[LG_DEDUP_BATCH];
