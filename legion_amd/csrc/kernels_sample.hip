@@ -1035,8 +1035,13 @@ void compact_kernel(HopParams hp, const LanePtrs* __restrict__ lanes)
 
     // the workgroup that finishes last: counter_update(op_id), op_id % 3 == 0 (operator_impl.cu:69-82), with nc[6] = n_new and
     // ec[2] = n_edge being what the reference's atomicAdds (:263-264) leave there; hop scratch; status words back to zero
-    if (tid == 0)
+    if (tid == 0) {
+        // this thread wrote the tiles' status words: they must have landed before the count says "finished", or the last
+        // workgroup's zeroes could be overtaken by one of them.  A workgroup-scope release is a wait for the thread's own
+        // stores, nothing else (no L2 write-back, unlike the agent-scope fence above)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         s_last = (__hip_atomic_fetch_add(hs + HS_CDONE, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (int32_t)gridDim.x - 1) ? 1 : 0;
+    }
     __syncthreads();
     if (!s_last) return;
     if (tid == 0) {
