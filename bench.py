@@ -527,7 +527,7 @@ def run_leg(c, engine, synth, stripe, replica_memory, headline):
             err_bits |= pl.error()
     if err_bits:
         raise RuntimeError(f"a kernel raised error bits {err_bits:#x} during the run (legion_core.h LG_ERR_*)")
-    dedup_form, state_bytes = pipe.pools[0][0].dedup_form(), pipe.pools[0][0].state_bytes()
+    dedup_form, state_bytes, lds_buckets = pipe.pools[0][0].dedup_form(), pipe.pools[0][0].state_bytes(), pipe.pools[0][0].lds_buckets()
 
     # ---- the same K steps once more with every group's sampler phase and gather phase on two streams (sampler k+1 runs
     #      under gathers k, pipeline.hip `split`): reported beside the headline as `overlapped`, not as `value`, because
@@ -693,7 +693,7 @@ def run_leg(c, engine, synth, stripe, replica_memory, headline):
                             "slower while sharing the machine (the gather at ~0.59 of peak instead of 0.78).  With the atomics forms "
                             "of the first-touch state this finishes a group 8-12 % sooner than one stream; with the LDS form and "
                             "the weave default it does not (DESIGN.md section 4.5)."},
-                "position_state": {"form": dedup_form, "bytes_per_lane": state_bytes, "lanes": G * args.slots},
+                "position_state": {"form": dedup_form, "bytes_per_lane": state_bytes, "lanes": G * args.slots, "lds_buckets_per_lane": lds_buckets},
                 "feature_cache_hit_rate": feat_hit_rows / max(feat_hit_rows + feat_miss_rows, 1),
                 "feature_cache_hit_rate_over": "every timed batch" if args.placement == "pinned" else "the first timed step",
             }

@@ -123,6 +123,8 @@ int32_t legion_pool_uses_table(const LegionMemoryPool* p);
 /* 0 direct array, 1 compact table, 2 "lds": no per-vertex state, a hop's claims are de-duplicated bucket by bucket in LDS
  * (hops of up to 2^25 slots per lane; a pool beyond that falls back to the table) */
 int32_t legion_pool_dedup_form(const LegionMemoryPool* p);
+/* hash buckets per lane of the lds form (8, 16, 64 or 256; 0 for the other forms) */
+int32_t legion_pool_lds_buckets(const LegionMemoryPool* p);
 int64_t legion_pool_state_bytes(const LegionMemoryPool* p);
 /* Sticky error bits raised on the device for this pool (0 = none): 1 position table full, 2 batch larger than the
  * feature buffer (gather stopped at its end; the reference overruns, SS/engine/server.cu:277), 4 internal.  The
@@ -356,6 +358,8 @@ typedef struct LegionTuning {
     int32_t pos_table_bits;      /* LEGION_POS_TABLE_BITS  (0 = sized by num_ids): log2 words of the compact table (tests) */
     int32_t lds_known_cap;       /* LEGION_LDS_KNOWN_CAP   (0 = 2 x an even share): entries per known-node list (tests) */
     int32_t lds_part_wg;         /* LEGION_LDS_PART_WG     (8192): workgroups a partitioning sample launch aims for */
+    int32_t lds_small_buckets;   /* LEGION_LDS_SMALL_BUCKETS (0 auto | 8 | 16): hash buckets per lane of pools whose hops have <= 2^19 slots;
+                                    auto = 16 where PreSC saw more last-hop edges + earlier nodes than 8 buckets take in one pass */
     int32_t sample_max_wg;       /* LEGION_SAMPLE_MAX_WG   (4096): workgroup cap of the strided sampler grids */
     int32_t gather_small_tiles;  /* LEGION_GATHER_SMALL_TILES (1): 16-row tiles for launches of fewer than 4096 tiles */
     int32_t gather_rows_per_wg;  /* LEGION_GATHER_ROWS     (0 = by row width): rows per gather workgroup, 16|32|64|128|256 */

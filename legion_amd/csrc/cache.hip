@@ -33,9 +33,16 @@ __global__ void find_range_kernel(const int32_t* __restrict__ sampled_ids,
     }
 }
 
-__global__ void track_max_kernel(const int32_t* __restrict__ nc, int32_t* __restrict__ max_ids)
+// max_ids[0]: nodes of a batch (cache.cu:55-61); [1], [2]: edges of its LAST hop and nodes before it -- the claims and the
+// known vertices of the largest de-duplication (lg_set_pool_claims_hint)
+__global__ void track_max_kernel(const int32_t* __restrict__ nc, const int32_t* __restrict__ ec, int32_t* __restrict__ max_ids)
 {
     atomicMax(max_ids, nc[INTRABATCH_CON * 2 + 1]);
+    const int32_t H = nc[INTRABATCH_CON * 3 - 1];
+    if (ec != nullptr && H >= 1 && H <= 6) {
+        atomicMax(max_ids + 1, ec[INTRABATCH_CON * 3 + H] - ec[INTRABATCH_CON * 3 + H - 1]);
+        atomicMax(max_ids + 2, nc[INTRABATCH_CON * 3 + H - 1]);
+    }
 }
 }  // namespace lg
 
@@ -56,8 +63,8 @@ public:
         edge_access_time_ = (unsigned long long*)d_alloc_space(bytes + (int64_t)sizeof(unsigned long long));
         HIP_CALL(hipMemset(node_access_time_, 0, (size_t)bytes));
         HIP_CALL(hipMemset(edge_access_time_, 0, (size_t)bytes + sizeof(unsigned long long)));
-        d_max_ids_ = (int32_t*)d_alloc_space(4);
-        HIP_CALL(hipMemset(d_max_ids_, 0, 4));
+        d_max_ids_ = (int32_t*)d_alloc_space(16);
+        HIP_CALL(hipMemset(d_max_ids_, 0, 16));
         iter_ = 0;
     }
 
@@ -77,12 +84,12 @@ public:
 
     // SS/cache/cache.cu:40-68
     void CacheProfiling(int32_t* sampled_ids, int32_t*, int32_t*, int32_t*, int32_t*,
-                        int32_t* node_counter, int32_t*, bool is_presc, void* stream) override
+                        int32_t* node_counter, int32_t* edge_counter, bool is_presc, void* stream) override
     {
         if (is_presc) {
             hipStream_t s = static_cast<hipStream_t>(stream);
             lg::launch_hotness_measure(s, sampled_ids, node_counter, node_access_time_);
-            lg::track_max_kernel<<<1, 1, 0, s>>>(node_counter, d_max_ids_);
+            lg::track_max_kernel<<<1, 1, 0, s>>>(node_counter, edge_counter, d_max_ids_);
             hipCheckError();
             if (iter_ == (train_step_ - 1)) iter_ = 0;
         }
@@ -152,6 +159,12 @@ public:
         int32_t v = 0;
         HIP_CALL(hipMemcpy(&v, d_max_ids_, 4, hipMemcpyDeviceToHost));
         return v;
+    }
+    // (new in this build) what PreSC saw of the last hop: {its edges, the batch's nodes before it}, maxima over the batches
+    void LastHopMax(int32_t out[2])
+    {
+        SetGPUDevice(device_idx_);
+        HIP_CALL(hipMemcpy(out, d_max_ids_ + 1, 8, hipMemcpyDeviceToHost));
     }
 
     const int32_t* NodeMap() const override { return node_map_; }
@@ -452,6 +465,12 @@ void UnifiedCache::FillUpLink(FeatureStorage* feature, GraphStorage* graph)
 }
 
 int32_t UnifiedCache::MaxIdNum(int32_t dev_id) { return cache_controller_[dev_id]->MaxIdNum(); }
+void UnifiedCache::LastHopMax(int32_t dev_id, int32_t out[2])
+{
+    out[0] = out[1] = 0;
+    if (dev_id >= 0 && dev_id < (int32_t)cache_controller_.size() && cache_controller_[dev_id] != nullptr)
+        static_cast<PreSCCacheController*>(cache_controller_[dev_id])->LastHopMax(out);
+}
 
 unsigned long long* UnifiedCache::GatherStats(int32_t dev_id)
 {

@@ -593,9 +593,6 @@ __global__ __launch_bounds__(LG_TILE) __attribute__((amdgpu_num_sgpr(LG_SAMPLE_S
 // scales with the graph.  The claims arrive as one segment per partition tile of the sampling kernel (run_off); a
 // workgroup addresses claim k of its bucket through the prefix of the segment lengths.
 // ------------------------------------------------------------------------------------------
-#ifndef LG_LDS_FILL_16THS
-#define LG_LDS_FILL_16THS 14         // a pass may fill its table up to this many sixteenths (bound: known + claims of the pass)
-#endif
 #define LG_DEDUP_BATCH 4             // claims a thread loads before it works on them (their loads are in flight together)
 #ifndef LG_DEDUP_THREADS
 #define LG_DEDUP_THREADS 1024
@@ -1166,7 +1163,8 @@ void launch_random_sample(hipStream_t s, const HopParams& p, const LanePtrs* d_l
         // most LG_LDS_MAX_PARTS partition tiles, and no larger than leaves the launch ~8 k workgroups by the hop's capacity
         // (a hop typically fills a quarter of it: ~2 k active ones; measured at B = 8000: 2 k -> 8 k +1...2 %, beyond: the same)
         HopParams q = p;
-        const int32_t k_hi = p.lds_bucket_bits == LG_LDS_BITS_SMALL ? 1 : (p.lds_bucket_bits == LG_LDS_BITS_MEDIUM ? LG_LDS_K_MEDIUM : LG_LDS_K_LARGE);
+        const bool small = p.lds_bucket_bits == LG_LDS_BITS_SMALL || p.lds_bucket_bits == LG_LDS_BITS_SMALL16;
+        const int32_t k_hi = small ? 1 : (p.lds_bucket_bits == LG_LDS_BITS_MEDIUM ? LG_LDS_K_MEDIUM : LG_LDS_K_LARGE);
         int32_t k_lo = p.lds_bucket_bits == LG_LDS_BITS_LARGE ? 4 : 1;
         while (max_super > LG_LDS_MAX_PARTS * k_lo) k_lo *= 2;
         int32_t k = k_hi > k_lo ? k_hi : k_lo;
@@ -1179,6 +1177,10 @@ void launch_random_sample(hipStream_t s, const HopParams& p, const LanePtrs* d_l
             sample_kernel<2, LG_LDS_BITS_SMALL, true><<<grid, LG_TILE, 0, s>>>(q, d_lanes);
             hipCheckError();
             dedup_lds_kernel<LG_LDS_BITS_SMALL><<<dim3(1 << LG_LDS_BITS_SMALL, n_lanes), LG_DEDUP_THREADS, 0, s>>>(q, d_lanes);
+        } else if (p.lds_bucket_bits == LG_LDS_BITS_SMALL16) {
+            sample_kernel<2, LG_LDS_BITS_SMALL16, true><<<grid, LG_TILE, 0, s>>>(q, d_lanes);
+            hipCheckError();
+            dedup_lds_kernel<LG_LDS_BITS_SMALL16><<<dim3(1 << LG_LDS_BITS_SMALL16, n_lanes), LG_DEDUP_THREADS, 0, s>>>(q, d_lanes);
         } else if (p.lds_bucket_bits == LG_LDS_BITS_MEDIUM) {
             sample_kernel<2, LG_LDS_BITS_MEDIUM, false><<<dim3(gp, n_lanes), LG_TILE, 0, s>>>(q, d_lanes);
             hipCheckError();
@@ -1201,6 +1203,7 @@ void launch_random_sample(hipStream_t s, const HopParams& p, const LanePtrs* d_l
         int32_t chunks = (p.max_slots + LG_LIST_CHUNK - 1) / LG_LIST_CHUNK;
         if (chunks > 256) chunks = 256;
         if (p.lds_bucket_bits == LG_LDS_BITS_SMALL) list_known_kernel<LG_LDS_BITS_SMALL><<<dim3(chunks, n_lanes), LG_TILE, 0, s>>>(p, d_lanes);
+        else if (p.lds_bucket_bits == LG_LDS_BITS_SMALL16) list_known_kernel<LG_LDS_BITS_SMALL16><<<dim3(chunks, n_lanes), LG_TILE, 0, s>>>(p, d_lanes);
         else if (p.lds_bucket_bits == LG_LDS_BITS_MEDIUM) list_known_kernel<LG_LDS_BITS_MEDIUM><<<dim3(chunks, n_lanes), LG_TILE, 0, s>>>(p, d_lanes);
         else list_known_kernel<LG_LDS_BITS_LARGE><<<dim3(chunks, n_lanes), LG_TILE, 0, s>>>(p, d_lanes);
         hipCheckError();

@@ -94,6 +94,7 @@
 // (B = 1024-class batches), 64 / 8192 up to 2^22 (B = 8000 with [25,10]), 256 up to 2^25 (B = 8000 with [15,10,5] has 6 M,
 // with [25,10,10] 20 M); at most 1024 partition tiles per hop.  The kernels are instantiated for the three classes.
 #define LG_LDS_BITS_SMALL 3
+#define LG_LDS_BITS_SMALL16 4                    // the same class with 16 buckets: dense graphs, see lg_set_pool_claims_hint
 #ifndef LG_LDS_BITS_MEDIUM
 #define LG_LDS_BITS_MEDIUM 6
 #endif
@@ -109,6 +110,9 @@
 #define LG_LDS_TABLE_BITS 13
 #endif
 #define LG_LDS_TABLE (1 << LG_LDS_TABLE_BITS)   // 64-bit words of LDS per (lane, bucket) workgroup
+#ifndef LG_LDS_FILL_16THS
+#define LG_LDS_FILL_16THS 14                    // a pass may fill its table up to this many sixteenths (bound: known + claims of the pass)
+#endif
 #define LG_LDS_MAX_SLOTS (1 << 25)
 #define LG_POS_VALUE_BITS_MIN 16
 #define LG_POS_VALUE_BITS_MAX 28
@@ -501,6 +505,7 @@ public:
     bool gather_stats_on_ = true;        // GatherStats() arms the counters; this pauses them (legion_cache_gather_stats_enable)
     unsigned long long* GatherStats(int32_t dev_id);   // device {stripe rows, replica rows, peer-stripe rows}, allocated on first use
     int32_t MaxIdNum(int32_t dev_id);
+    void LastHopMax(int32_t dev_id, int32_t out[2]);   // PreSC maxima {edges of the last hop, nodes before it}; {0, 0} before PreSC
     unsigned long long int* GetEdgeAccessedMap(int32_t dev_id);
     // the gather over a group of lanes (the reference's per-array arguments live in LanePtrs)
     // first_op_id < op_id: one launch also covers the new-node ranges of the earlier ops first_op_id, +3, ...
@@ -641,6 +646,10 @@ void lg_pool_alloc_private(MemoryPool* mp, int32_t dev_id, int32_t total_num_nod
 // how many pools of this shape the caller is about to keep in flight on the device (Pipeline: lanes x slots);
 // feeds the direct-vs-table choice of the position state (LEGION_DEDUP=auto).  Thread-local; 0 = one pool.
 void lg_set_pool_lanes_hint(int32_t lanes);
+// what PreSC saw of the LAST hop, the largest one: its edges (= the claims its de-duplication takes) and the batch's nodes
+// before it (= what that de-duplication must recognise), maxima over the PreSC batches; 0, 0 = unknown.  Pools created
+// afterwards by this thread pick the small class's bucket count from it (8, or 16 where a bucket would need two passes).
+void lg_set_pool_claims_hint(int64_t last_hop_edges, int64_t nodes_before_last_hop);
 
 // alloc helpers, SS/engine/server_imp.cuh:2-51
 extern "C" void* d_alloc_space(int64_t num_bytes);
@@ -677,7 +686,7 @@ struct HopParams {                  // what every lane of a launch shares
     int32_t max_slots;              // capacity of slot_dst for this hop
     unsigned long long* edge_access_time;  // presample only (single lane), else null
     unsigned long long* topo_transactions; // presample only: 64-byte transactions the hop's topology reads amount to
-    int32_t lds_bucket_bits;        // lds form: LG_LDS_BITS_SMALL / MEDIUM / LARGE (the pool's)
+    int32_t lds_bucket_bits;        // lds form: LG_LDS_BITS_SMALL / SMALL16 / MEDIUM / LARGE (the pool's)
     int32_t lds_k;                  // lds form: super tiles per partition tile in this hop (set by launch_random_sample)
 };
 // form: 0 direct array, 1 table, 2 lds

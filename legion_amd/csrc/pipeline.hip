@@ -129,6 +129,12 @@ extern "C" LegionPipeline* legion_pipeline_create(LegionGraphStorage* graph, Leg
     }
     p->slots.resize(p->slots_n);
     lg_set_pool_lanes_hint(p->group_size * p->slots_n);   // direct-vs-table choice of the position state sees every lane
+    {   // what PreSC saw of the largest hop decides the small class's bucket count (8 or 16, storage.hip)
+        int32_t last_hop[2] = {0, 0};
+        if (p->cache_handle != nullptr)     // (the handle boxes the UnifiedCache as its first member, cache.hip)
+            reinterpret_cast<UnifiedCache*>(p->cache_handle)->LastHopMax(dev_id, last_hop);
+        lg_set_pool_claims_hint(last_hop[0], last_hop[1]);
+    }
     for (Slot& sl : p->slots) {
         std::vector<LegionMemoryPool*> handles;
         for (int32_t g = 0; g < p->group_size; g++) {
@@ -158,6 +164,7 @@ extern "C" LegionPipeline* legion_pipeline_create(LegionGraphStorage* graph, Leg
         HIP_CALL(hipEventCreateWithFlags(&sl.sampled, hipEventDisableTiming));
     }
     lg_set_pool_lanes_hint(0);
+    lg_set_pool_claims_hint(0, 0);
     return p;
 }
 

@@ -538,6 +538,12 @@ void MemoryPool::Finalize()
 static bool lg_use_pos_table(int64_t total_num_nodes);
 static thread_local int32_t g_pool_lanes_hint = 0;
 void lg_set_pool_lanes_hint(int32_t lanes) { g_pool_lanes_hint = lanes; }
+static thread_local int64_t g_pool_claims_hint[2] = {0, 0};
+void lg_set_pool_claims_hint(int64_t last_hop_edges, int64_t nodes_before_last_hop)
+{
+    g_pool_claims_hint[0] = last_hop_edges;
+    g_pool_claims_hint[1] = nodes_before_last_hop;
+}
 
 // 0 direct array, 1 table, 2 lds (legion_core.h)
 static int lg_dedup_form(int64_t total_num_nodes, int64_t max_slots)
@@ -594,6 +600,16 @@ void lg_pool_alloc_private(MemoryPool* mp, int32_t dev_id, int32_t total_num_nod
         mp->lds_form = true;
         mp->claim_pairs = (unsigned long long*)d_alloc_space(slots * sizeof(unsigned long long));
         mp->lds_bucket_bits = slots <= LG_LDS_SLOTS_SMALL ? LG_LDS_BITS_SMALL : (slots <= LG_LDS_SLOTS_MEDIUM ? LG_LDS_BITS_MEDIUM : LG_LDS_BITS_LARGE);
+        if (mp->lds_bucket_bits == LG_LDS_BITS_SMALL) {
+            // The small class has 8 or 16 buckets per lane.  Slots say how large a hop CAN get, not how many of them hold an
+            // edge: on a dense graph (ogbn-products: 60 k edges per batch of 1024 where RMAT-26 has 35 k) a bucket of 8 holds
+            // more vertices than one LDS table takes and every workgroup runs two passes (217 us instead of ~110 per
+            // 256-lane group).  PreSC has seen the real numbers: 16 buckets where 8 would overflow one pass, else 8 (which
+            // is 8 us faster per group where both fit).
+            const int64_t one_pass = LG_LDS_TABLE / 16 * LG_LDS_FILL_16THS;
+            const int64_t need = (g_pool_claims_hint[0] + g_pool_claims_hint[1]) * 11 / 10;      // (+10 %: buckets are not even)
+            if (tune.lds_small_buckets == 16 || (tune.lds_small_buckets != 8 && need / 8 > one_pass)) mp->lds_bucket_bits = LG_LDS_BITS_SMALL16;
+        }
         const int64_t n_buckets = (int64_t)1 << mp->lds_bucket_bits;
         const int64_t n_parts = std::min<int64_t>(n_super, LG_LDS_MAX_PARTS) + 2;    // launch_random_sample keeps every hop within LG_LDS_MAX_PARTS
         mp->run_off = (int32_t*)d_alloc_space(n_parts * (n_buckets + 1) * sizeof(int32_t));
@@ -809,6 +825,12 @@ extern "C" int32_t legion_pool_uses_table(const LegionMemoryPool* p_)
 }
 
 // 0 direct uint32[N] array, 1 compact table, 2 lds (no per-vertex state)
+extern "C" int32_t legion_pool_lds_buckets(const LegionMemoryPool* p_)
+{
+    const MemoryPool* p = reinterpret_cast<const MemoryPool*>(p_);
+    return (p && p->lds_form) ? (1 << p->lds_bucket_bits) : 0;
+}
+
 extern "C" int32_t legion_pool_dedup_form(const LegionMemoryPool* p_)
 {
     const MemoryPool* mp = reinterpret_cast<const MemoryPool*>(p_);

@@ -281,6 +281,10 @@ class MemoryPool:
         """'direct', 'table' or 'lds' (legion_hip.h: legion_pool_dedup_form)."""
         return ("direct", "table", "lds")[int(self._lib.legion_pool_dedup_form(self.handle))]
 
+    def lds_buckets(self):
+        """Hash buckets per lane of the lds form (8, 16, 64, 256), 0 for the other forms."""
+        return int(self._lib.legion_pool_lds_buckets(self.handle))
+
     def state_bytes(self):
         return int(self._lib.legion_pool_state_bytes(self.handle))
 

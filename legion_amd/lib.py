@@ -42,6 +42,7 @@ SIGNATURES = {
     "legion_pool_destroy": (None, [c_p]),
     "legion_pool_uses_table": (c_i32, [c_p]),
     "legion_pool_dedup_form": (c_i32, [c_p]),
+    "legion_pool_lds_buckets": (c_i32, [c_p]),
     "legion_pool_state_bytes": (c_i64, [c_p]),
     "legion_pool_error": (c_i32, [c_p]),
     "legion_cache_create": (c_p, [c_i64, c_i32, c_i32, c_i32, c_i32]),
@@ -134,7 +135,7 @@ class LinkCounters(ctypes.Structure):          # LegionLinkCounters
 
 class Tuning(ctypes.Structure):                # LegionTuning (include/legion_hip.h section 6)
     _fields_ = [(n, c_i32) for n in (
-        "dedup_form", "pos_value_bits", "pos_table_bits", "lds_known_cap", "lds_part_wg", "sample_max_wg",
+        "dedup_form", "pos_value_bits", "pos_table_bits", "lds_known_cap", "lds_part_wg", "lds_small_buckets", "sample_max_wg",
         "gather_small_tiles", "gather_rows_per_wg", "col_slots", "split_sampler_cus", "split_priority", "runner_graph", "runner_lanes",
         "runner_pair", "runner_ho_stream", "runner_stats", "table_placement", "shm_mirror", "link_counters")] + \
         [("link_counter_values", c_u64 * 2)]

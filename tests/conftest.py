@@ -45,13 +45,17 @@ def hip():
     return L
 
 
-@pytest.fixture(params=["direct", "table", "lds"])
+@pytest.fixture(params=["direct", "table", "lds", "lds-16-buckets"])
 def dedup(request, monkeypatch):
     """Runs a GPU test once per form of the first-touch state (legion_core.h): the direct uint32[N] array, the compact
-    open-addressing table, and the LDS form (no per-vertex state; pools whose largest hop exceeds 2^19 slots fall back to
-    the table).  All must give bit-identical batches."""
-    monkeypatch.setenv("LEGION_DEDUP", request.param)
-    return request.param
+    open-addressing table, and the LDS form (no per-vertex state) -- the latter with the small class's 8 and with its 16
+    hash buckets per lane (LegionTuning.lds_small_buckets; classes of larger hops have 64 / 256 either way).  All must give
+    bit-identical batches.  Returns the form's name as MemoryPool.dedup_form() reports it."""
+    form = request.param.split("-")[0]
+    monkeypatch.setenv("LEGION_DEDUP", form)
+    if request.param.endswith("16-buckets"):
+        monkeypatch.setenv("LEGION_LDS_SMALL_BUCKETS", "16")
+    return form
 
 
 @pytest.fixture(params=["0", "1"], ids=["no-column-slots", "column-slots"])

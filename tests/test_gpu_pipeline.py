@@ -331,6 +331,37 @@ def test_hot_row_replica_keeps_results_and_saves_peer_reads(hip, P, mode_bits, c
     gpu.close(); cpu.close()
 
 
+def test_lds_small_class_picks_16_buckets_on_a_dense_graph(hip, monkeypatch):
+    """The small class of the LDS form has 8 or 16 hash buckets per lane; slots say how large a hop CAN get, PreSC says how many
+    of them held an edge.  A pipeline created after PreSC on a DENSE graph (every slot of the last hop valid: more claims than 8
+    buckets take in one pass) gets 16 buckets, the same shape on a sparse graph 8 -- and both serve what the oracle serves."""
+    from legion_amd import engine
+    from oracle import ffi
+    monkeypatch.setenv("LEGION_DEDUP", "lds")
+    monkeypatch.delenv("LEGION_LDS_SMALL_BUCKETS", raising=False)
+    fanout, batch = [25, 10], 512                                   # hop 2: up to 128 k slots per lane
+    for scale, ef, want in ((14, 64, 16), (16, 2, 8)):              # mean degree 64: nearly every slot valid; 2: few are
+        wl = Workload(scale=scale, edge_factor=ef, dim=4, n_seeds=4 * batch)
+        gpu, cpu = GpuSide(wl, batch, fanout), CpuSide(wl, batch, fanout)
+        assert gpu.pools[0].lds_buckets() == 8                      # created before PreSC: nothing known yet
+        for it in range(2):                                         # PreSC: the controller records the last hop's maxima
+            g, c = gpu.run(0, it, 0, is_presc=True), cpu.run(0, it, 0, is_presc=True)
+            compare_batches(g, c, f"presc {it}: ")
+        last_edges, before = int(g["edge_counter"][11] - g["edge_counter"][10]), int(g["node_counter"][10])
+        assert ((last_edges + before) * 11 // 10 // 8 > 7168) == (want == 16), (last_edges, before)    # (storage.hip's rule)
+        gpu.cache.candidate_selection(0, gpu.graph)
+        gpu.cache.set_capacity(64, 8)
+        gpu.cache.fill_up(gpu.feature, gpu.graph)
+        cpu.build_cache(0, capacity=(64, 8))
+        pipe = engine.Pipeline(gpu.graph, gpu.feature, gpu.cache, 0, batch, fanout, 2, ffi.num_ids_for(batch, fanout), True, 2)
+        assert pipe.pools[0][0].dedup_form() == "lds" and pipe.pools[0][0].lds_buckets() == want
+        slot = pipe.submit(0)
+        pipe.wait(slot)
+        for lane in range(2):
+            compare_batches(engine.read_batch(pipe.pools[slot][lane]), cpu.run(0, lane, 0), f"scale {scale} lane {lane}: ")
+        pipe.close(); gpu.close(); cpu.close()
+
+
 def test_lds_dedup_multi_pass_buckets(hip, monkeypatch):
     """The LDS form when a bucket's vertices do not fit its table: batches of up to ~100 k claims per lane make every
     (lane, bucket) workgroup run 2-4 passes over sub-buckets; still bit-exact, no error raised.  Also a graph with hubs
