@@ -339,7 +339,9 @@ __device__ __forceinline__ HopGeom hop_geometry(const SampleArgs& a)
 #ifndef LG_SAMPLE_SGPRS
 #define LG_SAMPLE_SGPRS 80           // 8 workgroups of 256 threads per CU need <= 80 SGPRs (MI355X_MICROARCH.md, residency); 90-106 give 6-7
 #endif
-template <int FORM, int BB, bool SINGLE>      // 0 direct array, 1 table, 2 lds with 2^BB buckets per lane; SINGLE: partition tile = super tile
+// LATER (with !SINGLE): the kernel stops after its first sweep -- neighbours in slot_dst, the partition tile's bucket offsets in
+// run_off -- and place_kernel writes the pairs (see there)
+template <int FORM, int BB, bool SINGLE, bool LATER = false>      // 0 direct array, 1 table, 2 lds with 2^BB buckets per lane; SINGLE: partition tile = super tile
 __global__ __launch_bounds__(LG_TILE) __attribute__((amdgpu_num_sgpr(LG_SAMPLE_SGPRS))) void sample_kernel(HopParams hp, const LanePtrs* __restrict__ lanes)
 {
     constexpr bool TABLE = FORM == 1;
@@ -554,7 +556,7 @@ __global__ __launch_bounds__(LG_TILE) __attribute__((amdgpu_num_sgpr(LG_SAMPLE_S
             }
             __syncthreads();
             if (tid < NB) a.run_off[(int64_t)m * (NB + 1) + tid] = s_base + s_boff[tid];
-            for (int32_t sub = 0; sub < K; sub++) {
+            for (int32_t sub = 0; sub < (LATER ? 0 : K); sub++) {
                 const int32_t idx0 = (m * K + sub) * LG_SUPER;
                 if (idx0 >= g.total) break;
                 int32_t d[LG_SLOTS_PER_LANE];
@@ -574,6 +576,55 @@ __global__ __launch_bounds__(LG_TILE) __attribute__((amdgpu_num_sgpr(LG_SAMPLE_S
             }
             __syncthreads();                       // the next partition tile zeroes s_bcnt
         }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// K1a (lds form, 64- and 256-bucket classes, partition tiles of at most LG_PLACE_MAX_K super tiles): the second sweep of the
+// sampling kernel as a kernel of its own.  With 64-256 buckets a wave's 64 pairs go to ~50 different runs: written straight
+// to memory they are 8-byte stores all over the partition tile's region, and the sweep cost the hop-3 launch of [15,10,5] at
+// B = 8000 as much again as its scattered column loads.  But a partition tile's pairs, grouped by bucket, form ONE
+// contiguous block of the lane's pair array: here they are ranked and staged in LDS (8 KB per super tile) and the block is
+// then streamed out, fully coalesced.  The sampling kernel keeps its occupancy for the scattered loads (no staging there);
+// this kernel reads slot_dst and writes the pairs as plain streams.
+// ------------------------------------------------------------------------------------------
+#define LG_PLACE_MAX_K 8
+template <int BB>
+__global__ __launch_bounds__(LG_TILE) void place_kernel(HopParams hp, const LanePtrs* __restrict__ lanes)
+{
+    constexpr int NB = 1 << BB;
+    extern __shared__ unsigned long long s_stage[];           // hp.lds_k * LG_SUPER pairs
+    __shared__ int32_t s_off[NB + 1], s_cnt[NB];
+    const SampleArgs a = lane_args(hp, lanes);
+    const int32_t K = hp.lds_k;
+    const HopGeom g = hop_geometry(a);
+    const int32_t tid = threadIdx.x;
+    const int32_t nparts = (g.nsuper + K - 1) / K;
+    for (int32_t m = blockIdx.x; m < nparts; m += gridDim.x) {
+        for (int32_t i = tid; i <= NB; i += LG_TILE) s_off[i] = a.run_off[(int64_t)m * (NB + 1) + i];
+        for (int32_t i = tid; i < NB; i += LG_TILE) s_cnt[i] = 0;
+        __syncthreads();
+        const int32_t base = s_off[0], tot = s_off[NB] - base;
+        for (int32_t sub = 0; sub < K; sub++) {
+            const int32_t idx0 = (m * K + sub) * LG_SUPER;
+            if (idx0 >= g.total) break;
+            int32_t d[LG_SLOTS_PER_LANE];
+#pragma unroll
+            for (int u = 0; u < LG_SLOTS_PER_LANE; u++) {
+                const int32_t idx = idx0 + u * LG_TILE + tid;
+                d[u] = idx < g.total ? a.slot_dst[idx] : -1;
+            }
+#pragma unroll
+            for (int u = 0; u < LG_SLOTS_PER_LANE; u++) {
+                if (d[u] < 0) continue;
+                const int32_t bk = (int32_t)(lg_tab_hash(d[u]) & (NB - 1));
+                const int32_t r = atomicAdd(&s_cnt[bk], 1);
+                s_stage[s_off[bk] - base + r] = ((unsigned long long)(uint32_t)d[u] << 32) | (uint32_t)(idx0 + u * LG_TILE + tid);
+            }
+        }
+        __syncthreads();
+        for (int32_t i = tid; i < tot; i += LG_TILE) a.claim_pairs[base + i] = s_stage[i];
+        __syncthreads();                           // (the next partition tile re-uses the stage and the counts)
     }
 }
 
@@ -1170,6 +1221,7 @@ void launch_random_sample(hipStream_t s, const HopParams& p, const LanePtrs* d_l
         int32_t k = k_hi > k_lo ? k_hi : k_lo;
         const int want_wg = tuning().lds_part_wg;
         while (k > k_lo && (int64_t)(max_super / k) * n_lanes < want_wg) k /= 2;
+        if (!small && k > LG_PLACE_MAX_K && k_lo <= LG_PLACE_MAX_K) k = LG_PLACE_MAX_K;     // (the staged placement takes 8 super tiles at most)
         q.lds_k = k;
         int32_t gp = (max_super + k - 1) / k;                  // one workgroup per partition tile ...
         while (gp > 16 && (int64_t)gp * n_lanes > 16384) gp = (gp + 1) / 2;  // ... within reason
@@ -1182,11 +1234,21 @@ void launch_random_sample(hipStream_t s, const HopParams& p, const LanePtrs* d_l
             hipCheckError();
             dedup_lds_kernel<LG_LDS_BITS_SMALL16><<<dim3(1 << LG_LDS_BITS_SMALL16, n_lanes), LG_DEDUP_THREADS, 0, s>>>(q, d_lanes);
         } else if (p.lds_bucket_bits == LG_LDS_BITS_MEDIUM) {
-            sample_kernel<2, LG_LDS_BITS_MEDIUM, false><<<dim3(gp, n_lanes), LG_TILE, 0, s>>>(q, d_lanes);
+            if (k <= LG_PLACE_MAX_K) {
+                sample_kernel<2, LG_LDS_BITS_MEDIUM, false, true><<<dim3(gp, n_lanes), LG_TILE, 0, s>>>(q, d_lanes);
+                hipCheckError();
+                place_kernel<LG_LDS_BITS_MEDIUM><<<dim3(gp, n_lanes), LG_TILE, (size_t)k * LG_SUPER * sizeof(unsigned long long), s>>>(q, d_lanes);
+            } else
+                sample_kernel<2, LG_LDS_BITS_MEDIUM, false><<<dim3(gp, n_lanes), LG_TILE, 0, s>>>(q, d_lanes);
             hipCheckError();
             dedup_lds_kernel<LG_LDS_BITS_MEDIUM><<<dim3(1 << LG_LDS_BITS_MEDIUM, n_lanes), LG_DEDUP_THREADS, 0, s>>>(q, d_lanes);
         } else {
-            sample_kernel<2, LG_LDS_BITS_LARGE, false><<<dim3(gp, n_lanes), LG_TILE, 0, s>>>(q, d_lanes);
+            if (k <= LG_PLACE_MAX_K) {
+                sample_kernel<2, LG_LDS_BITS_LARGE, false, true><<<dim3(gp, n_lanes), LG_TILE, 0, s>>>(q, d_lanes);
+                hipCheckError();
+                place_kernel<LG_LDS_BITS_LARGE><<<dim3(gp, n_lanes), LG_TILE, (size_t)k * LG_SUPER * sizeof(unsigned long long), s>>>(q, d_lanes);
+            } else
+                sample_kernel<2, LG_LDS_BITS_LARGE, false><<<dim3(gp, n_lanes), LG_TILE, 0, s>>>(q, d_lanes);
             hipCheckError();
             dedup_lds_kernel<LG_LDS_BITS_LARGE><<<dim3(1 << LG_LDS_BITS_LARGE, n_lanes), LG_DEDUP_THREADS, 0, s>>>(q, d_lanes);
         }
