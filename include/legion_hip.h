@@ -368,6 +368,8 @@ typedef struct LegionTuning {
                                     -1 when the column array is device memory and the copy fits a quarter of the free HBM */
     int32_t split_sampler_cus;   /* LEGION_SPLIT_SAMPLER_CUS (0 = no CU mask): CUs of the sampler stream in split mode */
     int32_t split_priority;      /* LEGION_SPLIT_PRIORITY  (1): split mode, 1 sampler stream first, 0 equal, -1 gathers first */
+    int32_t weave_priority;      /* LEGION_WEAVE_PRIORITY  (-1): weave arrangement, priority of the light stream (heads of the next group):
+                                    -1 low, 0 equal, 1 high */
     int32_t runner_graph;        /* LEGION_RUNNER_GRAPH    (1): Runner serves from lane groups + hipGraph; 0 = operator by operator */
     int32_t runner_lanes;        /* LEGION_RUNNER_LANES    (0 = min(128, 262144 / batch)): lanes of a Runner group */
     int32_t runner_pair;         /* LEGION_RUNNER_PAIR     (1): one hand-over launch for two batches when both pipe slots are free */

@@ -102,7 +102,16 @@ extern "C" LegionPipeline* legion_pipeline_create(LegionGraphStorage* graph, Leg
     // split mode with a CU partition (LEGION_SPLIT_SAMPLER_CUS = n): the sampler stream may only use n of the 256 CUs
     // (every (256/n)-th bit of the mask), the gather stream the others.  The sampler is bound by the latency of scattered
     // atomics, not by CUs; the gather needs every wave slot it can get to keep ~12 MB of loads in flight.
-    if (p->weave) HIP_CALL(hipStreamCreateWithFlags(&p->sample_stream, hipStreamNonBlocking));
+    if (p->weave) {
+        // the light stream (heads of the next group) runs at LOW priority: its dozen small kernels have the whole rest of the
+        // current group (1.6 ms for 0.2 ms of work) to finish, and at equal priority their workgroups take slots from the
+        // dominant gather whenever both have some ready (measured: 5.11-5.12 -> 5.21-5.23 G edges/s at the headline)
+        const int wp = lg::tuning().weave_priority;
+        int lo = 0, hi = 0;                                  // hi is the numerically lowest = highest priority
+        HIP_CALL(hipDeviceGetStreamPriorityRange(&lo, &hi));
+        if (wp == 0) HIP_CALL(hipStreamCreateWithFlags(&p->sample_stream, hipStreamNonBlocking))
+        else HIP_CALL(hipStreamCreateWithPriority(&p->sample_stream, hipStreamNonBlocking, wp > 0 ? hi : lo));
+    }
     std::vector<uint32_t> mask_s, mask_g;
     if (p->split) {
         const int n_cu = lg::tuning().split_sampler_cus;

@@ -45,6 +45,7 @@ void parse_env(LegionTuning& t)
     t.col_slots = env_int("LEGION_COL_SLOTS", -1);
     t.split_sampler_cus = env_int("LEGION_SPLIT_SAMPLER_CUS", 0);
     t.split_priority = env_int("LEGION_SPLIT_PRIORITY", 1);
+    t.weave_priority = env_int("LEGION_WEAVE_PRIORITY", -1);
     t.runner_graph = env_int("LEGION_RUNNER_GRAPH", 1);
     t.runner_lanes = env_int("LEGION_RUNNER_LANES", 0);
     t.runner_pair = env_int("LEGION_RUNNER_PAIR", 1);

@@ -1,10 +1,13 @@
 """LegionTuning (include/legion_hip.h section 6): one struct, filled from the LEGION_* environment by one function, or set
 by the host program.  Host-only: no GPU needed."""
 import ctypes
+import os
 
 import pytest
 
 from legion_amd import engine, lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 @pytest.fixture(autouse=True)
@@ -52,8 +55,15 @@ def test_programmatic_values_survive_until_the_environment_is_asked_again(monkey
 
 def test_struct_mirror_matches_the_header():
     """The ctypes mirror has the header's field order and size."""
-    assert ctypes.sizeof(lib.Tuning) == 19 * 4 + 4 + 16      # 19 int32, padding, 2 uint64
-    assert [n for n, _ in lib.Tuning._fields_][:3] == ["dedup_form", "pos_value_bits", "pos_table_bits"]
+    import re
+    hdr = open(os.path.join(ROOT, "include", "legion_hip.h")).read()
+    body = hdr[hdr.index("typedef struct LegionTuning {"):hdr.index("} LegionTuning;")]
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)                         # (comments may mention types)
+    fields = re.findall(r"\b(int32_t|uint64_t)\s+(\w+)(\[\d+\])?\s*;", body)
+    assert [n for _, n, _ in fields] == [n for n, _ in lib.Tuning._fields_]     # same names, same order
+    n32 = sum(1 for t, _, _ in fields if t == "int32_t")
+    assert fields[-1][0] == "uint64_t" and n32 == len(fields) - 1
+    assert ctypes.sizeof(lib.Tuning) == (n32 * 4 + 7) // 8 * 8 + 16             # int32 fields, padding to 8, 2 uint64
     assert ctypes.sizeof(lib.LinkCounters) == 8 * 3 + 8 * 16 + 8 + 32
 
 
