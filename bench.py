@@ -5,7 +5,7 @@
     (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
 
 A "step" is ONE LAUNCH GROUP through the whole hot path on one GPU: `batches_per_step` (= --group,
-default 128 at B = 1024) independent mini-batches, each seed batch -> 2-hop sampling [25,10] -> per-hop
+default 512 at B = 1024) independent mini-batches, each seed batch -> 2-hop sampling [25,10] -> per-hop
 feature-cache lookup + gather -> end-of-batch clean-up (the op order of the reference's
 GPURunner::RunOnce, SS/engine/server.cu:302-332), served by one hipGraph replay, inputs resident in HBM.
 The timed region is exactly K steps between barrier + synchronize brackets; because K steps of ~1 ms are
@@ -13,7 +13,7 @@ far too short to time (launch latency, clock ramp), the same region is repeated 
 GPU work have been timed and the MEDIAN region (max over ranks per repeat) gives `value`.
 Workload: synthetic RMAT-26 (N = 2^26, E = 2^30), float32[N x 128] counter-hash
 features, B = 1024, seeds = a seeded permutation, GPU p of P takes seeds with id % P == p.
-Mini-batches are served in groups: every kernel launch covers --group (default 262144 / B, at most 256) independent
+Mini-batches are served in groups: every kernel launch covers --group (default 524288 / B, at most 512) independent
 batches (grid.y = lanes) and a group's op list is one hipGraph replay (legion_amd/csrc/pipeline.hip).
 
 One process per GPU.  The path shards by seeds with no per-batch exchange; the only collective is
@@ -125,7 +125,8 @@ def parse_args():
     ap.add_argument("--cpu-seconds", type=float, default=16.0,
                     help="target time of EACH CPU-baseline leg (Legion-semantics port, DGL-semantics port); 0 disables")
     ap.add_argument("--group", type=int, default=0,
-                    help="mini-batches served by every launch (lanes of a group); 0 = 262144 // batch, at most 256")
+                    help="mini-batches served by every launch (lanes of a group); 0 = 524288 // batch rounded down to a power of "
+                         "two, at most 512, halved while the lanes in flight would not fit 0.7 of the free HBM")
     ap.add_argument("--slots", type=int, default=2, help="groups in flight per GPU")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
     ap.add_argument("--overlap", action="store_true", help="let kernels of different slots share the GPU")
@@ -212,8 +213,6 @@ def main():
     c.N = N = args.nodes if args.nodes > 0 else 1 << args.scale
     c.D = D = args.dim
     c.B = B = args.batch
-    c.G = G = args.group if args.group > 0 else max(1, min(256, 262144 // B))   # mini-batches per step (launch group)
-    c.n_warm, c.n_timed = args.warmup * G, args.steps * G                      # in mini-batches
     c.t_setup = time.time()
 
     # ---- workload, resident in HBM --------------------------------------------------------------
@@ -245,6 +244,28 @@ def main():
     else:
         features = synth.features_device(N, D, 7, dev)
     c.indptr, c.col, c.features = indptr, col, features
+    # mini-batches per step (launch group): 524288 // B rounded down to a power of two, at most 512 (512 at B = 1024, 64 at
+    # B = 8000) -- measured on one box: 128 / 256 / 512 / 1024 lanes 5.04 / 5.27 / 5.43-5.52 / 5.52-5.56 G edges/s at B = 1024,
+    # 32 / 64 lanes 5.67 / 5.83 G at B = 8000 -- halved while the lanes of all groups in flight would take more than 0.7
+    # of the HBM that the tables left free
+    if args.group > 0:
+        G = args.group
+    else:
+        G = 1
+        while G * 2 <= 512 and G * 2 * B <= 524288:
+            G *= 2
+        num_ids, per = B, B
+        for f in c.fanout:
+            per *= f
+            num_ids += per
+        lane_bytes = num_ids * 56 + per * 28 + (num_ids // (8 if c.H <= 2 else 16)) * D * 4   # ids / edges / headers, slot arrays, feature rows (1.2 x the unique nodes: ~1/8 of num_ids at two hops, less beyond)
+        free_t = torch.tensor([torch.cuda.mem_get_info(dev)[0]], dtype=torch.int64, device=dev)
+        if use_dist:
+            dist.all_reduce(free_t, op=dist.ReduceOp.MIN)                      # every rank takes the same group size
+        while G > 1 and G * args.slots * lane_bytes > int(free_t.item()) * 7 // 10:
+            G //= 2
+    c.G = G
+    c.n_warm, c.n_timed = args.warmup * G, args.steps * G                      # in mini-batches
     need = (c.n_warm + c.n_timed + 2) * B * world + B
     need = max(need, (args.presc_steps + 2) * B * world)
     all_seeds = synth.seed_ids(N, min(max(need * 2, N // 10), N), 11)
