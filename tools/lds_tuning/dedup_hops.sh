@@ -1,5 +1,5 @@
 #!/bin/bash
-# duration of every sampler kernel by launch order inside a group (hop 1 and hop 2 share a grid for some of them)
+# duration of every kernel of a launch group by launch order (hop 1 and hop 2 share a grid for some of them); one stream (--no-weave)
 R=$GRAFT_REPO_ROOT
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/px_h
@@ -14,12 +14,11 @@ starts = [i for i, r in enumerate(rows) if 'batch_generate' in r[1]]
 seq = collections.defaultdict(list)
 for a, b in zip(starts[-40:-1], starts[-39:]):
     for j, r in enumerate(rows[a:b]):
-        gap = (r[4] - rows[a + j - 1][5]) / 1e3 if j else 0.0
-        seq[(j, r[1])].append((r[3], gap))
+        seq[(j, r[1])].append(r[3])
 tot = 0
 for (j, name), v in sorted(seq.items()):
-    d = sorted(x[0] for x in v); g = sorted(x[1] for x in v)
-    print(f"{j:2d} {name:42s} n={len(v):3d} median {d[len(d)//2]:8.1f} us   gap before {g[len(g)//2]:6.1f} us")
-    tot += d[len(d)//2] + g[len(g)//2]
-print("sum of medians + gaps %.1f us" % tot)
+    d = sorted(v)
+    print(f"{j:2d} {name:44s} n={len(v):3d} median {d[len(d)//2]:8.1f} us")
+    tot += d[len(d)//2]
+print("sum of medians %.1f us" % tot)
 PY
