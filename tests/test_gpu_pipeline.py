@@ -215,6 +215,34 @@ def test_pipeline_groups_and_graph_replay(hip, dedup, group, slots, use_graph, s
     gpu.close(); cpu.close()
 
 
+@pytest.mark.parametrize("batch,fanout,group", [(1024, [25, 10], 128), (2000, [15, 10, 5], 16)])
+def test_full_width_groups_against_the_oracle(hip, batch, fanout, group):
+    """The headline's own geometry -- B = 1024, [25,10], lane groups wide enough to keep every XCD busy, the weave arrangement
+    under hipGraph replay, the default (LDS) form -- with EVERY lane of two consecutive groups compared with the oracle: the
+    ticketed tiles and the decoupled look-back of compact_kernel, the winners' published positions and the software-pipelined
+    gather under the concurrency they run with in the bench (250 super tiles per lane at hop 2, 128 lanes in flight).  The
+    second shape has three hops in the 64-bucket class (staged placement, known lists across two hops)."""
+    from legion_amd import engine
+    wl = Workload(scale=19, edge_factor=16, dim=16, n_seeds=2 * group * batch + batch)
+    gpu, cpu = GpuSide(wl, batch, fanout), CpuSide(wl, batch, fanout)
+    for it in range(2):
+        gpu.run(0, it, 0, is_presc=True); cpu.run(0, it, 0, is_presc=True)
+    gpu.cache.candidate_selection(0, gpu.graph)
+    gpu.cache.set_capacity(20_000, 2_000)
+    gpu.cache.fill_up(gpu.feature, gpu.graph)
+    cpu.build_cache(0, capacity=(20_000, 2_000))
+    pipe = engine.Pipeline(gpu.graph, gpu.feature, gpu.cache, 0, batch, fanout, group, gpu.pools[0].num_ids, True, 2, weave=True)
+    assert pipe.pools[0][0].dedup_form() == "lds"
+    slots = [pipe.submit(0, 0), pipe.submit(group, 0)]
+    for gi, sl in enumerate(slots):
+        pipe.wait(sl)
+        for lane in range(group):
+            compare_batches(engine.read_batch(pipe.pools[sl][lane]), cpu.run(0, gi * group + lane, 0), f"group {gi} lane {lane}: ")
+            assert pipe.pools[sl][lane].error() == 0
+    pipe.close()
+    gpu.close(); cpu.close()
+
+
 def test_lane_group_eager(hip, dedup):
     """legion_enqueue_group on caller-owned pools (no pipeline, no graph)."""
     from legion_amd import engine
