@@ -21,3 +21,6 @@ run uk_union_size_d256_b8000 --nodes 133633040 --edges 5507679822 --dim 256 --ba
 LEGION_COL_SLOTS=1 run uk_union_size_d256_b8000_column_slots --nodes 133633040 --edges 5507679822 --dim 256 --batch 8000
 run papers100m_size_3hop_pinned --nodes 111059956 --edges 1615685872 --dim 128 --batch 8000 --fanout 15,10,5 --placement pinned --link-counters smi
 run papers100m_size_3hop_hbm --nodes 111059956 --edges 1615685872 --dim 128 --batch 8000 --fanout 15,10,5
+# configs[4]'s graph on one GPU: RMAT-28 (N = 2^28, edge factor 4), [15,10,5], B = 8000 -- with D = 128 (the 256-wide table of 2^28 rows
+# is 275 GB and exists only striped over eight GPUs)
+run rmat28_ef4_d128_3hop --scale 28 --edge-factor 4 --dim 128 --batch 8000 --fanout 15,10,5
