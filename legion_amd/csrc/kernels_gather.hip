@@ -293,13 +293,17 @@ static void launch_gather_impl(hipStream_t s, GatherParams g, const LanePtrs* d_
         // rows per workgroup (LegionTuning.gather_rows_per_wg; 0 = the default below).  A launch of one or a few lanes (the
         // Runner's per-batch hand-over) has too few 64-row tiles to keep 256 CUs busy: 16-row tiles give it 4 x the
         // workgroups; a full lane group is indifferent to the tile size at D = 128
-        // Default for a full group: the tile whose payload is 32 KB (measured, profiles/r03/gather_experiments.txt: D = 256 with
-        // 32 rows 0.758 of peak against 0.727 with 64 and 0.720 with 128; D = 64 with 128 rows 0.710 against 0.685 with 64;
-        // D = 128 with 64 or 128 rows 0.776 / 0.777, with 32 rows 0.751)
+        // Default for a full group, early in round 3 (one tile per workgroup, 256-lane groups, profiles/r03/gather_experiments.txt): the
+        // tile whose payload is 32 KB -- D = 256 with 32 rows 0.758 of peak against 0.727 with 64; D = 64 with 128 rows 0.710 against
+        // 0.685 with 64; D = 128 with 64 or 128 rows 0.776 / 0.777, with 32 rows 0.751.  Re-measured at the end of the round: below
         int rows = tune.gather_rows_per_wg;
         if (rows <= 0) {
             rows = 16;
-            while (rows < 256 && (int64_t)rows * 2 * g.D * 4 <= 32768 + 8192) rows *= 2;       // D = 100 -> 64, D = 602 -> 16
+            // (round 3, with the pipelined walk and 512-lane groups: 16 KB of payload for rows of 512 bytes and more -- 32 rows at
+            // D = 128: the same at the headline, +1.4 % at B = 8000, +2...3 % on the cold three-hop shapes; D = 256 with 16 rows
+            // +1 % -- and 32 KB below that: D = 64 with 128 rows 8.31 G edges/s, with 64 rows 8.17 G)
+            const int64_t payload = g.D * 4 >= 512 ? 16384 : 32768;
+            while (rows < 256 && (int64_t)rows * 2 * g.D * 4 <= payload + payload / 4) rows *= 2;       // D = 100 -> 64, D = 128 -> 32, D = 256 -> 16
             if (tune.gather_small_tiles && (int64_t)((g.max_rows + rows - 1) / rows) * n_lanes < 4096) rows = 16;
         }
         switch (rows) {
