@@ -472,13 +472,26 @@ void UnifiedCache::LastHopMax(int32_t dev_id, int32_t out[2])
         static_cast<PreSCCacheController*>(cache_controller_[dev_id])->LastHopMax(out);
 }
 
+void UnifiedCache::SetGatherStats(bool on)
+{
+    gather_stats_on_ = on;
+    const unsigned long long v = on ? 1ull : 0ull;
+    for (size_t dvc = 0; dvc < gather_stats_.size(); dvc++) {
+        if (gather_stats_[dvc] == nullptr) continue;
+        SetGPUDevice((int32_t)dvc);
+        HIP_CALL(hipDeviceSynchronize());                 // (launches in flight keep the value they started with)
+        HIP_CALL(hipMemcpy(gather_stats_[dvc] + 3, &v, sizeof(v), hipMemcpyHostToDevice));
+    }
+}
+
 unsigned long long* UnifiedCache::GatherStats(int32_t dev_id)
 {
     if ((int32_t)gather_stats_.size() < device_count_) gather_stats_.resize(device_count_, nullptr);
     if (gather_stats_[dev_id] == nullptr) {
         SetGPUDevice(dev_id);
         gather_stats_[dev_id] = (unsigned long long*)d_alloc_space(4 * sizeof(unsigned long long));
-        HIP_CALL(hipMemset(gather_stats_[dev_id], 0, 4 * sizeof(unsigned long long)));
+        const unsigned long long init[4] = {0, 0, 0, gather_stats_on_ ? 1ull : 0ull};     // [3]: the device-side switch
+        HIP_CALL(hipMemcpy(gather_stats_[dev_id], init, sizeof(init), hipMemcpyHostToDevice));
     }
     return gather_stats_[dev_id];
 }
@@ -501,7 +514,7 @@ void UnifiedCache::FeatCacheLookup(const LanePtrs* d_lanes, int32_t n_lanes, int
     g.Kg = Kg_;
     g.member = dev_id % (Kg_ > 0 ? Kg_ : 1);
     g.striped = Kg_ > 1;
-    g.stats = (gather_stats_on_ && dev_id < (int32_t)gather_stats_.size()) ? gather_stats_[dev_id] : nullptr;
+    g.stats = dev_id < (int32_t)gather_stats_.size() ? gather_stats_[dev_id] : nullptr;      // (armed or not: the kernel reads stats[3])
     g.full_table = cpu_float_features_;
     g.cache_tables = filled ? d_float_feature_cache_ptr_[dev_id] : nullptr;
     g.local_table = filled ? float_feature_cache_[dev_id] : nullptr;
@@ -551,7 +564,7 @@ extern "C" void legion_cache_gather_stats(LegionUnifiedCache* c, int32_t dev_id,
 // counting costs the gather an atomic per hit row: a measurement switches it off again before anything is timed
 extern "C" void legion_cache_gather_stats_enable(LegionUnifiedCache* c, int32_t on)
 {
-    if (UnifiedCache* u = as_cache(c)) u->gather_stats_on_ = on != 0;
+    if (UnifiedCache* u = as_cache(c)) u->SetGatherStats(on != 0);
 }
 
 extern "C" void legion_cache_gather_stats3(LegionUnifiedCache* c, int32_t dev_id, uint64_t* out3)

@@ -148,6 +148,9 @@ __global__ __launch_bounds__(LG_GATHER_THREADS, LG_GATHER_MIN_WAVES) void gather
     int32_t tile = blockIdx.x;
     if (tile >= ntiles) return;                        // (surplus workgroups of a short lane)
 
+    // row-source statistics: armed by the host (UnifiedCache::GatherStats) and switched by a DEVICE word, so that a launch
+    // captured in a hipGraph follows the switch too (a pointer baked in at capture time kept counting through every replay)
+    const bool counting = gp.stats != nullptr && gp.Kg > 1 && gp.stats[3] != 0ull;
     // a row's source: FindFeat (cache.cu:180-215) + the address arithmetic of cache_impl.cuh:259-268
     auto source_of = [&](int32_t id, int32_t g) -> const LG_G float* {
         const LG_G float* p = nullptr;
@@ -165,9 +168,15 @@ __global__ __launch_bounds__(LG_GATHER_THREADS, LG_GATHER_MIN_WAVES) void gather
                 p = LG_GPTR(const float, gp.local_table) + (int64_t)fidx * D;
             else
                 p = LG_GPTR(const float, gp.cache_tables[didx]) + (int64_t)fidx * D;                               // :268
-            if (gp.stats != nullptr && gp.Kg > 1) {    // tests / diagnostics / the computed xGMI count: [0] rows read through a stripe
-                atomicAdd(gp.stats + (local_copy ? 1 : 0), 1ull);   // pointer, [1] from the replica, [2] the part of [0] from a peer's stripe
-                if (!local_copy && didx != gp.member) atomicAdd(gp.stats + 2, 1ull);
+            if (counting) {    // tests / diagnostics / the computed xGMI count: [0] rows read through a stripe pointer, [1] from the
+                               // replica, [2] the part of [0] from a peer's stripe -- one atomic per wave and counter
+                const unsigned long long m_rep = __ballot(local_copy), m_str = __ballot(!local_copy);
+                const unsigned long long m_peer = __ballot(!local_copy && didx != gp.member);
+                if ((int)(threadIdx.x & 63) == __ffsll((unsigned long long)(m_rep | m_str)) - 1) {
+                    if (m_str) atomicAdd(gp.stats + 0, (unsigned long long)__popcll(m_str));
+                    if (m_rep) atomicAdd(gp.stats + 1, (unsigned long long)__popcll(m_rep));
+                    if (m_peer) atomicAdd(gp.stats + 2, (unsigned long long)__popcll(m_peer));
+                }
             }
         }
         return p;

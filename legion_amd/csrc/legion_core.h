@@ -502,7 +502,8 @@ public:
     void SetReplicaMemory(int64_t bytes) { replica_bytes_ = bytes; }
     int32_t ReplicaRows(int32_t dev_id) const { return replica_rows_.empty() ? 0 : replica_rows_[dev_id]; }
     int32_t FloatFeatureLen() const { return float_feature_len_; }
-    bool gather_stats_on_ = true;        // GatherStats() arms the counters; this pauses them (legion_cache_gather_stats_enable)
+    bool gather_stats_on_ = true;        // GatherStats() arms the counters; SetGatherStats pauses them (a device word: graphs follow)
+    void SetGatherStats(bool on);
     unsigned long long* GatherStats(int32_t dev_id);   // device {stripe rows, replica rows, peer-stripe rows}, allocated on first use
     int32_t MaxIdNum(int32_t dev_id);
     void LastHopMax(int32_t dev_id, int32_t out[2]);   // PreSC maxima {edges of the last hop, nodes before it}; {0, 0} before PreSC
