@@ -15,8 +15,10 @@ SHAPES[3hop_15_10_5_b8000]="--batch 8000 --fanout 15,10,5"
 SHAPES[products_d100]="--scale 21 --edge-factor 29 --dim 100"
 SHAPES[d64]="--dim 64"
 SHAPES[d602_rmat22]="--scale 22 --dim 602"
+SHAPES[papers100m_size_3hop]="--nodes 111059956 --edges 1615685872 --batch 8000 --fanout 15,10,5 --group 8"
+SHAPES[uk_union_size_d256]="--nodes 133633040 --edges 5507679822 --dim 256 --batch 8000 --group 8"
 LIST="$@"
-[ -z "$LIST" ] && LIST="headline d256_b8000 3hop_15_10_5_b8000 products_d100 d64"
+[ -z "$LIST" ] && LIST="headline d256_b8000 3hop_15_10_5_b8000 products_d100 d64 papers100m_size_3hop uk_union_size_d256"
 GROUPS_PMC=(
  "FETCH_SIZE"
  "WRITE_SIZE"
