@@ -148,6 +148,8 @@ def parse_args():
     ap.add_argument("--no-boundary", action="store_true",
                     help="skip the drop-in boundary leg (sampling_server binary -> shm/semaphores/IPC handles -> ipc_service "
                          "consumer on an RMAT-22 data set written in the reference's file formats; N = 1 only, ~15 s)")
+    ap.add_argument("--boundary-batches", type=int, default=40000,
+                    help="boundary leg: timed batches per server run at least (the server runs as many epochs as that takes)")
     ap.add_argument("--measured-counters", action="store_true", help="same as --link-counters computed")
     ap.add_argument("--link-counters", type=str, default="v2", choices=["v2", "computed", "smi"],
                     help="what feeds CostModel's PCIe transaction counters: v2 = {0,0} as the reference's v2 does; computed = the "
@@ -760,20 +762,31 @@ def boundary_leg(args, fanout):
         note = f"/tmp has {free >> 20} MiB free, the RMAT-{scale} data set needs {need >> 20}: boundary leg run at RMAT-22 instead"
         scale = min(scale, 22)
     batches = [args.batch] + ([8000] if args.batch != 8000 else [])
+    # three ways a batch reaches the trainer end (LegionTuning.runner_handover, server.hip): `views` -- whole launch groups into
+    # the server's lane arena, this build's ipc_service takes every batch as views of its lane: what a user of legion_graphsage.py
+    # gets; `copy` -- the same pipeline serving a trainer end that knows only the reference's slab: one copy launch per batch into
+    # the pipe slot; `gather` -- round 3's path, one gather launch per batch straight into the pipe slot
     cmd = [sys.executable, os.path.join(ROOT, "tools", "server_throughput.py"), "--scale", str(scale), "--edge-factor", str(args.edge_factor),
            "--batch", ",".join(str(b) for b in batches), "--dim", str(args.dim), "--fanout", ",".join(str(f) for f in fanout),
-           "--train-batches", str(max(64, min(3000, (3 << 20) // args.batch))), "--no-features-file", "--cache-memory", str(args.cache_memory)]
+           "--train-batches", str(max(64, min(3000, (3 << 20) // args.batch))), "--no-features-file", "--cache-memory", str(args.cache_memory),
+           "--modes", "views,copy,gather", "--min-timed-batches", str(args.boundary_batches), "--watchdog", "800"]
     try:
-        res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+        res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=1200)
         lines = [json.loads(ln) for ln in res.stdout.splitlines() if ln.startswith("{")]
         if not lines:
             raise RuntimeError(res.stderr[-300:])
-        legs = [{"batch": r["batch"], "batches_per_sec": r["batches_per_sec"], "edges_per_sec": r["edges_per_sec"], "path": r["path"],
-                 "workload": r["workload"], "ms_per_batch": r["ms_per_batch"], "timed_batches": r["timed_batches"]} for r in lines]
+        legs = [{"mode": r.get("mode"), "batch": r["batch"], "batches_per_sec": r["batches_per_sec"], "edges_per_sec": r["edges_per_sec"],
+                 "handover": r.get("handover"), "path": r["path"], "workload": r["workload"], "ms_per_batch": r["ms_per_batch"],
+                 "timed_batches": r["timed_batches"], "epochs": r.get("epochs")} for r in lines]
         first = legs[0]
         out = {"boundary_batches_per_sec": first["batches_per_sec"], "boundary_edges_per_sec": first["edges_per_sec"],
                "boundary": {"path": first["path"], "workload": first["workload"], "ms_per_batch": first["ms_per_batch"],
-                            "timed_batches": first["timed_batches"], "by_batch_size": legs}}
+                            "timed_batches": first["timed_batches"], "handover": first["handover"],
+                            "by_batch_size": [l for l in legs if l["mode"] == "views"],
+                            "slab_only_trainer": {"note": "a trainer end that opens only the reference's slab (no views of the lane arena): "
+                                                          "the batch is copied (`copy`) or gathered (`gather`, LEGION_RUNNER_HANDOVER=gather) "
+                                                          "into the pipe slot by one launch per batch, two slots in flight",
+                                                  "by_batch_size": [l for l in legs if l["mode"] != "views"]}}}
         if note:
             out["boundary"]["note"] = note
         return out

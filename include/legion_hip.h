@@ -375,6 +375,20 @@ typedef struct LegionTuning {
     int32_t runner_pair;         /* LEGION_RUNNER_PAIR     (1): one hand-over launch for two batches when both pipe slots are free */
     int32_t runner_ho_stream;    /* LEGION_RUNNER_HO_STREAM (2): hand-over streams: 0 the sampler's, 1 one shared, 2 one per pipe slot */
     int32_t runner_stats;        /* LEGION_RUNNER_STATS    (0): print where a hand-over's time went at Finalize */
+    int32_t runner_handover;     /* LEGION_RUNNER_HANDOVER=auto|gather|copy -> 0|1|2: how the Runner's batches reach a trainer.  auto: whole
+                                    launch groups (sampler + full-width gathers) into per-lane buffers of one exported arena; a trainer end
+                                    that opened the arena gets a batch as VIEWS of its lane (no per-batch GPU work), any other gets a copy in
+                                    the pipe slot.  copy: the same pipeline, always copied.  gather: round 3's path (sampler phase in groups,
+                                    one gather launch per batch straight into the pipe slot) */
+    int32_t peer_gather;         /* LEGION_PEER_GATHER=direct|bulk -> 0|1: rows of OTHER members' stripes of a striped feature cache are
+                                    read by direct peer loads, or pulled owner by owner in bulk (hipMemcpyPeerAsync) */
+    int32_t feature_pitch;       /* LEGION_FEATURE_PITCH=auto|dense|aligned -> -1|0|1: row pitch of the HBM-resident feature cache; aligned =
+                                    rounded up to 128 bytes (a 400-byte row then touches 4 cache lines, never 5), auto = aligned when it
+                                    costs at most 1/8 more memory */
+    int32_t hotness_reduce;      /* LEGION_HOTNESS_REDUCE=auto|p2p|rccl -> -1|0|1: the clique sum of the access counters: rccl = all-reduce
+                                    over the server's distinct physical GPUs, p2p = the reference's leader loop over peer pointers
+                                    (SS/cache/cache.cu:408-411); auto = rccl when the members sit on distinct physical GPUs */
+    int32_t markers;             /* LEGION_MARKERS         (1): roctx ranges around ops and launch groups (visible to rocprofv3 --marker-trace) */
     int32_t table_placement;     /* LEGION_TABLE_PLACEMENT=hbm|pinned -> 0|1: where the server puts the full CSR / feature table */
     int32_t shm_mirror;          /* LEGION_NO_SHM_MIRROR unset -> 1: counters also go to a host-visible mirror (no D2H copy per batch) */
     int32_t link_counters;       /* LEGION_LINK_COUNTERS=v2|measured|smi|"a,b" -> 0|1|2|3: what feeds CostModel's counters */

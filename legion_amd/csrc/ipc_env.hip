@@ -37,11 +37,25 @@ typedef struct shmStruct_st {
 } shmStruct;
 static_assert(offsetof(shmStruct, memHandle) == 12 && sizeof(shmStruct) == 12 + MAX_DEVICE * INTERBATCH_CON * MEMORY_USAGE * 64,
               "the reference's slab layout is the wire format");
+// Version 2 of the object (round 4) adds the "direct view" hand-over.  The server produces mini-batches in launch groups
+// into per-lane buffers (server.hip) that all live in ONE device allocation per GPU, the lane arena; its IPC handle is
+// published here.  A trainer end that can open it (this build's ipc_service) says so in trainer_direct[dev] BEFORE its first
+// sem_post; from then on a hand-over is no GPU work at all: the server writes, per (device, pipe slot), where the five
+// trainer-visible arrays of the batch start inside the arena and posts sem_w -- same semaphores, same two-slot order, and
+// the reference-sized slab above stays valid for a trainer that knows nothing of this (it gets copies in the slot buffers).
 typedef struct shmExt_st {
     int32_t ext_magic;                                         // LEGION_SHM_EXT_MAGIC once the mirror below is live
-    int32_t ext_reserved[3];
+    int32_t ext_version;                                       // 2: the fields behind `counters` exist
+    int32_t server_state;                                      // 0 serving, 1 the server stopped on an error (trainers must not wait)
+    int32_t ext_reserved;
     int32_t counters[MAX_DEVICE][INTERBATCH_CON][32];          // [0..15] node_counter, [16..31] edge_counter
+    hipIpcMemHandle_t arena[MAX_DEVICE];                       // lane arena of each server GPU, valid when arena_bytes > 0
+    int64_t arena_bytes[MAX_DEVICE];
+    int32_t trainer_direct[MAX_DEVICE];                        // written by the trainer end: 1 = it opened the arena and takes views
+    int32_t view_on[MAX_DEVICE][INTERBATCH_CON];               // 1: the batch in this slot is the view below, 0: it is in the slot's buffers
+    int64_t view[MAX_DEVICE][INTERBATCH_CON][5];               // byte offsets into the arena: ids, features, labels, agg_src, agg_dst
 } shmExt;
+#define LEGION_SHM_EXT_VERSION 2
 
 typedef struct sharedMemoryInfo_st {
     void* addr;
@@ -273,7 +287,52 @@ public:
     {
         return ext_dev_ ? &ext_dev_->counters[d][p % pipeline_depth_][0] : nullptr;
     }
-    void PublishMirror() override { if (ext_dev_) ext_->ext_magic = LEGION_SHM_EXT_MAGIC; }
+    void PublishMirror() override
+    {
+        if (!ext_dev_) return;
+        ext_->ext_version = LEGION_SHM_EXT_VERSION;
+        __sync_synchronize();
+        ext_->ext_magic = LEGION_SHM_EXT_MAGIC;
+    }
+    // ---- direct-view hand-over (see shmExt) ----
+    int32_t* HostCounterMirror(int32_t d, int32_t p) override
+    {
+        return ext_ ? (int32_t*)&ext_->counters[d][p % pipeline_depth_][0] : nullptr;
+    }
+    bool PublishArena(int32_t dev_id, void* base, int64_t bytes) override
+    {
+        if (!ext_ || !ext_dev_ || base == nullptr || bytes <= 0) return false;
+        hipIpcMemHandle_t h;
+        lg_ipc_export(&h, base, __FILE__, __LINE__);
+        memcpy((void*)&ext_->arena[dev_id], &h, sizeof(h));
+        __sync_synchronize();
+        ext_->arena_bytes[dev_id] = bytes;
+        return true;
+    }
+    bool TrainerTakesViews(int32_t dev_id) override { return ext_ && ext_->arena_bytes[dev_id] > 0 && ext_->trainer_direct[dev_id] == 1; }
+    void SetView(int32_t dev_id, int32_t pipe, const int64_t* off5, const int32_t* counters32) override
+    {
+        if (!ext_) return;
+        if (counters32) for (int i = 0; i < 32; i++) ext_->counters[dev_id][pipe][i] = counters32[i];
+        if (off5) for (int i = 0; i < 5; i++) ext_->view[dev_id][pipe][i] = off5[i];
+        ext_->view_on[dev_id][pipe] = off5 ? 1 : 0;
+    }
+    // The server stops on an error (corrupt batch): trainers blocked in sem_wait would wait for ever.  Say so where this
+    // build's trainer end looks (server_state), wake every waiter, and take the names away.
+    void AbortServing() override
+    {
+        if (ext_) ext_->server_state = 1;
+        __sync_synchronize();
+        const std::string sfx = ipc_suffix();
+        for (int32_t i = 0; i < device_count_; i++)
+            for (size_t j = 0; j < semw_[i].size(); j++) {
+                if (semw_[i][j] != nullptr && semw_[i][j] != SEM_FAILED) { sem_post(semw_[i][j]); sem_post(semw_[i][j]); }
+                sem_unlink(("sem_r_" + std::to_string(i) + "_" + std::to_string(j) + sfx).c_str());
+                sem_unlink(("sem_w_" + std::to_string(i) + "_" + std::to_string(j) + sfx).c_str());
+            }
+        if (!shm_name_.empty()) shm_unlink(shm_name_.c_str());
+        if (!ext_name_.empty()) shm_unlink(ext_name_.c_str());
+    }
     bool IPCTryWait(int32_t dev_id, int32_t current_pipe) override { return sem_trywait(semr_[dev_id][current_pipe]) == 0; }
 
     void IPCPost(int32_t dev_id, int32_t current_pipe) override { sem_post(semw_[dev_id][current_pipe]); }

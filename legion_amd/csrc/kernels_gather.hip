@@ -84,6 +84,52 @@ void launch_deliver(hipStream_t s, const LanePtrs* d_lane, const DeliverParams& 
     hipCheckError();
 }
 
+// ------------------------------------------------------------------------------------------
+// Hand-over by copy (GPURunner, "lanes" pipeline, trainer end that does not take views): the launch group has gathered the
+// lane's rows at full width into the lane's own feature buffer; this copies the finished batch -- rows and everything
+// deliver_slice moves -- into the trainer-visible pipe slot.  A pure stream: 16-byte loads, non-temporal stores, four in
+// flight per thread.  Costs the rows a second trip through HBM (2 x rows x D x 4 bytes per batch on top of the gather's).
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void handover_copy_kernel(const LanePtrs* __restrict__ lane_p, DeliverParams d)
+{
+    const LanePtrs& L = *lane_p;
+    deliver_slice(L, d, blockIdx.x, gridDim.x);
+    if (d.float_features == nullptr || L.float_features == nullptr || d.D <= 0) return;
+    const LG_G int32_t* nc = LG_GPTR(const int32_t, L.node_counter);
+    const int32_t hop_num = nc[INTRABATCH_CON * 3 - 1];
+    int32_t n = nc[INTRABATCH_CON * 3 + hop_num];
+    n = n < 0 ? 0 : n;
+    if (n > d.feature_rows) n = d.feature_rows;
+    if (n > L.feature_rows) n = L.feature_rows;
+    const int64_t words = (int64_t)n * d.D;                 // floats
+    typedef float v4 __attribute__((ext_vector_type(4)));
+    const LG_G float* src = LG_GPTR(const float, L.float_features);
+    LG_G float* dst = LG_GPTR(float, d.float_features);
+    const int64_t q = words >> 2;                           // both buffers are 256-byte aligned allocations
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    for (; i + 3 * stride < q; i += 4 * stride) {
+        v4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) v[u] = ((const LG_G v4*)src)[i + u * stride];
+#pragma unroll
+        for (int u = 0; u < 4; u++) __builtin_nontemporal_store(v[u], (LG_G v4*)dst + i + u * stride);
+    }
+    for (; i < q; i += stride) __builtin_nontemporal_store(((const LG_G v4*)src)[i], (LG_G v4*)dst + i);
+    if (blockIdx.x == 0)
+        for (int64_t k = (q << 2) + threadIdx.x; k < words; k += 256) dst[k] = src[k];
+}
+
+void launch_handover_copy(hipStream_t s, const LanePtrs* d_lane, const DeliverParams& d, int32_t max_rows)
+{
+    const int64_t bytes = (int64_t)max_rows * (d.D > 0 ? d.D : 0) * 4 + (int64_t)d.num_ids * 12;
+    int64_t grid = (bytes + 16383) / 16384;                 // ~16 KB per workgroup: 1 k workgroups for a 16 MB batch
+    if (grid > 4096) grid = 4096;
+    if (grid < 1) grid = 1;
+    handover_copy_kernel<<<(int32_t)grid, 256, 0, s>>>(d_lane, d);
+    hipCheckError();
+}
+
 // VecT: float4 for rows that are multiples of 16 bytes; `v4u` -- the same 16 bytes per lane at 4-byte alignment -- for every other
 // width of at least 4 floats (gfx950 global loads / stores of 16 bytes need dword alignment only; the compiler emits
 // global_load_dwordx4 for both), with the D % 4 trailing floats of each row moved by a scalar pass (TAIL); float below that.

@@ -102,6 +102,7 @@ struct BracketLane {
     LG_G int32_t* hop_scratch; LG_G uint32_t* position_map; LG_G int32_t* slot_mark; LG_G int32_t* node_slot;
     LG_G unsigned long long* pos_table; uint32_t pos_mask; LG_G int32_t* err_flag;
     LG_G int32_t* known_cnt; int32_t lds_buckets;
+    LG_G int32_t* counter_mirror;
     int32_t total_num_nodes, max_slots;
 };
 __device__ __forceinline__ BracketLane bracket_lane(const LanePtrs& P)
@@ -114,6 +115,7 @@ __device__ __forceinline__ BracketLane bracket_lane(const LanePtrs& P)
     L.pos_table = LG_GPTR(unsigned long long, P.pos_table); L.pos_mask = P.pos_table_mask;
     L.err_flag = LG_GPTR(int32_t, P.err_flag);
     L.known_cnt = LG_GPTR(int32_t, P.known_cnt); L.lds_buckets = P.lds_buckets;
+    L.counter_mirror = LG_GPTR(int32_t, P.counter_mirror);
     L.total_num_nodes = P.total_num_nodes; L.max_slots = P.max_slots;
     return L;
 }
@@ -1352,6 +1354,17 @@ __global__ void end_of_batch_kernel(const LanePtrs* __restrict__ lanes, int32_t*
         // the loser marks carry (epoch, hop): epochs are about to repeat
         for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < L.max_slots; i += (int64_t)gridDim.x * blockDim.x)
             L.slot_mark[i] = 0;
+    }
+    // GPURunner's lanes: the batch's counters in host-visible memory, as the trainer end will read them -- node_counter[2..3]
+    // already holding what the last gather op leaves there (counter_update(op%3==1), operator_impl.cu:83-85: the range of the
+    // last hop's new nodes), whether or not that gather has run yet.  Visible to the host once the launch group has completed.
+    if (L.counter_mirror != nullptr && blockIdx.x == 0 && threadIdx.x < 32) {
+        const int32_t t = threadIdx.x;
+        int32_t v = t < 16 ? L.node_counter[t] : L.edge_counter[t - 16];
+        const int32_t hop_num = L.node_counter[INTRABATCH_CON * 3 - 1];
+        if (t == 2 && hop_num >= 0 && hop_num <= 6) v = L.hop_scratch[HS_RANGE + 2 * hop_num];
+        if (t == 3 && hop_num >= 0 && hop_num <= 6) v = L.hop_scratch[HS_RANGE + 2 * hop_num + 1];
+        L.counter_mirror[t] = v;
     }
     __syncthreads();
     if (threadIdx.x == 0)   // no fence needed: the kernel boundary publishes the refill and the new epoch

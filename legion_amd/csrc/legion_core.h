@@ -248,6 +248,8 @@ struct LanePtrs {
     int32_t* known_cnt;                // [buckets] entries appended (may exceed known_cap: then the list is not used)
     int32_t known_cap;
     int32_t* err_flag;                 // mapped pinned host word: kernels OR LG_ERR_* bits into it
+    int32_t* counter_mirror;           // mapped pinned host int32[32] or null: the end-of-batch kernel leaves the batch's
+                                       // node_counter / edge_counter there (GPURunner's lanes: no device read-back per hand-over)
     const void* deliver;               // lg::DeliverParams* (device) or null: the gather of this lane also hands its batch
                                        // over to that trainer-visible pipe slot (GPURunner's hand-over descriptors)
     int32_t* node_counter;
@@ -336,6 +338,11 @@ public:
     int32_t* err_host = nullptr;       // host-visible error word (mapped pinned), err_dev = its device address
     int32_t* err_dev = nullptr;
     int32_t ErrorBits() const { return err_host ? *(volatile int32_t*)err_host : 0; }
+    // lanes of a GPURunner group (lg_set_pool_arena): the trainer-visible arrays live in the runner's arena (not freed
+    // here) and the counters are mirrored to host-visible memory by the end-of-batch kernel
+    bool arena_backed = false;
+    int32_t* counter_mirror_dev = nullptr;
+    int32_t* counter_mirror_host = nullptr;
     int32_t num_ids = 0;
     int32_t max_slots = 0;             // largest hop = B * f1 * ... * fH
     std::vector<int64_t> max_new;      // [h] upper bound of new nodes of op 3h (h = 0: the seeds)
@@ -574,6 +581,13 @@ public:
     virtual int32_t* GetCounterMirror(int32_t dev_id, int32_t current_pipe) = 0;
     virtual void PublishMirror() = 0;
     virtual bool IPCTryWait(int32_t dev_id, int32_t current_pipe) = 0;
+    // direct-view hand-over (round 4, ipc_env.hip shmExt): the lane arena's IPC handle, whether the trainer end of dev_id
+    // takes views of it, and the per-slot description of the batch being posted
+    virtual int32_t* HostCounterMirror(int32_t dev_id, int32_t current_pipe) = 0;
+    virtual bool PublishArena(int32_t dev_id, void* base, int64_t bytes) = 0;
+    virtual bool TrainerTakesViews(int32_t dev_id) = 0;
+    virtual void SetView(int32_t dev_id, int32_t pipe, const int64_t* off5, const int32_t* counters32) = 0;
+    virtual void AbortServing() = 0;
     virtual void Finalize() = 0;
     virtual int32_t GetTrainStep() = 0;
 };
@@ -652,6 +666,20 @@ void lg_set_pool_lanes_hint(int32_t lanes);
 // afterwards by this thread pick the small class's bucket count from it (8, or 16 where a bucket would need two passes).
 void lg_set_pool_claims_hint(int64_t last_hop_edges, int64_t nodes_before_last_hop);
 
+// Where the pools a thread is about to create put their trainer-visible arrays (sampled_ids, features, labels, agg_src_off,
+// agg_dst_off, the two counter blocks).  Default (null): one allocation each.  GPURunner sets an arena -- ONE exportable device
+// allocation for every lane of its groups, so that a trainer end can open it with a single IPC handle and take a batch as
+// views of its lane (no copy into a pipe slot) -- and a host-visible block for the lanes' counters.  Thread-local.
+struct PoolArena {
+    char* base = nullptr;
+    int64_t bytes = 0, used = 0;
+    int32_t* mirror_host = nullptr;    // [mirror_lanes][32] mapped pinned host memory ...
+    int32_t* mirror_dev = nullptr;     // ... and its device address
+    int32_t mirror_lanes = 0, mirror_used = 0;
+};
+void lg_set_pool_arena(PoolArena* arena);
+int64_t lg_pool_arena_bytes(int64_t batch_size, int64_t num_ids, int64_t feature_rows, int64_t float_feature_len);
+
 // alloc helpers, SS/engine/server_imp.cuh:2-51
 extern "C" void* d_alloc_space(int64_t num_bytes);
 extern "C" void d_free_space(void* d_ptr);
@@ -670,7 +698,7 @@ namespace lg {
 // the process-wide LegionTuning (include/legion_hip.h section 6, tuning.hip): launch paths read it here, nothing else
 // parses LEGION_* tuning variables.  tuning_refresh() re-reads the environment (unless a host program installed its own
 // values with legion_tuning_set); pools, pipelines and servers call it when they are created.
-const LegionTuning& tuning();
+LegionTuning tuning();           // a snapshot by value (tuning.hip)
 void tuning_refresh();
 
 struct HopParams {                  // what every lane of a launch shares
@@ -700,6 +728,9 @@ struct DeliverParams {
     int32_t* mirror;          // device address of the slot's host-visible counter mirror [32], or null
     int32_t num_ids;          // capacity of the id / edge arrays
     int32_t batch_cap;        // capacity of labels
+    float* float_features;    // launch_handover_copy only: the slot's feature buffer, its rows and the row width
+    int32_t feature_rows;
+    int32_t D;
 };
 
 struct GatherParams {
@@ -725,6 +756,8 @@ struct GatherParams {
 };
 void launch_gather(hipStream_t s, const GatherParams& g, const LanePtrs* d_lanes, int32_t n_lanes);
 void launch_deliver(hipStream_t s, const LanePtrs* d_lane, const DeliverParams& d);
+// the whole finished batch of a lane -- ids, feature rows, labels, both edge arrays, counters -- copied into a pipe slot
+void launch_handover_copy(hipStream_t s, const LanePtrs* d_lane, const DeliverParams& d, int32_t max_rows);
 // stand-alone form for tests / probes: explicit arrays, one lane
 void launch_gather_explicit(hipStream_t s, const GatherParams& g, const int32_t* sampled_ids,
                             int32_t* cache_index_out, const int32_t* range, float* dst, int32_t dst_rows);

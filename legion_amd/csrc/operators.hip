@@ -417,6 +417,11 @@ extern "C" LegionLaneGroup* legion_group_create(LegionMemoryPool** pools, int32_
 }
 
 extern "C" void legion_group_set_iter_state(LegionLaneGroup* g, int32_t* iter_state_devptr) { if (g) g->iter_state = iter_state_devptr; }
+// device address of lane `lane`'s descriptor (GPURunner: the source of a hand-over copy)
+extern "C" const void* legion_group_lane_desc(LegionLaneGroup* g, int32_t lane)
+{
+    return (g && lane >= 0 && lane < (int32_t)g->pools.size()) ? (const void*)(g->d_lanes + lane) : nullptr;
+}
 
 extern "C" void legion_group_destroy(LegionLaneGroup* g)
 {

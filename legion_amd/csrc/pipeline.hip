@@ -36,6 +36,7 @@ extern "C" void legion_enqueue_group_phase(legion_stream_t strm_hdl, LegionGraph
                                            int32_t batch_size, int32_t counter0, int32_t dev_id, int32_t mode,
                                            const int32_t* fanout, int32_t hop_num, int32_t phase);
 extern "C" void legion_pool_profile_begin(LegionMemoryPool* p_, int32_t max_ops);
+extern "C" const void* legion_group_lane_desc(LegionLaneGroup* g, int32_t lane);
 
 struct Slot {
     std::vector<MemoryPool*> pools;           // G lanes
@@ -392,6 +393,13 @@ extern "C" LegionMemoryPool* legion_pipeline_pool(LegionPipeline* p, int32_t slo
 {
     if (!p) return nullptr;
     return reinterpret_cast<LegionMemoryPool*>(p->slots[slot % p->slots_n].pools[lane % p->group_size]);
+}
+
+// device address of the LanePtrs of (slot, lane)
+extern "C" const void* legion_pipeline_lane_desc(LegionPipeline* p, int32_t slot, int32_t lane)
+{
+    if (!p) return nullptr;
+    return legion_group_lane_desc(p->slots[slot % p->slots_n].group, lane);
 }
 
 extern "C" void legion_pipeline_destroy(LegionPipeline* p)

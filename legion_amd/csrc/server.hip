@@ -303,6 +303,8 @@ extern "C" legion_stream_t legion_pipeline_stream(LegionPipeline* p);
 extern "C" void* legion_pipeline_slot_done_event(LegionPipeline* p, int32_t slot);
 extern "C" LegionMemoryPool* legion_pipeline_pool(LegionPipeline* p, int32_t slot, int32_t lane);
 extern "C" void legion_pipeline_destroy(LegionPipeline* p);
+extern "C" void legion_pipeline_wait(LegionPipeline* p, int32_t slot);
+extern "C" const void* legion_pipeline_lane_desc(LegionPipeline* p, int32_t slot, int32_t lane);
 
 class GPURunner : public Runner {
 public:
@@ -314,6 +316,7 @@ public:
         UnifiedCache* cache = (UnifiedCache*)(params->cache);
         FeatureStorage* feature = (FeatureStorage*)(params->feature);
         IPCEnv* env = (IPCEnv*)(params->env);
+        env_ = env;
 
         streams_.resize(INTRABATCH_CON);
         for (int i = 0; i < INTRABATCH_CON; i++) HIP_CALL(hipStreamCreate(&streams_[i]));
@@ -449,6 +452,7 @@ public:
             return;
         }
         if (pipe_ == nullptr) PrepareServing(params);
+        if (lanes_mode_) { RunOnceLanes(params); return; }
         if (pair_pending_) {                       // this batch went out together with the previous one (one launch, both slots)
             pair_pending_ = false;
             if (batch_id % 1000 == 0 && local_dev_id_ == 0) std::cout << "batch id: " << batch_id << "\n";
@@ -522,6 +526,74 @@ public:
         current_pipe_ = (current_pipe_ + 1) % interbatch_concurrency_;
     }
 
+    // The "lanes" hand-over (round 4, LegionTuning.runner_handover = auto | copy).  Whole launch groups -- sampler AND the
+    // full-width gathers, the arrangement bench.py times -- run into per-lane buffers that live in ONE exported device
+    // allocation (the lane arena).  A call still hands ONE batch over, in order, through the same two semaphores per pipe slot:
+    //   * trainer end that opened the arena (this build's ipc_service): the hand-over is a few host stores -- where the five
+    //     arrays of the batch start inside the arena, its counters -- and sem_post.  No GPU work per batch at all.
+    //   * any other trainer end: one pure copy launch moves the finished batch into the pipe slot's buffers.
+    // Lanes are reused by a later group only after the trainer has RELEASED every batch of the group that used them (a view
+    // is read in place): the semaphore token that lets batch k through says batch k-2 was released, so the next group may be
+    // submitted from the second batch of the current one on -- the GPU works on group g+1 while group g is handed over.
+    void RunOnceLanes(RunnerParams* params)
+    {
+        IPCEnv* env = (IPCEnv*)(params->env);
+        const int32_t k = params->global_batch_id;
+        const int p = current_pipe_;
+        const auto t_a = std::chrono::steady_clock::now();
+        {
+            bool got = false;
+            for (int spin = 0; spin < 20000 && !got; spin++) got = env->IPCTryWait(local_dev_id_, p);
+            if (!got) env->IPCWait(local_dev_id_, p);
+        }
+        const auto t_b = std::chrono::steady_clock::now();
+        if (!direct_decided_) {                 // the trainer end said what it is before its first sem_post
+            direct_ = handover_ == 0 && env->TrainerTakesViews(local_dev_id_);
+            direct_decided_ = true;
+            std::cout << "runner " << local_dev_id_ << ": hand-over by " << (direct_ ? "views of the lane arena" : "copy into the pipe slots")
+                      << ", " << lanes_ << " lanes per group\n" << std::flush;
+        }
+        if (cur_slot_ < 0 || k >= cur_first_ + cur_n_) {                  // this call opens a new group
+            if (next_slot_ >= 0 && next_first_ == k) {
+                cur_slot_ = next_slot_; cur_first_ = next_first_; cur_n_ = next_n_;
+                next_slot_ = -1;
+            } else {
+                SubmitGroup(env, k, cur_slot_, cur_first_, cur_n_);
+            }
+            legion_pipeline_wait(pipe_, cur_slot_);                       // the group has completed on the GPU
+        }
+        const int32_t lane = k - cur_first_;
+        // token k consumed => batch k-2 released => every batch of the group before this one is released once lane >= 1
+        if (next_slot_ < 0 && lane >= 1 && cur_first_ + cur_n_ < max_step_)
+            SubmitGroup(env, cur_first_ + cur_n_, next_slot_, next_first_, next_n_);
+        MemoryPool* lp = reinterpret_cast<MemoryPool*>(legion_pipeline_pool(pipe_, cur_slot_, lane));
+        if (direct_) {
+            ReportErrors(lp);
+            const LanePtrs h = lp->HostLane(0);
+            const int64_t off[5] = {(char*)h.sampled_ids - arena_.base, (char*)h.float_features - arena_.base, (char*)h.labels - arena_.base,
+                                    (char*)h.agg_src_off - arena_.base, (char*)h.agg_dst_off - arena_.base};
+            env->SetView(local_dev_id_, p, off, lp->counter_mirror_host);
+            env->IPCPost(local_dev_id_, p);
+        } else {
+            hipStream_t s = ho_streams_[p % 2] != nullptr ? ho_streams_[p % 2] : static_cast<hipStream_t>(legion_pipeline_stream(pipe_));
+            const int64_t max_rows = std::min<int64_t>(memorypool_->feature_rows, memorypool_->num_ids);
+            lg::launch_handover_copy(s, static_cast<const LanePtrs*>(legion_pipeline_lane_desc(pipe_, cur_slot_, lane)), deliver_[p],
+                                     (int32_t)max_rows);
+            HIP_CALL(hipEventRecord(batch_done_[p], s));
+            const uint32_t t = q_tail_.load(std::memory_order_relaxed);
+            ring_[t % kRing] = {batch_done_[p], p, lp, std::chrono::steady_clock::now()};
+            q_tail_.store(t + 1, std::memory_order_release);
+        }
+        if (stats_) {
+            const auto t_c = std::chrono::steady_clock::now();
+            st_wait_ += std::chrono::duration<double>(t_b - t_a).count();
+            st_launch_ += std::chrono::duration<double>(t_c - t_b).count();
+            st_n_++;
+        }
+        if (k % 1000 == 0 && local_dev_id_ == 0) std::cout << "batch id: " << k << "\n";
+        current_pipe_ = (current_pipe_ + 1) % interbatch_concurrency_;
+    }
+
     // Everything serving needs that allocates, captures or instantiates -- lanes, descriptors, the first group's graph and
     // its sampler phase -- done BEFORE the server announces itself: while trainers attach to the IPC buffers the server
     // process then only launches kernels (concurrent allocation in the exporting process made hipIpcOpenMemHandle fail
@@ -568,6 +640,9 @@ public:
         if (pipe_) {
             legion_pipeline_destroy(pipe_);
             pipe_ = nullptr;
+            if (arena_.base) d_free_space(arena_.base);
+            if (arena_.mirror_host) HIP_CALL(hipHostFree(arena_.mirror_host));
+            arena_ = PoolArena();
             d_free_space(d_desc_);
             d_desc_ = nullptr;
             d_free_space(d_deliver_);
@@ -596,8 +671,27 @@ private:
         // buffer (above) stays a warning: ids, edges and the rows that fit are correct.
         if (bits & (LG_ERR_TABLE_FULL | LG_ERR_CHAIN)) {
             std::cout << "legion_hip: corrupt batch on gpu " << local_dev_id_ << ", not posted; stopping the server\n" << std::flush;
-            _exit(EXIT_FAILURE);     // (from the poster thread too: no destructors, the trainer sees the server gone)
+            // trainers blocked in sem_wait must not wait for ever: mark the mirror object (this build's trainer end checks it
+            // after every wake-up and fails), wake every waiter, unlink the names -- then go (no destructors: other runner
+            // threads are still in launch paths)
+            if (env_ != nullptr) env_->AbortServing();
+            _exit(EXIT_FAILURE);
         }
+    }
+
+    // the largest group the schedule ever forms (consecutive batches of one mode with consecutive local ids)
+    int32_t LargestGroup(IPCEnv* env, int32_t cap)
+    {
+        int32_t best = 1, keep = lanes_;
+        lanes_ = cap;
+        for (int32_t first = 0; first < max_step_;) {
+            int32_t mode = 0, local0 = 0;
+            const int32_t n = PlanGroup(env, first, mode, local0);
+            best = std::max(best, n);
+            first += n;
+        }
+        lanes_ = keep;
+        return best;
     }
 
     // G internal lanes x 2 groups in flight + the hand-over descriptors of every (group slot, lane, pipe slot)
@@ -607,13 +701,47 @@ private:
         hop_num_ = (int32_t)params->fanout.size();
         max_step_ = env->GetMaxStep();
         std::vector<int32_t> fanout(params->fanout.begin(), params->fanout.end());
-        lanes_ = std::max(1, std::min(128, 262144 / std::max(1, memorypool_->batch_size)));
-        if (lg::tuning().runner_lanes > 0) lanes_ = lg::tuning().runner_lanes;
-        // use_graph bits: 1 graph replay, 8 sampler phase only (the gathers go straight into the pipe slots)
-        pipe_ = legion_pipeline_create((LegionGraphStorage*)params->graph, (LegionFeatureStorage*)params->feature,
-                                       (LegionUnifiedCache*)params->cache, local_dev_id_, memorypool_->batch_size,
-                                       fanout.data(), hop_num_, lanes_, 2, 0, 1 | 8);
-        const int32_t ho_mode = lg::tuning().runner_ho_stream;    // 0 the sampler's stream, 1 one shared, 2 one per pipe slot
+        const LegionTuning tune = lg::tuning();
+        const int64_t feature_rows = std::max<int64_t>(1, std::min<int64_t>(memorypool_->feature_rows, memorypool_->num_ids));
+        if (lanes_mode_) {
+            // groups as large as bench.py's (524288 / B rounded down to a power of two, at most 512: the launch tails and the
+            // per-kernel floors are paid once per group), never larger than the schedule can fill, halved while the lanes of
+            // the two groups in flight would take more than 0.6 of the HBM that is free now (tables and caches are in place)
+            lanes_ = 1;
+            while (lanes_ * 2 <= 512 && (int64_t)lanes_ * 2 * memorypool_->batch_size <= 524288) lanes_ *= 2;
+            if (tune.runner_lanes > 0) lanes_ = tune.runner_lanes;
+            lanes_ = std::min(lanes_, LargestGroup(env, lanes_));
+            const int64_t arena_lane = lg_pool_arena_bytes(memorypool_->batch_size, memorypool_->num_ids, feature_rows, float_feature_len_);
+            const int64_t lane_bytes = arena_lane + (int64_t)memorypool_->num_ids * 40 + (int64_t)memorypool_->max_slots * 28;
+            size_t free_b = 0, total_b = 0;
+            HIP_CALL(hipMemGetInfo(&free_b, &total_b));
+            while (lanes_ > 1 && (int64_t)lanes_ * 2 * lane_bytes > (int64_t)(free_b / 10 * 6)) lanes_ /= 2;
+            arena_.bytes = arena_lane * lanes_ * 2;
+            arena_.base = (char*)d_alloc_space(arena_.bytes);
+            arena_.used = 0;
+            arena_.mirror_lanes = lanes_ * 2;
+            arena_.mirror_used = 0;
+            HIP_CALL(hipHostMalloc((void**)&arena_.mirror_host, (size_t)arena_.mirror_lanes * 32 * sizeof(int32_t), hipHostMallocMapped));
+            memset(arena_.mirror_host, 0, (size_t)arena_.mirror_lanes * 32 * sizeof(int32_t));
+            HIP_CALL(hipHostGetDevicePointer((void**)&arena_.mirror_dev, arena_.mirror_host, 0));
+            lg_set_pool_arena(&arena_);
+            // use_graph bits: 1 graph replay, 16 weave (the next group's head on a second stream under this group's heavy kernels)
+            pipe_ = legion_pipeline_create((LegionGraphStorage*)params->graph, (LegionFeatureStorage*)params->feature,
+                                           (LegionUnifiedCache*)params->cache, local_dev_id_, memorypool_->batch_size,
+                                           fanout.data(), hop_num_, lanes_, 2, float_feature_len_ > 0 ? feature_rows : 0, 1 | 16);
+            lg_set_pool_arena(nullptr);
+            if (handover_ == 0 && env->PublishArena(local_dev_id_, arena_.base, arena_.bytes))
+                std::cout << "runner " << local_dev_id_ << ": lane arena of " << (arena_.bytes >> 20) << " MiB published ("
+                          << lanes_ << " lanes x 2 groups)\n" << std::flush;
+        } else {
+            lanes_ = std::max(1, std::min(128, 262144 / std::max(1, memorypool_->batch_size)));
+            if (tune.runner_lanes > 0) lanes_ = tune.runner_lanes;
+            // use_graph bits: 1 graph replay, 8 sampler phase only (the gathers go straight into the pipe slots)
+            pipe_ = legion_pipeline_create((LegionGraphStorage*)params->graph, (LegionFeatureStorage*)params->feature,
+                                           (LegionUnifiedCache*)params->cache, local_dev_id_, memorypool_->batch_size,
+                                           fanout.data(), hop_num_, lanes_, 2, 0, 1 | 8);
+        }
+        const int32_t ho_mode = tune.runner_ho_stream;    // 0 the sampler's stream, 1 one shared, 2 one per pipe slot
         if (ho_mode != 0) {
             int lo = 0, hi = 0;
             HIP_CALL(hipDeviceGetStreamPriorityRange(&lo, &hi));
@@ -639,6 +767,9 @@ private:
             d.mirror = env->GetCounterMirror(local_dev_id_, p);
             d.num_ids = memorypool_->num_ids;
             d.batch_cap = memorypool_->batch_size;
+            d.float_features = float_feature_len_ > 0 ? env->GetFloatFeatures(local_dev_id_, p) : nullptr;
+            d.feature_rows = (int32_t)feature_rows;
+            d.D = float_feature_len_;
             HIP_CALL(hipEventCreateWithFlags(&batch_done_[p], hipEventDisableTiming));
         }
         d_deliver_ = (lg::DeliverParams*)d_alloc_space(sizeof(deliver_));
@@ -646,8 +777,8 @@ private:
         // hand-over descriptors [parity][group slot][lane]: the lane's own buffers as the source, the pipe slot
         // (parity + lane) % 2 as the destination -- consecutive lanes alternate pipe slots like consecutive batches do,
         // so two consecutive batches can be handed over by ONE launch (grid.y = 2) when both slots are free
-        std::vector<LanePtrs> h((size_t)interbatch_concurrency_ * 2 * lanes_);
-        for (int par = 0; par < interbatch_concurrency_; par++)
+        std::vector<LanePtrs> h(lanes_mode_ ? 0 : (size_t)interbatch_concurrency_ * 2 * lanes_);
+        for (int par = 0; par < interbatch_concurrency_ && !lanes_mode_; par++)
             for (int sl = 0; sl < 2; sl++)
                 for (int g = 0; g < lanes_; g++) {
                     MemoryPool* lp = reinterpret_cast<MemoryPool*>(legion_pipeline_pool(pipe_, sl, g));
@@ -660,7 +791,7 @@ private:
                     h[((size_t)par * 2 + sl) * lanes_ + g] = d;
                 }
         d_desc_ = (LanePtrs*)d_alloc_space((int64_t)h.size() * sizeof(LanePtrs));
-        HIP_CALL(hipMemcpy(d_desc_, h.data(), h.size() * sizeof(LanePtrs), hipMemcpyHostToDevice));
+        if (!h.empty()) HIP_CALL(hipMemcpy(d_desc_, h.data(), h.size() * sizeof(LanePtrs), hipMemcpyHostToDevice));
         poster_ = std::thread([this, env] {
             // The poster polls (the reference's runner thread polls cudaEventQuery the same way, server.cu:319-324): one core
             // per GPU buys a hand-over latency of about a microsecond instead of a condition-variable wake-up.
@@ -713,7 +844,7 @@ private:
         // the pipeline hands its two slots out in turn: the sampler may overwrite the lanes of the slot it gets now only
         // after every batch of the group that used them before has been handed over
         const int target = submit_count_++ % 2;
-        if (ho_streams_[0] != nullptr && ho_done_valid_[target])
+        if (!lanes_mode_ && ho_streams_[0] != nullptr && ho_done_valid_[target])
             for (int i = 0; i < 2; i++)
                 HIP_CALL(hipStreamWaitEvent(static_cast<hipStream_t>(legion_pipeline_stream(pipe_)), ho_done_[target][i], 0));
         slot_out = legion_pipeline_submit_ex(pipe_, local0, mode, n, env->GetCurrentBatchsize(local_dev_id_, mode));
@@ -725,6 +856,12 @@ private:
     int32_t num_ids_ = 0;
     int32_t float_feature_len_ = 0;
     MemoryPool* memorypool_ = nullptr;
+    IPCEnv* env_ = nullptr;
+    // the "lanes" hand-over (RunOnceLanes)
+    int32_t handover_ = lg::tuning().runner_handover;     // 0 auto, 1 gather (round 3), 2 copy
+    bool lanes_mode_ = lg::tuning().runner_graph != 0 && lg::tuning().runner_handover != 1;
+    PoolArena arena_;
+    bool direct_ = false, direct_decided_ = false;
     int current_pipe_ = 0;
     int interbatch_concurrency_ = INTERBATCH_CON;
     int local_dev_id_ = 0;

@@ -440,6 +440,7 @@ LanePtrs MemoryPool::HostLane(int32_t pipe) const
     h.pos_table = pos_table;
     h.pos_table_mask = pos_table_mask;
     h.err_flag = err_dev;
+    h.counter_mirror = counter_mirror_dev;
     h.claim_pairs = claim_pairs;
     h.run_off = run_off;
     h.lds_buckets = lds_form ? (1 << lds_bucket_bits) : 0;
@@ -731,6 +732,29 @@ extern "C" void legion_feature_destroy(LegionFeatureStorage* f_)
     delete f;
 }
 
+// ---- output arena (legion_core.h PoolArena) ---------------------------------------------------
+static thread_local PoolArena* g_pool_arena = nullptr;
+void lg_set_pool_arena(PoolArena* arena) { g_pool_arena = arena; }
+static inline int64_t arena_round(int64_t b) { return (b + 255) & ~(int64_t)255; }
+int64_t lg_pool_arena_bytes(int64_t batch_size, int64_t num_ids, int64_t feature_rows, int64_t float_feature_len)
+{
+    return 3 * arena_round(num_ids * 4) + arena_round(batch_size * 4) + 2 * arena_round(64) +
+           arena_round(feature_rows * float_feature_len * 4);
+}
+static void* arena_take(int64_t bytes)
+{
+    PoolArena* a = g_pool_arena;
+    const int64_t need = arena_round(bytes);
+    if (a->used + need > a->bytes) {
+        printf("legion_hip: lane arena of %lld bytes is too small (%lld in use, %lld more asked for)\n", (long long)a->bytes,
+               (long long)a->used, (long long)need);
+        exit(EXIT_FAILURE);
+    }
+    void* p = a->base + a->used;
+    a->used += need;
+    return p;
+}
+
 extern "C" LegionMemoryPool* legion_pool_create(int32_t dev_id, int32_t total_num_nodes, int32_t batch_size,
                                                 const int32_t* fanout, int32_t hop_num,
                                                 int32_t float_feature_len, int32_t pipeline_depth)
@@ -738,14 +762,22 @@ extern "C" LegionMemoryPool* legion_pool_create(int32_t dev_id, int32_t total_nu
     if (pipeline_depth < 1) pipeline_depth = 1;
     MemoryPool* mp = new MemoryPool(pipeline_depth);
     lg_pool_alloc_private(mp, dev_id, total_num_nodes, batch_size, fanout, hop_num, float_feature_len);
-    mp->owns_buffers = true;
+    const bool in_arena = g_pool_arena != nullptr && pipeline_depth == 1;
+    mp->owns_buffers = !in_arena;
+    mp->arena_backed = in_arena;
+    auto take = [&](int64_t bytes) { return in_arena ? arena_take(bytes) : d_alloc_space(bytes); };
+    if (in_arena && g_pool_arena->mirror_dev != nullptr && g_pool_arena->mirror_used < g_pool_arena->mirror_lanes) {
+        mp->counter_mirror_dev = g_pool_arena->mirror_dev + 32 * (int64_t)g_pool_arena->mirror_used;
+        mp->counter_mirror_host = g_pool_arena->mirror_host + 32 * (int64_t)g_pool_arena->mirror_used;
+        g_pool_arena->mirror_used++;
+    }
     for (int i = 0; i < pipeline_depth; i++) {            // ipc_service.cu:134-161 without the handles
-        mp->SetSampledIds((int32_t*)d_alloc_space((int64_t)mp->num_ids * 4), i);
-        mp->SetLabels((int32_t*)d_alloc_space((int64_t)batch_size * 4), i);
-        mp->SetAggSrcOf((int32_t*)d_alloc_space((int64_t)mp->num_ids * 4), i);
-        mp->SetAggDstOf((int32_t*)d_alloc_space((int64_t)mp->num_ids * 4), i);
-        mp->SetNodeCounter((int32_t*)d_alloc_space(16 * 4), i);
-        mp->SetEdgeCounter((int32_t*)d_alloc_space(16 * 4), i);
+        mp->SetSampledIds((int32_t*)take((int64_t)mp->num_ids * 4), i);
+        mp->SetLabels((int32_t*)take((int64_t)batch_size * 4), i);
+        mp->SetAggSrcOf((int32_t*)take((int64_t)mp->num_ids * 4), i);
+        mp->SetAggDstOf((int32_t*)take((int64_t)mp->num_ids * 4), i);
+        mp->SetNodeCounter((int32_t*)take(16 * 4), i);
+        mp->SetEdgeCounter((int32_t*)take(16 * 4), i);
         mp->SetCurrentPipe(i);
         HIP_CALL(hipMemset(mp->GetNodeCounter(), 0, 64));
         HIP_CALL(hipMemset(mp->GetEdgeCounter(), 0, 64));
@@ -762,6 +794,11 @@ extern "C" void legion_pool_alloc_features(LegionMemoryPool* p_, int64_t rows)
     const int32_t cur = mp->GetCurrentPipe();
     for (int i = 0; i < mp->PipelineDepth(); i++) {
         mp->SetCurrentPipe(i);
+        if (mp->arena_backed) {           // (once per pool: the arena is sized for exactly one feature buffer per lane)
+            if (g_pool_arena == nullptr) { printf("legion_hip: arena-backed pool without its arena\n"); exit(EXIT_FAILURE); }
+            mp->SetFloatFeatures((float*)arena_take(rows * (int64_t)mp->float_feature_len * sizeof(float)), i);
+            continue;
+        }
         d_free_space(mp->GetFloatFeatures());
         mp->SetFloatFeatures((float*)d_alloc_space(rows * (int64_t)mp->float_feature_len * sizeof(float)), i);
     }

@@ -7,7 +7,10 @@
 #include "legion_core.h"
 
 #include <cstring>
+#include <initializer_list>
 #include <mutex>
+#include <string>
+#include <utility>
 
 namespace {
 LegionTuning g_tuning;
@@ -51,6 +54,22 @@ void parse_env(LegionTuning& t)
     t.runner_pair = env_int("LEGION_RUNNER_PAIR", 1);
     t.runner_ho_stream = env_int("LEGION_RUNNER_HO_STREAM", 2);
     t.runner_stats = getenv("LEGION_RUNNER_STATS") != nullptr ? 1 : 0;
+    auto word = [](const char* name, std::initializer_list<std::pair<const char*, int>> words, int dflt) {
+        const char* e = getenv(name);
+        if (!e || !*e) return dflt;
+        std::string all;
+        for (const auto& w : words) {
+            if (strcmp(e, w.first) == 0) return w.second;
+            all += (all.empty() ? "" : "|") + std::string(w.first);
+        }
+        printf("legion_hip: %s=%s is not one of %s\n", name, e, all.c_str());
+        exit(EXIT_FAILURE);
+    };
+    t.runner_handover = word("LEGION_RUNNER_HANDOVER", {{"auto", 0}, {"gather", 1}, {"copy", 2}}, 0);
+    t.peer_gather = word("LEGION_PEER_GATHER", {{"direct", 0}, {"bulk", 1}}, 0);
+    t.feature_pitch = word("LEGION_FEATURE_PITCH", {{"auto", -1}, {"dense", 0}, {"aligned", 1}}, -1);
+    t.hotness_reduce = word("LEGION_HOTNESS_REDUCE", {{"auto", -1}, {"p2p", 0}, {"rccl", 1}}, -1);
+    t.markers = env_int("LEGION_MARKERS", 1);
     t.table_placement = 0;
     if (const char* e = getenv("LEGION_TABLE_PLACEMENT")) t.table_placement = strcmp(e, "pinned") == 0 ? 1 : 0;
     t.shm_mirror = getenv("LEGION_NO_SHM_MIRROR") != nullptr ? 0 : 1;
@@ -72,11 +91,21 @@ void parse_env(LegionTuning& t)
 }  // namespace
 
 namespace lg {
-const LegionTuning& tuning()
+// A SNAPSHOT by value: the process-wide copy is replaced as a whole under the lock (parsed into a local first -- parse_env may
+// exit() on a bad value and must not do so holding the lock), so a launch path running beside another thread's refresh sees
+// either the old values or the new ones, never a half-written struct (a transient sample_max_wg = 0 once baked gx = 1 into a
+// captured hipGraph for the life of its pipeline).
+LegionTuning tuning()
 {
+    {
+        std::lock_guard<std::mutex> lk(g_tuning_mu);
+        if (g_tuning_valid) return g_tuning;
+    }
+    LegionTuning t;
+    parse_env(t);
     std::lock_guard<std::mutex> lk(g_tuning_mu);
     if (!g_tuning_valid) {
-        parse_env(g_tuning);
+        g_tuning = t;
         g_tuning_valid = true;
     }
     return g_tuning;
@@ -86,17 +115,25 @@ const LegionTuning& tuning()
 // installed its own values
 void tuning_refresh()
 {
+    {
+        std::lock_guard<std::mutex> lk(g_tuning_mu);
+        if (g_tuning_pinned) return;
+    }
+    LegionTuning t;
+    parse_env(t);
     std::lock_guard<std::mutex> lk(g_tuning_mu);
     if (g_tuning_pinned) return;
-    parse_env(g_tuning);
+    g_tuning = t;
     g_tuning_valid = true;
 }
 }  // namespace lg
 
 extern "C" void legion_tuning_from_env(void)
 {
+    LegionTuning t;
+    parse_env(t);
     std::lock_guard<std::mutex> lk(g_tuning_mu);
-    parse_env(g_tuning);
+    g_tuning = t;
     g_tuning_valid = true;
     g_tuning_pinned = false;
 }

@@ -48,10 +48,23 @@ typedef struct shmStruct_st {
     int32_t steps[3];
     hipIpcMemHandle_t memHandle[MAX_DEVICE][INTERBATCH_CON][MEMORY_USAGE];
 } shmStruct;
+// Version 2 of that object adds the direct-view hand-over (server: ipc_env.hip): the server's mini-batches are produced into
+// per-lane buffers that all live in one device allocation per GPU, the lane arena, whose IPC handle is published here.  This
+// module opens it, says so in trainer_direct[dev] before its first sem_post, and from then on get_next returns VIEWS of the
+// batch's lane (view[dev][pipe] = byte offsets into the arena) instead of views of the two pipe slots' buffers: the server
+// then does no per-batch GPU work at all.  Same semaphores, same two-slot order, same tensors as far as a training script
+// can tell.  LEGION_NO_DIRECT_VIEWS=1 keeps this module on the slot buffers.
 typedef struct shmExt_st {
     int32_t ext_magic;
-    int32_t ext_reserved[3];
+    int32_t ext_version;
+    int32_t server_state;          // 1: the server stopped on an error
+    int32_t ext_reserved;
     int32_t counters[MAX_DEVICE][INTERBATCH_CON][32];
+    hipIpcMemHandle_t arena[MAX_DEVICE];
+    int64_t arena_bytes[MAX_DEVICE];
+    int32_t trainer_direct[MAX_DEVICE];
+    int32_t view_on[MAX_DEVICE][INTERBATCH_CON];
+    int64_t view[MAX_DEVICE][INTERBATCH_CON][5];
 } shmExt;
 static_assert(sizeof(hipIpcMemHandle_t) == 64, "IPC handle size is part of the wire format");
 
@@ -110,6 +123,37 @@ public:
             }
         }
         std::cout << "HIP: " << central_device << " IPC shared memory opened\n";
+        if (!getenv("LEGION_NO_SHM_MIRROR")) {                  // this build's server: counters in host memory (never created here)
+            const std::string ext_name = std::string("legionIPCext") + ipc_suffix();
+            const int efd = shm_open(ext_name.c_str(), O_RDWR, 0);
+            if (efd >= 0) {
+                void* ea = mmap(0, sizeof(shmExt), PROT_READ | PROT_WRITE, MAP_SHARED, efd, 0);
+                if (ea != MAP_FAILED && ((volatile shmExt*)ea)->ext_magic == LEGION_SHM_EXT_MAGIC) mirror_ = (volatile shmExt*)ea;
+                else if (ea != MAP_FAILED) munmap(ea, sizeof(shmExt));
+                close(efd);
+            }
+        }
+        // direct views: open the server's lane arena and say so BEFORE the first sem_post below (the server reads the flag
+        // when its first wait returns)
+        if (mirror_ != nullptr && mirror_->ext_version >= 2 && mirror_->arena_bytes[central_device] > 0 && !getenv("LEGION_NO_DIRECT_VIEWS")) {
+            hipIpcMemHandle_t h = *(hipIpcMemHandle_t*)&mirror_->arena[central_device];
+            hipError_t e = hipIpcOpenMemHandle(&arena_, h, hipIpcMemLazyEnablePeerAccess);
+            for (int attempt = 0; e != hipSuccess && attempt < 10; attempt++) {
+                (void)hipGetLastError();
+                usleep(25000);
+                e = hipIpcOpenMemHandle(&arena_, h, hipIpcMemLazyEnablePeerAccess);
+            }
+            if (e == hipSuccess) {
+                arena_bytes_ = mirror_->arena_bytes[central_device];
+                mirror_->trainer_direct[central_device] = 1;
+                __sync_synchronize();
+                std::cout << "HIP: " << central_device << " lane arena opened (" << (arena_bytes_ >> 20) << " MiB): batches arrive as views\n";
+            } else {
+                (void)hipGetLastError();
+                arena_ = nullptr;
+                printf("ipc_service: could not open the server's lane arena ('%s'); batches arrive in the pipe slots\n", hipGetErrorString(e));
+            }
+        }
         semr_.resize(INTERBATCH_CON);
         semw_.resize(INTERBATCH_CON);
         const std::string sfx = ipc_suffix();
@@ -133,20 +177,26 @@ public:
         slab_device_ = central_device;
         munmap(addr, sizeof(shmStruct));
         close(fd);
-        if (!getenv("LEGION_NO_SHM_MIRROR")) {                  // this build's server: counters in host memory (never created here)
-            const std::string ext_name = std::string("legionIPCext") + ipc_suffix();
-            const int efd = shm_open(ext_name.c_str(), O_RDONLY, 0);
-            if (efd >= 0) {
-                void* ea = mmap(0, sizeof(shmExt), PROT_READ, MAP_SHARED, efd, 0);
-                if (ea != MAP_FAILED && ((volatile shmExt*)ea)->ext_magic == LEGION_SHM_EXT_MAGIC) mirror_ = (volatile shmExt*)ea;
-                else if (ea != MAP_FAILED) munmap(ea, sizeof(shmExt));
-                close(efd);
-            }
-        }
         return central_device;
     }
 
-    void Wait() { sem_wait(semw_[current_pipe_]); }
+    void Wait()
+    {
+        sem_wait(semw_[current_pipe_]);
+        if (mirror_ != nullptr && mirror_->server_state != 0) {      // the server woke every waiter before it stopped on an error
+            printf("ipc_service: the sampling server stopped on an error; no batch was handed over\n");
+            fflush(stdout);
+            exit(EXIT_FAILURE);
+        }
+    }
+    // the batch in the current pipe slot as byte offsets into the lane arena {ids, features, labels, agg_src, agg_dst}, or null
+    const volatile int64_t* View() const
+    {
+        if (arena_ == nullptr || mirror_ == nullptr || mirror_->view_on[slab_device_][current_pipe_] == 0) return nullptr;
+        return &mirror_->view[slab_device_][current_pipe_][0];
+    }
+    void* Arena() const { return arena_; }
+    long long ArenaBytes() const { return arena_bytes_; }
     void Post()
     {
         sem_post(semr_[current_pipe_]);
@@ -176,6 +226,8 @@ public:
             if (sem_close(semw_[i]) == -1) std::cout << "close sem " << i << " failed\n";
             sem_close(semr_[i]);
         }
+        if (arena_ != nullptr && getenv("LEGION_IPC_CLOSE_ARENA")) hipIpcCloseMemHandle(arena_);
+        arena_ = nullptr;
     }
 
 private:
@@ -186,6 +238,8 @@ private:
     int device_ = 0;        // physical device the tensors live on
     int slab_device_ = 0;   // index of this trainer's GPU in the server's slab / semaphore names
     volatile shmExt* mirror_ = nullptr;
+    void* arena_ = nullptr;          // the server's lane arena, opened (direct views), or null
+    long long arena_bytes_ = 0;
 };
 
 static GPUIPCEnv* env = nullptr;
@@ -197,6 +251,8 @@ static int32_t h_edge_counter[16];
 struct SlotTensors { torch::Tensor ids, feats, labels, src, dst; };
 static SlotTensors slot_base[INTERBATCH_CON];
 static bool slot_base_ready[INTERBATCH_CON] = {false, false};
+static torch::Tensor arena_i32, arena_f32;     // the whole lane arena as int32 / float32 (direct views)
+static bool arena_ready = false;
 // extent (in elements) of the device allocation behind an IPC-opened pointer
 static long long whole_buffer(void* p, size_t elem)
 {
@@ -222,6 +278,9 @@ void FinalizeIPC()
         slot_base[i] = SlotTensors();
         slot_base_ready[i] = false;
     }
+    arena_i32 = torch::Tensor();
+    arena_f32 = torch::Tensor();
+    arena_ready = false;
     env->Finalize();
 }
 
@@ -241,6 +300,28 @@ std::vector<torch::Tensor> get_next(int feature_dim)
     }
     const int hop_num = h_node_counter[INTRABATCH_CON * 3 - 1];
     const int pipe = env->CurrentPipe();
+    if (const volatile int64_t* vw = env->View()) {
+        // the batch is where the server's launch group left it: views of its lane inside the arena
+        if (!arena_ready) {
+            const auto dev = torch::Device(torch::kCUDA, env->Device());
+            arena_i32 = torch::from_blob(env->Arena(), {env->ArenaBytes() / 4}, torch::TensorOptions().dtype(torch::kI32).device(dev));
+            arena_f32 = torch::from_blob(env->Arena(), {env->ArenaBytes() / 4}, torch::TensorOptions().dtype(torch::kF32).device(dev));
+            arena_ready = true;
+        }
+        const long long o_ids = vw[0] / 4, o_feat = vw[1] / 4, o_lab = vw[2] / 4, o_src = vw[3] / 4, o_dst = vw[4] / 4;
+        std::vector<torch::Tensor> ret;
+        ret.reserve(3 + 2 * hop_num);
+        const long long n_total = std::max(h_node_counter[INTRABATCH_CON * 3 + hop_num], 0);
+        ret.push_back(arena_i32.as_strided({n_total}, {1}, o_ids));
+        ret.push_back(arena_f32.as_strided({n_total, (long long)feature_dim}, {(long long)feature_dim, 1}, o_feat));
+        ret.push_back(arena_i32.as_strided({(long long)std::max(h_node_counter[INTRABATCH_CON * 3], 0)}, {1}, o_lab));
+        for (int i = hop_num; i > 0; i--) {
+            const long long n_edges = std::max(h_edge_counter[INTRABATCH_CON * 3 + i], 0);
+            ret.push_back(arena_i32.as_strided({n_edges}, {1}, o_src));
+            ret.push_back(arena_i32.as_strided({n_edges}, {1}, o_dst));
+        }
+        return ret;
+    }
     SlotTensors& b = slot_base[pipe];
     if (!slot_base_ready[pipe]) {
         const auto dev = torch::Device(torch::kCUDA, env->Device());

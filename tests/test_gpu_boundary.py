@@ -30,15 +30,24 @@ def write_dataset(path, wl_indptr, wl_col, feats, labels, train, valid, test):
 
 
 @pytest.mark.parametrize("server_env", [
-    {},                                                        # defaults: launch groups of up to 128 batches, counter mirror
-    {"LEGION_RUNNER_LANES": "3"},                              # many small groups: prefetch, partial groups, mode changes mid-run
-    {"LEGION_RUNNER_LANES": "4", "LEGION_DEDUP": "table"},     # compact position state inside the server
-    {"LEGION_RUNNER_LANES": "1", "LEGION_RUNNER_PAIR": "0"},   # one batch per group
+    {},                                                        # defaults: whole launch groups into the lane arena, batches handed over as VIEWS of their lane
+    {"LEGION_RUNNER_LANES": "3"},                              # many small groups: prefetch, partial groups, mode changes mid-run, lane reuse
+    {"LEGION_RUNNER_LANES": "1"},                              # one batch per group: a lane is reused as soon as its batch is released
+    {"LEGION_RUNNER_LANES": "2", "LEGION_DEDUP": "direct"},    # per-vertex position state inside the lanes pipeline
+    {"LEGION_NO_DIRECT_VIEWS": "1"},                           # a trainer end that does not take views: the same pipeline, one copy launch per batch
+    {"LEGION_RUNNER_HANDOVER": "copy", "LEGION_RUNNER_LANES": "5"},   # copies forced on the server side (no arena published)
+    {"LEGION_RUNNER_HANDOVER": "copy", "LEGION_RUNNER_LANES": "4", "LEGION_RUNNER_HO_STREAM": "0"},   # ... on the pipeline's own stream
+    {"LEGION_RUNNER_HANDOVER": "gather"},                      # round 3's path: sampler phase in groups, one gather launch per batch into the pipe slot
+    {"LEGION_RUNNER_HANDOVER": "gather", "LEGION_RUNNER_LANES": "3"},
+    {"LEGION_RUNNER_HANDOVER": "gather", "LEGION_RUNNER_LANES": "4", "LEGION_DEDUP": "table"},     # compact position state inside the server
+    {"LEGION_RUNNER_HANDOVER": "gather", "LEGION_RUNNER_LANES": "1", "LEGION_RUNNER_PAIR": "0"},   # one batch per group
     {"LEGION_RUNNER_GRAPH": "0"},                              # the reference's operator-by-operator Runner
-    {"LEGION_NO_SHM_MIRROR": "1"},                             # counters copied from the device, as the reference's trainer end does
-    {"LEGION_RUNNER_LANES": "5", "LEGION_RUNNER_HO_STREAM": "0"},   # hand-overs on the sampler's own stream
-    {"LEGION_RUNNER_LANES": "6", "LEGION_RUNNER_HO_STREAM": "1"},   # one hand-over stream for both pipe slots
-], ids=["default", "lanes3", "lanes4-table", "lanes1", "operators", "no-mirror", "lanes5-one-stream", "lanes6-shared-ho-stream"])
+    {"LEGION_NO_SHM_MIRROR": "1"},                             # no mirror object at all: counters copied from the device, as the reference's trainer end does
+    {"LEGION_RUNNER_HANDOVER": "gather", "LEGION_RUNNER_LANES": "5", "LEGION_RUNNER_HO_STREAM": "0"},   # hand-overs on the sampler's own stream
+    {"LEGION_RUNNER_HANDOVER": "gather", "LEGION_RUNNER_LANES": "6", "LEGION_RUNNER_HO_STREAM": "1"},   # one hand-over stream for both pipe slots
+], ids=["default-views", "views-lanes3", "views-lanes1", "views-lanes2-direct-state", "trainer-without-views", "copy-lanes5", "copy-lanes4-one-stream",
+        "gather", "gather-lanes3", "gather-lanes4-table", "gather-lanes1", "operators", "no-mirror", "gather-lanes5-one-stream",
+        "gather-lanes6-shared-ho-stream"])
 def test_server_binary_serves_fake_trainer(hip, tmp_path, server_env, monkeypatch):
     import torch
     for k, v in server_env.items():
@@ -132,6 +141,12 @@ def test_server_binary_serves_fake_trainer(hip, tmp_path, server_env, monkeypatc
         assert server.returncode == 0
         text = open(work / "server.log").read()
         assert "Server Stopped" in text and "Train Steps: %d" % st.train_step in text
+        # which hand-over served the run
+        lanes_pipeline = server_env.get("LEGION_RUNNER_HANDOVER", "auto") != "gather" and server_env.get("LEGION_RUNNER_GRAPH") != "0"
+        views = lanes_pipeline and not ({"LEGION_NO_DIRECT_VIEWS", "LEGION_NO_SHM_MIRROR"} & set(server_env)) and \
+            server_env.get("LEGION_RUNNER_HANDOVER", "auto") == "auto"
+        assert ("hand-over by views of the lane arena" in text) == views, text[-1500:]
+        assert ("hand-over by copy into the pipe slots" in text) == (lanes_pipeline and not views), text[-1500:]
     finally:
         if server.poll() is None:
             server.kill()
@@ -210,10 +225,16 @@ def test_server_stops_instead_of_posting_a_corrupt_batch(hip, tmp_path):
         assert server.returncode not in (0, None), text[-2000:]
         assert "position table overflow" in text and "not posted" in text and "Server Stopped" not in text, text[-2000:]
         assert not os.path.exists(work / "out.npz")          # the trainer never got the whole schedule
+        # ... and it does not hang on the semaphore of the batch that never came: the server woke it before it went
+        t_out = trainer.communicate(timeout=60)[0].decode()
+        assert trainer.returncode not in (0, None) and "the sampling server stopped on an error" in t_out, t_out[-1500:]
+        left = [n for n in os.listdir("/dev/shm") if n.endswith(ns)]
+        assert not [n for n in left if n.startswith(("simpleIPCshm", "legionIPCext", "sem.sem_w", "sem.sem_r"))], left
     finally:
         if server.poll() is None:
             server.kill()
-        trainer.kill()                                       # it is blocked on the semaphore of the batch that never came
+        if trainer.poll() is None:
+            trainer.kill()
         trainer.wait()
         log.close()
         for name in os.listdir("/dev/shm"):
@@ -221,13 +242,13 @@ def test_server_stops_instead_of_posting_a_corrupt_batch(hip, tmp_path):
                 os.unlink(os.path.join("/dev/shm", name))
 
 
-@pytest.mark.parametrize("lanes", ["16", "5"])
-def test_boundary_soak_every_batch_verified(hip, lanes):
+@pytest.mark.parametrize("lanes,handover", [("16", "auto"), ("5", "auto"), ("5", "copy"), ("16", "gather"), ("5", "gather")])
+def test_boundary_soak_every_batch_verified(hip, lanes, handover):
     """600+ consecutive hand-overs through the binary and the two pipe slots with a consumer that checks EVERY batch on the
     device (rows = the generator's rows of the batch's ids, unique ids, edge endpoints inside the batch, the seeds are the
     training batch's): a wrong slot, a stale or half-copied batch, a lost or duplicated post shows up here."""
     import json
-    env = dict(os.environ, LEGION_RUNNER_LANES=lanes)
+    env = dict(os.environ, LEGION_RUNNER_LANES=lanes, LEGION_RUNNER_HANDOVER=handover)
     res = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "server_throughput.py"), "--scale", "16", "--batch", "100",
                           "--dim", "32", "--fanout", "6,4", "--train-batches", "620", "--verify-every", "1", "--watchdog", "150",
                           "--cache-memory", str(1 << 20)], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,

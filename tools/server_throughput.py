@@ -32,6 +32,18 @@ def main():
                     help="do not write the `features` file: the server then serves a zero-filled table of the same shape (v2 of the "
                          "reference reads no features either, storage_management.cu:162); a 34 GB file is too slow to write for a "
                          "throughput run at RMAT-26, the traffic is the same")
+    ap.add_argument("--handover", type=str, default="", choices=["", "auto", "copy", "gather"],
+                    help="LEGION_RUNNER_HANDOVER for the server (default: whatever the environment says, i.e. auto)")
+    ap.add_argument("--no-views", action="store_true",
+                    help="the consumer does not take batches as views of the server's lane arena (a trainer end that knows only the "
+                         "reference's slab): LEGION_NO_DIRECT_VIEWS=1 for the python consumer, no `views` flag for the native one")
+    ap.add_argument("--modes", type=str, default="",
+                    help="comma list of views|copy|gather: one server run per (mode, batch size) over the same data set files "
+                         "(views = handover auto + a consumer that takes views, copy = handover auto + a consumer that does not, "
+                         "gather = handover gather); overrides --handover / --no-views")
+    ap.add_argument("--min-timed-batches", type=int, default=0,
+                    help="run as many epochs as it takes for the timed window to hold at least this many batches (views mode hands "
+                         "over 100 k+ batches/s: a single epoch of a few thousand batches is a window of milliseconds)")
     ap.add_argument("--edge-factor", type=int, default=16)
     ap.add_argument("--nodes", type=int, default=0, help="with --edges: synth.csr_device_large(nodes, edges) instead of RMAT-<scale>")
     ap.add_argument("--edges", type=int, default=0)
@@ -65,21 +77,38 @@ def main():
     del indptr, col
     torch.cuda.empty_cache()
     try:
-        for b in batches:
-            n_train = b * tb[b] + 1
-            train[:b].tofile(ds + "validationset"); train[:b].tofile(ds + "testingset")
-            run_one(a, ds, tmp, b, n_train, train, fanout, N, E)
+        for mode in (a.modes.split(",") if a.modes else [""]):
+            if mode:
+                a.handover = "gather" if mode == "gather" else "auto"
+                a.no_views = mode == "copy"
+                os.environ.pop("LEGION_NO_DIRECT_VIEWS", None)
+            for b in batches:
+                n_train = b * tb[b] + 1
+                train[:b].tofile(ds + "validationset"); train[:b].tofile(ds + "testingset")
+                if a.min_timed_batches > 0:
+                    a.epochs = max(1, -(-a.min_timed_batches // tb[b]))
+                run_one(a, ds, tmp, b, n_train, train, fanout, N, E, mode)
     finally:
         subprocess.call(["rm", "-rf", tmp])
 
 
-def run_one(a, ds, tmp, batch, n_train, train, fanout, N, E):
-    work = os.path.join(tmp, f"run_b{batch}")
+def run_one(a, ds, tmp, batch, n_train, train, fanout, N, E, mode=""):
+    work = os.path.join(tmp, f"run_b{batch}{mode}")
     os.makedirs(work)
     open(os.path.join(work, "meta_config"), "w").write("{} {} {} {} {} {} {} {} {} {}".format(
         ds, batch, N, E, a.dim, n_train, batch, batch, a.cache_memory, a.epochs))
     ns = f"_b{os.getpid()}"
     os.environ["LEGION_IPC_NAMESPACE"] = ns
+    if a.handover:
+        os.environ["LEGION_RUNNER_HANDOVER"] = a.handover
+    if a.no_views:
+        os.environ["LEGION_NO_DIRECT_VIEWS"] = "1"
+
+    def handover_of():
+        for line in open(os.path.join(work, "server.log")):
+            if "hand-over by" in line:
+                return line.strip().split(": ", 1)[1]
+        return "one gather launch per batch straight into the pipe slot" if os.environ.get("LEGION_RUNNER_HANDOVER") == "gather" else "?"
     workload = (f"N={N}, E={E} (synth.csr_device_large)" if a.nodes > 0 else f"RMAT-{a.scale} EF{a.edge_factor}") + f", D={a.dim}, batch {batch}, fanout {fanout}, train mode, 1 GPU" + \
                (", zero-filled feature table (no `features` file)" if a.no_features_file else "")
     log = open(os.path.join(work, "server.log"), "w")
@@ -94,7 +123,7 @@ def run_one(a, ds, tmp, batch, n_train, train, fanout, N, E):
         if a.consumer == "native":
             exe = os.path.join(tmp, "boundary_consumer")
             subprocess.check_call(["gcc", "-O2", os.path.join(ROOT, "tools", "boundary_consumer.c"), "-o", exe, "-lrt", "-lpthread"])
-            out = subprocess.check_output([exe, ns, "0", str(len(fanout)), "5", str(a.epochs)]).decode().strip().splitlines()[-1]
+            out = subprocess.check_output([exe, ns, "0", str(len(fanout)), "5", str(a.epochs), "0" if a.no_views else "1"]).decode().strip().splitlines()[-1]
             server.wait(timeout=120)
             log.flush()
             for line in open(os.path.join(work, "server.log")):
@@ -102,7 +131,7 @@ def run_one(a, ds, tmp, batch, n_train, train, fanout, N, E):
                     print(line.strip(), file=sys.stderr)
             res = json.loads(out)
             res.update({"path": "sampling_server binary -> shm/semaphores -> protocol-only consumer (counters from the server's host-visible mirror)",
-                        "workload": workload, "batch": batch})
+                        "workload": workload, "batch": batch, "handover": handover_of(), "mode": mode, "epochs": a.epochs})
             print(json.dumps(res), flush=True)
             return
         import ipc_service
@@ -144,7 +173,7 @@ def run_one(a, ds, tmp, batch, n_train, train, fanout, N, E):
         server.wait(timeout=120)
         dt = t1 - t0
         print(json.dumps({"path": "sampling_server binary -> shm/semaphores/IPC handles -> ipc_service consumer",
-                          "workload": workload, "batch": batch,
+                          "workload": workload, "batch": batch, "handover": handover_of(), "mode": mode, "epochs": a.epochs,
                           "batches_per_sec": n_timed / dt, "edges_per_sec": edges / dt, "timed_batches": n_timed,
                           "ms_per_batch": dt / n_timed * 1e3, "verified_batches": verified}), flush=True)
     finally:
