@@ -167,6 +167,10 @@ def parse_args():
     ap.add_argument("--striped-replica-memory", type=int, default=4 << 30,
                     help="bytes per GPU of the hot-row replica in the `striped_replica` leg")
     ap.add_argument("--backend", type=str, default="nccl", help="torch.distributed backend (nccl = RCCL)")
+    ap.add_argument("--no-product-collective", action="store_true",
+                    help="hotness all-reduce through torch.distributed instead of the library's own RCCL call")
+    ap.add_argument("--collective-deadline", type=int, default=120,
+                    help="seconds the library's communicator may take to form before the run falls back to torch.distributed")
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise torch.distributed and run the collectives even at N = 1 (exercises the RCCL calls on a 1-GPU box)")
     ap.add_argument("--extra-legs-deadline", type=int, default=600,
@@ -365,17 +369,59 @@ def run_leg(c, engine, synth, stripe, replica_memory, headline):
     collective = None
     if use_dist:    # the only collective of the path: RCCL all-reduce of the uint64 hotness counters
         ones = torch.ones(1, dtype=torch.int64, device=red_dev)
-        dist.all_reduce(ones)                                   # the world size as the collective itself sees it
+        dist.all_reduce(ones)                                   # the world size as torch.distributed sees it
         torch.cuda.synchronize()
-        dist.barrier()
-        t0 = time.perf_counter()
-        dist.all_reduce(cache.array("node_access_time", d))
-        dist.all_reduce(cache.array("edge_access_time", d))
-        torch.cuda.synchronize()
-        ar_ms = (time.perf_counter() - t0) * 1e3
+        # The PRODUCT issues the collective (legion_amd/csrc/collective.hip: ncclAllReduce(ncclUint64, ncclSum) over its own
+        # communicator); torch.distributed only carries rank 0's 128-byte unique id to the other ranks.  A join or a call that
+        # fails or does not return within --collective-deadline seconds falls back to dist.all_reduce on the same arrays and
+        # the line says so -- a SCALE run must not be lost to the first meeting of this code with a second physical GPU.
+        issued_by, product_err, world_seen, ar_ms = None, None, 0, 0.0
+        if args.backend == "nccl" and not args.no_product_collective:
+            ids = [engine.collective_unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(ids, src=0)
+            box = {}
+
+            def product_call():
+                try:
+                    if not engine.collective_init_rank(ids[0], world, rank, d):
+                        box["err"] = "legion_collective_init_rank failed"
+                        return
+                    box["joined"] = True
+                except Exception as e:      # noqa: BLE001
+                    box["err"] = repr(e)[:200]
+
+            th = threading.Thread(target=product_call, daemon=True)
+            th.start()
+            th.join(args.collective_deadline)
+            ok_t = torch.tensor([1 if box.get("joined") else 0], dtype=torch.int64, device=red_dev)
+            dist.all_reduce(ok_t, op=dist.ReduceOp.MIN)         # every rank takes the same path
+            if int(ok_t.item()) == 1:
+                dist.barrier()
+                t0 = time.perf_counter()
+                world_seen, ar_ms_lib = cache.allreduce_hotness(d)
+                torch.cuda.synchronize()
+                ar_ms = (time.perf_counter() - t0) * 1e3
+                ok_t = torch.tensor([1 if world_seen == world else 0], dtype=torch.int64, device=red_dev)
+                dist.all_reduce(ok_t, op=dist.ReduceOp.MIN)
+                if int(ok_t.item()) == 1:
+                    issued_by = "liblegion_hip.so (collective.hip: ncclAllReduce, ncclUint64, ncclSum, in place, the library's own communicator)"
+                else:
+                    raise RuntimeError("the product's hotness all-reduce ran on some ranks only: the counters are inconsistent")
+            else:
+                product_err = box.get("err", f"no join within {args.collective_deadline} s")
+        if issued_by is None:
+            dist.barrier()
+            t0 = time.perf_counter()
+            dist.all_reduce(cache.array("node_access_time", d))
+            dist.all_reduce(cache.array("edge_access_time", d))
+            torch.cuda.synchronize()
+            ar_ms = (time.perf_counter() - t0) * 1e3
+            world_seen = int(ones.item())
+            issued_by = f"torch.distributed ({dist.get_backend()})" + (" -- the product's own call was not used: " + product_err if product_err else "")
         ar_t = torch.tensor([ar_ms], dtype=torch.float64, device=red_dev)
         dist.all_reduce(ar_t, op=dist.ReduceOp.MAX)
-        collective = {"backend": dist.get_backend(), "world_size_seen_by_all_reduce": int(ones.item()),
+        collective = {"backend": "rccl" if "liblegion" in issued_by else dist.get_backend(), "issued_by": issued_by,
+                      "world_size_seen_by_all_reduce": int(world_seen),
                       "hotness_all_reduce_ms": float(ar_t.item()), "hotness_all_reduce_bytes": 2 * N * 8,
                       "hotness_all_reduce_GBps_algorithmic": 2 * N * 8 / max(float(ar_t.item()), 1e-6) / 1e6,
                       "note": "two uint64[N] arrays (node and edge access counts), all-reduced in place once before CandidateSelection; "

@@ -155,6 +155,20 @@ void legion_cache_gather_stats_enable(LegionUnifiedCache* c, int32_t on);
  * already all-reduced the counters across processes with RCCL and they are used as they are. */
 void legion_cache_candidate_selection(LegionUnifiedCache* c, int32_t cache_agg_mode,
                                       LegionGraphStorage* graph, int32_t world_reduced);
+/* The hotness all-reduce as the product's own RCCL call (collective.hip; reference: the leader's aggregate_access loop over peer
+ * pointers, SS/cache/cache.cu:408-411,428-431).  Inside ONE server process (a thread per GPU) CandidateSelection issues it itself
+ * over the clique's distinct physical GPUs (LegionTuning.hotness_reduce).  With one process per GPU the host program carries a
+ * 128-byte unique id from rank 0 to every rank (any channel), each rank joins with the logical GPU it owns, and
+ * legion_cache_allreduce_hotness sums GPU dev_id's two uint64[N] counter arrays in place over all ranks; then
+ * candidate_selection(world_reduced = 1).  Returns: 1 / the world size on success, 0 on failure. */
+int32_t legion_collective_unique_id(void* out128);
+int32_t legion_collective_init_rank(const void* id128, int32_t world, int32_t rank, int32_t dev_id);
+int32_t legion_collective_allreduce_u64(void* devptr, int64_t count, double* ms_out);
+void legion_collective_destroy(void);
+int32_t legion_cache_allreduce_hotness(LegionUnifiedCache* c, int32_t dev_id, double* ms_out);
+/* how the last candidate selection summed the counters of dev_id's clique: 0 nothing to sum / taken as given, 1 the leader loop
+ * over peer pointers, 2 an RCCL all-reduce issued by the library */
+int32_t legion_cache_hotness_reduce_path(const LegionUnifiedCache* c, int32_t dev_id);
 /* SS/cache/cache.cu:445-551; counters[2] = PCIe/xGMI transaction counts (zeros reproduce v2). */
 void legion_cache_cost_model(LegionUnifiedCache* c, LegionFeatureStorage* feature,
                              LegionGraphStorage* graph, const uint64_t* counters, int32_t train_step);
@@ -365,7 +379,7 @@ typedef struct LegionTuning {
     int32_t gather_rows_per_wg;  /* LEGION_GATHER_ROWS     (0 = by row width): rows per gather workgroup, 16|32|64|128|256 */
     int32_t col_slots;           /* LEGION_COL_SLOTS       (-1 auto): the {neighbour id, feature-cache slot} copy of the column array that
                                     lets the gather skip its node_map lookup (8 B per edge of HBM per GPU): 1 always, 0 never,
-                                    -1 when the column array is device memory and the copy fits a quarter of the free HBM */
+                                    -1 when the column array is device memory and the copy fits half of the HBM that is free after the fills, leaving 24 GB */
     int32_t split_sampler_cus;   /* LEGION_SPLIT_SAMPLER_CUS (0 = no CU mask): CUs of the sampler stream in split mode */
     int32_t split_priority;      /* LEGION_SPLIT_PRIORITY  (1): split mode, 1 sampler stream first, 0 equal, -1 gathers first */
     int32_t weave_priority;      /* LEGION_WEAVE_PRIORITY  (-1): weave arrangement, priority of the light stream (heads of the next group):
@@ -375,11 +389,13 @@ typedef struct LegionTuning {
     int32_t runner_pair;         /* LEGION_RUNNER_PAIR     (1): one hand-over launch for two batches when both pipe slots are free */
     int32_t runner_ho_stream;    /* LEGION_RUNNER_HO_STREAM (2): hand-over streams: 0 the sampler's, 1 one shared, 2 one per pipe slot */
     int32_t runner_stats;        /* LEGION_RUNNER_STATS    (0): print where a hand-over's time went at Finalize */
-    int32_t runner_handover;     /* LEGION_RUNNER_HANDOVER=auto|gather|copy -> 0|1|2: how the Runner's batches reach a trainer.  auto: whole
-                                    launch groups (sampler + full-width gathers) into per-lane buffers of one exported arena; a trainer end
-                                    that opened the arena gets a batch as VIEWS of its lane (no per-batch GPU work), any other gets a copy in
-                                    the pipe slot.  copy: the same pipeline, always copied.  gather: round 3's path (sampler phase in groups,
-                                    one gather launch per batch straight into the pipe slot) */
+    int32_t runner_handover;     /* LEGION_RUNNER_HANDOVER=auto|gather|copy -> 0|1|2: how the Runner's batches reach a trainer.  auto: the lanes of
+                                    the launch groups live in one exported arena; a trainer end that opened it gets a batch as VIEWS of its lane
+                                    (whole groups incl. full-width gathers, no per-batch GPU work), any other gets its rows gathered straight
+                                    into the pipe slot by one launch per batch.  gather: that for every trainer end.  copy: whole groups, one
+                                    copy launch per batch into the pipe slot (measured alternative) */
+    int32_t runner_slots;        /* LEGION_RUNNER_SLOTS    (3): launch groups the Runner keeps in flight (2..4): one being handed over, one
+                                    running, one queued behind it */
     int32_t peer_gather;         /* LEGION_PEER_GATHER=direct|bulk -> 0|1: rows of OTHER members' stripes of a striped feature cache are
                                     read by direct peer loads, or pulled owner by owner in bulk (hipMemcpyPeerAsync) */
     int32_t feature_pitch;       /* LEGION_FEATURE_PITCH=auto|dense|aligned -> -1|0|1: row pitch of the HBM-resident feature cache; aligned =

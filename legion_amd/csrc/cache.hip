@@ -16,6 +16,7 @@
 #include "legion_core.h"
 
 #include <algorithm>
+#include <atomic>
 #include <iostream>
 
 #define MIN_INTERVAL 0.01   // SS/cache/cache_impl.cuh:30
@@ -259,6 +260,9 @@ void UnifiedCache::CandidateSelection(int cache_agg_mode, FeatureStorage* featur
     for (void* p : AT_) d_free_space(p);
     QF_.clear(); QT_.clear(); AF_.clear(); AT_.clear();
 
+    hotness_reduce_path_.assign(Kc, 0);
+    hotness_reduce_ms_ = 0;
+    const int32_t how = lg::tuning().hotness_reduce;   // -1 auto, 0 the leader loop over peer pointers, 1 RCCL
     for (int32_t i = 0; i < Kc; i++) {
         int32_t lead = -1;                             // the clique leader; in a clique spread over processes
         for (int32_t j = 0; j < Kg && lead < 0; j++)   // every process leads with its own member
@@ -266,6 +270,40 @@ void UnifiedCache::CandidateSelection(int cache_agg_mode, FeatureStorage* featur
         if (lead < 0) {
             QF_.push_back(nullptr); AF_.push_back(nullptr); QT_.push_back(nullptr); AT_.push_back(nullptr);
             continue;
+        }
+        // The clique sum of the counters (cache.cu:408-411,428-431).  North star: an RCCL all-reduce over xGMI -- every member
+        // ends up with the sum, in place, and the leader sorts its own copy.  Possible when every member lives in this
+        // process on a physical GPU of its own (the reference's deployment: one server, a thread per GPU); logical GPUs that
+        // share a device (tests on one GPU) cannot form a communicator and keep the reference's leader loop.
+        bool reduced = world_reduced;
+        if (!world_reduced) {
+            std::vector<int32_t> devs;
+            for (int32_t j = 0; j < Kg; j++)
+                if (lg_is_local(i * Kg + j)) devs.push_back(i * Kg + j);
+            const bool all_local = (int32_t)devs.size() == Kg;
+            const bool distinct = all_local && lg::clique_is_physical(devs);
+            if (how == 1 && !distinct) {
+                printf("legion_hip: LEGION_HOTNESS_REDUCE=rccl, but the %d members of clique %d do not sit on %d distinct GPUs of this process\n", Kg, i, Kg);
+                exit(EXIT_FAILURE);
+            }
+            if (how == 1 || (how == -1 && distinct && Kg > 1)) {
+                double ms = 0;
+                for (int which = 0; which < 2; which++) {
+                    std::vector<unsigned long long*> bufs;
+                    for (int32_t d : devs)
+                        bufs.push_back(which == 0 ? cache_controller_[d]->GetNodeAccessedMap() : cache_controller_[d]->GetEdgeAccessedMap());
+                    ms += lg::allreduce_u64_clique(devs, bufs, N);
+                }
+                std::cout << "Hotness reduce on clique " << i << ": RCCL all-reduce (ncclUint64, ncclSum) over " << Kg << " GPU" << (Kg > 1 ? "s" : "")
+                          << ", 2 x " << N << " x 8 bytes per GPU, " << ms << " ms\n";
+                hotness_reduce_path_[i] = 2;
+                hotness_reduce_ms_ += ms;
+                reduced = true;
+            } else if (Kg > 1) {
+                std::cout << "Hotness reduce on clique " << i << ": leader loop over peer pointers ("
+                          << (all_local ? "its logical GPUs share physical devices" : "members in other processes") << ")\n";
+                hotness_reduce_path_[i] = 1;
+            }
         }
         SetGPUDevice(lead);
         for (int which = 0; which < 2; which++) {     // 0: node hotness -> QF/AF, 1: edge hotness -> QT/AT
@@ -276,7 +314,7 @@ void UnifiedCache::CandidateSelection(int cache_agg_mode, FeatureStorage* featur
             // When the counters were already all-reduced across processes (RCCL), every member
             // holds the clique sum: take the leader's copy once.
             for (int32_t j = 0; j < Kg; j++) {
-                if (world_reduced ? (i * Kg + j != lead) : !lg_is_local(i * Kg + j)) continue;
+                if (reduced ? (i * Kg + j != lead) : !lg_is_local(i * Kg + j)) continue;
                 CacheController* cc = cache_controller_[i * Kg + j];
                 lg::aggregate_access(nullptr, agg, which == 0 ? cc->GetNodeAccessedMap() : cc->GetEdgeAccessedMap(), N);
             }
@@ -399,9 +437,25 @@ void UnifiedCache::FillUp(int cache_agg_mode, FeatureStorage* feature, GraphStor
 
 void UnifiedCache::FillUpLocal(FeatureStorage* feature, GraphStorage* graph)
 {
+    {   // a new fill: pairs built from the previous node_map (of this or any other cache) are stale from here on
+        static std::atomic<uint64_t> next_uid{1};
+        if (uid_ == 0) uid_ = next_uid.fetch_add(1);
+        fill_generation_++;
+        for (int32_t d = 0; d < device_count_; d++)
+            if (lg_is_local(d)) graph->DropColumnSlots(d);
+    }
     const int32_t N = feature->TotalNodeNum();
     float* cpu_float_feature = feature->GetAllFloatFeature();
     cpu_float_features_ = cpu_float_feature;
+    {   // row pitch of the stripes (LegionTuning.feature_pitch): dense, or rounded up to whole 128-byte lines
+        const int32_t mode = lg::tuning().feature_pitch;
+        const int32_t aligned = (int32_t)((((int64_t)float_feature_len_ * 4 + 127) / 128 * 128) / 4);
+        cache_pitch_ = float_feature_len_;
+        if (mode == 1) cache_pitch_ = aligned;
+        // auto: dense.  Measured (profiles/r04/gather_pitch.md): a row that is not a whole number of 128-byte lines costs the
+        // same lines at either pitch -- 400 bytes at any 16-byte offset cover exactly four -- so padding buys nothing.
+    }
+    const int32_t pitch = CachePitch();
     for (int32_t i = 0; i < Kc_; i++)
         for (int32_t j = 0; j < Kg_; j++) {
             const int32_t dev_id = i * Kg_ + j;
@@ -413,9 +467,9 @@ void UnifiedCache::FillUpLocal(FeatureStorage* feature, GraphStorage* graph)
             d_float_feature_cache_ptr_[dev_id] = (float**)d_alloc_space(device_count_ * sizeof(float*));
             if (float_feature_len_ > 0) {                      // this member's stripe: rows QF[r*Kg + j]
                 d_free_space(float_feature_cache_[dev_id]);
-                float* new_cache = (float*)d_alloc_space((int64_t)node_capacity_[i] * float_feature_len_ * sizeof(float));
+                float* new_cache = (float*)d_alloc_space((int64_t)node_capacity_[i] * pitch * sizeof(float));
                 lg::feat_fill_up(nullptr, node_capacity_[i], float_feature_len_, new_cache, cpu_float_feature,
-                                 QF_[i], Kg_, j, N);
+                                 QF_[i], Kg_, j, N, pitch);
                 HIP_CALL(hipDeviceSynchronize());
                 float_feature_cache_[dev_id] = new_cache;
                 // hot-row replica: ranks 0 .. R-1 of the clique order, identical on every member (Kg = 1 addressing)
@@ -424,11 +478,11 @@ void UnifiedCache::FillUpLocal(FeatureStorage* feature, GraphStorage* graph)
                 replica_[dev_id] = nullptr;
                 replica_rows_[dev_id] = 0;
                 if (replica_bytes_ > 0 && Kg_ > 1) {
-                    int64_t rows = replica_bytes_ / ((int64_t)float_feature_len_ * sizeof(float));
+                    int64_t rows = replica_bytes_ / ((int64_t)pitch * sizeof(float));
                     rows = std::min<int64_t>(rows, std::min<int64_t>((int64_t)node_capacity_[i] * Kg_, N));
                     if (rows > 0) {
-                        replica_[dev_id] = (float*)d_alloc_space(rows * float_feature_len_ * sizeof(float));
-                        lg::feat_fill_up(nullptr, (int32_t)rows, float_feature_len_, replica_[dev_id], cpu_float_feature, QF_[i], 1, 0, N);
+                        replica_[dev_id] = (float*)d_alloc_space(rows * pitch * sizeof(float));
+                        lg::feat_fill_up(nullptr, (int32_t)rows, float_feature_len_, replica_[dev_id], cpu_float_feature, QF_[i], 1, 0, N, pitch);
                         HIP_CALL(hipDeviceSynchronize());
                         replica_rows_[dev_id] = (int32_t)rows;
                     }
@@ -460,7 +514,7 @@ void UnifiedCache::FillUpLink(FeatureStorage* feature, GraphStorage* graph)
         SetGPUDevice(i);
         HIP_CALL(hipDeviceSynchronize());
         // column slots: with the id -> slot map of this GPU final, pair the column array with it (legion_core.h, GraphStorage)
-        if (QF_[i / Kg_] != nullptr && float_feature_len_ > 0) graph->BuildColumnSlots(i, cache_controller_[i]->NodeMap());
+        if (QF_[i / Kg_] != nullptr && float_feature_len_ > 0) graph->BuildColumnSlots(i, cache_controller_[i]->NodeMap(), FillStamp());
     }
 }
 
@@ -521,6 +575,7 @@ void UnifiedCache::FeatCacheLookup(const LanePtrs* d_lanes, int32_t n_lanes, int
     g.node_map = filled ? cache_controller_[dev_id]->NodeMap() : nullptr;
     g.node_capacity = filled ? NodeCapacity(dev_id) : 1;
     g.D = float_feature_len_;
+    g.cache_pitch = CachePitch();
     g.total_num_nodes = total_num_nodes_;
     g.max_rows = max_rows;
     g.hop = use_snapshot ? op_id / INTRABATCH_CON : -1;
@@ -614,6 +669,32 @@ extern "C" void legion_cache_candidate_selection(LegionUnifiedCache* c, int32_t 
     if (!u) { printf("invalid cache ptr\n"); return; }
     u->world_reduced = world_reduced != 0;
     u->CandidateSelection(cache_agg_mode, nullptr, reinterpret_cast<GraphStorage*>(graph));
+}
+
+// One process per GPU: all-reduce (RCCL, the process-wide communicator of legion_collective_init_rank) of GPU dev_id's two
+// access-counter arrays in place; returns the world size the collective ran over (0: no communicator).  Afterwards call
+// legion_cache_candidate_selection(..., world_reduced = 1).
+extern "C" int32_t legion_collective_allreduce_u64(void* devptr, int64_t count, double* ms_out);
+extern "C" int32_t legion_cache_allreduce_hotness(LegionUnifiedCache* c, int32_t dev_id, double* ms_out)
+{
+    UnifiedCache* u = as_cache(c);
+    if (!u || !u->Controller(dev_id)) { printf("invalid cache ptr\n"); return 0; }
+    double ms = 0, total = 0;
+    int32_t world = legion_collective_allreduce_u64(u->Controller(dev_id)->GetNodeAccessedMap(), u->total_num_nodes_, &ms);
+    total += ms;
+    if (world > 0) world = legion_collective_allreduce_u64(u->Controller(dev_id)->GetEdgeAccessedMap(), u->total_num_nodes_, &ms);
+    total += ms;
+    if (ms_out) *ms_out = total;
+    return world;
+}
+// how the last candidate selection summed the counters of dev_id's clique: 0 nothing to sum / as given, 1 leader loop over
+// peer pointers, 2 RCCL all-reduce inside the library
+extern "C" int32_t legion_cache_hotness_reduce_path(const LegionUnifiedCache* c, int32_t dev_id)
+{
+    const UnifiedCache* u = as_cache(c);
+    if (!u || u->hotness_reduce_path_.empty()) return 0;
+    const int32_t clique = dev_id / (u->Kg_ > 0 ? u->Kg_ : 1);
+    return clique < (int32_t)u->hotness_reduce_path_.size() ? u->hotness_reduce_path_[clique] : 0;
 }
 
 extern "C" void legion_cache_cost_model(LegionUnifiedCache* c, LegionFeatureStorage* feature,

@@ -209,11 +209,11 @@ __global__ __launch_bounds__(LG_GATHER_THREADS, LG_GATHER_MIN_WAVES) void gather
             const int64_t rank = (int64_t)fidx * gp.Kg + didx;                               // hotness rank of the row (cache_impl.cuh:104-109)
             const bool local_copy = gp.replica != nullptr && rank < gp.replica_rows;
             if (local_copy)      // the clique's hottest rows are also kept locally: same row, no xGMI hop
-                p = LG_GPTR(const float, gp.replica) + rank * D;
+                p = LG_GPTR(const float, gp.replica) + rank * gp.cache_pitch;
             else if (didx == gp.member && gp.local_table != nullptr)     // own stripe: its address came with the launch
-                p = LG_GPTR(const float, gp.local_table) + (int64_t)fidx * D;
+                p = LG_GPTR(const float, gp.local_table) + (int64_t)fidx * gp.cache_pitch;
             else
-                p = LG_GPTR(const float, gp.cache_tables[didx]) + (int64_t)fidx * D;                               // :268
+                p = LG_GPTR(const float, gp.cache_tables[didx]) + (int64_t)fidx * gp.cache_pitch;                  // :268
             if (counting) {    // tests / diagnostics / the computed xGMI count: [0] rows read through a stripe pointer, [1] from the
                                // replica, [2] the part of [0] from a peer's stripe -- one atomic per wave and counter
                 const unsigned long long m_rep = __ballot(local_copy), m_str = __ballot(!local_copy);
@@ -342,6 +342,7 @@ static void launch_gather_impl(hipStream_t s, GatherParams g, const LanePtrs* d_
 {
     if (g.D <= 0 || g.max_rows <= 0) return;            // :256 float_feature_len > 0
     if (g.node_capacity < 1) g.node_capacity = 1;
+    if (g.cache_pitch < g.D) g.cache_pitch = g.D;
     const dim3 grid(gather_grid_x(g.max_rows, LG_GATHER_ROWS, n_lanes), n_lanes);     // (the 4-byte vector path, and 64-row tiles at dword alignment)
     const LegionTuning& tune = tuning();
     if (g.D % 4 == 0) {

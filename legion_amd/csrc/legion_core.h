@@ -187,6 +187,8 @@ enum HopScratch {
 // "weave" arrangement (pipeline.hip): the group cut where its character changes
 #define LG_PHASE_HEAD 3     // BatchGenerate + every hop but the last, complete: small, latency-bound kernels
 #define LG_PHASE_REST 4     // the last hop (sample .. localise) + IOComplete + every gather, in that order
+#define LG_PHASE_REST_SAMPLE 5   // LG_PHASE_REST without the gathers (GPURunner serving a trainer end that gets its rows gathered
+                                 // batch by batch straight into a pipe slot)
 
 // Feature-cache slot of a sampled neighbour, carried from the sampler to the gather (see "column slots", GraphStorage):
 // a value >= 0 or CACHEMISS_FLAG is what node_map[id] holds; LG_FS_UNKNOWN means "not carried: look it up"
@@ -412,8 +414,14 @@ public:
     // paired: their picks carry LG_FS_UNKNOWN and the gather looks those rows up as before.
     virtual int32_t** GetCSRXMatrix(int32_t part_id) const = 0;       // device table [P+1] of pair arrays (null entries), or null
     virtual const int32_t* GetColumnSlotsFull(int32_t part_id) const = 0;   // that GPU's pair copy of the full column array, or null
-    virtual void BuildColumnSlots(int32_t dev, const int32_t* node_map) = 0;
+    // The pairs are only as good as the node_map they were built from: they carry the stamp (cache uid, fill generation) of
+    // that fill, and the sampler is given them only by a cache whose CURRENT fill has the same stamp (ColumnSlotsStamp) -- a
+    // re-fill with other capacities, or another cache object over the same graph, samples from the plain column array and
+    // the gather looks the slots up (a stale carried slot would address a wrong or out-of-range cache row).  Launch groups
+    // captured into hipGraphs hold these pointers: destroy pipelines before re-filling a cache.
+    virtual void BuildColumnSlots(int32_t dev, const int32_t* node_map, uint64_t stamp = 0) = 0;
     virtual void DropColumnSlots(int32_t dev) = 0;
+    virtual uint64_t ColumnSlotsStamp(int32_t dev) const = 0;     // stamp of the fill the pairs belong to; 0: none built
     // GraphCache in two steps, so that a clique spread over processes can exchange the stripes in
     // between: build the cached CSR of every LOCAL member, then link every known member's CSR into the
     // local members' pointer tables and row headers.  SetPeerCSR registers a member owned by another
@@ -509,6 +517,7 @@ public:
     void SetReplicaMemory(int64_t bytes) { replica_bytes_ = bytes; }
     int32_t ReplicaRows(int32_t dev_id) const { return replica_rows_.empty() ? 0 : replica_rows_[dev_id]; }
     int32_t FloatFeatureLen() const { return float_feature_len_; }
+    int32_t CachePitch() const { return cache_pitch_ > 0 ? cache_pitch_ : float_feature_len_; }   // floats per row of a stripe
     bool gather_stats_on_ = true;        // GatherStats() arms the counters; SetGatherStats pauses them (a device word: graphs follow)
     void SetGatherStats(bool on);
     unsigned long long* GatherStats(int32_t dev_id);   // device {stripe rows, replica rows, peer-stripe rows}, allocated on first use
@@ -528,7 +537,13 @@ public:
     int32_t EdgeCapacity(int32_t dev_id) const;
     CacheController* Controller(int32_t dev_id) const { return cache_controller_[dev_id]; }
     bool IsPresc() const { return is_presc_; }
+    // (uid of this cache object, generation of its latest FillUpLocal): what column slots built from its node_map carry
+    uint64_t FillStamp() const { return (uid_ << 24) | (fill_generation_ & 0xFFFFFFu); }
     bool world_reduced = false;   // hotness already all-reduced across processes (RCCL)
+    // how the last CandidateSelection summed the counters of each clique: 0 nothing to sum / taken as they are, 1 the leader
+    // loop over peer pointers, 2 RCCL all-reduce; and the milliseconds the RCCL calls took
+    std::vector<int32_t> hotness_reduce_path_;
+    double hotness_reduce_ms_ = 0;
     int32_t total_num_nodes_ = 0;
     int32_t Kc_ = 1, Kg_ = 1;
     int cache_agg_mode_ = 0;
@@ -545,6 +560,8 @@ private:
     std::vector<float*> float_feature_cache_;
     std::vector<float**> d_float_feature_cache_ptr_;
     int32_t float_feature_len_ = 0;
+    uint64_t uid_ = 0, fill_generation_ = 0;
+    int32_t cache_pitch_ = 0;             // floats per row of the feature-cache stripes and the replica (0: dense)
     float* cpu_float_features_ = nullptr;
     bool is_presc_ = true;
     std::vector<int32_t> peer_max_ids_;   // MaxIdNum of every clique member when they live in other processes
@@ -746,6 +763,7 @@ struct GatherParams {
     const int32_t* node_map;
     int32_t node_capacity;
     int32_t D;
+    int32_t cache_pitch;            // floats between consecutive rows of a cache stripe / the replica (>= D; the full table is always dense)
     int32_t total_num_nodes;
     int32_t max_rows;               // grid bound: rows any lane can have for this op
     int32_t hop;                    // >= 0: take the range from hop_scratch[HS_RANGE + 2*hop] (snapshot that later
@@ -784,6 +802,10 @@ void launch_find(hipStream_t s, const int32_t* keys, int32_t n, const int32_t* m
                  const char* map8, int32_t* out32, char* out8);
 void launch_draw_batch(hipStream_t s, const int32_t* idx, const int32_t* deg, int32_t* out, int32_t n);
 
+// the hotness all-reduce (collective.hip): RCCL over the members of a clique that live in this process
+bool clique_is_physical(const std::vector<int32_t>& devs);
+double allreduce_u64_clique(const std::vector<int32_t>& devs, const std::vector<unsigned long long*>& bufs, int64_t count);
+
 // set-up kernels (kernels_cache.hip)
 void aggregate_access(hipStream_t s, unsigned long long* agg, const unsigned long long* add, int32_t n);
 void sort_hotness_desc(hipStream_t s, unsigned long long* keys_inout, int32_t* order_out, int32_t n);
@@ -798,7 +820,7 @@ void fill_value_i32(hipStream_t s, int32_t* p, int32_t v, int64_t n);
 void build_column_slots(hipStream_t s, const int32_t* col, const int32_t* node_map, int32_t* colx_pairs, int64_t num_edges);
 void fill_value_i8(hipStream_t s, char* p, char v, int64_t n);
 void feat_fill_up(hipStream_t s, int32_t capacity, int32_t D, float* cache, const float* table,
-                  const int32_t* QF, int32_t Kg, int32_t Ki, int32_t n);
+                  const int32_t* QF, int32_t Kg, int32_t Ki, int32_t n, int32_t pitch = 0);
 void topo_neighbor_count(hipStream_t s, const int32_t* QT, int32_t Kg, int32_t Ki, int32_t capacity,
                          int32_t n, const int64_t* csr_index, int64_t* counts);
 void inclusive_scan_i64(hipStream_t s, const int64_t* in, int64_t* out, int32_t n);

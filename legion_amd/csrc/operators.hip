@@ -110,7 +110,10 @@ static void do_random_sample(hipStream_t s, GraphStorage* graph, UnifiedCache* c
     p.count = count;
     p.partition_count = graph->GetPartitionCount();
     p.csr_dst_node_ids = graph->GetCSRNodeMatrix(dev_id);
-    p.csr_dst_x = (is_presc || pool0->slot_fs == nullptr) ? nullptr : graph->GetCSRXMatrix(dev_id);
+    // column slots only from the fill of THIS cache that built them (legion_core.h GraphStorage::BuildColumnSlots)
+    const bool pairs_ok = !is_presc && pool0->slot_fs != nullptr && cache != nullptr && graph->ColumnSlotsStamp(dev_id) != 0 &&
+                          graph->ColumnSlotsStamp(dev_id) == cache->FillStamp();
+    p.csr_dst_x = pairs_ok ? graph->GetCSRXMatrix(dev_id) : nullptr;
     p.col_full = graph->GetCSRNodeMatrixCPU();
     p.colx_full = p.csr_dst_x != nullptr ? graph->GetColumnSlotsFull(dev_id) : nullptr;
     p.row_hdr = graph->GetRowHeaders(dev_id);
@@ -323,6 +326,7 @@ extern "C" void legion_gather_rows(legion_stream_t stream, const float* full_tab
     g.node_map = node_map;
     g.node_capacity = node_capacity;
     g.D = float_feature_len;
+    g.cache_pitch = float_feature_len;
     g.total_num_nodes = total_num_nodes;
     g.max_rows = max_rows;
     lg::launch_gather_explicit(static_cast<hipStream_t>(stream), g, sampled_ids, cache_index_out, range_devptr, dst,
@@ -362,6 +366,7 @@ static void enqueue_lanes(hipStream_t s, GraphStorage* graph, FeatureStorage* fe
         } else {
             if (last >= 0) do_random_sample(s, graph, cache, d_lanes, n_lanes, pool0, fanout[last], dev_id, INTRABATCH_CON * (last + 1), false);
             lg::launch_end_of_batch(s, d_lanes, n_lanes, iter_state, pool_state_bytes(pool0));
+            if (phase == LG_PHASE_REST_SAMPLE) return;
             if (!seeds_ride) do_feature_lookup(s, cache, d_lanes, n_lanes, pool0, 1, dev_id, true);
             for (int32_t h = 0; h <= last; h++)
                 do_feature_lookup(s, cache, d_lanes, n_lanes, pool0, INTRABATCH_CON * (h + 1) + 1, dev_id, true,

@@ -63,6 +63,7 @@ struct LegionPipeline {
     bool overlap = false;   // let kernels of different slots run concurrently (default: chained)
     bool split = false;     // sampler and gather phases on two streams (see the header comment)
     bool weave = false;     // head of group k+1 on a second stream under the heavy kernels of group k (see submit)
+    bool gathers = true;        // weave: false = the REST phase stops before the gathers (legion_pipeline_set_gathers)
     bool sample_only = false;   // only the sampler phase runs here; the owner gathers each lane itself (GPURunner: straight
                                 // into a trainer-visible pipe slot)
     hipStream_t sample_stream = nullptr;
@@ -249,7 +250,7 @@ extern "C" void legion_pipeline_prepare(LegionPipeline* p, int32_t mode, int32_t
         legion_group_set_iter_state(sl.group, sl.d_iter);
         if (p->weave) {
             (void)graph_of(p, sl, p->sample_stream, LG_PHASE_HEAD, mode, n_active, batch_size);
-            (void)graph_of(p, sl, sl.stream, LG_PHASE_REST, mode, n_active, batch_size);
+            (void)graph_of(p, sl, sl.stream, p->gathers ? LG_PHASE_REST : LG_PHASE_REST_SAMPLE, mode, n_active, batch_size);
             continue;
         }
         (void)graph_of(p, sl, p->split ? p->sample_stream : sl.stream, first_phase, mode, n_active, batch_size);
@@ -332,7 +333,7 @@ extern "C" int32_t legion_pipeline_submit_ex(LegionPipeline* p, int32_t counter0
         run(Y, LG_PHASE_HEAD);
         HIP_CALL(hipEventRecord(sl.sampled, Y));
         HIP_CALL(hipStreamWaitEvent(X, sl.sampled, 0));
-        run(X, LG_PHASE_REST);
+        run(X, p->gathers ? LG_PHASE_REST : LG_PHASE_REST_SAMPLE);
         if (eager) {
             sl.next_iter = -1;
             sl.prof_pairs = sl.pools[0]->prof_used;
@@ -394,6 +395,10 @@ extern "C" LegionMemoryPool* legion_pipeline_pool(LegionPipeline* p, int32_t slo
     if (!p) return nullptr;
     return reinterpret_cast<LegionMemoryPool*>(p->slots[slot % p->slots_n].pools[lane % p->group_size]);
 }
+
+// weave arrangement: whether the groups submitted (and the graphs prepared) from now on include their gathers.  GPURunner
+// switches them off when the trainer end it serves gets its rows gathered batch by batch straight into a pipe slot.
+extern "C" void legion_pipeline_set_gathers(LegionPipeline* p, int32_t on) { if (p) p->gathers = on != 0; }
 
 // device address of the LanePtrs of (slot, lane)
 extern "C" const void* legion_pipeline_lane_desc(LegionPipeline* p, int32_t slot, int32_t lane)

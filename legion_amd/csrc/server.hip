@@ -23,6 +23,7 @@
 #include <chrono>
 #include <atomic>
 #include <cstring>
+#include <deque>
 #include <map>
 #include <fstream>
 #include <iostream>
@@ -305,6 +306,7 @@ extern "C" LegionMemoryPool* legion_pipeline_pool(LegionPipeline* p, int32_t slo
 extern "C" void legion_pipeline_destroy(LegionPipeline* p);
 extern "C" void legion_pipeline_wait(LegionPipeline* p, int32_t slot);
 extern "C" const void* legion_pipeline_lane_desc(LegionPipeline* p, int32_t slot, int32_t lane);
+extern "C" void legion_pipeline_set_gathers(LegionPipeline* p, int32_t on);
 
 class GPURunner : public Runner {
 public:
@@ -422,13 +424,25 @@ public:
     }
 
     // SS/engine/server.cu:302-332.  The reference produces ONE mini-batch per call, ~16 launches and three blocking
-    // read-backs each.  Here a call hands ONE batch over (same semaphores, same two pipe slots, same order), but the
-    // batches are PRODUCED in launch groups: the sampler phase of G consecutive batches runs as one hipGraph replay
-    // over G internal lanes (pipeline.hip, grid.y = G); per call ONE launch gathers the lane's feature rows straight into
-    // the free pipe slot's buffer and copies its ids / edges / labels / counters there (deliver_slice in gather_kernel).  A
-    // poster thread polls the batch's event and posts it, so this thread never blocks on the GPU and a finished
-    // batch never waits for the trainer to release another slot.  LEGION_RUNNER_GRAPH=0: the operator-by-operator
-    // path of the reference (one batch per call, eager launches).
+    // read-backs each.  Here a call still hands ONE batch over -- in order, through the same two semaphores per pipe slot --
+    // but the batches are PRODUCED in launch groups (pipeline.hip: every kernel runs with grid.y = lanes, a group is one
+    // hipGraph replay per stream), up to three groups in flight, into per-lane buffers that all live in ONE exported device
+    // allocation, the lane arena.  How a finished batch reaches the trainer end (LegionTuning.runner_handover):
+    //   views   the trainer end opened the arena (this build's ipc_service says so before its first sem_post): the group ran
+    //           the whole path, full-width gathers included -- the arrangement bench.py times -- and the hand-over is a few
+    //           host stores (where the batch's five arrays start inside the arena, its counters) and sem_post.  No GPU work
+    //           per batch at all.
+    //   gather  any other trainer end (it opens only the reference's slab): the groups run the sampler phase; per batch ONE
+    //           launch gathers the lane's rows straight into the pipe slot's feature buffer and copies its ids / edges /
+    //           labels / counters there (deliver_slice in gather_kernel).  Bound by the launch -> completion latency of one
+    //           small kernel with two slots in flight.
+    //   copy    (only when asked for) the groups run the whole path; per batch one pure copy launch moves the finished batch
+    //           from its lane into the pipe slot.  Measured slower than `gather` at every batch size (the rows cross HBM
+    //           twice): kept as the measured alternative.
+    // A slot's lanes are reused by a later group only when the trainer has RELEASED every batch of the group that used
+    // them (a view is read in place; a copied / gathered batch was posted before it was released): the semaphore token that
+    // lets batch k through says batch k-2 was released.  LEGION_RUNNER_GRAPH=0: the operator-by-operator path of the
+    // reference (one batch per call, eager launches).
     void RunOnce(RunnerParams* params) override
     {
         SetGPUDevice(local_dev_id_);
@@ -452,122 +466,35 @@ public:
             return;
         }
         if (pipe_ == nullptr) PrepareServing(params);
-        if (lanes_mode_) { RunOnceLanes(params); return; }
-        if (pair_pending_) {                       // this batch went out together with the previous one (one launch, both slots)
-            pair_pending_ = false;
-            if (batch_id % 1000 == 0 && local_dev_id_ == 0) std::cout << "batch id: " << batch_id << "\n";
-            current_pipe_ = (current_pipe_ + 1) % interbatch_concurrency_;
-            return;
-        }
-        if (cur_slot_ < 0 || batch_id >= cur_first_ + cur_n_) {           // this call opens a new group
-            if (next_slot_ >= 0 && next_first_ == batch_id) {
-                cur_slot_ = next_slot_; cur_first_ = next_first_; cur_n_ = next_n_;
-                next_slot_ = -1;
-            } else {
-                SubmitGroup(env, batch_id, cur_slot_, cur_first_, cur_n_);
-            }
-            // the hand-over stream may touch this group's lanes once its sampler phase has finished
-            for (int i = 0; i < 2; i++)
-                if (ho_streams_[i] != nullptr)
-                    HIP_CALL(hipStreamWaitEvent(ho_streams_[i], (hipEvent_t)legion_pipeline_slot_done_event(pipe_, cur_slot_), 0));
-        }
-        const int32_t lane = batch_id - cur_first_;
-        // the next group's sampler is queued while this group is still being handed over: the GPU never idles
-        // between groups, and by the time its first batch is due it has long finished
-        if (next_slot_ < 0 && lane >= cur_n_ / 2 && cur_first_ + cur_n_ < max_step_)
-            SubmitGroup(env, cur_first_ + cur_n_, next_slot_, next_first_, next_n_);
+        const int32_t k = batch_id;
+        const int p = current_pipe_;
         const auto t_a = std::chrono::steady_clock::now();
-        const int p = current_pipe_, p2 = (p + 1) % interbatch_concurrency_;
         {   // the trainer has released this slot?  Poll for a short while (a futex wake costs more than a small batch's
             // GPU time) before blocking
             bool got = false;
             for (int spin = 0; spin < 20000 && !got; spin++) got = env->IPCTryWait(local_dev_id_, p);
             if (!got) env->IPCWait(local_dev_id_, p);
         }
-        // A hand-over launch of one small batch is latency-bound (~18 us for 31 k rows, against 5.5 us per batch inside a
-        // 128-lane launch): when the next batch belongs to this group and ITS slot is free too, one launch serves both
-        int32_t n_out = 1;
-        if (pair_ && lane + 1 < cur_n_ && env->IPCTryWait(local_dev_id_, p2)) n_out = 2;
         const auto t_b = std::chrono::steady_clock::now();
-        // hand-overs run on their own (high-priority) stream: queued behind the next group's sampler phase on ONE stream
-        // they stalled for its whole duration once per group, the trainer starving meanwhile
-        hipStream_t s = ho_streams_[p % 2] != nullptr ? ho_streams_[p % 2] : static_cast<hipStream_t>(legion_pipeline_stream(pipe_));
-        const int par = (p + lane) % interbatch_concurrency_;           // pipe of lane g = (par + g) % 2
-        const LanePtrs* desc = d_desc_ + ((size_t)par * 2 + cur_slot_) * lanes_ + lane;
-        UnifiedCache* cache = (UnifiedCache*)(params->cache);
-        const int64_t max_rows = std::min<int64_t>(memorypool_->feature_rows, memorypool_->num_ids);
-        if (float_feature_len_ > 0 && max_rows > 0)   // one launch: gather of every row of the batch(es) + the hand-over copies
-            cache->FeatCacheLookup(desc, n_out, INTRABATCH_CON * hop_num_ + 1, local_dev_id_, s, (int32_t)max_rows, true, 1);
-        else
-            for (int k = 0; k < n_out; k++) lg::launch_deliver(s, desc + k, deliver_[(p + k) % interbatch_concurrency_]);
-        for (int k = 0; k < n_out; k++) {
-            const int pk = (p + k) % interbatch_concurrency_;
-            HIP_CALL(hipEventRecord(batch_done_[pk], s));
-            // single producer (this thread), single consumer (the poster): at most INTERBATCH_CON jobs are outstanding
-            // (a slot is only reused after the trainer released it, i.e. after its previous job was posted)
-            const uint32_t t = q_tail_.load(std::memory_order_relaxed);
-            ring_[t % kRing] = {batch_done_[pk], pk, reinterpret_cast<MemoryPool*>(legion_pipeline_pool(pipe_, cur_slot_, lane + k)),
-                                std::chrono::steady_clock::now()};
-            q_tail_.store(t + 1, std::memory_order_release);
-        }
-        pair_pending_ = n_out == 2;
-        if (ho_streams_[0] != nullptr && lane + n_out >= cur_n_) {   // the group's lanes are free again once these have run
-            for (int i = 0; i < 2; i++) HIP_CALL(hipEventRecord(ho_done_[cur_slot_][i], ho_streams_[i]));
-            ho_done_valid_[cur_slot_] = true;
-        }
-        if (stats_) {
-            const auto t_c = std::chrono::steady_clock::now();
-            st_wait_ += std::chrono::duration<double>(t_b - t_a).count();
-            st_launch_ += std::chrono::duration<double>(t_c - t_b).count();
-            st_n_++;
-            st_pairs_ += n_out == 2;
-        }
-        if (batch_id % 1000 == 0 && local_dev_id_ == 0) std::cout << "batch id: " << batch_id << "\n";
-        current_pipe_ = (current_pipe_ + 1) % interbatch_concurrency_;
-    }
-
-    // The "lanes" hand-over (round 4, LegionTuning.runner_handover = auto | copy).  Whole launch groups -- sampler AND the
-    // full-width gathers, the arrangement bench.py times -- run into per-lane buffers that live in ONE exported device
-    // allocation (the lane arena).  A call still hands ONE batch over, in order, through the same two semaphores per pipe slot:
-    //   * trainer end that opened the arena (this build's ipc_service): the hand-over is a few host stores -- where the five
-    //     arrays of the batch start inside the arena, its counters -- and sem_post.  No GPU work per batch at all.
-    //   * any other trainer end: one pure copy launch moves the finished batch into the pipe slot's buffers.
-    // Lanes are reused by a later group only after the trainer has RELEASED every batch of the group that used them (a view
-    // is read in place): the semaphore token that lets batch k through says batch k-2 was released, so the next group may be
-    // submitted from the second batch of the current one on -- the GPU works on group g+1 while group g is handed over.
-    void RunOnceLanes(RunnerParams* params)
-    {
-        IPCEnv* env = (IPCEnv*)(params->env);
-        const int32_t k = params->global_batch_id;
-        const int p = current_pipe_;
-        const auto t_a = std::chrono::steady_clock::now();
-        {
-            bool got = false;
-            for (int spin = 0; spin < 20000 && !got; spin++) got = env->IPCTryWait(local_dev_id_, p);
-            if (!got) env->IPCWait(local_dev_id_, p);
-        }
-        const auto t_b = std::chrono::steady_clock::now();
-        if (!direct_decided_) {                 // the trainer end said what it is before its first sem_post
-            direct_ = handover_ == 0 && env->TrainerTakesViews(local_dev_id_);
-            direct_decided_ = true;
-            std::cout << "runner " << local_dev_id_ << ": hand-over by " << (direct_ ? "views of the lane arena" : "copy into the pipe slots")
-                      << ", " << lanes_ << " lanes per group\n" << std::flush;
-        }
-        if (cur_slot_ < 0 || k >= cur_first_ + cur_n_) {                  // this call opens a new group
-            if (next_slot_ >= 0 && next_first_ == k) {
-                cur_slot_ = next_slot_; cur_first_ = next_first_; cur_n_ = next_n_;
-                next_slot_ = -1;
+        if (kind_ == KIND_UNDECIDED) DecideHandover(env);       // the trainer end said what it is before its first sem_post
+        while (!groups_.empty() && k >= groups_.front().first + groups_.front().n) groups_.pop_front();
+        SubmitWhatFits(env, k);                                  // token k consumed => batches <= k-2 are released
+        if (groups_.empty() || k < groups_.front().first) { printf("legion_hip: runner lost track of its groups\n"); exit(EXIT_FAILURE); }
+        Group& g = groups_.front();
+        if (!g.complete) {
+            if (kind_ == KIND_GATHER) {
+                // the hand-over streams may touch this group's lanes once its sampler phase has finished
+                for (int i = 0; i < 2; i++)
+                    if (ho_streams_[i] != nullptr)
+                        HIP_CALL(hipStreamWaitEvent(ho_streams_[i], (hipEvent_t)legion_pipeline_slot_done_event(pipe_, g.slot), 0));
             } else {
-                SubmitGroup(env, k, cur_slot_, cur_first_, cur_n_);
+                legion_pipeline_wait(pipe_, g.slot);             // the group has completed on the GPU
             }
-            legion_pipeline_wait(pipe_, cur_slot_);                       // the group has completed on the GPU
+            g.complete = true;
         }
-        const int32_t lane = k - cur_first_;
-        // token k consumed => batch k-2 released => every batch of the group before this one is released once lane >= 1
-        if (next_slot_ < 0 && lane >= 1 && cur_first_ + cur_n_ < max_step_)
-            SubmitGroup(env, cur_first_ + cur_n_, next_slot_, next_first_, next_n_);
-        MemoryPool* lp = reinterpret_cast<MemoryPool*>(legion_pipeline_pool(pipe_, cur_slot_, lane));
-        if (direct_) {
+        const int32_t lane = k - g.first;
+        MemoryPool* lp = reinterpret_cast<MemoryPool*>(legion_pipeline_pool(pipe_, g.slot, lane));
+        if (kind_ == KIND_VIEWS) {
             ReportErrors(lp);
             const LanePtrs h = lp->HostLane(0);
             const int64_t off[5] = {(char*)h.sampled_ids - arena_.base, (char*)h.float_features - arena_.base, (char*)h.labels - arena_.base,
@@ -575,11 +502,23 @@ public:
             env->SetView(local_dev_id_, p, off, lp->counter_mirror_host);
             env->IPCPost(local_dev_id_, p);
         } else {
+            // hand-overs run on their own (high-priority) streams, one per pipe slot: the two in flight overlap on the GPU
             hipStream_t s = ho_streams_[p % 2] != nullptr ? ho_streams_[p % 2] : static_cast<hipStream_t>(legion_pipeline_stream(pipe_));
             const int64_t max_rows = std::min<int64_t>(memorypool_->feature_rows, memorypool_->num_ids);
-            lg::launch_handover_copy(s, static_cast<const LanePtrs*>(legion_pipeline_lane_desc(pipe_, cur_slot_, lane)), deliver_[p],
-                                     (int32_t)max_rows);
+            if (kind_ == KIND_COPY) {
+                lg::launch_handover_copy(s, static_cast<const LanePtrs*>(legion_pipeline_lane_desc(pipe_, g.slot, lane)), deliver_[p],
+                                         (int32_t)max_rows);
+            } else {
+                const LanePtrs* desc = d_desc_ + ((size_t)p * slots_ + g.slot) * lanes_ + lane;     // lane -> pipe slot p
+                UnifiedCache* cache = (UnifiedCache*)(params->cache);
+                if (float_feature_len_ > 0 && max_rows > 0)   // one launch: gather of every row of the batch + the hand-over copies
+                    cache->FeatCacheLookup(desc, 1, INTRABATCH_CON * hop_num_ + 1, local_dev_id_, s, (int32_t)max_rows, true, 1);
+                else
+                    lg::launch_deliver(s, desc, deliver_[p]);
+            }
             HIP_CALL(hipEventRecord(batch_done_[p], s));
+            // single producer (this thread), single consumer (the poster): at most INTERBATCH_CON jobs are outstanding
+            // (a slot is only reused after the trainer released it, i.e. after its previous job was posted)
             const uint32_t t = q_tail_.load(std::memory_order_relaxed);
             ring_[t % kRing] = {batch_done_[p], p, lp, std::chrono::steady_clock::now()};
             q_tail_.store(t + 1, std::memory_order_release);
@@ -594,25 +533,34 @@ public:
         current_pipe_ = (current_pipe_ + 1) % interbatch_concurrency_;
     }
 
-    // Everything serving needs that allocates, captures or instantiates -- lanes, descriptors, the first group's graph and
-    // its sampler phase -- done BEFORE the server announces itself: while trainers attach to the IPC buffers the server
+    // Everything serving needs that allocates, captures or instantiates -- lanes, descriptors, every group shape's graphs, the
+    // first groups' launches -- done BEFORE the server announces itself: while trainers attach to the IPC buffers the server
     // process then only launches kernels (concurrent allocation in the exporting process made hipIpcOpenMemHandle fail
-    // now and then with two trainers attaching at once, ROCm 7.2), and the first batch is ready when the trainer asks.
+    // now and then with two trainers attaching at once, ROCm 7.2), and the first batches are ready when the trainer asks.
     void PrepareServing(RunnerParams* params) override
     {
         if (!use_groups_ || pipe_ != nullptr) return;
         SetGPUDevice(local_dev_id_);
         IPCEnv* env = (IPCEnv*)(params->env);
         CreateGroups(params);
-        // every group shape of the whole schedule gets its graph now: no stream capture while the poster thread polls events
-        for (int32_t first = 0; first < max_step_;) {
-            int32_t mode = 0, local0 = 0;
-            const int32_t n = PlanGroup(env, first, mode, local0);
-            legion_pipeline_prepare(pipe_, mode, n, env->GetCurrentBatchsize(local_dev_id_, mode));
-            first += n;
+        // every group shape of the whole schedule gets its graphs now, with and without the gathers (which of the two runs is
+        // known only when the trainer end attaches): no stream capture while the poster thread polls events
+        for (int with_gathers = 0; with_gathers < 2; with_gathers++) {
+            if ((handover_ == 1 || !lane_features_) && with_gathers) continue;     // forced `gather` (or no features at all): the groups never gather
+            if (handover_ == 2 && lane_features_ && !with_gathers) continue;       // forced `copy`: they always do
+            legion_pipeline_set_gathers(pipe_, with_gathers);
+            for (int32_t first = 0; first < max_step_;) {
+                int32_t mode = 0, local0 = 0;
+                const int32_t n = PlanGroup(env, first, mode, local0);
+                legion_pipeline_prepare(pipe_, mode, n, env->GetCurrentBatchsize(local_dev_id_, mode));
+                first += n;
+            }
         }
+        // the first group runs now (with its gathers unless they are ruled out: a trainer end that takes views finds its first
+        // batches ready, any other finds them sampled -- its rows are gathered at hand-over either way)
+        legion_pipeline_set_gathers(pipe_, handover_ != 1 && lane_features_);
         if (max_step_ > 0) {
-            SubmitGroup(env, 0, cur_slot_, cur_first_, cur_n_);
+            SubmitNext(env);
             HIP_CALL(hipStreamSynchronize(static_cast<hipStream_t>(legion_pipeline_stream(pipe_))));
         }
     }
@@ -628,8 +576,8 @@ public:
         env->IPCWait(local_dev_id_, (current_pipe_ + 1) % interbatch_concurrency_);
         SetGPUDevice(local_dev_id_);
         if (stats_ && st_n_ > 0)   // LEGION_RUNNER_STATS=1: where a hand-over's time goes, averages per batch
-            std::cout << "runner " << local_dev_id_ << ": " << st_n_ << " hand-over launches (" << st_pairs_ << " of two batches); waiting for a free slot " << st_wait_ / st_n_ * 1e6
-                      << " us, launch calls " << st_launch_ / st_n_ * 1e6 << " us, enqueue -> completion seen "
+            std::cout << "runner " << local_dev_id_ << ": " << st_n_ << " hand-overs; waiting for a free slot " << st_wait_ / st_n_ * 1e6
+                      << " us, hand-over calls " << st_launch_ / st_n_ * 1e6 << " us, enqueue -> completion seen "
                       << st_gpu_ / st_n_ * 1e6 << " us\n";
         for (int i = 0; i < 2; i++) {
             if (ho_streams_[i] == nullptr) continue;
@@ -653,6 +601,8 @@ public:
 
 private:
     struct Pending { hipEvent_t ev; int pipe; MemoryPool* lane; std::chrono::steady_clock::time_point enqueued; };
+    struct Group { int slot; int32_t first, n; bool complete; };
+    enum { KIND_UNDECIDED = 0, KIND_VIEWS, KIND_GATHER, KIND_COPY };
 
     void ReportErrors(MemoryPool* mp)
     {
@@ -679,6 +629,20 @@ private:
         }
     }
 
+    // what the trainer end of this GPU is, known when the first semaphore token arrives
+    void DecideHandover(IPCEnv* env)
+    {
+        if (handover_ == 2) kind_ = KIND_COPY;
+        else if (handover_ == 0 && env->TrainerTakesViews(local_dev_id_)) kind_ = KIND_VIEWS;
+        else kind_ = KIND_GATHER;
+        // groups submitted from now on gather their rows only when somebody reads them from the lanes
+        legion_pipeline_set_gathers(pipe_, kind_ != KIND_GATHER && lane_features_);
+        std::cout << "runner " << local_dev_id_ << ": hand-over by "
+                  << (kind_ == KIND_VIEWS ? "views of the lane arena" : kind_ == KIND_COPY ? "copy into the pipe slots"
+                                                                                         : "one gather launch per batch into the pipe slots")
+                  << ", " << lanes_ << " lanes per group, " << slots_ << " groups in flight\n" << std::flush;
+    }
+
     // the largest group the schedule ever forms (consecutive batches of one mode with consecutive local ids)
     int32_t LargestGroup(IPCEnv* env, int32_t cap)
     {
@@ -694,7 +658,7 @@ private:
         return best;
     }
 
-    // G internal lanes x 2 groups in flight + the hand-over descriptors of every (group slot, lane, pipe slot)
+    // lanes x groups in flight, their arena, the hand-over descriptors of every (pipe slot, group slot, lane), the poster
     void CreateGroups(RunnerParams* params)
     {
         IPCEnv* env = (IPCEnv*)(params->env);
@@ -703,45 +667,43 @@ private:
         std::vector<int32_t> fanout(params->fanout.begin(), params->fanout.end());
         const LegionTuning tune = lg::tuning();
         const int64_t feature_rows = std::max<int64_t>(1, std::min<int64_t>(memorypool_->feature_rows, memorypool_->num_ids));
-        if (lanes_mode_) {
-            // groups as large as bench.py's (524288 / B rounded down to a power of two, at most 512: the launch tails and the
-            // per-kernel floors are paid once per group), never larger than the schedule can fill, halved while the lanes of
-            // the two groups in flight would take more than 0.6 of the HBM that is free now (tables and caches are in place)
-            lanes_ = 1;
-            while (lanes_ * 2 <= 512 && (int64_t)lanes_ * 2 * memorypool_->batch_size <= 524288) lanes_ *= 2;
-            if (tune.runner_lanes > 0) lanes_ = tune.runner_lanes;
-            lanes_ = std::min(lanes_, LargestGroup(env, lanes_));
-            const int64_t arena_lane = lg_pool_arena_bytes(memorypool_->batch_size, memorypool_->num_ids, feature_rows, float_feature_len_);
-            const int64_t lane_bytes = arena_lane + (int64_t)memorypool_->num_ids * 40 + (int64_t)memorypool_->max_slots * 28;
-            size_t free_b = 0, total_b = 0;
-            HIP_CALL(hipMemGetInfo(&free_b, &total_b));
-            while (lanes_ > 1 && (int64_t)lanes_ * 2 * lane_bytes > (int64_t)(free_b / 10 * 6)) lanes_ /= 2;
-            arena_.bytes = arena_lane * lanes_ * 2;
-            arena_.base = (char*)d_alloc_space(arena_.bytes);
-            arena_.used = 0;
-            arena_.mirror_lanes = lanes_ * 2;
-            arena_.mirror_used = 0;
-            HIP_CALL(hipHostMalloc((void**)&arena_.mirror_host, (size_t)arena_.mirror_lanes * 32 * sizeof(int32_t), hipHostMallocMapped));
-            memset(arena_.mirror_host, 0, (size_t)arena_.mirror_lanes * 32 * sizeof(int32_t));
-            HIP_CALL(hipHostGetDevicePointer((void**)&arena_.mirror_dev, arena_.mirror_host, 0));
-            lg_set_pool_arena(&arena_);
-            // use_graph bits: 1 graph replay, 16 weave (the next group's head on a second stream under this group's heavy kernels)
-            pipe_ = legion_pipeline_create((LegionGraphStorage*)params->graph, (LegionFeatureStorage*)params->feature,
-                                           (LegionUnifiedCache*)params->cache, local_dev_id_, memorypool_->batch_size,
-                                           fanout.data(), hop_num_, lanes_, 2, float_feature_len_ > 0 ? feature_rows : 0, 1 | 16);
-            lg_set_pool_arena(nullptr);
-            if (handover_ == 0 && env->PublishArena(local_dev_id_, arena_.base, arena_.bytes))
-                std::cout << "runner " << local_dev_id_ << ": lane arena of " << (arena_.bytes >> 20) << " MiB published ("
-                          << lanes_ << " lanes x 2 groups)\n" << std::flush;
-        } else {
-            lanes_ = std::max(1, std::min(128, 262144 / std::max(1, memorypool_->batch_size)));
-            if (tune.runner_lanes > 0) lanes_ = tune.runner_lanes;
-            // use_graph bits: 1 graph replay, 8 sampler phase only (the gathers go straight into the pipe slots)
-            pipe_ = legion_pipeline_create((LegionGraphStorage*)params->graph, (LegionFeatureStorage*)params->feature,
-                                           (LegionUnifiedCache*)params->cache, local_dev_id_, memorypool_->batch_size,
-                                           fanout.data(), hop_num_, lanes_, 2, 0, 1 | 8);
-        }
-        const int32_t ho_mode = tune.runner_ho_stream;    // 0 the sampler's stream, 1 one shared, 2 one per pipe slot
+        // groups as large as bench.py's (524288 / B rounded down to a power of two, at most 512: the launch tails and the
+        // per-kernel floors are paid once per group), never larger than the schedule can fill, halved while the lanes of
+        // the groups in flight would take more than 0.6 of the HBM that is free now (tables and caches are in place).
+        // Three groups in flight: one being handed over, one running, one queued behind it -- with two, the GPU could only
+        // start group g+2 after the trainer had taken the first batch of g+1, and the next group's head never ran under the
+        // current group's heavy kernels (measured at RMAT-26, views: 132 k batches/s with two)
+        slots_ = tune.runner_slots >= 2 ? std::min(tune.runner_slots, 4) : 3;
+        lanes_ = 1;
+        while (lanes_ * 2 <= 512 && (int64_t)lanes_ * 2 * memorypool_->batch_size <= 524288) lanes_ *= 2;
+        if (tune.runner_lanes > 0) lanes_ = tune.runner_lanes;
+        lanes_ = std::min(lanes_, LargestGroup(env, lanes_));
+        const bool lane_features = handover_ != 1 && float_feature_len_ > 0;        // forced `gather`: rows never land in a lane
+        lane_features_ = lane_features;
+        const int64_t arena_lane = lg_pool_arena_bytes(memorypool_->batch_size, memorypool_->num_ids, lane_features ? feature_rows : 0, float_feature_len_);
+        const int64_t lane_bytes = arena_lane + (int64_t)memorypool_->num_ids * 40 + (int64_t)memorypool_->max_slots * 28;
+        size_t free_b = 0, total_b = 0;
+        HIP_CALL(hipMemGetInfo(&free_b, &total_b));
+        while (lanes_ > 1 && (int64_t)lanes_ * slots_ * lane_bytes > (int64_t)(free_b / 10 * 6)) lanes_ /= 2;
+        arena_.bytes = arena_lane * lanes_ * slots_;
+        arena_.base = (char*)d_alloc_space(arena_.bytes);
+        arena_.used = 0;
+        arena_.mirror_lanes = lanes_ * slots_;
+        arena_.mirror_used = 0;
+        HIP_CALL(hipHostMalloc((void**)&arena_.mirror_host, (size_t)arena_.mirror_lanes * 32 * sizeof(int32_t), hipHostMallocMapped));
+        memset(arena_.mirror_host, 0, (size_t)arena_.mirror_lanes * 32 * sizeof(int32_t));
+        HIP_CALL(hipHostGetDevicePointer((void**)&arena_.mirror_dev, arena_.mirror_host, 0));
+        lg_set_pool_arena(&arena_);
+        // use_graph bits: 1 graph replay, 16 weave (the next group's head on a second stream under this group's heavy kernels)
+        pipe_ = legion_pipeline_create((LegionGraphStorage*)params->graph, (LegionFeatureStorage*)params->feature,
+                                       (LegionUnifiedCache*)params->cache, local_dev_id_, memorypool_->batch_size,
+                                       fanout.data(), hop_num_, lanes_, slots_, lane_features ? feature_rows : 0, 1 | 16);
+        lg_set_pool_arena(nullptr);
+        if (handover_ == 0 && lane_features && env->PublishArena(local_dev_id_, arena_.base, arena_.bytes))
+            std::cout << "runner " << local_dev_id_ << ": lane arena of " << (arena_.bytes >> 20) << " MiB published ("
+                      << lanes_ << " lanes x " << slots_ << " groups)\n" << std::flush;
+        slot_end_.assign(slots_, -1);
+        const int32_t ho_mode = tune.runner_ho_stream;    // 0 the pipeline's stream, 1 one shared, 2 one per pipe slot
         if (ho_mode != 0) {
             int lo = 0, hi = 0;
             HIP_CALL(hipDeviceGetStreamPriorityRange(&lo, &hi));
@@ -753,8 +715,6 @@ private:
                 ho_streams_[1] = ho_streams_[0];
             else
                 HIP_CALL(hipStreamCreateWithPriority(&ho_streams_[1], hipStreamNonBlocking, hi));
-            for (int i = 0; i < 2; i++)
-                for (int j = 0; j < 2; j++) HIP_CALL(hipEventCreateWithFlags(&ho_done_[i][j], hipEventDisableTiming));
         }
         for (int p = 0; p < interbatch_concurrency_; p++) {
             lg::DeliverParams& d = deliver_[p];
@@ -774,30 +734,28 @@ private:
         }
         d_deliver_ = (lg::DeliverParams*)d_alloc_space(sizeof(deliver_));
         HIP_CALL(hipMemcpy(d_deliver_, deliver_, sizeof(deliver_), hipMemcpyHostToDevice));
-        // hand-over descriptors [parity][group slot][lane]: the lane's own buffers as the source, the pipe slot
-        // (parity + lane) % 2 as the destination -- consecutive lanes alternate pipe slots like consecutive batches do,
-        // so two consecutive batches can be handed over by ONE launch (grid.y = 2) when both slots are free
-        std::vector<LanePtrs> h(lanes_mode_ ? 0 : (size_t)interbatch_concurrency_ * 2 * lanes_);
-        for (int par = 0; par < interbatch_concurrency_ && !lanes_mode_; par++)
-            for (int sl = 0; sl < 2; sl++)
+        // `gather` hand-over descriptors [pipe slot][group slot][lane]: the lane's own buffers as the source, the pipe slot's
+        // feature buffer as the gather's destination, its other arrays as deliver_slice's
+        std::vector<LanePtrs> h((size_t)interbatch_concurrency_ * slots_ * lanes_);
+        for (int p = 0; p < interbatch_concurrency_; p++)
+            for (int sl = 0; sl < slots_; sl++)
                 for (int g = 0; g < lanes_; g++) {
                     MemoryPool* lp = reinterpret_cast<MemoryPool*>(legion_pipeline_pool(pipe_, sl, g));
-                    const int p = (par + g) % interbatch_concurrency_;
                     LanePtrs d = lp->HostLane(0);
                     d.float_features = env->GetFloatFeatures(local_dev_id_, p);
                     d.feature_rows = (int32_t)std::min<int64_t>(memorypool_->feature_rows, memorypool_->num_ids);
                     d.deliver = d_deliver_ + p;
                     // counters stay the lane's: deliver_slice reads them there and writes the slot's (incl. [2..3])
-                    h[((size_t)par * 2 + sl) * lanes_ + g] = d;
+                    h[((size_t)p * slots_ + sl) * lanes_ + g] = d;
                 }
         d_desc_ = (LanePtrs*)d_alloc_space((int64_t)h.size() * sizeof(LanePtrs));
-        if (!h.empty()) HIP_CALL(hipMemcpy(d_desc_, h.data(), h.size() * sizeof(LanePtrs), hipMemcpyHostToDevice));
+        HIP_CALL(hipMemcpy(d_desc_, h.data(), h.size() * sizeof(LanePtrs), hipMemcpyHostToDevice));
         poster_ = std::thread([this, env] {
             // The poster polls (the reference's runner thread polls cudaEventQuery the same way, server.cu:319-324): one core
             // per GPU buys a hand-over latency of about a microsecond instead of a condition-variable wake-up.
             // (Measured and rejected, tools/micro/stream_wait_probe.hip + LEGION_RUNNER_STATS: queueing the hand-over ahead
             // behind hipStreamWaitValue32 and signalling completion with hipStreamWriteValue32 -- 36 k batches/s against
-            // 44 k with events at B = 1024.)
+            // 44 k with events at B = 1024.)  With the `views` hand-over it has nothing to do and sleeps.
             SetGPUDevice(local_dev_id_);
             uint32_t head = 0;
             for (uint32_t idle = 0;;) {
@@ -824,8 +782,8 @@ private:
         });
     }
 
-    // plans and enqueues the sampler phase of the group that starts at global batch `first`: consecutive batches of
-    // one mode with consecutive local ids (ipc_service.cu:213-253), at most `lanes_`
+    // the group that starts at global batch `first`: consecutive batches of one mode with consecutive local ids
+    // (ipc_service.cu:213-253), at most `lanes_`
     int32_t PlanGroup(IPCEnv* env, int32_t first, int32_t& mode, int32_t& local0)
     {
         mode = env->GetCurrentMode(first);
@@ -837,31 +795,34 @@ private:
         return n;
     }
 
-    void SubmitGroup(IPCEnv* env, int32_t first, int& slot_out, int32_t& first_out, int32_t& n_out)
+    // enqueues the next group of the schedule on the pipeline's next slot
+    void SubmitNext(IPCEnv* env)
     {
         int32_t mode = 0, local0 = 0;
-        const int32_t n = PlanGroup(env, first, mode, local0);
-        // the pipeline hands its two slots out in turn: the sampler may overwrite the lanes of the slot it gets now only
-        // after every batch of the group that used them before has been handed over
-        const int target = submit_count_++ % 2;
-        if (!lanes_mode_ && ho_streams_[0] != nullptr && ho_done_valid_[target])
-            for (int i = 0; i < 2; i++)
-                HIP_CALL(hipStreamWaitEvent(static_cast<hipStream_t>(legion_pipeline_stream(pipe_)), ho_done_[target][i], 0));
-        slot_out = legion_pipeline_submit_ex(pipe_, local0, mode, n, env->GetCurrentBatchsize(local_dev_id_, mode));
-        if (slot_out != target) { printf("legion_hip: runner lost track of the pipeline's slots\n"); exit(EXIT_FAILURE); }
-        first_out = first;
-        n_out = n;
+        const int32_t n = PlanGroup(env, next_first_, mode, local0);
+        const int target = submit_count_++ % slots_;
+        const int slot = legion_pipeline_submit_ex(pipe_, local0, mode, n, env->GetCurrentBatchsize(local_dev_id_, mode));
+        if (slot != target) { printf("legion_hip: runner lost track of the pipeline's slots\n"); exit(EXIT_FAILURE); }
+        groups_.push_back({slot, next_first_, n, false});
+        slot_end_[slot] = next_first_ + n;
+        next_first_ += n;
+    }
+
+    // With token k consumed, batches <= k-2 have been released by the trainer: a pipeline slot whose previous group ended
+    // at or before batch k-1 (exclusive end) may be overwritten.  Keeps up to slots_ groups submitted.
+    void SubmitWhatFits(IPCEnv* env, int32_t k)
+    {
+        while (next_first_ < max_step_ && (int)groups_.size() < slots_) {
+            const int target = submit_count_ % slots_;
+            if (slot_end_[target] >= 0 && slot_end_[target] > k - 1) break;
+            SubmitNext(env);
+        }
     }
 
     int32_t num_ids_ = 0;
     int32_t float_feature_len_ = 0;
     MemoryPool* memorypool_ = nullptr;
     IPCEnv* env_ = nullptr;
-    // the "lanes" hand-over (RunOnceLanes)
-    int32_t handover_ = lg::tuning().runner_handover;     // 0 auto, 1 gather (round 3), 2 copy
-    bool lanes_mode_ = lg::tuning().runner_graph != 0 && lg::tuning().runner_handover != 1;
-    PoolArena arena_;
-    bool direct_ = false, direct_decided_ = false;
     int current_pipe_ = 0;
     int interbatch_concurrency_ = INTERBATCH_CON;
     int local_dev_id_ = 0;
@@ -872,28 +833,28 @@ private:
     std::vector<Operator*> op_factory_;
     std::vector<OpParams*> op_params_;
     bool use_groups_ = lg::tuning().runner_graph != 0;
-    // lane groups
+    // launch groups
+    int32_t handover_ = lg::tuning().runner_handover;     // 0 auto (views, else gather), 1 gather, 2 copy
+    int kind_ = KIND_UNDECIDED;
+    bool lane_features_ = false;                           // the lanes have feature buffers (and the groups may gather into them)
     LegionPipeline* pipe_ = nullptr;
-    int32_t lanes_ = 1, hop_num_ = 0, max_step_ = 0;
+    PoolArena arena_;
+    int32_t lanes_ = 1, slots_ = 3, hop_num_ = 0, max_step_ = 0;
+    std::deque<Group> groups_;                             // submitted, not yet fully handed over; front = being handed over
+    std::vector<int32_t> slot_end_;                        // [pipeline slot] exclusive end of the group that last used it, -1: none
+    int32_t next_first_ = 0;                               // first batch of the next group to submit
+    int submit_count_ = 0;
     LanePtrs* d_desc_ = nullptr;
     lg::DeliverParams deliver_[INTERBATCH_CON] = {};
     lg::DeliverParams* d_deliver_ = nullptr;
     hipEvent_t batch_done_[INTERBATCH_CON] = {};
-    int cur_slot_ = -1, next_slot_ = -1;
-    int32_t cur_first_ = 0, cur_n_ = 0, next_first_ = 0, next_n_ = 0;
     int32_t reported_ = 0;
     std::thread poster_;
     static constexpr uint32_t kRing = 8;
     Pending ring_[kRing] = {};
     std::atomic<uint32_t> q_tail_{0};
     std::atomic<bool> stop_{false};
-    bool pair_pending_ = false;
-    hipStream_t ho_streams_[2] = {nullptr, nullptr};    // hand-over launches of pipe slot 0 / 1 (LEGION_RUNNER_HO_STREAM=0: the sampler's stream; 1: one for both)
-    hipEvent_t ho_done_[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};   // [pipeline slot][stream]: behind the group's last hand-over
-    bool ho_done_valid_[2] = {false, false};
-    int submit_count_ = 0;
-    bool pair_ = lg::tuning().runner_pair != 0;
-    int64_t st_pairs_ = 0;
+    hipStream_t ho_streams_[2] = {nullptr, nullptr};    // hand-over launches of pipe slot 0 / 1 (LEGION_RUNNER_HO_STREAM=0: the pipeline's stream; 1: one for both)
     bool stats_ = lg::tuning().runner_stats != 0;
     double st_wait_ = 0, st_launch_ = 0, st_gpu_ = 0;
     int64_t st_n_ = 0;

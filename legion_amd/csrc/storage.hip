@@ -37,6 +37,9 @@ static int g_local_only = -1;
 extern "C" void legion_set_local_device(int32_t dev) { g_local_only = dev; }
 bool lg_is_local(int32_t dev) { return g_local_only < 0 || dev == g_local_only; }
 
+// physical device a logical GPU of this process runs on
+int lg_physical_device(int32_t dev) { return (g_device_base + dev) % lg_physical_count(); }
+
 extern "C" void SetGPUDevice(int32_t shard_id)
 {
     HIP_CALL(hipSetDevice((g_device_base + shard_id) % lg_physical_count()));
@@ -198,6 +201,10 @@ public:
             const int32_t dev = Ki * Kg + i;
             if (!lg_is_local(dev)) continue;
             SetGPUDevice(dev);
+            // a new fill: headers that an earlier fill pointed into ITS cached CSR go back to the full CSR first (a vertex
+            // cached then and not now kept a row offset into arrays the pointer table no longer names)
+            lg::init_row_headers(nullptr, row_hdr_[dev], csr_node_index_cpu_, node_num_, partition_count_);
+            HIP_CALL(hipDeviceSynchronize());
             int64_t* neighbor_count = (int64_t*)d_alloc_space((int64_t)capacity * sizeof(int64_t));
             lg::topo_neighbor_count(nullptr, QT, Kg, i, capacity, node_num_, csr_node_index_cpu_, neighbor_count);
             int64_t* d_csr_node_index = (int64_t*)d_alloc_space(((int64_t)capacity + 1) * sizeof(int64_t));
@@ -246,10 +253,11 @@ public:
     int32_t* CachedCSRDst(int32_t dev) const override { return topo_col_[dev]; }
 
     // column slots (legion_core.h): {neighbour id, node_map[neighbour]} pairs of the FULL column array, for GPU dev
-    void BuildColumnSlots(int32_t dev, const int32_t* node_map) override
+    void BuildColumnSlots(int32_t dev, const int32_t* node_map, uint64_t stamp) override
     {
         if (dev < 0 || dev >= partition_count_ || !lg_is_local(dev)) return;
         DropColumnSlots(dev);
+        if ((int32_t)colx_stamp_.size() < partition_count_) colx_stamp_.assign(partition_count_, 0);
         const int32_t mode = lg::tuning().col_slots;
         if (mode == 0 || node_map == nullptr || edge_num_ <= 0) return;
         SetGPUDevice(dev);
@@ -261,9 +269,14 @@ public:
                 (void)hipGetLastError();
                 return;                       // column array in (pinned) host memory: the spill-over configuration keeps HBM free
             }
+            // What is free NOW is what the full tables, the caches and the maps left (FillUp has run); the lanes of the launch
+            // groups come afterwards and size themselves to what remains (bench.py, GPURunner::CreateGroups).  The copy is worth
+            // 3-7 % of the whole job (the gather stops fetching a 128-byte line of node_map per row), so it is taken whenever it
+            // fits half of the free HBM and leaves 24 GB for the lanes -- uk-union's 44 GB copy beside 160 GB of tables on a
+            // 288 GB part (round 3 declined it: a flat quarter of the free memory)
             size_t free_b = 0, total_b = 0;
             HIP_CALL(hipMemGetInfo(&free_b, &total_b));
-            if (bytes > (int64_t)(free_b / 4)) return;
+            if (bytes > (int64_t)(free_b / 2) || (int64_t)free_b - bytes < ((int64_t)24 << 30)) return;
         }
         colx_full_[dev] = (int32_t*)d_alloc_space(bytes);
         lg::build_column_slots(nullptr, csr_dst_node_ids_cpu_, node_map, colx_full_[dev], edge_num_);
@@ -272,6 +285,11 @@ public:
         csr_dst_x_[dev] = (int32_t**)d_alloc_space((partition_count_ + 1) * sizeof(int32_t*));
         HIP_CALL(hipMemcpy(csr_dst_x_[dev], tab.data(), tab.size() * sizeof(int32_t*), hipMemcpyHostToDevice));
         HIP_CALL(hipDeviceSynchronize());
+        colx_stamp_[dev] = stamp;
+    }
+    uint64_t ColumnSlotsStamp(int32_t dev) const override
+    {
+        return (dev >= 0 && dev < (int32_t)colx_stamp_.size() && dev < (int32_t)csr_dst_x_.size() && csr_dst_x_[dev] != nullptr) ? colx_stamp_[dev] : 0;
     }
     void DropColumnSlots(int32_t dev) override
     {
@@ -282,6 +300,7 @@ public:
         d_free_space(colx_full_[dev]);
         csr_dst_x_[dev] = nullptr;
         colx_full_[dev] = nullptr;
+        if (dev < (int32_t)colx_stamp_.size()) colx_stamp_[dev] = 0;
     }
     int32_t** GetCSRXMatrix(int32_t part_id) const override { return csr_dst_x_.empty() ? nullptr : csr_dst_x_[part_id]; }
     const int32_t* GetColumnSlotsFull(int32_t part_id) const override { return colx_full_.empty() ? nullptr : colx_full_[part_id]; }
@@ -336,6 +355,7 @@ private:
     std::vector<int32_t*> topo_col_;
     std::vector<int32_t**> csr_dst_x_;   // [P] device tables of pair arrays (column slots), null until built
     std::vector<int32_t*> colx_full_;    // [P] this GPU's {id, feature-cache slot} copy of the full column array
+    std::vector<uint64_t> colx_stamp_;   // [P] (cache uid, fill generation) the pairs were built from
 };
 
 extern "C" GraphStorage* NewCompleteGraphStorage() { return new CompleteGraphStorage(); }

@@ -66,6 +66,7 @@ void parse_env(LegionTuning& t)
         exit(EXIT_FAILURE);
     };
     t.runner_handover = word("LEGION_RUNNER_HANDOVER", {{"auto", 0}, {"gather", 1}, {"copy", 2}}, 0);
+    t.runner_slots = env_int("LEGION_RUNNER_SLOTS", 3);
     t.peer_gather = word("LEGION_PEER_GATHER", {{"direct", 0}, {"bulk", 1}}, 0);
     t.feature_pitch = word("LEGION_FEATURE_PITCH", {{"auto", -1}, {"dense", 0}, {"aligned", 1}}, -1);
     t.hotness_reduce = word("LEGION_HOTNESS_REDUCE", {{"auto", -1}, {"p2p", 0}, {"rccl", 1}}, -1);

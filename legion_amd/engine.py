@@ -328,6 +328,23 @@ class LaneGroup:
             self.handle = None
 
 
+def collective_unique_id():
+    """128 bytes that rank 0 creates and every rank needs for collective_init_rank (carry them over any channel)."""
+    buf = ctypes.create_string_buffer(128)
+    if not _libmod.load().legion_collective_unique_id(buf):
+        raise RuntimeError("ncclGetUniqueId failed")
+    return buf.raw
+
+
+def collective_init_rank(unique_id, world, rank, dev_id=0):
+    """Joins the library's own RCCL communicator (the hotness all-reduce of a one-process-per-GPU deployment)."""
+    return bool(_libmod.load().legion_collective_init_rank(ctypes.create_string_buffer(unique_id, 128), int(world), int(rank), int(dev_id)))
+
+
+def collective_destroy():
+    _libmod.load().legion_collective_destroy()
+
+
 class Pipeline:
     """`slots` groups of `group_size` mini-batches in flight on one GPU, each group replayed as one
     hipGraph (pipeline.hip).  submit(counter0) enqueues batches counter0 .. counter0+group_size-1."""
@@ -406,6 +423,17 @@ class UnifiedCache:
     def candidate_selection(self, cache_agg_mode, graph, world_reduced=False):
         self._lib.legion_cache_candidate_selection(self.handle, int(cache_agg_mode), graph.handle,
                                                    1 if world_reduced else 0)
+
+    def allreduce_hotness(self, dev_id=0):
+        """One process per GPU: RCCL all-reduce (issued by the library, collective_init_rank's communicator) of this GPU's two
+        access-counter arrays in place.  Returns (world size the collective ran over -- 0 on failure --, milliseconds)."""
+        ms = ctypes.c_double(0)
+        world = int(self._lib.legion_cache_allreduce_hotness(self.handle, int(dev_id), ctypes.byref(ms)))
+        return world, float(ms.value)
+
+    def hotness_reduce_path(self, dev_id=0):
+        """How the last candidate_selection summed the clique's counters: 'none', 'p2p' (leader loop) or 'rccl'."""
+        return ("none", "p2p", "rccl")[int(self._lib.legion_cache_hotness_reduce_path(self.handle, int(dev_id)))]
 
     def cost_model(self, feature, graph, counters=(0, 0), train_step=0):
         cnt = (ctypes.c_uint64 * 2)(int(counters[0]), int(counters[1]))

@@ -61,6 +61,12 @@ SIGNATURES = {
     "legion_cache_export": (None, [c_p, c_p, c_i32, c_p]),
     "legion_cache_import_peer": (None, [c_p, c_p, c_i32, c_i32, c_p]),
     "legion_cache_fill_up_link": (None, [c_p, c_p, c_p]),
+    "legion_collective_unique_id": (c_i32, [c_p]),
+    "legion_collective_init_rank": (c_i32, [c_p, c_i32, c_i32, c_i32]),
+    "legion_collective_allreduce_u64": (c_i32, [c_p, c_i64, ctypes.POINTER(ctypes.c_double)]),
+    "legion_collective_destroy": (None, []),
+    "legion_cache_allreduce_hotness": (c_i32, [c_p, c_i32, ctypes.POINTER(ctypes.c_double)]),
+    "legion_cache_hotness_reduce_path": (c_i32, [c_p, c_i32]),
     "legion_cache_node_capacity": (c_i32, [c_p, c_i32]),
     "legion_cache_edge_capacity": (c_i32, [c_p, c_i32]),
     "legion_cache_max_id_num": (c_i32, [c_p, c_i32]),
@@ -137,7 +143,7 @@ class Tuning(ctypes.Structure):                # LegionTuning (include/legion_hi
     _fields_ = [(n, c_i32) for n in (
         "dedup_form", "pos_value_bits", "pos_table_bits", "lds_known_cap", "lds_part_wg", "lds_small_buckets", "sample_max_wg",
         "gather_small_tiles", "gather_rows_per_wg", "col_slots", "split_sampler_cus", "split_priority", "weave_priority", "runner_graph", "runner_lanes",
-        "runner_pair", "runner_ho_stream", "runner_stats", "runner_handover", "peer_gather", "feature_pitch", "hotness_reduce", "markers", "table_placement", "shm_mirror", "link_counters")] + \
+        "runner_pair", "runner_ho_stream", "runner_stats", "runner_handover", "runner_slots", "peer_gather", "feature_pitch", "hotness_reduce", "markers", "table_placement", "shm_mirror", "link_counters")] + \
         [("link_counter_values", c_u64 * 2)]
 
 

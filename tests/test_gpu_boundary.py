@@ -31,23 +31,25 @@ def write_dataset(path, wl_indptr, wl_col, feats, labels, train, valid, test):
 
 @pytest.mark.parametrize("server_env", [
     {},                                                        # defaults: whole launch groups into the lane arena, batches handed over as VIEWS of their lane
-    {"LEGION_RUNNER_LANES": "3"},                              # many small groups: prefetch, partial groups, mode changes mid-run, lane reuse
+    {"LEGION_RUNNER_LANES": "3"},                              # many small groups: three in flight, partial groups, mode changes mid-run, lane reuse
     {"LEGION_RUNNER_LANES": "1"},                              # one batch per group: a lane is reused as soon as its batch is released
-    {"LEGION_RUNNER_LANES": "2", "LEGION_DEDUP": "direct"},    # per-vertex position state inside the lanes pipeline
-    {"LEGION_NO_DIRECT_VIEWS": "1"},                           # a trainer end that does not take views: the same pipeline, one copy launch per batch
-    {"LEGION_RUNNER_HANDOVER": "copy", "LEGION_RUNNER_LANES": "5"},   # copies forced on the server side (no arena published)
+    {"LEGION_RUNNER_LANES": "2", "LEGION_RUNNER_SLOTS": "2", "LEGION_DEDUP": "direct"},    # two groups in flight; per-vertex position state in the lanes
+    {"LEGION_RUNNER_LANES": "2", "LEGION_RUNNER_SLOTS": "4"},
+    {"LEGION_NO_DIRECT_VIEWS": "1"},                           # a trainer end that does not take views: sampler phase in groups, one gather launch per batch into the pipe slot
+    {"LEGION_NO_DIRECT_VIEWS": "1", "LEGION_RUNNER_LANES": "3"},
+    {"LEGION_RUNNER_HANDOVER": "copy", "LEGION_RUNNER_LANES": "5"},   # whole groups + one copy launch per batch (the measured alternative)
     {"LEGION_RUNNER_HANDOVER": "copy", "LEGION_RUNNER_LANES": "4", "LEGION_RUNNER_HO_STREAM": "0"},   # ... on the pipeline's own stream
-    {"LEGION_RUNNER_HANDOVER": "gather"},                      # round 3's path: sampler phase in groups, one gather launch per batch into the pipe slot
-    {"LEGION_RUNNER_HANDOVER": "gather", "LEGION_RUNNER_LANES": "3"},
+    {"LEGION_RUNNER_HANDOVER": "gather"},                      # gather hand-over for every trainer end (no arena published, lanes without feature buffers)
     {"LEGION_RUNNER_HANDOVER": "gather", "LEGION_RUNNER_LANES": "4", "LEGION_DEDUP": "table"},     # compact position state inside the server
-    {"LEGION_RUNNER_HANDOVER": "gather", "LEGION_RUNNER_LANES": "1", "LEGION_RUNNER_PAIR": "0"},   # one batch per group
+    {"LEGION_RUNNER_HANDOVER": "gather", "LEGION_RUNNER_LANES": "1"},   # one batch per group
     {"LEGION_RUNNER_GRAPH": "0"},                              # the reference's operator-by-operator Runner
     {"LEGION_NO_SHM_MIRROR": "1"},                             # no mirror object at all: counters copied from the device, as the reference's trainer end does
-    {"LEGION_RUNNER_HANDOVER": "gather", "LEGION_RUNNER_LANES": "5", "LEGION_RUNNER_HO_STREAM": "0"},   # hand-overs on the sampler's own stream
+    {"LEGION_RUNNER_HANDOVER": "gather", "LEGION_RUNNER_LANES": "5", "LEGION_RUNNER_HO_STREAM": "0"},   # hand-overs on the pipeline's own stream
     {"LEGION_RUNNER_HANDOVER": "gather", "LEGION_RUNNER_LANES": "6", "LEGION_RUNNER_HO_STREAM": "1"},   # one hand-over stream for both pipe slots
-], ids=["default-views", "views-lanes3", "views-lanes1", "views-lanes2-direct-state", "trainer-without-views", "copy-lanes5", "copy-lanes4-one-stream",
-        "gather", "gather-lanes3", "gather-lanes4-table", "gather-lanes1", "operators", "no-mirror", "gather-lanes5-one-stream",
-        "gather-lanes6-shared-ho-stream"])
+    {"LEGION_HOTNESS_REDUCE": "rccl"},                         # the clique sum of the access counters as the library's RCCL all-reduce (a 1-rank communicator here)
+], ids=["default-views", "views-lanes3", "views-lanes1", "views-lanes2-two-groups-direct-state", "views-lanes2-four-groups", "trainer-without-views",
+        "trainer-without-views-lanes3", "copy-lanes5", "copy-lanes4-one-stream", "gather", "gather-lanes4-table", "gather-lanes1", "operators",
+        "no-mirror", "gather-lanes5-one-stream", "gather-lanes6-shared-ho-stream", "rccl-hotness-reduce"])
 def test_server_binary_serves_fake_trainer(hip, tmp_path, server_env, monkeypatch):
     import torch
     for k, v in server_env.items():
@@ -142,11 +144,14 @@ def test_server_binary_serves_fake_trainer(hip, tmp_path, server_env, monkeypatc
         text = open(work / "server.log").read()
         assert "Server Stopped" in text and "Train Steps: %d" % st.train_step in text
         # which hand-over served the run
-        lanes_pipeline = server_env.get("LEGION_RUNNER_HANDOVER", "auto") != "gather" and server_env.get("LEGION_RUNNER_GRAPH") != "0"
-        views = lanes_pipeline and not ({"LEGION_NO_DIRECT_VIEWS", "LEGION_NO_SHM_MIRROR"} & set(server_env)) and \
-            server_env.get("LEGION_RUNNER_HANDOVER", "auto") == "auto"
-        assert ("hand-over by views of the lane arena" in text) == views, text[-1500:]
-        assert ("hand-over by copy into the pipe slots" in text) == (lanes_pipeline and not views), text[-1500:]
+        groups = server_env.get("LEGION_RUNNER_GRAPH") != "0"
+        ho = server_env.get("LEGION_RUNNER_HANDOVER", "auto")
+        views = groups and ho == "auto" and not ({"LEGION_NO_DIRECT_VIEWS", "LEGION_NO_SHM_MIRROR"} & set(server_env))
+        want_kind = None if not groups else ("views of the lane arena" if views else
+                                             "copy into the pipe slots" if ho == "copy" else "one gather launch per batch into the pipe slots")
+        for kind in ("views of the lane arena", "copy into the pipe slots", "one gather launch per batch into the pipe slots"):
+            assert (("hand-over by " + kind) in text) == (kind == want_kind), text[-1500:]
+        assert ("RCCL all-reduce (ncclUint64, ncclSum) over 1 GPU" in text) == (server_env.get("LEGION_HOTNESS_REDUCE") == "rccl"), text[-1500:]
     finally:
         if server.poll() is None:
             server.kill()

@@ -126,3 +126,84 @@ def test_full_size_properties(hip, scale, batch, group):
             hit = pl.buffer("cache_search_buffer")[:int(nc[1])]
             assert int((hit >= 0).sum()) > 0
     pipe.close(); pool.close(); cache.close(); feature.close(); graph.close()
+
+
+def test_refill_and_second_cache_with_column_slots(hip, monkeypatch):
+    """Column slots ({neighbour id, feature-cache slot} pairs of the column array) belong to ONE fill of ONE cache: after a
+    re-fill with another capacity, or with a second cache object over the same graph, the sampler must not carry slots of the
+    old node_map into the gather (stale pairs gave wrong rows, or out-of-range reads when the capacity shrank).
+    fill -> serve -> set_capacity -> fill -> serve, then a second cache serving from the same graph: all bit-exact."""
+    monkeypatch.setenv("LEGION_COL_SLOTS", "1")
+    wl = Workload(scale=11, edge_factor=8, dim=24, n_seeds=1200)
+    fanout, batch = [6, 4], 64
+    gpu, cpu = GpuSide(wl, batch, fanout), CpuSide(wl, batch, fanout)
+    for it in range(4):
+        gpu.run(0, it, 0, is_presc=True); cpu.run(0, it, 0, is_presc=True)
+    gpu.cache.candidate_selection(0, gpu.graph)
+    for capacity in ((400, 50), (90, 20), (700, 10)):            # shrink, then grow
+        gpu.cache.set_capacity(*capacity)
+        gpu.cache.fill_up(gpu.feature, gpu.graph)
+        assert gpu.graph.column_slots(0)
+        cpu.build_cache(0, capacity=capacity)
+        hits = 0
+        for it in range(3):
+            g, c = gpu.run(0, it, 0), cpu.run(0, it, 0)
+            compare_batches(g, c, f"capacity {capacity} batch {it}: ")
+            assert np.array_equal(g["cache_search_buffer"], c["cache_search_buffer"])
+            hits += int((g["cache_search_buffer"] >= 0).sum())
+        assert hits > 0
+    # a second cache over the same graph, filled with yet another capacity: the graph's pairs now belong to IT ...
+    cache2 = engine.UnifiedCache(0, wl.D, 1, 1, wl.N)
+    cache2.init_controller(0)
+    pool2 = engine.MemoryPool(0, wl.N, batch, fanout, wl.D)
+    pool2.alloc_features(pool2.num_ids)
+    for it in range(4):
+        engine.enqueue_batch(None, gpu.graph, gpu.feature, cache2, pool2, batch, it, 0, 0, True, fanout)
+    torch.cuda.synchronize()
+    cache2.candidate_selection(0, gpu.graph)
+    cache2.set_capacity(33, 10)                  # (a graph holds ONE topology cache: the same vertices as the first cache's last fill)
+    cache2.fill_up(gpu.feature, gpu.graph)
+    cpu2 = CpuSide(wl, batch, fanout)
+    for it in range(4):
+        cpu2.run(0, it, 0, is_presc=True)
+    cpu2.build_cache(0, capacity=(33, 10))
+    engine.enqueue_batch(None, gpu.graph, gpu.feature, cache2, pool2, batch, 1, 0, 0, False, fanout)
+    torch.cuda.synchronize()
+    compare_batches(engine.read_batch(pool2), cpu2.run(0, 1, 0), "second cache: ")
+    # ... and the FIRST cache (capacity 700), whose pairs are gone, still serves correctly: it looks its slots up
+    cpu.build_cache(0, capacity=(700, 10))       # (the oracle graph's attached cache is the latest one built: rebuild)
+    g, c = gpu.run(0, 2, 0), cpu.run(0, 2, 0)
+    compare_batches(g, c, "first cache after the second fill: ")
+    assert np.array_equal(g["cache_search_buffer"], c["cache_search_buffer"])
+    pool2.close(); cache2.close(); cpu2.close()
+    gpu.close(); cpu.close()
+
+
+@pytest.mark.parametrize("D", [7, 100, 602])
+@pytest.mark.parametrize("pitch", ["dense", "aligned"])
+def test_feature_cache_row_pitch(hip, monkeypatch, col_slots, D, pitch):
+    """LegionTuning.feature_pitch: rows of the HBM-resident feature cache (stripes and replica) dense, or padded to whole
+    128-byte lines.  Outputs are dense and byte-identical either way (SS/cache/cache_impl.cuh:259-268 fixes the values, not
+    the cache's layout); D = 7 (28-byte rows, scalar path), 100 (products: 400 bytes), 602 (2408 bytes, unaligned 16-byte
+    chunks + tail)."""
+    monkeypatch.setenv("LEGION_FEATURE_PITCH", pitch)
+    wl = Workload(scale=11, edge_factor=8, dim=D, partition_count=2, n_seeds=1200)
+    fanout, batch = [5, 4], 64
+    gpu, cpu = GpuSide(wl, batch, fanout), CpuSide(wl, batch, fanout)
+    for p in range(2):
+        for it in range(3):
+            gpu.run(p, it, 0, is_presc=True); cpu.run(p, it, 0, is_presc=True)
+    gpu.cache.candidate_selection(1, gpu.graph)               # one clique of two: own stripe + the other member's
+    gpu.cache.set_replica_memory(40 * D * 4)                  # + a 40-row (or fewer, padded) replica
+    gpu.cache.set_capacity(300, 40)
+    gpu.cache.fill_up(gpu.feature, gpu.graph)
+    cpu.build_cache(1, capacity=(300, 40))
+    hits = 0
+    for p in range(2):
+        for it in range(2):
+            g, c = gpu.run(p, it, 0), cpu.run(p, it, 0)
+            compare_batches(g, c, f"D={D} {pitch} gpu {p} batch {it}: ")
+            assert np.array_equal(g["cache_search_buffer"], c["cache_search_buffer"])
+            hits += int((g["cache_search_buffer"] >= 0).sum())
+    assert hits > 0
+    gpu.close(); cpu.close()
