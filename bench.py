@@ -808,14 +808,14 @@ def boundary_leg(args, fanout):
         note = f"/tmp has {free >> 20} MiB free, the RMAT-{scale} data set needs {need >> 20}: boundary leg run at RMAT-22 instead"
         scale = min(scale, 22)
     batches = [args.batch] + ([8000] if args.batch != 8000 else [])
-    # three ways a batch reaches the trainer end (LegionTuning.runner_handover, server.hip): `views` -- whole launch groups into
-    # the server's lane arena, this build's ipc_service takes every batch as views of its lane: what a user of legion_graphsage.py
-    # gets; `copy` -- the same pipeline serving a trainer end that knows only the reference's slab: one copy launch per batch into
-    # the pipe slot; `gather` -- round 3's path, one gather launch per batch straight into the pipe slot
+    # how a batch reaches the trainer end (LegionTuning.runner_handover, server.hip): `views` -- whole launch groups into the
+    # server's lane arena, this build's ipc_service takes every batch as views of its lane: what a user of legion_graphsage.py
+    # gets; `slab` -- the same server with a trainer end that opens only the reference's slab: one gather launch per batch
+    # straight into the pipe slot (round 3's path); `copy` -- whole groups + one copy launch per batch (the measured alternative)
     cmd = [sys.executable, os.path.join(ROOT, "tools", "server_throughput.py"), "--scale", str(scale), "--edge-factor", str(args.edge_factor),
            "--batch", ",".join(str(b) for b in batches), "--dim", str(args.dim), "--fanout", ",".join(str(f) for f in fanout),
            "--train-batches", str(max(64, min(3000, (3 << 20) // args.batch))), "--no-features-file", "--cache-memory", str(args.cache_memory),
-           "--modes", "views,copy,gather", "--min-timed-batches", str(args.boundary_batches), "--watchdog", "800"]
+           "--modes", "views,slab,copy", "--min-timed-batches", str(args.boundary_batches), "--watchdog", "800"]
     try:
         res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=1200)
         lines = [json.loads(ln) for ln in res.stdout.splitlines() if ln.startswith("{")]
@@ -829,9 +829,10 @@ def boundary_leg(args, fanout):
                "boundary": {"path": first["path"], "workload": first["workload"], "ms_per_batch": first["ms_per_batch"],
                             "timed_batches": first["timed_batches"], "handover": first["handover"],
                             "by_batch_size": [l for l in legs if l["mode"] == "views"],
-                            "slab_only_trainer": {"note": "a trainer end that opens only the reference's slab (no views of the lane arena): "
-                                                          "the batch is copied (`copy`) or gathered (`gather`, LEGION_RUNNER_HANDOVER=gather) "
-                                                          "into the pipe slot by one launch per batch, two slots in flight",
+                            "slab_only_trainer": {"note": "a trainer end that opens only the reference's slab (no views of the lane arena): the batch "
+                                                          "is gathered (`slab`: what the server does by itself for such a trainer end) or copied "
+                                                          "(`copy`: LEGION_RUNNER_HANDOVER=copy) into the pipe slot by one launch per batch, two "
+                                                          "slots in flight",
                                                   "by_batch_size": [l for l in legs if l["mode"] != "views"]}}}
         if note:
             out["boundary"]["note"] = note

@@ -321,8 +321,12 @@ typedef struct LegionLinkCounters {
     uint64_t xgmi_read_bytes_link[8], xgmi_write_bytes_link[8];
     int32_t format_revision, content_revision;
     char pci_bus_id[32];
+    int32_t source;              /* 1 rocm_smi_lib's versioned decoder (rsmi_dev_gpu_metrics_info_get), 2 the table parsed by byte offset */
+    int32_t reserved;
 } LegionLinkCounters;
 int32_t legion_link_counters_ex(int32_t dev_id, LegionLinkCounters* out);
+/* the same from ONE source (1 / 2 as above; 0 = the library's decoder first, the byte-offset parser second, as _ex does) */
+int32_t legion_link_counters_from(int32_t dev_id, int32_t source, LegionLinkCounters* out);
 /* 64-byte transactions the gathers of dev_id have so far read from OTHER members' stripes of a striped feature cache
  * (rows read through a peer's pointer x row bytes / 64; enables the row-source statistics like
  * legion_cache_gather_stats).  The computed stand-in for the xGMI counter where the driver's table is unavailable or

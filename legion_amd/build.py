@@ -18,7 +18,7 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 ARCH = "gfx950"
 
 SOURCES = ["kernels_sample.hip", "kernels_gather.hip", "kernels_cache.hip", "kernels_synth.hip",
-           "storage.hip", "tuning.hip", "link_counters.hip", "collective.hip", "cache.hip", "operators.hip", "pipeline.hip", "ipc_env.hip", "server.hip"]
+           "storage.hip", "tuning.hip", "link_counters.hip", "collective.hip", "markers.hip", "cache.hip", "operators.hip", "pipeline.hip", "ipc_env.hip", "server.hip"]
 FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-fno-fast-math", "-Wall",
          "-Wno-unused-result", "-Wno-unused-function"] + os.environ.get("LEGION_EXTRA_HIPCC_FLAGS", "").split()
 
@@ -48,7 +48,7 @@ def build_lib(force=False, verbose=True):
     if failed:
         raise RuntimeError(f"hipcc failed for {failed}")
     if force or procs or not os.path.exists(LIB):
-        cmd = [HIPCC, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", LIB] + objs + ["-lpthread", "-lrt", "-L/opt/rocm/lib", "-lrccl",
+        cmd = [HIPCC, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", LIB] + objs + ["-lpthread", "-lrt", "-ldl", "-L/opt/rocm/lib", "-lrccl",
                                                                                         "-Wl,-rpath,/opt/rocm/lib"]
         if verbose:
             print(" ".join(cmd), flush=True)
@@ -96,7 +96,7 @@ def build_variant(name, extra_flags, verbose=True):
         raise RuntimeError(f"hipcc failed for {failed}")
     lib = os.path.join(out, "liblegion_hip.so")
     subprocess.check_call([HIPCC, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", lib] + objs +
-                          ["-lpthread", "-lrt", "-L/opt/rocm/lib", "-lrccl", "-Wl,-rpath,/opt/rocm/lib"])
+                          ["-lpthread", "-lrt", "-ldl", "-L/opt/rocm/lib", "-lrccl", "-Wl,-rpath,/opt/rocm/lib"])
     for o in objs:
         os.unlink(o)
     if verbose:

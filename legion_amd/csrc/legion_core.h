@@ -802,6 +802,16 @@ void launch_find(hipStream_t s, const int32_t* keys, int32_t n, const int32_t* m
                  const char* map8, int32_t* out32, char* out8);
 void launch_draw_batch(hipStream_t s, const int32_t* idx, const int32_t* deg, int32_t* out, int32_t n);
 
+// a roctx range for the enclosing scope (markers.hip): visible to rocprofv3 --marker-trace, near-free otherwise
+struct Range {
+    explicit Range(const char* fmt, ...) __attribute__((format(printf, 2, 3)));
+    ~Range();
+    Range(const Range&) = delete;
+    Range& operator=(const Range&) = delete;
+private:
+    bool on_;
+};
+
 // the hotness all-reduce (collective.hip): RCCL over the members of a clique that live in this process
 bool clique_is_physical(const std::vector<int32_t>& devs);
 double allreduce_u64_clique(const std::vector<int32_t>& devs, const std::vector<unsigned long long*>& bufs, int64_t count);

@@ -79,6 +79,7 @@ static void do_batch_generate(hipStream_t s, FeatureStorage* feature, const Lane
                               MemoryPool* pool0, int32_t batch_size, int32_t counter, int32_t dev_id, int32_t mode,
                               int32_t hop_num, const int32_t* iter_state)
 {
+    lg::Range mark("op0 batch_generate lanes=%d B=%d", n_lanes, batch_size);
     lg::SeedParams p;
     int32_t* all_ids = nullptr;
     int32_t* all_labels = nullptr;
@@ -105,6 +106,7 @@ static void do_random_sample(hipStream_t s, GraphStorage* graph, UnifiedCache* c
         printf("Sampling Parameters Error\n");   // counter_update's complaint, operator_impl.cu:86-88
         return;
     }
+    lg::Range mark("op%d sample%s fanout=%d lanes=%d", op_id, is_presc ? " (presc)" : "", count, n_lanes);
     lg::HopParams p;
     p.op_id = op_id;
     p.count = count;
@@ -139,6 +141,7 @@ static void do_feature_lookup(hipStream_t s, UnifiedCache* cache, const LanePtrs
         std::cout << "invalid feature table ptr\n";
         return;
     }
+    lg::Range mark("op%d gather lanes=%d first_op=%d", op_id, n_lanes, first_op_id);
     int64_t max_rows = pool0->feature_rows;
     if (max_rows > pool0->num_ids) max_rows = pool0->num_ids;
     const size_t hop = (size_t)(op_id / INTRABATCH_CON);          // grid bound: new nodes of op 3h <= B f1..fh

@@ -290,6 +290,7 @@ extern "C" int32_t legion_pipeline_submit_ex(LegionPipeline* p, int32_t counter0
     const int32_t si = p->rr;
     p->rr = (p->rr + 1) % p->slots_n;
     Slot& sl = p->slots[si];
+    lg::Range mark("group slot=%d first=%d lanes=%d mode=%d B=%d", si, counter0, n_active, mode, batch_size);
     slot_wait(p, sl);
     for (int32_t g = 0; g < p->group_size; g++) {
         sl.pools[g]->SetCurrentMode(mode);

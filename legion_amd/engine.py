@@ -61,12 +61,13 @@ def link_counters(dev_id=0):
     return (int(a.value), int(b.value)) if ok else None
 
 
-def link_counters_ex(dev_id=0):
+def link_counters_ex(dev_id=0, source=0):
     """The whole table as a dict (legion_hip.h: LegionLinkCounters) plus 'supported': PCIe bytes, xGMI bytes read / written
-    in total and per link, the gpu_metrics revision found and the GPU's PCI bus id."""
+    in total and per link, the gpu_metrics revision found, the GPU's PCI bus id and which decoder produced the numbers
+    (source: 0 = rocm_smi_lib's versioned decoder first, the byte-offset parser second; 1 / 2 = that one only)."""
     c = _libmod.LinkCounters()
-    ok = _libmod.load().legion_link_counters_ex(int(dev_id), ctypes.byref(c))
-    return {"supported": bool(ok), "pcie_bytes": int(c.pcie_bytes), "xgmi_read_bytes": int(c.xgmi_read_bytes),
+    ok = _libmod.load().legion_link_counters_from(int(dev_id), int(source), ctypes.byref(c))
+    return {"supported": bool(ok), "source": {0: None, 1: "rocm_smi_lib", 2: "sysfs gpu_metrics by offset"}.get(int(c.source)), "pcie_bytes": int(c.pcie_bytes), "xgmi_read_bytes": int(c.xgmi_read_bytes),
             "xgmi_write_bytes": int(c.xgmi_write_bytes), "xgmi_read_bytes_link": [int(x) for x in c.xgmi_read_bytes_link],
             "xgmi_write_bytes_link": [int(x) for x in c.xgmi_write_bytes_link],
             "gpu_metrics_revision": f"{int(c.format_revision)}.{int(c.content_revision)}",

@@ -116,6 +116,7 @@ SIGNATURES = {
     "legion_synth_feature_check": (None, [c_p, c_p, c_p, c_i64, c_i32, c_u64, c_p]),
     "legion_link_counters": (c_i32, [c_i32, P_U64, P_U64]),
     "legion_link_counters_ex": (c_i32, [c_i32, c_p]),
+    "legion_link_counters_from": (c_i32, [c_i32, c_i32, c_p]),
     "legion_cache_peer_transactions": (ctypes.c_uint64, [c_p, c_i32]),
     "legion_cache_gather_stats3": (None, [c_p, c_i32, P_U64]),
     "legion_cache_gather_stats_enable": (None, [c_p, c_i32]),
@@ -136,7 +137,8 @@ SIGNATURES = {
 class LinkCounters(ctypes.Structure):          # LegionLinkCounters
     _fields_ = [("pcie_bytes", c_u64), ("xgmi_read_bytes", c_u64), ("xgmi_write_bytes", c_u64),
                 ("xgmi_read_bytes_link", c_u64 * 8), ("xgmi_write_bytes_link", c_u64 * 8),
-                ("format_revision", c_i32), ("content_revision", c_i32), ("pci_bus_id", ctypes.c_char * 32)]
+                ("format_revision", c_i32), ("content_revision", c_i32), ("pci_bus_id", ctypes.c_char * 32),
+                ("source", c_i32), ("reserved", c_i32)]
 
 
 class Tuning(ctypes.Structure):                # LegionTuning (include/legion_hip.h section 6)

@@ -64,7 +64,7 @@ def test_struct_mirror_matches_the_header():
     n32 = sum(1 for t, _, _ in fields if t == "int32_t")
     assert fields[-1][0] == "uint64_t" and n32 == len(fields) - 1
     assert ctypes.sizeof(lib.Tuning) == (n32 * 4 + 7) // 8 * 8 + 16             # int32 fields, padding to 8, 2 uint64
-    assert ctypes.sizeof(lib.LinkCounters) == 8 * 3 + 8 * 16 + 8 + 32
+    assert ctypes.sizeof(lib.LinkCounters) == 8 * 3 + 8 * 16 + 8 + 32 + 8
 
 
 def test_link_counters_without_a_gpu_report_unsupported():

@@ -38,9 +38,11 @@ def main():
                     help="the consumer does not take batches as views of the server's lane arena (a trainer end that knows only the "
                          "reference's slab): LEGION_NO_DIRECT_VIEWS=1 for the python consumer, no `views` flag for the native one")
     ap.add_argument("--modes", type=str, default="",
-                    help="comma list of views|copy|gather: one server run per (mode, batch size) over the same data set files "
-                         "(views = handover auto + a consumer that takes views, copy = handover auto + a consumer that does not, "
-                         "gather = handover gather); overrides --handover / --no-views")
+                    help="comma list of views|slab|gather|copy: one server run per (mode, batch size) over the same data set files.  views = "
+                         "server as it starts by default + a consumer that takes views of the lane arena; slab = the same server + a "
+                         "consumer that opens only the reference's slab (the server then gathers each batch into the pipe slot); gather = "
+                         "LEGION_RUNNER_HANDOVER=gather (that hand-over for everybody, no arena); copy = LEGION_RUNNER_HANDOVER=copy (whole "
+                         "groups + one copy launch per batch); overrides --handover / --no-views")
     ap.add_argument("--min-timed-batches", type=int, default=0,
                     help="run as many epochs as it takes for the timed window to hold at least this many batches (views mode hands "
                          "over 100 k+ batches/s: a single epoch of a few thousand batches is a window of milliseconds)")
@@ -79,8 +81,8 @@ def main():
     try:
         for mode in (a.modes.split(",") if a.modes else [""]):
             if mode:
-                a.handover = "gather" if mode == "gather" else "auto"
-                a.no_views = mode == "copy"
+                a.handover = mode if mode in ("gather", "copy") else "auto"
+                a.no_views = mode != "views"
                 os.environ.pop("LEGION_NO_DIRECT_VIEWS", None)
             for b in batches:
                 n_train = b * tb[b] + 1
