@@ -92,6 +92,67 @@ class OneLine:
         return fallback
 
 
+class BulkPipe:
+    """engine.Pipeline's submit / wait / run_range interface over the two-phase bulk protocol (pipeline.hip): phase A on every
+    rank -> barrier -> phase B on every rank -> barrier.  No hipGraphs, no per-gather HIP events."""
+
+    def __init__(self, pipe, use_dist):
+        self.p, self.pools, self.use_dist = pipe, pipe.pools, use_dist
+        self.group_size = pipe.group_size
+        pipe.bulk_enable()
+        self.count_rows, self.rows_listed = False, 0
+        self.reset_clocks()
+
+    def reset_clocks(self):
+        self.t_a = self.t_b = self.t_bar = 0.0
+        self.groups = 0
+
+    def submit(self, counter0, mode=0, n_active=None):
+        t0 = time.perf_counter()
+        slot = self.p.bulk_phase_a(counter0, mode, n_active)
+        t1 = time.perf_counter()
+        if self.use_dist:
+            dist.barrier()
+        t2 = time.perf_counter()
+        if self.count_rows:
+            self.rows_listed += self.p.bulk_listed(slot)
+            t2 = time.perf_counter()
+        self.p.bulk_phase_b(slot)
+        t3 = time.perf_counter()
+        if self.use_dist:
+            dist.barrier()
+        t4 = time.perf_counter()
+        self.t_a += t1 - t0
+        self.t_b += t3 - t2
+        self.t_bar += (t2 - t1) + (t4 - t3)
+        self.groups += 1
+        return slot
+
+    def run_range(self, first, count, mode=0, wrap=None):
+        k, last = 0, None
+        while k < count:
+            b = (first + k) % wrap if wrap else first + k
+            n = min(self.group_size, count - k, (wrap - b) if wrap else count)
+            last = (self.submit(b, mode, n), b, n)
+            k += n
+        return last
+
+    def wait(self, slot=-1):
+        pass                                        # both phases synchronise their stream
+
+    def profile_begin(self):
+        pass
+
+    def profile_end(self):
+        pass
+
+    def profile_read(self):
+        return {}
+
+    def close(self):
+        self.p.close()
+
+
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -164,6 +225,8 @@ def parse_args():
     ap.add_argument("--no-striped-leg", action="store_true",
                     help="N > 1 without --stripe: skip the two extra timed legs with the caches striped over one clique of N "
                          "(plain, and with a hot-row replica of --striped-replica-memory bytes)")
+    ap.add_argument("--no-bulk-leg", action="store_true",
+                    help="N > 1: skip the `striped_bulk` leg (striped caches, remote rows pushed by their owners: peer_gather = bulk)")
     ap.add_argument("--striped-replica-memory", type=int, default=4 << 30,
                     help="bytes per GPU of the hot-row replica in the `striped_replica` leg")
     ap.add_argument("--backend", type=str, default="nccl", help="torch.distributed backend (nccl = RCCL)")
@@ -297,18 +360,36 @@ def main():
                 out_rep = run_leg(c, engine, synth, True, args.striped_replica_memory, headline=False)
                 if rank == 0:
                     out["striped_replica"] = out_rep["json"]
+            if not args.no_bulk_leg:
+                out_bulk = run_leg(c, engine, synth, True, 0, headline=False, bulk=True)
+                if rank == 0:
+                    out["striped_bulk"] = out_bulk["json"]
         except Exception as e:      # the headline stands; say what the extra leg did
+            import traceback
+            traceback.print_exc()
             if rank == 0:
                 out["extra_legs_error"] = f"{type(e).__name__}: {e}"[:600]
                 one_line.emit(out)
-            raise
+            # not `raise`: the armed libc exit hook is a Python callable, and an interpreter that finalises first would have
+            # libc call into it afterwards (segfault / changed exit status).  Leave without finalising, as the success path does.
+            sys.stdout.flush()
+            sys.stderr.flush()
+            os._exit(1)
 
     if rank == 0:
-        if world == 1 and not args.no_boundary and args.placement == "hbm":
-            out.update(boundary_leg(args, c.fanout))
-        if args.cpu_seconds > 0 and world == 1:      # reported at N = 1 only
-            out["cpu_baseline"] = cpu_baseline(indptr, col, c.mine, N, B, c.fanout, c.n_warm, args.cpu_seconds,
-                                               features if args.placement == "hbm" else None)
+        try:
+            if world == 1 and not args.no_boundary and args.placement == "hbm":
+                out.update(boundary_leg(args, c.fanout))
+            if args.cpu_seconds > 0 and world == 1:      # reported at N = 1 only
+                out["cpu_baseline"] = cpu_baseline(indptr, col, c.mine, N, B, c.fanout, c.n_warm, args.cpu_seconds,
+                                                   features if args.placement == "hbm" else None)
+        except Exception as e:      # (an armed exit hook must not outlive the interpreter: see above)
+            import traceback
+            traceback.print_exc()
+            out["post_legs_error"] = f"{type(e).__name__}: {e}"[:600]
+            one_line.emit(out)
+            sys.stderr.flush()
+            os._exit(1)
         one_line.emit(out)
     if use_dist:
         dist.barrier()
@@ -318,7 +399,7 @@ def main():
         os._exit(0)
 
 
-def run_leg(c, engine, synth, stripe, replica_memory, headline):
+def run_leg(c, engine, synth, stripe, replica_memory, headline, bulk=False):
     """One cache layout over the resident workload: objects -> PreSC -> hotness all-reduce -> cost model -> fills -> pipeline ->
     counting pass -> warm-up -> timed regions -> eager pass with HIP events around the gathers.  Returns {"json": rank 0's
     report of the leg}.  The headline leg also verifies, and runs the `overlapped` arrangement; the extra legs are shorter."""
@@ -467,8 +548,20 @@ def run_leg(c, engine, synth, stripe, replica_memory, headline):
     feature_rows = int(max_ids * 1.2)                                        # server.cu:277
     pool.close()
     weave = not (args.no_weave or args.split or args.overlap)
-    pipe = engine.Pipeline(graph, feature, cache, d, B, fanout, G, feature_rows, not args.no_graph, args.slots,
-                           args.overlap, args.split, weave)
+    if bulk:
+        # peer_gather = bulk (pipeline.hip): the rows of other members' stripes are pushed by their OWNERS; a group runs as
+        # phase A (own sampler + lists + local gather) -> barrier -> phase B (push for the others) -> barrier, eager launches
+        weave = False
+        pipe = BulkPipe(engine.Pipeline(graph, feature, cache, d, B, fanout, G, feature_rows, False, args.slots, arena=True), use_dist)
+        hs = [None] * world
+        dist.all_gather_object(hs, pipe.p.bulk_export())
+        for r, h in enumerate(hs):
+            if r != rank:
+                pipe.p.bulk_import(h)
+        dist.barrier()
+    else:
+        pipe = engine.Pipeline(graph, feature, cache, d, B, fanout, G, feature_rows, not args.no_graph, args.slots,
+                               args.overlap, args.split, weave)
     torch.cuda.synchronize()
     setup_s = time.time() - (c.t_setup if headline else t_leg)
 
@@ -484,6 +577,8 @@ def run_leg(c, engine, synth, stripe, replica_memory, headline):
     feat_hit_rows = feat_miss_rows = 0           # over every timed batch (all hops)
     if stripe:
         cache.gather_stats3(d)                   # arms the row-source counters for this (untimed) pass only
+    if bulk:
+        pipe.count_rows = True
     for k in range(n_timed):
         if k % G == 0:
             slot = pipe.submit((first + k) % wrap if wrap else first + k)
@@ -514,6 +609,9 @@ def run_leg(c, engine, synth, stripe, replica_memory, headline):
             src_g = pl.buffer("agg_src_ids")[:e].long()
             assert bool((ids.long()[pl.buffer("agg_src_off")[:e].long()] == src_g).all())
             hits = int((pl.buffer("cache_search_buffer")[:int(nc[1])] >= 0).sum())
+    if bulk:
+        pipe.count_rows = False
+        pipe.reset_clocks()
     source_rows = None
     if stripe:                                   # where this rank's gathers read the timed batches' hit rows from
         source_rows = cache.gather_stats3(d)
@@ -662,6 +760,14 @@ def run_leg(c, engine, synth, stripe, replica_memory, headline):
                               "peer_read_GBps_computed": peer_rows * D * 4 / max(own_region, 1e-9) / 1e9})
             if "xgmi_read_bytes" in mine_info:
                 mine_info["xgmi_read_bytes_per_region_measured"] = mine_info["xgmi_read_bytes"] / repeats
+        if bulk:
+            pushed = pipe.rows_listed                              # rows the other members pushed into this GPU per counted region
+            mine_info["bulk"] = {"rows_pushed_into_me_per_region": pushed, "bytes_pushed_into_me_per_region": pushed * D * 4,
+                                 "phase_a_s_per_group": pipe.t_a / max(pipe.groups, 1), "phase_b_s_per_group": pipe.t_b / max(pipe.groups, 1),
+                                 "barriers_s_per_group": pipe.t_bar / max(pipe.groups, 1), "groups_clocked": pipe.groups,
+                                 "push_GBps_out_of_me": (pushed * D * 4 / max(args.steps, 1)) / max(pipe.t_b / max(pipe.groups, 1), 1e-9) / 1e9,
+                                 "note": "phase A = own sampler + per-owner lists + gather of local rows; phase B = this GPU as an owner pushing "
+                                         "the rows the others listed (about as many as were pushed into it); wall clock incl. stream synchronise"}
         per_rank = [None] * world
         dist.all_gather_object(per_rank, mine_info)
 
@@ -711,6 +817,12 @@ def run_leg(c, engine, synth, stripe, replica_memory, headline):
                            "one clique of all ranks (hotness rank t on GPU t % N), remote rows and adjacency read with direct peer loads "
                            "over xGMI; per_rank[].rows_from_* were counted by the gather itself in an untimed pass over the timed batches, "
                            "xgmi_* are deltas of the driver's cumulative gpu_metrics counters over the timed regions"}
+            if bulk:
+                out["peer_gather"] = "bulk"
+                out["note"] = ("same striped clique as `striped`, but the rows of other members' stripes are listed per owner and PUSHED by the "
+                               "owners (LegionTuning.peer_gather = bulk: whole rows as coalesced posted stores over xGMI instead of scattered "
+                               "512-1024-byte load round trips); eager launches, two host barriers per launch group (per_rank[].bulk has the "
+                               "phase clocks): compare its xGMI GB/s and ms_per_step with `striped`, minus the barrier time")
         else:
             out = {
                 "metric": "sampled_edges_per_sec",

@@ -278,6 +278,21 @@ int32_t legion_pipeline_submit_n(LegionPipeline* p, int32_t counter0, int32_t mo
 void legion_pipeline_wait(LegionPipeline* p, int32_t slot);                          /* slot < 0: all slots */
 LegionMemoryPool* legion_pipeline_pool(LegionPipeline* p, int32_t slot, int32_t lane);
 void legion_pipeline_destroy(LegionPipeline* p);
+/* Owner-bucketed bulk transfer for a striped feature cache (LegionTuning.peer_gather = bulk; SURVEY section 7 "hard parts"; the
+ * alternative to the 512-1024-byte direct peer loads of SS/cache/cache_impl.cuh:268).  A pipeline created with use_graph bit 5 keeps
+ * its lanes' trainer-visible arrays in ONE exportable allocation (the lane arena).  Per group, phase A on every member of the clique
+ * (sampler, bucket pass that lists per owner {row inside its stripe, destination inside the requester's arena}, gather of everything
+ * that is not another member's stripe) -> the caller's barrier -> phase B on every member as an OWNER (its rows, read from its own
+ * HBM, pushed to the requesters with coalesced posted stores) -> barrier.  Lookup results and rows are those of the direct
+ * arrangement, bit for bit.  _export / _import carry a member's IPC handles (<= 512 bytes) between processes, _link takes a member
+ * that lives in the same process. */
+int32_t legion_pipeline_bulk_enable(LegionPipeline* p);
+int32_t legion_pipeline_bulk_export(LegionPipeline* p, void* out_handles, int32_t out_bytes);
+int32_t legion_pipeline_bulk_import(LegionPipeline* p, const void* handles);
+int32_t legion_pipeline_bulk_link(LegionPipeline* p, LegionPipeline* other);
+int32_t legion_pipeline_bulk_phase_a(LegionPipeline* p, int32_t counter0, int32_t mode, int32_t n_active, int32_t batch_size);
+void legion_pipeline_bulk_phase_b(LegionPipeline* p, int32_t slot);
+int64_t legion_pipeline_bulk_listed(LegionPipeline* p, int32_t slot);
 /* Measurement aid: HIP events on each slot's stream around every gather launch.  While it is on,
  * groups are launched eagerly (HIP cannot time events recorded by graph nodes).  read() fills, per
  * gather op id, the summed elapsed ms and the launch count of every batch waited for since begin();
@@ -390,7 +405,6 @@ typedef struct LegionTuning {
                                     -1 low, 0 equal, 1 high */
     int32_t runner_graph;        /* LEGION_RUNNER_GRAPH    (1): Runner serves from lane groups + hipGraph; 0 = operator by operator */
     int32_t runner_lanes;        /* LEGION_RUNNER_LANES    (0 = min(128, 262144 / batch)): lanes of a Runner group */
-    int32_t runner_pair;         /* LEGION_RUNNER_PAIR     (1): one hand-over launch for two batches when both pipe slots are free */
     int32_t runner_ho_stream;    /* LEGION_RUNNER_HO_STREAM (2): hand-over streams: 0 the sampler's, 1 one shared, 2 one per pipe slot */
     int32_t runner_stats;        /* LEGION_RUNNER_STATS    (0): print where a hand-over's time went at Finalize */
     int32_t runner_handover;     /* LEGION_RUNNER_HANDOVER=auto|gather|copy -> 0|1|2: how the Runner's batches reach a trainer.  auto: the lanes of

@@ -557,7 +557,29 @@ unsigned long long int* UnifiedCache::GetEdgeAccessedMap(int32_t dev_id)
 
 // SS/cache/cache.cu:726-748 -- lookup (FindFeat) fused into the gather
 void UnifiedCache::FeatCacheLookup(const LanePtrs* d_lanes, int32_t n_lanes, int32_t op_id, int32_t dev_id,
-                                   hipStream_t strm_hdl, int32_t max_rows, bool use_snapshot, int32_t first_op_id, bool last_op)
+                                   hipStream_t strm_hdl, int32_t max_rows, bool use_snapshot, int32_t first_op_id, bool last_op,
+                                   bool skip_remote)
+{
+    lg::GatherParams g = GatherParamsOf(dev_id, op_id, max_rows, use_snapshot, first_op_id, last_op);
+    g.skip_remote = skip_remote;
+    lg::launch_gather(strm_hdl, g, d_lanes, n_lanes);
+}
+
+void UnifiedCache::BulkBucket(const LanePtrs* d_lanes, int32_t n_lanes, int32_t op_id, int32_t dev_id, hipStream_t s, int32_t max_rows,
+                              const lg::BulkLists& lists, const char* arena_base)
+{
+    const lg::GatherParams g = GatherParamsOf(dev_id, op_id, max_rows, true, 1, true);
+    lg::launch_bulk_bucket(s, g, d_lanes, n_lanes, lists, arena_base);
+}
+
+void UnifiedCache::BulkPush(int32_t owner_dev, hipStream_t s, const int32_t* fidx, const int64_t* dst, const unsigned long long* cnt,
+                            int64_t cap, char* peer_arena)
+{
+    lg::launch_bulk_push(s, float_feature_cache_[owner_dev], CachePitch(), float_feature_len_, fidx, dst, cnt, cap, peer_arena);
+}
+
+lg::GatherParams UnifiedCache::GatherParamsOf(int32_t dev_id, int32_t op_id, int32_t max_rows, bool use_snapshot, int32_t first_op_id,
+                                              bool last_op)
 {
     const bool filled = !node_capacity_.empty() && d_float_feature_cache_ptr_[dev_id] != nullptr &&
                         cache_controller_[dev_id]->NodeMap() != nullptr;
@@ -581,7 +603,8 @@ void UnifiedCache::FeatCacheLookup(const LanePtrs* d_lanes, int32_t n_lanes, int
     g.hop = use_snapshot ? op_id / INTRABATCH_CON : -1;
     g.first_hop = (use_snapshot && first_op_id >= 0 && first_op_id < op_id) ? first_op_id / INTRABATCH_CON : g.hop;
     g.last_op = last_op;
-    lg::launch_gather(strm_hdl, g, d_lanes, n_lanes);
+    g.skip_remote = false;
+    return g;
 }
 
 // ---- C API ----------------------------------------------------------------------------------

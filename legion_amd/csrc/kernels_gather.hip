@@ -212,6 +212,8 @@ __global__ __launch_bounds__(LG_GATHER_THREADS, LG_GATHER_MIN_WAVES) void gather
                 p = LG_GPTR(const float, gp.replica) + rank * gp.cache_pitch;
             else if (didx == gp.member && gp.local_table != nullptr)     // own stripe: its address came with the launch
                 p = LG_GPTR(const float, gp.local_table) + (int64_t)fidx * gp.cache_pitch;
+            else if (gp.skip_remote)     // peer_gather = bulk: the owner pushes this row (bulk_push_kernel); nothing to fetch here
+                p = nullptr;
             else
                 p = LG_GPTR(const float, gp.cache_tables[didx]) + (int64_t)fidx * gp.cache_pitch;                  // :268
             if (counting) {    // tests / diagnostics / the computed xGMI count: [0] rows read through a stripe pointer, [1] from the
@@ -318,6 +320,99 @@ __global__ __launch_bounds__(LG_GATHER_THREADS, LG_GATHER_MIN_WAVES) void gather
         __syncthreads();
         buf ^= 1;
     }
+}
+
+// ------------------------------------------------------------------------------------------
+// peer_gather = bulk, requester side: every row of the group's batches that is a hit in ANOTHER member's stripe (and not in the
+// local replica) is listed for its owner -- {row inside the owner's stripe, byte offset of the destination row inside this
+// GPU's lane arena} -- one reservation per wave and owner (ballot + popcount).  The order inside a list is arbitrary; what lands
+// where is not.  Same lookup as the gather's (FindFeat: carried slot or node_map[id]).
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void bulk_bucket_kernel(GatherParams gp, const LanePtrs* __restrict__ lanes, BulkLists b, const char* arena_base)
+{
+    const LanePtrs& L = lanes[blockIdx.y];
+    const LG_G int32_t* nc = LG_GPTR(const int32_t, L.node_counter);
+    const int32_t hop_num = nc[INTRABATCH_CON * 3 - 1];
+    int32_t n = nc[INTRABATCH_CON * 3 + hop_num];
+    if (n > L.feature_rows) n = L.feature_rows;
+    if (n > gp.max_rows) n = gp.max_rows;
+    const LG_G int32_t* sampled_ids = LG_GPTR(const int32_t, L.sampled_ids);
+    const LG_G int32_t* node_slot = (L.node_slot != nullptr && gp.node_map != nullptr) ? LG_GPTR(const int32_t, L.node_slot) : nullptr;
+    const int32_t lane = threadIdx.x & 63;
+    for (int32_t r0 = (blockIdx.x * 256 + (threadIdx.x & ~63)); r0 < n; r0 += gridDim.x * 256) {     // a wave takes 64 consecutive rows
+        const int32_t r = r0 + lane;
+        int32_t owner = -1, fidx = 0;
+        if (r < n) {
+            const int32_t id = sampled_ids[r];
+            int32_t g = node_slot != nullptr ? node_slot[r] : LG_FS_UNKNOWN;
+            if (g == LG_FS_UNKNOWN) g = (gp.node_map != nullptr && id >= 0) ? gp.node_map[id] : CACHEMISS_FLAG;
+            if (g >= 0) {
+                const int32_t didx = g / gp.node_capacity;
+                fidx = g - didx * gp.node_capacity;
+                const int64_t rank = (int64_t)fidx * gp.Kg + didx;
+                const bool local_copy = gp.replica != nullptr && rank < gp.replica_rows;
+                if (!local_copy && didx != gp.member) owner = didx;
+            }
+        }
+        for (int32_t o = 0; o < b.Kg; o++) {
+            const unsigned long long m = __ballot(owner == o);
+            if (m == 0ull) continue;
+            unsigned long long base = 0;
+            if (lane == __ffsll((long long)m) - 1) base = atomicAdd(b.cnt + o, (unsigned long long)__popcll(m));
+            base = __shfl(base, __ffsll((long long)m) - 1);
+            if (owner == o) {
+                const int64_t at = (int64_t)base + __popcll(m & ((lane == 0) ? 0ull : (~0ull >> (64 - lane))));
+                if (at < b.cap) {
+                    b.fidx[(int64_t)o * b.cap + at] = fidx;
+                    b.dst[(int64_t)o * b.cap + at] = (const char*)(L.float_features + (int64_t)r * gp.D) - arena_base;
+                }
+            }
+        }
+    }
+}
+
+void launch_bulk_bucket(hipStream_t s, const GatherParams& g, const LanePtrs* d_lanes, int32_t n_lanes, const BulkLists& lists,
+                        const char* arena_base)
+{
+    if (g.D <= 0 || g.max_rows <= 0 || g.node_map == nullptr || g.Kg <= 1) return;
+    GatherParams gp = g;
+    if (gp.node_capacity < 1) gp.node_capacity = 1;
+    int32_t gx = (g.max_rows + 255) / 256;
+    while (gx > 16 && (int64_t)gx * n_lanes > 16384) gx = (gx + 1) / 2;
+    bulk_bucket_kernel<<<dim3(gx, n_lanes), 256, 0, s>>>(gp, d_lanes, lists, arena_base);
+    hipCheckError();
+}
+
+// ------------------------------------------------------------------------------------------
+// peer_gather = bulk, owner side: the rows a requester listed for THIS GPU's stripe, read from local HBM and written straight to
+// their destination rows in the requester's lane arena -- whole rows, 16-byte chunks, consecutive lanes on consecutive chunks:
+// over xGMI these are posted stores of contiguous 512-1024-byte runs instead of the requester's scattered load round trips.
+// The lists (12 bytes per row) are read through the requester's peer mapping.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void bulk_push_kernel(const float* __restrict__ stripe, int32_t pitch, int32_t D, const int32_t* __restrict__ fidx,
+                                                       const int64_t* __restrict__ dst, const unsigned long long* __restrict__ cnt,
+                                                       int64_t cap, char* __restrict__ peer_arena)
+{
+    typedef float v4u __attribute__((ext_vector_type(4), aligned(4)));
+    int64_t n = (int64_t)cnt[0];
+    if (n > cap) n = cap;
+    const int32_t lane = threadIdx.x & 63;
+    const int64_t wave = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 6, nwaves = ((int64_t)gridDim.x * 256) >> 6;
+    const int32_t C = D / 4;
+    for (int64_t i = wave; i < n; i += nwaves) {
+        const LG_G float* src = LG_GPTR(const float, stripe) + (int64_t)fidx[i] * pitch;
+        LG_G float* out = (LG_G float*)(peer_arena + dst[i]);
+        for (int32_t c = lane; c < C; c += 64) ((LG_G v4u*)out)[c] = ((const LG_G v4u*)src)[c];
+        for (int32_t k = C * 4 + lane; k < D; k += 64) out[k] = src[k];
+    }
+}
+
+void launch_bulk_push(hipStream_t s, const float* stripe, int32_t pitch, int32_t D, const int32_t* fidx, const int64_t* dst,
+                      const unsigned long long* cnt, int64_t cap, char* peer_arena)
+{
+    if (stripe == nullptr || D <= 0 || cap <= 0) return;
+    bulk_push_kernel<<<2048, 256, 0, s>>>(stripe, pitch < D ? D : pitch, D, fidx, dst, cnt, cap, peer_arena);
+    hipCheckError();
 }
 
 // tiles of a lane are walked by gx workgroups: about LG_GATHER_TARGET_WG workgroups per launch, never more than tiles

@@ -236,7 +236,7 @@ struct SampleArgs {
     int32_t* const* csr_dst_x;
     const LG_G int32_t* col_full; const LG_G lg_v2i* colx_full;
     const LG_G RowHdr* row_hdr;
-    bool last_hop, is_presc;
+    bool last_hop, is_presc, loser_in_dst;
     LG_G unsigned long long* edge_access_time;
     LG_G unsigned long long* topo_transactions;
     // the lane's buffers, in the global address space (see LG_G in legion_core.h)
@@ -279,7 +279,7 @@ __device__ __forceinline__ SampleArgs lane_args(const HopParams& p, const LanePt
     SampleArgs a;
     a.op_id = p.op_id; a.count = p.count; a.partition_count = p.partition_count; a.max_slots = p.max_slots;
     a.csr_dst_node_ids = p.csr_dst_node_ids; a.csr_dst_x = p.csr_dst_x;
-    a.col_full = LG_GPTR(const int32_t, p.col_full); a.colx_full = LG_GPTR(const lg_v2i, p.colx_full); a.row_hdr = LG_GPTR(const RowHdr, p.row_hdr); a.last_hop = p.last_hop; a.is_presc = p.is_presc;
+    a.col_full = LG_GPTR(const int32_t, p.col_full); a.colx_full = LG_GPTR(const lg_v2i, p.colx_full); a.row_hdr = LG_GPTR(const RowHdr, p.row_hdr); a.last_hop = p.last_hop; a.is_presc = p.is_presc; a.loser_in_dst = p.loser_in_dst;
     a.edge_access_time = LG_GPTR(unsigned long long, p.edge_access_time);
     a.topo_transactions = LG_GPTR(unsigned long long, p.topo_transactions);
     a.sampled_ids = LG_GPTR(int32_t, L.sampled_ids); a.agg_src_ids = LG_GPTR(int32_t, L.agg_src_ids);
@@ -828,7 +828,8 @@ void dedup_lds_kernel(HopParams hp, const LanePtrs* __restrict__ lanes)
                     p = (p + 1) & (LG_LDS_TABLE - 1);
                 }
                 if (v != (PENDING | slot)) {          // not the lowest slot of a new vertex
-                    a.slot_mark[slot] = a.mark_tag;
+                    if (a.loser_in_dst) a.slot_dst[slot] = (int32_t)(id | LG_LOSER_BIT);      // (vertex ids < 2^30: the mark rides in the id)
+                    else a.slot_mark[slot] = a.mark_tag;
                     a.slot_pos[slot] = (v & PENDING) ? -2 - (int32_t)(v & ~PENDING) : (int32_t)v;
                 }
             }
@@ -917,16 +918,18 @@ void compact_kernel(HopParams hp, const LanePtrs* __restrict__ lanes)
         const int32_t idx0 = st * LG_SUPER;
         int32_t v[LG_SLOTS_PER_LANE], mk[LG_SLOTS_PER_LANE];
         unsigned long long mv[LG_SLOTS_PER_LANE], mf[LG_SLOTS_PER_LANE];
+        const bool inl = a.loser_in_dst;                                  // (uniform) the loser mark rides in slot_dst
 #pragma unroll
         for (int u = 0; u < LG_SLOTS_PER_LANE; u++) {
             const int32_t idx = idx0 + u * LG_TILE + tid;
             v[u] = idx < total ? a.slot_dst[idx] : -1;
-            mk[u] = idx < total ? a.slot_mark[idx] : 0;
+            mk[u] = (idx < total && !inl) ? a.slot_mark[idx] : 0;
         }
 #pragma unroll
         for (int u = 0; u < LG_SLOTS_PER_LANE; u++) {
             const bool valid = v[u] >= 0;
-            const bool first = valid && mk[u] != a.mark_tag;              // nobody marked it a loser in this hop
+            const bool first = valid && (inl ? (v[u] & LG_LOSER_BIT) == 0 : mk[u] != a.mark_tag);   // nobody marked it a loser in this hop
+            if (valid && inl) v[u] &= ~LG_LOSER_BIT;
             mv[u] = __ballot(valid);
             mf[u] = __ballot(first);
             if (lane == 0) {
@@ -1087,9 +1090,12 @@ void compact_kernel(HopParams hp, const LanePtrs* __restrict__ lanes)
     // ec[2] = n_edge being what the reference's atomicAdds (:263-264) leave there; hop scratch; status words back to zero
     if (tid == 0) {
         // this thread wrote the tiles' status words: they must have landed before the count says "finished", or the last
-        // workgroup's zeroes could be overtaken by one of them.  A workgroup-scope release is a wait for the thread's own
-        // stores, nothing else (no L2 write-back, unlike the agent-scope fence above)
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        // workgroup could read state[nsuper-1] before its PREF word is there, or its zeroes could be overtaken by one of them.
+        // A workgroup-scope release fence does NOT wait for the thread's own global stores on gfx950 (it compiles to nothing
+        // before the atomic: global_store ... ; global_atomic_add); what orders them is an explicit wait for this thread's
+        // outstanding memory operations -- vmcnt(0): stores count in vmcnt on CDNA -- and nothing else is needed: the status
+        // words are self-contained and read with agent-scope atomics at the L2 they were written through.
+        __builtin_amdgcn_s_waitcnt(0x0F70);                // vmcnt(0), expcnt / lgkmcnt untouched
         s_last = (__hip_atomic_fetch_add(hs + HS_CDONE, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (int32_t)gridDim.x - 1) ? 1 : 0;
     }
     __syncthreads();

@@ -193,6 +193,7 @@ enum HopScratch {
 // Feature-cache slot of a sampled neighbour, carried from the sampler to the gather (see "column slots", GraphStorage):
 // a value >= 0 or CACHEMISS_FLAG is what node_map[id] holds; LG_FS_UNKNOWN means "not carried: look it up"
 #define LG_FS_UNKNOWN (-3)
+#define LG_LOSER_BIT 0x40000000   // see HopParams::loser_in_dst
 
 #define LG_TILE 256            // compaction tile == threads per workgroup in the sampler kernels
 #define LG_SLOTS_PER_LANE 4    // independent slots each lane keeps in flight
@@ -488,6 +489,8 @@ public:
 };
 CacheController* NewPreSCCacheController(int32_t train_step, int32_t device_count);
 
+namespace lg { struct BulkLists; struct GatherParams; }
+
 class UnifiedCache {
 public:
     void Initialize(int64_t cache_memory, int32_t float_feature_len, int32_t train_step,
@@ -527,7 +530,14 @@ public:
     // the gather over a group of lanes (the reference's per-array arguments live in LanePtrs)
     // first_op_id < op_id: one launch also covers the new-node ranges of the earlier ops first_op_id, +3, ...
     void FeatCacheLookup(const LanePtrs* d_lanes, int32_t n_lanes, int32_t op_id, int32_t dev_id,
-                         hipStream_t strm_hdl, int32_t max_rows, bool use_snapshot, int32_t first_op_id = -1, bool last_op = true);
+                         hipStream_t strm_hdl, int32_t max_rows, bool use_snapshot, int32_t first_op_id = -1, bool last_op = true,
+                         bool skip_remote = false);
+    // peer_gather = bulk (lg::BulkLists): the requester's bucket pass over every row of its group's batches, and the owner's push
+    void BulkBucket(const LanePtrs* d_lanes, int32_t n_lanes, int32_t op_id, int32_t dev_id, hipStream_t s, int32_t max_rows,
+                    const lg::BulkLists& lists, const char* arena_base);
+    lg::GatherParams GatherParamsOf(int32_t dev_id, int32_t op_id, int32_t max_rows, bool use_snapshot, int32_t first_op_id, bool last_op);
+    void BulkPush(int32_t owner_dev, hipStream_t s, const int32_t* fidx, const int64_t* dst, const unsigned long long* cnt,
+                  int64_t cap, char* peer_arena);
 
     // new / exposed for the C API and the fused kernels
     void SetCapacity(int32_t node_capacity, int32_t edge_capacity);
@@ -732,6 +742,8 @@ struct HopParams {                  // what every lane of a launch shares
     int32_t max_slots;              // capacity of slot_dst for this hop
     unsigned long long* edge_access_time;  // presample only (single lane), else null
     unsigned long long* topo_transactions; // presample only: 64-byte transactions the hop's topology reads amount to
+    bool loser_in_dst;              // lds form, vertex ids < 2^30: a slot that lost its first touch carries LG_LOSER_BIT in slot_dst (written by
+                                    // the de-duplication kernel) instead of the hop's tag in slot_mark -- the compaction then streams one array less
     int32_t lds_bucket_bits;        // lds form: LG_LDS_BITS_SMALL / SMALL16 / MEDIUM / LARGE (the pool's)
     int32_t lds_k;                  // lds form: super tiles per partition tile in this hop (set by launch_random_sample)
 };
@@ -771,7 +783,25 @@ struct GatherParams {
     int32_t first_hop;              // with hop >= 0: also gather the ranges of hops first_hop .. hop-1 (they are adjacent in
                                     // sampled_ids); == hop for a plain single-op gather
     bool last_op;                   // the gather of the batch's last op (kernel instance of its own: hand-over, traces)
+    bool skip_remote;               // peer_gather = bulk: rows of OTHER members' stripes are not fetched here (their owners push them)
 };
+
+// Owner-bucketed bulk transfer of a striped gather (LegionTuning.peer_gather = bulk; SURVEY section 7 "hard parts", the
+// alternative to 512-1024-byte direct loads over xGMI, SS/cache/cache_impl.cuh:268).  The REQUESTER lists, per owner, the rows
+// of that owner's stripe its launch group needs and where they go: row index inside the stripe, byte offset of the destination
+// row inside the requester's lane arena.  The OWNER then reads its own HBM and pushes whole rows to the requester with
+// coalesced posted stores (bulk_push_kernel).  One list set per pipeline slot, in requester memory, exported to the owners.
+struct BulkLists {
+    int32_t Kg;
+    int64_t cap;                     // entries per owner list
+    int32_t* fidx;                   // [Kg][cap]
+    int64_t* dst;                    // [Kg][cap]
+    unsigned long long* cnt;         // [Kg] entries listed (never beyond cap: a group has at most cap rows)
+};
+void launch_bulk_bucket(hipStream_t s, const GatherParams& g, const LanePtrs* d_lanes, int32_t n_lanes, const BulkLists& lists,
+                        const char* arena_base);
+void launch_bulk_push(hipStream_t s, const float* stripe, int32_t pitch, int32_t D, const int32_t* fidx, const int64_t* dst,
+                      const unsigned long long* cnt, int64_t cap, char* peer_arena);
 void launch_gather(hipStream_t s, const GatherParams& g, const LanePtrs* d_lanes, int32_t n_lanes);
 void launch_deliver(hipStream_t s, const LanePtrs* d_lane, const DeliverParams& d);
 // the whole finished batch of a lane -- ids, feature rows, labels, both edge arrays, counters -- copied into a pipe slot

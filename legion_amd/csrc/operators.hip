@@ -125,6 +125,7 @@ static void do_random_sample(hipStream_t s, GraphStorage* graph, UnifiedCache* c
     p.max_slots = (int32_t)(hop < pool0->max_new.size() ? pool0->max_new[hop] : pool0->max_slots);
     p.edge_access_time = (is_presc && cache) ? cache->GetEdgeAccessedMap(dev_id) : nullptr;   // :473
     p.topo_transactions = (is_presc && cache) ? cache->Controller(dev_id)->GetTopoTransactions() : nullptr;
+    p.loser_in_dst = pool0->lds_form && (int64_t)pool0->total_num_nodes <= ((int64_t)1 << 30);
     p.lds_bucket_bits = pool0->lds_bucket_bits;
     p.lds_k = 1;                             // (launch_random_sample picks the hop's partition tile)
     lg::launch_random_sample(s, p, d_lanes, n_lanes, pool0->lds_form ? 2 : (pool0->pos_table != nullptr ? 1 : 0));
@@ -330,6 +331,7 @@ extern "C" void legion_gather_rows(legion_stream_t stream, const float* full_tab
     g.node_capacity = node_capacity;
     g.D = float_feature_len;
     g.cache_pitch = float_feature_len;
+    g.skip_remote = false;
     g.total_num_nodes = total_num_nodes;
     g.max_rows = max_rows;
     lg::launch_gather_explicit(static_cast<hipStream_t>(stream), g, sampled_ids, cache_index_out, range_devptr, dst,

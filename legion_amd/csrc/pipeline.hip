@@ -21,6 +21,7 @@
 #include "legion_core.h"
 
 #include <algorithm>
+#include <cstring>
 #include <map>
 
 struct LegionLaneGroup;
@@ -52,6 +53,21 @@ struct Slot {
     int32_t prof_pairs = 0;                   // timed gathers of the group in flight
 };
 
+// peer_gather = bulk (lg::BulkLists, kernels_gather.hip): per pipeline slot this GPU's request lists, and what it knows of
+// the other members of its clique -- their lane arenas and their lists, as pointers this process can dereference
+struct BulkPeer {
+    char* arena = nullptr;
+    std::vector<lg::BulkLists> lists;            // [slot], pointers into the peer's memory
+};
+struct BulkState {
+    int32_t Kg = 1, member = 0;
+    int64_t cap = 0;
+    std::vector<void*> alloc;                    // [slot] one exportable allocation: cnt | fidx | dst
+    std::vector<lg::BulkLists> mine;             // [slot]
+    std::vector<BulkPeer> peers;                 // [Kg]
+    std::vector<hipStream_t> owner_streams;      // [Kg] in-process pull: a stream on each owner's device for THIS requester's pushes
+};
+
 struct LegionPipeline {
     GraphStorage* graph;
     FeatureStorage* feature;
@@ -73,6 +89,10 @@ struct LegionPipeline {
     bool profiling = false;
     std::map<int32_t, double> prof_ms;        // op id -> summed elapsed ms of its gather launches
     std::map<int32_t, int64_t> prof_cnt;
+    PoolArena arena;                          // use_graph bit 5: the lanes' trainer-visible arrays live in ONE exportable allocation
+    BulkState* bulk = nullptr;
+    bool arena_borrowed = false;              // the arena belongs to the caller (legion_pipeline_bulk_enable_shared)
+    int64_t feature_rows = 0;
 };
 
 extern "C" LegionPipeline* legion_pipeline_create(LegionGraphStorage* graph, LegionFeatureStorage* feature,
@@ -139,6 +159,15 @@ extern "C" LegionPipeline* legion_pipeline_create(LegionGraphStorage* graph, Leg
         if (prio < 0) p->gather_high = true;
     }
     p->slots.resize(p->slots_n);
+    p->feature_rows = feature_rows;
+    if ((use_graph & 32) != 0) {       // one arena for every lane (peer_gather = bulk: the owners push rows into it)
+        const int32_t D = p->feature->GetFloatFeatureLen();
+        int64_t num_ids = batch_size, per = batch_size;
+        for (int32_t h = 0; h < hop_num; h++) { per *= fanout[h]; num_ids += per; }
+        p->arena.bytes = lg_pool_arena_bytes(batch_size, num_ids, feature_rows, D) * p->group_size * p->slots_n;
+        p->arena.base = (char*)d_alloc_space(p->arena.bytes);
+        lg_set_pool_arena(&p->arena);
+    }
     lg_set_pool_lanes_hint(p->group_size * p->slots_n);   // direct-vs-table choice of the position state sees every lane
     {   // what PreSC saw of the largest hop decides the small class's bucket count (8 or 16, storage.hip)
         int32_t last_hop[2] = {0, 0};
@@ -176,6 +205,7 @@ extern "C" LegionPipeline* legion_pipeline_create(LegionGraphStorage* graph, Leg
     }
     lg_set_pool_lanes_hint(0);
     lg_set_pool_claims_hint(0, 0);
+    lg_set_pool_arena(nullptr);
     return p;
 }
 
@@ -426,7 +456,246 @@ extern "C" void legion_pipeline_destroy(LegionPipeline* p)
         if (p->overlap || &sl == &p->slots[0]) HIP_CALL(hipStreamDestroy(sl.stream));
     }
     if (p->sample_stream) HIP_CALL(hipStreamDestroy(p->sample_stream));
+    if (p->bulk) {
+        for (size_t o = 0; o < p->bulk->owner_streams.size(); o++)
+            if (p->bulk->owner_streams[o] != nullptr) {
+                SetGPUDevice(p->dev_id / p->bulk->Kg * p->bulk->Kg + (int32_t)o);
+                HIP_CALL(hipStreamDestroy(p->bulk->owner_streams[o]));
+            }
+        SetGPUDevice(p->dev_id);
+        for (void* a : p->bulk->alloc) d_free_space(a);
+        delete p->bulk;
+    }
+    if (p->arena.base && !p->arena_borrowed) d_free_space(p->arena.base);
     delete p;
+}
+
+// ---- peer_gather = bulk: owner-bucketed transfer of the rows a striped gather needs from other members ----------------------
+// (kernels_gather.hip bulk_bucket_kernel / bulk_push_kernel; LegionTuning.peer_gather.)  A group is produced in two host-visible
+// phases, because the owners of the rows are other GPUs -- possibly other processes -- that must know the group's lists are final:
+//   phase A (every member, its own group):  sampler -> bucket pass (per-owner lists) -> gather of everything that is NOT another
+//            member's stripe (own stripe, replica, misses); stream synchronised on return
+//   --- the caller's barrier over the clique (threads: any barrier; processes: e.g. torch.distributed) ---
+//   phase B (every member, as an owner):    for every other member, push the rows it listed for this GPU into its lane arena;
+//            stream synchronised on return
+//   --- barrier --- : every lane of the slot holds its complete batch.
+// Lookup results (cache_search_buffer, hit mask) and rows are those of the direct arrangement, bit for bit.
+struct LegionBulkHandles {
+    hipIpcMemHandle_t arena;
+    hipIpcMemHandle_t lists[4];
+    int64_t cap;
+    int32_t slots, member;
+};
+
+extern "C" int32_t legion_pipeline_bulk_enable(LegionPipeline* p)
+{
+    if (!p || p->arena.base == nullptr) { printf("legion_hip: bulk transfers need a pipeline created with arena-backed lanes (use_graph bit 5)\n"); return 0; }
+    if (p->slots_n > 4) { printf("legion_hip: at most 4 pipeline slots with bulk transfers\n"); return 0; }
+    UnifiedCache* cache = reinterpret_cast<UnifiedCache*>(p->cache_handle);
+    SetGPUDevice(p->dev_id);
+    BulkState* b = new BulkState();
+    b->Kg = cache->Kg_ > 0 ? cache->Kg_ : 1;
+    b->member = p->dev_id % b->Kg;
+    b->cap = (int64_t)p->group_size * std::max<int64_t>(p->feature_rows, 1);
+    b->peers.resize(b->Kg);
+    for (int32_t s = 0; s < p->slots_n; s++) {
+        const int64_t bytes = 256 + b->Kg * b->cap * 12;
+        char* a = (char*)d_alloc_space(bytes);
+        HIP_CALL(hipMemset(a, 0, 256));
+        lg::BulkLists l;
+        l.Kg = b->Kg;
+        l.cap = b->cap;
+        l.cnt = (unsigned long long*)a;
+        l.dst = (int64_t*)(a + 256);
+        l.fidx = (int32_t*)(a + 256 + b->Kg * b->cap * 8);
+        b->alloc.push_back(a);
+        b->mine.push_back(l);
+    }
+    p->bulk = b;
+    return 1;
+}
+
+// the lanes were carved from an arena the CALLER owns (GPURunner's lane arena, lg_set_pool_arena before legion_pipeline_create):
+// bulk transfers address it, the pipeline does not free it
+extern "C" int32_t legion_pipeline_bulk_enable_shared(LegionPipeline* p, const PoolArena* arena)
+{
+    if (!p || !arena || arena->base == nullptr || p->arena.base != nullptr) return 0;
+    p->arena = *arena;
+    p->arena_borrowed = true;
+    return legion_pipeline_bulk_enable(p);
+}
+
+static lg::BulkLists lists_at(char* a, int32_t Kg, int64_t cap)
+{
+    lg::BulkLists l;
+    l.Kg = Kg;
+    l.cap = cap;
+    l.cnt = (unsigned long long*)a;
+    l.dst = (int64_t*)(a + 256);
+    l.fidx = (int32_t*)(a + 256 + Kg * cap * 8);
+    return l;
+}
+
+// what the other members need of this GPU: IPC handles of its lane arena and of its lists (400 bytes)
+extern "C" int32_t legion_pipeline_bulk_export(LegionPipeline* p, void* out_handles, int32_t out_bytes)
+{
+    if (!p || !p->bulk || !out_handles || out_bytes < (int32_t)sizeof(LegionBulkHandles)) return 0;
+    SetGPUDevice(p->dev_id);
+    LegionBulkHandles h;
+    memset(&h, 0, sizeof(h));
+    lg_ipc_export(&h.arena, p->arena.base, __FILE__, __LINE__);
+    for (int32_t s = 0; s < p->slots_n; s++) lg_ipc_export(&h.lists[s], p->bulk->alloc[s], __FILE__, __LINE__);
+    h.cap = p->bulk->cap;
+    h.slots = p->slots_n;
+    h.member = p->bulk->member;
+    memcpy(out_handles, &h, sizeof(h));
+    return (int32_t)sizeof(h);
+}
+
+// a member that lives in ANOTHER process: open its handles
+extern "C" int32_t legion_pipeline_bulk_import(LegionPipeline* p, const void* handles)
+{
+    if (!p || !p->bulk || !handles) return 0;
+    LegionBulkHandles h;
+    memcpy(&h, handles, sizeof(h));
+    // (a member's lists have ITS capacity -- lanes x its own feature rows, which follow its own PreSC maximum)
+    if (h.member < 0 || h.member >= p->bulk->Kg || h.member == p->bulk->member || h.slots != p->slots_n || h.cap <= 0) {
+        printf("legion_hip: bulk handles of member %d do not fit this pipeline (slots %d/%d, cap %lld)\n", h.member, h.slots, p->slots_n,
+               (long long)h.cap);
+        return 0;
+    }
+    SetGPUDevice(p->dev_id);
+    BulkPeer& peer = p->bulk->peers[h.member];
+    void* a = nullptr;
+    HIP_CALL(hipIpcOpenMemHandle(&a, h.arena, hipIpcMemLazyEnablePeerAccess));
+    peer.arena = (char*)a;
+    peer.lists.clear();
+    for (int32_t s = 0; s < h.slots; s++) {
+        void* l = nullptr;
+        HIP_CALL(hipIpcOpenMemHandle(&l, h.lists[s], hipIpcMemLazyEnablePeerAccess));
+        peer.lists.push_back(lists_at((char*)l, p->bulk->Kg, h.cap));
+    }
+    return 1;
+}
+
+// a member that lives in THIS process (a thread per GPU, or logical GPUs of a test): take its pointers
+extern "C" int32_t legion_pipeline_bulk_link(LegionPipeline* p, LegionPipeline* other)
+{
+    if (!p || !p->bulk || !other || !other->bulk || other->bulk->member == p->bulk->member || other->slots_n != p->slots_n) return 0;
+    BulkPeer& peer = p->bulk->peers[other->bulk->member];
+    peer.arena = other->arena.base;
+    peer.lists = other->bulk->mine;
+    return 1;
+}
+
+// phase A; returns the slot
+extern "C" int32_t legion_pipeline_bulk_phase_a(LegionPipeline* p, int32_t counter0, int32_t mode, int32_t n_active, int32_t batch_size)
+{
+    if (!p || !p->bulk) { printf("invalid pipeline ptr\n"); return -1; }
+    if (n_active < 1 || n_active > p->group_size) n_active = p->group_size;
+    batch_size = checked_batch_size(p, batch_size);
+    SetGPUDevice(p->dev_id);
+    const int32_t si = p->rr;
+    p->rr = (p->rr + 1) % p->slots_n;
+    Slot& sl = p->slots[si];
+    lg::Range mark("bulk group A slot=%d first=%d lanes=%d", si, counter0, n_active);
+    slot_wait(p, sl);
+    for (int32_t g = 0; g < p->group_size; g++) {
+        sl.pools[g]->SetCurrentMode(mode);
+        sl.pools[g]->SetIter(counter0 + g);
+    }
+    hipStream_t X = sl.stream;
+    LegionGraphStorage* gr = reinterpret_cast<LegionGraphStorage*>(p->graph);
+    LegionFeatureStorage* f = reinterpret_cast<LegionFeatureStorage*>(p->feature);
+    UnifiedCache* cache = reinterpret_cast<UnifiedCache*>(p->cache_handle);
+    legion_group_set_iter_state(sl.group, nullptr);            // eager launches: the iteration by value
+    legion_enqueue_group_phase(X, gr, f, p->cache_handle, sl.group, n_active, batch_size, counter0, p->dev_id, mode, p->fanout.data(),
+                               p->hop_num, LG_PHASE_SAMPLE);
+    const lg::BulkLists& mine = p->bulk->mine[si];
+    HIP_CALL(hipMemsetAsync(mine.cnt, 0, 256, X));
+    const LanePtrs* d_lanes = static_cast<const LanePtrs*>(legion_group_lane_desc(sl.group, 0));
+    const int32_t max_rows = (int32_t)std::min<int64_t>(p->feature_rows, sl.pools[0]->num_ids);
+    const int32_t last_op = INTRABATCH_CON * p->hop_num + 1;
+    cache->BulkBucket(d_lanes, n_active, last_op, p->dev_id, X, max_rows, mine, p->arena.base);
+    // the gathers in the op order of a whole-batch enqueue (operators.hip enqueue_lanes: the seeds ride along with hop 1 when a
+    // later gather follows), each skipping the rows of other members' stripes
+    const bool seeds_ride = p->hop_num >= 2;
+    if (!seeds_ride) cache->FeatCacheLookup(d_lanes, n_active, 1, p->dev_id, X, max_rows, true, -1, p->hop_num == 0, true);
+    for (int32_t h = 0; h < p->hop_num; h++)
+        cache->FeatCacheLookup(d_lanes, n_active, INTRABATCH_CON * (h + 1) + 1, p->dev_id, X, max_rows, true, (h == 0 && seeds_ride) ? 1 : -1,
+                               h + 1 == p->hop_num, /*skip_remote=*/true);
+    HIP_CALL(hipStreamSynchronize(X));
+    sl.next_iter = -1;
+    p->last_slot = si;
+    return si;
+}
+
+// phase B: this GPU as an owner, for the group every member has in `slot`
+extern "C" void legion_pipeline_bulk_phase_b(LegionPipeline* p, int32_t slot)
+{
+    if (!p || !p->bulk || slot < 0 || slot >= p->slots_n) { printf("invalid pipeline ptr\n"); return; }
+    SetGPUDevice(p->dev_id);
+    lg::Range mark("bulk group B slot=%d", slot);
+    Slot& sl = p->slots[slot];
+    UnifiedCache* cache = reinterpret_cast<UnifiedCache*>(p->cache_handle);
+    const int32_t me = p->bulk->member;
+    for (int32_t r = 0; r < p->bulk->Kg; r++) {
+        if (r == me) continue;
+        const BulkPeer& peer = p->bulk->peers[r];
+        if (peer.arena == nullptr || (int32_t)peer.lists.size() <= slot) {
+            printf("legion_hip: member %d of the clique was never imported / linked\n", r);
+            exit(EXIT_FAILURE);
+        }
+        const lg::BulkLists& l = peer.lists[slot];
+        cache->BulkPush(p->dev_id, sl.stream, l.fidx + (int64_t)me * l.cap, l.dst + (int64_t)me * l.cap, l.cnt + me, l.cap, peer.arena);
+    }
+    HIP_CALL(hipStreamSynchronize(sl.stream));
+    HIP_CALL(hipEventRecord(sl.done, sl.stream));
+    sl.busy = true;
+}
+
+// One server process, a thread per GPU (the reference's deployment): the whole group in one call, no barrier.  Every member's
+// stripe lives in this process, so the REQUESTER's thread itself launches the push kernels on the owners' devices (any thread
+// may launch on any device; peer access is on: StorageManagement::EnableP2PAccess) as soon as its own lists are final, and waits
+// for them.  Eager launches, synchronous: returns the slot with the group complete.
+extern "C" int32_t legion_pipeline_submit_bulk_inproc(LegionPipeline* p, int32_t counter0, int32_t mode, int32_t n_active, int32_t batch_size)
+{
+    if (!p || !p->bulk) { printf("invalid pipeline ptr\n"); return -1; }
+    const int32_t si = legion_pipeline_bulk_phase_a(p, counter0, mode, n_active, batch_size);
+    if (si < 0) return si;
+    BulkState* b = p->bulk;
+    UnifiedCache* cache = reinterpret_cast<UnifiedCache*>(p->cache_handle);
+    const int32_t base = p->dev_id / b->Kg * b->Kg, me = b->member;
+    const lg::BulkLists& l = b->mine[si];
+    if (b->owner_streams.empty()) b->owner_streams.assign(b->Kg, nullptr);
+    for (int32_t o = 0; o < b->Kg; o++) {
+        if (o == me) continue;
+        SetGPUDevice(base + o);
+        if (b->owner_streams[o] == nullptr) HIP_CALL(hipStreamCreateWithFlags(&b->owner_streams[o], hipStreamNonBlocking));
+        cache->BulkPush(base + o, b->owner_streams[o], l.fidx + (int64_t)o * l.cap, l.dst + (int64_t)o * l.cap, l.cnt + o, l.cap, p->arena.base);
+    }
+    for (int32_t o = 0; o < b->Kg; o++) {
+        if (o == me) continue;
+        SetGPUDevice(base + o);
+        HIP_CALL(hipStreamSynchronize(b->owner_streams[o]));
+    }
+    SetGPUDevice(p->dev_id);
+    Slot& sl = p->slots[si];
+    HIP_CALL(hipEventRecord(sl.done, sl.stream));
+    sl.busy = true;
+    return si;
+}
+
+// rows this GPU listed for the other members in `slot` (diagnostics: what crosses xGMI towards this GPU in phase B)
+extern "C" int64_t legion_pipeline_bulk_listed(LegionPipeline* p, int32_t slot)
+{
+    if (!p || !p->bulk || slot < 0 || slot >= p->slots_n) return 0;
+    SetGPUDevice(p->dev_id);
+    unsigned long long c[8] = {0};
+    HIP_CALL(hipMemcpy(c, p->bulk->mine[slot].cnt, sizeof(unsigned long long) * std::min(p->bulk->Kg, 8), hipMemcpyDeviceToHost));
+    int64_t n = 0;
+    for (int32_t i = 0; i < std::min(p->bulk->Kg, 8); i++) n += (int64_t)c[i];
+    return n;
 }
 
 // Gather timing over the live pipeline: HIP events recorded on each slot's stream right before and

@@ -307,6 +307,8 @@ extern "C" void legion_pipeline_destroy(LegionPipeline* p);
 extern "C" void legion_pipeline_wait(LegionPipeline* p, int32_t slot);
 extern "C" const void* legion_pipeline_lane_desc(LegionPipeline* p, int32_t slot, int32_t lane);
 extern "C" void legion_pipeline_set_gathers(LegionPipeline* p, int32_t on);
+extern "C" int32_t legion_pipeline_bulk_enable_shared(LegionPipeline* p, const PoolArena* arena);
+extern "C" int32_t legion_pipeline_submit_bulk_inproc(LegionPipeline* p, int32_t counter0, int32_t mode, int32_t n_active, int32_t batch_size);
 
 class GPURunner : public Runner {
 public:
@@ -699,6 +701,11 @@ private:
                                        (LegionUnifiedCache*)params->cache, local_dev_id_, memorypool_->batch_size,
                                        fanout.data(), hop_num_, lanes_, slots_, lane_features ? feature_rows : 0, 1 | 16);
         lg_set_pool_arena(nullptr);
+        {   // LegionTuning.peer_gather = bulk: only where it means something (a clique of several GPUs, rows landing in lanes)
+            UnifiedCache* uc = (UnifiedCache*)(params->cache);
+            bulk_ = tune.peer_gather == 1 && uc->Kg_ > 1 && lane_features && legion_pipeline_bulk_enable_shared(pipe_, &arena_) != 0;
+            if (bulk_) std::cout << "runner " << local_dev_id_ << ": rows of other members' stripes are pushed by their owners (peer_gather = bulk)\n";
+        }
         if (handover_ == 0 && lane_features && env->PublishArena(local_dev_id_, arena_.base, arena_.bytes))
             std::cout << "runner " << local_dev_id_ << ": lane arena of " << (arena_.bytes >> 20) << " MiB published ("
                       << lanes_ << " lanes x " << slots_ << " groups)\n" << std::flush;
@@ -801,7 +808,11 @@ private:
         int32_t mode = 0, local0 = 0;
         const int32_t n = PlanGroup(env, next_first_, mode, local0);
         const int target = submit_count_++ % slots_;
-        const int slot = legion_pipeline_submit_ex(pipe_, local0, mode, n, env->GetCurrentBatchsize(local_dev_id_, mode));
+        // peer_gather = bulk (striped caches, rows landing in the lanes): the rows of other members' stripes are listed per owner
+        // and pushed by kernels on the owners' devices instead of being loaded one by one over xGMI (pipeline.hip)
+        const bool bulk = bulk_ && kind_ != KIND_GATHER && kind_ != KIND_UNDECIDED;
+        const int slot = bulk ? legion_pipeline_submit_bulk_inproc(pipe_, local0, mode, n, env->GetCurrentBatchsize(local_dev_id_, mode))
+                              : legion_pipeline_submit_ex(pipe_, local0, mode, n, env->GetCurrentBatchsize(local_dev_id_, mode));
         if (slot != target) { printf("legion_hip: runner lost track of the pipeline's slots\n"); exit(EXIT_FAILURE); }
         groups_.push_back({slot, next_first_, n, false});
         slot_end_[slot] = next_first_ + n;
@@ -837,6 +848,7 @@ private:
     int32_t handover_ = lg::tuning().runner_handover;     // 0 auto (views, else gather), 1 gather, 2 copy
     int kind_ = KIND_UNDECIDED;
     bool lane_features_ = false;                           // the lanes have feature buffers (and the groups may gather into them)
+    bool bulk_ = false;                                    // peer_gather = bulk is in effect for this runner's groups
     LegionPipeline* pipe_ = nullptr;
     PoolArena arena_;
     int32_t lanes_ = 1, slots_ = 3, hop_num_ = 0, max_step_ = 0;

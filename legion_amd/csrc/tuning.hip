@@ -51,7 +51,6 @@ void parse_env(LegionTuning& t)
     t.weave_priority = env_int("LEGION_WEAVE_PRIORITY", -1);
     t.runner_graph = env_int("LEGION_RUNNER_GRAPH", 1);
     t.runner_lanes = env_int("LEGION_RUNNER_LANES", 0);
-    t.runner_pair = env_int("LEGION_RUNNER_PAIR", 1);
     t.runner_ho_stream = env_int("LEGION_RUNNER_HO_STREAM", 2);
     t.runner_stats = getenv("LEGION_RUNNER_STATS") != nullptr ? 1 : 0;
     auto word = [](const char* name, std::initializer_list<std::pair<const char*, int>> words, int dflt) {

@@ -351,7 +351,7 @@ class Pipeline:
     hipGraph (pipeline.hip).  submit(counter0) enqueues batches counter0 .. counter0+group_size-1."""
 
     def __init__(self, graph, feature, cache, dev_id, batch_size, fanout, group_size, feature_rows, use_graph=True,
-                 slots=2, overlap=False, split=False, weave=False):
+                 slots=2, overlap=False, split=False, weave=False, arena=False):
         self._lib = _libmod.load()
         self.group_size, self.slots = int(group_size), int(slots)
         self.fanout = [int(f) for f in fanout]
@@ -359,7 +359,7 @@ class Pipeline:
                                                        int(batch_size), _i32_array(self.fanout), len(self.fanout),
                                                        self.group_size, self.slots, int(feature_rows),
                                                        (1 if use_graph else 0) | (2 if overlap else 0) | (4 if split else 0) |
-                                                       (16 if weave else 0))
+                                                       (16 if weave else 0) | (32 if arena else 0))
         self.pools = [[MemoryPool._borrowed(self._lib.legion_pipeline_pool(self.handle, s, g), dev_id,
                                             feature.total_num_nodes, batch_size, fanout, feature.float_feature_len,
                                             feature_rows) for g in range(self.group_size)]
@@ -385,6 +385,43 @@ class Pipeline:
 
     def wait(self, slot=-1):
         self._lib.legion_pipeline_wait(self.handle, int(slot))
+
+    # ---- peer_gather = bulk (pipeline.hip): owner-bucketed transfer of the rows a striped gather needs from other members ----
+    def bulk_enable(self):
+        """Needs arena=True.  Allocates this GPU's per-owner request lists (one set per slot)."""
+        if not self._lib.legion_pipeline_bulk_enable(self.handle):
+            raise RuntimeError("legion_pipeline_bulk_enable failed (pipeline not created with arena=True?)")
+
+    def bulk_export(self):
+        """Bytes the other members need (IPC handles of the lane arena and the lists)."""
+        buf = ctypes.create_string_buffer(512)
+        n = int(self._lib.legion_pipeline_bulk_export(self.handle, buf, 512))
+        if n <= 0:
+            raise RuntimeError("legion_pipeline_bulk_export failed")
+        return buf.raw[:n]
+
+    def bulk_import(self, handles):
+        """A member in ANOTHER process."""
+        if not self._lib.legion_pipeline_bulk_import(self.handle, ctypes.create_string_buffer(handles, len(handles))):
+            raise RuntimeError("legion_pipeline_bulk_import failed")
+
+    def bulk_link(self, other):
+        """A member in THIS process (logical GPUs of a test, a thread per GPU)."""
+        if not self._lib.legion_pipeline_bulk_link(self.handle, other.handle):
+            raise RuntimeError("legion_pipeline_bulk_link failed")
+
+    def bulk_phase_a(self, counter0, mode=TRAINMODE, n_active=None, batch_size=0):
+        """Sampler + bucket pass + gather of everything that is not another member's stripe; returns the slot.  The caller
+        barriers over the clique, calls bulk_phase_b(slot) on every member, and barriers again."""
+        return int(self._lib.legion_pipeline_bulk_phase_a(self.handle, int(counter0), int(mode),
+                                                          int(n_active) if n_active else self.group_size, int(batch_size)))
+
+    def bulk_phase_b(self, slot):
+        self._lib.legion_pipeline_bulk_phase_b(self.handle, int(slot))
+
+    def bulk_listed(self, slot):
+        """Rows this GPU listed for other members in `slot` (what phase B sends towards it)."""
+        return int(self._lib.legion_pipeline_bulk_listed(self.handle, int(slot)))
 
     def profile_begin(self):
         self._lib.legion_pipeline_profile_begin(self.handle)

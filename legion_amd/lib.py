@@ -100,6 +100,13 @@ SIGNATURES = {
     "legion_pipeline_wait": (None, [c_p, c_i32]),
     "legion_pipeline_pool": (c_p, [c_p, c_i32, c_i32]),
     "legion_pipeline_destroy": (None, [c_p]),
+    "legion_pipeline_bulk_enable": (c_i32, [c_p]),
+    "legion_pipeline_bulk_export": (c_i32, [c_p, c_p, c_i32]),
+    "legion_pipeline_bulk_import": (c_i32, [c_p, c_p]),
+    "legion_pipeline_bulk_link": (c_i32, [c_p, c_p]),
+    "legion_pipeline_bulk_phase_a": (c_i32, [c_p, c_i32, c_i32, c_i32, c_i32]),
+    "legion_pipeline_bulk_phase_b": (None, [c_p, c_i32]),
+    "legion_pipeline_bulk_listed": (c_i64, [c_p, c_i32]),
     "legion_pipeline_profile_begin": (None, [c_p]),
     "legion_pipeline_profile_end": (None, [c_p]),
     "legion_pipeline_profile_read": (c_i32, [c_p, P_I32, ctypes.POINTER(ctypes.c_double),
@@ -145,7 +152,7 @@ class Tuning(ctypes.Structure):                # LegionTuning (include/legion_hi
     _fields_ = [(n, c_i32) for n in (
         "dedup_form", "pos_value_bits", "pos_table_bits", "lds_known_cap", "lds_part_wg", "lds_small_buckets", "sample_max_wg",
         "gather_small_tiles", "gather_rows_per_wg", "col_slots", "split_sampler_cus", "split_priority", "weave_priority", "runner_graph", "runner_lanes",
-        "runner_pair", "runner_ho_stream", "runner_stats", "runner_handover", "runner_slots", "peer_gather", "feature_pitch", "hotness_reduce", "markers", "table_placement", "shm_mirror", "link_counters")] + \
+        "runner_ho_stream", "runner_stats", "runner_handover", "runner_slots", "peer_gather", "feature_pitch", "hotness_reduce", "markers", "table_placement", "shm_mirror", "link_counters")] + \
         [("link_counter_values", c_u64 * 2)]
 
 

@@ -90,7 +90,28 @@ def _worker(rank, world, port, q):
                 ci = pool.buffer("cache_search_buffer")[:int(g["node_counter"][1])].cpu().numpy()
                 assert np.array_equal(ci, c["cache_search_buffer"])
                 remote_hits += int(((ci >= 0) & (ci // cap[0] != rank)).sum())
+        # ---- the same batches with the remote rows moved by the OWNERS (peer_gather = bulk): lists and lane arenas exchanged as
+        #      IPC handles, two host barriers per launch group ------------------------------------------------------------
+        G = 3
+        pipe = engine.Pipeline(graph, feature, cache, rank, batch, fanout, G, pool.num_ids, use_graph=False, slots=2, arena=True)
+        pipe.bulk_enable()
+        for r, h in enumerate(all_gather_bytes(pipe.bulk_export())):
+            if r != rank:
+                pipe.bulk_import(h)
+        bulk_rows = 0
+        for grp in range(2):
+            slot = pipe.bulk_phase_a(grp * G)
+            dist.barrier()                  # every member's lists are final
+            bulk_rows += pipe.bulk_listed(slot)
+            pipe.bulk_phase_b(slot)
+            dist.barrier()                  # every member's pushes have landed
+            for lane in range(G):
+                g, c = engine.read_batch(pipe.pools[slot][lane]), cpu.run(rank, grp * G + lane, 0)
+                compare_batches(g, c, f"bulk rank {rank} group {grp} lane {lane}: ")
+            dist.barrier()                  # nobody's lanes are overwritten before everybody has looked
+        assert bulk_rows > 0, f"rank {rank}: no row travelled by the bulk path"
         dist.barrier()                      # peers keep their stripes alive until everyone is done
+        pipe.close()
         q.put((rank, "ok", remote_hits))
         dist.destroy_process_group()
     except Exception as e:                  # pragma: no cover

@@ -78,6 +78,12 @@ def test_scale_command_line_two_ranks_on_one_gpu(hip, stripe):
         for a, b in zip(plain, repl):                    # the replica takes hit rows away from the stripes, peers' included
             assert a["rows_from_peer_stripes"] > 0 and a["rows_from_local_replica"] == 0 and b["rows_from_local_replica"] > 0
             assert b["rows_from_peer_stripes"] < a["rows_from_peer_stripes"]
+        # the owner-bucketed bulk transfer (peer_gather = bulk): the same clique, the peers' rows pushed by their owners -- across
+        # two PROCESSES here (IPC handles of lane arenas and request lists), the same edges, exactly the rows `striped` read from peers
+        bulk = d["striped_bulk"]
+        assert bulk["peer_gather"] == "bulk" and bulk["value"] > 0 and abs(bulk["value"] * bulk["ms_per_step"] / (d["striped"]["value"] * d["striped"]["ms_per_step"]) - 1) < 1e-6
+        for a, b in zip(plain, bulk["per_rank"]):
+            assert b["bulk"]["rows_pushed_into_me_per_region"] == a["rows_from_peer_stripes"] and b["bulk"]["phase_b_s_per_group"] > 0
     one = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1"] + SMALL, cwd=ROOT,
                          stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
     assert one.returncode == 0, one.stderr[-4000:]
@@ -113,13 +119,15 @@ def test_rccl_calls_execute_at_n1(hip):
     assert d["n_gpus"] == 1 and d["value"] > 0
 
 
-@pytest.mark.parametrize("partition_file", [False, True], ids=["modulo", "partition-file"])
-def test_one_server_process_two_gpus_thread_per_gpu(hip, tmp_path, partition_file):
+@pytest.mark.parametrize("partition_file,peer_gather", [(False, "direct"), (True, "direct"), (False, "bulk")],
+                         ids=["modulo", "partition-file", "modulo-bulk-peer-gather"])
+def test_one_server_process_two_gpus_thread_per_gpu(hip, tmp_path, partition_file, peer_gather):
     """`sampling_server 2 1 5 3`: GPUServer with two runners (a host thread each), PreSC on both, hotness summed over the
     clique, caches striped Kg = 2, two pipe-slot sets, two trainer processes.  Logical GPU 1 shares the box's one GPU.
     With a `partition` file in the dataset directory (the reference's xtrapulp output, storage_management.cu:165-183)
     training seeds go to the GPU the file names -- an uneven split, entries >= 2 dropped -- while validation and testing
-    seeds stay on id % 2."""
+    seeds stay on id % 2.  peer_gather = bulk: the rows a runner needs from the OTHER member's stripe are listed per owner and pushed
+    by kernels on the owner's device (LegionTuning.peer_gather, pipeline.hip) instead of being loaded through peer pointers."""
     scale, D, B, fanout, epoch, cache_memory = 11, 24, 40, [5, 3], 2, 40_000
     part = None
     if partition_file:
@@ -140,7 +148,7 @@ def test_one_server_process_two_gpus_thread_per_gpu(hip, tmp_path, partition_fil
     (work / "meta_config").write_text("{} {} {} {} {} {} {} {} {} {}".format(
         ds, B, N, wl.col.size, D, train.size, valid.size, test.size, cache_memory, epoch))
     ns = f"_m{os.getpid()}"
-    env = dict(os.environ, LEGION_IPC_NAMESPACE=ns)
+    env = dict(os.environ, LEGION_IPC_NAMESPACE=ns, LEGION_PEER_GATHER=peer_gather)
     server, log = start_server([os.path.join(ROOT, "legion_amd", "bin", "sampling_server"), "2", "1"] + [str(f) for f in fanout],
                                work, env, work / "server.log")
     trainers = []
@@ -155,6 +163,9 @@ def test_one_server_process_two_gpus_thread_per_gpu(hip, tmp_path, partition_fil
             assert t.returncode == 0, open(tmp_path / f"t{dev}.log").read()[-3000:]
         server.wait(timeout=120)
         assert server.returncode == 0, open(work / "server.log").read()[-3000:]
+        text = open(work / "server.log").read()
+        assert ("pushed by their owners (peer_gather = bulk)" in text) == (peer_gather == "bulk"), text[-2000:]
+        assert "leader loop over peer pointers (its logical GPUs share physical devices)" in text      # one GPU in the box: no RCCL communicator
 
         # ---- the oracle: the same two-GPU server in one address space --------------------------------
         from oracle import ffi

@@ -533,3 +533,57 @@ def test_pipeline_partial_group(hip):
                             f"range {first}+{count} tail lane {lane}: ")
     pipe.close()
     gpu.close(); cpu.close()
+
+
+@pytest.mark.parametrize("P,mode_bits,capacity,replica_rows,D", [(2, 1, (150, 90), 0, 32), (4, 2, (64, 33), 0, 100), (8, 3, (40, 20), 0, 24),
+                                                                 (4, 2, (64, 33), 40, 32), (4, 1, (100, 50), 0, 7)])
+def test_owner_bucketed_bulk_transfer_matches_direct_peer_loads(hip, col_slots, P, mode_bits, capacity, replica_rows, D):
+    """LegionTuning.peer_gather = bulk (pipeline.hip, kernels_gather.hip): every member lists, per owner, the rows of that owner's
+    stripe its launch group needs; the owners read their own HBM and push whole rows into the requesters' lane arenas.  Batches,
+    hit masks, global slots and rows are those of the oracle's striped clique (= what direct peer loads give), on cliques of
+    2 / 4 / 8 logical GPUs (two cliques of two in the last case), with and without a hot-row replica, widths 7 / 24 / 32 / 100."""
+    from legion_amd import engine
+    wl = Workload(scale=11, edge_factor=8, dim=D, partition_count=P, n_seeds=1600)
+    fanout, batch, G = [5, 4], 48, 3
+    gpu, cpu = GpuSide(wl, batch, fanout), CpuSide(wl, batch, fanout)
+    steps = min((wl.sets[(p, 0)][0].size - 1) // batch for p in range(P))
+    for p in range(P):
+        for it in range(steps):
+            gpu.run(p, it, 0, is_presc=True); cpu.run(p, it, 0, is_presc=True)
+    gpu.cache.candidate_selection(mode_bits, gpu.graph)
+    gpu.cache.set_capacity(*capacity)
+    if replica_rows:
+        gpu.cache.set_replica_memory(replica_rows * D * 4)
+    gpu.cache.fill_up(gpu.feature, gpu.graph)
+    cpu.build_cache(mode_bits, capacity=capacity)
+    Kg = cpu.Kg
+    from oracle import ffi
+    rows = ffi.num_ids_for(batch, fanout)
+    pipes = [engine.Pipeline(gpu.graph, gpu.feature, gpu.cache, p, batch, fanout, G, rows, use_graph=False, slots=2, arena=True)
+             for p in range(P)]
+    for pl in pipes:
+        pl.bulk_enable()
+    for p in range(P):                                   # every member knows the other members of ITS clique
+        for q in range(p // Kg * Kg, p // Kg * Kg + Kg):
+            if q != p:
+                pipes[p].bulk_link(pipes[q])
+    n_groups = min(2, (steps - 1) // G)
+    assert n_groups >= 1
+    listed = 0
+    for grp in range(n_groups):
+        slots = [pipes[p].bulk_phase_a(grp * G) for p in range(P)]          # (phase A synchronises its stream: the lists are final)
+        assert len(set(slots)) == 1
+        listed += sum(pipes[p].bulk_listed(slots[0]) for p in range(P))
+        for p in range(P):
+            pipes[p].bulk_phase_b(slots[0])                                  # every member pushes what the others listed for it
+        for p in range(P):
+            for lane in range(G):
+                g = engine.read_batch(pipes[p].pools[slots[0]][lane])
+                c = cpu.run(p, grp * G + lane, 0)
+                compare_batches(g, c, f"bulk gpu {p} group {grp} lane {lane}: ")
+                got = pipes[p].pools[slots[0]][lane].buffer("cache_search_buffer")[:max(int(g["node_counter"][1]), 0)].cpu().numpy()
+                assert np.array_equal(got, c["cache_search_buffer"])
+    assert listed > 0                                    # rows did travel by the bulk path
+    for pl in pipes:
+        pl.close()
+    gpu.close(); cpu.close()

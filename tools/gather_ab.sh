@@ -1,6 +1,6 @@
 #!/bin/bash
 # A/B of library builds on the gather: the cold-row probe + bench shapes.   bash tools/gather_ab.sh base v0 ...   (v0 = the library in place)
-R=$GRAFT_REPO_ROOT
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.."; pwd)}
 for V in "$@"; do
   if [ $V = v0 ]; then unset LEGION_HIP_LIB; else export LEGION_HIP_LIB=$R/tools/lds_tuning/variants/$V/liblegion_hip.so; fi
   echo "#### $V"

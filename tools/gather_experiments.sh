@@ -1,6 +1,6 @@
 #!/bin/bash
 # One-line summaries of bench.py runs that vary only the gather: bash tools/gather_experiments.sh <tag> -- <bench args> [-- <bench args> ...]
-R=$GRAFT_REPO_ROOT; OUT=$R/gpurun_out/gather_exp; mkdir -p $OUT
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.."; pwd)}; OUT=$R/gpurun_out/gather_exp; mkdir -p $OUT
 TAG=$1; shift; shift
 i=0
 args=()

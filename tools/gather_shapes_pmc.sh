@@ -4,7 +4,7 @@
 # One rocprofv3 --kernel-trace --pmc pass per counter group (never combined with other trace domains), each a
 # short bench.py run of the shape; tools/gather_shapes_summary.py folds them into one table.
 RND=${1:-r03}; shift
-R=$GRAFT_REPO_ROOT
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.."; pwd)}
 OUT=$R/gpurun_out/gather_pmc_$RND
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp

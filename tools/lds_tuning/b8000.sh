@@ -1,6 +1,6 @@
 #!/bin/bash
 # GPU box: the three forms of the first-touch state at Legion's default batch size (B = 8000), whole-job bench value
-R=$GRAFT_REPO_ROOT
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../.."; pwd)}
 mkdir -p $R/gpurun_out/b8000
 for F in direct lds; do
   for FO in "25,10" "15,10,5"; do

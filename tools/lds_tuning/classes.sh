@@ -1,7 +1,7 @@
 #!/bin/bash
 # GPU box: bucket counts of the medium / large classes (variant libraries built by build_variant.sh) at B = 8000;
 # variants are selected through LEGION_HIP_LIB, the library in place is never touched
-R=$GRAFT_REPO_ROOT
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../.."; pwd)}
 for V in $VLIST; do
   if [ $V = v0 ]; then unset LEGION_HIP_LIB; else export LEGION_HIP_LIB=$R/tools/lds_tuning/variants/$V/liblegion_hip.so; fi
   for FO in "25,10" "15,10,5" "25,10,10"; do

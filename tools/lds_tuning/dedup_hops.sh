@@ -1,6 +1,6 @@
 #!/bin/bash
 # duration of every kernel of a launch group by launch order (hop 1 and hop 2 share a grid for some of them); one stream (--no-weave)
-R=$GRAFT_REPO_ROOT
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../.."; pwd)}
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/px_h
 timeout -k 5 400 rocprofv3 --kernel-trace --output-format csv -d /tmp/px_h -- python3 $R/bench.py --no-boundary --no-overlap-leg --cpu-seconds 0 --no-weave --no-verify --steps 8 --warmup 2 --min-seconds 0.3 $EXTRA > /dev/null 2> /dev/null < /dev/null

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Median kernel times (rocprofv3 kernel trace) of one-stream launch groups + the bench value, for the library in place.
 # GPU box:  bash tools/lds_tuning/kernel_times.sh   -> gpurun_out/dedupx/summary.txt   (EXTRA='--batch 8000 ...' for other shapes)
-R=$GRAFT_REPO_ROOT
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../.."; pwd)}
 OUT=$R/gpurun_out/dedupx
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp

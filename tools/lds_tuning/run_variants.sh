@@ -2,7 +2,7 @@
 # GPU box:  VLIST='v0 v16 ...' bash tools/lds_tuning/run_variants.sh   (v0 = the library in place)
 # Selects each variant library through LEGION_HIP_LIB (legion_amd/lib.py) -- the library in place is never touched --
 # and runs kernel_times.sh and the default bench with it.
-R=$GRAFT_REPO_ROOT
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../.."; pwd)}
 mkdir -p $R/gpurun_out/dedupx
 for V in $VLIST; do
   if [ $V = v0 ]; then unset LEGION_HIP_LIB; else export LEGION_HIP_LIB=$R/tools/lds_tuning/variants/$V/liblegion_hip.so; fi

@@ -25,14 +25,9 @@ def main():
                 key = (n[:n.rfind("(")] if "(" in n else n, int(r["Grid_Size"]))
                 a = acc[key][r["Counter_Name"]]
                 a[0] += float(r["Counter_Value"]); a[1] += 1
-        for f in glob.glob(d + "/*/*kernel_trace.csv") + glob.glob(d + "/*kernel_trace.csv"):
-            for r in csv.DictReader(open(f)):
-                n = r["Kernel_Name"]
-                if not any(w in n for w in wanted):
-                    continue
-                key = (n[:n.rfind("(")] if "(" in n else n, int(r["Grid_Size"]))
-                t = dur[key]
-                t[0] += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3; t[1] += 1
+                if "Start_Timestamp" in r and r["Counter_Name"] == "SQ_WAVES":      # (one row per dispatch: the pass that counts waves)
+                    t = dur[key]
+                    t[0] += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3; t[1] += 1
     def c(key, name):
         a = acc[key].get(name)
         return a[0] / a[1] if a and a[1] else None

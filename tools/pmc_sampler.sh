@@ -4,7 +4,7 @@
 FORM=${1:-direct}
 SCR=$2
 cd /tmp && export TMPDIR=/tmp
-R=$GRAFT_REPO_ROOT
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.."; pwd)}
 TAG=pmc_s_$FORM$( [ -n "$SCR" ] && echo _scr )
 i=0
 rm -f $R/gpurun_out/$TAG/pmc_sampler_kernels.csv

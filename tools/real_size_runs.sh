@@ -3,7 +3,7 @@
 #   uk-union   N = 133 633 040, E = 5 507 679 822, D = 256, B = 8000, [25,10]   (configs[3]'s data set; all resident: 160 GB)
 #   papers100M N = 111 059 956, E = 1 615 685 872, D = 128, B = 8000, [15,10,5], CSR + features in pinned host memory (configs[2])
 RND=${1:-r03}
-R=$GRAFT_REPO_ROOT; OUT=$R/gpurun_out/real_$RND; mkdir -p $OUT
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.."; pwd)}; OUT=$R/gpurun_out/real_$RND; mkdir -p $OUT
 COMMON="--cpu-seconds 0 --no-boundary --no-overlap-leg --presc-steps 64 --steps 8 --warmup 2 --group 8"
 run() { name=$1; shift; ( time timeout -k 5 1200 python3 $R/bench.py $COMMON "$@" > $OUT/$name.json 2> $OUT/$name.err < /dev/null ) 2>&1 | grep real
   python3 - $OUT/$name.json $name <<'PY'

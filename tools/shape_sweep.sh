@@ -1,6 +1,6 @@
 #!/bin/bash
 # Other workload shapes on one MI355X: one bench line each under gpurun_out/shapes/
-R=$GRAFT_REPO_ROOT; OUT=$R/gpurun_out/shapes; mkdir -p $OUT
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.."; pwd)}; OUT=$R/gpurun_out/shapes; mkdir -p $OUT
 run() { name=$1; shift; timeout -k 5 400 python3 $R/bench.py --cpu-seconds 0 --no-boundary "$@" > $OUT/$name.json 2> $OUT/$name.err < /dev/null
   python3 - $OUT/$name.json $name <<'PY'
 import json, sys

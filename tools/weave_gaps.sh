@@ -1,7 +1,7 @@
 #!/bin/bash
 # Under the weave default: how long the heavy stream idles between the last gather of group k and the first kernel of the rest of
 # group k+1 (= the head of k+1 was not done in time), and how busy the heavy stream is overall.   bash tools/weave_gaps.sh
-R=$GRAFT_REPO_ROOT
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.."; pwd)}
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/px_w
 timeout -k 5 400 rocprofv3 --kernel-trace --output-format csv -d /tmp/px_w -- python3 $R/bench.py --no-boundary --no-overlap-leg --cpu-seconds 0 --no-verify --steps 8 --warmup 2 --min-seconds 0.3 $EXTRA > /dev/null 2> /dev/null < /dev/null
