@@ -62,11 +62,21 @@ class OneLine:
             if self.done:
                 return
             self.done = True
-        os.write(self.fd, (json.dumps(obj) + "\n").encode())
+        text = None
+        for _ in range(5):          # (the fallback may serialise the object while the main thread adds a leg to it)
+            try:
+                text = json.dumps(obj)
+                break
+            except RuntimeError:
+                time.sleep(0.01)
+        if text is None:
+            text = json.dumps({k: v for k, v in list(obj.items()) if k not in ("striped", "striped_replica", "striped_bulk")})
+        os.write(self.fd, (text + "\n").encode())
 
     def arm(self, headline_obj, deadline_s=900):
-        """From here on a dying -- or, after `deadline_s`, a hung -- process still prints `headline_obj`."""
-        self.line = dict(headline_obj)
+        """From here on a dying -- or, after `deadline_s`, a hung -- process still prints `headline_obj` -- the object itself, not a
+        copy: whatever extra legs have been added to it by then go out with it."""
+        self.line = headline_obj
 
         def fallback(why):
             if self.line is not None and not self.done:
@@ -457,7 +467,7 @@ def run_leg(c, engine, synth, stripe, replica_memory, headline, bulk=False):
         # fails or does not return within --collective-deadline seconds falls back to dist.all_reduce on the same arrays and
         # the line says so -- a SCALE run must not be lost to the first meeting of this code with a second physical GPU.
         issued_by, product_err, world_seen, ar_ms = None, None, 0, 0.0
-        if args.backend == "nccl" and not args.no_product_collective:
+        if args.backend == "nccl" and not args.no_product_collective and not getattr(c, "product_collective_broken", False):
             ids = [engine.collective_unique_id() if rank == 0 else None]
             dist.broadcast_object_list(ids, src=0)
             box = {}
@@ -490,6 +500,7 @@ def run_leg(c, engine, synth, stripe, replica_memory, headline, bulk=False):
                     raise RuntimeError("the product's hotness all-reduce ran on some ranks only: the counters are inconsistent")
             else:
                 product_err = box.get("err", f"no join within {args.collective_deadline} s")
+                c.product_collective_broken = True      # (a join that is still stuck holds the library's lock: later legs do not try again)
         if issued_by is None:
             dist.barrier()
             t0 = time.perf_counter()
@@ -787,6 +798,20 @@ def run_leg(c, engine, synth, stripe, replica_memory, headline, bulk=False):
             traffic_src = os.path.relpath(f, ROOT)
             break
 
+    # the same kernel's average duration in the committed rocprofv3 kernel trace of this command (profiles/rNN/, tools/profile_round.sh)
+    rocprof_us, rocprof_src = None, None
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "bench_default_kernel_trace_by_grid.csv")), reverse=True):
+        try:
+            import csv
+            for r in csv.DictReader(open(f)):
+                if "gather_kernel" in r["kernel"] and r["kernel"].rstrip().endswith("true>") and int(r["grid_y"]) == G:
+                    rocprof_us, rocprof_src = float(r["avg_us"]), os.path.relpath(f, ROOT)
+                    break
+        except (OSError, ValueError, KeyError):
+            continue
+        if rocprof_us is not None:
+            break
+
     out = None
     if rank == 0:
         layout = (f"seed-sharded x{world}, replicated graph+features, one clique of {world}: caches striped over the ranks, peer reads "
@@ -795,7 +820,11 @@ def run_leg(c, engine, synth, stripe, replica_memory, headline, bulk=False):
         roof = {"bound": "hbm", "kernel": "lg::gather_kernel<..., LASTOP = true> (hop-%d gather, op %d: the instance launched for a batch's last op)" % (H, last_op),
                 "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_unit": "bytes per launch",
-                "traffic_source": traffic_src, "algorithmic_bytes_per_launch": rows_last / max(n_last, 1) * bytes_per_row,
+                "traffic_source": traffic_src,
+                "traffic_is": "the committed PMC figure of this kernel on this configuration rescaled by this run's rows -- a claim about the "
+                              "kernel, not a measurement of this run (counters cannot be read while timing)",
+                "rocprofv3_avg_launch_us": rocprof_us, "rocprofv3_source": rocprof_src,
+                "algorithmic_bytes_per_launch": rows_last / max(n_last, 1) * bytes_per_row,
                 "bytes_per_row": bytes_per_row, "rows_per_launch": rows_last / max(n_last, 1),
                 "launches": n_last, "avg_launch_us": t_last / max(n_last, 1) * 1e6,
                 "measured": "HIP events on the launch stream around each hop-%d gather launch over the same %d "
@@ -926,7 +955,7 @@ def boundary_leg(args, fanout):
     # straight into the pipe slot (round 3's path); `copy` -- whole groups + one copy launch per batch (the measured alternative)
     cmd = [sys.executable, os.path.join(ROOT, "tools", "server_throughput.py"), "--scale", str(scale), "--edge-factor", str(args.edge_factor),
            "--batch", ",".join(str(b) for b in batches), "--dim", str(args.dim), "--fanout", ",".join(str(f) for f in fanout),
-           "--train-batches", str(max(64, min(3000, (3 << 20) // args.batch))), "--no-features-file", "--cache-memory", str(args.cache_memory),
+           "--train-batches", str(max(64, min(3072, (3 << 20) // args.batch))), "--no-features-file", "--cache-memory", str(args.cache_memory),
            "--modes", "views,slab,copy", "--min-timed-batches", str(args.boundary_batches), "--watchdog", "800"]
     try:
         res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=1200)

@@ -394,6 +394,8 @@ typedef struct LegionTuning {
     int32_t lds_small_buckets;   /* LEGION_LDS_SMALL_BUCKETS (0 auto | 8 | 16): hash buckets per lane of pools whose hops have <= 2^19 slots;
                                     auto = 16 where PreSC saw more last-hop edges + earlier nodes than 8 buckets take in one pass */
     int32_t sample_max_wg;       /* LEGION_SAMPLE_MAX_WG   (4096): workgroup cap of the strided sampler grids */
+    int32_t loser_in_dst;        /* LEGION_LOSER_IN_DST    (1): lds form, N <= 2^30: a slot that lost its first touch is marked in bit 30 of its
+                                    slot_dst entry (the compaction then reads one array less) instead of in slot_mark */
     int32_t gather_small_tiles;  /* LEGION_GATHER_SMALL_TILES (1): 16-row tiles for launches of fewer than 4096 tiles */
     int32_t gather_rows_per_wg;  /* LEGION_GATHER_ROWS     (0 = by row width): rows per gather workgroup, 16|32|64|128|256 */
     int32_t col_slots;           /* LEGION_COL_SLOTS       (-1 auto): the {neighbour id, feature-cache slot} copy of the column array that
@@ -403,6 +405,9 @@ typedef struct LegionTuning {
     int32_t split_priority;      /* LEGION_SPLIT_PRIORITY  (1): split mode, 1 sampler stream first, 0 equal, -1 gathers first */
     int32_t weave_priority;      /* LEGION_WEAVE_PRIORITY  (-1): weave arrangement, priority of the light stream (heads of the next group):
                                     -1 low, 0 equal, 1 high */
+    int32_t weave_early_gathers; /* LEGION_WEAVE_EARLY_GATHERS (see tuning.hip for the default): weave arrangement, the gathers of the seeds and of every
+                                    hop but the last run with the HEAD on the light stream (under the previous group's heavy kernels) instead of
+                                    in front of the last hop's gather on the heavy stream */
     int32_t runner_graph;        /* LEGION_RUNNER_GRAPH    (1): Runner serves from lane groups + hipGraph; 0 = operator by operator */
     int32_t runner_lanes;        /* LEGION_RUNNER_LANES    (0 = min(128, 262144 / batch)): lanes of a Runner group */
     int32_t runner_ho_stream;    /* LEGION_RUNNER_HO_STREAM (2): hand-over streams: 0 the sampler's, 1 one shared, 2 one per pipe slot */

@@ -30,6 +30,12 @@ extern "C" void RandomSample(legion_stream_t strm_hdl, LegionGraphStorage* graph
 // UnifiedCache as its first member (cache.hip: LegionCacheBox).
 static inline UnifiedCache* cache_of(LegionUnifiedCache* c) { return reinterpret_cast<UnifiedCache*>(c); }
 
+// weave_early_gathers needs to know, while a HEAD phase is enqueued, whether this group gathers at all (a REST_SAMPLE group --
+// GPURunner serving a slab-only trainer -- must not): pipeline.hip says so around its enqueue / capture calls.  Thread-local.
+static thread_local bool g_weave_head_gathers = true;
+extern "C" void legion_set_weave_head_gathers(int32_t on) { g_weave_head_gathers = on != 0; }
+static inline bool lg_weave_head_gathers() { return g_weave_head_gathers; }
+
 // ---- lane-group bodies: every operator works on n lanes (n = 1 for the reference-shaped calls) ----
 struct LegionLaneGroup {
     std::vector<MemoryPool*> pools;
@@ -125,7 +131,7 @@ static void do_random_sample(hipStream_t s, GraphStorage* graph, UnifiedCache* c
     p.max_slots = (int32_t)(hop < pool0->max_new.size() ? pool0->max_new[hop] : pool0->max_slots);
     p.edge_access_time = (is_presc && cache) ? cache->GetEdgeAccessedMap(dev_id) : nullptr;   // :473
     p.topo_transactions = (is_presc && cache) ? cache->Controller(dev_id)->GetTopoTransactions() : nullptr;
-    p.loser_in_dst = pool0->lds_form && (int64_t)pool0->total_num_nodes <= ((int64_t)1 << 30);
+    p.loser_in_dst = pool0->lds_form && (int64_t)pool0->total_num_nodes <= ((int64_t)1 << 30) && lg::tuning().loser_in_dst != 0;
     p.lds_bucket_bits = pool0->lds_bucket_bits;
     p.lds_k = 1;                             // (launch_random_sample picks the hop's partition tile)
     lg::launch_random_sample(s, p, d_lanes, n_lanes, pool0->lds_form ? 2 : (pool0->pos_table != nullptr ? 1 : 0));
@@ -364,18 +370,32 @@ static void enqueue_lanes(hipStream_t s, GraphStorage* graph, FeatureStorage* fe
     const bool seeds_ride = hop_num >= 2;
     if (phase >= LG_PHASE_HEAD) {          // the two pieces of the weave arrangement (serve mode only)
         const int32_t last = hop_num - 1;
+        // weave_early_gathers: the rows of the seeds and of every hop but the last are complete when the HEAD's sampling is done;
+        // their gathers (hot rows: mostly L2 / Infinity-Cache hits) then run on the light stream too, under the PREVIOUS group's
+        // last-hop gather, and only the last hop's gather stays on the heavy stream.  (REST_SAMPLE groups never gather.)
+        const bool early = lg::tuning().weave_early_gathers != 0 && last >= 1;
+        auto early_gathers = [&]() {
+            if (!seeds_ride) do_feature_lookup(s, cache, d_lanes, n_lanes, pool0, 1, dev_id, true);
+            for (int32_t h = 0; h < last; h++)
+                do_feature_lookup(s, cache, d_lanes, n_lanes, pool0, INTRABATCH_CON * (h + 1) + 1, dev_id, true, (h == 0 && seeds_ride) ? 1 : -1);
+        };
         if (phase == LG_PHASE_HEAD) {
             do_batch_generate(s, feature, d_lanes, n_lanes, pool0, batch_size, counter, dev_id, mode, hop_num, iter_state);
             for (int32_t h = 0; h < last; h++)
                 do_random_sample(s, graph, cache, d_lanes, n_lanes, pool0, fanout[h], dev_id, INTRABATCH_CON * (h + 1), false);
+            if (early && pool0->GetFloatFeatures() != nullptr && lg_weave_head_gathers()) early_gathers();
         } else {
             if (last >= 0) do_random_sample(s, graph, cache, d_lanes, n_lanes, pool0, fanout[last], dev_id, INTRABATCH_CON * (last + 1), false);
             lg::launch_end_of_batch(s, d_lanes, n_lanes, iter_state, pool_state_bytes(pool0));
             if (phase == LG_PHASE_REST_SAMPLE) return;
-            if (!seeds_ride) do_feature_lookup(s, cache, d_lanes, n_lanes, pool0, 1, dev_id, true);
-            for (int32_t h = 0; h <= last; h++)
-                do_feature_lookup(s, cache, d_lanes, n_lanes, pool0, INTRABATCH_CON * (h + 1) + 1, dev_id, true,
-                                  (h == 0 && seeds_ride) ? 1 : -1);
+            if (early && lg_weave_head_gathers()) {
+                do_feature_lookup(s, cache, d_lanes, n_lanes, pool0, INTRABATCH_CON * (last + 1) + 1, dev_id, true, -1);
+            } else {
+                if (!seeds_ride) do_feature_lookup(s, cache, d_lanes, n_lanes, pool0, 1, dev_id, true);
+                for (int32_t h = 0; h <= last; h++)
+                    do_feature_lookup(s, cache, d_lanes, n_lanes, pool0, INTRABATCH_CON * (h + 1) + 1, dev_id, true,
+                                      (h == 0 && seeds_ride) ? 1 : -1);
+            }
         }
         return;
     }

@@ -38,6 +38,7 @@ extern "C" void legion_enqueue_group_phase(legion_stream_t strm_hdl, LegionGraph
                                            const int32_t* fanout, int32_t hop_num, int32_t phase);
 extern "C" void legion_pool_profile_begin(LegionMemoryPool* p_, int32_t max_ops);
 extern "C" const void* legion_group_lane_desc(LegionLaneGroup* g, int32_t lane);
+extern "C" void legion_set_weave_head_gathers(int32_t on);
 
 struct Slot {
     std::vector<MemoryPool*> pools;           // G lanes
@@ -231,12 +232,15 @@ static void slot_wait(LegionPipeline* p, Slot& sl)
 static hipGraphExec_t graph_of(LegionPipeline* p, Slot& sl, hipStream_t strm, int32_t phase, int32_t mode, int32_t n_active,
                                int32_t batch_size)
 {
-    const int64_t key = ((int64_t)phase << 48) | ((int64_t)mode << 40) | ((int64_t)n_active << 32) | (uint32_t)batch_size;
+    // (a HEAD captured for a group that gathers may carry the early gathers: its key differs from the sampler-only HEAD's)
+    const int64_t key = ((int64_t)phase << 48) | ((int64_t)((phase == LG_PHASE_HEAD && !p->gathers) ? 1 : 0) << 56) | ((int64_t)mode << 40) |
+                        ((int64_t)n_active << 32) | (uint32_t)batch_size;
     auto it = sl.exec.find(key);
     if (it == sl.exec.end()) {
         hipGraph_t graph = nullptr;
         hipGraphExec_t exec = nullptr;
         HIP_CALL(hipStreamSynchronize(strm));
+        legion_set_weave_head_gathers(p->gathers ? 1 : 0);
         HIP_CALL(hipStreamBeginCapture(strm, hipStreamCaptureModeThreadLocal));
         legion_enqueue_group_phase(strm, reinterpret_cast<LegionGraphStorage*>(p->graph), reinterpret_cast<LegionFeatureStorage*>(p->feature),
                                    p->cache_handle, sl.group, n_active, batch_size, 0, p->dev_id, mode, p->fanout.data(),
@@ -355,6 +359,7 @@ extern "C" int32_t legion_pipeline_submit_ex(LegionPipeline* p, int32_t counter0
             HIP_CALL(hipMemcpyAsync(sl.d_iter, sl.h_iter, 2 * sizeof(int32_t), hipMemcpyHostToDevice, Y));
         }
         auto run = [&](hipStream_t strm, int32_t phase) {
+            legion_set_weave_head_gathers(p->gathers ? 1 : 0);
             if (eager)
                 legion_enqueue_group_phase(strm, gr, f, p->cache_handle, sl.group, n_active, batch_size, counter0, p->dev_id, mode,
                                            p->fanout.data(), p->hop_num, phase);

@@ -43,12 +43,14 @@ void parse_env(LegionTuning& t)
     t.lds_part_wg = env_int("LEGION_LDS_PART_WG", 8192);
     t.lds_small_buckets = env_int("LEGION_LDS_SMALL_BUCKETS", 0);
     t.sample_max_wg = env_int("LEGION_SAMPLE_MAX_WG", 4096);
+    t.loser_in_dst = env_int("LEGION_LOSER_IN_DST", 1);
     t.gather_small_tiles = env_int("LEGION_GATHER_SMALL_TILES", 1);
     t.gather_rows_per_wg = env_int("LEGION_GATHER_ROWS", 0);
     t.col_slots = env_int("LEGION_COL_SLOTS", -1);
     t.split_sampler_cus = env_int("LEGION_SPLIT_SAMPLER_CUS", 0);
     t.split_priority = env_int("LEGION_SPLIT_PRIORITY", 1);
     t.weave_priority = env_int("LEGION_WEAVE_PRIORITY", -1);
+    t.weave_early_gathers = env_int("LEGION_WEAVE_EARLY_GATHERS", 0);
     t.runner_graph = env_int("LEGION_RUNNER_GRAPH", 1);
     t.runner_lanes = env_int("LEGION_RUNNER_LANES", 0);
     t.runner_ho_stream = env_int("LEGION_RUNNER_HO_STREAM", 2);

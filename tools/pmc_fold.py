@@ -45,7 +45,7 @@ def main():
         valu, vmem, lds = c(key, "SQ_INSTS_VALU"), c(key, "SQ_INSTS_VMEM"), c(key, "SQ_INSTS_LDS")
         n_l = max((a[1] for a in acc[key].values()), default=0)
         f = lambda v, fmt="{:.1f}": "" if v is None else fmt.format(v)
-        tbs = (rd + wr) / us / 1e6 * 1e6 / 1e6 if (rd is not None and wr is not None and us) else None     # MB / us = TB/s
+        tbs = (rd + wr) / us if (rd is not None and wr is not None and us) else None     # MB / us = TB/s
         lines.append("| `{}` | {} | {} | {} | {} | {} | {} | {} | {} | {} | {} | {} | {} | {} | {} |".format(
             key[0].replace("void ", "").replace("lg::", ""), key[1], n_l, f(us), f(rd), f(wr), f(tbs, "{:.2f}"),
             f(hit / (hit + miss) if hit is not None and miss is not None and hit + miss > 0 else None, "{:.2f}"),

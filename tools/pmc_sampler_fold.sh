@@ -17,3 +17,5 @@ for grp in "SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_LDS" "FETCH_SIZE" "
   find $OUT/g$i -name "*agent_info.csv" -delete
 done
 python3 $R/tools/pmc_fold.py $OUT $OUT/table.md
+cp $OUT/g1/bench.json $OUT/bench_under_counters.json 2>/dev/null
+rm -rf $OUT/g[0-9]*            # the raw per-dispatch csv files are tens of MB: only the folded table travels back

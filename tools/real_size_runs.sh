@@ -17,8 +17,11 @@ except Exception as e:
     print(sys.argv[2], "FAILED", e); print(open(sys.argv[1].replace(".json", ".err")).read()[-1500:])
 PY
 }
-run uk_union_size_d256_b8000 --nodes 133633040 --edges 5507679822 --dim 256 --batch 8000
-LEGION_COL_SLOTS=1 run uk_union_size_d256_b8000_column_slots --nodes 133633040 --edges 5507679822 --dim 256 --batch 8000
+if [ "${PART:-all}" != "rest" ]; then
+run uk_union_size_d256_b8000 --nodes 133633040 --edges 5507679822 --dim 256 --batch 8000          # (column slots: auto takes the 44 GB copy since round 4)
+LEGION_COL_SLOTS=0 run uk_union_size_d256_b8000_no_column_slots --nodes 133633040 --edges 5507679822 --dim 256 --batch 8000
+fi
+[ "${PART:-all}" = "uk" ] && exit 0
 run papers100m_size_3hop_pinned --nodes 111059956 --edges 1615685872 --dim 128 --batch 8000 --fanout 15,10,5 --placement pinned --link-counters smi
 run papers100m_size_3hop_hbm --nodes 111059956 --edges 1615685872 --dim 128 --batch 8000 --fanout 15,10,5
 # configs[4]'s graph on one GPU: RMAT-28 (N = 2^28, edge factor 4), [15,10,5], B = 8000 -- with D = 128 (the 256-wide table of 2^28 rows
