@@ -219,6 +219,9 @@ def parse_args():
     ap.add_argument("--no-boundary", action="store_true",
                     help="skip the drop-in boundary leg (sampling_server binary -> shm/semaphores/IPC handles -> ipc_service "
                          "consumer on an RMAT-22 data set written in the reference's file formats; N = 1 only, ~15 s)")
+    ap.add_argument("--boundary-modes", type=str, default="views,slab",
+                    help="boundary leg: hand-overs to measure, one server run per mode and batch size (tools/server_throughput.py --modes: "
+                         "views | slab | gather | copy); tools/profile_round.sh adds copy")
     ap.add_argument("--boundary-batches", type=int, default=40000,
                     help="boundary leg: timed batches per server run at least (the server runs as many epochs as that takes)")
     ap.add_argument("--measured-counters", action="store_true", help="same as --link-counters computed")
@@ -956,7 +959,7 @@ def boundary_leg(args, fanout):
     cmd = [sys.executable, os.path.join(ROOT, "tools", "server_throughput.py"), "--scale", str(scale), "--edge-factor", str(args.edge_factor),
            "--batch", ",".join(str(b) for b in batches), "--dim", str(args.dim), "--fanout", ",".join(str(f) for f in fanout),
            "--train-batches", str(max(64, min(3072, (3 << 20) // args.batch))), "--no-features-file", "--cache-memory", str(args.cache_memory),
-           "--modes", "views,slab,copy", "--min-timed-batches", str(args.boundary_batches), "--watchdog", "800"]
+           "--modes", args.boundary_modes, "--min-timed-batches", str(args.boundary_batches), "--watchdog", "800"]
     try:
         res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=1200)
         lines = [json.loads(ln) for ln in res.stdout.splitlines() if ln.startswith("{")]

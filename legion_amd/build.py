@@ -33,7 +33,7 @@ def _newer(target, deps):
 def build_lib(force=False, verbose=True):
     objdir = os.path.join(HERE, "_obj")
     os.makedirs(objdir, exist_ok=True)
-    headers = [os.path.join(CSRC, "legion_core.h"), os.path.join(HERE, "..", "include", "legion_hip.h")]
+    headers = [os.path.join(CSRC, "legion_core.h"), os.path.join(CSRC, "runner_schedule.h"), os.path.join(HERE, "..", "include", "legion_hip.h")]
     objs, procs = [], []
     for src in SOURCES:
         s = os.path.join(CSRC, src)

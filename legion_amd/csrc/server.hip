@@ -13,6 +13,7 @@
 // only stream 0's last event).  Full CSR / feature table go to HBM when they fit
 // (288 GB per MI355X), to mapped pinned host memory otherwise.
 #include "legion_core.h"
+#include "runner_schedule.h"
 
 #include <fcntl.h>
 #include <sys/mman.h>
@@ -479,10 +480,10 @@ public:
         }
         const auto t_b = std::chrono::steady_clock::now();
         if (kind_ == KIND_UNDECIDED) DecideHandover(env);       // the trainer end said what it is before its first sem_post
-        while (!groups_.empty() && k >= groups_.front().first + groups_.front().n) groups_.pop_front();
-        SubmitWhatFits(env, k);                                  // token k consumed => batches <= k-2 are released
-        if (groups_.empty() || k < groups_.front().first) { printf("legion_hip: runner lost track of its groups\n"); exit(EXIT_FAILURE); }
-        Group& g = groups_.front();
+        sched_.retire_before(k);
+        SubmitWhatFits(env, k);                                  // token k consumed => batches <= k-2 are released (runner_schedule.h)
+        if (sched_.groups.empty() || k < sched_.groups.front().first) { printf("legion_hip: runner lost track of its groups\n"); exit(EXIT_FAILURE); }
+        RunnerSchedule::Group& g = sched_.groups.front();
         if (!g.complete) {
             if (kind_ == KIND_GATHER) {
                 // the hand-over streams may touch this group's lanes once its sampler phase has finished
@@ -603,7 +604,6 @@ public:
 
 private:
     struct Pending { hipEvent_t ev; int pipe; MemoryPool* lane; std::chrono::steady_clock::time_point enqueued; };
-    struct Group { int slot; int32_t first, n; bool complete; };
     enum { KIND_UNDECIDED = 0, KIND_VIEWS, KIND_GATHER, KIND_COPY };
 
     void ReportErrors(MemoryPool* mp)
@@ -709,7 +709,7 @@ private:
         if (handover_ == 0 && lane_features && env->PublishArena(local_dev_id_, arena_.base, arena_.bytes))
             std::cout << "runner " << local_dev_id_ << ": lane arena of " << (arena_.bytes >> 20) << " MiB published ("
                       << lanes_ << " lanes x " << slots_ << " groups)\n" << std::flush;
-        slot_end_.assign(slots_, -1);
+        sched_.reset(slots_);
         const int32_t ho_mode = tune.runner_ho_stream;    // 0 the pipeline's stream, 1 one shared, 2 one per pipe slot
         if (ho_mode != 0) {
             int lo = 0, hi = 0;
@@ -806,28 +806,22 @@ private:
     void SubmitNext(IPCEnv* env)
     {
         int32_t mode = 0, local0 = 0;
-        const int32_t n = PlanGroup(env, next_first_, mode, local0);
-        const int target = submit_count_++ % slots_;
+        const int32_t n = PlanGroup(env, sched_.next_first, mode, local0);
+        const int target = sched_.next_slot();
         // peer_gather = bulk (striped caches, rows landing in the lanes): the rows of other members' stripes are listed per owner
         // and pushed by kernels on the owners' devices instead of being loaded one by one over xGMI (pipeline.hip)
         const bool bulk = bulk_ && kind_ != KIND_GATHER && kind_ != KIND_UNDECIDED;
         const int slot = bulk ? legion_pipeline_submit_bulk_inproc(pipe_, local0, mode, n, env->GetCurrentBatchsize(local_dev_id_, mode))
                               : legion_pipeline_submit_ex(pipe_, local0, mode, n, env->GetCurrentBatchsize(local_dev_id_, mode));
         if (slot != target) { printf("legion_hip: runner lost track of the pipeline's slots\n"); exit(EXIT_FAILURE); }
-        groups_.push_back({slot, next_first_, n, false});
-        slot_end_[slot] = next_first_ + n;
-        next_first_ += n;
+        sched_.submitted(slot, n);
     }
 
-    // With token k consumed, batches <= k-2 have been released by the trainer: a pipeline slot whose previous group ended
-    // at or before batch k-1 (exclusive end) may be overwritten.  Keeps up to slots_ groups submitted.
+    // Keeps up to slots_ groups submitted; a slot is overwritten only when the trainer has released every batch of the group
+    // that used it last (runner_schedule.h: the rule and why the semaphore tokens are enough to know)
     void SubmitWhatFits(IPCEnv* env, int32_t k)
     {
-        while (next_first_ < max_step_ && (int)groups_.size() < slots_) {
-            const int target = submit_count_ % slots_;
-            if (slot_end_[target] >= 0 && slot_end_[target] > k - 1) break;
-            SubmitNext(env);
-        }
+        while (sched_.next_first < max_step_ && sched_.may_submit(k)) SubmitNext(env);
     }
 
     int32_t num_ids_ = 0;
@@ -852,10 +846,7 @@ private:
     LegionPipeline* pipe_ = nullptr;
     PoolArena arena_;
     int32_t lanes_ = 1, slots_ = 3, hop_num_ = 0, max_step_ = 0;
-    std::deque<Group> groups_;                             // submitted, not yet fully handed over; front = being handed over
-    std::vector<int32_t> slot_end_;                        // [pipeline slot] exclusive end of the group that last used it, -1: none
-    int32_t next_first_ = 0;                               // first batch of the next group to submit
-    int submit_count_ = 0;
+    RunnerSchedule sched_;                                 // which group sits in which slot, and when a slot may be overwritten
     LanePtrs* d_desc_ = nullptr;
     lg::DeliverParams deliver_[INTERBATCH_CON] = {};
     lg::DeliverParams* d_deliver_ = nullptr;
