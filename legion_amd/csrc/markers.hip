@@ -1,7 +1,7 @@
 // markers.hip -- roctx ranges around ops and launch groups (tracing row: the reference has none).
 //
 // `rocprofv3 --kernel-trace --marker-trace` then shows, beside every kernel, which op (eager launches) or which launch group
-// (hipGraph replay: the ranges bracket the host-side graph launches of a group's phases) it belongs to; tools/trace_timeline.py
+// (hipGraph replay: the ranges bracket the host-side graph launches of a group's phases) it belongs to; tools/trace_group.py
 // folds such a trace into DESIGN.md's "what hides under what" timeline.  The marker library (librocprofiler-sdk-roctx) is
 // opened on first use: without it, or with LegionTuning.markers = 0, a range is one predictable branch.
 #include "legion_core.h"

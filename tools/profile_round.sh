@@ -34,10 +34,10 @@ for c in FETCH_SIZE WRITE_SIZE; do
   timeout -k 5 900 rocprofv3 --kernel-trace --pmc $c --output-format csv -d /tmp/pmc_$c -- python3 $R/bench.py --steps 4 --warmup 2 --presc-steps 64 --cpu-seconds 0 --no-verify --no-boundary --no-overlap-leg --min-seconds 0.01 > /tmp/pmc_$c/bench.json 2> /tmp/pmc_$c/err.txt < /dev/null
 done
 python3 $R/tools/pmc_summary.py /tmp/pmc_FETCH_SIZE /tmp/pmc_WRITE_SIZE $OUT/pmc_gather_kernel.json > /dev/null
-# 4. the timeline of one launch group under the weave (kernel trace + roctx group ranges), folded by tools/trace_timeline.py
+# 4. the timeline of one launch group under the weave (kernel trace + roctx group ranges), folded by tools/trace_group.py
 rm -rf /tmp/prof_tl
 timeout -k 5 600 rocprofv3 --kernel-trace --marker-trace --output-format csv -d /tmp/prof_tl -- python3 $R/bench.py --no-boundary --no-overlap-leg --cpu-seconds 0 --no-verify --steps 8 --warmup 2 --min-seconds 0.3 > /dev/null 2> /tmp/prof_tl.err < /dev/null
-python3 $R/tools/trace_timeline.py /tmp/prof_tl $OUT/group_timeline.md > /dev/null
+python3 $R/tools/trace_group.py /tmp/prof_tl $OUT/group_timeline.md > /dev/null
 cut -c1-300 $OUT/bench_default.json
 head -14 $OUT/bench_default_kernel_trace_by_grid.csv
 cat $OUT/pmc_gather_kernel.json

@@ -63,7 +63,8 @@ def main():
     else:
         indptr, col = synth.rmat_csr_device(a.scale, a.edge_factor, 20231, dev)
     tb = {b: (a.train_batches if len(batches) == 1 else max(64, min(a.train_batches, a.train_batches * batches[0] // b))) for b in batches}
-    tb = {b: (v // 64 * 64 if v >= 64 else v) for b, v in tb.items()}     # an epoch of whole launch groups where it is long enough (groups never straddle epochs)
+    if a.min_timed_batches > 0:           # many short epochs: make each a whole number of launch groups (groups never straddle epochs)
+        tb = {b: (v // 64 * 64 if v >= 64 else v) for b, v in tb.items()}
     train = synth.seed_ids(N, max(b * tb[b] for b in batches) + 1, 11).astype(np.int32)
     tmp = tempfile.mkdtemp(prefix="legion_srv_", dir="/tmp")
     ds = os.path.join(tmp, "ds") + "/"

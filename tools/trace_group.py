@@ -3,7 +3,7 @@ steady-state launch group: which kernels run on the heavy stream, in which order
 kernels (the next group's head) add up to and how much of that is hidden under heavy kernels, and where the heavy stream idles.
 
     cd /tmp && rocprofv3 --kernel-trace --marker-trace --output-format csv -d /tmp/tl -- python3 bench.py --steps 8 --warmup 2 ...
-    python tools/trace_timeline.py /tmp/tl [out.md]
+    python tools/trace_group.py /tmp/tl [out.md]
 
 A group's interval = from the end of one LASTOP gather (`gather_kernel<..., true>`, the last kernel of a group's REST phase) to the
 end of the next; medians over the groups of the second half of the trace (the timed replays).  With `--marker-trace` the host-side
