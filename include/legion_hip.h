@@ -408,8 +408,6 @@ typedef struct LegionTuning {
     int32_t weave_early_gathers; /* LEGION_WEAVE_EARLY_GATHERS (see tuning.hip for the default): weave arrangement, the gathers of the seeds and of every
                                     hop but the last run with the HEAD on the light stream (under the previous group's heavy kernels) instead of
                                     in front of the last hop's gather on the heavy stream */
-    int32_t last_hop_split;      /* LEGION_LAST_HOP_SPLIT  (see tuning.hip): the LAST hop of a lane group runs as two half groups on two streams, the
-                                    second half's sampling (HBM-request-bound) beside the first half's de-duplication (LDS-bound) */
     int32_t runner_graph;        /* LEGION_RUNNER_GRAPH    (1): Runner serves from lane groups + hipGraph; 0 = operator by operator */
     int32_t runner_lanes;        /* LEGION_RUNNER_LANES    (0 = min(128, 262144 / batch)): lanes of a Runner group */
     int32_t runner_ho_stream;    /* LEGION_RUNNER_HO_STREAM (2): hand-over streams: 0 the sampler's, 1 one shared, 2 one per pipe slot */

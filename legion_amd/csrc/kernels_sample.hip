@@ -1207,7 +1207,7 @@ __global__ __launch_bounds__(LG_TILE) void localise_kernel(HopParams hp, const L
     }
 }
 
-void launch_random_sample(hipStream_t s, const HopParams& p, const LanePtrs* d_lanes, int32_t n_lanes, int32_t form, hipEvent_t after_sample)
+void launch_random_sample(hipStream_t s, const HopParams& p, const LanePtrs* d_lanes, int32_t n_lanes, int32_t form)
 {
     // Fixed grids that stride over super tiles; grid.y = lanes (independent mini-batches of a group).
     int32_t max_super = (p.max_slots + LG_SUPER - 1) / LG_SUPER;
@@ -1236,12 +1236,10 @@ void launch_random_sample(hipStream_t s, const HopParams& p, const LanePtrs* d_l
         if (p.lds_bucket_bits == LG_LDS_BITS_SMALL) {
             sample_kernel<2, LG_LDS_BITS_SMALL, true><<<grid, LG_TILE, 0, s>>>(q, d_lanes);
             hipCheckError();
-            if (after_sample) HIP_CALL(hipEventRecord(after_sample, s));
             dedup_lds_kernel<LG_LDS_BITS_SMALL><<<dim3(1 << LG_LDS_BITS_SMALL, n_lanes), LG_DEDUP_THREADS, 0, s>>>(q, d_lanes);
         } else if (p.lds_bucket_bits == LG_LDS_BITS_SMALL16) {
             sample_kernel<2, LG_LDS_BITS_SMALL16, true><<<grid, LG_TILE, 0, s>>>(q, d_lanes);
             hipCheckError();
-            if (after_sample) HIP_CALL(hipEventRecord(after_sample, s));
             dedup_lds_kernel<LG_LDS_BITS_SMALL16><<<dim3(1 << LG_LDS_BITS_SMALL16, n_lanes), LG_DEDUP_THREADS, 0, s>>>(q, d_lanes);
         } else if (p.lds_bucket_bits == LG_LDS_BITS_MEDIUM) {
             if (k <= LG_PLACE_MAX_K) {
@@ -1251,7 +1249,6 @@ void launch_random_sample(hipStream_t s, const HopParams& p, const LanePtrs* d_l
             } else
                 sample_kernel<2, LG_LDS_BITS_MEDIUM, false><<<dim3(gp, n_lanes), LG_TILE, 0, s>>>(q, d_lanes);
             hipCheckError();
-            if (after_sample) HIP_CALL(hipEventRecord(after_sample, s));
             dedup_lds_kernel<LG_LDS_BITS_MEDIUM><<<dim3(1 << LG_LDS_BITS_MEDIUM, n_lanes), LG_DEDUP_THREADS, 0, s>>>(q, d_lanes);
         } else {
             if (k <= LG_PLACE_MAX_K) {
@@ -1261,15 +1258,12 @@ void launch_random_sample(hipStream_t s, const HopParams& p, const LanePtrs* d_l
             } else
                 sample_kernel<2, LG_LDS_BITS_LARGE, false><<<dim3(gp, n_lanes), LG_TILE, 0, s>>>(q, d_lanes);
             hipCheckError();
-            if (after_sample) HIP_CALL(hipEventRecord(after_sample, s));
             dedup_lds_kernel<LG_LDS_BITS_LARGE><<<dim3(1 << LG_LDS_BITS_LARGE, n_lanes), LG_DEDUP_THREADS, 0, s>>>(q, d_lanes);
         }
     } else if (form == 1) {
         sample_kernel<1, 0, true><<<grid, LG_TILE, 0, s>>>(p, d_lanes);
-        if (after_sample) HIP_CALL(hipEventRecord(after_sample, s));
     } else {
         sample_kernel<0, 0, true><<<grid, LG_TILE, 0, s>>>(p, d_lanes);
-        if (after_sample) HIP_CALL(hipEventRecord(after_sample, s));
     }
     hipCheckError();
     if (p.last_hop) compact_kernel<true><<<grid, LG_TILE, 0, s>>>(p, d_lanes);

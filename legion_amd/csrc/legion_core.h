@@ -748,9 +748,7 @@ struct HopParams {                  // what every lane of a launch shares
     int32_t lds_k;                  // lds form: super tiles per partition tile in this hop (set by launch_random_sample)
 };
 // form: 0 direct array, 1 table, 2 lds
-// after_sample (optional): recorded on s behind the hop's sampling kernel(s), in front of its de-duplication / compaction
-void launch_random_sample(hipStream_t s, const HopParams& p, const LanePtrs* d_lanes, int32_t n_lanes, int32_t form,
-                          hipEvent_t after_sample = nullptr);
+void launch_random_sample(hipStream_t s, const HopParams& p, const LanePtrs* d_lanes, int32_t n_lanes, int32_t form);
 
 // hand-over of a lane's finished batch to a trainer-visible pipe slot (kernels_gather.hip)
 struct DeliverParams {

@@ -36,17 +36,6 @@ static thread_local bool g_weave_head_gathers = true;
 extern "C" void legion_set_weave_head_gathers(int32_t on) { g_weave_head_gathers = on != 0; }
 static inline bool lg_weave_head_gathers() { return g_weave_head_gathers; }
 
-// last_hop_split (pipeline.hip sets the context around a group's enqueue / capture): a second stream and two events with which
-// the last hop of a group runs as two half groups -- the second half's sampling beside the first half's de-duplication.
-struct HopSplitCtx { hipStream_t aux = nullptr; hipEvent_t fork = nullptr, join = nullptr; };
-static thread_local HopSplitCtx g_hop_split;
-extern "C" void legion_set_hop_split(void* aux_stream, void* ev_fork, void* ev_join)
-{
-    g_hop_split.aux = static_cast<hipStream_t>(aux_stream);
-    g_hop_split.fork = static_cast<hipEvent_t>(ev_fork);
-    g_hop_split.join = static_cast<hipEvent_t>(ev_join);
-}
-
 // ---- lane-group bodies: every operator works on n lanes (n = 1 for the reference-shaped calls) ----
 struct LegionLaneGroup {
     std::vector<MemoryPool*> pools;
@@ -145,19 +134,7 @@ static void do_random_sample(hipStream_t s, GraphStorage* graph, UnifiedCache* c
     p.loser_in_dst = pool0->lds_form && (int64_t)pool0->total_num_nodes <= ((int64_t)1 << 30) && lg::tuning().loser_in_dst != 0;
     p.lds_bucket_bits = pool0->lds_bucket_bits;
     p.lds_k = 1;                             // (launch_random_sample picks the hop's partition tile)
-    const int32_t form = pool0->lds_form ? 2 : (pool0->pos_table != nullptr ? 1 : 0);
-    if (p.last_hop && !is_presc && n_lanes >= 64 && g_hop_split.aux != nullptr && lg::tuning().last_hop_split != 0) {
-        // two half groups: [sample A][dedup A][compact A] on s, [sample B][dedup B][compact B] on the second stream behind sample A --
-        // the sampling kernel is bound by HBM requests, the de-duplication by LDS work: they use different parts of the machine
-        const int32_t nA = n_lanes / 2;
-        lg::launch_random_sample(s, p, d_lanes, nA, form, g_hop_split.fork);
-        HIP_CALL(hipStreamWaitEvent(g_hop_split.aux, g_hop_split.fork, 0));
-        lg::launch_random_sample(g_hop_split.aux, p, d_lanes + nA, n_lanes - nA, form);
-        HIP_CALL(hipEventRecord(g_hop_split.join, g_hop_split.aux));
-        HIP_CALL(hipStreamWaitEvent(s, g_hop_split.join, 0));
-        return;
-    }
-    lg::launch_random_sample(s, p, d_lanes, n_lanes, form);
+    lg::launch_random_sample(s, p, d_lanes, n_lanes, pool0->lds_form ? 2 : (pool0->pos_table != nullptr ? 1 : 0));
 }
 
 static void do_feature_lookup(hipStream_t s, UnifiedCache* cache, const LanePtrs* d_lanes, int32_t n_lanes,

@@ -39,7 +39,6 @@ extern "C" void legion_enqueue_group_phase(legion_stream_t strm_hdl, LegionGraph
 extern "C" void legion_pool_profile_begin(LegionMemoryPool* p_, int32_t max_ops);
 extern "C" const void* legion_group_lane_desc(LegionLaneGroup* g, int32_t lane);
 extern "C" void legion_set_weave_head_gathers(int32_t on);
-extern "C" void legion_set_hop_split(void* aux_stream, void* ev_fork, void* ev_join);
 
 struct Slot {
     std::vector<MemoryPool*> pools;           // G lanes
@@ -47,7 +46,6 @@ struct Slot {
     hipStream_t stream = nullptr;
     hipEvent_t done = nullptr;
     hipEvent_t sampled = nullptr;             // split mode: the group's sampler phase has finished (weave: its head)
-    hipEvent_t hs_fork = nullptr, hs_join = nullptr;   // last_hop_split: the fork / join of the last hop's two half groups
     bool busy = false;
     std::map<int64_t, hipGraphExec_t> exec;   // key: (mode, active lanes, batch_size, phase)
     int32_t* d_iter = nullptr;                // device {next counter0, stride}
@@ -86,7 +84,6 @@ struct LegionPipeline {
     bool sample_only = false;   // only the sampler phase runs here; the owner gathers each lane itself (GPURunner: straight
                                 // into a trainer-visible pipe slot)
     hipStream_t sample_stream = nullptr;
-    hipStream_t aux_stream = nullptr;         // last_hop_split: the second half group's stream
     bool gather_high = false;
     int32_t rr = 0;
     int32_t last_slot = -1;
@@ -206,10 +203,7 @@ extern "C" LegionPipeline* legion_pipeline_create(LegionGraphStorage* graph, Leg
             sl.stream = p->slots[0].stream;
         HIP_CALL(hipEventCreateWithFlags(&sl.done, hipEventDisableTiming));
         HIP_CALL(hipEventCreateWithFlags(&sl.sampled, hipEventDisableTiming));
-        HIP_CALL(hipEventCreateWithFlags(&sl.hs_fork, hipEventDisableTiming));
-        HIP_CALL(hipEventCreateWithFlags(&sl.hs_join, hipEventDisableTiming));
     }
-    if (lg::tuning().last_hop_split != 0) HIP_CALL(hipStreamCreateWithFlags(&p->aux_stream, hipStreamNonBlocking));
     lg_set_pool_lanes_hint(0);
     lg_set_pool_claims_hint(0, 0);
     lg_set_pool_arena(nullptr);
@@ -247,13 +241,11 @@ static hipGraphExec_t graph_of(LegionPipeline* p, Slot& sl, hipStream_t strm, in
         hipGraphExec_t exec = nullptr;
         HIP_CALL(hipStreamSynchronize(strm));
         legion_set_weave_head_gathers(p->gathers ? 1 : 0);
-        legion_set_hop_split(p->aux_stream, sl.hs_fork, sl.hs_join);
         HIP_CALL(hipStreamBeginCapture(strm, hipStreamCaptureModeThreadLocal));
         legion_enqueue_group_phase(strm, reinterpret_cast<LegionGraphStorage*>(p->graph), reinterpret_cast<LegionFeatureStorage*>(p->feature),
                                    p->cache_handle, sl.group, n_active, batch_size, 0, p->dev_id, mode, p->fanout.data(),
                                    p->hop_num, phase);
         HIP_CALL(hipStreamEndCapture(strm, &graph));
-        legion_set_hop_split(nullptr, nullptr, nullptr);
         HIP_CALL(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
         HIP_CALL(hipGraphDestroy(graph));
         it = sl.exec.emplace(key, exec).first;
@@ -368,12 +360,9 @@ extern "C" int32_t legion_pipeline_submit_ex(LegionPipeline* p, int32_t counter0
         }
         auto run = [&](hipStream_t strm, int32_t phase) {
             legion_set_weave_head_gathers(p->gathers ? 1 : 0);
-            if (eager) {
-                legion_set_hop_split(p->aux_stream, sl.hs_fork, sl.hs_join);
+            if (eager)
                 legion_enqueue_group_phase(strm, gr, f, p->cache_handle, sl.group, n_active, batch_size, counter0, p->dev_id, mode,
                                            p->fanout.data(), p->hop_num, phase);
-                legion_set_hop_split(nullptr, nullptr, nullptr);
-            }
             else
                 HIP_CALL(hipGraphLaunch(graph_of(p, sl, strm, phase, mode, n_active, batch_size), strm));
         };
@@ -469,12 +458,9 @@ extern "C" void legion_pipeline_destroy(LegionPipeline* p)
         for (MemoryPool* mp : sl.pools) legion_pool_destroy(reinterpret_cast<LegionMemoryPool*>(mp));
         HIP_CALL(hipEventDestroy(sl.done));
         HIP_CALL(hipEventDestroy(sl.sampled));
-        HIP_CALL(hipEventDestroy(sl.hs_fork));
-        HIP_CALL(hipEventDestroy(sl.hs_join));
         if (p->overlap || &sl == &p->slots[0]) HIP_CALL(hipStreamDestroy(sl.stream));
     }
     if (p->sample_stream) HIP_CALL(hipStreamDestroy(p->sample_stream));
-    if (p->aux_stream) { HIP_CALL(hipStreamSynchronize(p->aux_stream)); HIP_CALL(hipStreamDestroy(p->aux_stream)); }
     if (p->bulk) {
         for (size_t o = 0; o < p->bulk->owner_streams.size(); o++)
             if (p->bulk->owner_streams[o] != nullptr) {

@@ -51,7 +51,6 @@ void parse_env(LegionTuning& t)
     t.split_priority = env_int("LEGION_SPLIT_PRIORITY", 1);
     t.weave_priority = env_int("LEGION_WEAVE_PRIORITY", -1);
     t.weave_early_gathers = env_int("LEGION_WEAVE_EARLY_GATHERS", 0);
-    t.last_hop_split = env_int("LEGION_LAST_HOP_SPLIT", 0);
     t.runner_graph = env_int("LEGION_RUNNER_GRAPH", 1);
     t.runner_lanes = env_int("LEGION_RUNNER_LANES", 0);
     t.runner_ho_stream = env_int("LEGION_RUNNER_HO_STREAM", 2);
