@@ -398,6 +398,8 @@ typedef struct LegionTuning {
                                     slot_dst entry (the compaction then reads one array less) instead of in slot_mark */
     int32_t gather_small_tiles;  /* LEGION_GATHER_SMALL_TILES (1): 16-row tiles for launches of fewer than 4096 tiles */
     int32_t gather_rows_per_wg;  /* LEGION_GATHER_ROWS     (0 = by row width): rows per gather workgroup, 16|32|64|128|256 */
+    int32_t compact_hoist;       /* LEGION_COMPACT_HOIST   (1): compact_kernel loads the per-slot inputs that depend on the slot index only
+                                    together with slot_dst, for every slot (more bytes, one dependent round trip less) */
     int32_t col_slots;           /* LEGION_COL_SLOTS       (-1 auto): the {neighbour id, feature-cache slot} copy of the column array that
                                     lets the gather skip its node_map lookup (8 B per edge of HBM per GPU): 1 always, 0 never,
                                     -1 when the column array is device memory and the copy fits half of the HBM that is free after the fills, leaving 24 GB */

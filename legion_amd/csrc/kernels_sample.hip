@@ -236,7 +236,7 @@ struct SampleArgs {
     int32_t* const* csr_dst_x;
     const LG_G int32_t* col_full; const LG_G lg_v2i* colx_full;
     const LG_G RowHdr* row_hdr;
-    bool last_hop, is_presc, loser_in_dst;
+    bool last_hop, is_presc, loser_in_dst, compact_hoist;
     LG_G unsigned long long* edge_access_time;
     LG_G unsigned long long* topo_transactions;
     // the lane's buffers, in the global address space (see LG_G in legion_core.h)
@@ -279,7 +279,7 @@ __device__ __forceinline__ SampleArgs lane_args(const HopParams& p, const LanePt
     SampleArgs a;
     a.op_id = p.op_id; a.count = p.count; a.partition_count = p.partition_count; a.max_slots = p.max_slots;
     a.csr_dst_node_ids = p.csr_dst_node_ids; a.csr_dst_x = p.csr_dst_x;
-    a.col_full = LG_GPTR(const int32_t, p.col_full); a.colx_full = LG_GPTR(const lg_v2i, p.colx_full); a.row_hdr = LG_GPTR(const RowHdr, p.row_hdr); a.last_hop = p.last_hop; a.is_presc = p.is_presc; a.loser_in_dst = p.loser_in_dst;
+    a.col_full = LG_GPTR(const int32_t, p.col_full); a.colx_full = LG_GPTR(const lg_v2i, p.colx_full); a.row_hdr = LG_GPTR(const RowHdr, p.row_hdr); a.last_hop = p.last_hop; a.is_presc = p.is_presc; a.loser_in_dst = p.loser_in_dst; a.compact_hoist = p.compact_hoist;
     a.edge_access_time = LG_GPTR(unsigned long long, p.edge_access_time);
     a.topo_transactions = LG_GPTR(unsigned long long, p.topo_transactions);
     a.sampled_ids = LG_GPTR(int32_t, L.sampled_ids); a.agg_src_ids = LG_GPTR(int32_t, L.agg_src_ids);
@@ -925,6 +925,23 @@ void compact_kernel(HopParams hp, const LanePtrs* __restrict__ lanes)
             v[u] = idx < total ? a.slot_dst[idx] : -1;
             mk[u] = (idx < total && !inl) ? a.slot_mark[idx] : 0;
         }
+        // (compact_hoist) what depends on the slot INDEX only -- the vertex the slot sampled for, its position, the carried cache slot --
+        // is loaded together with slot_dst, for every slot of the tile: more bytes (invalid slots too), one dependent round trip less
+        int32_t src_of[LG_SLOTS_PER_LANE], src_pos[LG_SLOTS_PER_LANE], fsv[LG_SLOTS_PER_LANE];
+        const bool hoist = a.compact_hoist;
+        if (hoist) {
+#pragma unroll
+            for (int u = 0; u < LG_SLOTS_PER_LANE; u++) {
+                const int32_t idx = idx0 + u * LG_TILE + tid;
+                src_of[u] = 0; src_pos[u] = 0; fsv[u] = LG_FS_UNKNOWN;
+                if (idx < total) {
+                    const int32_t q = idx / a.count;
+                    src_of[u] = frontier[q];
+                    src_pos[u] = seeds ? q : a.agg_src_off[f_off + q];
+                    if (a.slot_fs != nullptr) fsv[u] = a.slot_fs[idx];
+                }
+            }
+        }
 #pragma unroll
         for (int u = 0; u < LG_SLOTS_PER_LANE; u++) {
             const bool valid = v[u] >= 0;
@@ -959,7 +976,7 @@ void compact_kernel(HopParams hp, const LanePtrs* __restrict__ lanes)
         }
         // phase 1: every load of the thread's four slots that does not need the prefix -- in flight while wave 0 looks back
         // (nothing is stored in between: the buffers may alias as far as the compiler knows)
-        int32_t src_of[LG_SLOTS_PER_LANE], src_pos[LG_SLOTS_PER_LANE], lost_pos[LG_SLOTS_PER_LANE], fsv[LG_SLOTS_PER_LANE];
+        int32_t lost_pos[LG_SLOTS_PER_LANE];
         uint32_t tab_at[LG_SLOTS_PER_LANE];
         RowHdr nh[LG_SLOTS_PER_LANE];
 #pragma unroll
@@ -968,13 +985,17 @@ void compact_kernel(HopParams hp, const LanePtrs* __restrict__ lanes)
             if (v[u] >= 0) {
                 const bool first = (mf[u] >> lane) & 1ull;
                 const int32_t dst = v[u];
-                const int32_t q = idx / a.count;
-                src_of[u] = frontier[q];
-                // position of the node sampled for == construct_graph's position_map[agg_dst_ids[e]]
-                src_pos[u] = seeds ? q : a.agg_src_off[f_off + q];
+                if (!hoist) {
+                    const int32_t q = idx / a.count;
+                    src_of[u] = frontier[q];
+                    // position of the node sampled for == construct_graph's position_map[agg_dst_ids[e]]
+                    src_pos[u] = seeds ? q : a.agg_src_off[f_off + q];
+                    fsv[u] = (first && a.slot_fs != nullptr) ? a.slot_fs[idx] : LG_FS_UNKNOWN;   // the new node's feature-cache slot, if carried
+                } else if (!first) {
+                    fsv[u] = LG_FS_UNKNOWN;
+                }
                 if (!LAST) nh[u] = load_hdr(a.row_hdr + dst);      // next hop's frontier header
                 lost_pos[u] = first ? 0 : a.slot_pos[idx];               // final already, or -2 - (slot it lost to)
-                fsv[u] = (first && a.slot_fs != nullptr) ? a.slot_fs[idx] : LG_FS_UNKNOWN;   // the new node's feature-cache slot, if carried
                 tab_at[u] = (first && !LAST && a.pos_table != nullptr) ? table_find(a.pos_table, a.pos_mask, a.pf, dst) : 0u;
             }
         }

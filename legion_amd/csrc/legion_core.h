@@ -744,6 +744,7 @@ struct HopParams {                  // what every lane of a launch shares
     unsigned long long* topo_transactions; // presample only: 64-byte transactions the hop's topology reads amount to
     bool loser_in_dst;              // lds form, vertex ids < 2^30: a slot that lost its first touch carries LG_LOSER_BIT in slot_dst (written by
                                     // the de-duplication kernel) instead of the hop's tag in slot_mark -- the compaction then streams one array less
+    bool compact_hoist;             // compact_kernel loads what depends on the slot index only together with slot_dst (LegionTuning.compact_hoist)
     int32_t lds_bucket_bits;        // lds form: LG_LDS_BITS_SMALL / SMALL16 / MEDIUM / LARGE (the pool's)
     int32_t lds_k;                  // lds form: super tiles per partition tile in this hop (set by launch_random_sample)
 };

@@ -132,6 +132,7 @@ static void do_random_sample(hipStream_t s, GraphStorage* graph, UnifiedCache* c
     p.edge_access_time = (is_presc && cache) ? cache->GetEdgeAccessedMap(dev_id) : nullptr;   // :473
     p.topo_transactions = (is_presc && cache) ? cache->Controller(dev_id)->GetTopoTransactions() : nullptr;
     p.loser_in_dst = pool0->lds_form && (int64_t)pool0->total_num_nodes <= ((int64_t)1 << 30) && lg::tuning().loser_in_dst != 0;
+    p.compact_hoist = lg::tuning().compact_hoist != 0;
     p.lds_bucket_bits = pool0->lds_bucket_bits;
     p.lds_k = 1;                             // (launch_random_sample picks the hop's partition tile)
     lg::launch_random_sample(s, p, d_lanes, n_lanes, pool0->lds_form ? 2 : (pool0->pos_table != nullptr ? 1 : 0));

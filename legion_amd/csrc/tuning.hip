@@ -46,6 +46,7 @@ void parse_env(LegionTuning& t)
     t.loser_in_dst = env_int("LEGION_LOSER_IN_DST", 1);
     t.gather_small_tiles = env_int("LEGION_GATHER_SMALL_TILES", 1);
     t.gather_rows_per_wg = env_int("LEGION_GATHER_ROWS", 0);
+    t.compact_hoist = env_int("LEGION_COMPACT_HOIST", 1);
     t.col_slots = env_int("LEGION_COL_SLOTS", -1);
     t.split_sampler_cus = env_int("LEGION_SPLIT_SAMPLER_CUS", 0);
     t.split_priority = env_int("LEGION_SPLIT_PRIORITY", 1);
