@@ -805,10 +805,10 @@ def run_leg(c, engine, synth, stripe, replica_memory, headline, bulk=False):
     rocprof_us, rocprof_src = None, None
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "bench_default_kernel_trace_by_grid.csv")), reverse=True):
         try:
-            import csv
-            for r in csv.DictReader(open(f)):
-                if "gather_kernel" in r["kernel"] and r["kernel"].rstrip().endswith("true>") and int(r["grid_y"]) == G:
-                    rocprof_us, rocprof_src = float(r["avg_us"]), os.path.relpath(f, ROOT)
+            for ln in open(f).read().splitlines()[1:]:
+                c = ln.rsplit(",", 10)          # kernel (its template arguments contain commas), then ten numeric columns
+                if len(c) == 11 and "gather_kernel" in c[0] and c[0].rstrip().endswith("true>") and int(c[2]) == G:
+                    rocprof_us, rocprof_src = float(c[7]), os.path.relpath(f, ROOT)
                     break
         except (OSError, ValueError, KeyError):
             continue

@@ -24,6 +24,10 @@ def main():
     for i in range(total):
         t = ipc_service.get_next(dim)
         sizes = ipc_service.get_block_size()
+        # the Python ABI of TB/ipc_service.cpp:44-79: int32 ids / labels / edge positions, float32 rows, all on the GPU
+        assert t[0].dtype == torch.int32 and t[1].dtype == torch.float32 and t[2].dtype == torch.int32 and all(x.is_cuda for x in t)
+        assert all(x.dtype == torch.int32 for x in t[3:]) and t[1].dim() == 2 and t[1].shape[1] == dim and t[1].shape[0] == t[0].shape[0]
+        out[f"b{i}_ntensors"] = np.int32(len(t))
         out[f"b{i}_ids"] = t[0].cpu().numpy()
         out[f"b{i}_feats"] = t[1].cpu().numpy().view(np.uint32)
         out[f"b{i}_labels"] = t[2].cpu().numpy()

@@ -96,6 +96,53 @@ def main():
         subprocess.call(["rm", "-rf", tmp])
 
 
+def consume(spec):
+    """The Python consumer of ONE server life, in a process of its own (a trainer attaches to one server; several server lives
+    attached to and detached from one long-lived process made a device-to-host copy of a freshly opened IPC buffer abort inside the
+    HIP runtime now and then): walks the schedule through the `ipc_service` module, times it, optionally verifies batches, prints
+    one JSON line."""
+    a = argparse.Namespace(**spec["args"])
+    batch, train, fanout = spec["batch"], np.fromfile(spec["train_file"], dtype=np.int32), spec["fanout"]
+    import ipc_service
+    torch.cuda.set_device(0)
+    ipc_service.initialize()
+    tr, va, te = ipc_service.get_steps()
+    edges, t0, t1, n_timed, verified = 0, None, None, 0, 0
+    t_start = time.time()
+    n_all = (tr + va) * a.epochs + te                # the reference's schedule (ipc_service.cu:130-132)
+    last_timed = (tr + va) * (a.epochs - 1) + tr - 1     # last training batch of the last epoch
+    for i in range(n_all):
+        if a.watchdog and time.time() - t_start > a.watchdog:
+            raise RuntimeError(f"watchdog: stuck or too slow at batch {i} of {n_all}")
+        out = ipc_service.get_next(a.dim)
+        if i <= last_timed:
+            if i == 5:
+                torch.cuda.synchronize(); t0 = time.perf_counter(); edges = 0; n_timed = 0
+            edges += int(out[3].numel())          # outermost block = every edge of the batch
+            n_timed += 1
+        if a.verify_every and i % a.verify_every == 0:
+            ids, fts = out[0], out[1]
+            n = int(ids.numel())
+            assert n > 0 and tuple(fts.shape) == (n, a.dim)
+            if not a.no_features_file:
+                assert synth.feature_check_device(fts.contiguous(), ids.contiguous(), a.dim, 7) == 0, f"batch {i}: rows differ"
+            assert int(torch.unique(ids).numel()) == n, f"batch {i}: duplicate ids"
+            sizes = ipc_service.get_block_size()
+            assert sizes[0] == n and int(out[3].max()) < n and int(out[4].max()) < sizes[1], f"batch {i}: edge endpoints"
+            seeds_expected = torch.from_numpy(train[i * batch:(i + 1) * batch]).cuda() if (i < tr and a.epochs == 1) else None
+            if seeds_expected is not None:
+                assert bool((ids[:batch] == seeds_expected).all()), f"batch {i}: not the seeds of training batch {i}"
+            verified += 1
+        del out
+        ipc_service.synchronize()
+        if i == last_timed:
+            torch.cuda.synchronize(); t1 = time.perf_counter()
+    ipc_service.finalize()
+    dt = t1 - t0
+    print(json.dumps({"batches_per_sec": n_timed / dt, "edges_per_sec": edges / dt, "timed_batches": n_timed,
+                      "ms_per_batch": dt / n_timed * 1e3, "verified_batches": verified}), flush=True)
+
+
 def run_one(a, ds, tmp, batch, n_train, train, fanout, N, E, mode=""):
     work = os.path.join(tmp, f"run_b{batch}{mode}")
     os.makedirs(work)
@@ -138,48 +185,19 @@ def run_one(a, ds, tmp, batch, n_train, train, fanout, N, E, mode=""):
                         "workload": workload, "batch": batch, "handover": handover_of(), "mode": mode, "epochs": a.epochs})
             print(json.dumps(res), flush=True)
             return
-        import ipc_service
-        torch.cuda.set_device(0)
-        ipc_service.initialize()
-        tr, va, te = ipc_service.get_steps()
-        H = len(fanout)
-        edges, t0, n_timed, verified = 0, None, 0, 0
-        t_start = time.time()
-        n_all = (tr + va) * a.epochs + te                # the reference's schedule (ipc_service.cu:130-132)
-        last_timed = (tr + va) * (a.epochs - 1) + tr - 1     # last training batch of the last epoch
-        for i in range(n_all):
-            if a.watchdog and time.time() - t_start > a.watchdog:
-                raise RuntimeError(f"watchdog: stuck or too slow at batch {i} of {n_all}")
-            out = ipc_service.get_next(a.dim)
-            if i <= last_timed:
-                if i == 5:
-                    torch.cuda.synchronize(); t0 = time.perf_counter(); edges = 0; n_timed = 0
-                edges += int(out[3].numel())          # outermost block = every edge of the batch
-                n_timed += 1
-            if a.verify_every and i % a.verify_every == 0:
-                ids, fts = out[0], out[1]
-                n = int(ids.numel())
-                assert n > 0 and tuple(fts.shape) == (n, a.dim)
-                if not a.no_features_file:
-                    assert synth.feature_check_device(fts.contiguous(), ids.contiguous(), a.dim, 7) == 0, f"batch {i}: rows differ"
-                assert int(torch.unique(ids).numel()) == n, f"batch {i}: duplicate ids"
-                sizes = ipc_service.get_block_size()
-                assert sizes[0] == n and int(out[3].max()) < n and int(out[4].max()) < sizes[1], f"batch {i}: edge endpoints"
-                seeds_expected = torch.from_numpy(train[i * batch:(i + 1) * batch]).cuda() if (i < tr and a.epochs == 1) else None
-                if seeds_expected is not None:
-                    assert bool((ids[:batch] == seeds_expected).all()), f"batch {i}: not the seeds of training batch {i}"
-                verified += 1
-            del out
-            ipc_service.synchronize()
-            if i == last_timed:
-                torch.cuda.synchronize(); t1 = time.perf_counter()
-        ipc_service.finalize()
+        spec = {"args": {k: getattr(a, k) for k in ("dim", "epochs", "watchdog", "verify_every", "no_features_file")},
+                "batch": batch, "fanout": fanout, "train_file": ds + "trainingset"}
+        child = subprocess.run([sys.executable, os.path.abspath(__file__), "--child-consumer", json.dumps(spec)], env=dict(os.environ),
+                               stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=(a.watchdog or 3000) + 120)
+        cl = [ln for ln in child.stdout.splitlines() if ln.startswith("{")]
+        if child.returncode != 0 or not cl:
+            raise RuntimeError(f"consumer failed (rc {child.returncode}): {child.stdout[-800:]} {child.stderr[-2500:]}")
+        r = json.loads(cl[-1])
         server.wait(timeout=120)
-        dt = t1 - t0
         print(json.dumps({"path": "sampling_server binary -> shm/semaphores/IPC handles -> ipc_service consumer",
                           "workload": workload, "batch": batch, "handover": handover_of(), "mode": mode, "epochs": a.epochs,
-                          "batches_per_sec": n_timed / dt, "edges_per_sec": edges / dt, "timed_batches": n_timed,
-                          "ms_per_batch": dt / n_timed * 1e3, "verified_batches": verified}), flush=True)
+                          "batches_per_sec": r["batches_per_sec"], "edges_per_sec": r["edges_per_sec"], "timed_batches": r["timed_batches"],
+                          "ms_per_batch": r["ms_per_batch"], "verified_batches": r["verified_batches"]}), flush=True)
     finally:
         if server.poll() is None:
             server.kill()
@@ -192,4 +210,7 @@ def run_one(a, ds, tmp, batch, n_train, train, fanout, N, E, mode=""):
 
 
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) == 3 and sys.argv[1] == "--child-consumer":
+        consume(json.loads(sys.argv[2]))
+    else:
+        main()
