@@ -806,9 +806,9 @@ def run_leg(c, engine, synth, stripe, replica_memory, headline, bulk=False):
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "bench_default_kernel_trace_by_grid.csv")), reverse=True):
         try:
             for ln in open(f).read().splitlines()[1:]:
-                c = ln.rsplit(",", 10)          # kernel (its template arguments contain commas), then ten numeric columns
-                if len(c) == 11 and "gather_kernel" in c[0] and c[0].rstrip().endswith("true>") and int(c[2]) == G:
-                    rocprof_us, rocprof_src = float(c[7]), os.path.relpath(f, ROOT)
+                cols = ln.rsplit(",", 10)       # kernel (its template arguments contain commas), then ten numeric columns
+                if len(cols) == 11 and "gather_kernel" in cols[0] and cols[0].rstrip().endswith("true>") and int(cols[2]) == G:
+                    rocprof_us, rocprof_src = float(cols[7]), os.path.relpath(f, ROOT)
                     break
         except (OSError, ValueError, KeyError):
             continue

@@ -46,6 +46,9 @@ def main():
     ap.add_argument("--min-timed-batches", type=int, default=0,
                     help="run as many epochs as it takes for the timed window to hold at least this many batches (views mode hands "
                          "over 100 k+ batches/s: a single epoch of a few thousand batches is a window of milliseconds)")
+    ap.add_argument("--profile-server", type=str, default="",
+                    help="directory: run the server under `rocprofv3 --kernel-trace --output-format csv -d <dir>/<mode>_b<batch>` (its kernel "
+                         "trace: per-batch hand-over launches, gaps, what runs beside them)")
     ap.add_argument("--edge-factor", type=int, default=16)
     ap.add_argument("--nodes", type=int, default=0, help="with --edges: synth.csr_device_large(nodes, edges) instead of RMAT-<scale>")
     ap.add_argument("--edges", type=int, default=0)
@@ -163,8 +166,11 @@ def run_one(a, ds, tmp, batch, n_train, train, fanout, N, E, mode=""):
     workload = (f"N={N}, E={E} (synth.csr_device_large)" if a.nodes > 0 else f"RMAT-{a.scale} EF{a.edge_factor}") + f", D={a.dim}, batch {batch}, fanout {fanout}, train mode, 1 GPU" + \
                (", zero-filled feature table (no `features` file)" if a.no_features_file else "")
     log = open(os.path.join(work, "server.log"), "w")
-    server = subprocess.Popen([os.path.join(ROOT, "legion_amd", "bin", "sampling_server"), "1", "0"] + [str(f) for f in fanout],
-                              cwd=work, env=dict(os.environ), stdout=log, stderr=subprocess.STDOUT)
+    prefix = []
+    if a.profile_server:
+        prefix = ["rocprofv3", "--kernel-trace", "--output-format", "csv", "-d", os.path.join(a.profile_server, f"{mode or 'run'}_b{batch}"), "--"]
+    server = subprocess.Popen(prefix + [os.path.join(ROOT, "legion_amd", "bin", "sampling_server"), "1", "0"] + [str(f) for f in fanout],
+                              cwd=work, env=dict(os.environ, TMPDIR="/tmp"), stdout=log, stderr=subprocess.STDOUT)
     try:
         deadline = time.time() + 600
         while "System is ready for serving" not in open(os.path.join(work, "server.log")).read():
