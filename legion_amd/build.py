@@ -86,7 +86,15 @@ def build_variant(name, extra_flags, verbose=True):
     out = os.path.join(HERE, "..", "tools", "lds_tuning", "variants", name)
     os.makedirs(out, exist_ok=True)
     objs, procs = [], []
+    # LEGION_VARIANT_ONLY="kernels_sample.hip ...": the constants only reach these sources; the rest is the build in place
+    only = os.environ.get("LEGION_VARIANT_ONLY", "").split()
+    if only:
+        build_lib(verbose=False)
+    keep = []
     for src in SOURCES:
+        if only and src not in only:
+            keep.append(os.path.join(HERE, "_obj", src + ".o"))
+            continue
         o = os.path.join(out, src + ".o")
         objs.append(o)
         cmd = [HIPCC] + FLAGS + ["-w"] + list(extra_flags) + ["-c", os.path.join(CSRC, src), "-o", o]
@@ -95,7 +103,7 @@ def build_variant(name, extra_flags, verbose=True):
     if failed:
         raise RuntimeError(f"hipcc failed for {failed}")
     lib = os.path.join(out, "liblegion_hip.so")
-    subprocess.check_call([HIPCC, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", lib] + objs +
+    subprocess.check_call([HIPCC, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", lib] + objs + keep +
                           ["-lpthread", "-lrt", "-ldl", "-L/opt/rocm/lib", "-lrccl", "-Wl,-rpath,/opt/rocm/lib"])
     for o in objs:
         os.unlink(o)

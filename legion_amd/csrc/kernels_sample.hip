@@ -101,7 +101,7 @@ struct BracketLane {
     LG_G int32_t* sampled_ids; LG_G int32_t* labels; LG_G int32_t* node_counter; LG_G int32_t* edge_counter;
     LG_G int32_t* hop_scratch; LG_G uint32_t* position_map; LG_G int32_t* slot_mark; LG_G int32_t* node_slot;
     LG_G unsigned long long* pos_table; uint32_t pos_mask; LG_G int32_t* err_flag;
-    LG_G int32_t* known_cnt; int32_t lds_buckets;
+    LG_G int32_t* known_cnt; LG_G int32_t* claim_cnt; int32_t lds_buckets;
     LG_G int32_t* counter_mirror;
     int32_t total_num_nodes, max_slots;
 };
@@ -114,7 +114,7 @@ __device__ __forceinline__ BracketLane bracket_lane(const LanePtrs& P)
     L.slot_mark = LG_GPTR(int32_t, P.slot_mark); L.node_slot = LG_GPTR(int32_t, P.node_slot);
     L.pos_table = LG_GPTR(unsigned long long, P.pos_table); L.pos_mask = P.pos_table_mask;
     L.err_flag = LG_GPTR(int32_t, P.err_flag);
-    L.known_cnt = LG_GPTR(int32_t, P.known_cnt); L.lds_buckets = P.lds_buckets;
+    L.known_cnt = LG_GPTR(int32_t, P.known_cnt); L.claim_cnt = LG_GPTR(int32_t, P.claim_cnt); L.lds_buckets = P.lds_buckets;
     L.counter_mirror = LG_GPTR(int32_t, P.counter_mirror);
     L.total_num_nodes = P.total_num_nodes; L.max_slots = P.max_slots;
     return L;
@@ -185,6 +185,7 @@ __global__ void batch_generate_kernel(SeedParams p, const LanePtrs* __restrict__
     const int32_t size = ((int64_t)p.batch_size * (counter + 1) >= p.total_cap)
                              ? (p.total_cap - p.batch_size * counter) : p.batch_size;
     if (L.known_cnt != nullptr && idx < L.lds_buckets) L.known_cnt[idx] = 0;    // lds form: the batch's known lists start empty
+    if (L.claim_cnt != nullptr && idx < L.lds_buckets) L.claim_cnt[idx * LG_CLAIM_CNT_STRIDE] = 0;    // (every hop's de-duplication leaves them zero; a batch cut short by an error may not)
     if (idx < 16) {                    // memset of both counter blocks, operator_impl.cu:155-156,
         int32_t v = 0;                 // then counter_update(op 0), :64-68
         if (idx == 1) v = size;
@@ -230,6 +231,10 @@ void launch_batch_generate(hipStream_t s, const SeedParams& p, const LanePtrs* d
 // the kernels' view of one lane: the launch-wide hop parameters + that lane's buffers
 typedef int32_t lg_v4i __attribute__((ext_vector_type(4)));
 typedef int32_t lg_v2i __attribute__((ext_vector_type(2)));
+template <int NB> __device__ __forceinline__ int64_t lg_claim_at(int32_t b, int32_t k)      // entry k of bucket b's claim list (LanePtrs)
+{
+    return ((((int64_t)(k >> LG_CLAIM_CHUNK_BITS) * NB) + b) << LG_CLAIM_CHUNK_BITS) + (k & (LG_CLAIM_CHUNK - 1));
+}
 struct SampleArgs {
     int32_t op_id, count, partition_count, max_slots;
     int32_t* const* csr_dst_node_ids;
@@ -245,7 +250,7 @@ struct SampleArgs {
     LG_G int32_t* slot_dst; LG_G int32_t* slot_pos; LG_G int32_t* slot_mark; LG_G int32_t* slot_fs; LG_G int32_t* node_slot; LG_G unsigned long long* tile_state; LG_G int32_t* hop_scratch;
     LG_G RowHdr* fh_edge;
     LG_G unsigned long long* pos_table; uint32_t pos_mask; LG_G int32_t* err_flag;
-    LG_G unsigned long long* claim_pairs; LG_G int32_t* run_off;
+    LG_G unsigned long long* claim_pairs; LG_G int32_t* run_off; LG_G int32_t* claim_cnt; int32_t claim_cap, ids_cap;
     LG_G unsigned long long* known_pairs; LG_G int32_t* known_cnt; int32_t known_cap;
     PosFmt pf;
     int32_t mark_tag;   // (epoch, hop): what slot_mark holds for a slot that lost its first touch in THIS hop
@@ -294,6 +299,7 @@ __device__ __forceinline__ SampleArgs lane_args(const HopParams& p, const LanePt
     a.err_flag = LG_GPTR(int32_t, L.err_flag);
     a.claim_pairs = LG_GPTR(unsigned long long, L.claim_pairs);
     a.run_off = LG_GPTR(int32_t, L.run_off);
+    a.claim_cnt = LG_GPTR(int32_t, L.claim_cnt); a.claim_cap = L.claim_cap; a.ids_cap = L.ids_cap;
     a.known_pairs = LG_GPTR(unsigned long long, L.known_pairs); a.known_cnt = LG_GPTR(int32_t, L.known_cnt); a.known_cap = L.known_cap;
     a.pf = lg_pos_fmt(a.hop_scratch[HS_EPOCH], a.hop_scratch[HS_VALUE_BITS]);
     a.mark_tag = (a.hop_scratch[HS_EPOCH] << 8) | (p.op_id / INTRABATCH_CON);
@@ -509,30 +515,22 @@ __global__ __launch_bounds__(LG_TILE) __attribute__((amdgpu_num_sgpr(LG_SAMPLE_S
                     }
                 }
                 __syncthreads();
-                if (NB <= 8) {
-                    if (tid == 0) {
-                        int32_t tot = 0;
-                        for (int b = 0; b < NB; b++) { s_boff[b] = tot; tot += s_bcnt[b]; }
-                        s_base = tot > 0 ? __hip_atomic_fetch_add(a.hop_scratch + HS_PAIR_CURSOR, tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
-                        a.run_off[(int64_t)st * (NB + 1) + NB] = s_base + tot;
-                    }
-                } else if (tid < 64) {                             // NB <= 64: wave 0 scans the bucket counts
-                    const int32_t c = tid < NB ? s_bcnt[tid] : 0;
-                    int32_t inc = c;
-                    for (int d = 1; d < 64; d <<= 1) { const int32_t o = __shfl_up(inc, d); if (tid >= d) inc += o; }
-                    if (tid < NB) s_boff[tid] = inc - c;
-                    if (tid == 63) {
-                        s_base = inc > 0 ? __hip_atomic_fetch_add(a.hop_scratch + HS_PAIR_CURSOR, inc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
-                        a.run_off[(int64_t)st * (NB + 1) + NB] = s_base + inc;
-                    }
+                // one list per bucket: the super tile's claims of a bucket take the next places of that bucket's list (one
+                // reservation per bucket and super tile).  A claim past the list's capacity is not written: the count says so, and
+                // the bucket's de-duplication workgroup then reads the hop's slots instead of the list
+                if (tid < NB) {
+                    const int32_t c = s_bcnt[tid];
+                    s_boff[tid] = c > 0 ? __hip_atomic_fetch_add(a.claim_cnt + tid * LG_CLAIM_CNT_STRIDE, c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
                 }
                 __syncthreads();
-                if (tid < NB) a.run_off[(int64_t)st * (NB + 1) + tid] = s_base + s_boff[tid];
 #pragma unroll
                 for (int u = 0; u < LG_SLOTS_PER_LANE; u++)
-                    if (bkt[u] >= 0)
-                        a.claim_pairs[s_base + s_boff[bkt[u]] + rank[u]] =
-                            ((unsigned long long)(uint32_t)dst[u] << 32) | (uint32_t)(idx0 + u * LG_TILE + tid);
+                    if (bkt[u] >= 0) {
+                        const int32_t at = s_boff[bkt[u]] + rank[u];
+                        if (at < a.claim_cap)
+                            a.claim_pairs[lg_claim_at<NB>(bkt[u], at)] =
+                                ((unsigned long long)(uint32_t)dst[u] << 32) | (uint32_t)(idx0 + u * LG_TILE + tid);
+                    }
             }
 
             if (FORM == 2 && !SINGLE) {
@@ -643,10 +641,27 @@ __global__ __launch_bounds__(LG_TILE) void place_kernel(HopParams hp, const Lane
 //      the atomics of the other two forms leave (here the chain of losers always has length one).
 // A bucket whose vertices cannot fit the table is processed in P passes over sub-buckets (further hash bits), so the
 // result never depends on how the hash spreads the batch.  Nothing survives the hop: nothing to clear, no state that
-// scales with the graph.  The claims arrive as one segment per partition tile of the sampling kernel (run_off); a
-// workgroup addresses claim k of its bucket through the prefix of the segment lengths.
+// scales with the graph.  The claims arrive as ONE LIST PER BUCKET in the 8- and 16-bucket classes (round 4: the workgroup's
+// reads then all leave in one round trip, see LISTS below), and as one segment per partition tile of the sampling kernel
+// (run_off) in the 64- and 256-bucket classes, where a workgroup addresses claim k of its bucket through the prefix of the
+// segment lengths.
 // ------------------------------------------------------------------------------------------
-#define LG_DEDUP_BATCH 4             // claims a thread loads before it works on them (their loads are in flight together)
+#define LG_DEDUP_BATCH 4             // known vertices a thread loads before it works on them (their loads are in flight together)
+#ifndef LG_DEDUP_CLAIMS
+#define LG_DEDUP_CLAIMS 5           // claims a thread keeps in registers (a bucket of at most LG_DEDUP_CLAIMS * LG_DEDUP_THREADS is "resident")
+#endif
+#ifndef LG_DEDUP_SPEC_KNOWN
+#define LG_DEDUP_SPEC_KNOWN 1      // LISTS: how many of a thread's LG_DEDUP_BATCH seeds / known-list entries are requested before the live lengths are known
+#endif
+#ifndef LG_DEDUP_FIXED
+#define LG_DEDUP_FIXED 0            // 1: a vertex's table word never moves (compare-and-swap on empty + min on the match); a resident claim reads it back in one LDS load
+#endif
+#ifdef LG_DEDUP_STAMPS                // tuning builds only (tools/lds_tuning): where a workgroup's time goes, summed over workgroups per hop
+__device__ unsigned long long g_dedup_stamps[8][16];
+#define LG_STAMP(i) do { stamp_t[i] = __builtin_amdgcn_s_memrealtime(); } while (0)      // (wave-uniform: lives in SGPRs)
+#else
+#define LG_STAMP(i) do { } while (0)
+#endif
 #ifndef LG_DEDUP_THREADS
 #define LG_DEDUP_THREADS 1024
 #endif
@@ -659,8 +674,9 @@ __global__ __launch_bounds__(LG_DEDUP_THREADS) __attribute__((amdgpu_num_sgpr(80
 void dedup_lds_kernel(HopParams hp, const LanePtrs* __restrict__ lanes)
 {
     constexpr int NB = 1 << BB;
+    constexpr bool LISTS = (BB == LG_LDS_BITS_SMALL || BB == LG_LDS_BITS_SMALL16);      // one claim list per bucket (no segment table)
     const int32_t K = hp.lds_k;                           // super tiles per partition tile (1 in the 8-bucket class)
-    constexpr int MAX_PARTS = LG_LDS_MAX_PARTS + 2;       // partition tiles of a hop (sample_kernel's K super tiles each)
+    constexpr int MAX_PARTS = LISTS ? 1 : LG_LDS_MAX_PARTS + 2;       // partition tiles of a hop (sample_kernel's K super tiles each)
     const SampleArgs a = lane_args(hp, lanes);
     __shared__ unsigned long long s_tab[LG_LDS_TABLE];
     __shared__ int32_t s_pref[MAX_PARTS];                  // exclusive prefix of the bucket's segment lengths
@@ -669,54 +685,123 @@ void dedup_lds_kernel(HopParams hp, const LanePtrs* __restrict__ lanes)
     const HopGeom g = hop_geometry(a);
     const int32_t nparts = (g.nsuper + K - 1) / K;
     const int32_t tid = threadIdx.x, b = blockIdx.x;
-    const int32_t n_known = a.node_counter[0] + a.node_counter[1];          // nodes of the batch before this hop
+#ifdef LG_DEDUP_STAMPS
+    unsigned long long stamp_t[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+    LG_STAMP(0);
     constexpr uint32_t PENDING = 0x80000000u;
     const LG_G int32_t* roff = a.run_off + b;              // roff[t * (NB + 1)]: start of this bucket's segment of partition tile t
+    const LG_G unsigned long long* klist = a.known_pairs + (int64_t)b * a.known_cap;
+
+    // The workgroup's life is a chain of dependent round trips to memory; LISTS cuts it to the shortest there is.  What a thread
+    // reads first -- its claims of the bucket's list, its seeds, its entries of the known list -- sits at addresses that do not
+    // depend on the live counters, so these loads leave TOGETHER with the loads of the counters and list lengths; entries past
+    // the live lengths are stale and are masked once the lengths have arrived.
+    unsigned long long rp[LG_DEDUP_CLAIMS];
+    int32_t kid[LG_DEDUP_BATCH];
+    unsigned long long kl[LG_DEDUP_BATCH];
+#if defined(LG_DEDUP_EXP) && LG_DEDUP_EXP == 3       // timing-only build: the launch alone
+    if (LISTS) { if (tid == 0) a.claim_cnt[b * LG_CLAIM_CNT_STRIDE] = 0; return; }
+#endif
+    if (LISTS) {
+#pragma unroll
+        for (int u = 0; u < LG_DEDUP_CLAIMS; u++) {
+            const int32_t k = u * LG_DEDUP_THREADS + tid;
+#if defined(LG_DEDUP_EXP) && LG_DEDUP_EXP == 2
+            rp[u] = ~0ull;
+#else
+            rp[u] = k < a.claim_cap ? a.claim_pairs[lg_claim_at<NB>(b, k)] : ~0ull;
+#endif
+        }
+#pragma unroll
+        for (int u = 0; u < LG_DEDUP_SPEC_KNOWN; u++) {
+            const int32_t i = u * LG_DEDUP_THREADS + tid;
+            kid[u] = i < a.ids_cap ? a.sampled_ids[i] : -1;
+            kl[u] = (a.known_pairs != nullptr && i < a.known_cap) ? klist[i] : ~0ull;
+        }
+    }
 
     // the batch's vertices before this hop: the seeds are read from sampled_ids, the nodes earlier hops added from the
     // bucket's list (list_known_kernel) -- or from sampled_ids too when there is no list or it outgrew its capacity
+    const int32_t n_known = a.node_counter[0] + a.node_counter[1];          // nodes of the batch before this hop
     const int32_t n_seed = min(max(a.node_counter[INTRABATCH_CON * 3], 0), n_known);
     const int32_t n_listed = a.known_pairs != nullptr ? a.known_cnt[b] : 0;
+    const int32_t n_claims = LISTS ? a.claim_cnt[b * LG_CLAIM_CNT_STRIDE] : 0;
     const bool listed = a.known_pairs != nullptr && n_listed <= a.known_cap;
     const int32_t n_scan = listed ? n_seed : n_known;
-    const LG_G unsigned long long* klist = a.known_pairs + (int64_t)b * a.known_cap;
-    // Nothing below depends on the segment table: the first LG_DEDUP_BATCH known ids / list entries of the thread are loaded
-    // now (the usual bucket has no more) and the table is cleared now, while the segment table is being built -- the
-    // workgroup's life is a chain of dependent round trips, these two leave it
-    int32_t kid[LG_DEDUP_BATCH];
-    unsigned long long kl[LG_DEDUP_BATCH];
+    {
+        // Nothing below depends on the segment table: the first LG_DEDUP_BATCH known ids / list entries of the thread are loaded
+        // now (the usual bucket has no more), while the segment table is being built.  (LISTS: what was not requested above.)
 #pragma unroll
-    for (int u = 0; u < LG_DEDUP_BATCH; u++) {
-        const int32_t i = u * LG_DEDUP_THREADS + tid;
-        kid[u] = i < n_scan ? a.sampled_ids[i] : -1;
-        kl[u] = (listed && i < n_listed) ? klist[i] : ~0ull;
+        for (int u = LISTS ? LG_DEDUP_SPEC_KNOWN : 0; u < LG_DEDUP_BATCH; u++) {
+            const int32_t i = u * LG_DEDUP_THREADS + tid;
+            kid[u] = i < n_scan ? a.sampled_ids[i] : -1;
+            kl[u] = (listed && i < n_listed) ? klist[i] : ~0ull;
+        }
     }
+#if !defined(LG_DEDUP_EXP) || LG_DEDUP_EXP != 4       // (4: timing-only build of what a workgroup reads, without the table's clearing)
     for (int32_t i = tid; i < LG_LDS_TABLE; i += LG_DEDUP_THREADS) s_tab[i] = ~0ull;
+#endif
     if (tid == 0) s_full = 0;
     bool cleared = true;
 
-    // the bucket's segments, one per partition tile: exclusive prefix of their lengths
-    if (tid == 0) s_total = 0;
-    for (int32_t t = tid; t < nparts; t += LG_DEDUP_THREADS) {
-        const int32_t off = roff[(int64_t)t * (NB + 1)];
-        s_pref[t + 1] = roff[(int64_t)t * (NB + 1) + 1] - off;
-        s_seg[t] = off;
+    int32_t total;
+    if (!LISTS) {
+        // the bucket's segments, one per partition tile: exclusive prefix of their lengths
+        if (tid == 0) s_total = 0;
+        for (int32_t t = tid; t < nparts; t += LG_DEDUP_THREADS) {
+            const int32_t off = roff[(int64_t)t * (NB + 1)];
+            s_pref[t + 1] = roff[(int64_t)t * (NB + 1) + 1] - off;
+            s_seg[t] = off;
+        }
+        __syncthreads();
+        LG_STAMP(1);
+        if (tid < 64) {                                    // <= 513 entries: wave 0 scans them, a few consecutive entries per lane
+            const int32_t per = (nparts + 63) / 64;
+            const int32_t lo = min(tid * per, nparts), hi = min(lo + per, nparts);
+            int32_t sum = 0;
+            for (int32_t t = lo; t < hi; t++) sum += s_pref[t + 1];
+            int32_t inc = sum;
+            for (int d = 1; d < 64; d <<= 1) { const int32_t o = __shfl_up(inc, d); if (tid >= d) inc += o; }
+            int32_t acc = inc - sum;
+            for (int32_t t = lo; t < hi; t++) { acc += s_pref[t + 1]; s_pref[t + 1] = acc; }
+            if (tid == 0) s_pref[0] = 0;
+            if (tid == 63) s_total = inc;
+        }
+        __syncthreads();
+        LG_STAMP(2);
+        total = s_total;
+    } else {
+        __syncthreads();                                   // the cleared table
+        LG_STAMP(1);
+        LG_STAMP(2);
+        total = n_claims;                                  // (the count of the bucket's claims even when the list could not take them all)
+#pragma unroll
+        for (int u = 0; u < LG_DEDUP_CLAIMS; u++)
+            if (u * LG_DEDUP_THREADS + tid >= total) rp[u] = ~0ull;
+#pragma unroll
+        for (int u = 0; u < LG_DEDUP_SPEC_KNOWN; u++) {
+            const int32_t i = u * LG_DEDUP_THREADS + tid;
+            if (i >= n_scan) kid[u] = -1;
+            if (!listed || i >= n_listed) kl[u] = ~0ull;
+        }
+#if defined(LG_DEDUP_EXP) && (LG_DEDUP_EXP == 1 || LG_DEDUP_EXP == 4)       // timing-only build: everything a workgroup reads, none of its table work
+        {
+            unsigned long long x = 0;
+            for (int u = 0; u < LG_DEDUP_CLAIMS; u++) x ^= rp[u];
+            for (int u = 0; u < LG_DEDUP_BATCH; u++) x ^= kl[u] ^ (unsigned long long)kid[u];
+            if (x == 0x1234567ull) a.slot_pos[0] = 1;
+            if (tid == 0) a.claim_cnt[b * LG_CLAIM_CNT_STRIDE] = 0;
+            return;
+        }
+#endif
+#if defined(LG_DEDUP_EXP) && LG_DEDUP_EXP == 2       // timing-only build: the table work on made-up claims of the right count, no memory reads of claims
+        for (int u = 0; u < LG_DEDUP_CLAIMS; u++) {
+            const uint32_t k = u * LG_DEDUP_THREADS + tid;
+            rp[u] = (int32_t)k < total ? (((unsigned long long)((k * 2654435761u + b * 40503u) & 0x3FFFFFFFu)) << 32) | k : ~0ull;
+        }
+#endif
     }
-    __syncthreads();
-    if (tid < 64) {                                    // <= 513 entries: wave 0 scans them, a few consecutive entries per lane
-        const int32_t per = (nparts + 63) / 64;
-        const int32_t lo = min(tid * per, nparts), hi = min(lo + per, nparts);
-        int32_t sum = 0;
-        for (int32_t t = lo; t < hi; t++) sum += s_pref[t + 1];
-        int32_t inc = sum;
-        for (int d = 1; d < 64; d <<= 1) { const int32_t o = __shfl_up(inc, d); if (tid >= d) inc += o; }
-        int32_t acc = inc - sum;
-        for (int32_t t = lo; t < hi; t++) { acc += s_pref[t + 1]; s_pref[t + 1] = acc; }
-        if (tid == 0) s_pref[0] = 0;
-        if (tid == 63) s_total = inc;
-    }
-    __syncthreads();
-    const int32_t total = s_total;
     // passes: distinct vertices <= known + claims; keep the expected load of a pass at or below LG_LDS_FILL_16THS / 16 of the
     // table.  The bucket's share of the scanned ids is ESTIMATED (an even spread + a quarter; counting it would cost every
     // workgroup one more round trip to memory), and the hash is assumed to spread the bucket evenly over its sub-buckets: when
@@ -741,19 +826,55 @@ void dedup_lds_kernel(HopParams hp, const LanePtrs* __restrict__ lanes)
         }
         s_full = 1;
     };
+#if LG_DEDUP_FIXED
+    // the same outcome with words that never move: the first word of a vertex takes the first empty place of its probe sequence
+    // (compare-and-swap), every later word of that vertex meets it there and is merged by min.  Returns the place.
+    auto insert_at = [&](unsigned long long w, uint32_t h) -> uint32_t {
+        uint32_t p = lds_slot_of(h);
+        for (int it = 0; it < LG_LDS_TABLE; it++) {
+            unsigned long long seen = ~0ull;
+            if (__hip_atomic_compare_exchange_strong(&s_tab[p], &seen, w, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP))
+                return p;
+            if ((uint32_t)(seen >> 32) == (uint32_t)(w >> 32)) {
+                if (w < seen) __hip_atomic_fetch_min(&s_tab[p], w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                return p;
+            }
+            p = (p + 1) & (LG_LDS_TABLE - 1);
+        }
+        s_full = 1;
+        return 0;
+    };
+#endif
 
-    // a bucket of at most LG_DEDUP_BATCH claims per thread (the usual case) keeps them in registers: one trip to memory for both
-    // sweeps of every pass
-    const bool resident = total <= LG_DEDUP_BATCH * LG_DEDUP_THREADS;
-    unsigned long long rp[LG_DEDUP_BATCH];
-    auto fetch = [&](int32_t k0, unsigned long long (&pr)[LG_DEDUP_BATCH]) {
+    // A bucket of at most LG_DEDUP_CLAIMS claims per thread (the usual case) keeps them in registers: one trip to memory for both
+    // sweeps of every pass.  A larger one is read again, sweep by sweep; and a LISTS bucket whose list could not take all its
+    // claims (its count says so) reads the hop's slots instead and keeps what hashes into this bucket.
+    const bool from_slots = LISTS && total > a.claim_cap;
+    const bool resident = !from_slots && total <= LG_DEDUP_CLAIMS * LG_DEDUP_THREADS;
+    const int32_t n_src = from_slots ? g.total : total;          // what a sweep of a bucket that is not resident walks over
+#if LG_DEDUP_FIXED
+    uint32_t place[LG_DEDUP_CLAIMS] = {};
+#endif
+    auto fetch = [&](int32_t k0, unsigned long long (&pr)[LG_DEDUP_CLAIMS]) {
 #pragma unroll
-        for (int u = 0; u < LG_DEDUP_BATCH; u++) {
+        for (int u = 0; u < LG_DEDUP_CLAIMS; u++) {
             const int32_t k = k0 + u * LG_DEDUP_THREADS + tid;
-            pr[u] = k < total ? a.claim_pairs[segment_of(k)] : ~0ull;
+            pr[u] = ~0ull;
+            if (k >= n_src) continue;
+            if (from_slots) {
+                int32_t d = a.slot_dst[k];
+                if (d < 0) continue;
+                if (a.loser_in_dst) d &= ~LG_LOSER_BIT;          // (an earlier pass may have marked the slot)
+                if ((lg_tab_hash(d) & (NB - 1)) == (uint32_t)b) pr[u] = ((unsigned long long)(uint32_t)d << 32) | (uint32_t)k;
+            } else if (LISTS) {
+                pr[u] = a.claim_pairs[lg_claim_at<NB>(b, k)];
+            } else {
+                pr[u] = a.claim_pairs[segment_of(k)];
+            }
         }
     };
-    if (resident) fetch(0, rp);
+    if (!LISTS && resident) fetch(0, rp);
+    LG_STAMP(3);
 
   for (;;) {
     const uint32_t pmask = (uint32_t)passes - 1u;
@@ -773,7 +894,11 @@ void dedup_lds_kernel(HopParams hp, const LanePtrs* __restrict__ lanes)
                 if (id < 0) continue;
                 const uint32_t h = lg_tab_hash(id);
                 if ((h & (NB - 1)) != (uint32_t)b || ((h >> BB) & pmask) != pass) continue;
+#if LG_DEDUP_FIXED
+                insert_at(((unsigned long long)(uint32_t)id << 32) | (uint32_t)i, h);
+#else
                 insert(((unsigned long long)(uint32_t)id << 32) | (uint32_t)i, h);
+#endif
             }
         }
         if (listed)
@@ -785,48 +910,78 @@ void dedup_lds_kernel(HopParams hp, const LanePtrs* __restrict__ lanes)
                     if (pr == ~0ull) continue;
                     const uint32_t h = lg_tab_hash((int32_t)(pr >> 32));
                     if (((h >> BB) & pmask) != pass) continue;
+#if LG_DEDUP_FIXED
+                    insert_at(pr, h);
+#else
                     insert(pr, h);
+#endif
                 }
             }
-        for (int32_t k0 = 0; k0 < total; k0 += LG_DEDUP_BATCH * LG_DEDUP_THREADS) {
-            unsigned long long pr[LG_DEDUP_BATCH];
+        LG_STAMP(4);
+        for (int32_t k0 = 0; k0 < n_src; k0 += LG_DEDUP_CLAIMS * LG_DEDUP_THREADS) {
+            unsigned long long pr[LG_DEDUP_CLAIMS];
             if (resident) {
 #pragma unroll
-                for (int u = 0; u < LG_DEDUP_BATCH; u++) pr[u] = rp[u];
+                for (int u = 0; u < LG_DEDUP_CLAIMS; u++) pr[u] = rp[u];
             } else
                 fetch(k0, pr);
 #pragma unroll
-            for (int u = 0; u < LG_DEDUP_BATCH; u++) {
+            for (int u = 0; u < LG_DEDUP_CLAIMS; u++) {
                 if (pr[u] == ~0ull) continue;
                 const uint32_t h = lg_tab_hash((int32_t)(pr[u] >> 32));
                 if (((h >> BB) & pmask) != pass) continue;
+#if LG_DEDUP_FIXED
+                place[u] = insert_at((pr[u] & 0xFFFFFFFF00000000ull) | PENDING | (uint32_t)pr[u], h);
+#else
                 insert((pr[u] & 0xFFFFFFFF00000000ull) | PENDING | (uint32_t)pr[u], h);
+#endif
             }
         }
+        LG_STAMP(5);
         __syncthreads();
+        LG_STAMP(6);
 #ifndef LG_LDS_NO_RETRY
         if (s_full != 0) { overflow = true; break; }       // (uniform: read behind the barrier, reset behind the next one)
 #endif
-        for (int32_t k0 = 0; k0 < total; k0 += LG_DEDUP_BATCH * LG_DEDUP_THREADS) {
-            unsigned long long pr[LG_DEDUP_BATCH];
+        for (int32_t k0 = 0; k0 < n_src; k0 += LG_DEDUP_CLAIMS * LG_DEDUP_THREADS) {
+            unsigned long long pr[LG_DEDUP_CLAIMS];
             if (resident) {
 #pragma unroll
-                for (int u = 0; u < LG_DEDUP_BATCH; u++) pr[u] = rp[u];
+                for (int u = 0; u < LG_DEDUP_CLAIMS; u++) pr[u] = rp[u];
             } else
                 fetch(k0, pr);
+#if LG_DEDUP_FIXED
+            // resident claims know where their vertex's word is: the loads of a thread's claims are independent
+            unsigned long long tw[LG_DEDUP_CLAIMS];
+            if (resident) {
 #pragma unroll
-            for (int u = 0; u < LG_DEDUP_BATCH; u++) {
+                for (int u = 0; u < LG_DEDUP_CLAIMS; u++) tw[u] = s_tab[place[u] & (LG_LDS_TABLE - 1)];
+            }
+#endif
+#pragma unroll
+            for (int u = 0; u < LG_DEDUP_CLAIMS; u++) {
                 if (pr[u] == ~0ull) continue;
                 const uint32_t id = (uint32_t)(pr[u] >> 32), slot = (uint32_t)pr[u];
                 const uint32_t h = lg_tab_hash((int32_t)id);
                 if (((h >> BB) & pmask) != pass) continue;
-                uint32_t p = lds_slot_of(h);
                 uint32_t v = 0xFFFFFFFFu;
-                for (int it = 0; it < LG_LDS_TABLE; it++) {
-                    const unsigned long long w = s_tab[p];
-                    if ((uint32_t)(w >> 32) == id) { v = (uint32_t)w; break; }
-                    p = (p + 1) & (LG_LDS_TABLE - 1);
+#if LG_DEDUP_FIXED
+                if (resident) {
+                    v = (uint32_t)tw[u];
+                } else
+#endif
+                {
+                    uint32_t p = lds_slot_of(h);
+                    for (int it = 0; it < LG_LDS_TABLE; it++) {
+                        const unsigned long long w = s_tab[p];
+                        if ((uint32_t)(w >> 32) == id) { v = (uint32_t)w; break; }
+                        p = (p + 1) & (LG_LDS_TABLE - 1);
+                    }
                 }
+#if defined(LG_DEDUP_EXP) && LG_DEDUP_EXP == 2
+                if (v == 0x12345u) a.slot_pos[0] = 1;
+                continue;
+#endif
                 if (v != (PENDING | slot)) {          // not the lowest slot of a new vertex
                     if (a.loser_in_dst) a.slot_dst[slot] = (int32_t)(id | LG_LOSER_BIT);      // (vertex ids < 2^30: the mark rides in the id)
                     else a.slot_mark[slot] = a.mark_tag;
@@ -834,7 +989,9 @@ void dedup_lds_kernel(HopParams hp, const LanePtrs* __restrict__ lanes)
                 }
             }
         }
+        LG_STAMP(7);
         __syncthreads();
+        LG_STAMP(8);
     }
     if (!overflow) break;
     if (passes >= (1 << 14)) {                             // 2^14 sub-buckets of one bucket still too full: not a hash problem
@@ -844,8 +1001,32 @@ void dedup_lds_kernel(HopParams hp, const LanePtrs* __restrict__ lanes)
     passes <<= 1;
     __syncthreads();
   }
-    if (b == 0 && tid == 0) a.hop_scratch[HS_PAIR_CURSOR] = 0;      // the next hop's sampling starts a new pair array
+    if (LISTS) {
+        if (tid == 0) a.claim_cnt[b * LG_CLAIM_CNT_STRIDE] = 0;                               // the next hop's sampling starts an empty list
+    } else if (b == 0 && tid == 0) a.hop_scratch[HS_PAIR_CURSOR] = 0;    // the next hop's sampling starts a new pair array
+#ifdef LG_DEDUP_STAMPS
+    if (tid == 0) {
+        const int hop = min(max(a.op_id / 3, 0), 7);
+        for (int i = 1; i < 9; i++) atomicAdd(&g_dedup_stamps[hop][i], stamp_t[i] - stamp_t[0]);
+        atomicAdd(&g_dedup_stamps[hop][0], 1ull);
+        atomicAdd(&g_dedup_stamps[hop][9], (unsigned long long)total);
+        atomicAdd(&g_dedup_stamps[hop][10], (unsigned long long)passes);
+        atomicMin(&g_dedup_stamps[hop][11], stamp_t[0]);
+        atomicMax(&g_dedup_stamps[hop][12], stamp_t[8]);
+    }
+#endif
 }
+#ifdef LG_DEDUP_STAMPS
+extern "C" void legion_debug_dedup_stamps(unsigned long long* out, int reset)
+{
+    hipMemcpyFromSymbol(out, HIP_SYMBOL(g_dedup_stamps), sizeof(g_dedup_stamps));
+    if (reset) {
+        unsigned long long z[8][16] = {};
+        for (int h = 0; h < 8; h++) z[h][11] = ~0ull;
+        hipMemcpyToSymbol(HIP_SYMBOL(g_dedup_stamps), z, sizeof(z));
+    }
+}
+#endif
 
 // ------------------------------------------------------------------------------------------
 // K2: compaction in ONE pass over the hop's slots (rounds 1-2 took three: per-tile counts, a one-workgroup prefix with

@@ -194,6 +194,11 @@ enum HopScratch {
 // a value >= 0 or CACHEMISS_FLAG is what node_map[id] holds; LG_FS_UNKNOWN means "not carried: look it up"
 #define LG_FS_UNKNOWN (-3)
 #define LG_LOSER_BIT 0x40000000   // see HopParams::loser_in_dst
+#ifndef LG_CLAIM_CNT_STRIDE
+#define LG_CLAIM_CNT_STRIDE 32        // ints between the claim-list counts of two buckets: a line each (the 8 / 16 reservations of a super tile go to different lines)
+#endif
+#define LG_CLAIM_CHUNK_BITS 9
+#define LG_CLAIM_CHUNK (1 << LG_CLAIM_CHUNK_BITS)
 
 #define LG_TILE 256            // compaction tile == threads per workgroup in the sampler kernels
 #define LG_SLOTS_PER_LANE 4    // independent slots each lane keeps in flight
@@ -242,9 +247,18 @@ struct LanePtrs {
     uint32_t pos_table_mask;
     // lds form of the first-touch state (no per-vertex state at all, legion_core.h "LDS form"): the hop's claims,
     // partitioned by hash bucket inside the run of every 1024-slot super tile
-    unsigned long long* claim_pairs;   // [max_slots] (vertex << 32 | slot)
+    unsigned long long* claim_pairs;   // (vertex << 32 | slot): [max_slots], or [buckets][claim_cap] in the 8/16-bucket classes
     int32_t* run_off;                  // [super tiles][buckets + 1] where each bucket's claims of that super tile start in claim_pairs
-    int32_t lds_buckets;               // 8, 64 or 256 (0: not the lds form)
+    int32_t lds_buckets;               // 8, 16, 64 or 256 (0: not the lds form)
+    // 8/16-bucket classes: one list of claims per bucket (no segment table): the sampling kernel appends a super tile's claims of a
+    // bucket with one reservation on claim_cnt[bucket]; a count beyond claim_cap says the list is incomplete and the bucket's
+    // workgroup reads the hop's slots instead (kernels_sample.hip)
+    // The lists are interleaved in chunks of LG_CLAIM_CHUNK entries -- entry k of bucket b sits at lg_claim_at(b, k, buckets) --
+    // so that what a hop really uses (a fraction of the capacity) is one dense prefix of the array, as few pages as the segment form
+    // touches (measured: with one contiguous region per bucket, 16 x oversized, both kernels lost ~15 us per group to translation misses)
+    int32_t* claim_cnt;                // [buckets], zero between hops
+    int32_t claim_cap;                 // 0: segment form
+    int32_t ids_cap;                   // capacity of sampled_ids (what may be read before the live counters are known)
     // ... and the batch's vertices that later hops must recognise (every node but the seeds and the last hop's), one list
     // per bucket: scatter appends (vertex << 32 | position), the next hop's workgroup of that bucket reads only its list
     unsigned long long* known_pairs;   // [buckets][known_cap]
@@ -331,6 +345,8 @@ public:
     int32_t* hop_scratch = nullptr;    // [HS_WORDS]
     unsigned long long* claim_pairs = nullptr; // lds form: see LanePtrs
     int32_t* run_off = nullptr;
+    int32_t* claim_cnt = nullptr;
+    int32_t claim_cap = 0;
     int32_t lds_bucket_bits = 0;
     unsigned long long* known_pairs = nullptr;
     int32_t* known_cnt = nullptr;

@@ -463,6 +463,9 @@ LanePtrs MemoryPool::HostLane(int32_t pipe) const
     h.counter_mirror = counter_mirror_dev;
     h.claim_pairs = claim_pairs;
     h.run_off = run_off;
+    h.claim_cnt = claim_cnt;
+    h.claim_cap = claim_cap;
+    h.ids_cap = num_ids;
     h.lds_buckets = lds_form ? (1 << lds_bucket_bits) : 0;
     h.known_pairs = known_pairs;
     h.known_cnt = known_cnt;
@@ -511,6 +514,8 @@ void MemoryPool::Finalize()
     pos_table = nullptr;
     d_free_space(claim_pairs);
     d_free_space(run_off);
+    d_free_space(claim_cnt);
+    claim_cnt = nullptr;
     d_free_space(known_pairs);
     d_free_space(known_cnt);
     known_pairs = nullptr;
@@ -619,7 +624,6 @@ void lg_pool_alloc_private(MemoryPool* mp, int32_t dev_id, int32_t total_num_nod
         const int64_t slots = hop_num > 0 ? per : batch_size;
         const int64_t n_super = (slots + LG_SUPER - 1) / LG_SUPER + 1;
         mp->lds_form = true;
-        mp->claim_pairs = (unsigned long long*)d_alloc_space(slots * sizeof(unsigned long long));
         mp->lds_bucket_bits = slots <= LG_LDS_SLOTS_SMALL ? LG_LDS_BITS_SMALL : (slots <= LG_LDS_SLOTS_MEDIUM ? LG_LDS_BITS_MEDIUM : LG_LDS_BITS_LARGE);
         if (mp->lds_bucket_bits == LG_LDS_BITS_SMALL) {
             // The small class has 8 or 16 buckets per lane.  Slots say how large a hop CAN get, not how many of them hold an
@@ -632,6 +636,18 @@ void lg_pool_alloc_private(MemoryPool* mp, int32_t dev_id, int32_t total_num_nod
             if (tune.lds_small_buckets == 16 || (tune.lds_small_buckets != 8 && need / 8 > one_pass)) mp->lds_bucket_bits = LG_LDS_BITS_SMALL16;
         }
         const int64_t n_buckets = (int64_t)1 << mp->lds_bucket_bits;
+        if (mp->lds_bucket_bits == LG_LDS_BITS_SMALL || mp->lds_bucket_bits == LG_LDS_BITS_SMALL16) {
+            // one claim list per bucket, twice an even share each (a bucket that outgrows its list is served from the hop's
+            // slots instead, kernels_sample.hip)
+            mp->claim_cap = (int32_t)(2 * ((slots + n_buckets - 1) / n_buckets) + 256);
+            if (tune.lds_claim_cap > 0) mp->claim_cap = tune.lds_claim_cap;      // tests: force the fallback
+            const int64_t chunks = ((int64_t)mp->claim_cap + LG_CLAIM_CHUNK - 1) / LG_CLAIM_CHUNK;      // (interleaved by chunk: LanePtrs)
+            mp->claim_pairs = (unsigned long long*)d_alloc_space(n_buckets * chunks * LG_CLAIM_CHUNK * sizeof(unsigned long long));
+            mp->claim_cnt = (int32_t*)d_alloc_space(n_buckets * 32 * sizeof(int32_t));
+            HIP_CALL(hipMemset(mp->claim_cnt, 0, n_buckets * 32 * sizeof(int32_t)));
+        } else {
+            mp->claim_pairs = (unsigned long long*)d_alloc_space(slots * sizeof(unsigned long long));
+        }
         const int64_t n_parts = std::min<int64_t>(n_super, LG_LDS_MAX_PARTS) + 2;    // launch_random_sample keeps every hop within LG_LDS_MAX_PARTS
         mp->run_off = (int32_t*)d_alloc_space(n_parts * (n_buckets + 1) * sizeof(int32_t));
         // per-bucket lists of the nodes hops 1 .. H-1 add (later hops must recognise them): twice an even share each;
@@ -899,7 +915,8 @@ extern "C" int64_t legion_pool_state_bytes(const LegionMemoryPool* p_)
 {
     const MemoryPool* mp = reinterpret_cast<const MemoryPool*>(p_);
     if (!mp) return 0;
-    if (mp->lds_form) return (int64_t)mp->max_slots * 8 + ((int64_t)mp->known_cap << mp->lds_bucket_bits) * 8;   // one hop's claim pairs + the known lists
+    if (mp->lds_form)      // one hop's claim pairs + the known lists
+        return (mp->claim_cap > 0 ? ((((int64_t)mp->claim_cap + LG_CLAIM_CHUNK - 1) / LG_CLAIM_CHUNK * LG_CLAIM_CHUNK) << mp->lds_bucket_bits) : (int64_t)mp->max_slots) * 8 + ((int64_t)mp->known_cap << mp->lds_bucket_bits) * 8;
     return mp->pos_table ? ((int64_t)mp->pos_table_mask + 1) * 8 : (int64_t)mp->total_num_nodes * 4;
 }
 

@@ -469,6 +469,30 @@ def test_lds_dedup_known_lists(hip, monkeypatch, known_cap):
     gpu.close(); cpu.close()
 
 
+@pytest.mark.parametrize("buckets", ["8", "16"])
+@pytest.mark.parametrize("claim_cap", ["1", "40", "700"], ids=["no-room", "some-buckets-overflow", "passes"])
+def test_lds_dedup_claim_lists_overflow(hip, monkeypatch, claim_cap, buckets):
+    """LDS form, 8/16-bucket classes: the sampling kernel appends a hop's claims to one list per hash bucket.  A list that
+    cannot take all of its bucket's claims says so by its count, and that bucket's workgroup reads the hop's slots instead:
+    forced for every bucket (capacity 1), for some of them (capacity 40 against ~45 claims per bucket of hop 2), and -- on a
+    batch whose buckets need several passes over the table -- with the slots walked once per sweep and pass."""
+    monkeypatch.setenv("LEGION_DEDUP", "lds")
+    monkeypatch.setenv("LEGION_LDS_CLAIM_CAP", claim_cap)
+    monkeypatch.setenv("LEGION_LDS_SMALL_BUCKETS", buckets)
+    if claim_cap == "700":
+        wl = Workload(scale=16, edge_factor=16, dim=4, n_seeds=5000)
+        fanout, batch, n_it = [12, 12], 1500, 2                # ~150 k claims in hop 2: ~19 k per bucket of 8 -> 4 passes
+    else:
+        wl = Workload(scale=12, edge_factor=8, dim=4, n_seeds=600)
+        fanout, batch, n_it = [4, 3, 3], 48, 6
+    gpu, cpu = GpuSide(wl, batch, fanout), CpuSide(wl, batch, fanout)
+    assert gpu.pools[0].dedup_form() == "lds"
+    for it in range(n_it):
+        compare_batches(gpu.run(0, it, 0), cpu.run(0, it, 0), f"claim lists (cap {claim_cap}, {buckets} buckets) batch {it}: ")
+    assert gpu.pools[0].error() == 0
+    gpu.close(); cpu.close()
+
+
 @pytest.mark.parametrize("part_wg", [None, "1", "100000000"], ids=["default-tiles", "largest-tiles", "smallest-tiles"])
 @pytest.mark.parametrize("batch,fanout", [(6000, [10, 10]), (5000, [5, 5, 5]), (6000, [10, 10, 8]), (8000, [13, 13, 13])],
                          ids=["b6000-10x10-64buckets", "b5000-5x5x5-64buckets", "b6000-10x10x8-256buckets", "b8000-13x13x13-17Mslots"])
