@@ -650,18 +650,6 @@ __global__ __launch_bounds__(LG_TILE) void place_kernel(HopParams hp, const Lane
 #ifndef LG_DEDUP_CLAIMS
 #define LG_DEDUP_CLAIMS 5           // claims a thread keeps in registers (a bucket of at most LG_DEDUP_CLAIMS * LG_DEDUP_THREADS is "resident")
 #endif
-#ifndef LG_DEDUP_SPEC_KNOWN
-#define LG_DEDUP_SPEC_KNOWN 1      // LISTS: how many of a thread's LG_DEDUP_BATCH seeds / known-list entries are requested before the live lengths are known
-#endif
-#ifndef LG_DEDUP_FIXED
-#define LG_DEDUP_FIXED 0            // 1: a vertex's table word never moves (compare-and-swap on empty + min on the match); a resident claim reads it back in one LDS load
-#endif
-#ifdef LG_DEDUP_STAMPS                // tuning builds only (tools/lds_tuning): where a workgroup's time goes, summed over workgroups per hop
-__device__ unsigned long long g_dedup_stamps[8][16];
-#define LG_STAMP(i) do { stamp_t[i] = __builtin_amdgcn_s_memrealtime(); } while (0)      // (wave-uniform: lives in SGPRs)
-#else
-#define LG_STAMP(i) do { } while (0)
-#endif
 #ifndef LG_DEDUP_THREADS
 #define LG_DEDUP_THREADS 1024
 #endif
@@ -669,14 +657,217 @@ __device__ __forceinline__ uint32_t lds_slot_of(uint32_t h) { return (h * 0x9E37
 
 // (SGPR cap: two of these 16-wave workgroups share a CU only while the kernel stays within 80 SGPRs -- 82..96 admit 28 waves
 // per CU, i.e. ONE workgroup, and the kernel takes 150 us instead of 94 at hop 2 of a 256-lane group; measured, round 3)
+//
+// A workgroup barrier that orders LDS traffic only.  __syncthreads() also waits for every global load AND STORE the wave has in
+// flight (its fence covers global memory): loads requested for later use would be waited for at the next barrier, and a tile's
+// stores would have to land before the next tile's loads could be addressed.
+__device__ __forceinline__ void lds_barrier()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
+// ---- 8- and 16-bucket classes: one claim list per bucket -----------------------------------------------------------------
+// A workgroup's life used to be a chain of dependent round trips to memory (lane pointers -> live counters -> segment table ->
+// claims); with one list per bucket, what a thread reads first -- its claims of the list, its seed, its entry of the known list --
+// sits at addresses that do not depend on the live counters, so these loads leave TOGETHER with the loads of the counters and
+// list lengths (entries past the live lengths are stale and are masked when they are used).  A workgroup can take UNITS buckets
+// of its lane in turn, the loads of the next bucket requested before the table work of the current one (the barriers order LDS
+// only -- lds_barrier -- so they do not wait for those loads); the default is ONE bucket per workgroup:
+// Measured on the 512-lane group of the headline workload (tools/lds_tuning/dedup_ab.sh, timing-only builds): launching 4096
+// workgroups of 16 waves costs 54 us before any of them does anything, with all reads requested up front and one barrier it is
+// 108 us, the table work brings it to ~190.  Fewer, longer-lived workgroups remove launch cost and hide the loads -- and lose
+// under the weave, where the heavy stream's kernel gets its share of the machine by asking for slots again and again while
+// the low-priority stream's workgroups take every slot a long-lived workgroup cannot ask for again: two buckets per workgroup
+// 209 us against 192; a persistent launch of 512 workgroups over all units (fixed stride or by ticket) 161 us ALONE but
+// 240-305 us under the weave.  Also rejected: a table whose words never move (compare-and-swap + min, one LDS load per
+// look-up): +25 us; 512-thread workgroups (8 or 16 buckets): +0..40 us.
+#ifndef LG_DEDUP_UNITS
+#define LG_DEDUP_UNITS 1
+#endif
+template <int BB, int UNITS>
+__global__ __launch_bounds__(LG_DEDUP_THREADS) __attribute__((amdgpu_num_sgpr(80)))
+void dedup_lists_kernel(HopParams hp, const LanePtrs* __restrict__ lanes)
+{
+    constexpr int NB = 1 << BB;
+    constexpr int STEP = NB / UNITS;
+    constexpr uint32_t PENDING = 0x80000000u;
+    static_assert(NB % UNITS == 0, "buckets per workgroup");
+    __shared__ unsigned long long s_tab[LG_LDS_TABLE];
+    __shared__ int32_t s_full;
+    const int32_t tid = threadIdx.x;
+    const SampleArgs a = lane_args(hp, lanes);
+
+    struct Req {                                   // what a unit (bucket) reads first
+        unsigned long long rp[LG_DEDUP_CLAIMS];    // the thread's claims u * THREADS + tid of the bucket's list
+        unsigned long long kl0;                    // the bucket's known list [tid]
+        int32_t n_listed, n_claims;
+    };
+    auto request = [&](int32_t b, Req& q) {
+#pragma unroll
+        for (int u = 0; u < LG_DEDUP_CLAIMS; u++) {
+            const int32_t k = u * LG_DEDUP_THREADS + tid;
+            q.rp[u] = k < a.claim_cap ? a.claim_pairs[lg_claim_at<NB>(b, k)] : ~0ull;
+        }
+        q.kl0 = (a.known_pairs != nullptr && tid < a.known_cap) ? a.known_pairs[(int64_t)b * a.known_cap + tid] : ~0ull;
+        q.n_listed = a.known_pairs != nullptr ? a.known_cnt[b] : 0;
+        q.n_claims = a.claim_cnt[b * LG_CLAIM_CNT_STRIDE];
+    };
+    auto insert = [&](unsigned long long w, uint32_t h) {
+        uint32_t p = lds_slot_of(h);
+        for (int it = 0; it < LG_LDS_TABLE; it++) {
+            const unsigned long long old = __hip_atomic_fetch_min(&s_tab[p], w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (old == ~0ull || (uint32_t)(old >> 32) == (uint32_t)(w >> 32)) return;    // placed, or merged with the same vertex
+            if (old > w) w = old;                                                          // displaced a larger word: carry it on
+            p = (p + 1) & (LG_LDS_TABLE - 1);
+        }
+        s_full = 1;
+    };
+
+    Req nxt;
+    request((int32_t)blockIdx.x, nxt);
+    // the lane's part (the same for every bucket): the first seed of the thread and the node counts before this hop
+    const int32_t kid0 = tid < a.ids_cap ? a.sampled_ids[tid] : -1;
+    const int32_t n_known = a.node_counter[0] + a.node_counter[1];
+    const int32_t n_seed = min(max(a.node_counter[INTRABATCH_CON * 3], 0), n_known);
+
+#pragma unroll
+    for (int j = 0; j < UNITS; j++) {
+        const int32_t b = (int32_t)blockIdx.x + j * STEP;
+        Req cur = nxt;
+        if (j + 1 < UNITS) request(b + STEP, nxt);
+
+        // the batch's vertices before this hop are the seeds (sampled_ids) and the nodes earlier hops added (the bucket's known
+        // list -- or sampled_ids too when there is no list or it outgrew its capacity)
+        const int32_t n_listed = cur.n_listed;
+        const bool listed = a.known_pairs != nullptr && n_listed <= a.known_cap;
+        const int32_t n_scan = listed ? n_seed : n_known;
+        const int32_t total = cur.n_claims;            // (the count of the bucket's claims even when the list could not take them all)
+        const LG_G unsigned long long* klist = a.known_pairs + (int64_t)b * a.known_cap;
+#pragma unroll
+        for (int u = 0; u < LG_DEDUP_CLAIMS; u++)
+            if (u * LG_DEDUP_THREADS + tid >= total) cur.rp[u] = ~0ull;
+        if (!listed || tid >= n_listed) cur.kl0 = ~0ull;
+        // passes over sub-buckets: see dedup_lds_kernel
+        const int32_t known_est = (listed ? n_listed : 0) + n_scan / NB + n_scan / (4 * NB) + 32;
+        int32_t passes = 1;
+        while ((int64_t)known_est + total > (int64_t)passes * (LG_LDS_TABLE / 16 * LG_LDS_FILL_16THS)) passes <<= 1;
+        // A bucket of at most LG_DEDUP_CLAIMS claims per thread (the usual case) works from the registers.  A larger one is read
+        // again, sweep by sweep; and a bucket whose list could not take all its claims (its count says so) reads the hop's slots
+        // instead and keeps what hashes into this bucket.
+        const bool from_slots = total > a.claim_cap;
+        const bool resident = !from_slots && total <= LG_DEDUP_CLAIMS * LG_DEDUP_THREADS;
+        const int32_t n_src = from_slots ? hop_geometry(a).total : total;
+        auto fetch = [&](int32_t k0, unsigned long long (&pr)[LG_DEDUP_CLAIMS]) {
+#pragma unroll
+            for (int u = 0; u < LG_DEDUP_CLAIMS; u++) {
+                const int32_t k = k0 + u * LG_DEDUP_THREADS + tid;
+                pr[u] = ~0ull;
+                if (k >= n_src) continue;
+                if (from_slots) {
+                    int32_t d = a.slot_dst[k];
+                    if (d < 0) continue;
+                    if (a.loser_in_dst) d &= ~LG_LOSER_BIT;          // (an earlier pass may have marked the slot)
+                    if ((lg_tab_hash(d) & (NB - 1)) == (uint32_t)b) pr[u] = ((unsigned long long)(uint32_t)d << 32) | (uint32_t)k;
+                } else {
+                    pr[u] = a.claim_pairs[lg_claim_at<NB>(b, k)];
+                }
+            }
+        };
+
+        for (;;) {
+            const uint32_t pmask = (uint32_t)passes - 1u;
+            bool overflow = false;
+            for (uint32_t pass = 0; pass <= pmask; pass++) {
+                for (int32_t i = tid; i < LG_LDS_TABLE; i += LG_DEDUP_THREADS) s_tab[i] = ~0ull;
+                if (tid == 0) s_full = 0;
+                lds_barrier();
+                for (int32_t i0 = 0; i0 < n_scan; i0 += LG_DEDUP_THREADS) {
+                    const int32_t i = i0 + tid;
+                    const int32_t id = i >= n_scan ? -1 : (i0 == 0 ? kid0 : a.sampled_ids[i]);      // (the first one came early)
+                    if (id < 0) continue;
+                    const uint32_t h = lg_tab_hash(id);
+                    if ((h & (NB - 1)) != (uint32_t)b || ((h >> BB) & pmask) != pass) continue;
+                    insert(((unsigned long long)(uint32_t)id << 32) | (uint32_t)i, h);
+                }
+                if (listed)
+                    for (int32_t i0 = 0; i0 < n_listed; i0 += LG_DEDUP_THREADS) {
+                        const int32_t i = i0 + tid;
+                        const unsigned long long pr = i0 == 0 ? cur.kl0 : (i < n_listed ? klist[i] : ~0ull);
+                        if (pr == ~0ull) continue;
+                        const uint32_t h = lg_tab_hash((int32_t)(pr >> 32));
+                        if (((h >> BB) & pmask) != pass) continue;
+                        insert(pr, h);
+                    }
+                for (int32_t k0 = 0; k0 < n_src; k0 += LG_DEDUP_CLAIMS * LG_DEDUP_THREADS) {
+                    unsigned long long pr[LG_DEDUP_CLAIMS];
+                    if (resident) {
+#pragma unroll
+                        for (int u = 0; u < LG_DEDUP_CLAIMS; u++) pr[u] = cur.rp[u];
+                    } else
+                        fetch(k0, pr);
+#pragma unroll
+                    for (int u = 0; u < LG_DEDUP_CLAIMS; u++) {
+                        if (pr[u] == ~0ull) continue;
+                        const uint32_t h = lg_tab_hash((int32_t)(pr[u] >> 32));
+                        if (((h >> BB) & pmask) != pass) continue;
+                        insert((pr[u] & 0xFFFFFFFF00000000ull) | PENDING | (uint32_t)pr[u], h);
+                    }
+                }
+                lds_barrier();
+#ifndef LG_LDS_NO_RETRY
+                if (s_full != 0) { overflow = true; break; }       // (uniform: read behind the barrier, reset behind the next one)
+#endif
+                for (int32_t k0 = 0; k0 < n_src; k0 += LG_DEDUP_CLAIMS * LG_DEDUP_THREADS) {
+                    unsigned long long pr[LG_DEDUP_CLAIMS];
+                    if (resident) {
+#pragma unroll
+                        for (int u = 0; u < LG_DEDUP_CLAIMS; u++) pr[u] = cur.rp[u];
+                    } else
+                        fetch(k0, pr);
+#pragma unroll
+                    for (int u = 0; u < LG_DEDUP_CLAIMS; u++) {
+                        if (pr[u] == ~0ull) continue;
+                        const uint32_t id = (uint32_t)(pr[u] >> 32), slot = (uint32_t)pr[u];
+                        const uint32_t h = lg_tab_hash((int32_t)id);
+                        if (((h >> BB) & pmask) != pass) continue;
+                        uint32_t p = lds_slot_of(h);
+                        uint32_t v = 0xFFFFFFFFu;
+                        for (int it = 0; it < LG_LDS_TABLE; it++) {
+                            const unsigned long long w = s_tab[p];
+                            if ((uint32_t)(w >> 32) == id) { v = (uint32_t)w; break; }
+                            p = (p + 1) & (LG_LDS_TABLE - 1);
+                        }
+                        if (v != (PENDING | slot)) {          // not the lowest slot of a new vertex
+                            if (a.loser_in_dst) a.slot_dst[slot] = (int32_t)(id | LG_LOSER_BIT);      // (vertex ids < 2^30: the mark rides in the id)
+                            else a.slot_mark[slot] = a.mark_tag;
+                            a.slot_pos[slot] = (v & PENDING) ? -2 - (int32_t)(v & ~PENDING) : (int32_t)v;
+                        }
+                    }
+                }
+                lds_barrier();                                 // (the next pass / bucket clears the table)
+            }
+            if (!overflow) break;
+            if (passes >= (1 << 14)) {                             // 2^14 sub-buckets of one bucket still too full: not a hash problem
+                if (tid == 0) raise_error(a.hop_scratch, a.err_flag, LG_ERR_TABLE_FULL);
+                break;
+            }
+            passes <<= 1;
+        }
+        if (tid == 0) a.claim_cnt[b * LG_CLAIM_CNT_STRIDE] = 0;      // the next hop's sampling starts an empty list
+    }
+}
+
+// ---- 64- and 256-bucket classes: the claims of a bucket arrive as one segment per partition tile of the sampling kernel
+//      (run_off); a workgroup addresses claim k of its bucket through the prefix of the segment lengths ------------------------
 template <int BB>
 __global__ __launch_bounds__(LG_DEDUP_THREADS) __attribute__((amdgpu_num_sgpr(80)))
 void dedup_lds_kernel(HopParams hp, const LanePtrs* __restrict__ lanes)
 {
     constexpr int NB = 1 << BB;
-    constexpr bool LISTS = (BB == LG_LDS_BITS_SMALL || BB == LG_LDS_BITS_SMALL16);      // one claim list per bucket (no segment table)
-    const int32_t K = hp.lds_k;                           // super tiles per partition tile (1 in the 8-bucket class)
-    constexpr int MAX_PARTS = LISTS ? 1 : LG_LDS_MAX_PARTS + 2;       // partition tiles of a hop (sample_kernel's K super tiles each)
+    const int32_t K = hp.lds_k;                           // super tiles per partition tile
+    constexpr int MAX_PARTS = LG_LDS_MAX_PARTS + 2;       // partition tiles of a hop (sample_kernel's K super tiles each)
     const SampleArgs a = lane_args(hp, lanes);
     __shared__ unsigned long long s_tab[LG_LDS_TABLE];
     __shared__ int32_t s_pref[MAX_PARTS];                  // exclusive prefix of the bucket's segment lengths
@@ -685,123 +876,54 @@ void dedup_lds_kernel(HopParams hp, const LanePtrs* __restrict__ lanes)
     const HopGeom g = hop_geometry(a);
     const int32_t nparts = (g.nsuper + K - 1) / K;
     const int32_t tid = threadIdx.x, b = blockIdx.x;
-#ifdef LG_DEDUP_STAMPS
-    unsigned long long stamp_t[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-#endif
-    LG_STAMP(0);
+    const int32_t n_known = a.node_counter[0] + a.node_counter[1];          // nodes of the batch before this hop
     constexpr uint32_t PENDING = 0x80000000u;
     const LG_G int32_t* roff = a.run_off + b;              // roff[t * (NB + 1)]: start of this bucket's segment of partition tile t
-    const LG_G unsigned long long* klist = a.known_pairs + (int64_t)b * a.known_cap;
-
-    // The workgroup's life is a chain of dependent round trips to memory; LISTS cuts it to the shortest there is.  What a thread
-    // reads first -- its claims of the bucket's list, its seeds, its entries of the known list -- sits at addresses that do not
-    // depend on the live counters, so these loads leave TOGETHER with the loads of the counters and list lengths; entries past
-    // the live lengths are stale and are masked once the lengths have arrived.
-    unsigned long long rp[LG_DEDUP_CLAIMS];
-    int32_t kid[LG_DEDUP_BATCH];
-    unsigned long long kl[LG_DEDUP_BATCH];
-#if defined(LG_DEDUP_EXP) && LG_DEDUP_EXP == 3       // timing-only build: the launch alone
-    if (LISTS) { if (tid == 0) a.claim_cnt[b * LG_CLAIM_CNT_STRIDE] = 0; return; }
-#endif
-    if (LISTS) {
-#pragma unroll
-        for (int u = 0; u < LG_DEDUP_CLAIMS; u++) {
-            const int32_t k = u * LG_DEDUP_THREADS + tid;
-#if defined(LG_DEDUP_EXP) && LG_DEDUP_EXP == 2
-            rp[u] = ~0ull;
-#else
-            rp[u] = k < a.claim_cap ? a.claim_pairs[lg_claim_at<NB>(b, k)] : ~0ull;
-#endif
-        }
-#pragma unroll
-        for (int u = 0; u < LG_DEDUP_SPEC_KNOWN; u++) {
-            const int32_t i = u * LG_DEDUP_THREADS + tid;
-            kid[u] = i < a.ids_cap ? a.sampled_ids[i] : -1;
-            kl[u] = (a.known_pairs != nullptr && i < a.known_cap) ? klist[i] : ~0ull;
-        }
-    }
 
     // the batch's vertices before this hop: the seeds are read from sampled_ids, the nodes earlier hops added from the
     // bucket's list (list_known_kernel) -- or from sampled_ids too when there is no list or it outgrew its capacity
-    const int32_t n_known = a.node_counter[0] + a.node_counter[1];          // nodes of the batch before this hop
     const int32_t n_seed = min(max(a.node_counter[INTRABATCH_CON * 3], 0), n_known);
     const int32_t n_listed = a.known_pairs != nullptr ? a.known_cnt[b] : 0;
-    const int32_t n_claims = LISTS ? a.claim_cnt[b * LG_CLAIM_CNT_STRIDE] : 0;
     const bool listed = a.known_pairs != nullptr && n_listed <= a.known_cap;
     const int32_t n_scan = listed ? n_seed : n_known;
-    {
-        // Nothing below depends on the segment table: the first LG_DEDUP_BATCH known ids / list entries of the thread are loaded
-        // now (the usual bucket has no more), while the segment table is being built.  (LISTS: what was not requested above.)
+    const LG_G unsigned long long* klist = a.known_pairs + (int64_t)b * a.known_cap;
+    // Nothing below depends on the segment table: the first LG_DEDUP_BATCH known ids / list entries of the thread are loaded
+    // now (the usual bucket has no more) and the table is cleared now, while the segment table is being built -- the
+    // workgroup's life is a chain of dependent round trips, these two leave it
+    int32_t kid[LG_DEDUP_BATCH];
+    unsigned long long kl[LG_DEDUP_BATCH];
 #pragma unroll
-        for (int u = LISTS ? LG_DEDUP_SPEC_KNOWN : 0; u < LG_DEDUP_BATCH; u++) {
-            const int32_t i = u * LG_DEDUP_THREADS + tid;
-            kid[u] = i < n_scan ? a.sampled_ids[i] : -1;
-            kl[u] = (listed && i < n_listed) ? klist[i] : ~0ull;
-        }
+    for (int u = 0; u < LG_DEDUP_BATCH; u++) {
+        const int32_t i = u * LG_DEDUP_THREADS + tid;
+        kid[u] = i < n_scan ? a.sampled_ids[i] : -1;
+        kl[u] = (listed && i < n_listed) ? klist[i] : ~0ull;
     }
-#if !defined(LG_DEDUP_EXP) || LG_DEDUP_EXP != 4       // (4: timing-only build of what a workgroup reads, without the table's clearing)
     for (int32_t i = tid; i < LG_LDS_TABLE; i += LG_DEDUP_THREADS) s_tab[i] = ~0ull;
-#endif
     if (tid == 0) s_full = 0;
     bool cleared = true;
 
-    int32_t total;
-    if (!LISTS) {
-        // the bucket's segments, one per partition tile: exclusive prefix of their lengths
-        if (tid == 0) s_total = 0;
-        for (int32_t t = tid; t < nparts; t += LG_DEDUP_THREADS) {
-            const int32_t off = roff[(int64_t)t * (NB + 1)];
-            s_pref[t + 1] = roff[(int64_t)t * (NB + 1) + 1] - off;
-            s_seg[t] = off;
-        }
-        __syncthreads();
-        LG_STAMP(1);
-        if (tid < 64) {                                    // <= 513 entries: wave 0 scans them, a few consecutive entries per lane
-            const int32_t per = (nparts + 63) / 64;
-            const int32_t lo = min(tid * per, nparts), hi = min(lo + per, nparts);
-            int32_t sum = 0;
-            for (int32_t t = lo; t < hi; t++) sum += s_pref[t + 1];
-            int32_t inc = sum;
-            for (int d = 1; d < 64; d <<= 1) { const int32_t o = __shfl_up(inc, d); if (tid >= d) inc += o; }
-            int32_t acc = inc - sum;
-            for (int32_t t = lo; t < hi; t++) { acc += s_pref[t + 1]; s_pref[t + 1] = acc; }
-            if (tid == 0) s_pref[0] = 0;
-            if (tid == 63) s_total = inc;
-        }
-        __syncthreads();
-        LG_STAMP(2);
-        total = s_total;
-    } else {
-        __syncthreads();                                   // the cleared table
-        LG_STAMP(1);
-        LG_STAMP(2);
-        total = n_claims;                                  // (the count of the bucket's claims even when the list could not take them all)
-#pragma unroll
-        for (int u = 0; u < LG_DEDUP_CLAIMS; u++)
-            if (u * LG_DEDUP_THREADS + tid >= total) rp[u] = ~0ull;
-#pragma unroll
-        for (int u = 0; u < LG_DEDUP_SPEC_KNOWN; u++) {
-            const int32_t i = u * LG_DEDUP_THREADS + tid;
-            if (i >= n_scan) kid[u] = -1;
-            if (!listed || i >= n_listed) kl[u] = ~0ull;
-        }
-#if defined(LG_DEDUP_EXP) && (LG_DEDUP_EXP == 1 || LG_DEDUP_EXP == 4)       // timing-only build: everything a workgroup reads, none of its table work
-        {
-            unsigned long long x = 0;
-            for (int u = 0; u < LG_DEDUP_CLAIMS; u++) x ^= rp[u];
-            for (int u = 0; u < LG_DEDUP_BATCH; u++) x ^= kl[u] ^ (unsigned long long)kid[u];
-            if (x == 0x1234567ull) a.slot_pos[0] = 1;
-            if (tid == 0) a.claim_cnt[b * LG_CLAIM_CNT_STRIDE] = 0;
-            return;
-        }
-#endif
-#if defined(LG_DEDUP_EXP) && LG_DEDUP_EXP == 2       // timing-only build: the table work on made-up claims of the right count, no memory reads of claims
-        for (int u = 0; u < LG_DEDUP_CLAIMS; u++) {
-            const uint32_t k = u * LG_DEDUP_THREADS + tid;
-            rp[u] = (int32_t)k < total ? (((unsigned long long)((k * 2654435761u + b * 40503u) & 0x3FFFFFFFu)) << 32) | k : ~0ull;
-        }
-#endif
+    // the bucket's segments, one per partition tile: exclusive prefix of their lengths
+    if (tid == 0) s_total = 0;
+    for (int32_t t = tid; t < nparts; t += LG_DEDUP_THREADS) {
+        const int32_t off = roff[(int64_t)t * (NB + 1)];
+        s_pref[t + 1] = roff[(int64_t)t * (NB + 1) + 1] - off;
+        s_seg[t] = off;
     }
+    __syncthreads();
+    if (tid < 64) {                                    // <= 513 entries: wave 0 scans them, a few consecutive entries per lane
+        const int32_t per = (nparts + 63) / 64;
+        const int32_t lo = min(tid * per, nparts), hi = min(lo + per, nparts);
+        int32_t sum = 0;
+        for (int32_t t = lo; t < hi; t++) sum += s_pref[t + 1];
+        int32_t inc = sum;
+        for (int d = 1; d < 64; d <<= 1) { const int32_t o = __shfl_up(inc, d); if (tid >= d) inc += o; }
+        int32_t acc = inc - sum;
+        for (int32_t t = lo; t < hi; t++) { acc += s_pref[t + 1]; s_pref[t + 1] = acc; }
+        if (tid == 0) s_pref[0] = 0;
+        if (tid == 63) s_total = inc;
+    }
+    __syncthreads();
+    const int32_t total = s_total;
     // passes: distinct vertices <= known + claims; keep the expected load of a pass at or below LG_LDS_FILL_16THS / 16 of the
     // table.  The bucket's share of the scanned ids is ESTIMATED (an even spread + a quarter; counting it would cost every
     // workgroup one more round trip to memory), and the hash is assumed to spread the bucket evenly over its sub-buckets: when
@@ -826,55 +948,19 @@ void dedup_lds_kernel(HopParams hp, const LanePtrs* __restrict__ lanes)
         }
         s_full = 1;
     };
-#if LG_DEDUP_FIXED
-    // the same outcome with words that never move: the first word of a vertex takes the first empty place of its probe sequence
-    // (compare-and-swap), every later word of that vertex meets it there and is merged by min.  Returns the place.
-    auto insert_at = [&](unsigned long long w, uint32_t h) -> uint32_t {
-        uint32_t p = lds_slot_of(h);
-        for (int it = 0; it < LG_LDS_TABLE; it++) {
-            unsigned long long seen = ~0ull;
-            if (__hip_atomic_compare_exchange_strong(&s_tab[p], &seen, w, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP))
-                return p;
-            if ((uint32_t)(seen >> 32) == (uint32_t)(w >> 32)) {
-                if (w < seen) __hip_atomic_fetch_min(&s_tab[p], w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                return p;
-            }
-            p = (p + 1) & (LG_LDS_TABLE - 1);
-        }
-        s_full = 1;
-        return 0;
-    };
-#endif
 
-    // A bucket of at most LG_DEDUP_CLAIMS claims per thread (the usual case) keeps them in registers: one trip to memory for both
-    // sweeps of every pass.  A larger one is read again, sweep by sweep; and a LISTS bucket whose list could not take all its
-    // claims (its count says so) reads the hop's slots instead and keeps what hashes into this bucket.
-    const bool from_slots = LISTS && total > a.claim_cap;
-    const bool resident = !from_slots && total <= LG_DEDUP_CLAIMS * LG_DEDUP_THREADS;
-    const int32_t n_src = from_slots ? g.total : total;          // what a sweep of a bucket that is not resident walks over
-#if LG_DEDUP_FIXED
-    uint32_t place[LG_DEDUP_CLAIMS] = {};
-#endif
-    auto fetch = [&](int32_t k0, unsigned long long (&pr)[LG_DEDUP_CLAIMS]) {
+    // a bucket of at most LG_DEDUP_BATCH claims per thread (the usual case) keeps them in registers: one trip to memory for both
+    // sweeps of every pass
+    const bool resident = total <= LG_DEDUP_BATCH * LG_DEDUP_THREADS;
+    unsigned long long rp[LG_DEDUP_BATCH];
+    auto fetch = [&](int32_t k0, unsigned long long (&pr)[LG_DEDUP_BATCH]) {
 #pragma unroll
-        for (int u = 0; u < LG_DEDUP_CLAIMS; u++) {
+        for (int u = 0; u < LG_DEDUP_BATCH; u++) {
             const int32_t k = k0 + u * LG_DEDUP_THREADS + tid;
-            pr[u] = ~0ull;
-            if (k >= n_src) continue;
-            if (from_slots) {
-                int32_t d = a.slot_dst[k];
-                if (d < 0) continue;
-                if (a.loser_in_dst) d &= ~LG_LOSER_BIT;          // (an earlier pass may have marked the slot)
-                if ((lg_tab_hash(d) & (NB - 1)) == (uint32_t)b) pr[u] = ((unsigned long long)(uint32_t)d << 32) | (uint32_t)k;
-            } else if (LISTS) {
-                pr[u] = a.claim_pairs[lg_claim_at<NB>(b, k)];
-            } else {
-                pr[u] = a.claim_pairs[segment_of(k)];
-            }
+            pr[u] = k < total ? a.claim_pairs[segment_of(k)] : ~0ull;
         }
     };
-    if (!LISTS && resident) fetch(0, rp);
-    LG_STAMP(3);
+    if (resident) fetch(0, rp);
 
   for (;;) {
     const uint32_t pmask = (uint32_t)passes - 1u;
@@ -894,11 +980,7 @@ void dedup_lds_kernel(HopParams hp, const LanePtrs* __restrict__ lanes)
                 if (id < 0) continue;
                 const uint32_t h = lg_tab_hash(id);
                 if ((h & (NB - 1)) != (uint32_t)b || ((h >> BB) & pmask) != pass) continue;
-#if LG_DEDUP_FIXED
-                insert_at(((unsigned long long)(uint32_t)id << 32) | (uint32_t)i, h);
-#else
                 insert(((unsigned long long)(uint32_t)id << 32) | (uint32_t)i, h);
-#endif
             }
         }
         if (listed)
@@ -910,78 +992,48 @@ void dedup_lds_kernel(HopParams hp, const LanePtrs* __restrict__ lanes)
                     if (pr == ~0ull) continue;
                     const uint32_t h = lg_tab_hash((int32_t)(pr >> 32));
                     if (((h >> BB) & pmask) != pass) continue;
-#if LG_DEDUP_FIXED
-                    insert_at(pr, h);
-#else
                     insert(pr, h);
-#endif
                 }
             }
-        LG_STAMP(4);
-        for (int32_t k0 = 0; k0 < n_src; k0 += LG_DEDUP_CLAIMS * LG_DEDUP_THREADS) {
-            unsigned long long pr[LG_DEDUP_CLAIMS];
+        for (int32_t k0 = 0; k0 < total; k0 += LG_DEDUP_BATCH * LG_DEDUP_THREADS) {
+            unsigned long long pr[LG_DEDUP_BATCH];
             if (resident) {
 #pragma unroll
-                for (int u = 0; u < LG_DEDUP_CLAIMS; u++) pr[u] = rp[u];
+                for (int u = 0; u < LG_DEDUP_BATCH; u++) pr[u] = rp[u];
             } else
                 fetch(k0, pr);
 #pragma unroll
-            for (int u = 0; u < LG_DEDUP_CLAIMS; u++) {
+            for (int u = 0; u < LG_DEDUP_BATCH; u++) {
                 if (pr[u] == ~0ull) continue;
                 const uint32_t h = lg_tab_hash((int32_t)(pr[u] >> 32));
                 if (((h >> BB) & pmask) != pass) continue;
-#if LG_DEDUP_FIXED
-                place[u] = insert_at((pr[u] & 0xFFFFFFFF00000000ull) | PENDING | (uint32_t)pr[u], h);
-#else
                 insert((pr[u] & 0xFFFFFFFF00000000ull) | PENDING | (uint32_t)pr[u], h);
-#endif
             }
         }
-        LG_STAMP(5);
         __syncthreads();
-        LG_STAMP(6);
 #ifndef LG_LDS_NO_RETRY
         if (s_full != 0) { overflow = true; break; }       // (uniform: read behind the barrier, reset behind the next one)
 #endif
-        for (int32_t k0 = 0; k0 < n_src; k0 += LG_DEDUP_CLAIMS * LG_DEDUP_THREADS) {
-            unsigned long long pr[LG_DEDUP_CLAIMS];
+        for (int32_t k0 = 0; k0 < total; k0 += LG_DEDUP_BATCH * LG_DEDUP_THREADS) {
+            unsigned long long pr[LG_DEDUP_BATCH];
             if (resident) {
 #pragma unroll
-                for (int u = 0; u < LG_DEDUP_CLAIMS; u++) pr[u] = rp[u];
+                for (int u = 0; u < LG_DEDUP_BATCH; u++) pr[u] = rp[u];
             } else
                 fetch(k0, pr);
-#if LG_DEDUP_FIXED
-            // resident claims know where their vertex's word is: the loads of a thread's claims are independent
-            unsigned long long tw[LG_DEDUP_CLAIMS];
-            if (resident) {
 #pragma unroll
-                for (int u = 0; u < LG_DEDUP_CLAIMS; u++) tw[u] = s_tab[place[u] & (LG_LDS_TABLE - 1)];
-            }
-#endif
-#pragma unroll
-            for (int u = 0; u < LG_DEDUP_CLAIMS; u++) {
+            for (int u = 0; u < LG_DEDUP_BATCH; u++) {
                 if (pr[u] == ~0ull) continue;
                 const uint32_t id = (uint32_t)(pr[u] >> 32), slot = (uint32_t)pr[u];
                 const uint32_t h = lg_tab_hash((int32_t)id);
                 if (((h >> BB) & pmask) != pass) continue;
+                uint32_t p = lds_slot_of(h);
                 uint32_t v = 0xFFFFFFFFu;
-#if LG_DEDUP_FIXED
-                if (resident) {
-                    v = (uint32_t)tw[u];
-                } else
-#endif
-                {
-                    uint32_t p = lds_slot_of(h);
-                    for (int it = 0; it < LG_LDS_TABLE; it++) {
-                        const unsigned long long w = s_tab[p];
-                        if ((uint32_t)(w >> 32) == id) { v = (uint32_t)w; break; }
-                        p = (p + 1) & (LG_LDS_TABLE - 1);
-                    }
+                for (int it = 0; it < LG_LDS_TABLE; it++) {
+                    const unsigned long long w = s_tab[p];
+                    if ((uint32_t)(w >> 32) == id) { v = (uint32_t)w; break; }
+                    p = (p + 1) & (LG_LDS_TABLE - 1);
                 }
-#if defined(LG_DEDUP_EXP) && LG_DEDUP_EXP == 2
-                if (v == 0x12345u) a.slot_pos[0] = 1;
-                continue;
-#endif
                 if (v != (PENDING | slot)) {          // not the lowest slot of a new vertex
                     if (a.loser_in_dst) a.slot_dst[slot] = (int32_t)(id | LG_LOSER_BIT);      // (vertex ids < 2^30: the mark rides in the id)
                     else a.slot_mark[slot] = a.mark_tag;
@@ -989,9 +1041,7 @@ void dedup_lds_kernel(HopParams hp, const LanePtrs* __restrict__ lanes)
                 }
             }
         }
-        LG_STAMP(7);
         __syncthreads();
-        LG_STAMP(8);
     }
     if (!overflow) break;
     if (passes >= (1 << 14)) {                             // 2^14 sub-buckets of one bucket still too full: not a hash problem
@@ -1001,32 +1051,8 @@ void dedup_lds_kernel(HopParams hp, const LanePtrs* __restrict__ lanes)
     passes <<= 1;
     __syncthreads();
   }
-    if (LISTS) {
-        if (tid == 0) a.claim_cnt[b * LG_CLAIM_CNT_STRIDE] = 0;                               // the next hop's sampling starts an empty list
-    } else if (b == 0 && tid == 0) a.hop_scratch[HS_PAIR_CURSOR] = 0;    // the next hop's sampling starts a new pair array
-#ifdef LG_DEDUP_STAMPS
-    if (tid == 0) {
-        const int hop = min(max(a.op_id / 3, 0), 7);
-        for (int i = 1; i < 9; i++) atomicAdd(&g_dedup_stamps[hop][i], stamp_t[i] - stamp_t[0]);
-        atomicAdd(&g_dedup_stamps[hop][0], 1ull);
-        atomicAdd(&g_dedup_stamps[hop][9], (unsigned long long)total);
-        atomicAdd(&g_dedup_stamps[hop][10], (unsigned long long)passes);
-        atomicMin(&g_dedup_stamps[hop][11], stamp_t[0]);
-        atomicMax(&g_dedup_stamps[hop][12], stamp_t[8]);
-    }
-#endif
+    if (b == 0 && tid == 0) a.hop_scratch[HS_PAIR_CURSOR] = 0;      // the next hop's sampling starts a new pair array
 }
-#ifdef LG_DEDUP_STAMPS
-extern "C" void legion_debug_dedup_stamps(unsigned long long* out, int reset)
-{
-    hipMemcpyFromSymbol(out, HIP_SYMBOL(g_dedup_stamps), sizeof(g_dedup_stamps));
-    if (reset) {
-        unsigned long long z[8][16] = {};
-        for (int h = 0; h < 8; h++) z[h][11] = ~0ull;
-        hipMemcpyToSymbol(HIP_SYMBOL(g_dedup_stamps), z, sizeof(z));
-    }
-}
-#endif
 
 // ------------------------------------------------------------------------------------------
 // K2: compaction in ONE pass over the hop's slots (rounds 1-2 took three: per-tile counts, a one-workgroup prefix with
@@ -1091,9 +1117,12 @@ void compact_kernel(HopParams hp, const LanePtrs* __restrict__ lanes)
     const int32_t wave = tid >> 6, lane = tid & 63;
     const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
 
+    // The next tile's ticket is drawn BEFORE this tile's stores are issued and the barriers inside the loop order LDS only: memory
+    // operations of a wave complete in order, so a ticket drawn after the stores (and a barrier that fences global memory) waits
+    // for the whole tile to have been written before the next tile's loads can even be addressed.
+    if (tid == 0) s_st = __hip_atomic_fetch_add(hs + HS_CTICKET, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
     for (;;) {
-        if (tid == 0) s_st = __hip_atomic_fetch_add(hs + HS_CTICKET, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __syncthreads();
         const int32_t st = s_st;
         if (st >= nsuper) break;                                          // (uniform)
         const int32_t idx0 = st * LG_SUPER;
@@ -1136,7 +1165,7 @@ void compact_kernel(HopParams hp, const LanePtrs* __restrict__ lanes)
                 s_mf[u * (LG_TILE / 64) + wave] = mf[u];
             }
         }
-        __syncthreads();
+        lds_barrier();
         // wave 0: this super tile's counts, for everybody behind it
         int32_t te = 0, tn = 0;
         if (wave == 0) {
@@ -1215,7 +1244,7 @@ void compact_kernel(HopParams hp, const LanePtrs* __restrict__ lanes)
                 __hip_atomic_store(state + st, st_word(LG_ST_PREF, xe + te, xn + tn), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         }
-        __syncthreads();
+        lds_barrier();
         const int32_t xe = s_ex[0], xn = s_ex[1];
         // lds form: the first touches' positions are known now -- publish them before anything else, later super tiles' losers
         // are waiting for nothing but this (publishing with the other stores below would chain every tile's loads behind the
@@ -1254,7 +1283,9 @@ void compact_kernel(HopParams hp, const LanePtrs* __restrict__ lanes)
                 }
             }
         }
-        // phase 2: the stores
+        // phase 2: the stores (V2: behind the draw of the next ticket)
+        int32_t next_st = 0;
+        if (tid == 0) next_st = __hip_atomic_fetch_add(hs + HS_CTICKET, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #pragma unroll
         for (int u = 0; u < LG_SLOTS_PER_LANE; u++) {
             const int32_t idx = idx0 + u * LG_TILE + tid;
@@ -1285,7 +1316,8 @@ void compact_kernel(HopParams hp, const LanePtrs* __restrict__ lanes)
                 a.agg_src_off[e] = lost_pos[u];
             }
         }
-        __syncthreads();
+        if (tid == 0) s_st = next_st;
+        lds_barrier();
     }
 
     // the workgroup that finishes last: counter_update(op_id), op_id % 3 == 0 (operator_impl.cu:69-82), with nc[6] = n_new and
@@ -1438,11 +1470,11 @@ void launch_random_sample(hipStream_t s, const HopParams& p, const LanePtrs* d_l
         if (p.lds_bucket_bits == LG_LDS_BITS_SMALL) {
             sample_kernel<2, LG_LDS_BITS_SMALL, true><<<grid, LG_TILE, 0, s>>>(q, d_lanes);
             hipCheckError();
-            dedup_lds_kernel<LG_LDS_BITS_SMALL><<<dim3(1 << LG_LDS_BITS_SMALL, n_lanes), LG_DEDUP_THREADS, 0, s>>>(q, d_lanes);
+            dedup_lists_kernel<LG_LDS_BITS_SMALL, LG_DEDUP_UNITS><<<dim3((1 << LG_LDS_BITS_SMALL) / LG_DEDUP_UNITS, n_lanes), LG_DEDUP_THREADS, 0, s>>>(q, d_lanes);
         } else if (p.lds_bucket_bits == LG_LDS_BITS_SMALL16) {
             sample_kernel<2, LG_LDS_BITS_SMALL16, true><<<grid, LG_TILE, 0, s>>>(q, d_lanes);
             hipCheckError();
-            dedup_lds_kernel<LG_LDS_BITS_SMALL16><<<dim3(1 << LG_LDS_BITS_SMALL16, n_lanes), LG_DEDUP_THREADS, 0, s>>>(q, d_lanes);
+            dedup_lists_kernel<LG_LDS_BITS_SMALL16, LG_DEDUP_UNITS><<<dim3((1 << LG_LDS_BITS_SMALL16) / LG_DEDUP_UNITS, n_lanes), LG_DEDUP_THREADS, 0, s>>>(q, d_lanes);
         } else if (p.lds_bucket_bits == LG_LDS_BITS_MEDIUM) {
             if (k <= LG_PLACE_MAX_K) {
                 sample_kernel<2, LG_LDS_BITS_MEDIUM, false, true><<<dim3(gp, n_lanes), LG_TILE, 0, s>>>(q, d_lanes);

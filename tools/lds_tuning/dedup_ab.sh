@@ -1,6 +1,7 @@
 #!/bin/bash
-# A/B of dedup_lds_kernel builds on one box: parity tests with the variant, its stamps build's phase table, and the group timeline.
-#   tools/lds_tuning/dedup_ab.sh all c6 fix spec      (variants v_<name> and s_<name> built by tools/lds_tuning/build_variant.sh)
+# A/B of sampler-chain builds on one box: parity tests with the variant and the group timeline (tools/trace_group.py).
+#   [PARITY="base x"] [EXTRA=--no-weave] tools/lds_tuning/dedup_ab.sh x y      (variants v_<name> built by
+#   tools/lds_tuning/build_variant.sh; variants/v_<name>/env, if present, holds `export` lines for that variant's runs)
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../.."; pwd)}
 V=$R/tools/lds_tuning/variants
 OUT=$R/gpurun_out/dedup_ab; mkdir -p $OUT; : > $OUT/summary.txt
@@ -14,12 +15,6 @@ for n in ${PARITY-base "$@"}; do
   rc=$?
   tail -2 $OUT/parity_$n.log >> $OUT/summary.txt
   if [ $rc != 0 ]; then echo "parity FAILED for v_$n" >> $OUT/summary.txt; cat $OUT/summary.txt; exit 1; fi
-done
-unset LEGION_HIP_LIB LEGION_LDS_SMALL_BUCKETS
-for n in ${STAMPS-base "$@"}; do
-  echo "=== stamps s_$n" >> $OUT/summary.txt
-  LEGION_HIP_LIB=$V/s_$n/liblegion_hip.so timeout -k 5 250 python tools/lds_tuning/dedup_stamps.py $BA $EXTRA > $OUT/stamps_$n.json 2> $OUT/stamps_$n.err
-  grep -A9 "^hop 2" $OUT/stamps_$n.err >> $OUT/summary.txt
 done
 cd /tmp && export TMPDIR=/tmp
 for rep in 1 2; do
