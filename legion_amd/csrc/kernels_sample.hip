@@ -1080,6 +1080,9 @@ void dedup_lds_kernel(HopParams hp, const LanePtrs* __restrict__ lanes)
 #ifndef LG_SCATTER_MIN_WAVES_LAST
 #define LG_SCATTER_MIN_WAVES_LAST 8
 #endif
+#ifndef LG_COMPACT_THREADS
+#define LG_COMPACT_THREADS 256
+#endif
 #define LG_SPIN_LIMIT (1 << 24)       // polls of one word before a waiter gives up with LG_ERR_CHAIN (seconds; a wait is microseconds)
 #define LG_ST_AGG (1ull << 62)
 #define LG_ST_PREF (2ull << 62)
@@ -1090,11 +1093,13 @@ __device__ __forceinline__ unsigned long long st_word(unsigned long long status,
 __device__ __forceinline__ int32_t st_edges(unsigned long long w) { return (int32_t)((w >> 31) & 0x7FFFFFFFull); }
 __device__ __forceinline__ int32_t st_nodes(unsigned long long w) { return (int32_t)(w & 0x7FFFFFFFull); }
 
-template <bool LAST>       // the last hop writes no frontier headers and no position state: fewer registers, more waves per SIMD
-__global__ __launch_bounds__(LG_TILE, LAST ? LG_SCATTER_MIN_WAVES_LAST : LG_SCATTER_MIN_WAVES) __attribute__((amdgpu_num_sgpr(80)))
+template <bool LAST, int CT>       // LAST: the last hop writes no frontier headers and no position state (fewer registers, more waves per SIMD); CT: threads
+                                   // per workgroup = slots per 'tile row' (a workgroup iteration takes LG_SLOTS_PER_LANE * CT consecutive slots)
+__global__ __launch_bounds__(CT, LAST ? LG_SCATTER_MIN_WAVES_LAST : LG_SCATTER_MIN_WAVES) __attribute__((amdgpu_num_sgpr(80)))
 void compact_kernel(HopParams hp, const LanePtrs* __restrict__ lanes)
 {
-    constexpr int NW = LG_SLOTS_PER_LANE * (LG_TILE / 64);     // waves' worth of slots in a super tile (16)
+    constexpr int NW = LG_SLOTS_PER_LANE * (CT / 64);     // waves' worth of slots in a workgroup iteration (16 or 32)
+    constexpr int CSUPER = LG_SLOTS_PER_LANE * CT;
     static_assert(NW <= 64, "one lane of wave 0 per (u, wave)");
     const SampleArgs a = lane_args(hp, lanes);
     __shared__ int32_t s_cnt[2][NW];               // [valid | first touch][u * 4 + wave]
@@ -1106,7 +1111,7 @@ void compact_kernel(HopParams hp, const LanePtrs* __restrict__ lanes)
     LG_G int32_t* nc = a.node_counter;
     LG_G int32_t* ec = a.edge_counter;
     const int32_t nc0 = nc[0], nc1 = nc[1], ec0 = ec[0], ec1 = ec[1];     // (rewritten by the LAST workgroup only)
-    const int32_t total = g.total, nsuper = g.nsuper;
+    const int32_t total = g.total, nsuper = (g.total + CSUPER - 1) / CSUPER;
     const bool seeds = a.op_id == INTRABATCH_CON;
     const int32_t f_off = g.frontier_off;
     const int32_t node_base = nc0 + nc1, edge_base = ec0 + ec1;           // operator_impl.cu:268, :275
@@ -1125,13 +1130,13 @@ void compact_kernel(HopParams hp, const LanePtrs* __restrict__ lanes)
     for (;;) {
         const int32_t st = s_st;
         if (st >= nsuper) break;                                          // (uniform)
-        const int32_t idx0 = st * LG_SUPER;
+        const int32_t idx0 = st * CSUPER;
         int32_t v[LG_SLOTS_PER_LANE], mk[LG_SLOTS_PER_LANE];
         unsigned long long mv[LG_SLOTS_PER_LANE], mf[LG_SLOTS_PER_LANE];
         const bool inl = a.loser_in_dst;                                  // (uniform) the loser mark rides in slot_dst
 #pragma unroll
         for (int u = 0; u < LG_SLOTS_PER_LANE; u++) {
-            const int32_t idx = idx0 + u * LG_TILE + tid;
+            const int32_t idx = idx0 + u * CT + tid;
             v[u] = idx < total ? a.slot_dst[idx] : -1;
             mk[u] = (idx < total && !inl) ? a.slot_mark[idx] : 0;
         }
@@ -1142,7 +1147,7 @@ void compact_kernel(HopParams hp, const LanePtrs* __restrict__ lanes)
         if (hoist) {
 #pragma unroll
             for (int u = 0; u < LG_SLOTS_PER_LANE; u++) {
-                const int32_t idx = idx0 + u * LG_TILE + tid;
+                const int32_t idx = idx0 + u * CT + tid;
                 src_of[u] = 0; src_pos[u] = 0; fsv[u] = LG_FS_UNKNOWN;
                 if (idx < total) {
                     const int32_t q = idx / a.count;
@@ -1160,9 +1165,9 @@ void compact_kernel(HopParams hp, const LanePtrs* __restrict__ lanes)
             mv[u] = __ballot(valid);
             mf[u] = __ballot(first);
             if (lane == 0) {
-                s_cnt[0][u * (LG_TILE / 64) + wave] = __popcll(mv[u]);
-                s_cnt[1][u * (LG_TILE / 64) + wave] = __popcll(mf[u]);
-                s_mf[u * (LG_TILE / 64) + wave] = mf[u];
+                s_cnt[0][u * (CT / 64) + wave] = __popcll(mv[u]);
+                s_cnt[1][u * (CT / 64) + wave] = __popcll(mf[u]);
+                s_mf[u * (CT / 64) + wave] = mf[u];
             }
         }
         lds_barrier();
@@ -1191,7 +1196,7 @@ void compact_kernel(HopParams hp, const LanePtrs* __restrict__ lanes)
         RowHdr nh[LG_SLOTS_PER_LANE];
 #pragma unroll
         for (int u = 0; u < LG_SLOTS_PER_LANE; u++) {
-            const int32_t idx = idx0 + u * LG_TILE + tid;
+            const int32_t idx = idx0 + u * CT + tid;
             if (v[u] >= 0) {
                 const bool first = (mf[u] >> lane) & 1ull;
                 const int32_t dst = v[u];
@@ -1254,8 +1259,8 @@ void compact_kernel(HopParams hp, const LanePtrs* __restrict__ lanes)
         for (int u = 0; u < LG_SLOTS_PER_LANE; u++) {
             n_at[u] = -1;
             if ((mf[u] >> lane) & 1ull) {
-                n_at[u] = node_base + xn + s_pre[1][u * (LG_TILE / 64) + wave] + __popcll(mf[u] & lt);
-                if (lds) __hip_atomic_store(a.slot_pos + idx0 + u * LG_TILE + tid, n_at[u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                n_at[u] = node_base + xn + s_pre[1][u * (CT / 64) + wave] + __popcll(mf[u] & lt);
+                if (lds) __hip_atomic_store(a.slot_pos + idx0 + u * CT + tid, n_at[u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         }
         if (lds) {
@@ -1288,10 +1293,10 @@ void compact_kernel(HopParams hp, const LanePtrs* __restrict__ lanes)
         if (tid == 0) next_st = __hip_atomic_fetch_add(hs + HS_CTICKET, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #pragma unroll
         for (int u = 0; u < LG_SLOTS_PER_LANE; u++) {
-            const int32_t idx = idx0 + u * LG_TILE + tid;
+            const int32_t idx = idx0 + u * CT + tid;
             if (v[u] < 0) continue;
             const int32_t dst = v[u];
-            const int32_t e = edge_base + xe + s_pre[0][u * (LG_TILE / 64) + wave] + __popcll(mv[u] & lt);
+            const int32_t e = edge_base + xe + s_pre[0][u * (CT / 64) + wave] + __popcll(mv[u] & lt);
             a.agg_src_ids[e] = dst;                                // :256, :276
             a.agg_dst_ids[e] = src_of[u];                          // :257, :277
             a.agg_dst_off[e] = src_pos[u];
@@ -1340,7 +1345,7 @@ void compact_kernel(HopParams hp, const LanePtrs* __restrict__ lanes)
         s_tot[1] = st_nodes(tw);
     }
     __syncthreads();
-    for (int32_t t = tid; t < nsuper; t += LG_TILE) state[t] = 0ull;
+    for (int32_t t = tid; t < nsuper; t += CT) state[t] = 0ull;
     if (tid == 0) {
         const int32_t n_edge = s_tot[0], n_new = s_tot[1];
         hs[HS_CTICKET] = 0;
@@ -1500,8 +1505,13 @@ void launch_random_sample(hipStream_t s, const HopParams& p, const LanePtrs* d_l
         sample_kernel<0, 0, true><<<grid, LG_TILE, 0, s>>>(p, d_lanes);
     }
     hipCheckError();
-    if (p.last_hop) compact_kernel<true><<<grid, LG_TILE, 0, s>>>(p, d_lanes);
-    else compact_kernel<false><<<grid, LG_TILE, 0, s>>>(p, d_lanes);
+    // compaction: LG_COMPACT_THREADS per workgroup (a workgroup iteration takes 4 x that many consecutive slots), as many workgroups per
+    // lane as the sampling launch has per 1024 slots' worth
+    {
+        const dim3 cgrid(std::max(1, (int)grid.x * LG_TILE / LG_COMPACT_THREADS), n_lanes);
+        if (p.last_hop) compact_kernel<true, LG_COMPACT_THREADS><<<cgrid, LG_COMPACT_THREADS, 0, s>>>(p, d_lanes);
+        else compact_kernel<false, LG_COMPACT_THREADS><<<cgrid, LG_COMPACT_THREADS, 0, s>>>(p, d_lanes);
+    }
     hipCheckError();
     if (form == 2 && !p.last_hop) {       // later hops must recognise the nodes this one added: their buckets' lists
         int32_t chunks = (p.max_slots + LG_LIST_CHUNK - 1) / LG_LIST_CHUNK;

@@ -13,7 +13,7 @@ import sys
 
 def main():
     src, out = sys.argv[1], sys.argv[2]
-    wanted = sys.argv[3:] or ["sample_kernel", "dedup_lds_kernel", "compact_kernel", "place_kernel", "list_known_kernel", "gather_kernel"]
+    wanted = sys.argv[3:] or ["sample_kernel", "dedup_lds_kernel", "dedup_lists_kernel", "compact_kernel", "place_kernel", "list_known_kernel", "gather_kernel"]
     acc = collections.defaultdict(lambda: collections.defaultdict(lambda: [0.0, 0]))     # (kernel, grid) -> counter -> [sum, n]
     dur = collections.defaultdict(lambda: [0.0, 0])
     for d in sorted(glob.glob(os.path.join(src, "g*"))):
