@@ -12,7 +12,7 @@ if not fs: print("no csv", open(sys.argv[1] + "/err.txt").read()[-400:]); sys.ex
 acc = collections.defaultdict(lambda: [0.0, 0])
 for r in csv.DictReader(open(fs[0])):
     n = r['Kernel_Name']
-    if 'sample_kernel' not in n and 'dedup_lds' not in n: continue
+    if 'sample_kernel' not in n and 'dedup_l' not in n: continue
     k = (n.split('(')[0][:44], r['Grid_Size'], r['Counter_Name'])
     acc[k][0] += float(r['Counter_Value']); acc[k][1] += 1
 for k, v in sorted(acc.items()):
