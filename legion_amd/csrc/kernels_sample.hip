@@ -496,9 +496,11 @@ __global__ __launch_bounds__(LG_TILE) __attribute__((amdgpu_num_sgpr(LG_SAMPLE_S
                     } else {
                         dst[u] = -1;
                     }
-                    a.slot_dst[idx] = dst[u];
-                    if (FORM == 2) a.slot_pos[idx] = -1;      // "no position yet": compact_kernel publishes a first touch's position here
-                    if (a.slot_fs != nullptr && dst[u] >= 0) a.slot_fs[idx] = fs[u];     // (read for first-touch slots only)
+                    // slot_dst / slot_fs are read once, by the compaction two kernels later: non-temporal stores (+0.5 % on the whole job,
+                    // tools/lds_tuning/value_rounds.sh: they do not push the column arrays' lines out of the caches)
+                    __builtin_nontemporal_store(dst[u], &a.slot_dst[idx]);
+                    if (FORM == 2) a.slot_pos[idx] = -1;      // "no position yet": compact_kernel publishes a first touch's position here (plain store: no difference)
+                    if (a.slot_fs != nullptr && dst[u] >= 0) __builtin_nontemporal_store(fs[u], &a.slot_fs[idx]);     // (read for first-touch slots only)
                 }
             }
             if (FORM == 2 && SINGLE) {
@@ -1297,9 +1299,21 @@ void compact_kernel(HopParams hp, const LanePtrs* __restrict__ lanes)
             if (v[u] < 0) continue;
             const int32_t dst = v[u];
             const int32_t e = edge_base + xe + s_pre[0][u * (CT / 64) + wave] + __popcll(mv[u] & lt);
-            a.agg_src_ids[e] = dst;                                // :256, :276
-            a.agg_dst_ids[e] = src_of[u];                          // :257, :277
-            a.agg_dst_off[e] = src_pos[u];
+#ifdef LG_COMPACT_NO_NT
+            constexpr bool NT = false;
+#else
+            constexpr bool NT = LAST;
+#endif
+            if (NT) {       // nobody on this GPU reads the last hop's edge arrays again: non-temporal stores (chain -5..-19 us and the gathers
+                              // behind it -25..-50 us on one box: what they read -- sampled_ids, node_slot -- stays cached)
+                __builtin_nontemporal_store(dst, &a.agg_src_ids[e]);
+                __builtin_nontemporal_store(src_of[u], &a.agg_dst_ids[e]);
+                __builtin_nontemporal_store(src_pos[u], &a.agg_dst_off[e]);
+            } else {
+                a.agg_src_ids[e] = dst;                            // :256, :276
+                a.agg_dst_ids[e] = src_of[u];                      // :257, :277
+                a.agg_dst_off[e] = src_pos[u];
+            }
             if (!LAST) store_hdr(a.fh_edge + e, nh[u]);
             const int32_t n = n_at[u];
             if (n >= 0) {
@@ -1316,9 +1330,11 @@ void compact_kernel(HopParams hp, const LanePtrs* __restrict__ lanes)
                         raise_error(a.hop_scratch, a.err_flag, LG_ERR_TABLE_FULL);
                 }
                 if (!lds) a.slot_pos[idx] = n;                     // (atomics forms: what localise follows)
-                a.agg_src_off[e] = n;                              // construct_graph's neighbour side, known here
+                if (NT) __builtin_nontemporal_store(n, &a.agg_src_off[e]);
+                else a.agg_src_off[e] = n;                              // construct_graph's neighbour side, known here
             } else {
-                a.agg_src_off[e] = lost_pos[u];
+                if (NT) __builtin_nontemporal_store(lost_pos[u], &a.agg_src_off[e]);
+                else a.agg_src_off[e] = lost_pos[u];
             }
         }
         if (tid == 0) s_st = next_st;
