@@ -199,6 +199,7 @@ def parse_args():
                     help="mini-batches served by every launch (lanes of a group); 0 = 524288 // batch rounded down to a power of "
                          "two, at most 512, halved while the lanes in flight would not fit 0.7 of the free HBM")
     ap.add_argument("--slots", type=int, default=2, help="groups in flight per GPU")
+    ap.add_argument("--probe-overlap", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
     ap.add_argument("--overlap", action="store_true", help="let kernels of different slots share the GPU")
     ap.add_argument("--split", action="store_true",
@@ -577,6 +578,16 @@ def run_leg(c, engine, synth, stripe, replica_memory, headline, bulk=False):
         pipe = engine.Pipeline(graph, feature, cache, d, B, fanout, G, feature_rows, not args.no_graph, args.slots,
                                args.overlap, args.split, weave)
     torch.cuda.synchronize()
+    if getattr(args, "probe_overlap", False) and headline and not bulk:
+        # experiment: the last hop's de-duplication + compaction of one group beside the gathers of another
+        import ctypes as _ct
+        out_ms = (_ct.c_double * 6)()
+        pipe.run_range(0, n_warm, wrap=wrap)
+        pipe.wait()
+        for prep, side, what in ((1, 6, "dedup+compact"), (3, 4, "compact"), (1, 2, "dedup"), (0, 1, "sample")):
+            ok = engine._libmod.load().legion_pipeline_probe_overlap(pipe.handle, int(n_warm), 0, out_ms, prep, side)
+            names = ["gathers(A) alone", what + "(B) alone", "one stream", "two streams, equal priority", "second stream high priority", "second stream low priority"]
+            print("probe_overlap", ok, {n: round(v, 4) for n, v in zip(names, out_ms)}, file=sys.stderr, flush=True)
     setup_s = time.time() - (c.t_setup if headline else t_leg)
 
     # ---- untimed counting pass over exactly the timed batches (deterministic) --------------------

@@ -1462,8 +1462,10 @@ __global__ __launch_bounds__(LG_TILE) void localise_kernel(HopParams hp, const L
     }
 }
 
+int g_sample_stages = 15;
 void launch_random_sample(hipStream_t s, const HopParams& p, const LanePtrs* d_lanes, int32_t n_lanes, int32_t form)
 {
+    const int stages = g_sample_stages;
     // Fixed grids that stride over super tiles; grid.y = lanes (independent mini-batches of a group).
     int32_t max_super = (p.max_slots + LG_SUPER - 1) / LG_SUPER;
     if (max_super < 1) max_super = 1;
@@ -1489,13 +1491,13 @@ void launch_random_sample(hipStream_t s, const HopParams& p, const LanePtrs* d_l
         int32_t gp = (max_super + k - 1) / k;                  // one workgroup per partition tile ...
         while (gp > 16 && (int64_t)gp * n_lanes > 16384) gp = (gp + 1) / 2;  // ... within reason
         if (p.lds_bucket_bits == LG_LDS_BITS_SMALL) {
-            sample_kernel<2, LG_LDS_BITS_SMALL, true><<<grid, LG_TILE, 0, s>>>(q, d_lanes);
+            if (stages & 1) sample_kernel<2, LG_LDS_BITS_SMALL, true><<<grid, LG_TILE, 0, s>>>(q, d_lanes);
             hipCheckError();
-            dedup_lists_kernel<LG_LDS_BITS_SMALL, LG_DEDUP_UNITS><<<dim3((1 << LG_LDS_BITS_SMALL) / LG_DEDUP_UNITS, n_lanes), LG_DEDUP_THREADS, 0, s>>>(q, d_lanes);
+            if (stages & 2) dedup_lists_kernel<LG_LDS_BITS_SMALL, LG_DEDUP_UNITS><<<dim3((1 << LG_LDS_BITS_SMALL) / LG_DEDUP_UNITS, n_lanes), LG_DEDUP_THREADS, 0, s>>>(q, d_lanes);
         } else if (p.lds_bucket_bits == LG_LDS_BITS_SMALL16) {
-            sample_kernel<2, LG_LDS_BITS_SMALL16, true><<<grid, LG_TILE, 0, s>>>(q, d_lanes);
+            if (stages & 1) sample_kernel<2, LG_LDS_BITS_SMALL16, true><<<grid, LG_TILE, 0, s>>>(q, d_lanes);
             hipCheckError();
-            dedup_lists_kernel<LG_LDS_BITS_SMALL16, LG_DEDUP_UNITS><<<dim3((1 << LG_LDS_BITS_SMALL16) / LG_DEDUP_UNITS, n_lanes), LG_DEDUP_THREADS, 0, s>>>(q, d_lanes);
+            if (stages & 2) dedup_lists_kernel<LG_LDS_BITS_SMALL16, LG_DEDUP_UNITS><<<dim3((1 << LG_LDS_BITS_SMALL16) / LG_DEDUP_UNITS, n_lanes), LG_DEDUP_THREADS, 0, s>>>(q, d_lanes);
         } else if (p.lds_bucket_bits == LG_LDS_BITS_MEDIUM) {
             if (k <= LG_PLACE_MAX_K) {
                 sample_kernel<2, LG_LDS_BITS_MEDIUM, false, true><<<dim3(gp, n_lanes), LG_TILE, 0, s>>>(q, d_lanes);
@@ -1521,6 +1523,7 @@ void launch_random_sample(hipStream_t s, const HopParams& p, const LanePtrs* d_l
         sample_kernel<0, 0, true><<<grid, LG_TILE, 0, s>>>(p, d_lanes);
     }
     hipCheckError();
+    if (!(stages & 4)) return;
     // compaction: LG_COMPACT_THREADS per workgroup (a workgroup iteration takes 4 x that many consecutive slots), as many workgroups per
     // lane as the sampling launch has per 1024 slots' worth
     {

@@ -764,6 +764,9 @@ struct HopParams {                  // what every lane of a launch shares
     int32_t lds_bucket_bits;        // lds form: LG_LDS_BITS_SMALL / SMALL16 / MEDIUM / LARGE (the pool's)
     int32_t lds_k;                  // lds form: super tiles per partition tile in this hop (set by launch_random_sample)
 };
+// which kernels of a hop launch_random_sample / the REST phase really launch (experiments: legion_pipeline_probe_overlap):
+// 1 sample (+ place), 2 de-duplication, 4 compaction (+ known lists), 8 end-of-batch.  15 = all (the only value product code uses).
+extern int g_sample_stages;
 // form: 0 direct array, 1 table, 2 lds
 void launch_random_sample(hipStream_t s, const HopParams& p, const LanePtrs* d_lanes, int32_t n_lanes, int32_t form);
 

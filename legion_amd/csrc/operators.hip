@@ -387,7 +387,7 @@ static void enqueue_lanes(hipStream_t s, GraphStorage* graph, FeatureStorage* fe
             if (early && pool0->GetFloatFeatures() != nullptr && lg_weave_head_gathers()) early_gathers();
         } else {
             if (last >= 0) do_random_sample(s, graph, cache, d_lanes, n_lanes, pool0, fanout[last], dev_id, INTRABATCH_CON * (last + 1), false);
-            lg::launch_end_of_batch(s, d_lanes, n_lanes, iter_state, pool_state_bytes(pool0));
+            if (lg::g_sample_stages & 8) lg::launch_end_of_batch(s, d_lanes, n_lanes, iter_state, pool_state_bytes(pool0));
             if (phase == LG_PHASE_REST_SAMPLE) return;
             if (early && lg_weave_head_gathers()) {
                 do_feature_lookup(s, cache, d_lanes, n_lanes, pool0, INTRABATCH_CON * (last + 1) + 1, dev_id, true, -1);

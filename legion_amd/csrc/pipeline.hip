@@ -418,6 +418,67 @@ extern "C" int32_t legion_pipeline_submit_ex(LegionPipeline* p, int32_t counter0
     return si;
 }
 
+// Experiment: can the last hop's de-duplication + compaction of group B run BESIDE the gathers of group A?
+// out_ms: [0] gathers(A) alone, [1] dedup+compact(B) alone, [2] both on one stream, [3] on two streams of equal priority,
+// [4] with the de-duplication's stream at high priority, [5] with it at low priority.  Eager launches, slots 0 and 1.
+extern "C" int32_t legion_pipeline_probe_overlap(LegionPipeline* p, int32_t counter0, int32_t mode, double* out_ms, int32_t prep_stages, int32_t side_stages)
+{
+    if (!p || p->slots_n < 2 || p->hop_num < 2) return 0;
+    SetGPUDevice(p->dev_id);
+    for (auto& sl : p->slots) slot_wait(p, sl);
+    Slot& A = p->slots[0];
+    Slot& B = p->slots[1];
+    LegionGraphStorage* gr = reinterpret_cast<LegionGraphStorage*>(p->graph);
+    LegionFeatureStorage* f = reinterpret_cast<LegionFeatureStorage*>(p->feature);
+    const int32_t G = p->group_size;
+    auto enq = [&](Slot& sl, hipStream_t s, int32_t phase, int stages, int32_t c0) {
+        for (int32_t g = 0; g < G; g++) { sl.pools[g]->SetCurrentMode(mode); sl.pools[g]->SetIter(c0 + g); }
+        legion_group_set_iter_state(sl.group, nullptr);
+        lg::g_sample_stages = stages;
+        legion_enqueue_group_phase(s, gr, f, p->cache_handle, sl.group, G, p->batch_size, c0, p->dev_id, mode, p->fanout.data(), p->hop_num, phase);
+        lg::g_sample_stages = 15;
+    };
+    hipStream_t X = A.stream, Z[3];
+    int lo = 0, hi = 0;
+    HIP_CALL(hipDeviceGetStreamPriorityRange(&lo, &hi));
+    HIP_CALL(hipStreamCreateWithPriority(&Z[0], hipStreamNonBlocking, 0));
+    HIP_CALL(hipStreamCreateWithPriority(&Z[1], hipStreamNonBlocking, hi));
+    HIP_CALL(hipStreamCreateWithPriority(&Z[2], hipStreamNonBlocking, lo));
+    hipEvent_t e0, e1, ez;
+    HIP_CALL(hipEventCreate(&e0)); HIP_CALL(hipEventCreate(&e1)); HIP_CALL(hipEventCreate(&ez));
+    enq(A, X, LG_PHASE_SAMPLE, 15, counter0);                         // A: sampled, ready for its gathers
+    auto prep_b = [&]() {                                              // B: everything up to and including the last hop's sampling kernel
+        enq(B, X, LG_PHASE_HEAD, 15, counter0 + G);
+        enq(B, X, LG_PHASE_REST_SAMPLE, prep_stages, counter0 + G);
+        HIP_CALL(hipStreamSynchronize(X));
+    };
+    auto timed = [&](int which) -> double {
+        prep_b();
+        float ms = 0;
+        HIP_CALL(hipEventRecord(e0, X));
+        if (which == 0) enq(A, X, LG_PHASE_GATHER, 15, counter0);
+        else if (which == 1) enq(B, X, LG_PHASE_REST_SAMPLE, side_stages, counter0 + G);
+        else if (which == 2) { enq(A, X, LG_PHASE_GATHER, 15, counter0); enq(B, X, LG_PHASE_REST_SAMPLE, side_stages, counter0 + G); }
+        else {
+            hipStream_t z = Z[which - 3];
+            HIP_CALL(hipStreamWaitEvent(z, e0, 0));
+            enq(A, X, LG_PHASE_GATHER, 15, counter0);
+            enq(B, z, LG_PHASE_REST_SAMPLE, side_stages, counter0 + G);
+            HIP_CALL(hipEventRecord(ez, z));
+            HIP_CALL(hipStreamWaitEvent(X, ez, 0));
+        }
+        HIP_CALL(hipEventRecord(e1, X));
+        HIP_CALL(hipEventSynchronize(e1));
+        HIP_CALL(hipEventElapsedTime(&ms, e0, e1));
+        return ms;
+    };
+    for (int rep = 0; rep < 2; rep++)                                  // (the first round warms up)
+        for (int w = 0; w < 6; w++) out_ms[w] = timed(w);
+    for (int i = 0; i < 3; i++) HIP_CALL(hipStreamDestroy(Z[i]));
+    HIP_CALL(hipEventDestroy(e0)); HIP_CALL(hipEventDestroy(e1)); HIP_CALL(hipEventDestroy(ez));
+    return 1;
+}
+
 extern "C" void legion_pipeline_wait(LegionPipeline* p, int32_t slot)
 {
     if (!p) return;

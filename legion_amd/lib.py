@@ -98,6 +98,7 @@ SIGNATURES = {
     "legion_pipeline_submit_n": (c_i32, [c_p, c_i32, c_i32, c_i32]),
     "legion_enqueue_group_n": (None, [c_p, c_p, c_p, c_p, c_p, c_i32, c_i32, c_i32, c_i32, c_i32, P_I32, c_i32]),
     "legion_pipeline_wait": (None, [c_p, c_i32]),
+    "legion_pipeline_probe_overlap": (c_i32, [c_p, c_i32, c_i32, ctypes.POINTER(ctypes.c_double), c_i32, c_i32]),
     "legion_pipeline_pool": (c_p, [c_p, c_i32, c_i32]),
     "legion_pipeline_destroy": (None, [c_p]),
     "legion_pipeline_bulk_enable": (c_i32, [c_p]),
