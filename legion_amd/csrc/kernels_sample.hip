@@ -688,7 +688,10 @@ __device__ __forceinline__ void lds_barrier()
 #ifndef LG_DEDUP_UNITS
 #define LG_DEDUP_UNITS 1
 #endif
-template <int BB, int UNITS>
+#ifndef LG_DEDUP_ONE_WG_SLOTS
+#define LG_DEDUP_ONE_WG_SLOTS 32768    // hops of at most this many slots (in groups of at least LegionTuning.lds_one_wg_lanes lanes): one workgroup per lane
+#endif
+template <int BB, int UNITS, int CL>      // CL: claims a thread keeps in registers (a bucket of at most CL * LG_DEDUP_THREADS claims is "resident")
 __global__ __launch_bounds__(LG_DEDUP_THREADS) __attribute__((amdgpu_num_sgpr(80)))
 void dedup_lists_kernel(HopParams hp, const LanePtrs* __restrict__ lanes)
 {
@@ -702,13 +705,13 @@ void dedup_lists_kernel(HopParams hp, const LanePtrs* __restrict__ lanes)
     const SampleArgs a = lane_args(hp, lanes);
 
     struct Req {                                   // what a unit (bucket) reads first
-        unsigned long long rp[LG_DEDUP_CLAIMS];    // the thread's claims u * THREADS + tid of the bucket's list
+        unsigned long long rp[CL];    // the thread's claims u * THREADS + tid of the bucket's list
         unsigned long long kl0;                    // the bucket's known list [tid]
         int32_t n_listed, n_claims;
     };
     auto request = [&](int32_t b, Req& q) {
 #pragma unroll
-        for (int u = 0; u < LG_DEDUP_CLAIMS; u++) {
+        for (int u = 0; u < CL; u++) {
             const int32_t k = u * LG_DEDUP_THREADS + tid;
             q.rp[u] = k < a.claim_cap ? a.claim_pairs[lg_claim_at<NB>(b, k)] : ~0ull;
         }
@@ -734,7 +737,7 @@ void dedup_lists_kernel(HopParams hp, const LanePtrs* __restrict__ lanes)
     const int32_t n_known = a.node_counter[0] + a.node_counter[1];
     const int32_t n_seed = min(max(a.node_counter[INTRABATCH_CON * 3], 0), n_known);
 
-#pragma unroll
+#pragma unroll 1
     for (int j = 0; j < UNITS; j++) {
         const int32_t b = (int32_t)blockIdx.x + j * STEP;
         Req cur = nxt;
@@ -748,22 +751,22 @@ void dedup_lists_kernel(HopParams hp, const LanePtrs* __restrict__ lanes)
         const int32_t total = cur.n_claims;            // (the count of the bucket's claims even when the list could not take them all)
         const LG_G unsigned long long* klist = a.known_pairs + (int64_t)b * a.known_cap;
 #pragma unroll
-        for (int u = 0; u < LG_DEDUP_CLAIMS; u++)
+        for (int u = 0; u < CL; u++)
             if (u * LG_DEDUP_THREADS + tid >= total) cur.rp[u] = ~0ull;
         if (!listed || tid >= n_listed) cur.kl0 = ~0ull;
         // passes over sub-buckets: see dedup_lds_kernel
         const int32_t known_est = (listed ? n_listed : 0) + n_scan / NB + n_scan / (4 * NB) + 32;
         int32_t passes = 1;
         while ((int64_t)known_est + total > (int64_t)passes * (LG_LDS_TABLE / 16 * LG_LDS_FILL_16THS)) passes <<= 1;
-        // A bucket of at most LG_DEDUP_CLAIMS claims per thread (the usual case) works from the registers.  A larger one is read
+        // A bucket of at most CL claims per thread (the usual case) works from the registers.  A larger one is read
         // again, sweep by sweep; and a bucket whose list could not take all its claims (its count says so) reads the hop's slots
         // instead and keeps what hashes into this bucket.
         const bool from_slots = total > a.claim_cap;
-        const bool resident = !from_slots && total <= LG_DEDUP_CLAIMS * LG_DEDUP_THREADS;
+        const bool resident = !from_slots && total <= CL * LG_DEDUP_THREADS;
         const int32_t n_src = from_slots ? hop_geometry(a).total : total;
-        auto fetch = [&](int32_t k0, unsigned long long (&pr)[LG_DEDUP_CLAIMS]) {
+        auto fetch = [&](int32_t k0, unsigned long long (&pr)[CL]) {
 #pragma unroll
-            for (int u = 0; u < LG_DEDUP_CLAIMS; u++) {
+            for (int u = 0; u < CL; u++) {
                 const int32_t k = k0 + u * LG_DEDUP_THREADS + tid;
                 pr[u] = ~0ull;
                 if (k >= n_src) continue;
@@ -802,15 +805,15 @@ void dedup_lists_kernel(HopParams hp, const LanePtrs* __restrict__ lanes)
                         if (((h >> BB) & pmask) != pass) continue;
                         insert(pr, h);
                     }
-                for (int32_t k0 = 0; k0 < n_src; k0 += LG_DEDUP_CLAIMS * LG_DEDUP_THREADS) {
-                    unsigned long long pr[LG_DEDUP_CLAIMS];
+                for (int32_t k0 = 0; k0 < n_src; k0 += CL * LG_DEDUP_THREADS) {
+                    unsigned long long pr[CL];
                     if (resident) {
 #pragma unroll
-                        for (int u = 0; u < LG_DEDUP_CLAIMS; u++) pr[u] = cur.rp[u];
+                        for (int u = 0; u < CL; u++) pr[u] = cur.rp[u];
                     } else
                         fetch(k0, pr);
 #pragma unroll
-                    for (int u = 0; u < LG_DEDUP_CLAIMS; u++) {
+                    for (int u = 0; u < CL; u++) {
                         if (pr[u] == ~0ull) continue;
                         const uint32_t h = lg_tab_hash((int32_t)(pr[u] >> 32));
                         if (((h >> BB) & pmask) != pass) continue;
@@ -821,15 +824,15 @@ void dedup_lists_kernel(HopParams hp, const LanePtrs* __restrict__ lanes)
 #ifndef LG_LDS_NO_RETRY
                 if (s_full != 0) { overflow = true; break; }       // (uniform: read behind the barrier, reset behind the next one)
 #endif
-                for (int32_t k0 = 0; k0 < n_src; k0 += LG_DEDUP_CLAIMS * LG_DEDUP_THREADS) {
-                    unsigned long long pr[LG_DEDUP_CLAIMS];
+                for (int32_t k0 = 0; k0 < n_src; k0 += CL * LG_DEDUP_THREADS) {
+                    unsigned long long pr[CL];
                     if (resident) {
 #pragma unroll
-                        for (int u = 0; u < LG_DEDUP_CLAIMS; u++) pr[u] = cur.rp[u];
+                        for (int u = 0; u < CL; u++) pr[u] = cur.rp[u];
                     } else
                         fetch(k0, pr);
 #pragma unroll
-                    for (int u = 0; u < LG_DEDUP_CLAIMS; u++) {
+                    for (int u = 0; u < CL; u++) {
                         if (pr[u] == ~0ull) continue;
                         const uint32_t id = (uint32_t)(pr[u] >> 32), slot = (uint32_t)pr[u];
                         const uint32_t h = lg_tab_hash((int32_t)id);
@@ -1490,14 +1493,24 @@ void launch_random_sample(hipStream_t s, const HopParams& p, const LanePtrs* d_l
         q.lds_k = k;
         int32_t gp = (max_super + k - 1) / k;                  // one workgroup per partition tile ...
         while (gp > 16 && (int64_t)gp * n_lanes > 16384) gp = (gp + 1) / 2;  // ... within reason
+        // a hop of few slots (the first hop of a B = 1024 batch: 25 600, ~400 claims per bucket): its 4096 one-bucket workgroups would
+        // be all launch (54 us of nothing per 512-lane group); ONE workgroup per lane takes the lane's buckets in turn instead
+        const int one_wg_lanes = tuning().lds_one_wg_lanes;
+        const bool one_wg_per_lane = small && one_wg_lanes > 0 && n_lanes >= one_wg_lanes && p.max_slots <= LG_DEDUP_ONE_WG_SLOTS;
         if (p.lds_bucket_bits == LG_LDS_BITS_SMALL) {
             if (stages & 1) sample_kernel<2, LG_LDS_BITS_SMALL, true><<<grid, LG_TILE, 0, s>>>(q, d_lanes);
             hipCheckError();
-            if (stages & 2) dedup_lists_kernel<LG_LDS_BITS_SMALL, LG_DEDUP_UNITS><<<dim3((1 << LG_LDS_BITS_SMALL) / LG_DEDUP_UNITS, n_lanes), LG_DEDUP_THREADS, 0, s>>>(q, d_lanes);
+            if (stages & 2) {
+                if (one_wg_per_lane) dedup_lists_kernel<LG_LDS_BITS_SMALL, 1 << LG_LDS_BITS_SMALL, 2><<<dim3(1, n_lanes), LG_DEDUP_THREADS, 0, s>>>(q, d_lanes);
+                else dedup_lists_kernel<LG_LDS_BITS_SMALL, LG_DEDUP_UNITS, LG_DEDUP_CLAIMS><<<dim3((1 << LG_LDS_BITS_SMALL) / LG_DEDUP_UNITS, n_lanes), LG_DEDUP_THREADS, 0, s>>>(q, d_lanes);
+            }
         } else if (p.lds_bucket_bits == LG_LDS_BITS_SMALL16) {
             if (stages & 1) sample_kernel<2, LG_LDS_BITS_SMALL16, true><<<grid, LG_TILE, 0, s>>>(q, d_lanes);
             hipCheckError();
-            if (stages & 2) dedup_lists_kernel<LG_LDS_BITS_SMALL16, LG_DEDUP_UNITS><<<dim3((1 << LG_LDS_BITS_SMALL16) / LG_DEDUP_UNITS, n_lanes), LG_DEDUP_THREADS, 0, s>>>(q, d_lanes);
+            if (stages & 2) {
+                if (one_wg_per_lane) dedup_lists_kernel<LG_LDS_BITS_SMALL16, 1 << LG_LDS_BITS_SMALL16, 2><<<dim3(1, n_lanes), LG_DEDUP_THREADS, 0, s>>>(q, d_lanes);
+                else dedup_lists_kernel<LG_LDS_BITS_SMALL16, LG_DEDUP_UNITS, LG_DEDUP_CLAIMS><<<dim3((1 << LG_LDS_BITS_SMALL16) / LG_DEDUP_UNITS, n_lanes), LG_DEDUP_THREADS, 0, s>>>(q, d_lanes);
+            }
         } else if (p.lds_bucket_bits == LG_LDS_BITS_MEDIUM) {
             if (k <= LG_PLACE_MAX_K) {
                 sample_kernel<2, LG_LDS_BITS_MEDIUM, false, true><<<dim3(gp, n_lanes), LG_TILE, 0, s>>>(q, d_lanes);

@@ -451,6 +451,27 @@ def test_lds_dedup_skewed_sub_bucket(hip, monkeypatch):
     gpu.close(); cpu.close()
 
 
+@pytest.mark.parametrize("buckets", ["8", "16"])
+@pytest.mark.parametrize("claim_cap", [None, "3"], ids=["lists", "lists-overflow"])
+def test_lds_dedup_one_workgroup_per_lane(hip, monkeypatch, claim_cap, buckets):
+    """LDS form, small hops: one de-duplication workgroup per lane takes the lane's buckets in turn, the next bucket's loads
+    requested before the current one's table work (large launch groups only by default: forced here).  Three hops, so that
+    the known lists and -- with 2 claims per thread in registers -- buckets that are not resident take part."""
+    monkeypatch.setenv("LEGION_DEDUP", "lds")
+    monkeypatch.setenv("LEGION_LDS_ONE_WG_LANES", "1")
+    monkeypatch.setenv("LEGION_LDS_SMALL_BUCKETS", buckets)
+    if claim_cap is not None:
+        monkeypatch.setenv("LEGION_LDS_CLAIM_CAP", claim_cap)
+    wl = Workload(scale=13, edge_factor=8, dim=4, n_seeds=2000)
+    fanout, batch = [6, 5, 4], 200                 # hops of 1200 / 6000 / 24000 slots: all below the one-workgroup limit; hop 3 has
+    gpu, cpu = GpuSide(wl, batch, fanout), CpuSide(wl, batch, fanout)      # ~2.5 k claims per bucket of 8 (> 2 per thread)
+    assert gpu.pools[0].dedup_form() == "lds"
+    for it in range(4):
+        compare_batches(gpu.run(0, it, 0), cpu.run(0, it, 0), f"one workgroup per lane (cap {claim_cap}, {buckets} buckets) batch {it}: ")
+    assert gpu.pools[0].error() == 0
+    gpu.close(); cpu.close()
+
+
 @pytest.mark.parametrize("known_cap", [None, "1", "80"], ids=["lists", "no-room", "some-buckets-overflow"])
 def test_lds_dedup_known_lists(hip, monkeypatch, known_cap):
     """LDS form, three hops: hops 2 and 3 recognise the nodes hops 1 and 2 added through the per-bucket lists scatter
