@@ -391,8 +391,9 @@ typedef struct LegionTuning {
     int32_t pos_table_bits;      /* LEGION_POS_TABLE_BITS  (0 = sized by num_ids): log2 words of the compact table (tests) */
     int32_t lds_known_cap;       /* LEGION_LDS_KNOWN_CAP   (0 = 2 x an even share): entries per known-node list (tests) */
     int32_t lds_claim_cap;       /* LEGION_LDS_CLAIM_CAP   (0 = 2 x an even share): entries per claim list of the 8/16-bucket classes (tests) */
-    int32_t lds_one_wg_lanes;    /* LEGION_LDS_ONE_WG_LANES (256): launch groups of at least this many lanes de-duplicate a hop of <= 32768 slots with
-                                    ONE workgroup per lane (all of the lane's buckets in turn) instead of one per bucket; 0 = never (tests: 1) */
+    int32_t lds_one_wg_lanes;    /* LEGION_LDS_ONE_WG_LANES (0 = never): launch groups of at least this many lanes de-duplicate a hop of <= 32768 slots
+                                    with ONE workgroup per lane (all of the lane's buckets in turn) instead of one per bucket: +1 % on one stream,
+                                    nothing under the weave */
     int32_t lds_part_wg;         /* LEGION_LDS_PART_WG     (8192): workgroups a partitioning sample launch aims for */
     int32_t lds_small_buckets;   /* LEGION_LDS_SMALL_BUCKETS (0 auto | 8 | 16): hash buckets per lane of pools whose hops have <= 2^19 slots;
                                     auto = 16 where PreSC saw more last-hop edges + earlier nodes than 8 buckets take in one pass */

@@ -1493,8 +1493,9 @@ void launch_random_sample(hipStream_t s, const HopParams& p, const LanePtrs* d_l
         q.lds_k = k;
         int32_t gp = (max_super + k - 1) / k;                  // one workgroup per partition tile ...
         while (gp > 16 && (int64_t)gp * n_lanes > 16384) gp = (gp + 1) / 2;  // ... within reason
-        // a hop of few slots (the first hop of a B = 1024 batch: 25 600, ~400 claims per bucket): its 4096 one-bucket workgroups would
-        // be all launch (54 us of nothing per 512-lane group); ONE workgroup per lane takes the lane's buckets in turn instead
+        // a hop of few slots (the first hop of a B = 1024 batch: 25 600, ~400 claims per bucket): its 4096 one-bucket workgroups are all
+        // launch (54 us of nothing per 512-lane group); ONE workgroup per lane can take the lane's buckets in turn instead
+        // (LegionTuning.lds_one_wg_lanes; off by default: no gain under the weave)
         const int one_wg_lanes = tuning().lds_one_wg_lanes;
         const bool one_wg_per_lane = small && one_wg_lanes > 0 && n_lanes >= one_wg_lanes && p.max_slots <= LG_DEDUP_ONE_WG_SLOTS;
         if (p.lds_bucket_bits == LG_LDS_BITS_SMALL) {
