@@ -576,7 +576,7 @@ def run_leg(c, engine, synth, stripe, replica_memory, headline, bulk=False):
         dist.barrier()
     else:
         pipe = engine.Pipeline(graph, feature, cache, d, B, fanout, G, feature_rows, not args.no_graph, args.slots,
-                               args.overlap, args.split, weave)
+                               args.overlap, args.split, weave, arena=bool(os.environ.get("LEGION_BENCH_ARENA")))
     torch.cuda.synchronize()
     if getattr(args, "probe_overlap", False) and headline and not bulk:
         # experiment: the last hop's de-duplication + compaction of one group beside the gathers of another
