@@ -168,6 +168,29 @@ def test_presc_topology_transactions_feed_cost_model(hip):
     gpu.close(); cpu.close()
 
 
+def test_overlap_probe_leaves_the_pipeline_usable(hip):
+    """`legion_pipeline_probe_overlap` (bench.py --probe-overlap) launches the last hop's kernels of one group stage by
+    stage beside the gathers of another: it must return six positive times, put the stage mask back to "everything" and leave
+    the pipeline producing the oracle's batches."""
+    import ctypes
+    from legion_amd import engine
+    wl = Workload(scale=11, edge_factor=8, dim=32, n_seeds=700)
+    fanout, batch, group = [6, 3], 64, 3
+    gpu, cpu = GpuSide(wl, batch, fanout), CpuSide(wl, batch, fanout)
+    pipe = engine.Pipeline(gpu.graph, gpu.feature, gpu.cache, 0, batch, fanout, group, gpu.pools[0].num_ids, True, 2, weave=True)
+    out = (ctypes.c_double * 6)()
+    for prep, side in ((1, 6), (3, 4), (1, 2)):
+        assert pipe._lib.legion_pipeline_probe_overlap(pipe.handle, 0, 0, out, prep, side) == 1
+        assert all(v > 0 for v in out), list(out)
+    for gi in range(2):
+        sl = pipe.submit(gi * group, 0)
+        pipe.wait(sl)
+        for lane in range(group):
+            compare_batches(engine.read_batch(pipe.pools[sl][lane]), cpu.run(0, gi * group + lane, 0), f"after the probe, batch {gi * group + lane}: ")
+    pipe.close()
+    gpu.close(); cpu.close()
+
+
 @pytest.mark.parametrize("group,slots,use_graph,split", [(1, 1, True, False), (3, 2, True, False), (4, 2, False, False),
                                                          (2, 3, True, False), (8, 2, True, False), (3, 2, True, True),
                                                          (4, 2, False, True), (2, 3, True, True), (1, 1, True, True),
