@@ -200,6 +200,9 @@ def parse_args():
                          "two, at most 512, halved while the lanes in flight would not fit 0.7 of the free HBM")
     ap.add_argument("--slots", type=int, default=2, help="groups in flight per GPU")
     ap.add_argument("--probe-overlap", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--lanes", dest="lane_arena", default=True, type=lambda v: {"arena": True, "plain-arena": "plain", "separate": False}[v],
+                    help="where the lanes' trainer-visible arrays live: arena (default: one arena of shuffled physical chunks), plain-arena (one plain "
+                         "allocation: what the server's hand-over needs), separate (an allocation per array and lane)")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
     ap.add_argument("--overlap", action="store_true", help="let kernels of different slots share the GPU")
     ap.add_argument("--split", action="store_true",
@@ -567,7 +570,7 @@ def run_leg(c, engine, synth, stripe, replica_memory, headline, bulk=False):
         # peer_gather = bulk (pipeline.hip): the rows of other members' stripes are pushed by their OWNERS; a group runs as
         # phase A (own sampler + lists + local gather) -> barrier -> phase B (push for the others) -> barrier, eager launches
         weave = False
-        pipe = BulkPipe(engine.Pipeline(graph, feature, cache, d, B, fanout, G, feature_rows, False, args.slots, arena=True), use_dist)
+        pipe = BulkPipe(engine.Pipeline(graph, feature, cache, d, B, fanout, G, feature_rows, False, args.slots, arena="plain"), use_dist)
         hs = [None] * world
         dist.all_gather_object(hs, pipe.p.bulk_export())
         for r, h in enumerate(hs):
@@ -576,7 +579,7 @@ def run_leg(c, engine, synth, stripe, replica_memory, headline, bulk=False):
         dist.barrier()
     else:
         pipe = engine.Pipeline(graph, feature, cache, d, B, fanout, G, feature_rows, not args.no_graph, args.slots,
-                               args.overlap, args.split, weave, arena=bool(os.environ.get("LEGION_BENCH_ARENA")))
+                               args.overlap, args.split, weave, arena=args.lane_arena)
     torch.cuda.synchronize()
     if getattr(args, "probe_overlap", False) and headline and not bulk:
         # experiment: the last hop's de-duplication + compaction of one group beside the gathers of another
@@ -728,7 +731,7 @@ def run_leg(c, engine, synth, stripe, replica_memory, headline, bulk=False):
     overlapped = None
     pipe.close()
     if headline and not args.split and not args.no_overlap_leg:
-        pipe = engine.Pipeline(graph, feature, cache, d, B, fanout, G, feature_rows, not args.no_graph, args.slots, False, True)
+        pipe = engine.Pipeline(graph, feature, cache, d, B, fanout, G, feature_rows, not args.no_graph, args.slots, False, True, arena=args.lane_arena)
         pipe.run_range(0, n_warm, wrap=wrap)
         pipe.wait()
         ov0, _ = timed_region(pipe)
@@ -884,7 +887,8 @@ def run_leg(c, engine, synth, stripe, replica_memory, headline, bulk=False):
                                         "hotness-ranked feature/topology caches in HBM")
                                        + (", vertex labels scrambled" if args.scramble else ""),
                            "parallelism": layout,
-                           "batches_per_launch_group": G, "groups_in_flight": args.slots, "epoch_batches": c.epoch_batches,
+                           "batches_per_launch_group": G, "groups_in_flight": args.slots,
+                           "lane_arrays": {True: "one arena of shuffled 2 MB physical chunks (LegionTuning.arena_scatter_mb)", "plain": "one plain arena", False: "separate allocations"}[args.lane_arena], "epoch_batches": c.epoch_batches,
                            "streams": "weave: head of group k+1 on a second stream under the heavy kernels of group k" if weave else
                                       ("split: sampler phase || gather phase" if args.split else "one"),
                            "epochs_wrap": bool(wrap), "hipgraph": not args.no_graph,

@@ -394,6 +394,10 @@ typedef struct LegionTuning {
     int32_t lds_one_wg_lanes;    /* LEGION_LDS_ONE_WG_LANES (0 = never): launch groups of at least this many lanes de-duplicate a hop of <= 32768 slots
                                     with ONE workgroup per lane (all of the lane's buckets in turn) instead of one per bucket: +1 % on one stream,
                                     nothing under the weave */
+    int32_t arena_scatter_mb;    /* LEGION_ARENA_SCATTER_MB (2; 0 = one plain allocation): a pipeline's own lane arena is built from physical chunks of
+                                    this many MB mapped in shuffled order (HIP virtual memory management): the gathers write a group's rows all over the
+                                    HBM instead of into one contiguous range (0.87 instead of 0.80 of the peak).  Arenas that another process or GPU
+                                    must reach (server hand-over, peer_gather = bulk) are always plain */
     int32_t lds_part_wg;         /* LEGION_LDS_PART_WG     (8192): workgroups a partitioning sample launch aims for */
     int32_t lds_small_buckets;   /* LEGION_LDS_SMALL_BUCKETS (0 auto | 8 | 16): hash buckets per lane of pools whose hops have <= 2^19 slots;
                                     auto = 16 where PreSC saw more last-hop edges + earlier nodes than 8 buckets take in one pass */

@@ -25,6 +25,7 @@
 #include <map>
 
 struct LegionLaneGroup;
+extern "C" void* d_alloc_scattered(int64_t num_bytes, int32_t chunk_mb);
 extern "C" LegionLaneGroup* legion_group_create(LegionMemoryPool** pools, int32_t n);
 extern "C" void legion_group_set_iter_state(LegionLaneGroup* g, int32_t* iter_state_devptr);
 extern "C" void legion_group_destroy(LegionLaneGroup* g);
@@ -166,7 +167,10 @@ extern "C" LegionPipeline* legion_pipeline_create(LegionGraphStorage* graph, Leg
         int64_t num_ids = batch_size, per = batch_size;
         for (int32_t h = 0; h < hop_num; h++) { per *= fanout[h]; num_ids += per; }
         p->arena.bytes = lg_pool_arena_bytes(batch_size, num_ids, feature_rows, D) * p->group_size * p->slots_n;
-        p->arena.base = (char*)d_alloc_space(p->arena.bytes);
+        // (use_graph bit 6: the arena must be reachable from another process or GPU -- peer_gather = bulk -- and is a plain allocation;
+        //  otherwise it is built from shuffled physical chunks, storage.hip d_alloc_scattered)
+        const int32_t chunk_mb = lg::tuning().arena_scatter_mb;
+        p->arena.base = (char*)(((use_graph & 64) == 0 && chunk_mb > 0) ? d_alloc_scattered(p->arena.bytes, chunk_mb) : d_alloc_space(p->arena.bytes));
         lg_set_pool_arena(&p->arena);
     }
     lg_set_pool_lanes_hint(p->group_size * p->slots_n);   // direct-vs-table choice of the position state sees every lane

@@ -11,6 +11,9 @@
 #include "legion_core.h"
 #include <unistd.h>
 #include <algorithm>
+#include <map>
+#include <mutex>
+#include <vector>
 
 #include <cstring>
 
@@ -50,6 +53,68 @@ extern "C" int32_t GetGPUDevice()
     int32_t dev_id = -1;
     HIP_CALL(hipGetDevice(&dev_id));
     return dev_id;
+}
+
+// ---- device memory whose pieces come from all over the HBM ----------------------------------------------------------------------------
+// One contiguous VIRTUAL range backed by physical chunks that are created one by one and mapped in shuffled order (HIP virtual memory
+// management).  Why ("where the lanes sit"): the last hop's gather writes a launch group's rows into the group's lanes; with
+// the lanes in one hipMalloc'ed block -- one contiguous physical range -- it runs at 0.80 of the HBM peak, with the same block built from
+// shuffled 2 MB ... 128 MB chunks at 0.87 (whole job 5.19 -> 5.57 G edges/s), better than what separate allocations get on a machine
+// whose free memory happens to be fragmented (0.84-0.85) and independent of that luck.  Not exportable with hipIpcGetMemHandle and
+// mapped for THIS device only: lanes that another process or another GPU must reach stay in plain allocations.
+namespace {
+struct ScatterLive { size_t bytes; std::vector<hipMemGenericAllocationHandle_t> chunks; };
+std::mutex g_scatter_mu;
+std::map<void*, ScatterLive> g_scatter_live;
+}
+extern "C" void* d_alloc_scattered(int64_t num_bytes, int32_t chunk_mb)
+{
+    int dev = 0;
+    HIP_CALL(hipGetDevice(&dev));
+    hipMemAllocationProp prop = {};
+    prop.type = hipMemAllocationTypePinned;
+    prop.location.type = hipMemLocationTypeDevice;
+    prop.location.id = dev;
+    size_t g0 = 0;
+    HIP_CALL(hipMemGetAllocationGranularity(&g0, &prop, hipMemAllocationGranularityRecommended));          // (4 KB on this stack)
+    const size_t want = (size_t)(chunk_mb > 0 ? chunk_mb : 2) << 20;
+    const size_t g = (want + g0 - 1) / g0 * g0;
+    const size_t n = ((size_t)(num_bytes > 0 ? num_bytes : 16) + g - 1) / g;
+    ScatterLive live;
+    live.bytes = n * g;
+    live.chunks.resize(n);
+    for (size_t i = 0; i < n; i++) HIP_CALL(hipMemCreate(&live.chunks[i], g, &prop, 0));
+    uint64_t r = 0x9E3779B97F4A7C15ull;
+    for (size_t i = n - 1; i > 0; i--) {                                                       // Fisher-Yates, fixed seed
+        r ^= r << 13; r ^= r >> 7; r ^= r << 17;
+        std::swap(live.chunks[i], live.chunks[(size_t)(r % (uint64_t)(i + 1))]);
+    }
+    void* ptr = nullptr;
+    HIP_CALL(hipMemAddressReserve(&ptr, n * g, 0, nullptr, 0));
+    for (size_t i = 0; i < n; i++) HIP_CALL(hipMemMap((char*)ptr + i * g, g, 0, live.chunks[i], 0));
+    hipMemAccessDesc acc = {};
+    acc.location.type = hipMemLocationTypeDevice;
+    acc.location.id = dev;
+    acc.flags = hipMemAccessFlagsProtReadWrite;
+    HIP_CALL(hipMemSetAccess(ptr, n * g, &acc, 1));
+    std::lock_guard<std::mutex> lk(g_scatter_mu);
+    g_scatter_live[ptr] = std::move(live);
+    return ptr;
+}
+static bool d_free_scattered(void* ptr)
+{
+    ScatterLive live;
+    {
+        std::lock_guard<std::mutex> lk(g_scatter_mu);
+        auto it = g_scatter_live.find(ptr);
+        if (it == g_scatter_live.end()) return false;
+        live = std::move(it->second);
+        g_scatter_live.erase(it);
+    }
+    HIP_CALL(hipMemUnmap(ptr, live.bytes));
+    HIP_CALL(hipMemAddressFree(ptr, live.bytes));
+    for (auto h : live.chunks) HIP_CALL(hipMemRelease(h));
+    return true;
 }
 
 extern "C" void* d_alloc_space(int64_t num_bytes)
@@ -114,7 +179,7 @@ void* lg_alloc_exported(int64_t num_bytes, void* handle64, const char* file, int
 
 extern "C" void d_free_space(void* d_ptr)
 {
-    if (d_ptr) HIP_CALL(hipFree(d_ptr));
+    if (d_ptr && !d_free_scattered(d_ptr)) HIP_CALL(hipFree(d_ptr));
 }
 
 extern "C" void* host_alloc_space(int64_t num_bytes)

@@ -42,6 +42,7 @@ void parse_env(LegionTuning& t)
     t.lds_known_cap = env_int("LEGION_LDS_KNOWN_CAP", 0);
     t.lds_claim_cap = env_int("LEGION_LDS_CLAIM_CAP", 0);
     t.lds_one_wg_lanes = env_int("LEGION_LDS_ONE_WG_LANES", 0);
+    t.arena_scatter_mb = env_int("LEGION_ARENA_SCATTER_MB", 2);
     t.lds_part_wg = env_int("LEGION_LDS_PART_WG", 8192);
     t.lds_small_buckets = env_int("LEGION_LDS_SMALL_BUCKETS", 0);
     t.sample_max_wg = env_int("LEGION_SAMPLE_MAX_WG", 4096);

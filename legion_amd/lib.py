@@ -151,7 +151,7 @@ class LinkCounters(ctypes.Structure):          # LegionLinkCounters
 
 class Tuning(ctypes.Structure):                # LegionTuning (include/legion_hip.h section 6)
     _fields_ = [(n, c_i32) for n in (
-        "dedup_form", "pos_value_bits", "pos_table_bits", "lds_known_cap", "lds_claim_cap", "lds_one_wg_lanes", "lds_part_wg", "lds_small_buckets", "sample_max_wg", "loser_in_dst",
+        "dedup_form", "pos_value_bits", "pos_table_bits", "lds_known_cap", "lds_claim_cap", "lds_one_wg_lanes", "arena_scatter_mb", "lds_part_wg", "lds_small_buckets", "sample_max_wg", "loser_in_dst",
         "gather_small_tiles", "gather_rows_per_wg", "compact_hoist", "col_slots", "split_sampler_cus", "split_priority", "weave_priority", "weave_early_gathers", "runner_graph", "runner_lanes",
         "runner_ho_stream", "runner_stats", "runner_handover", "runner_slots", "peer_gather", "feature_pitch", "hotness_reduce", "markers", "table_placement", "shm_mirror", "link_counters")] + \
         [("link_counter_values", c_u64 * 2)]

@@ -93,7 +93,7 @@ def _worker(rank, world, port, q):
         # ---- the same batches with the remote rows moved by the OWNERS (peer_gather = bulk): lists and lane arenas exchanged as
         #      IPC handles, two host barriers per launch group ------------------------------------------------------------
         G = 3
-        pipe = engine.Pipeline(graph, feature, cache, rank, batch, fanout, G, pool.num_ids, use_graph=False, slots=2, arena=True)
+        pipe = engine.Pipeline(graph, feature, cache, rank, batch, fanout, G, pool.num_ids, use_graph=False, slots=2, arena="plain")
         pipe.bulk_enable()
         for r, h in enumerate(all_gather_bytes(pipe.bulk_export())):
             if r != rank:

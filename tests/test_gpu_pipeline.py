@@ -168,6 +168,29 @@ def test_presc_topology_transactions_feed_cost_model(hip):
     gpu.close(); cpu.close()
 
 
+@pytest.mark.parametrize("chunk_mb", [None, "64", "0"], ids=["2MB-chunks", "64MB-chunks", "plain"])
+def test_pipeline_lanes_in_a_scattered_arena(hip, monkeypatch, chunk_mb):
+    """arena=True: every lane's trainer-visible arrays live in ONE arena built from physical chunks mapped in shuffled order (HIP
+    virtual memory management, storage.hip d_alloc_scattered; LEGION_ARENA_SCATTER_MB=0: one plain allocation).  Same batches as
+    the oracle's under graph replay and the weave, twice (the second pipeline re-uses what the first one released)."""
+    from legion_amd import engine
+    if chunk_mb is not None:
+        monkeypatch.setenv("LEGION_ARENA_SCATTER_MB", chunk_mb)
+    wl = Workload(scale=11, edge_factor=8, dim=32, n_seeds=700)
+    fanout, batch, group = [6, 3], 64, 4
+    gpu, cpu = GpuSide(wl, batch, fanout), CpuSide(wl, batch, fanout)
+    for rep in range(2):
+        pipe = engine.Pipeline(gpu.graph, gpu.feature, gpu.cache, 0, batch, fanout, group, gpu.pools[0].num_ids, True, 2, weave=True, arena=True)
+        for gi in range(3):
+            sl = pipe.submit(gi * group, 0)
+            pipe.wait(sl)
+            for lane in range(group):
+                compare_batches(engine.read_batch(pipe.pools[sl][lane]), cpu.run(0, gi * group + lane, 0),
+                                f"scattered arena ({chunk_mb}) rep {rep} batch {gi * group + lane}: ")
+        pipe.close()
+    gpu.close(); cpu.close()
+
+
 def test_overlap_probe_leaves_the_pipeline_usable(hip):
     """`legion_pipeline_probe_overlap` (bench.py --probe-overlap) launches the last hop's kernels of one group stage by
     stage beside the gathers of another: it must return six positive times, put the stage mask back to "everything" and leave
@@ -627,7 +650,7 @@ def test_owner_bucketed_bulk_transfer_matches_direct_peer_loads(hip, col_slots, 
     Kg = cpu.Kg
     from oracle import ffi
     rows = ffi.num_ids_for(batch, fanout)
-    pipes = [engine.Pipeline(gpu.graph, gpu.feature, gpu.cache, p, batch, fanout, G, rows, use_graph=False, slots=2, arena=True)
+    pipes = [engine.Pipeline(gpu.graph, gpu.feature, gpu.cache, p, batch, fanout, G, rows, use_graph=False, slots=2, arena="plain")
              for p in range(P)]
     for pl in pipes:
         pl.bulk_enable()

@@ -7,7 +7,7 @@ OUT=$R/gpurun_out/value_rounds.txt; mkdir -p $R/gpurun_out; : > $OUT
 for i in $(seq 1 ${ROUNDS:-5}); do
   for n in "$@"; do
     if [ $n = base ]; then unset LEGION_HIP_LIB; else export LEGION_HIP_LIB=$V/v_$n/liblegion_hip.so; fi
-    unset LEGION_LDS_SMALL_BUCKETS LEGION_SAMPLE_MAX_WG LEGION_BENCH_ARENA LEGION_ARENA_ALIGN LEGION_ARENA_JITTER LEGION_SCATTER_LANES; [ -f $V/v_$n/env ] && . $V/v_$n/env
+    unset LEGION_LDS_SMALL_BUCKETS LEGION_SAMPLE_MAX_WG LEGION_BENCH_ARENA LEGION_ARENA_ALIGN LEGION_ARENA_JITTER LEGION_SCATTER_LANES LEGION_SCATTER_ARENA LEGION_SCATTER_CHUNK_MB LEGION_ARENA_ORDER; [ -f $V/v_$n/env ] && . $V/v_$n/env
     echo -n "$n " >> $OUT
     timeout -k 5 200 python3 $R/bench.py --no-boundary --no-overlap-leg --cpu-seconds 0 --no-verify $EXTRA 2>/dev/null < /dev/null | tail -1 | python3 -c "import json,sys; d=json.loads(sys.stdin.read()); print(round(d['value']/1e9,4), round(d['ms_per_step'],4), round(d['roofline']['frac'],4))" >> $OUT
   done
