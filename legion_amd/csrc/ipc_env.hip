@@ -10,6 +10,11 @@
 // hipIpcMemHandle_t is 64 bytes like cudaIpcMemHandle_t.  LEGION_IPC_NAMESPACE (optional env)
 // suffixes the shm/semaphore names so that independent servers (tests) can share a host.
 #include "legion_core.h"
+#include <sys/socket.h>
+#include <sys/un.h>
+#include <cerrno>
+#include <cstddef>
+#include <thread>
 
 #include <fcntl.h>
 #include <semaphore.h>
@@ -43,9 +48,11 @@ static_assert(offsetof(shmStruct, memHandle) == 12 && sizeof(shmStruct) == 12 + 
 // sem_post; from then on a hand-over is no GPU work at all: the server writes, per (device, pipe slot), where the five
 // trainer-visible arrays of the batch start inside the arena and posts sem_w -- same semaphores, same two-slot order, and
 // the reference-sized slab above stays valid for a trainer that knows nothing of this (it gets copies in the slot buffers).
+extern "C" int64_t lg_scattered_info(void* ptr, int32_t* n_chunks);
+extern "C" int lg_scattered_export_fd(void* ptr, int32_t index);
 typedef struct shmExt_st {
     int32_t ext_magic;                                         // LEGION_SHM_EXT_MAGIC once the mirror below is live
-    int32_t ext_version;                                       // 2: the fields behind `counters` exist
+    int32_t ext_version;                                       // >= 2: the fields behind `counters` exist; 3: those behind `view` too
     int32_t server_state;                                      // 0 serving, 1 the server stopped on an error (trainers must not wait)
     int32_t ext_reserved;
     int32_t counters[MAX_DEVICE][INTERBATCH_CON][32];          // [0..15] node_counter, [16..31] edge_counter
@@ -54,8 +61,17 @@ typedef struct shmExt_st {
     int32_t trainer_direct[MAX_DEVICE];                        // written by the trainer end: 1 = it opened the arena and takes views
     int32_t view_on[MAX_DEVICE][INTERBATCH_CON];               // 1: the batch in this slot is the view below, 0: it is in the slot's buffers
     int64_t view[MAX_DEVICE][INTERBATCH_CON][5];               // byte offsets into the arena: ids, features, labels, agg_src, agg_dst
+    // version 3: the arena may be built from physical chunks mapped in shuffled order (storage.hip d_alloc_scattered: the gathers then
+    // write a group's rows all over the HBM, +7 %), which hipIpcGetMemHandle cannot export.  arena_kind 1: `arena` is unused; the trainer
+    // connects to the abstract unix socket "legion_arena_<arena_sock_pid>_<dev>", receives arena_chunks file descriptors (SCM_RIGHTS, in
+    // mapping order), imports each (hipMemImportFromShareableHandle) and maps them back to back: arena_chunks x arena_chunk_bytes >= arena_bytes
+    int32_t arena_kind[MAX_DEVICE];
+    int32_t arena_chunks[MAX_DEVICE];
+    int64_t arena_chunk_bytes[MAX_DEVICE];
+    int32_t arena_sock_pid;
+    int32_t ext_reserved2;
 } shmExt;
-#define LEGION_SHM_EXT_VERSION 2
+#define LEGION_SHM_EXT_VERSION 3
 
 typedef struct sharedMemoryInfo_st {
     void* addr;
@@ -302,6 +318,51 @@ public:
     bool PublishArena(int32_t dev_id, void* base, int64_t bytes) override
     {
         if (!ext_ || !ext_dev_ || base == nullptr || bytes <= 0) return false;
+        int32_t n_chunks = 0;
+        const int64_t chunk_bytes = lg_scattered_info(base, &n_chunks);
+        if (chunk_bytes > 0) {          // an arena of shuffled chunks: handed over as file descriptors (shmExt, version 3)
+            const int ls = socket(AF_UNIX, SOCK_STREAM | SOCK_CLOEXEC, 0);
+            if (ls < 0) return false;
+            sockaddr_un addr;
+            memset(&addr, 0, sizeof(addr));
+            addr.sun_family = AF_UNIX;
+            const int len = snprintf(addr.sun_path + 1, sizeof(addr.sun_path) - 1, "legion_arena_%d_%d", (int)getpid(), dev_id);
+            if (bind(ls, (sockaddr*)&addr, (socklen_t)(offsetof(sockaddr_un, sun_path) + 1 + len)) != 0 || listen(ls, 8) != 0) { close(ls); return false; }
+            std::thread([ls, base, n_chunks]() {
+                for (;;) {
+                    const int c = accept(ls, nullptr, nullptr);
+                    if (c < 0) { if (errno == EINTR) continue; return; }
+                    bool ok = true;
+                    for (int32_t i0 = 0; i0 < n_chunks && ok; i0 += 64) {           // 64 descriptors per message
+                        const int32_t n = std::min(64, n_chunks - i0);
+                        int fds[64];
+                        for (int32_t i = 0; i < n; i++) { fds[i] = lg_scattered_export_fd(base, i0 + i); ok = ok && fds[i] >= 0; }
+                        if (ok) {
+                            char payload = 'f';
+                            iovec io = {&payload, 1};
+                            alignas(cmsghdr) char ctl[CMSG_SPACE(sizeof(int) * 64)];
+                            memset(ctl, 0, sizeof(ctl));
+                            msghdr msg;
+                            memset(&msg, 0, sizeof(msg));
+                            msg.msg_iov = &io; msg.msg_iovlen = 1; msg.msg_control = ctl; msg.msg_controllen = CMSG_SPACE(sizeof(int) * n);
+                            cmsghdr* cm = CMSG_FIRSTHDR(&msg);
+                            cm->cmsg_level = SOL_SOCKET; cm->cmsg_type = SCM_RIGHTS; cm->cmsg_len = CMSG_LEN(sizeof(int) * n);
+                            memcpy(CMSG_DATA(cm), fds, sizeof(int) * n);
+                            ok = sendmsg(c, &msg, MSG_NOSIGNAL) == 1;
+                        }
+                        for (int32_t i = 0; i < n; i++) if (fds[i] >= 0) close(fds[i]);
+                    }
+                    close(c);
+                }
+            }).detach();
+            ext_->arena_kind[dev_id] = 1;
+            ext_->arena_chunks[dev_id] = n_chunks;
+            ext_->arena_chunk_bytes[dev_id] = chunk_bytes;
+            ext_->arena_sock_pid = (int32_t)getpid();
+            __sync_synchronize();
+            ext_->arena_bytes[dev_id] = bytes;
+            return true;
+        }
         hipIpcMemHandle_t h;
         lg_ipc_export(&h, base, __FILE__, __LINE__);
         memcpy((void*)&ext_->arena[dev_id], &h, sizeof(h));

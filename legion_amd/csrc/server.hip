@@ -13,6 +13,7 @@
 // only stream 0's last event).  Full CSR / feature table go to HBM when they fit
 // (288 GB per MI355X), to mapped pinned host memory otherwise.
 #include "legion_core.h"
+extern "C" void* d_alloc_scattered_exportable(int64_t num_bytes, int32_t chunk_mb);
 #include "runner_schedule.h"
 
 #include <fcntl.h>
@@ -688,7 +689,14 @@ private:
         HIP_CALL(hipMemGetInfo(&free_b, &total_b));
         while (lanes_ > 1 && (int64_t)lanes_ * slots_ * lane_bytes > (int64_t)(free_b / 10 * 6)) lanes_ /= 2;
         arena_.bytes = arena_lane * lanes_ * slots_;
-        arena_.base = (char*)d_alloc_space(arena_.bytes);
+        // The arena is built from physical chunks mapped in shuffled order unless another GPU must reach it (peer_gather = bulk):
+        // 128 MB chunks -- a trainer end receives them as file descriptors (IPCEnv::PublishArena) -- against the 2 MB of an arena
+        // nobody else maps; LegionTuning.arena_scatter_mb = 0: one plain allocation, handed over as a hipIpcMemHandle.
+        {
+            const int32_t mb = tune.arena_scatter_mb;
+            const bool plain = mb <= 0 || tune.peer_gather != 0;
+            arena_.base = (char*)(plain ? d_alloc_space(arena_.bytes) : d_alloc_scattered_exportable(arena_.bytes, std::max(mb, 128)));
+        }
         arena_.used = 0;
         arena_.mirror_lanes = lanes_ * slots_;
         arena_.mirror_used = 0;

@@ -67,7 +67,11 @@ struct ScatterLive { size_t bytes; std::vector<hipMemGenericAllocationHandle_t> 
 std::mutex g_scatter_mu;
 std::map<void*, ScatterLive> g_scatter_live;
 }
-extern "C" void* d_alloc_scattered(int64_t num_bytes, int32_t chunk_mb)
+static void* alloc_scattered(int64_t num_bytes, int32_t chunk_mb, bool exportable);
+extern "C" void* d_alloc_scattered(int64_t num_bytes, int32_t chunk_mb) { return alloc_scattered(num_bytes, chunk_mb, false); }
+// ... whose chunks can be handed to another process as file descriptors (the server's lane arena: lg_scattered_export_fd)
+extern "C" void* d_alloc_scattered_exportable(int64_t num_bytes, int32_t chunk_mb) { return alloc_scattered(num_bytes, chunk_mb, true); }
+static void* alloc_scattered(int64_t num_bytes, int32_t chunk_mb, bool exportable)
 {
     int dev = 0;
     HIP_CALL(hipGetDevice(&dev));
@@ -75,6 +79,7 @@ extern "C" void* d_alloc_scattered(int64_t num_bytes, int32_t chunk_mb)
     prop.type = hipMemAllocationTypePinned;
     prop.location.type = hipMemLocationTypeDevice;
     prop.location.id = dev;
+    if (exportable) prop.requestedHandleType = hipMemHandleTypePosixFileDescriptor;
     size_t g0 = 0;
     HIP_CALL(hipMemGetAllocationGranularity(&g0, &prop, hipMemAllocationGranularityRecommended));          // (4 KB on this stack)
     const size_t want = (size_t)(chunk_mb > 0 ? chunk_mb : 2) << 20;
@@ -100,6 +105,29 @@ extern "C" void* d_alloc_scattered(int64_t num_bytes, int32_t chunk_mb)
     std::lock_guard<std::mutex> lk(g_scatter_mu);
     g_scatter_live[ptr] = std::move(live);
     return ptr;
+}
+// chunk size of a scattered allocation (0: `ptr` is not one) and its number of chunks, in mapping order
+extern "C" int64_t lg_scattered_info(void* ptr, int32_t* n_chunks)
+{
+    std::lock_guard<std::mutex> lk(g_scatter_mu);
+    auto it = g_scatter_live.find(ptr);
+    if (it == g_scatter_live.end() || it->second.chunks.empty()) return 0;
+    if (n_chunks) *n_chunks = (int32_t)it->second.chunks.size();
+    return (int64_t)(it->second.bytes / it->second.chunks.size());
+}
+// a new file descriptor for chunk `index` of an exportable scattered allocation (the caller closes it), or -1
+extern "C" int lg_scattered_export_fd(void* ptr, int32_t index)
+{
+    hipMemGenericAllocationHandle_t h;
+    {
+        std::lock_guard<std::mutex> lk(g_scatter_mu);
+        auto it = g_scatter_live.find(ptr);
+        if (it == g_scatter_live.end() || index < 0 || (size_t)index >= it->second.chunks.size()) return -1;
+        h = it->second.chunks[(size_t)index];
+    }
+    int fd = -1;
+    if (hipMemExportToShareableHandle(&fd, h, hipMemHandleTypePosixFileDescriptor, 0) != hipSuccess) { (void)hipGetLastError(); return -1; }
+    return fd;
 }
 static bool d_free_scattered(void* ptr)
 {

@@ -8,6 +8,9 @@
 // (0 ids, 1 features, 2 labels, 3 agg_src, 4 agg_dst, 5 node_counter, 6 edge_counter).
 // HIP runtime calls replace the CUDA ones (hipIpcOpenMemHandle, hipMemcpy); there is no device
 // code in this module.  LEGION_IPC_NAMESPACE (optional) must match the server's.
+#include <sys/socket.h>
+#include <sys/un.h>
+#include <cstddef>
 #include <fcntl.h>
 #include <semaphore.h>
 #include <sys/mman.h>
@@ -65,8 +68,73 @@ typedef struct shmExt_st {
     int32_t trainer_direct[MAX_DEVICE];
     int32_t view_on[MAX_DEVICE][INTERBATCH_CON];
     int64_t view[MAX_DEVICE][INTERBATCH_CON][5];
+    // version 3 (ipc_env.hip): arena_kind 1 = the arena consists of arena_chunks physical chunks of arena_chunk_bytes, received as file
+    // descriptors from the abstract unix socket "legion_arena_<arena_sock_pid>_<dev>" and mapped back to back
+    int32_t arena_kind[MAX_DEVICE];
+    int32_t arena_chunks[MAX_DEVICE];
+    int64_t arena_chunk_bytes[MAX_DEVICE];
+    int32_t arena_sock_pid;
+    int32_t ext_reserved2;
 } shmExt;
 static_assert(sizeof(hipIpcMemHandle_t) == 64, "IPC handle size is part of the wire format");
+
+// The server's lane arena as chunks: connect, receive the descriptors (64 per message), import and map them in order.
+static void* map_arena_chunks(int pid, int dev, int n_chunks, long long chunk_bytes, int hip_dev, std::string* why)
+{
+    const int c = socket(AF_UNIX, SOCK_STREAM | SOCK_CLOEXEC, 0);
+    if (c < 0) { *why = "socket()"; return nullptr; }
+    sockaddr_un addr;
+    memset(&addr, 0, sizeof(addr));
+    addr.sun_family = AF_UNIX;
+    const int len = snprintf(addr.sun_path + 1, sizeof(addr.sun_path) - 1, "legion_arena_%d_%d", pid, dev);
+    if (connect(c, (sockaddr*)&addr, (socklen_t)(offsetof(sockaddr_un, sun_path) + 1 + len)) != 0) { close(c); *why = "connect()"; return nullptr; }
+    void* base = nullptr;
+    if (hipMemAddressReserve(&base, (size_t)n_chunks * (size_t)chunk_bytes, 0, nullptr, 0) != hipSuccess) { (void)hipGetLastError(); close(c); *why = "hipMemAddressReserve"; return nullptr; }
+    int got = 0, rt_version = 0;
+    (void)hipRuntimeGetVersion(&rt_version);
+    const bool fd_by_value = rt_version >= 70200000;
+    bool ok = true;
+    while (got < n_chunks && ok) {
+        char payload = 0;
+        iovec io = {&payload, 1};
+        alignas(cmsghdr) char ctl[CMSG_SPACE(sizeof(int) * 64)];
+        msghdr msg;
+        memset(&msg, 0, sizeof(msg));
+        msg.msg_iov = &io; msg.msg_iovlen = 1; msg.msg_control = ctl; msg.msg_controllen = sizeof(ctl);
+        if (recvmsg(c, &msg, MSG_CMSG_CLOEXEC) != 1) { *why = "recvmsg()"; ok = false; break; }
+        cmsghdr* cm = CMSG_FIRSTHDR(&msg);
+        if (cm == nullptr || cm->cmsg_level != SOL_SOCKET || cm->cmsg_type != SCM_RIGHTS) { *why = "no descriptors in the message"; ok = false; break; }
+        const int n = (int)((cm->cmsg_len - CMSG_LEN(0)) / sizeof(int));
+        int fds[64];
+        memcpy(fds, CMSG_DATA(cm), sizeof(int) * (size_t)n);
+        for (int i = 0; i < n; i++) {
+            if (ok && got < n_chunks) {
+                hipMemGenericAllocationHandle_t h;
+                // (the HIP runtime bundled with torch 2.10+rocm7.0 -- the one this module runs on inside a trainer -- takes a POINTER to the
+                //  descriptor and crashes on the value; ROCm 7.2's takes the value, as CUDA's does: tools/micro/vmm_torch_probe.py)
+                void* os_handle = fd_by_value ? (void*)(uintptr_t)fds[i] : (void*)&fds[i];
+                if (hipMemImportFromShareableHandle(&h, os_handle, hipMemHandleTypePosixFileDescriptor) != hipSuccess ||
+                    hipMemMap((char*)base + (size_t)got * (size_t)chunk_bytes, (size_t)chunk_bytes, 0, h, 0) != hipSuccess) {
+                    (void)hipGetLastError();
+                    *why = "hipMemImportFromShareableHandle / hipMemMap";
+                    ok = false;
+                } else {
+                    got++;
+                }
+            }
+            close(fds[i]);
+        }
+    }
+    close(c);
+    if (ok) {
+        hipMemAccessDesc acc = {};
+        acc.location.type = hipMemLocationTypeDevice;
+        acc.location.id = hip_dev;
+        acc.flags = hipMemAccessFlagsProtReadWrite;
+        if (hipMemSetAccess(base, (size_t)n_chunks * (size_t)chunk_bytes, &acc, 1) != hipSuccess) { (void)hipGetLastError(); *why = "hipMemSetAccess"; ok = false; }
+    }
+    return ok ? base : nullptr;      // (on failure what was mapped stays mapped: the process falls back to the pipe slots)
+}
 
 static std::string ipc_suffix()
 {
@@ -135,7 +203,24 @@ public:
         }
         // direct views: open the server's lane arena and say so BEFORE the first sem_post below (the server reads the flag
         // when its first wait returns)
-        if (mirror_ != nullptr && mirror_->ext_version >= 2 && mirror_->arena_bytes[central_device] > 0 && !getenv("LEGION_NO_DIRECT_VIEWS")) {
+        if (mirror_ != nullptr && mirror_->ext_version >= 3 && mirror_->arena_bytes[central_device] > 0 && mirror_->arena_kind[central_device] == 1 &&
+            !getenv("LEGION_NO_DIRECT_VIEWS")) {
+            int hip_dev = 0;
+            (void)hipGetDevice(&hip_dev);
+            std::string why;
+            arena_ = map_arena_chunks(mirror_->arena_sock_pid, central_device, mirror_->arena_chunks[central_device],
+                                      mirror_->arena_chunk_bytes[central_device], hip_dev, &why);
+            if (arena_ != nullptr) {
+                arena_bytes_ = mirror_->arena_bytes[central_device];
+                arena_is_chunks_ = true;
+                mirror_->trainer_direct[central_device] = 1;
+                __sync_synchronize();
+                std::cout << "HIP: " << central_device << " lane arena mapped (" << (arena_bytes_ >> 20) << " MiB in " << mirror_->arena_chunks[central_device]
+                          << " chunks): batches arrive as views" << std::endl;
+            } else {
+                printf("ipc_service: could not map the server's lane arena (%s); batches arrive in the pipe slots\n", why.c_str());
+            }
+        } else if (mirror_ != nullptr && mirror_->ext_version >= 2 && mirror_->arena_bytes[central_device] > 0 && !getenv("LEGION_NO_DIRECT_VIEWS")) {
             hipIpcMemHandle_t h = *(hipIpcMemHandle_t*)&mirror_->arena[central_device];
             hipError_t e = hipIpcOpenMemHandle(&arena_, h, hipIpcMemLazyEnablePeerAccess);
             for (int attempt = 0; e != hipSuccess && attempt < 10; attempt++) {
@@ -226,7 +311,7 @@ public:
             if (sem_close(semw_[i]) == -1) std::cout << "close sem " << i << " failed\n";
             sem_close(semr_[i]);
         }
-        if (arena_ != nullptr && getenv("LEGION_IPC_CLOSE_ARENA")) hipIpcCloseMemHandle(arena_);
+        if (arena_ != nullptr && !arena_is_chunks_ && getenv("LEGION_IPC_CLOSE_ARENA")) hipIpcCloseMemHandle(arena_);
         arena_ = nullptr;
     }
 
@@ -240,6 +325,7 @@ private:
     volatile shmExt* mirror_ = nullptr;
     void* arena_ = nullptr;          // the server's lane arena, opened (direct views), or null
     long long arena_bytes_ = 0;
+    bool arena_is_chunks_ = false;   // mapped from file descriptors (stays mapped until the process ends)
 };
 
 static GPUIPCEnv* env = nullptr;

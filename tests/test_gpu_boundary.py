@@ -50,9 +50,11 @@ def write_dataset(path, wl_indptr, wl_col, feats, labels, train, valid, test):
     {"LEGION_RUNNER_HANDOVER": "gather", "LEGION_RUNNER_LANES": "5", "LEGION_RUNNER_HO_STREAM": "0"},   # hand-overs on the pipeline's own stream
     {"LEGION_RUNNER_HANDOVER": "gather", "LEGION_RUNNER_LANES": "6", "LEGION_RUNNER_HO_STREAM": "1"},   # one hand-over stream for both pipe slots
     {"LEGION_HOTNESS_REDUCE": "rccl"},                         # the clique sum of the access counters as the library's RCCL all-reduce (a 1-rank communicator here)
+    {"LEGION_ARENA_SCATTER_MB": "0"},                          # the lane arena as ONE plain allocation, handed over as a hipIpcMemHandle (default: shuffled chunks, as file descriptors)
+    {"LEGION_ARENA_SCATTER_MB": "0", "LEGION_RUNNER_LANES": "3"},
 ], ids=["default-views", "views-lanes3", "views-lanes1", "views-lanes2-two-groups-direct-state", "views-lanes2-four-groups", "trainer-without-views",
         "trainer-without-views-lanes3", "copy-lanes5", "copy-lanes4-one-stream", "gather", "gather-lanes4-table", "gather-lanes1", "operators",
-        "no-mirror", "gather-lanes5-one-stream", "gather-lanes6-shared-ho-stream", "rccl-hotness-reduce"])
+        "no-mirror", "gather-lanes5-one-stream", "gather-lanes6-shared-ho-stream", "rccl-hotness-reduce", "views-plain-arena", "views-plain-arena-lanes3"])
 def test_server_binary_serves_fake_trainer(hip, tmp_path, server_env, monkeypatch):
     for k, v in server_env.items():
         monkeypatch.setenv(k, v)
