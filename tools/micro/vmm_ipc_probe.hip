@@ -1,5 +1,5 @@
 // Can a chunk made with hipMemCreate be handed to another process as a file descriptor?  (the server's lane arena in shuffled chunks needs it)
-//   hipcc --offload-arch=gfx950 -o tools/micro/vmm_ipc_probe tools/micro/vmm_ipc_probe.cpp && tools/micro/vmm_ipc_probe
+//   hipcc --offload-arch=gfx950 -o /tmp/vmm_ipc_probe tools/micro/vmm_ipc_probe.hip && /tmp/vmm_ipc_probe
 #include <hip/hip_runtime.h>
 #include <sys/socket.h>
 #include <sys/wait.h>
