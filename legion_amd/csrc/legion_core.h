@@ -721,6 +721,7 @@ struct PoolArena {
     int32_t mirror_lanes = 0, mirror_used = 0;
 };
 void lg_set_pool_arena(PoolArena* arena);
+PoolArena* lg_get_pool_arena();
 int64_t lg_pool_arena_bytes(int64_t batch_size, int64_t num_ids, int64_t feature_rows, int64_t float_feature_len);
 
 // alloc helpers, SS/engine/server_imp.cuh:2-51

@@ -26,6 +26,11 @@
 
 struct LegionLaneGroup;
 extern "C" void* d_alloc_scattered(int64_t num_bytes, int32_t chunk_mb);
+extern "C" void* lg_private_arena_begin(int64_t bytes, int32_t scatter_mb);
+extern "C" void lg_private_arena_end();
+extern "C" void lg_private_arena_free(void* handle);
+extern "C" void lg_alloc_count_begin();
+extern "C" int64_t lg_alloc_count_end();
 extern "C" LegionLaneGroup* legion_group_create(LegionMemoryPool** pools, int32_t n);
 extern "C" void legion_group_set_iter_state(LegionLaneGroup* g, int32_t* iter_state_devptr);
 extern "C" void legion_group_destroy(LegionLaneGroup* g);
@@ -93,6 +98,7 @@ struct LegionPipeline {
     std::map<int32_t, int64_t> prof_cnt;
     PoolArena arena;                          // use_graph bit 5: the lanes' trainer-visible arrays live in ONE exportable allocation
     BulkState* bulk = nullptr;
+    void* priv_arena = nullptr;               // the block of shuffled chunks the lanes' private arrays were carved from (arena pipelines)
     bool arena_borrowed = false;              // the arena belongs to the caller (legion_pipeline_bulk_enable_shared)
     int64_t feature_rows = 0;
 };
@@ -180,6 +186,23 @@ extern "C" LegionPipeline* legion_pipeline_create(LegionGraphStorage* graph, Leg
             reinterpret_cast<UnifiedCache*>(p->cache_handle)->LastHopMax(dev_id, last_hop);
         lg_set_pool_claims_hint(last_hop[0], last_hop[1]);
     }
+    // Arena pipelines (own arena or the caller's -- the server's) also carve their lanes' PRIVATE arrays from one block of shuffled
+    // chunks (storage.hip): one lane is created with plain allocations first, only to add up what a lane asks for.
+    if (lg_get_pool_arena() != nullptr && lg::tuning().arena_scatter_mb > 0 && !(getenv("LEGION_PRIVATE_ARENA") && atoi(getenv("LEGION_PRIVATE_ARENA")) == 0)) {
+        PoolArena* trainer_arena = lg_get_pool_arena();
+        lg_set_pool_arena(nullptr);
+        lg_alloc_count_begin();
+        LegionMemoryPool* probe = legion_pool_create(dev_id, p->feature->TotalNodeNum(), batch_size, fanout, hop_num, p->feature->GetFloatFeatureLen(), 1);
+        if (feature_rows > 0) legion_pool_alloc_features(probe, feature_rows);
+        const int64_t asked = lg_alloc_count_end();
+        legion_pool_destroy(probe);
+        lg_set_pool_arena(trainer_arena);
+        int64_t num_ids = batch_size, per = batch_size;
+        for (int32_t h = 0; h < hop_num; h++) { per *= fanout[h]; num_ids += per; }
+        const int64_t visible = lg_pool_arena_bytes(batch_size, num_ids, feature_rows, p->feature->GetFloatFeatureLen());
+        const int64_t lane = std::max<int64_t>(asked - visible, 0) + (64 << 10);
+        p->priv_arena = lg_private_arena_begin(lane * p->group_size * p->slots_n + ((int64_t)8 << 20), lg::tuning().arena_scatter_mb);
+    }
     for (Slot& sl : p->slots) {
         std::vector<LegionMemoryPool*> handles;
         for (int32_t g = 0; g < p->group_size; g++) {
@@ -211,6 +234,7 @@ extern "C" LegionPipeline* legion_pipeline_create(LegionGraphStorage* graph, Leg
     lg_set_pool_lanes_hint(0);
     lg_set_pool_claims_hint(0, 0);
     lg_set_pool_arena(nullptr);
+    if (p->priv_arena) lg_private_arena_end();
     return p;
 }
 
@@ -537,6 +561,7 @@ extern "C" void legion_pipeline_destroy(LegionPipeline* p)
         delete p->bulk;
     }
     if (p->arena.base && !p->arena_borrowed) d_free_space(p->arena.base);
+    if (p->priv_arena) lg_private_arena_free(p->priv_arena);
     delete p;
 }
 

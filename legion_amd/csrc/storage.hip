@@ -145,8 +145,56 @@ static bool d_free_scattered(void* ptr)
     return true;
 }
 
+// ---- a pipeline's lane-PRIVATE arrays (slot arrays, claim lists, frontier headers ...) from one block of shuffled chunks as well: while a
+//      thread has a private arena set, its d_alloc_space calls are carved from it (never freed one by one: the block goes when the pipeline
+//      goes).  Measured: +0.9 % on the whole job, +4 % on the sampler chain, against both separate allocations and one plain block -----------
+namespace {
+struct PrivArena { char* base; int64_t bytes, used; };
+thread_local PrivArena* g_priv = nullptr;
+thread_local int64_t g_count_bytes = -1;          // >= 0: d_alloc_space adds up what this thread asks for (lg_alloc_count_begin / _end)
+std::mutex g_priv_mu;
+std::vector<std::pair<char*, int64_t>> g_priv_ranges;
+}
+extern "C" void* lg_private_arena_begin(int64_t bytes, int32_t scatter_mb)
+{
+    PrivArena* a = new PrivArena();
+    a->base = (char*)(scatter_mb > 0 ? d_alloc_scattered(bytes, scatter_mb) : nullptr);
+    if (a->base == nullptr) HIP_CALL(hipMalloc((void**)&a->base, (size_t)bytes));
+    a->bytes = bytes;
+    a->used = 0;
+    { std::lock_guard<std::mutex> lk(g_priv_mu); g_priv_ranges.push_back({a->base, bytes}); }
+    g_priv = a;
+    return a;
+}
+extern "C" void lg_private_arena_end() { g_priv = nullptr; }
+extern "C" void lg_alloc_count_begin() { g_count_bytes = 0; }
+extern "C" int64_t lg_alloc_count_end() { const int64_t v = g_count_bytes; g_count_bytes = -1; return v; }
+extern "C" void lg_private_arena_free(void* handle)
+{
+    PrivArena* a = (PrivArena*)handle;
+    if (!a) return;
+    {
+        std::lock_guard<std::mutex> lk(g_priv_mu);
+        for (size_t i = 0; i < g_priv_ranges.size(); i++)
+            if (g_priv_ranges[i].first == a->base) { g_priv_ranges.erase(g_priv_ranges.begin() + (long)i); break; }
+    }
+    if (!d_free_scattered(a->base)) HIP_CALL(hipFree(a->base));
+    delete a;
+}
+static bool in_private_arena(void* p)
+{
+    std::lock_guard<std::mutex> lk(g_priv_mu);
+    for (auto& r : g_priv_ranges) if ((char*)p >= r.first && (char*)p < r.first + r.second) return true;
+    return false;
+}
+
 extern "C" void* d_alloc_space(int64_t num_bytes)
 {
+    if (g_count_bytes >= 0) g_count_bytes += ((num_bytes > 0 ? num_bytes : 16) + 255) & ~(int64_t)255;
+    if (g_priv != nullptr) {
+        const int64_t need = ((num_bytes > 0 ? num_bytes : 16) + 255) & ~(int64_t)255;
+        if (g_priv->used + need <= g_priv->bytes) { void* p = g_priv->base + g_priv->used; g_priv->used += need; return p; }
+    }
     void* ret = nullptr;
     HIP_CALL(hipMalloc(&ret, num_bytes > 0 ? (size_t)num_bytes : 16));
     return ret;
@@ -207,7 +255,7 @@ void* lg_alloc_exported(int64_t num_bytes, void* handle64, const char* file, int
 
 extern "C" void d_free_space(void* d_ptr)
 {
-    if (d_ptr && !d_free_scattered(d_ptr)) HIP_CALL(hipFree(d_ptr));
+    if (d_ptr && !in_private_arena(d_ptr) && !d_free_scattered(d_ptr)) HIP_CALL(hipFree(d_ptr));
 }
 
 extern "C" void* host_alloc_space(int64_t num_bytes)
@@ -864,6 +912,7 @@ extern "C" void legion_feature_destroy(LegionFeatureStorage* f_)
 // ---- output arena (legion_core.h PoolArena) ---------------------------------------------------
 static thread_local PoolArena* g_pool_arena = nullptr;
 void lg_set_pool_arena(PoolArena* arena) { g_pool_arena = arena; }
+PoolArena* lg_get_pool_arena() { return g_pool_arena; }
 static inline int64_t arena_round(int64_t b) { return (b + 255) & ~(int64_t)255; }
 int64_t lg_pool_arena_bytes(int64_t batch_size, int64_t num_ids, int64_t feature_rows, int64_t float_feature_len)
 {
