@@ -328,7 +328,10 @@ public:
             addr.sun_family = AF_UNIX;
             const int len = snprintf(addr.sun_path + 1, sizeof(addr.sun_path) - 1, "legion_arena_%d_%d", (int)getpid(), dev_id);
             if (bind(ls, (sockaddr*)&addr, (socklen_t)(offsetof(sockaddr_un, sun_path) + 1 + len)) != 0 || listen(ls, 8) != 0) { close(ls); return false; }
-            std::thread([ls, base, n_chunks]() {
+            int hip_dev = 0;
+            (void)hipGetDevice(&hip_dev);                      // (the Runner thread's device: the arena's)
+            std::thread([ls, base, n_chunks, hip_dev]() {
+                (void)hipSetDevice(hip_dev);
                 for (;;) {
                     const int c = accept(ls, nullptr, nullptr);
                     if (c < 0) { if (errno == EINTR) continue; return; }
