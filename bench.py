@@ -171,11 +171,6 @@ def parse_args():
     ap.add_argument("--min-seconds", type=float, default=1.5,
                     help="repeat the K-step timed region until this much time has been measured (median reported)")
     ap.add_argument("--max-repeats", type=int, default=400)
-    ap.add_argument("--dedup", type=str, default="auto", choices=["auto", "direct", "table", "lds"],
-                    help="form of the per-lane first-touch/position state: direct uint32[N] array, compact open-addressing "
-                         "table, lds (no per-vertex state: a hop's claims are de-duplicated bucket by bucket in LDS), or auto "
-                         "(lds up to 2^25 slots per hop and lane; beyond: direct, or table when the arrays of all lanes in "
-                         "flight would exceed a quarter of HBM)")
     ap.add_argument("--placement", type=str, default="hbm", choices=["hbm", "pinned"],
                     help="pinned: full CSR and full feature table in mapped pinned host memory (the reference's only tier; "
                          "BASELINE configs[2]): cache hits come from HBM, misses are read in place over PCIe")
@@ -199,14 +194,11 @@ def parse_args():
                     help="mini-batches served by every launch (lanes of a group); 0 = 524288 // batch rounded down to a power of "
                          "two, at most 512, halved while the lanes in flight would not fit 0.7 of the free HBM")
     ap.add_argument("--slots", type=int, default=2, help="groups in flight per GPU")
-    ap.add_argument("--probe-overlap", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--lanes", dest="lane_arena", default=True, type=lambda v: {"arena": True, "plain-arena": "plain", "separate": False}[v],
                     help="where the lanes' trainer-visible arrays live: arena (default: one arena of shuffled physical chunks), plain-arena (one plain "
                          "allocation: what the server's hand-over needs), separate (an allocation per array and lane)")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
     ap.add_argument("--overlap", action="store_true", help="let kernels of different slots share the GPU")
-    ap.add_argument("--split", action="store_true",
-                    help="sampler phase and gather phase of every group on two streams (sampler k+1 under gathers k)")
     ap.add_argument("--no-weave", action="store_true",
                     help="everything of a group on ONE stream (default: the next group's head -- seeds + every hop but the last, small "
                          "latency-bound kernels -- runs on a second stream under the current group's heavy kernels, pipeline.hip)")
@@ -218,8 +210,7 @@ def parse_args():
                          "gather makes no node_map lookup -- what the lookup's 128-byte line per row costs the gather")
     ap.add_argument("--gather-rows", type=int, default=0, help="experiment: rows per gather workgroup (LegionTuning.gather_rows_per_wg)")
     ap.add_argument("--no-verify", action="store_true")
-    ap.add_argument("--no-overlap-leg", action="store_true",
-                    help="skip the extra timed region with sampler and gather phases overlapped on two streams")
+    ap.add_argument("--no-overlap-leg", action="store_true", help=argparse.SUPPRESS)      # (accepted, ignored: the leg it skipped was removed in round 5)
     ap.add_argument("--no-boundary", action="store_true",
                     help="skip the drop-in boundary leg (sampling_server binary -> shm/semaphores/IPC handles -> ipc_service "
                          "consumer on an RMAT-22 data set written in the reference's file formats; N = 1 only, ~15 s)")
@@ -302,8 +293,6 @@ def main():
     c.t_setup = time.time()
 
     # ---- workload, resident in HBM --------------------------------------------------------------
-    if args.dedup != "auto":
-        os.environ["LEGION_DEDUP"] = args.dedup
     if args.gather_rows > 0:
         os.environ["LEGION_GATHER_ROWS"] = str(args.gather_rows)
     engine.set_device_base(local_rank)
@@ -419,7 +408,7 @@ def main():
 def run_leg(c, engine, synth, stripe, replica_memory, headline, bulk=False):
     """One cache layout over the resident workload: objects -> PreSC -> hotness all-reduce -> cost model -> fills -> pipeline ->
     counting pass -> warm-up -> timed regions -> eager pass with HIP events around the gathers.  Returns {"json": rank 0's
-    report of the leg}.  The headline leg also verifies, and runs the `overlapped` arrangement; the extra legs are shorter."""
+    report of the leg}.  The headline leg also verifies; the extra legs are shorter."""
     args, world, rank, dev, use_dist = c.args, c.world, c.rank, c.dev, c.use_dist
     if not headline and args.fail_extra_leg and rank == 0:        # (tests of OneLine)
         if args.fail_extra_leg == "raise":
@@ -565,7 +554,7 @@ def run_leg(c, engine, synth, stripe, replica_memory, headline, bulk=False):
             cache.fill_up(feature, graph)
     feature_rows = int(max_ids * 1.2)                                        # server.cu:277
     pool.close()
-    weave = not (args.no_weave or args.split or args.overlap)
+    weave = not (args.no_weave or args.overlap)
     if bulk:
         # peer_gather = bulk (pipeline.hip): the rows of other members' stripes are pushed by their OWNERS; a group runs as
         # phase A (own sampler + lists + local gather) -> barrier -> phase B (push for the others) -> barrier, eager launches
@@ -579,18 +568,8 @@ def run_leg(c, engine, synth, stripe, replica_memory, headline, bulk=False):
         dist.barrier()
     else:
         pipe = engine.Pipeline(graph, feature, cache, d, B, fanout, G, feature_rows, not args.no_graph, args.slots,
-                               args.overlap, args.split, weave, arena=args.lane_arena)
+                               args.overlap, False, weave, arena=args.lane_arena)
     torch.cuda.synchronize()
-    if getattr(args, "probe_overlap", False) and headline and not bulk:
-        # experiment: the last hop's de-duplication + compaction of one group beside the gathers of another
-        import ctypes as _ct
-        out_ms = (_ct.c_double * 6)()
-        pipe.run_range(0, n_warm, wrap=wrap)
-        pipe.wait()
-        for prep, side, what in ((1, 6, "dedup+compact"), (3, 4, "compact"), (1, 2, "dedup"), (0, 1, "sample")):
-            ok = engine._libmod.load().legion_pipeline_probe_overlap(pipe.handle, int(n_warm), 0, out_ms, prep, side)
-            names = ["gathers(A) alone", what + "(B) alone", "one stream", "two streams, equal priority", "second stream high priority", "second stream low priority"]
-            print("probe_overlap", ok, {n: round(v, 4) for n, v in zip(names, out_ms)}, file=sys.stderr, flush=True)
     setup_s = time.time() - (c.t_setup if headline else t_leg)
 
     # ---- untimed counting pass over exactly the timed batches (deterministic) --------------------
@@ -722,28 +701,9 @@ def run_leg(c, engine, synth, stripe, replica_memory, headline, bulk=False):
             err_bits |= pl.error()
     if err_bits:
         raise RuntimeError(f"a kernel raised error bits {err_bits:#x} during the run (legion_core.h LG_ERR_*)")
-    dedup_form, state_bytes, lds_buckets = pipe.pools[0][0].dedup_form(), pipe.pools[0][0].state_bytes(), pipe.pools[0][0].lds_buckets()
+    state_bytes, lds_buckets = pipe.pools[0][0].state_bytes(), pipe.pools[0][0].lds_buckets()
 
-    # ---- the same K steps once more with every group's sampler phase and gather phase on two streams (sampler k+1 runs
-    #      under gathers k, pipeline.hip `split`): reported beside the headline as `overlapped`, not as `value`, because
-    #      two kernels sharing the machine make the per-kernel roofline of the timed region meaningless.  --split makes
-    #      this arrangement the headline instead. ------------------------------------------------------------------
-    overlapped = None
     pipe.close()
-    if headline and not args.split and not args.no_overlap_leg:
-        pipe = engine.Pipeline(graph, feature, cache, d, B, fanout, G, feature_rows, not args.no_graph, args.slots, False, True, arena=args.lane_arena)
-        pipe.run_range(0, n_warm, wrap=wrap)
-        pipe.wait()
-        ov0, _ = timed_region(pipe)
-        reps2 = torch.tensor([max(1, min(args.max_repeats, int(np.ceil(0.5 * args.min_seconds / max(ov0, 1e-6)))))],
-                             dtype=torch.int64, device=dev)
-        if use_dist:
-            dist.all_reduce(reps2, op=dist.ReduceOp.MAX)
-        ov = torch.tensor([ov0] + [timed_region(pipe)[0] for _ in range(int(reps2.item()) - 1)], dtype=torch.float64, device=dev)
-        if use_dist:
-            dist.all_reduce(ov, op=dist.ReduceOp.MAX)
-        overlapped = float(np.median(ov.cpu().numpy())), int(ov.numel())
-        pipe.close()
 
     tot_edges = torch.tensor([float(edges.sum())], dtype=torch.float64, device=dev)
     gather_bytes_t = torch.tensor([float(rows.sum() * D * 4)], dtype=torch.float64, device=dev)
@@ -889,8 +849,7 @@ def run_leg(c, engine, synth, stripe, replica_memory, headline, bulk=False):
                            "parallelism": layout,
                            "batches_per_launch_group": G, "groups_in_flight": args.slots,
                            "lane_arrays": {True: "one arena of shuffled 2 MB physical chunks (LegionTuning.arena_scatter_mb)", "plain": "one plain arena", False: "separate allocations"}[args.lane_arena], "epoch_batches": c.epoch_batches,
-                           "streams": "weave: head of group k+1 on a second stream under the heavy kernels of group k" if weave else
-                                      ("split: sampler phase || gather phase" if args.split else "one"),
+                           "streams": "weave: head of group k+1 on a second stream under the heavy kernels of group k" if weave else "one",
                            "epochs_wrap": bool(wrap), "hipgraph": not args.no_graph,
                            "cache_memory_bytes": args.cache_memory,
                            "feature_cache_rows": cache.node_capacity(d), "topology_cache_vertices": cache.edge_capacity(d),
@@ -905,23 +864,15 @@ def run_leg(c, engine, synth, stripe, replica_memory, headline, bulk=False):
                                   "frac_of_hbm_peak": samp_bytes / t_sampling / 1e9 / HBM_PEAK_GBPS,
                                   "note": "rank 0; time = timed region minus the HIP-event time of all gather launches (with the weave "
                                           "arrangement the head of the next group runs hidden under this group's heavy kernels, so this is the "
-                                          "sampler time that is NOT hidden); the sampler is bound by scattered 4-byte column loads (~43-47 G sector "
-                                          "misses/s, tools/micro/random_access.hip) and, in the atomics forms of the first-touch state, by "
-                                          "memory-side atomics (~13-19 G claims/s, tools/micro/dedup_tables.hip): DESIGN.md section 4.2"},
+                                          "sampler time that is NOT hidden); the sampling kernel is bound by the part's rate of random 128-byte requests, "
+                                          "the de-duplication and compaction by their dependent chains: DESIGN.md section 4.2"},
                 "edges_per_step": float(edges.sum()) / args.steps, "rows_per_step": float(rows.sum()) / args.steps,
                 "edges_per_batch": float(edges.mean()), "rows_per_batch": float(rows.sum(axis=1).mean()),
                 "seed_feature_cache_hits_step0": hits,
                 "roofline": roof,
                 "setup_seconds": setup_s,
-                "overlapped": None if overlapped is None else {
-                    "value": float(tot_edges.item()) / overlapped[0], "unit": "edges/s", "ms_per_step": overlapped[0] / args.steps * 1e3,
-                    "repeats": overlapped[1],
-                    "note": "same K steps, same batches, with every group's sampler phase on one stream and its gathers on another "
-                            "(sampler k+1 runs under gathers k; `bench.py --split` makes this the headline).  Each kernel runs "
-                            "slower while sharing the machine (the gather at ~0.59 of peak instead of 0.78).  With the atomics forms "
-                            "of the first-touch state this finishes a group 8-12 % sooner than one stream; with the LDS form and "
-                            "the weave default it does not (DESIGN.md section 4.5)."},
-                "position_state": {"form": dedup_form, "bytes_per_lane": state_bytes, "lanes": G * args.slots, "lds_buckets_per_lane": lds_buckets},
+                "first_touch_state": {"form": "none per vertex: a hop's claims are de-duplicated bucket by bucket in LDS", "bytes_per_lane": state_bytes,
+                                      "lanes": G * args.slots, "lds_buckets_per_lane": lds_buckets},
                 "feature_cache_hit_rate": feat_hit_rows / max(feat_hit_rows + feat_miss_rows, 1),
                 "feature_cache_hit_rate_over": "every timed batch" if args.placement == "pinned" else "the first timed step",
             }

@@ -113,20 +113,13 @@ int32_t legion_pool_num_ids(const LegionMemoryPool* p);
  *        7 agg_src_ids 8 agg_dst_ids 9 cache_search_buffer 10 tmp_part_ind 11 tmp_part_off
  *        12 position_map.  Returns the device pointer of the CURRENT pipe slot. */
 void* legion_pool_buffer(LegionMemoryPool* p, int32_t which);
-/* New in this build.  The first-touch/position state of a pool (the reference's accessed_map + position_map,
- * SS/engine/memorypool.cuh:120-135) takes one of three forms: a direct uint32[N] array (N x 4 B per pool), a compact
- * open-addressing table sized by num_ids, or (form "lds", the default wherever it applies) nothing at all per vertex.
- * LEGION_DEDUP=direct|table|lds|auto; auto = lds for pools whose largest hop has at most 2^25 slots per lane (every shape
- * of legion_server.py), beyond that direct, or table when the arrays of all pools in flight would exceed a quarter of
- * HBM.  All three give bit-identical batches. */
-int32_t legion_pool_uses_table(const LegionMemoryPool* p);
-/* 0 direct array, 1 compact table, 2 "lds": no per-vertex state, a hop's claims are de-duplicated bucket by bucket in LDS
- * (hops of up to 2^25 slots per lane; a pool beyond that falls back to the table) */
-int32_t legion_pool_dedup_form(const LegionMemoryPool* p);
-/* hash buckets per lane of the lds form (8, 16, 64 or 256; 0 for the other forms) */
+/* New in this build.  The reference keeps first touches in accessed_map (N bits, memset per batch) + position_map (N entries,
+ * SS/engine/memorypool.cuh:120-135); a pool here keeps NOTHING per vertex: a hop's claims are de-duplicated bucket by bucket in
+ * LDS (legion_core.h).  hash buckets per lane: 8, 16, 64 or 256 by the pool's largest hop; state_bytes: one hop's claim lists +
+ * the known lists (scale with the batch, not with the graph).  which = 12 of legion_pool_buffer (position_map) returns NULL. */
 int32_t legion_pool_lds_buckets(const LegionMemoryPool* p);
 int64_t legion_pool_state_bytes(const LegionMemoryPool* p);
-/* Sticky error bits raised on the device for this pool (0 = none): 1 position table full, 2 batch larger than the
+/* Sticky error bits raised on the device for this pool (0 = none): 1 a de-duplication bucket that fits no LDS table, 2 batch larger than the
  * feature buffer (gather stopped at its end; the reference overruns, SS/engine/server.cu:277), 4 internal.  The
  * word lives in host-visible memory: reading it after the batch completed needs no copy. */
 int32_t legion_pool_error(const LegionMemoryPool* p);
@@ -382,64 +375,50 @@ int32_t legion_get_device_base(void);
  *    environment is then only read again after legion_tuning_from_env() is called explicitly).
  *    No reference counterpart (the reference has compile-time constants only, system_config.cuh).
  *    Not tuning and therefore still plain environment: LEGION_IPC_NAMESPACE, LEGION_IPC_LOCAL,
- *    LEGION_IPC_DEVICE (deployment: which shm names / which GPU a trainer attaches to).
+ *    LEGION_IPC_DEVICE (deployment: which shm names / which GPU a trainer attaches to), and the trainer module's own
+ *    LEGION_NO_DIRECT_VIEWS / LEGION_NO_SHM_MIRROR (ipc_service is a separate extension: it reads them once, in initialize()).
  * ===================================================================================== */
 typedef struct LegionTuning {
-    int32_t dedup_form;          /* LEGION_DEDUP=auto|direct|table|lds -> -1|0|1|2.  auto: lds when the pool's largest hop has
-                                    <= 2^25 slots, else direct while N*4 B x lanes in flight fit a quarter of HBM, else table */
-    int32_t pos_value_bits;      /* LEGION_POS_VALUE_BITS  (0): minimum width of the position-state value field (tests) */
-    int32_t pos_table_bits;      /* LEGION_POS_TABLE_BITS  (0 = sized by num_ids): log2 words of the compact table (tests) */
-    int32_t lds_known_cap;       /* LEGION_LDS_KNOWN_CAP   (0 = 2 x an even share): entries per known-node list (tests) */
-    int32_t lds_claim_cap;       /* LEGION_LDS_CLAIM_CAP   (0 = 2 x an even share): entries per claim list of the 8/16-bucket classes (tests) */
-    int32_t lds_one_wg_lanes;    /* LEGION_LDS_ONE_WG_LANES (0 = never): launch groups of at least this many lanes de-duplicate a hop of <= 32768 slots
-                                    with ONE workgroup per lane (all of the lane's buckets in turn) instead of one per bucket: +1 % on one stream,
-                                    nothing under the weave */
-    int32_t arena_scatter_mb;    /* LEGION_ARENA_SCATTER_MB (2; 0 = one plain allocation): a pipeline's own lane arena is built from physical chunks of
-                                    this many MB mapped in shuffled order (HIP virtual memory management): the gathers write a group's rows all over the
-                                    HBM instead of into one contiguous range (0.87 instead of 0.80 of the peak).  Arenas that another process or GPU
-                                    must reach (server hand-over, peer_gather = bulk) are always plain */
-    int32_t lds_part_wg;         /* LEGION_LDS_PART_WG     (8192): workgroups a partitioning sample launch aims for */
+    /* -- sampler ------------------------------------------------------------------------------------------------------------ */
     int32_t lds_small_buckets;   /* LEGION_LDS_SMALL_BUCKETS (0 auto | 8 | 16): hash buckets per lane of pools whose hops have <= 2^19 slots;
                                     auto = 16 where PreSC saw more last-hop edges + earlier nodes than 8 buckets take in one pass */
+    int32_t lds_part_wg;         /* LEGION_LDS_PART_WG     (8192): workgroups a sampling launch of the 64/256-bucket classes aims for (picks the
+                                    partition tile: 1..8 super tiles) */
     int32_t sample_max_wg;       /* LEGION_SAMPLE_MAX_WG   (4096): workgroup cap of the strided sampler grids */
-    int32_t loser_in_dst;        /* LEGION_LOSER_IN_DST    (1): lds form, N <= 2^30: a slot that lost its first touch is marked in bit 30 of its
-                                    slot_dst entry (the compaction then reads one array less) instead of in slot_mark */
-    int32_t gather_small_tiles;  /* LEGION_GATHER_SMALL_TILES (1): 16-row tiles for launches of fewer than 4096 tiles */
-    int32_t gather_rows_per_wg;  /* LEGION_GATHER_ROWS     (0 = by row width): rows per gather workgroup, 16|32|64|128|256 */
-    int32_t compact_hoist;       /* LEGION_COMPACT_HOIST   (1): compact_kernel loads the per-slot inputs that depend on the slot index only
-                                    together with slot_dst, for every slot (more bytes, one dependent round trip less) */
+    int32_t lds_known_cap;       /* LEGION_LDS_KNOWN_CAP   (0 = 2 x an even share): entries per known-node list (tests force the fallback) */
+    int32_t lds_claim_cap;       /* LEGION_LDS_CLAIM_CAP   (0 = 2 x an even share): entries per claim list (tests force the fallback) */
     int32_t col_slots;           /* LEGION_COL_SLOTS       (-1 auto): the {neighbour id, feature-cache slot} copy of the column array that
                                     lets the gather skip its node_map lookup (8 B per edge of HBM per GPU): 1 always, 0 never,
                                     -1 when the column array is device memory and the copy fits half of the HBM that is free after the fills, leaving 24 GB */
-    int32_t split_sampler_cus;   /* LEGION_SPLIT_SAMPLER_CUS (0 = no CU mask): CUs of the sampler stream in split mode */
-    int32_t split_priority;      /* LEGION_SPLIT_PRIORITY  (1): split mode, 1 sampler stream first, 0 equal, -1 gathers first */
-    int32_t weave_priority;      /* LEGION_WEAVE_PRIORITY  (-1): weave arrangement, priority of the light stream (heads of the next group):
-                                    -1 low, 0 equal, 1 high */
-    int32_t weave_early_gathers; /* LEGION_WEAVE_EARLY_GATHERS (see tuning.hip for the default): weave arrangement, the gathers of the seeds and of every
-                                    hop but the last run with the HEAD on the light stream (under the previous group's heavy kernels) instead of
-                                    in front of the last hop's gather on the heavy stream */
+    /* -- gather ------------------------------------------------------------------------------------------------------------- */
+    int32_t gather_rows_per_wg;  /* LEGION_GATHER_ROWS     (0 = by row width): rows per gather workgroup, 16|32|64|128|256 */
+    int32_t peer_gather;         /* LEGION_PEER_GATHER=direct|bulk -> 0|1: rows of OTHER members' stripes of a striped feature cache are
+                                    read by direct peer loads, or pushed by their owners in bulk (pipeline.hip) */
+    /* -- launch groups ------------------------------------------------------------------------------------------------------- */
+    int32_t arena_scatter_mb;    /* LEGION_ARENA_SCATTER_MB (2; 0 = plain allocations): lane arenas are built from physical chunks of this many MB
+                                    mapped in shuffled order (HIP virtual memory management): the gathers write a group's rows all over the
+                                    HBM instead of into one contiguous range (0.87 instead of 0.80 of the peak) */
+    int32_t weave_priority;      /* LEGION_WEAVE_PRIORITY  (-1): priority of the light stream (heads of the next group): -1 low, 0 equal, 1 high */
+    int32_t markers;             /* LEGION_MARKERS         (1): roctx ranges around ops and launch groups (visible to rocprofv3 --marker-trace) */
+    /* -- Runner (server side of the boundary) -------------------------------------------------------------------------------- */
     int32_t runner_graph;        /* LEGION_RUNNER_GRAPH    (1): Runner serves from lane groups + hipGraph; 0 = operator by operator */
-    int32_t runner_lanes;        /* LEGION_RUNNER_LANES    (0 = min(128, 262144 / batch)): lanes of a Runner group */
-    int32_t runner_ho_stream;    /* LEGION_RUNNER_HO_STREAM (2): hand-over streams: 0 the sampler's, 1 one shared, 2 one per pipe slot */
-    int32_t runner_stats;        /* LEGION_RUNNER_STATS    (0): print where a hand-over's time went at Finalize */
-    int32_t runner_handover;     /* LEGION_RUNNER_HANDOVER=auto|gather|copy -> 0|1|2: how the Runner's batches reach a trainer.  auto: the lanes of
-                                    the launch groups live in one exported arena; a trainer end that opened it gets a batch as VIEWS of its lane
-                                    (whole groups incl. full-width gathers, no per-batch GPU work), any other gets its rows gathered straight
-                                    into the pipe slot by one launch per batch.  gather: that for every trainer end.  copy: whole groups, one
-                                    copy launch per batch into the pipe slot (measured alternative) */
+    int32_t runner_lanes;        /* LEGION_RUNNER_LANES    (0 = min(512, 524288 / batch)): lanes of a Runner group */
     int32_t runner_slots;        /* LEGION_RUNNER_SLOTS    (3): launch groups the Runner keeps in flight (2..4): one being handed over, one
                                     running, one queued behind it */
-    int32_t peer_gather;         /* LEGION_PEER_GATHER=direct|bulk -> 0|1: rows of OTHER members' stripes of a striped feature cache are
-                                    read by direct peer loads, or pulled owner by owner in bulk (hipMemcpyPeerAsync) */
-    int32_t feature_pitch;       /* LEGION_FEATURE_PITCH=auto|dense|aligned -> -1|0|1: row pitch of the HBM-resident feature cache; aligned =
-                                    rounded up to 128 bytes (a 400-byte row then touches 4 cache lines, never 5), auto = aligned when it
-                                    costs at most 1/8 more memory */
+    int32_t runner_handover;     /* LEGION_RUNNER_HANDOVER=auto|gather -> 0|1: how the Runner's batches reach a trainer.  auto: a trainer end that
+                                    opened the lane arena gets a batch as VIEWS of its lane (no per-batch GPU work), any other gets its rows
+                                    gathered straight into the pipe slot by one launch per batch.  gather: that for every trainer end */
+    int32_t runner_ho_stream;    /* LEGION_RUNNER_HO_STREAM (2): hand-over streams of the gather hand-over: 0 the sampler's, 1 one shared, 2 one per pipe slot */
+    int32_t runner_spin_us;      /* LEGION_RUNNER_SPIN_US  (-1 auto): how long the Runner polls (a trainer's semaphore, a group's completion) before it
+                                    blocks.  auto: 20 us when batches are handed over as views (a group completes every few ms: the host
+                                    sleeps in between), polling only with the gather hand-over (per-batch latency is the rate there) */
+    int32_t runner_stats;        /* LEGION_RUNNER_STATS    (0): print where a hand-over's time went at Finalize */
+    int32_t shm_mirror;          /* LEGION_NO_SHM_MIRROR unset -> 1: counters also go to a host-visible mirror (no D2H copy per batch) */
+    /* -- set-up -------------------------------------------------------------------------------------------------------------- */
+    int32_t table_placement;     /* LEGION_TABLE_PLACEMENT=hbm|pinned -> 0|1: where the server puts the full CSR / feature table */
     int32_t hotness_reduce;      /* LEGION_HOTNESS_REDUCE=auto|p2p|rccl -> -1|0|1: the clique sum of the access counters: rccl = all-reduce
                                     over the server's distinct physical GPUs, p2p = the reference's leader loop over peer pointers
-                                    (SS/cache/cache.cu:408-411); auto = rccl when the members sit on distinct physical GPUs */
-    int32_t markers;             /* LEGION_MARKERS         (1): roctx ranges around ops and launch groups (visible to rocprofv3 --marker-trace) */
-    int32_t table_placement;     /* LEGION_TABLE_PLACEMENT=hbm|pinned -> 0|1: where the server puts the full CSR / feature table */
-    int32_t shm_mirror;          /* LEGION_NO_SHM_MIRROR unset -> 1: counters also go to a host-visible mirror (no D2H copy per batch) */
+                                    (SS/cache/cache.cu:408-411); auto = rccl when the members sit on distinct physical GPUs, p2p if that fails */
     int32_t link_counters;       /* LEGION_LINK_COUNTERS=v2|measured|smi|"a,b" -> 0|1|2|3: what feeds CostModel's counters */
     uint64_t link_counter_values[2];   /* the injected pair of LEGION_LINK_COUNTERS="a,b" */
 } LegionTuning;

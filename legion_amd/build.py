@@ -61,6 +61,14 @@ def build_lib(force=False, verbose=True):
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)
+    # the stand-alone probe of the file-descriptor convention of /opt/rocm's HIP runtime (tests/test_gpu_boundary.py)
+    probe_src = os.path.join(HERE, "..", "tools", "micro", "vmm_convention_probe.cpp")
+    probe_bin = os.path.join(HERE, "bin", "vmm_convention_probe")
+    if force or _newer(probe_bin, [probe_src, os.path.join(HERE, "trainer", "vmm_probe.h")]):
+        cmd = [HIPCC, "-O2", "-std=c++17", probe_src, "-o", probe_bin]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
     return LIB
 
 
@@ -68,7 +76,7 @@ def build_trainer(verbose=True, force=False):
     tdir = os.path.join(HERE, "trainer")
     import glob
     built = glob.glob(os.path.join(tdir, "ipc_service*.so"))
-    srcs = [os.path.join(tdir, "ipc_service.cpp"), os.path.join(tdir, "setup.py")]
+    srcs = [os.path.join(tdir, "ipc_service.cpp"), os.path.join(tdir, "vmm_probe.h"), os.path.join(tdir, "setup.py")]
     if built and not force and not _newer(built[0], srcs):
         return built[0]
     env = dict(os.environ, PYTORCH_ROCM_ARCH=ARCH)

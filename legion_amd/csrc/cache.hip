@@ -447,15 +447,10 @@ void UnifiedCache::FillUpLocal(FeatureStorage* feature, GraphStorage* graph)
     const int32_t N = feature->TotalNodeNum();
     float* cpu_float_feature = feature->GetAllFloatFeature();
     cpu_float_features_ = cpu_float_feature;
-    {   // row pitch of the stripes (LegionTuning.feature_pitch): dense, or rounded up to whole 128-byte lines
-        const int32_t mode = lg::tuning().feature_pitch;
-        const int32_t aligned = (int32_t)((((int64_t)float_feature_len_ * 4 + 127) / 128 * 128) / 4);
-        cache_pitch_ = float_feature_len_;
-        if (mode == 1) cache_pitch_ = aligned;
-        // auto: dense.  Measured (profiles/r04/gather_pitch.md): a row that is not a whole number of 128-byte lines costs the
-        // same lines at either pitch -- 400 bytes at any 16-byte offset cover exactly four -- so padding buys nothing.
-    }
-    const int32_t pitch = CachePitch();
+    // (stripes and replica are dense.  Rows padded to whole 128-byte lines were built and measured in round 4 -- a row that is not a
+    // whole number of lines costs the same lines at either pitch, 400 bytes at any 16-byte offset cover exactly four -- and removed:
+    // DESIGN_HISTORY.md, profiles/r04/gather_pitch.md)
+    const int32_t pitch = float_feature_len_;
     for (int32_t i = 0; i < Kc_; i++)
         for (int32_t j = 0; j < Kg_; j++) {
             const int32_t dev_id = i * Kg_ + j;
@@ -469,7 +464,7 @@ void UnifiedCache::FillUpLocal(FeatureStorage* feature, GraphStorage* graph)
                 d_free_space(float_feature_cache_[dev_id]);
                 float* new_cache = (float*)d_alloc_space((int64_t)node_capacity_[i] * pitch * sizeof(float));
                 lg::feat_fill_up(nullptr, node_capacity_[i], float_feature_len_, new_cache, cpu_float_feature,
-                                 QF_[i], Kg_, j, N, pitch);
+                                 QF_[i], Kg_, j, N);
                 HIP_CALL(hipDeviceSynchronize());
                 float_feature_cache_[dev_id] = new_cache;
                 // hot-row replica: ranks 0 .. R-1 of the clique order, identical on every member (Kg = 1 addressing)
@@ -482,7 +477,7 @@ void UnifiedCache::FillUpLocal(FeatureStorage* feature, GraphStorage* graph)
                     rows = std::min<int64_t>(rows, std::min<int64_t>((int64_t)node_capacity_[i] * Kg_, N));
                     if (rows > 0) {
                         replica_[dev_id] = (float*)d_alloc_space(rows * pitch * sizeof(float));
-                        lg::feat_fill_up(nullptr, (int32_t)rows, float_feature_len_, replica_[dev_id], cpu_float_feature, QF_[i], 1, 0, N, pitch);
+                        lg::feat_fill_up(nullptr, (int32_t)rows, float_feature_len_, replica_[dev_id], cpu_float_feature, QF_[i], 1, 0, N);
                         HIP_CALL(hipDeviceSynchronize());
                         replica_rows_[dev_id] = (int32_t)rows;
                     }
@@ -575,7 +570,7 @@ void UnifiedCache::BulkBucket(const LanePtrs* d_lanes, int32_t n_lanes, int32_t 
 void UnifiedCache::BulkPush(int32_t owner_dev, hipStream_t s, const int32_t* fidx, const int64_t* dst, const unsigned long long* cnt,
                             int64_t cap, char* peer_arena)
 {
-    lg::launch_bulk_push(s, float_feature_cache_[owner_dev], CachePitch(), float_feature_len_, fidx, dst, cnt, cap, peer_arena);
+    lg::launch_bulk_push(s, float_feature_cache_[owner_dev], float_feature_len_, fidx, dst, cnt, cap, peer_arena);
 }
 
 lg::GatherParams UnifiedCache::GatherParamsOf(int32_t dev_id, int32_t op_id, int32_t max_rows, bool use_snapshot, int32_t first_op_id,
@@ -597,7 +592,6 @@ lg::GatherParams UnifiedCache::GatherParamsOf(int32_t dev_id, int32_t op_id, int
     g.node_map = filled ? cache_controller_[dev_id]->NodeMap() : nullptr;
     g.node_capacity = filled ? NodeCapacity(dev_id) : 1;
     g.D = float_feature_len_;
-    g.cache_pitch = CachePitch();
     g.total_num_nodes = total_num_nodes_;
     g.max_rows = max_rows;
     g.hop = use_snapshot ? op_id / INTRABATCH_CON : -1;

@@ -188,7 +188,7 @@ void init_edge_maps(hipStream_t s, char* index_map, int32_t* offset_map, const i
 }
 
 // FeatFillUp, cache_impl.cuh:183-188: one 64-lane wave per cached row, 16 B per lane when D%4==0
-__global__ void feat_fill_up_kernel(int32_t capacity, int32_t D, int32_t pitch, float* __restrict__ cache,
+__global__ void feat_fill_up_kernel(int32_t capacity, int32_t D, float* __restrict__ cache,
                                     const float* __restrict__ table, const int32_t* __restrict__ QF,
                                     int32_t Kg, int32_t Ki, int32_t n)
 {
@@ -200,7 +200,7 @@ __global__ void feat_fill_up_kernel(int32_t capacity, int32_t D, int32_t pitch, 
         if (t >= n) continue;
         const int32_t id = QF[t];
         const float* src = table + (int64_t)id * D;
-        float* dst = cache + (int64_t)r * pitch;      // (pitch >= D floats: LegionTuning.feature_pitch)
+        float* dst = cache + (int64_t)r * D;
         if ((D & 3) == 0) {
             typedef float v4 __attribute__((ext_vector_type(4)));
             for (int32_t c = lane; c < D / 4; c += 64)
@@ -212,12 +212,10 @@ __global__ void feat_fill_up_kernel(int32_t capacity, int32_t D, int32_t pitch, 
 }
 
 void feat_fill_up(hipStream_t s, int32_t capacity, int32_t D, float* cache, const float* table,
-                  const int32_t* QF, int32_t Kg, int32_t Ki, int32_t n, int32_t pitch)
+                  const int32_t* QF, int32_t Kg, int32_t Ki, int32_t n)
 {
     if (capacity <= 0 || D <= 0) return;
-    if (pitch < D) pitch = D;
-    feat_fill_up_kernel<<<grid_for((int64_t)capacity * 64, 256, 8192), 256, 0, s>>>(capacity, D, pitch, cache, table,
-                                                                                   QF, Kg, Ki, n);
+    feat_fill_up_kernel<<<grid_for((int64_t)capacity * 64, 256, 8192), 256, 0, s>>>(capacity, D, cache, table, QF, Kg, Ki, n);
     hipCheckError();
 }
 

@@ -84,52 +84,6 @@ void launch_deliver(hipStream_t s, const LanePtrs* d_lane, const DeliverParams& 
     hipCheckError();
 }
 
-// ------------------------------------------------------------------------------------------
-// Hand-over by copy (GPURunner, "lanes" pipeline, trainer end that does not take views): the launch group has gathered the
-// lane's rows at full width into the lane's own feature buffer; this copies the finished batch -- rows and everything
-// deliver_slice moves -- into the trainer-visible pipe slot.  A pure stream: 16-byte loads, non-temporal stores, four in
-// flight per thread.  Costs the rows a second trip through HBM (2 x rows x D x 4 bytes per batch on top of the gather's).
-// ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void handover_copy_kernel(const LanePtrs* __restrict__ lane_p, DeliverParams d)
-{
-    const LanePtrs& L = *lane_p;
-    deliver_slice(L, d, blockIdx.x, gridDim.x);
-    if (d.float_features == nullptr || L.float_features == nullptr || d.D <= 0) return;
-    const LG_G int32_t* nc = LG_GPTR(const int32_t, L.node_counter);
-    const int32_t hop_num = nc[INTRABATCH_CON * 3 - 1];
-    int32_t n = nc[INTRABATCH_CON * 3 + hop_num];
-    n = n < 0 ? 0 : n;
-    if (n > d.feature_rows) n = d.feature_rows;
-    if (n > L.feature_rows) n = L.feature_rows;
-    const int64_t words = (int64_t)n * d.D;                 // floats
-    typedef float v4 __attribute__((ext_vector_type(4)));
-    const LG_G float* src = LG_GPTR(const float, L.float_features);
-    LG_G float* dst = LG_GPTR(float, d.float_features);
-    const int64_t q = words >> 2;                           // both buffers are 256-byte aligned allocations
-    const int64_t stride = (int64_t)gridDim.x * 256;
-    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    for (; i + 3 * stride < q; i += 4 * stride) {
-        v4 v[4];
-#pragma unroll
-        for (int u = 0; u < 4; u++) v[u] = ((const LG_G v4*)src)[i + u * stride];
-#pragma unroll
-        for (int u = 0; u < 4; u++) __builtin_nontemporal_store(v[u], (LG_G v4*)dst + i + u * stride);
-    }
-    for (; i < q; i += stride) __builtin_nontemporal_store(((const LG_G v4*)src)[i], (LG_G v4*)dst + i);
-    if (blockIdx.x == 0)
-        for (int64_t k = (q << 2) + threadIdx.x; k < words; k += 256) dst[k] = src[k];
-}
-
-void launch_handover_copy(hipStream_t s, const LanePtrs* d_lane, const DeliverParams& d, int32_t max_rows)
-{
-    const int64_t bytes = (int64_t)max_rows * (d.D > 0 ? d.D : 0) * 4 + (int64_t)d.num_ids * 12;
-    int64_t grid = (bytes + 16383) / 16384;                 // ~16 KB per workgroup: 1 k workgroups for a 16 MB batch
-    if (grid > 4096) grid = 4096;
-    if (grid < 1) grid = 1;
-    handover_copy_kernel<<<(int32_t)grid, 256, 0, s>>>(d_lane, d);
-    hipCheckError();
-}
-
 // VecT: float4 for rows that are multiples of 16 bytes; `v4u` -- the same 16 bytes per lane at 4-byte alignment -- for every other
 // width of at least 4 floats (gfx950 global loads / stores of 16 bytes need dword alignment only; the compiler emits
 // global_load_dwordx4 for both), with the D % 4 trailing floats of each row moved by a scalar pass (TAIL); float below that.
@@ -209,13 +163,13 @@ __global__ __launch_bounds__(LG_GATHER_THREADS, LG_GATHER_MIN_WAVES) void gather
             const int64_t rank = (int64_t)fidx * gp.Kg + didx;                               // hotness rank of the row (cache_impl.cuh:104-109)
             const bool local_copy = gp.replica != nullptr && rank < gp.replica_rows;
             if (local_copy)      // the clique's hottest rows are also kept locally: same row, no xGMI hop
-                p = LG_GPTR(const float, gp.replica) + rank * gp.cache_pitch;
+                p = LG_GPTR(const float, gp.replica) + rank * gp.D;
             else if (didx == gp.member && gp.local_table != nullptr)     // own stripe: its address came with the launch
-                p = LG_GPTR(const float, gp.local_table) + (int64_t)fidx * gp.cache_pitch;
+                p = LG_GPTR(const float, gp.local_table) + (int64_t)fidx * gp.D;
             else if (gp.skip_remote)     // peer_gather = bulk: the owner pushes this row (bulk_push_kernel); nothing to fetch here
                 p = nullptr;
             else
-                p = LG_GPTR(const float, gp.cache_tables[didx]) + (int64_t)fidx * gp.cache_pitch;                  // :268
+                p = LG_GPTR(const float, gp.cache_tables[didx]) + (int64_t)fidx * gp.D;                  // :268
             if (counting) {    // tests / diagnostics / the computed xGMI count: [0] rows read through a stripe pointer, [1] from the
                                // replica, [2] the part of [0] from a peer's stripe -- one atomic per wave and counter
                 const unsigned long long m_rep = __ballot(local_copy), m_str = __ballot(!local_copy);
@@ -389,7 +343,7 @@ void launch_bulk_bucket(hipStream_t s, const GatherParams& g, const LanePtrs* d_
 // over xGMI these are posted stores of contiguous 512-1024-byte runs instead of the requester's scattered load round trips.
 // The lists (12 bytes per row) are read through the requester's peer mapping.
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void bulk_push_kernel(const float* __restrict__ stripe, int32_t pitch, int32_t D, const int32_t* __restrict__ fidx,
+__global__ __launch_bounds__(256) void bulk_push_kernel(const float* __restrict__ stripe, int32_t D, const int32_t* __restrict__ fidx,
                                                        const int64_t* __restrict__ dst, const unsigned long long* __restrict__ cnt,
                                                        int64_t cap, char* __restrict__ peer_arena)
 {
@@ -400,18 +354,18 @@ __global__ __launch_bounds__(256) void bulk_push_kernel(const float* __restrict_
     const int64_t wave = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 6, nwaves = ((int64_t)gridDim.x * 256) >> 6;
     const int32_t C = D / 4;
     for (int64_t i = wave; i < n; i += nwaves) {
-        const LG_G float* src = LG_GPTR(const float, stripe) + (int64_t)fidx[i] * pitch;
+        const LG_G float* src = LG_GPTR(const float, stripe) + (int64_t)fidx[i] * D;
         LG_G float* out = (LG_G float*)(peer_arena + dst[i]);
         for (int32_t c = lane; c < C; c += 64) ((LG_G v4u*)out)[c] = ((const LG_G v4u*)src)[c];
         for (int32_t k = C * 4 + lane; k < D; k += 64) out[k] = src[k];
     }
 }
 
-void launch_bulk_push(hipStream_t s, const float* stripe, int32_t pitch, int32_t D, const int32_t* fidx, const int64_t* dst,
+void launch_bulk_push(hipStream_t s, const float* stripe, int32_t D, const int32_t* fidx, const int64_t* dst,
                       const unsigned long long* cnt, int64_t cap, char* peer_arena)
 {
     if (stripe == nullptr || D <= 0 || cap <= 0) return;
-    bulk_push_kernel<<<2048, 256, 0, s>>>(stripe, pitch < D ? D : pitch, D, fidx, dst, cnt, cap, peer_arena);
+    bulk_push_kernel<<<2048, 256, 0, s>>>(stripe, D, fidx, dst, cnt, cap, peer_arena);
     hipCheckError();
 }
 
@@ -437,7 +391,6 @@ static void launch_gather_impl(hipStream_t s, GatherParams g, const LanePtrs* d_
 {
     if (g.D <= 0 || g.max_rows <= 0) return;            // :256 float_feature_len > 0
     if (g.node_capacity < 1) g.node_capacity = 1;
-    if (g.cache_pitch < g.D) g.cache_pitch = g.D;
     const dim3 grid(gather_grid_x(g.max_rows, LG_GATHER_ROWS, n_lanes), n_lanes);     // (the 4-byte vector path, and 64-row tiles at dword alignment)
     const LegionTuning& tune = tuning();
     if (g.D % 4 == 0) {
@@ -455,7 +408,7 @@ static void launch_gather_impl(hipStream_t s, GatherParams g, const LanePtrs* d_
             // +1 % -- and 32 KB below that: D = 64 with 128 rows 8.31 G edges/s, with 64 rows 8.17 G)
             const int64_t payload = g.D * 4 >= 512 ? 16384 : 32768;
             while (rows < 256 && (int64_t)rows * 2 * g.D * 4 <= payload + payload / 4) rows *= 2;       // D = 100 -> 64, D = 128 -> 32, D = 256 -> 16
-            if (tune.gather_small_tiles && (int64_t)((g.max_rows + rows - 1) / rows) * n_lanes < 4096) rows = 16;
+            if ((int64_t)((g.max_rows + rows - 1) / rows) * n_lanes < 4096) rows = 16;      // (a launch of few tiles: 4 x the workgroups)
         }
         switch (rows) {
             case 16: launch_gather_v4<16>(s, g, d_lanes, n_lanes, copy_range); break;
@@ -468,7 +421,7 @@ static void launch_gather_impl(hipStream_t s, GatherParams g, const LanePtrs* d_
         // rows that are not multiples of 16 bytes (D = 602: 2408-byte rows): 16-byte chunks at dword alignment + a scalar
         // tail, instead of the 8- / 4-byte vector paths of rounds 1-2 (0.65 of peak at D = 602)
         typedef float v4u __attribute__((ext_vector_type(4), aligned(4)));
-        const bool small = tune.gather_small_tiles && (int64_t)((g.max_rows + LG_GATHER_ROWS - 1) / LG_GATHER_ROWS) * n_lanes < 4096;
+        const bool small = (int64_t)((g.max_rows + LG_GATHER_ROWS - 1) / LG_GATHER_ROWS) * n_lanes < 4096;
         const bool r16 = small || (int64_t)g.D * 4 * 64 > 65536;
         const dim3 gr = r16 ? dim3(gather_grid_x(g.max_rows, 16, n_lanes), n_lanes) : grid;
         if (r16 && g.last_op) gather_kernel<v4u, 16, LG_GATHER_UNROLL, true, true><<<gr, LG_GATHER_THREADS, 0, s>>>(g, d_lanes, copy_range);

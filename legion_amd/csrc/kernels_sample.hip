@@ -8,26 +8,30 @@
 //   construct_graph  SS/engine/operator_impl.cu:283-296
 //   ClearPosMap      SS/engine/operator_impl.cu:542-548
 // How it computes it is new.  The reference compacts edges/new nodes with shared + global
-// atomicAdd (order is a race) and reads its counters back to the host twice per hop.  Here:
+// atomicAdd (order is a race), marks first touches in an N-bit map + an N-entry position map that it clears per batch, and
+// reads its counters back to the host twice per hop.  Here a hop is
 //   * sample_kernel: a workgroup owns 1024 consecutive slots, four per lane; the tile's frontier row
 //     headers (row start, degree, CSR slot) are staged once in LDS; the minstd draw is a table-driven
-//     modular power + one IEEE double divide; the neighbour is published with
-//     atomicMin(position_state[dst], PENDING + slot) so that the LOWEST slot owns a first touch
-//     (deterministic, unlike atomicOr on a bitmap), and the value the atomic returns tells which slot
-//     lost (slot_mark / slot_pos), so nothing re-reads the state array;
-//   * dedup_lds_kernel (lds form of the first-touch state, the default): a hop's claims de-duplicated bucket by bucket in LDS;
+//     modular power + one IEEE double divide; the picks (claims: vertex, slot) are written grouped by hash bucket into one
+//     list per bucket of the lane (8 / 16 buckets: here; 64 / 256 buckets: by place_kernel);
+//   * dedup_lists_kernel: a (lane, bucket)'s claims de-duplicated in an LDS table against the batch's known vertices: the LOWEST
+//     slot owns a first touch (deterministic, unlike atomicOr on a bitmap); every other claim's slot is marked a loser.  No
+//     per-vertex state in memory at all: nothing to clear, nothing that scales with the graph;
 //   * compact_kernel: ONE pass -- tiles handed out by ticket, counts of valid edges / first touches by wave ballots, the
 //     prefix over a lane's tiles by decoupled look-back, then the slot-ordered compaction of edges (global ids + both local
 //     positions) and of new nodes, + the next hop's row headers; its last workgroup does the counter_update state machine,
 //     so there is no host round trip and no <<<1,1>>> launch;
-//   * localise_kernel (atomics forms only): agg_src_off[e] of the edges whose neighbour another slot of the hop owns.
+//   * list_known_kernel (every hop but the last): the hop's new nodes appended to the buckets' known lists.
+// (Rounds 1-4 also carried two atomics forms of the first-touch state -- a uint32[N] array per lane and an open-addressing table,
+// claimed with atomicMin per pick -- which the LDS form beat by 5-14 % wherever it applied; since round 5 it applies to hops of
+// any size and the other two are gone: DESIGN_HISTORY.md 3, 4.2.)
 // Every kernel runs with grid.y = lanes (independent mini-batches, LanePtrs) and takes its pointers
 // from the lane descriptor as global-address-space pointers.
 // Every kernel is a fixed-size grid that strides over tiles and reads the frontier length from
 // device memory, so the whole hop is enqueued without knowing any size on the host.
 //
-// Bound: the rate of scattered 4-byte atomics and loads (~19 G atomics/s on data-dependent addresses),
-// not HBM bytes; no MFMA.
+// Bound: sample_kernel by the part's rate of random 128-byte requests; the other kernels by their dependent chains
+// (DESIGN.md 4.2); no MFMA.
 #include "legion_core.h"
 
 #include <cstdlib>
@@ -99,24 +103,18 @@ void launch_draw_batch(hipStream_t s, const int32_t* idx, const int32_t* deg, in
 // the per-batch buffers the two bracket kernels touch, as global-address-space pointers
 struct BracketLane {
     LG_G int32_t* sampled_ids; LG_G int32_t* labels; LG_G int32_t* node_counter; LG_G int32_t* edge_counter;
-    LG_G int32_t* hop_scratch; LG_G uint32_t* position_map; LG_G int32_t* slot_mark; LG_G int32_t* node_slot;
-    LG_G unsigned long long* pos_table; uint32_t pos_mask; LG_G int32_t* err_flag;
+    LG_G int32_t* hop_scratch; LG_G int32_t* node_slot;
     LG_G int32_t* known_cnt; LG_G int32_t* claim_cnt; int32_t lds_buckets;
     LG_G int32_t* counter_mirror;
-    int32_t total_num_nodes, max_slots;
 };
 __device__ __forceinline__ BracketLane bracket_lane(const LanePtrs& P)
 {
     BracketLane L;
     L.sampled_ids = LG_GPTR(int32_t, P.sampled_ids); L.labels = LG_GPTR(int32_t, P.labels);
     L.node_counter = LG_GPTR(int32_t, P.node_counter); L.edge_counter = LG_GPTR(int32_t, P.edge_counter);
-    L.hop_scratch = LG_GPTR(int32_t, P.hop_scratch); L.position_map = LG_GPTR(uint32_t, P.position_map);
-    L.slot_mark = LG_GPTR(int32_t, P.slot_mark); L.node_slot = LG_GPTR(int32_t, P.node_slot);
-    L.pos_table = LG_GPTR(unsigned long long, P.pos_table); L.pos_mask = P.pos_table_mask;
-    L.err_flag = LG_GPTR(int32_t, P.err_flag);
+    L.hop_scratch = LG_GPTR(int32_t, P.hop_scratch); L.node_slot = LG_GPTR(int32_t, P.node_slot);
     L.known_cnt = LG_GPTR(int32_t, P.known_cnt); L.claim_cnt = LG_GPTR(int32_t, P.claim_cnt); L.lds_buckets = P.lds_buckets;
     L.counter_mirror = LG_GPTR(int32_t, P.counter_mirror);
-    L.total_num_nodes = P.total_num_nodes; L.max_slots = P.max_slots;
     return L;
 }
 
@@ -124,52 +122,6 @@ __device__ __forceinline__ void raise_error(LG_G int32_t* hop_scratch, LG_G int3
 {
     __hip_atomic_fetch_or(hop_scratch + HS_ERROR, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (err_flag) __hip_atomic_fetch_or(err_flag, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-}
-
-// ------------------------------------------------------------------------------------------
-// Compact position state (legion_core.h): one claim = an ordered-linear-probing insert of
-// [epoch | vertex | pending | value] with one atomicMin(u64) per probe.  `low` is pending | slot for a
-// sampled neighbour, the final position for a seed.  Whoever is merged away (same vertex, larger value)
-// is a slot that lost its first touch: it gets the hop's mark and, in slot_pos, the final position or
-// -2 - (the slot it lost to) -- written by the one thread that saw the merge.
-// ------------------------------------------------------------------------------------------
-__device__ __forceinline__ void table_claim(LG_G unsigned long long* tab, uint32_t mask, const PosFmt& pf, int32_t id,
-                                            uint32_t low, LG_G int32_t* slot_mark, LG_G int32_t* slot_pos, int32_t mark_tag,
-                                            LG_G int32_t* hop_scratch, LG_G int32_t* err_flag)
-{
-    unsigned long long w = lg_tab_word(pf, id, low);
-    uint32_t p = lg_tab_hash(id) & mask;
-    const int sh = pf.vb + 1;
-    const uint32_t lowmask = pf.pending | pf.vmask;
-    for (uint32_t it = 0; it <= mask; it++) {
-        const unsigned long long old = __hip_atomic_fetch_min(tab + p, w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (!lg_tab_current(pf, old)) return;                 // took a stale or empty word's place
-        if (((old ^ w) >> sh) == 0) {                         // the same vertex: the lower value stays
-            const uint32_t a = (uint32_t)old & lowmask, b = (uint32_t)w & lowmask;
-            const uint32_t surv = a < b ? a : b, elim = a < b ? b : a;
-            if ((elim & pf.pending) && slot_mark != nullptr) {
-                const int32_t loser = (int32_t)(elim & pf.vmask);
-                slot_mark[loser] = mark_tag;
-                slot_pos[loser] = (surv & pf.pending) ? -2 - (int32_t)(surv & pf.vmask) : (int32_t)(surv & pf.vmask);
-            }
-            return;
-        }
-        if (old > w) w = old;                                 // displaced a larger word: carry it on
-        p = (p + 1) & mask;
-    }
-    raise_error(hop_scratch, err_flag, LG_ERR_TABLE_FULL);
-}
-
-// where the (present) vertex lives: plain loads, the table is not being claimed while this runs
-__device__ __forceinline__ uint32_t table_find(const LG_G unsigned long long* tab, uint32_t mask, const PosFmt& pf, int32_t id)
-{
-    uint32_t p = lg_tab_hash(id) & mask;
-    const unsigned long long want = lg_tab_word(pf, id, 0) >> (pf.vb + 1);
-    for (uint32_t it = 0; it <= mask; it++) {
-        if ((tab[p] >> (pf.vb + 1)) == want) return p;
-        p = (p + 1) & mask;
-    }
-    return 0xFFFFFFFFu;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -207,12 +159,7 @@ __global__ void batch_generate_kernel(SeedParams p, const LanePtrs* __restrict__
             const int32_t src_id = p.all_ids[at % p.total_cap];
             L.sampled_ids[idx] = src_id;
             if (L.node_slot != nullptr) L.node_slot[idx] = LG_FS_UNKNOWN;     // seeds: the gather looks their cache slots up
-            const PosFmt pf = lg_pos_fmt(L.hop_scratch[HS_EPOCH], L.hop_scratch[HS_VALUE_BITS]);
-            if (L.pos_table != nullptr)
-                table_claim(L.pos_table, L.pos_mask, pf, src_id, (uint32_t)idx, nullptr, nullptr, 0, L.hop_scratch, L.err_flag);
-            else if (L.position_map != nullptr)       // (lds form: no per-vertex state, the seeds are re-read from sampled_ids)
-                __hip_atomic_fetch_min(L.position_map + src_id, pf.hi | (uint32_t)idx,
-                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // seeds are unique (":26 assume no duplicate")
+            // (no per-vertex state: the de-duplication re-reads the seeds from sampled_ids; ":26 assume no duplicate")
             L.labels[idx] = p.all_labels[at % p.total_cap];
         }
     }
@@ -220,7 +167,7 @@ __global__ void batch_generate_kernel(SeedParams p, const LanePtrs* __restrict__
 
 void launch_batch_generate(hipStream_t s, const SeedParams& p, const LanePtrs* d_lanes, int32_t n_lanes)
 {
-    const int32_t n = p.batch_size > 16 ? p.batch_size : 16;
+    const int32_t n = p.batch_size > 256 ? p.batch_size : 256;      // (>= the lane's hash buckets: their list counts are zeroed here)
     batch_generate_kernel<<<dim3((n + 255) / 256, n_lanes), 256, 0, s>>>(p, d_lanes);
     hipCheckError();
 }
@@ -241,19 +188,17 @@ struct SampleArgs {
     int32_t* const* csr_dst_x;
     const LG_G int32_t* col_full; const LG_G lg_v2i* colx_full;
     const LG_G RowHdr* row_hdr;
-    bool last_hop, is_presc, loser_in_dst, compact_hoist;
+    bool last_hop, is_presc;
     LG_G unsigned long long* edge_access_time;
     LG_G unsigned long long* topo_transactions;
     // the lane's buffers, in the global address space (see LG_G in legion_core.h)
     LG_G int32_t* sampled_ids; LG_G int32_t* agg_src_ids; LG_G int32_t* agg_dst_ids; LG_G int32_t* agg_src_off; LG_G int32_t* agg_dst_off;
-    LG_G char* tmp_part_ind; LG_G uint32_t* position_map; LG_G int32_t* node_counter; LG_G int32_t* edge_counter;
-    LG_G int32_t* slot_dst; LG_G int32_t* slot_pos; LG_G int32_t* slot_mark; LG_G int32_t* slot_fs; LG_G int32_t* node_slot; LG_G unsigned long long* tile_state; LG_G int32_t* hop_scratch;
+    LG_G char* tmp_part_ind; LG_G int32_t* node_counter; LG_G int32_t* edge_counter;
+    LG_G int32_t* slot_dst; LG_G int32_t* slot_pos; LG_G int32_t* slot_fs; LG_G int32_t* node_slot; LG_G unsigned long long* tile_state; LG_G int32_t* hop_scratch;
     LG_G RowHdr* fh_edge;
-    LG_G unsigned long long* pos_table; uint32_t pos_mask; LG_G int32_t* err_flag;
+    LG_G int32_t* err_flag;
     LG_G unsigned long long* claim_pairs; LG_G int32_t* run_off; LG_G int32_t* claim_cnt; int32_t claim_cap, ids_cap;
     LG_G unsigned long long* known_pairs; LG_G int32_t* known_cnt; int32_t known_cap;
-    PosFmt pf;
-    int32_t mark_tag;   // (epoch, hop): what slot_mark holds for a slot that lost its first touch in THIS hop
 };
 
 // 16-byte header load / store through a global-address-space pointer (no implicit struct copy across
@@ -284,25 +229,22 @@ __device__ __forceinline__ SampleArgs lane_args(const HopParams& p, const LanePt
     SampleArgs a;
     a.op_id = p.op_id; a.count = p.count; a.partition_count = p.partition_count; a.max_slots = p.max_slots;
     a.csr_dst_node_ids = p.csr_dst_node_ids; a.csr_dst_x = p.csr_dst_x;
-    a.col_full = LG_GPTR(const int32_t, p.col_full); a.colx_full = LG_GPTR(const lg_v2i, p.colx_full); a.row_hdr = LG_GPTR(const RowHdr, p.row_hdr); a.last_hop = p.last_hop; a.is_presc = p.is_presc; a.loser_in_dst = p.loser_in_dst; a.compact_hoist = p.compact_hoist;
+    a.col_full = LG_GPTR(const int32_t, p.col_full); a.colx_full = LG_GPTR(const lg_v2i, p.colx_full); a.row_hdr = LG_GPTR(const RowHdr, p.row_hdr); a.last_hop = p.last_hop; a.is_presc = p.is_presc;
     a.edge_access_time = LG_GPTR(unsigned long long, p.edge_access_time);
     a.topo_transactions = LG_GPTR(unsigned long long, p.topo_transactions);
     a.sampled_ids = LG_GPTR(int32_t, L.sampled_ids); a.agg_src_ids = LG_GPTR(int32_t, L.agg_src_ids);
     a.agg_dst_ids = LG_GPTR(int32_t, L.agg_dst_ids); a.agg_src_off = LG_GPTR(int32_t, L.agg_src_off);
     a.agg_dst_off = LG_GPTR(int32_t, L.agg_dst_off); a.tmp_part_ind = LG_GPTR(char, L.tmp_part_ind);
-    a.position_map = LG_GPTR(uint32_t, L.position_map); a.node_counter = LG_GPTR(int32_t, L.node_counter);
+    a.node_counter = LG_GPTR(int32_t, L.node_counter);
     a.edge_counter = LG_GPTR(int32_t, L.edge_counter); a.slot_dst = LG_GPTR(int32_t, L.slot_dst);
-    a.slot_pos = LG_GPTR(int32_t, L.slot_pos); a.slot_mark = LG_GPTR(int32_t, L.slot_mark);
+    a.slot_pos = LG_GPTR(int32_t, L.slot_pos);
     a.slot_fs = LG_GPTR(int32_t, L.slot_fs); a.node_slot = LG_GPTR(int32_t, L.node_slot); a.tile_state = LG_GPTR(unsigned long long, L.tile_state); a.hop_scratch = LG_GPTR(int32_t, L.hop_scratch);
     a.fh_edge = LG_GPTR(RowHdr, L.fh_edge);
-    a.pos_table = LG_GPTR(unsigned long long, L.pos_table); a.pos_mask = L.pos_table_mask;
     a.err_flag = LG_GPTR(int32_t, L.err_flag);
     a.claim_pairs = LG_GPTR(unsigned long long, L.claim_pairs);
     a.run_off = LG_GPTR(int32_t, L.run_off);
     a.claim_cnt = LG_GPTR(int32_t, L.claim_cnt); a.claim_cap = L.claim_cap; a.ids_cap = L.ids_cap;
     a.known_pairs = LG_GPTR(unsigned long long, L.known_pairs); a.known_cnt = LG_GPTR(int32_t, L.known_cnt); a.known_cap = L.known_cap;
-    a.pf = lg_pos_fmt(a.hop_scratch[HS_EPOCH], a.hop_scratch[HS_VALUE_BITS]);
-    a.mark_tag = (a.hop_scratch[HS_EPOCH] << 8) | (p.op_id / INTRABATCH_CON);
     return a;
 }
 
@@ -347,18 +289,18 @@ __device__ __forceinline__ HopGeom hop_geometry(const SampleArgs& a)
 #ifndef LG_SAMPLE_SGPRS
 #define LG_SAMPLE_SGPRS 80           // 8 workgroups of 256 threads per CU need <= 80 SGPRs (MI355X_MICROARCH.md, residency); 90-106 give 6-7
 #endif
-// LATER (with !SINGLE): the kernel stops after its first sweep -- neighbours in slot_dst, the partition tile's bucket offsets in
-// run_off -- and place_kernel writes the pairs (see there)
-template <int FORM, int BB, bool SINGLE, bool LATER = false>      // 0 direct array, 1 table, 2 lds with 2^BB buckets per lane; SINGLE: partition tile = super tile
+// !SINGLE (64- and 256-bucket classes): the kernel samples K super tiles (a partition tile), counts their claims per bucket and
+// reserves, with one atomic per bucket, that many places of each bucket's claim list (run_off: {first place, count} per
+// partition tile and bucket); place_kernel writes the pairs (see there)
+template <int BB, bool SINGLE>      // 2^BB hash buckets per lane; SINGLE: partition tile = super tile
 __global__ __launch_bounds__(LG_TILE) __attribute__((amdgpu_num_sgpr(LG_SAMPLE_SGPRS))) void sample_kernel(HopParams hp, const LanePtrs* __restrict__ lanes)
 {
-    constexpr bool TABLE = FORM == 1;
     constexpr int NB = 1 << BB;
     const int32_t K = SINGLE ? 1 : hp.lds_k;      // super tiles per partition tile
     static_assert(NB <= LG_TILE, "one thread per bucket in the prefix");
     const SampleArgs a = lane_args(hp, lanes);
     __shared__ RowHdr s_hdr[LG_SUPER];
-    __shared__ int32_t s_bcnt[NB], s_boff[NB], s_base, s_wtot[LG_TILE / 64];
+    __shared__ int32_t s_bcnt[NB], s_boff[SINGLE ? NB : 1];
 
     const HopGeom g = hop_geometry(a);
     const int32_t tid = threadIdx.x;
@@ -366,13 +308,12 @@ __global__ __launch_bounds__(LG_TILE) __attribute__((amdgpu_num_sgpr(LG_SAMPLE_S
     const bool seeds = (a.op_id == INTRABATCH_CON);
     const LG_G RowHdr* fh = a.fh_edge + g.frontier_off;
 
-    // lds form: the claims of K consecutive super tiles (a partition tile) go, grouped by bucket, into ONE run of the lane's
-    // pair array.  SINGLE (K = 1): ranks are taken while the super tile is sampled.  Otherwise (many buckets: a run must stay long
-    // enough per bucket to be read in whole sectors): the first sweep samples and counts, the second re-reads slot_dst
-    // (this workgroup's own stores) and places the pairs.
+    // lds form: a hop's claims go, grouped by hash bucket, to ONE LIST PER BUCKET of the lane.  SINGLE (8 / 16 buckets): ranks are
+    // taken while the super tile is sampled and the pairs are written here.  Otherwise (many buckets: a bucket's share of a super
+    // tile is a few pairs) the kernel only samples and counts; place_kernel re-reads slot_dst and writes the pairs.
     const int32_t nparts = (g.nsuper + K - 1) / K;
     for (int32_t m = blockIdx.x; m < nparts; m += gridDim.x) {
-        if (FORM == 2 && !SINGLE && tid < NB) s_bcnt[tid] = 0;      // (visible after the first barrier of the first super tile)
+        if (!SINGLE && tid < NB) s_bcnt[tid] = 0;      // (visible after the first barrier of the first super tile)
         for (int32_t sub = 0; sub < K; sub++) {
             const int32_t st = m * K + sub;
             if (st >= g.nsuper) break;
@@ -416,7 +357,7 @@ __global__ __launch_bounds__(LG_TILE) __attribute__((amdgpu_num_sgpr(LG_SAMPLE_S
             }
             __syncthreads();
 
-            if (FORM == 2 && SINGLE && tid < NB) s_bcnt[tid] = 0;     // (made visible by the barrier above the loads' use below)
+            if (SINGLE && tid < NB) s_bcnt[tid] = 0;     // (made visible by the barrier above the loads' use below)
             int32_t dst[LG_SLOTS_PER_LANE], fs[LG_SLOTS_PER_LANE];
 #pragma unroll
             for (int u = 0; u < LG_SLOTS_PER_LANE; u++) {
@@ -458,52 +399,19 @@ __global__ __launch_bounds__(LG_TILE) __attribute__((amdgpu_num_sgpr(LG_SAMPLE_S
             for (int u = 0; u < LG_SLOTS_PER_LANE; u++) {
                 const int32_t idx = idx0 + u * LG_TILE + tid;
                 if (idx < g.total) {
-                    if (FORM == 2) {
-                        // lds form: no claim here; the pair goes to its hash bucket below
-                        if (dst[u] >= 0 && a.edge_access_time)
-                            __hip_atomic_fetch_add(a.edge_access_time + g.frontier[idx / count], 1ull, __ATOMIC_RELAXED,
-                                                   __HIP_MEMORY_SCOPE_AGENT);
-                        if (dst[u] < 0) dst[u] = -1;
-                    } else if (dst[u] >= 0) {                                  // :244
-                        // First touch goes to the LOWEST slot that sampled the vertex.  The atomic returns what
-                        // it replaced, so every loser is known without a second look at the state array:
-                        //   old < key : the vertex is already in the batch (final position) or a lower slot of this
-                        //               hop holds it -> this slot lost, and knows to whom;
-                        //   old > key, this epoch : old is a higher slot that held it until now -> THAT slot lost to
-                        //               this one (it wrote nothing itself, so the two stores below have one writer);
-                        //   otherwise : untouched so far; this slot holds it unless a lower one shows up.
-                        // A loser gets the hop's tag in slot_mark and, in slot_pos, the final position or -2 - (the
-                        // slot it lost to); the chain of losers ends at the winner (localise follows it).
-                        if (TABLE) {      // compact form: the same outcome through the lane's open-addressing table
-                            table_claim(a.pos_table, a.pos_mask, a.pf, dst[u], a.pf.pending | (uint32_t)idx, a.slot_mark, a.slot_pos,
-                                        a.mark_tag, a.hop_scratch, a.err_flag);
-                        } else {
-                            const uint32_t key = a.pf.hi | a.pf.pending | (uint32_t)idx;
-                            const uint32_t old = __hip_atomic_fetch_min(a.position_map + dst[u], key, __ATOMIC_RELAXED,
-                                                                        __HIP_MEMORY_SCOPE_AGENT);
-                            if (old < key) {
-                                a.slot_mark[idx] = a.mark_tag;
-                                a.slot_pos[idx] = (old & a.pf.pending) ? -2 - (int32_t)(old & a.pf.vmask) : (int32_t)(old & a.pf.vmask);
-                            } else if ((old & ~(a.pf.pending | a.pf.vmask)) == a.pf.hi) {
-                                const int32_t loser = (int32_t)(old & a.pf.vmask);
-                                a.slot_mark[loser] = a.mark_tag;
-                                a.slot_pos[loser] = -2 - idx;
-                            }
-                        }
-                        if (a.edge_access_time)                                // :358
-                            __hip_atomic_fetch_add(a.edge_access_time + g.frontier[idx / count], 1ull, __ATOMIC_RELAXED,
-                                                   __HIP_MEMORY_SCOPE_AGENT);
-                    } else {
-                        dst[u] = -1;
-                    }
+                    // (no claim here: the pair goes to its hash bucket below / in place_kernel)
+                    if (dst[u] >= 0 && a.edge_access_time)                     // :358
+                        __hip_atomic_fetch_add(a.edge_access_time + g.frontier[idx / count], 1ull, __ATOMIC_RELAXED,
+                                               __HIP_MEMORY_SCOPE_AGENT);
+                    if (dst[u] < 0) dst[u] = -1;                               // :244
                     // slot_dst / slot_fs are read once, by the compaction two kernels later: non-temporal stores (+0.5 % on the whole job,
                     // tools/lds_tuning/value_rounds.sh: they do not push the column arrays' lines out of the caches)
                     __builtin_nontemporal_store(dst[u], &a.slot_dst[idx]);
-                    if (FORM == 2) a.slot_pos[idx] = -1;      // "no position yet": compact_kernel publishes a first touch's position here (plain store: no difference)
+                    a.slot_pos[idx] = -1;      // "no position yet": compact_kernel publishes a first touch's position here (plain store: no difference)
                     if (a.slot_fs != nullptr && dst[u] >= 0) __builtin_nontemporal_store(fs[u], &a.slot_fs[idx]);     // (read for first-touch slots only)
                 }
             }
-            if (FORM == 2 && SINGLE) {
+            if (SINGLE) {
                 // the super tile's claims, grouped by hash bucket, into one run of the lane's pair array: ranks by LDS atomics
                 // (the order inside a bucket does not matter), ONE global reservation per super tile
                 int32_t rank[LG_SLOTS_PER_LANE], bkt[LG_SLOTS_PER_LANE];
@@ -535,46 +443,22 @@ __global__ __launch_bounds__(LG_TILE) __attribute__((amdgpu_num_sgpr(LG_SAMPLE_S
                     }
             }
 
-            if (FORM == 2 && !SINGLE) {
+            if (!SINGLE) {
 #pragma unroll
                 for (int u = 0; u < LG_SLOTS_PER_LANE; u++)
                     if (dst[u] >= 0) atomicAdd(&s_bcnt[lg_tab_hash(dst[u]) & (NB - 1)], 1);
             }
             __syncthreads();
         }
-        if (FORM == 2 && !SINGLE) {
-            // exclusive prefix of the bucket counts over the workgroup, one global reservation, then the second sweep
-            const int32_t c = tid < NB ? s_bcnt[tid] : 0;
-            int32_t inc = c;
-            for (int d = 1; d < 64; d <<= 1) { const int32_t o = __shfl_up(inc, d); if ((tid & 63) >= d) inc += o; }
-            if ((tid & 63) == 63) s_wtot[tid >> 6] = inc;
-            __syncthreads();
-            int32_t wbase = 0, tot = 0;
-            for (int w = 0; w < LG_TILE / 64; w++) { if (w < (tid >> 6)) wbase += s_wtot[w]; tot += s_wtot[w]; }
-            if (tid < NB) { s_boff[tid] = wbase + inc - c; s_bcnt[tid] = 0; }
-            if (tid == 0) {
-                s_base = tot > 0 ? __hip_atomic_fetch_add(a.hop_scratch + HS_PAIR_CURSOR, tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
-                a.run_off[(int64_t)m * (NB + 1) + NB] = s_base + tot;
-            }
-            __syncthreads();
-            if (tid < NB) a.run_off[(int64_t)m * (NB + 1) + tid] = s_base + s_boff[tid];
-            for (int32_t sub = 0; sub < (LATER ? 0 : K); sub++) {
-                const int32_t idx0 = (m * K + sub) * LG_SUPER;
-                if (idx0 >= g.total) break;
-                int32_t d[LG_SLOTS_PER_LANE];
-#pragma unroll
-                for (int u = 0; u < LG_SLOTS_PER_LANE; u++) {
-                    const int32_t idx = idx0 + u * LG_TILE + tid;
-                    d[u] = idx < g.total ? a.slot_dst[idx] : -1;
-                }
-#pragma unroll
-                for (int u = 0; u < LG_SLOTS_PER_LANE; u++) {
-                    if (d[u] < 0) continue;
-                    const int32_t bk = (int32_t)(lg_tab_hash(d[u]) & (NB - 1));
-                    const int32_t r = atomicAdd(&s_bcnt[bk], 1);
-                    a.claim_pairs[s_base + s_boff[bk] + r] =
-                        ((unsigned long long)(uint32_t)d[u] << 32) | (uint32_t)(idx0 + u * LG_TILE + tid);
-                }
+        if (!SINGLE) {
+            // one reservation per bucket and partition tile (a count past the list's capacity is not written by place_kernel:
+            // the list's count then says so, and the bucket's de-duplication workgroup reads the hop's slots instead)
+            if (tid < NB) {
+                const int32_t c = s_bcnt[tid];
+                lg_v2i r;
+                r.x = c > 0 ? __hip_atomic_fetch_add(a.claim_cnt + tid * LG_CLAIM_CNT_STRIDE, c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+                r.y = c;
+                ((LG_G lg_v2i*)a.run_off)[(int64_t)m * NB + tid] = r;
             }
             __syncthreads();                       // the next partition tile zeroes s_bcnt
         }
@@ -582,50 +466,69 @@ __global__ __launch_bounds__(LG_TILE) __attribute__((amdgpu_num_sgpr(LG_SAMPLE_S
 }
 
 // ------------------------------------------------------------------------------------------
-// K1a (lds form, 64- and 256-bucket classes, partition tiles of at most LG_PLACE_MAX_K super tiles): the second sweep of the
-// sampling kernel as a kernel of its own.  With 64-256 buckets a wave's 64 pairs go to ~50 different runs: written straight
-// to memory they are 8-byte stores all over the partition tile's region, and the sweep cost the hop-3 launch of [15,10,5] at
-// B = 8000 as much again as its scattered column loads.  But a partition tile's pairs, grouped by bucket, form ONE
-// contiguous block of the lane's pair array: here they are ranked and staged in LDS (8 KB per super tile) and the block is
-// then streamed out, fully coalesced.  The sampling kernel keeps its occupancy for the scattered loads (no staging there);
-// this kernel reads slot_dst and writes the pairs as plain streams.
+// K1a (lds form, 64- and 256-bucket classes, partition tiles of at most LG_PLACE_MAX_K super tiles): the pairs of a partition
+// tile, written to the buckets' claim lists.  With 64-256 buckets a wave's 64 pairs go to ~50 different lists: written straight
+// from the sampling kernel they are 8-byte stores all over the lane's pair array (that sweep cost the hop-3 launch of [15,10,5]
+// at B = 8000 as much again as its scattered column loads).  Here the partition tile's pairs are ranked and staged in LDS grouped
+// by bucket (8 KB per super tile), and the staged block is then written out entry by entry: consecutive entries of a bucket go
+// to consecutive places of that bucket's list (the places sample_kernel reserved), so a bucket's share of the partition tile
+// leaves as one run.  The sampling kernel keeps its occupancy for the scattered loads (no staging there); this kernel reads
+// slot_dst as a plain stream.
 // ------------------------------------------------------------------------------------------
+// Workgroups of 1024 threads (one slot per thread and super tile): with the 64 KB stage of K = 8 two of them share a CU, i.e. 32
+// waves per CU keep this stream's loads in flight (round 4's 256-thread workgroups left 8 waves per CU: 107 us per 64-lane
+// group of B = 8000 for 250 MB).
 #define LG_PLACE_MAX_K 8
+#define LG_PLACE_THREADS 1024
 template <int BB>
-__global__ __launch_bounds__(LG_TILE) void place_kernel(HopParams hp, const LanePtrs* __restrict__ lanes)
+__global__ __launch_bounds__(LG_PLACE_THREADS) void place_kernel(HopParams hp, const LanePtrs* __restrict__ lanes)
 {
     constexpr int NB = 1 << BB;
+    static_assert(NB <= 256 && LG_SUPER == LG_PLACE_THREADS, "one thread per bucket in the prefix, one slot per thread and super tile");
     extern __shared__ unsigned long long s_stage[];           // hp.lds_k * LG_SUPER pairs
-    __shared__ int32_t s_off[NB + 1], s_cnt[NB];
+    __shared__ int32_t s_off[NB + 1], s_cnt[NB], s_list[NB], s_wtot[4];
     const SampleArgs a = lane_args(hp, lanes);
     const int32_t K = hp.lds_k;
     const HopGeom g = hop_geometry(a);
     const int32_t tid = threadIdx.x;
     const int32_t nparts = (g.nsuper + K - 1) / K;
     for (int32_t m = blockIdx.x; m < nparts; m += gridDim.x) {
-        for (int32_t i = tid; i <= NB; i += LG_TILE) s_off[i] = a.run_off[(int64_t)m * (NB + 1) + i];
-        for (int32_t i = tid; i < NB; i += LG_TILE) s_cnt[i] = 0;
+        // what sample_kernel reserved: {first place in the bucket's list, count}; exclusive prefix of the counts = the staging order
+        lg_v2i r; r.x = 0; r.y = 0;
+        if (tid < NB) r = ((const LG_G lg_v2i*)a.run_off)[(int64_t)m * NB + tid];
+        int32_t inc = r.y;
+        if (tid < 256) {
+            for (int d = 1; d < 64; d <<= 1) { const int32_t o = __shfl_up(inc, d); if ((tid & 63) >= d) inc += o; }
+            if ((tid & 63) == 63) s_wtot[tid >> 6] = inc;
+        }
         __syncthreads();
-        const int32_t base = s_off[0], tot = s_off[NB] - base;
-        for (int32_t sub = 0; sub < K; sub++) {
-            const int32_t idx0 = (m * K + sub) * LG_SUPER;
-            if (idx0 >= g.total) break;
-            int32_t d[LG_SLOTS_PER_LANE];
+        int32_t wbase = 0, tot = 0;
+        for (int w = 0; w < 4; w++) { if (w < (tid >> 6)) wbase += s_wtot[w]; tot += s_wtot[w]; }
+        if (tid < NB) { s_off[tid] = wbase + inc - r.y; s_list[tid] = r.x; s_cnt[tid] = 0; }
+        if (tid == 0) s_off[NB] = tot;
+        __syncthreads();
+        for (int32_t sub0 = 0; sub0 < K; sub0 += 4) {
+            int32_t d[4];
 #pragma unroll
-            for (int u = 0; u < LG_SLOTS_PER_LANE; u++) {
-                const int32_t idx = idx0 + u * LG_TILE + tid;
-                d[u] = idx < g.total ? a.slot_dst[idx] : -1;
+            for (int u = 0; u < 4; u++) {
+                const int32_t idx = (m * K + sub0 + u) * LG_SUPER + tid;
+                d[u] = (sub0 + u < K && idx < g.total) ? a.slot_dst[idx] : -1;
             }
 #pragma unroll
-            for (int u = 0; u < LG_SLOTS_PER_LANE; u++) {
+            for (int u = 0; u < 4; u++) {
                 if (d[u] < 0) continue;
                 const int32_t bk = (int32_t)(lg_tab_hash(d[u]) & (NB - 1));
-                const int32_t r = atomicAdd(&s_cnt[bk], 1);
-                s_stage[s_off[bk] - base + r] = ((unsigned long long)(uint32_t)d[u] << 32) | (uint32_t)(idx0 + u * LG_TILE + tid);
+                const int32_t rk = atomicAdd(&s_cnt[bk], 1);
+                s_stage[s_off[bk] + rk] = ((unsigned long long)(uint32_t)d[u] << 32) | (uint32_t)((m * K + sub0 + u) * LG_SUPER + tid);
             }
         }
         __syncthreads();
-        for (int32_t i = tid; i < tot; i += LG_TILE) a.claim_pairs[base + i] = s_stage[i];
+        for (int32_t i = tid; i < tot; i += LG_PLACE_THREADS) {
+            const unsigned long long pr = s_stage[i];
+            const int32_t bk = (int32_t)(lg_tab_hash((int32_t)(pr >> 32)) & (NB - 1));
+            const int32_t at = s_list[bk] + (i - s_off[bk]);
+            if (at < a.claim_cap) a.claim_pairs[lg_claim_at<NB>(bk, at)] = pr;
+        }
         __syncthreads();                           // (the next partition tile re-uses the stage and the counts)
     }
 }
@@ -634,21 +537,29 @@ __global__ __launch_bounds__(LG_TILE) void place_kernel(HopParams hp, const Lane
 // K1b (lds form): de-duplication of a hop's claims, one workgroup per (bucket, lane), entirely in LDS.
 //   table word = [ vertex : 32 | pending : 1 | value : 31 ], empty = all ones, ordered linear probing with atomicMin.
 //   1. the batch's known vertices that hash into this bucket go in with their position: the seeds from sampled_ids, the
-//      nodes earlier hops added from the bucket's list (list_known_kernel) -- or all of them from sampled_ids when the
+//      nodes earlier hops added from the bucket's known list (list_known_kernel) -- or all of them from sampled_ids when the
 //      list outgrew its capacity;
 //   2. the bucket's claims go in as pending | slot: per vertex the lowest value survives -- a known position beats any
 //      slot, a lower slot beats a higher one;
 //   3. every claim looks its vertex up: the claim that IS the surviving word is a first touch and stays unmarked; every
-//      other claim gets the hop's mark and, in slot_pos, the final position or -2 - (the winning slot) -- exactly what
-//      the atomics of the other two forms leave (here the chain of losers always has length one).
+//      other claim's slot is marked a loser -- slot_dst[slot] = -2 - vertex (LG_SLOT_LOSER: any int32 vertex id fits, and the
+//      compaction reads the mark in the stream it reads anyway) -- and gets, in slot_pos, the vertex's final position or
+//      -2 - (the winning slot: always a LOWER slot of this hop, and itself a first touch).
 // A bucket whose vertices cannot fit the table is processed in P passes over sub-buckets (further hash bits), so the
 // result never depends on how the hash spreads the batch.  Nothing survives the hop: nothing to clear, no state that
-// scales with the graph.  The claims arrive as ONE LIST PER BUCKET in the 8- and 16-bucket classes (round 4: the workgroup's
-// reads then all leave in one round trip, see LISTS below), and as one segment per partition tile of the sampling kernel
-// (run_off) in the 64- and 256-bucket classes, where a workgroup addresses claim k of its bucket through the prefix of the
-// segment lengths.
+// scales with the graph.
+// The claims arrive as ONE LIST PER BUCKET in every class (8 / 16 buckets: written by sample_kernel; 64 / 256: by place_kernel).
+// A workgroup's life used to be a chain of dependent round trips to memory (lane pointers -> live counters -> segment table ->
+// claims); with one list per bucket, what a thread reads first -- its claims of the list, its seed, its entry of the known list --
+// sits at addresses that do not depend on the live counters, so these loads leave TOGETHER with the loads of the counters and
+// list lengths (entries past the live lengths are stale and are masked when they are used).
+// Measured on the 512-lane group of the headline workload (round 4, timing-only builds): launching 4096 workgroups of 16 waves
+// costs 54 us before any of them does anything, with all reads requested up front and one barrier it is 108 us, the table work
+// brings it to ~190.  Fewer, longer-lived workgroups remove launch cost and hide the loads -- and lose under the weave, where the
+// heavy stream's kernel gets its share of the machine by asking for slots again and again while the low-priority stream's
+// workgroups take every slot a long-lived workgroup cannot ask for again (DESIGN_HISTORY 4.2: two buckets per workgroup, a
+// persistent launch, one workgroup per lane for small hops -- all rejected and removed).
 // ------------------------------------------------------------------------------------------
-#define LG_DEDUP_BATCH 4             // known vertices a thread loads before it works on them (their loads are in flight together)
 #ifndef LG_DEDUP_CLAIMS
 #define LG_DEDUP_CLAIMS 5           // claims a thread keeps in registers (a bucket of at most LG_DEDUP_CLAIMS * LG_DEDUP_THREADS is "resident")
 #endif
@@ -670,55 +581,32 @@ __device__ __forceinline__ void lds_barrier()
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
 }
 
-// ---- 8- and 16-bucket classes: one claim list per bucket -----------------------------------------------------------------
-// A workgroup's life used to be a chain of dependent round trips to memory (lane pointers -> live counters -> segment table ->
-// claims); with one list per bucket, what a thread reads first -- its claims of the list, its seed, its entry of the known list --
-// sits at addresses that do not depend on the live counters, so these loads leave TOGETHER with the loads of the counters and
-// list lengths (entries past the live lengths are stale and are masked when they are used).  A workgroup can take UNITS buckets
-// of its lane in turn, the loads of the next bucket requested before the table work of the current one (the barriers order LDS
-// only -- lds_barrier -- so they do not wait for those loads); the default is ONE bucket per workgroup:
-// Measured on the 512-lane group of the headline workload (tools/lds_tuning/dedup_ab.sh, timing-only builds): launching 4096
-// workgroups of 16 waves costs 54 us before any of them does anything, with all reads requested up front and one barrier it is
-// 108 us, the table work brings it to ~190.  Fewer, longer-lived workgroups remove launch cost and hide the loads -- and lose
-// under the weave, where the heavy stream's kernel gets its share of the machine by asking for slots again and again while
-// the low-priority stream's workgroups take every slot a long-lived workgroup cannot ask for again: two buckets per workgroup
-// 209 us against 192; a persistent launch of 512 workgroups over all units (fixed stride or by ticket) 161 us ALONE but
-// 240-305 us under the weave.  Also rejected: a table whose words never move (compare-and-swap + min, one LDS load per
-// look-up): +25 us; 512-thread workgroups (8 or 16 buckets): +0..40 us.
-#ifndef LG_DEDUP_UNITS
-#define LG_DEDUP_UNITS 1
-#endif
-#ifndef LG_DEDUP_ONE_WG_SLOTS
-#define LG_DEDUP_ONE_WG_SLOTS 32768    // hops of at most this many slots (in groups of at least LegionTuning.lds_one_wg_lanes lanes): one workgroup per lane
-#endif
-template <int BB, int UNITS, int CL>      // CL: claims a thread keeps in registers (a bucket of at most CL * LG_DEDUP_THREADS claims is "resident")
+template <int BB, int CL>      // CL: claims a thread keeps in registers (a bucket of at most CL * LG_DEDUP_THREADS claims is "resident")
 __global__ __launch_bounds__(LG_DEDUP_THREADS) __attribute__((amdgpu_num_sgpr(80)))
 void dedup_lists_kernel(HopParams hp, const LanePtrs* __restrict__ lanes)
 {
     constexpr int NB = 1 << BB;
-    constexpr int STEP = NB / UNITS;
     constexpr uint32_t PENDING = 0x80000000u;
-    static_assert(NB % UNITS == 0, "buckets per workgroup");
     __shared__ unsigned long long s_tab[LG_LDS_TABLE];
     __shared__ int32_t s_full;
-    const int32_t tid = threadIdx.x;
+    const int32_t tid = threadIdx.x, b = (int32_t)blockIdx.x;
     const SampleArgs a = lane_args(hp, lanes);
 
-    struct Req {                                   // what a unit (bucket) reads first
-        unsigned long long rp[CL];    // the thread's claims u * THREADS + tid of the bucket's list
-        unsigned long long kl0;                    // the bucket's known list [tid]
-        int32_t n_listed, n_claims;
-    };
-    auto request = [&](int32_t b, Req& q) {
+    // what the workgroup reads first: the thread's claims u * THREADS + tid of the bucket's list, its entry of the bucket's known
+    // list, the list lengths, its first seed and the node counts before this hop -- one round trip
+    unsigned long long rp[CL];
 #pragma unroll
-        for (int u = 0; u < CL; u++) {
-            const int32_t k = u * LG_DEDUP_THREADS + tid;
-            q.rp[u] = k < a.claim_cap ? a.claim_pairs[lg_claim_at<NB>(b, k)] : ~0ull;
-        }
-        q.kl0 = (a.known_pairs != nullptr && tid < a.known_cap) ? a.known_pairs[(int64_t)b * a.known_cap + tid] : ~0ull;
-        q.n_listed = a.known_pairs != nullptr ? a.known_cnt[b] : 0;
-        q.n_claims = a.claim_cnt[b * LG_CLAIM_CNT_STRIDE];
-    };
+    for (int u = 0; u < CL; u++) {
+        const int32_t k = u * LG_DEDUP_THREADS + tid;
+        rp[u] = k < a.claim_cap ? a.claim_pairs[lg_claim_at<NB>(b, k)] : ~0ull;
+    }
+    unsigned long long kl0 = (a.known_pairs != nullptr && tid < a.known_cap) ? a.known_pairs[(int64_t)b * a.known_cap + tid] : ~0ull;
+    const int32_t n_listed = a.known_pairs != nullptr ? a.known_cnt[b] : 0;
+    const int32_t total = a.claim_cnt[b * LG_CLAIM_CNT_STRIDE];      // (the count of the bucket's claims even when the list could not take them all)
+    const int32_t kid0 = tid < a.ids_cap ? a.sampled_ids[tid] : -1;
+    const int32_t n_known = a.node_counter[0] + a.node_counter[1];
+    const int32_t n_seed = min(max(a.node_counter[INTRABATCH_CON * 3], 0), n_known);
+
     auto insert = [&](unsigned long long w, uint32_t h) {
         uint32_t p = lds_slot_of(h);
         for (int it = 0; it < LG_LDS_TABLE; it++) {
@@ -730,205 +618,15 @@ void dedup_lists_kernel(HopParams hp, const LanePtrs* __restrict__ lanes)
         s_full = 1;
     };
 
-    Req nxt;
-    request((int32_t)blockIdx.x, nxt);
-    // the lane's part (the same for every bucket): the first seed of the thread and the node counts before this hop
-    const int32_t kid0 = tid < a.ids_cap ? a.sampled_ids[tid] : -1;
-    const int32_t n_known = a.node_counter[0] + a.node_counter[1];
-    const int32_t n_seed = min(max(a.node_counter[INTRABATCH_CON * 3], 0), n_known);
-
-#pragma unroll 1
-    for (int j = 0; j < UNITS; j++) {
-        const int32_t b = (int32_t)blockIdx.x + j * STEP;
-        Req cur = nxt;
-        if (j + 1 < UNITS) request(b + STEP, nxt);
-
-        // the batch's vertices before this hop are the seeds (sampled_ids) and the nodes earlier hops added (the bucket's known
-        // list -- or sampled_ids too when there is no list or it outgrew its capacity)
-        const int32_t n_listed = cur.n_listed;
-        const bool listed = a.known_pairs != nullptr && n_listed <= a.known_cap;
-        const int32_t n_scan = listed ? n_seed : n_known;
-        const int32_t total = cur.n_claims;            // (the count of the bucket's claims even when the list could not take them all)
-        const LG_G unsigned long long* klist = a.known_pairs + (int64_t)b * a.known_cap;
-#pragma unroll
-        for (int u = 0; u < CL; u++)
-            if (u * LG_DEDUP_THREADS + tid >= total) cur.rp[u] = ~0ull;
-        if (!listed || tid >= n_listed) cur.kl0 = ~0ull;
-        // passes over sub-buckets: see dedup_lds_kernel
-        const int32_t known_est = (listed ? n_listed : 0) + n_scan / NB + n_scan / (4 * NB) + 32;
-        int32_t passes = 1;
-        while ((int64_t)known_est + total > (int64_t)passes * (LG_LDS_TABLE / 16 * LG_LDS_FILL_16THS)) passes <<= 1;
-        // A bucket of at most CL claims per thread (the usual case) works from the registers.  A larger one is read
-        // again, sweep by sweep; and a bucket whose list could not take all its claims (its count says so) reads the hop's slots
-        // instead and keeps what hashes into this bucket.
-        const bool from_slots = total > a.claim_cap;
-        const bool resident = !from_slots && total <= CL * LG_DEDUP_THREADS;
-        const int32_t n_src = from_slots ? hop_geometry(a).total : total;
-        auto fetch = [&](int32_t k0, unsigned long long (&pr)[CL]) {
-#pragma unroll
-            for (int u = 0; u < CL; u++) {
-                const int32_t k = k0 + u * LG_DEDUP_THREADS + tid;
-                pr[u] = ~0ull;
-                if (k >= n_src) continue;
-                if (from_slots) {
-                    int32_t d = a.slot_dst[k];
-                    if (d < 0) continue;
-                    if (a.loser_in_dst) d &= ~LG_LOSER_BIT;          // (an earlier pass may have marked the slot)
-                    if ((lg_tab_hash(d) & (NB - 1)) == (uint32_t)b) pr[u] = ((unsigned long long)(uint32_t)d << 32) | (uint32_t)k;
-                } else {
-                    pr[u] = a.claim_pairs[lg_claim_at<NB>(b, k)];
-                }
-            }
-        };
-
-        for (;;) {
-            const uint32_t pmask = (uint32_t)passes - 1u;
-            bool overflow = false;
-            for (uint32_t pass = 0; pass <= pmask; pass++) {
-                for (int32_t i = tid; i < LG_LDS_TABLE; i += LG_DEDUP_THREADS) s_tab[i] = ~0ull;
-                if (tid == 0) s_full = 0;
-                lds_barrier();
-                for (int32_t i0 = 0; i0 < n_scan; i0 += LG_DEDUP_THREADS) {
-                    const int32_t i = i0 + tid;
-                    const int32_t id = i >= n_scan ? -1 : (i0 == 0 ? kid0 : a.sampled_ids[i]);      // (the first one came early)
-                    if (id < 0) continue;
-                    const uint32_t h = lg_tab_hash(id);
-                    if ((h & (NB - 1)) != (uint32_t)b || ((h >> BB) & pmask) != pass) continue;
-                    insert(((unsigned long long)(uint32_t)id << 32) | (uint32_t)i, h);
-                }
-                if (listed)
-                    for (int32_t i0 = 0; i0 < n_listed; i0 += LG_DEDUP_THREADS) {
-                        const int32_t i = i0 + tid;
-                        const unsigned long long pr = i0 == 0 ? cur.kl0 : (i < n_listed ? klist[i] : ~0ull);
-                        if (pr == ~0ull) continue;
-                        const uint32_t h = lg_tab_hash((int32_t)(pr >> 32));
-                        if (((h >> BB) & pmask) != pass) continue;
-                        insert(pr, h);
-                    }
-                for (int32_t k0 = 0; k0 < n_src; k0 += CL * LG_DEDUP_THREADS) {
-                    unsigned long long pr[CL];
-                    if (resident) {
-#pragma unroll
-                        for (int u = 0; u < CL; u++) pr[u] = cur.rp[u];
-                    } else
-                        fetch(k0, pr);
-#pragma unroll
-                    for (int u = 0; u < CL; u++) {
-                        if (pr[u] == ~0ull) continue;
-                        const uint32_t h = lg_tab_hash((int32_t)(pr[u] >> 32));
-                        if (((h >> BB) & pmask) != pass) continue;
-                        insert((pr[u] & 0xFFFFFFFF00000000ull) | PENDING | (uint32_t)pr[u], h);
-                    }
-                }
-                lds_barrier();
-#ifndef LG_LDS_NO_RETRY
-                if (s_full != 0) { overflow = true; break; }       // (uniform: read behind the barrier, reset behind the next one)
-#endif
-                for (int32_t k0 = 0; k0 < n_src; k0 += CL * LG_DEDUP_THREADS) {
-                    unsigned long long pr[CL];
-                    if (resident) {
-#pragma unroll
-                        for (int u = 0; u < CL; u++) pr[u] = cur.rp[u];
-                    } else
-                        fetch(k0, pr);
-#pragma unroll
-                    for (int u = 0; u < CL; u++) {
-                        if (pr[u] == ~0ull) continue;
-                        const uint32_t id = (uint32_t)(pr[u] >> 32), slot = (uint32_t)pr[u];
-                        const uint32_t h = lg_tab_hash((int32_t)id);
-                        if (((h >> BB) & pmask) != pass) continue;
-                        uint32_t p = lds_slot_of(h);
-                        uint32_t v = 0xFFFFFFFFu;
-                        for (int it = 0; it < LG_LDS_TABLE; it++) {
-                            const unsigned long long w = s_tab[p];
-                            if ((uint32_t)(w >> 32) == id) { v = (uint32_t)w; break; }
-                            p = (p + 1) & (LG_LDS_TABLE - 1);
-                        }
-                        if (v != (PENDING | slot)) {          // not the lowest slot of a new vertex
-                            if (a.loser_in_dst) a.slot_dst[slot] = (int32_t)(id | LG_LOSER_BIT);      // (vertex ids < 2^30: the mark rides in the id)
-                            else a.slot_mark[slot] = a.mark_tag;
-                            a.slot_pos[slot] = (v & PENDING) ? -2 - (int32_t)(v & ~PENDING) : (int32_t)v;
-                        }
-                    }
-                }
-                lds_barrier();                                 // (the next pass / bucket clears the table)
-            }
-            if (!overflow) break;
-            if (passes >= (1 << 14)) {                             // 2^14 sub-buckets of one bucket still too full: not a hash problem
-                if (tid == 0) raise_error(a.hop_scratch, a.err_flag, LG_ERR_TABLE_FULL);
-                break;
-            }
-            passes <<= 1;
-        }
-        if (tid == 0) a.claim_cnt[b * LG_CLAIM_CNT_STRIDE] = 0;      // the next hop's sampling starts an empty list
-    }
-}
-
-// ---- 64- and 256-bucket classes: the claims of a bucket arrive as one segment per partition tile of the sampling kernel
-//      (run_off); a workgroup addresses claim k of its bucket through the prefix of the segment lengths ------------------------
-template <int BB>
-__global__ __launch_bounds__(LG_DEDUP_THREADS) __attribute__((amdgpu_num_sgpr(80)))
-void dedup_lds_kernel(HopParams hp, const LanePtrs* __restrict__ lanes)
-{
-    constexpr int NB = 1 << BB;
-    const int32_t K = hp.lds_k;                           // super tiles per partition tile
-    constexpr int MAX_PARTS = LG_LDS_MAX_PARTS + 2;       // partition tiles of a hop (sample_kernel's K super tiles each)
-    const SampleArgs a = lane_args(hp, lanes);
-    __shared__ unsigned long long s_tab[LG_LDS_TABLE];
-    __shared__ int32_t s_pref[MAX_PARTS];                  // exclusive prefix of the bucket's segment lengths
-    __shared__ int32_t s_seg[MAX_PARTS];                   // where the bucket's segment of partition tile t starts in claim_pairs
-    __shared__ int32_t s_total, s_full;
-    const HopGeom g = hop_geometry(a);
-    const int32_t nparts = (g.nsuper + K - 1) / K;
-    const int32_t tid = threadIdx.x, b = blockIdx.x;
-    const int32_t n_known = a.node_counter[0] + a.node_counter[1];          // nodes of the batch before this hop
-    constexpr uint32_t PENDING = 0x80000000u;
-    const LG_G int32_t* roff = a.run_off + b;              // roff[t * (NB + 1)]: start of this bucket's segment of partition tile t
-
-    // the batch's vertices before this hop: the seeds are read from sampled_ids, the nodes earlier hops added from the
-    // bucket's list (list_known_kernel) -- or from sampled_ids too when there is no list or it outgrew its capacity
-    const int32_t n_seed = min(max(a.node_counter[INTRABATCH_CON * 3], 0), n_known);
-    const int32_t n_listed = a.known_pairs != nullptr ? a.known_cnt[b] : 0;
+    // the batch's vertices before this hop are the seeds (sampled_ids) and the nodes earlier hops added (the bucket's known
+    // list -- or sampled_ids too when there is no list or it outgrew its capacity)
     const bool listed = a.known_pairs != nullptr && n_listed <= a.known_cap;
     const int32_t n_scan = listed ? n_seed : n_known;
     const LG_G unsigned long long* klist = a.known_pairs + (int64_t)b * a.known_cap;
-    // Nothing below depends on the segment table: the first LG_DEDUP_BATCH known ids / list entries of the thread are loaded
-    // now (the usual bucket has no more) and the table is cleared now, while the segment table is being built -- the
-    // workgroup's life is a chain of dependent round trips, these two leave it
-    int32_t kid[LG_DEDUP_BATCH];
-    unsigned long long kl[LG_DEDUP_BATCH];
 #pragma unroll
-    for (int u = 0; u < LG_DEDUP_BATCH; u++) {
-        const int32_t i = u * LG_DEDUP_THREADS + tid;
-        kid[u] = i < n_scan ? a.sampled_ids[i] : -1;
-        kl[u] = (listed && i < n_listed) ? klist[i] : ~0ull;
-    }
-    for (int32_t i = tid; i < LG_LDS_TABLE; i += LG_DEDUP_THREADS) s_tab[i] = ~0ull;
-    if (tid == 0) s_full = 0;
-    bool cleared = true;
-
-    // the bucket's segments, one per partition tile: exclusive prefix of their lengths
-    if (tid == 0) s_total = 0;
-    for (int32_t t = tid; t < nparts; t += LG_DEDUP_THREADS) {
-        const int32_t off = roff[(int64_t)t * (NB + 1)];
-        s_pref[t + 1] = roff[(int64_t)t * (NB + 1) + 1] - off;
-        s_seg[t] = off;
-    }
-    __syncthreads();
-    if (tid < 64) {                                    // <= 513 entries: wave 0 scans them, a few consecutive entries per lane
-        const int32_t per = (nparts + 63) / 64;
-        const int32_t lo = min(tid * per, nparts), hi = min(lo + per, nparts);
-        int32_t sum = 0;
-        for (int32_t t = lo; t < hi; t++) sum += s_pref[t + 1];
-        int32_t inc = sum;
-        for (int d = 1; d < 64; d <<= 1) { const int32_t o = __shfl_up(inc, d); if (tid >= d) inc += o; }
-        int32_t acc = inc - sum;
-        for (int32_t t = lo; t < hi; t++) { acc += s_pref[t + 1]; s_pref[t + 1] = acc; }
-        if (tid == 0) s_pref[0] = 0;
-        if (tid == 63) s_total = inc;
-    }
-    __syncthreads();
-    const int32_t total = s_total;
+    for (int u = 0; u < CL; u++)
+        if (u * LG_DEDUP_THREADS + tid >= total) rp[u] = ~0ull;
+    if (!listed || tid >= n_listed) kl0 = ~0ull;
     // passes: distinct vertices <= known + claims; keep the expected load of a pass at or below LG_LDS_FILL_16THS / 16 of the
     // table.  The bucket's share of the scanned ids is ESTIMATED (an even spread + a quarter; counting it would cost every
     // workgroup one more round trip to memory), and the hash is assumed to spread the bucket evenly over its sub-buckets: when
@@ -937,126 +635,110 @@ void dedup_lds_kernel(HopParams hp, const LanePtrs* __restrict__ lanes)
     const int32_t known_est = (listed ? n_listed : 0) + n_scan / NB + n_scan / (4 * NB) + 32;
     int32_t passes = 1;
     while ((int64_t)known_est + total > (int64_t)passes * (LG_LDS_TABLE / 16 * LG_LDS_FILL_16THS)) passes <<= 1;
-
-    auto segment_of = [&](int32_t k) {                 // claim k of the bucket -> index into claim_pairs
-        int32_t lo = 0, hi = nparts;                   // s_pref[lo] <= k < s_pref[hi]
-        while (hi - lo > 1) { const int32_t mid = (lo + hi) >> 1; if (s_pref[mid] <= k) lo = mid; else hi = mid; }
-        return s_seg[lo] + (k - s_pref[lo]);
-    };
-    auto insert = [&](unsigned long long w, uint32_t h) {
-        uint32_t p = lds_slot_of(h);
-        for (int it = 0; it < LG_LDS_TABLE; it++) {
-            const unsigned long long old = __hip_atomic_fetch_min(&s_tab[p], w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            if (old == ~0ull || (uint32_t)(old >> 32) == (uint32_t)(w >> 32)) return;    // placed, or merged with the same vertex
-            if (old > w) w = old;                                                          // displaced a larger word: carry it on
-            p = (p + 1) & (LG_LDS_TABLE - 1);
-        }
-        s_full = 1;
-    };
-
-    // a bucket of at most LG_DEDUP_BATCH claims per thread (the usual case) keeps them in registers: one trip to memory for both
-    // sweeps of every pass
-    const bool resident = total <= LG_DEDUP_BATCH * LG_DEDUP_THREADS;
-    unsigned long long rp[LG_DEDUP_BATCH];
-    auto fetch = [&](int32_t k0, unsigned long long (&pr)[LG_DEDUP_BATCH]) {
+    // A bucket of at most CL claims per thread (the usual case) works from the registers.  A larger one is read
+    // again, sweep by sweep; and a bucket whose list could not take all its claims (its count says so) reads the hop's slots
+    // instead and keeps what hashes into this bucket.
+    const bool from_slots = total > a.claim_cap;
+    const bool resident = !from_slots && total <= CL * LG_DEDUP_THREADS;
+    const int32_t n_src = from_slots ? hop_geometry(a).total : total;
+    auto fetch = [&](int32_t k0, unsigned long long (&pr)[CL]) {
 #pragma unroll
-        for (int u = 0; u < LG_DEDUP_BATCH; u++) {
+        for (int u = 0; u < CL; u++) {
             const int32_t k = k0 + u * LG_DEDUP_THREADS + tid;
-            pr[u] = k < total ? a.claim_pairs[segment_of(k)] : ~0ull;
+            pr[u] = ~0ull;
+            if (k >= n_src) continue;
+            if (from_slots) {
+                int32_t d = a.slot_dst[k];
+                if (d == -1) continue;
+                if (d < -1) d = LG_SLOT_LOSER(d);                // (an earlier pass may have marked the slot)
+                if ((lg_tab_hash(d) & (NB - 1)) == (uint32_t)b) pr[u] = ((unsigned long long)(uint32_t)d << 32) | (uint32_t)k;
+            } else {
+                pr[u] = a.claim_pairs[lg_claim_at<NB>(b, k)];
+            }
         }
     };
-    if (resident) fetch(0, rp);
 
-  for (;;) {
-    const uint32_t pmask = (uint32_t)passes - 1u;
-    bool overflow = false;
-    for (uint32_t pass = 0; pass <= pmask; pass++) {
-        if (!cleared) {
+    for (;;) {
+        const uint32_t pmask = (uint32_t)passes - 1u;
+        bool overflow = false;
+        for (uint32_t pass = 0; pass <= pmask; pass++) {
             for (int32_t i = tid; i < LG_LDS_TABLE; i += LG_DEDUP_THREADS) s_tab[i] = ~0ull;
             if (tid == 0) s_full = 0;
-            __syncthreads();
-        }
-        cleared = false;
-        for (int32_t i0 = 0; i0 < n_scan; i0 += LG_DEDUP_BATCH * LG_DEDUP_THREADS) {
-#pragma unroll
-            for (int u = 0; u < LG_DEDUP_BATCH; u++) {
-                const int32_t i = i0 + u * LG_DEDUP_THREADS + tid;
-                const int32_t id = i0 == 0 ? kid[u] : (i < n_scan ? a.sampled_ids[i] : -1);      // (the first chunk came early)
+            lds_barrier();
+            for (int32_t i0 = 0; i0 < n_scan; i0 += LG_DEDUP_THREADS) {
+                const int32_t i = i0 + tid;
+                const int32_t id = i >= n_scan ? -1 : (i0 == 0 ? kid0 : a.sampled_ids[i]);      // (the first one came early)
                 if (id < 0) continue;
                 const uint32_t h = lg_tab_hash(id);
                 if ((h & (NB - 1)) != (uint32_t)b || ((h >> BB) & pmask) != pass) continue;
                 insert(((unsigned long long)(uint32_t)id << 32) | (uint32_t)i, h);
             }
-        }
-        if (listed)
-            for (int32_t i0 = 0; i0 < n_listed; i0 += LG_DEDUP_BATCH * LG_DEDUP_THREADS) {
-#pragma unroll
-                for (int u = 0; u < LG_DEDUP_BATCH; u++) {
-                    const int32_t i = i0 + u * LG_DEDUP_THREADS + tid;
-                    const unsigned long long pr = i0 == 0 ? kl[u] : (i < n_listed ? klist[i] : ~0ull);
+            if (listed)
+                for (int32_t i0 = 0; i0 < n_listed; i0 += LG_DEDUP_THREADS) {
+                    const int32_t i = i0 + tid;
+                    const unsigned long long pr = i0 == 0 ? kl0 : (i < n_listed ? klist[i] : ~0ull);
                     if (pr == ~0ull) continue;
                     const uint32_t h = lg_tab_hash((int32_t)(pr >> 32));
                     if (((h >> BB) & pmask) != pass) continue;
                     insert(pr, h);
                 }
-            }
-        for (int32_t k0 = 0; k0 < total; k0 += LG_DEDUP_BATCH * LG_DEDUP_THREADS) {
-            unsigned long long pr[LG_DEDUP_BATCH];
-            if (resident) {
+            for (int32_t k0 = 0; k0 < n_src; k0 += CL * LG_DEDUP_THREADS) {
+                unsigned long long pr[CL];
+                if (resident) {
 #pragma unroll
-                for (int u = 0; u < LG_DEDUP_BATCH; u++) pr[u] = rp[u];
-            } else
-                fetch(k0, pr);
+                    for (int u = 0; u < CL; u++) pr[u] = rp[u];
+                } else
+                    fetch(k0, pr);
 #pragma unroll
-            for (int u = 0; u < LG_DEDUP_BATCH; u++) {
-                if (pr[u] == ~0ull) continue;
-                const uint32_t h = lg_tab_hash((int32_t)(pr[u] >> 32));
-                if (((h >> BB) & pmask) != pass) continue;
-                insert((pr[u] & 0xFFFFFFFF00000000ull) | PENDING | (uint32_t)pr[u], h);
-            }
-        }
-        __syncthreads();
-#ifndef LG_LDS_NO_RETRY
-        if (s_full != 0) { overflow = true; break; }       // (uniform: read behind the barrier, reset behind the next one)
-#endif
-        for (int32_t k0 = 0; k0 < total; k0 += LG_DEDUP_BATCH * LG_DEDUP_THREADS) {
-            unsigned long long pr[LG_DEDUP_BATCH];
-            if (resident) {
-#pragma unroll
-                for (int u = 0; u < LG_DEDUP_BATCH; u++) pr[u] = rp[u];
-            } else
-                fetch(k0, pr);
-#pragma unroll
-            for (int u = 0; u < LG_DEDUP_BATCH; u++) {
-                if (pr[u] == ~0ull) continue;
-                const uint32_t id = (uint32_t)(pr[u] >> 32), slot = (uint32_t)pr[u];
-                const uint32_t h = lg_tab_hash((int32_t)id);
-                if (((h >> BB) & pmask) != pass) continue;
-                uint32_t p = lds_slot_of(h);
-                uint32_t v = 0xFFFFFFFFu;
-                for (int it = 0; it < LG_LDS_TABLE; it++) {
-                    const unsigned long long w = s_tab[p];
-                    if ((uint32_t)(w >> 32) == id) { v = (uint32_t)w; break; }
-                    p = (p + 1) & (LG_LDS_TABLE - 1);
-                }
-                if (v != (PENDING | slot)) {          // not the lowest slot of a new vertex
-                    if (a.loser_in_dst) a.slot_dst[slot] = (int32_t)(id | LG_LOSER_BIT);      // (vertex ids < 2^30: the mark rides in the id)
-                    else a.slot_mark[slot] = a.mark_tag;
-                    a.slot_pos[slot] = (v & PENDING) ? -2 - (int32_t)(v & ~PENDING) : (int32_t)v;
+                for (int u = 0; u < CL; u++) {
+                    if (pr[u] == ~0ull) continue;
+                    const uint32_t h = lg_tab_hash((int32_t)(pr[u] >> 32));
+                    if (((h >> BB) & pmask) != pass) continue;
+                    insert((pr[u] & 0xFFFFFFFF00000000ull) | PENDING | (uint32_t)pr[u], h);
                 }
             }
+            lds_barrier();
+            // (uniform: every thread reads s_full behind the barrier above, and nobody resets it before the next barrier every
+            // thread passes -- the one below, or the one behind `passes <<= 1`)
+            if (s_full != 0) { overflow = true; break; }
+            for (int32_t k0 = 0; k0 < n_src; k0 += CL * LG_DEDUP_THREADS) {
+                unsigned long long pr[CL];
+                if (resident) {
+#pragma unroll
+                    for (int u = 0; u < CL; u++) pr[u] = rp[u];
+                } else
+                    fetch(k0, pr);
+#pragma unroll
+                for (int u = 0; u < CL; u++) {
+                    if (pr[u] == ~0ull) continue;
+                    const uint32_t id = (uint32_t)(pr[u] >> 32), slot = (uint32_t)pr[u];
+                    const uint32_t h = lg_tab_hash((int32_t)id);
+                    if (((h >> BB) & pmask) != pass) continue;
+                    uint32_t p = lds_slot_of(h);
+                    uint32_t v = 0xFFFFFFFFu;
+                    for (int it = 0; it < LG_LDS_TABLE; it++) {
+                        const unsigned long long w = s_tab[p];
+                        if ((uint32_t)(w >> 32) == id) { v = (uint32_t)w; break; }
+                        p = (p + 1) & (LG_LDS_TABLE - 1);
+                    }
+                    if (v != (PENDING | slot)) {          // not the lowest slot of a new vertex
+                        a.slot_dst[slot] = LG_SLOT_LOSER((int32_t)id);
+                        a.slot_pos[slot] = (v & PENDING) ? -2 - (int32_t)(v & ~PENDING) : (int32_t)v;
+                    }
+                }
+            }
+            lds_barrier();                                 // (the next pass clears the table)
         }
-        __syncthreads();
+        if (!overflow) break;
+        if (passes >= (1 << 14)) {                             // 2^14 sub-buckets of one bucket still too full: not a hash problem
+            if (tid == 0) raise_error(a.hop_scratch, a.err_flag, LG_ERR_TABLE_FULL);
+            break;
+        }
+        passes <<= 1;
+        lds_barrier();      // every thread has read s_full before thread 0 clears it for the retry (without this a fast wave
+                            // could reset it while a slow one had not yet left the barrier above: a split workgroup)
     }
-    if (!overflow) break;
-    if (passes >= (1 << 14)) {                             // 2^14 sub-buckets of one bucket still too full: not a hash problem
-        if (tid == 0) raise_error(a.hop_scratch, a.err_flag, LG_ERR_TABLE_FULL);
-        break;
-    }
-    passes <<= 1;
-    __syncthreads();
-  }
-    if (b == 0 && tid == 0) a.hop_scratch[HS_PAIR_CURSOR] = 0;      // the next hop's sampling starts a new pair array
+    if (tid == 0) a.claim_cnt[b * LG_CLAIM_CNT_STRIDE] = 0;      // the next hop's sampling starts an empty list
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1122,7 +804,6 @@ void compact_kernel(HopParams hp, const LanePtrs* __restrict__ lanes)
     const int32_t node_base = nc0 + nc1, edge_base = ec0 + ec1;           // operator_impl.cu:268, :275
     const LG_G int32_t* frontier = g.frontier;
     LG_G unsigned long long* state = a.tile_state;
-    const bool lds = a.claim_pairs != nullptr;                            // the lds form of the first-touch state
     const int32_t tid = threadIdx.x;
     const int32_t wave = tid >> 6, lane = tid & 63;
     const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
@@ -1136,37 +817,32 @@ void compact_kernel(HopParams hp, const LanePtrs* __restrict__ lanes)
         const int32_t st = s_st;
         if (st >= nsuper) break;                                          // (uniform)
         const int32_t idx0 = st * CSUPER;
-        int32_t v[LG_SLOTS_PER_LANE], mk[LG_SLOTS_PER_LANE];
+        int32_t v[LG_SLOTS_PER_LANE];
         unsigned long long mv[LG_SLOTS_PER_LANE], mf[LG_SLOTS_PER_LANE];
-        const bool inl = a.loser_in_dst;                                  // (uniform) the loser mark rides in slot_dst
 #pragma unroll
         for (int u = 0; u < LG_SLOTS_PER_LANE; u++) {
             const int32_t idx = idx0 + u * CT + tid;
             v[u] = idx < total ? a.slot_dst[idx] : -1;
-            mk[u] = (idx < total && !inl) ? a.slot_mark[idx] : 0;
         }
-        // (compact_hoist) what depends on the slot INDEX only -- the vertex the slot sampled for, its position, the carried cache slot --
-        // is loaded together with slot_dst, for every slot of the tile: more bytes (invalid slots too), one dependent round trip less
+        // what depends on the slot INDEX only -- the vertex the slot sampled for, its position, the carried cache slot -- is loaded
+        // together with slot_dst, for every slot of the tile: more bytes (invalid slots too), one dependent round trip less (-4 %, round 4)
         int32_t src_of[LG_SLOTS_PER_LANE], src_pos[LG_SLOTS_PER_LANE], fsv[LG_SLOTS_PER_LANE];
-        const bool hoist = a.compact_hoist;
-        if (hoist) {
 #pragma unroll
-            for (int u = 0; u < LG_SLOTS_PER_LANE; u++) {
-                const int32_t idx = idx0 + u * CT + tid;
-                src_of[u] = 0; src_pos[u] = 0; fsv[u] = LG_FS_UNKNOWN;
-                if (idx < total) {
-                    const int32_t q = idx / a.count;
-                    src_of[u] = frontier[q];
-                    src_pos[u] = seeds ? q : a.agg_src_off[f_off + q];
-                    if (a.slot_fs != nullptr) fsv[u] = a.slot_fs[idx];
-                }
+        for (int u = 0; u < LG_SLOTS_PER_LANE; u++) {
+            const int32_t idx = idx0 + u * CT + tid;
+            src_of[u] = 0; src_pos[u] = 0; fsv[u] = LG_FS_UNKNOWN;
+            if (idx < total) {
+                const int32_t q = idx / a.count;
+                src_of[u] = frontier[q];
+                src_pos[u] = seeds ? q : a.agg_src_off[f_off + q];
+                if (a.slot_fs != nullptr) fsv[u] = a.slot_fs[idx];
             }
         }
 #pragma unroll
         for (int u = 0; u < LG_SLOTS_PER_LANE; u++) {
-            const bool valid = v[u] >= 0;
-            const bool first = valid && (inl ? (v[u] & LG_LOSER_BIT) == 0 : mk[u] != a.mark_tag);   // nobody marked it a loser in this hop
-            if (valid && inl) v[u] &= ~LG_LOSER_BIT;
+            const bool valid = v[u] != -1;
+            const bool first = v[u] >= 0;                     // the de-duplication did not mark it a loser (LG_SLOT_LOSER)
+            if (v[u] < -1) v[u] = LG_SLOT_LOSER(v[u]);        // valid slots hold the vertex id from here on; invalid ones -1
             mv[u] = __ballot(valid);
             mf[u] = __ballot(first);
             if (lane == 0) {
@@ -1197,26 +873,15 @@ void compact_kernel(HopParams hp, const LanePtrs* __restrict__ lanes)
         // phase 1: every load of the thread's four slots that does not need the prefix -- in flight while wave 0 looks back
         // (nothing is stored in between: the buffers may alias as far as the compiler knows)
         int32_t lost_pos[LG_SLOTS_PER_LANE];
-        uint32_t tab_at[LG_SLOTS_PER_LANE];
         RowHdr nh[LG_SLOTS_PER_LANE];
 #pragma unroll
         for (int u = 0; u < LG_SLOTS_PER_LANE; u++) {
             const int32_t idx = idx0 + u * CT + tid;
             if (v[u] >= 0) {
                 const bool first = (mf[u] >> lane) & 1ull;
-                const int32_t dst = v[u];
-                if (!hoist) {
-                    const int32_t q = idx / a.count;
-                    src_of[u] = frontier[q];
-                    // position of the node sampled for == construct_graph's position_map[agg_dst_ids[e]]
-                    src_pos[u] = seeds ? q : a.agg_src_off[f_off + q];
-                    fsv[u] = (first && a.slot_fs != nullptr) ? a.slot_fs[idx] : LG_FS_UNKNOWN;   // the new node's feature-cache slot, if carried
-                } else if (!first) {
-                    fsv[u] = LG_FS_UNKNOWN;
-                }
-                if (!LAST) nh[u] = load_hdr(a.row_hdr + dst);      // next hop's frontier header
-                lost_pos[u] = first ? 0 : a.slot_pos[idx];               // final already, or -2 - (slot it lost to)
-                tab_at[u] = (first && !LAST && a.pos_table != nullptr) ? table_find(a.pos_table, a.pos_mask, a.pf, dst) : 0u;
+                if (!first) fsv[u] = LG_FS_UNKNOWN;
+                if (!LAST) nh[u] = load_hdr(a.row_hdr + v[u]);     // next hop's frontier header
+                lost_pos[u] = first ? 0 : a.slot_pos[idx];         // final already, or -2 - (slot it lost to)
             }
         }
         if (wave == 0) {
@@ -1256,7 +921,7 @@ void compact_kernel(HopParams hp, const LanePtrs* __restrict__ lanes)
         }
         lds_barrier();
         const int32_t xe = s_ex[0], xn = s_ex[1];
-        // lds form: the first touches' positions are known now -- publish them before anything else, later super tiles' losers
+        // the first touches' positions are known now -- publish them before anything else, later super tiles' losers
         // are waiting for nothing but this (publishing with the other stores below would chain every tile's loads behind the
         // stores of the tiles before it)
         int32_t n_at[LG_SLOTS_PER_LANE];
@@ -1265,10 +930,10 @@ void compact_kernel(HopParams hp, const LanePtrs* __restrict__ lanes)
             n_at[u] = -1;
             if ((mf[u] >> lane) & 1ull) {
                 n_at[u] = node_base + xn + s_pre[1][u * (CT / 64) + wave] + __popcll(mf[u] & lt);
-                if (lds) __hip_atomic_store(a.slot_pos + idx0 + u * CT + tid, n_at[u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(a.slot_pos + idx0 + u * CT + tid, n_at[u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         }
-        if (lds) {
+        {
             // a slot that lost to ANOTHER slot of the hop: that slot IS the winner (chains have length one), and it is a LOWER slot
 #pragma unroll
             for (int u = 0; u < LG_SLOTS_PER_LANE; u++) {
@@ -1322,17 +987,7 @@ void compact_kernel(HopParams hp, const LanePtrs* __restrict__ lanes)
             if (n >= 0) {
                 a.sampled_ids[n] = dst;                            // :270
                 if (a.node_slot != nullptr) a.node_slot[n] = fsv[u];
-                // :271 -- later hops look the position up in the state array; after the last hop nobody
-                // does, and same-hop duplicates resolve through slot_pos (a small, cache-resident array)
-                if (!LAST) {
-                    if (a.pos_table == nullptr) {
-                        if (a.position_map != nullptr) a.position_map[dst] = (int32_t)(a.pf.hi | (uint32_t)n);   // (lds form: none)
-                    } else if (tab_at[u] != 0xFFFFFFFFu)
-                        a.pos_table[tab_at[u]] = lg_tab_word(a.pf, dst, (uint32_t)n);
-                    else
-                        raise_error(a.hop_scratch, a.err_flag, LG_ERR_TABLE_FULL);
-                }
-                if (!lds) a.slot_pos[idx] = n;                     // (atomics forms: what localise follows)
+                // (:271 -- no position map: later hops find the node in its bucket's known list, list_known_kernel)
                 if (NT) __builtin_nontemporal_store(n, &a.agg_src_off[e]);
                 else a.agg_src_off[e] = n;                              // construct_graph's neighbour side, known here
             } else {
@@ -1433,42 +1088,8 @@ __global__ __launch_bounds__(LG_TILE) void list_known_kernel(HopParams hp, const
     }
 }
 
-// ------------------------------------------------------------------------------------------
-// K5: construct_graph's neighbour side
-// ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(LG_TILE) void localise_kernel(HopParams hp, const LanePtrs* __restrict__ lanes)
+void launch_random_sample(hipStream_t s, const HopParams& p, const LanePtrs* d_lanes, int32_t n_lanes)
 {
-    const SampleArgs a = lane_args(hp, lanes);
-    const LG_G int32_t* hs = a.hop_scratch;
-    const int32_t n_edge = hs[HS_N_EDGE], edge_base = hs[HS_EDGE_BASE];
-    const int32_t nsuper = (n_edge + LG_SUPER - 1) / LG_SUPER;
-    // scatter already localised every edge whose neighbour was final or first-touched by that very
-    // slot; what is left (< 0) are neighbours owned by ANOTHER slot of this hop, whose new position
-    // scatter left in slot_pos[winner]: a short walk through a small array (:289-293)
-    for (int32_t st = blockIdx.x; st < nsuper; st += gridDim.x) {
-        int32_t cur[LG_SLOTS_PER_LANE];
-#pragma unroll
-        for (int u = 0; u < LG_SLOTS_PER_LANE; u++) {
-            const int32_t e = st * LG_SUPER + u * LG_TILE + threadIdx.x;
-            cur[u] = e < n_edge ? a.agg_src_off[edge_base + e] : 0;
-        }
-#pragma unroll
-        for (int u = 0; u < LG_SLOTS_PER_LANE; u++) {
-            const int32_t e = st * LG_SUPER + u * LG_TILE + threadIdx.x;
-            if (cur[u] < 0) {      // -2 - (slot it lost to); that slot may have lost to a lower one in turn
-                int32_t c = cur[u];
-                for (int it = 0; it < (1 << 20) && c < -1; it++) c = a.slot_pos[-2 - c];   // strictly descending slots
-                if (c < -1) raise_error(a.hop_scratch, a.err_flag, LG_ERR_CHAIN);         // cannot happen: every chain ends at a winner
-                a.agg_src_off[edge_base + e] = c;
-            }
-        }
-    }
-}
-
-int g_sample_stages = 15;
-void launch_random_sample(hipStream_t s, const HopParams& p, const LanePtrs* d_lanes, int32_t n_lanes, int32_t form)
-{
-    const int stages = g_sample_stages;
     // Fixed grids that stride over super tiles; grid.y = lanes (independent mini-batches of a group).
     int32_t max_super = (p.max_slots + LG_SUPER - 1) / LG_SUPER;
     if (max_super < 1) max_super = 1;
@@ -1477,67 +1098,51 @@ void launch_random_sample(hipStream_t s, const HopParams& p, const LanePtrs* d_l
     while (gx > 64 && (int64_t)gx * n_lanes > max_wg) gx /= 2;  // keep the whole launch near 2 x resident capacity
     while (gx > 1 && (int64_t)gx * n_lanes > max_wg && max_wg < 4096) gx /= 2;   // (experiments with fewer workgroups)
     const dim3 grid(gx, n_lanes);
-    if (form == 2) {
-        // buckets per lane follow the pool's largest hop (legion_core.h); super tiles per partition tile follow THIS hop: at
-        // most LG_LDS_MAX_PARTS partition tiles, and no larger than leaves the launch ~8 k workgroups by the hop's capacity
-        // (a hop typically fills a quarter of it: ~2 k active ones; measured at B = 8000: 2 k -> 8 k +1...2 %, beyond: the same)
+    {
+        // buckets per lane follow the pool's largest hop (legion_core.h).  8 / 16 buckets: the sampling kernel writes the claim
+        // lists itself.  64 / 256 buckets: it samples partition tiles of K super tiles and place_kernel writes the lists; K follows
+        // THIS hop: as large as the staging allows (LG_PLACE_MAX_K) unless that leaves the launch with fewer than ~8 k workgroups
+        // by the hop's capacity (a hop typically fills a quarter of it: ~2 k active ones; measured at B = 8000: 2 k -> 8 k
+        // +1...2 %, beyond: the same), and never below the class's minimum (run_off is sized by it, storage.hip)
         HopParams q = p;
         const bool small = p.lds_bucket_bits == LG_LDS_BITS_SMALL || p.lds_bucket_bits == LG_LDS_BITS_SMALL16;
-        const int32_t k_hi = small ? 1 : (p.lds_bucket_bits == LG_LDS_BITS_MEDIUM ? LG_LDS_K_MEDIUM : LG_LDS_K_LARGE);
-        int32_t k_lo = p.lds_bucket_bits == LG_LDS_BITS_LARGE ? 4 : 1;
-        while (max_super > LG_LDS_MAX_PARTS * k_lo) k_lo *= 2;
-        int32_t k = k_hi > k_lo ? k_hi : k_lo;
+        const int32_t k_lo = lg_lds_k_min(p.lds_bucket_bits);
+        int32_t k = small ? 1 : LG_PLACE_MAX_K;
         const int want_wg = tuning().lds_part_wg;
         while (k > k_lo && (int64_t)(max_super / k) * n_lanes < want_wg) k /= 2;
-        if (!small && k > LG_PLACE_MAX_K && k_lo <= LG_PLACE_MAX_K) k = LG_PLACE_MAX_K;     // (the staged placement takes 8 super tiles at most)
         q.lds_k = k;
         int32_t gp = (max_super + k - 1) / k;                  // one workgroup per partition tile ...
         while (gp > 16 && (int64_t)gp * n_lanes > 16384) gp = (gp + 1) / 2;  // ... within reason
-        // a hop of few slots (the first hop of a B = 1024 batch: 25 600, ~400 claims per bucket): its 4096 one-bucket workgroups are all
-        // launch (54 us of nothing per 512-lane group); ONE workgroup per lane can take the lane's buckets in turn instead
-        // (LegionTuning.lds_one_wg_lanes; off by default: no gain under the weave)
-        const int one_wg_lanes = tuning().lds_one_wg_lanes;
-        const bool one_wg_per_lane = small && one_wg_lanes > 0 && n_lanes >= one_wg_lanes && p.max_slots <= LG_DEDUP_ONE_WG_SLOTS;
-        if (p.lds_bucket_bits == LG_LDS_BITS_SMALL) {
-            if (stages & 1) sample_kernel<2, LG_LDS_BITS_SMALL, true><<<grid, LG_TILE, 0, s>>>(q, d_lanes);
+        const dim3 pgrid(gp, n_lanes);
+        const size_t stage = (size_t)k * LG_SUPER * sizeof(unsigned long long);
+        switch (p.lds_bucket_bits) {
+        case LG_LDS_BITS_SMALL:
+            sample_kernel<LG_LDS_BITS_SMALL, true><<<grid, LG_TILE, 0, s>>>(q, d_lanes);
             hipCheckError();
-            if (stages & 2) {
-                if (one_wg_per_lane) dedup_lists_kernel<LG_LDS_BITS_SMALL, 1 << LG_LDS_BITS_SMALL, 2><<<dim3(1, n_lanes), LG_DEDUP_THREADS, 0, s>>>(q, d_lanes);
-                else dedup_lists_kernel<LG_LDS_BITS_SMALL, LG_DEDUP_UNITS, LG_DEDUP_CLAIMS><<<dim3((1 << LG_LDS_BITS_SMALL) / LG_DEDUP_UNITS, n_lanes), LG_DEDUP_THREADS, 0, s>>>(q, d_lanes);
-            }
-        } else if (p.lds_bucket_bits == LG_LDS_BITS_SMALL16) {
-            if (stages & 1) sample_kernel<2, LG_LDS_BITS_SMALL16, true><<<grid, LG_TILE, 0, s>>>(q, d_lanes);
+            dedup_lists_kernel<LG_LDS_BITS_SMALL, LG_DEDUP_CLAIMS><<<dim3(1 << LG_LDS_BITS_SMALL, n_lanes), LG_DEDUP_THREADS, 0, s>>>(q, d_lanes);
+            break;
+        case LG_LDS_BITS_SMALL16:
+            sample_kernel<LG_LDS_BITS_SMALL16, true><<<grid, LG_TILE, 0, s>>>(q, d_lanes);
             hipCheckError();
-            if (stages & 2) {
-                if (one_wg_per_lane) dedup_lists_kernel<LG_LDS_BITS_SMALL16, 1 << LG_LDS_BITS_SMALL16, 2><<<dim3(1, n_lanes), LG_DEDUP_THREADS, 0, s>>>(q, d_lanes);
-                else dedup_lists_kernel<LG_LDS_BITS_SMALL16, LG_DEDUP_UNITS, LG_DEDUP_CLAIMS><<<dim3((1 << LG_LDS_BITS_SMALL16) / LG_DEDUP_UNITS, n_lanes), LG_DEDUP_THREADS, 0, s>>>(q, d_lanes);
-            }
-        } else if (p.lds_bucket_bits == LG_LDS_BITS_MEDIUM) {
-            if (k <= LG_PLACE_MAX_K) {
-                sample_kernel<2, LG_LDS_BITS_MEDIUM, false, true><<<dim3(gp, n_lanes), LG_TILE, 0, s>>>(q, d_lanes);
-                hipCheckError();
-                place_kernel<LG_LDS_BITS_MEDIUM><<<dim3(gp, n_lanes), LG_TILE, (size_t)k * LG_SUPER * sizeof(unsigned long long), s>>>(q, d_lanes);
-            } else
-                sample_kernel<2, LG_LDS_BITS_MEDIUM, false><<<dim3(gp, n_lanes), LG_TILE, 0, s>>>(q, d_lanes);
+            dedup_lists_kernel<LG_LDS_BITS_SMALL16, LG_DEDUP_CLAIMS><<<dim3(1 << LG_LDS_BITS_SMALL16, n_lanes), LG_DEDUP_THREADS, 0, s>>>(q, d_lanes);
+            break;
+        case LG_LDS_BITS_MEDIUM:
+            sample_kernel<LG_LDS_BITS_MEDIUM, false><<<pgrid, LG_TILE, 0, s>>>(q, d_lanes);
             hipCheckError();
-            dedup_lds_kernel<LG_LDS_BITS_MEDIUM><<<dim3(1 << LG_LDS_BITS_MEDIUM, n_lanes), LG_DEDUP_THREADS, 0, s>>>(q, d_lanes);
-        } else {
-            if (k <= LG_PLACE_MAX_K) {
-                sample_kernel<2, LG_LDS_BITS_LARGE, false, true><<<dim3(gp, n_lanes), LG_TILE, 0, s>>>(q, d_lanes);
-                hipCheckError();
-                place_kernel<LG_LDS_BITS_LARGE><<<dim3(gp, n_lanes), LG_TILE, (size_t)k * LG_SUPER * sizeof(unsigned long long), s>>>(q, d_lanes);
-            } else
-                sample_kernel<2, LG_LDS_BITS_LARGE, false><<<dim3(gp, n_lanes), LG_TILE, 0, s>>>(q, d_lanes);
+            place_kernel<LG_LDS_BITS_MEDIUM><<<pgrid, LG_PLACE_THREADS, stage, s>>>(q, d_lanes);
             hipCheckError();
-            dedup_lds_kernel<LG_LDS_BITS_LARGE><<<dim3(1 << LG_LDS_BITS_LARGE, n_lanes), LG_DEDUP_THREADS, 0, s>>>(q, d_lanes);
+            dedup_lists_kernel<LG_LDS_BITS_MEDIUM, LG_DEDUP_CLAIMS><<<dim3(1 << LG_LDS_BITS_MEDIUM, n_lanes), LG_DEDUP_THREADS, 0, s>>>(q, d_lanes);
+            break;
+        default:
+            sample_kernel<LG_LDS_BITS_LARGE, false><<<pgrid, LG_TILE, 0, s>>>(q, d_lanes);
+            hipCheckError();
+            place_kernel<LG_LDS_BITS_LARGE><<<pgrid, LG_PLACE_THREADS, stage, s>>>(q, d_lanes);
+            hipCheckError();
+            dedup_lists_kernel<LG_LDS_BITS_LARGE, LG_DEDUP_CLAIMS><<<dim3(1 << LG_LDS_BITS_LARGE, n_lanes), LG_DEDUP_THREADS, 0, s>>>(q, d_lanes);
+            break;
         }
-    } else if (form == 1) {
-        sample_kernel<1, 0, true><<<grid, LG_TILE, 0, s>>>(p, d_lanes);
-    } else {
-        sample_kernel<0, 0, true><<<grid, LG_TILE, 0, s>>>(p, d_lanes);
     }
     hipCheckError();
-    if (!(stages & 4)) return;
     // compaction: LG_COMPACT_THREADS per workgroup (a workgroup iteration takes 4 x that many consecutive slots), as many workgroups per
     // lane as the sampling launch has per 1024 slots' worth
     {
@@ -1546,17 +1151,13 @@ void launch_random_sample(hipStream_t s, const HopParams& p, const LanePtrs* d_l
         else compact_kernel<false, LG_COMPACT_THREADS><<<cgrid, LG_COMPACT_THREADS, 0, s>>>(p, d_lanes);
     }
     hipCheckError();
-    if (form == 2 && !p.last_hop) {       // later hops must recognise the nodes this one added: their buckets' lists
+    if (!p.last_hop) {       // later hops must recognise the nodes this one added: their buckets' lists
         int32_t chunks = (p.max_slots + LG_LIST_CHUNK - 1) / LG_LIST_CHUNK;
         if (chunks > 256) chunks = 256;
         if (p.lds_bucket_bits == LG_LDS_BITS_SMALL) list_known_kernel<LG_LDS_BITS_SMALL><<<dim3(chunks, n_lanes), LG_TILE, 0, s>>>(p, d_lanes);
         else if (p.lds_bucket_bits == LG_LDS_BITS_SMALL16) list_known_kernel<LG_LDS_BITS_SMALL16><<<dim3(chunks, n_lanes), LG_TILE, 0, s>>>(p, d_lanes);
         else if (p.lds_bucket_bits == LG_LDS_BITS_MEDIUM) list_known_kernel<LG_LDS_BITS_MEDIUM><<<dim3(chunks, n_lanes), LG_TILE, 0, s>>>(p, d_lanes);
         else list_known_kernel<LG_LDS_BITS_LARGE><<<dim3(chunks, n_lanes), LG_TILE, 0, s>>>(p, d_lanes);
-        hipCheckError();
-    }
-    if (form != 2) {      // (lds form: scatter placed every loser itself from the first-touch ballots)
-        localise_kernel<<<grid, LG_TILE, 0, s>>>(p, d_lanes);
         hipCheckError();
     }
 }
@@ -1613,35 +1214,16 @@ void cache_row_headers(hipStream_t s, RowHdr* hdr, const int32_t* QT, int32_t Kg
 // ------------------------------------------------------------------------------------------
 // end of batch (IOComplete).  The reference zeroes position_map for every node of the batch
 // (ClearPosMap, operator_impl.cu:542-548) and memsets the N/8-byte bitmap at the next batch's
-// start (:151).  Here nothing is cleared: the lane's epoch goes up by one, which turns every entry
-// the batch wrote into "untouched" (see legion_core.h).  Every lg_pos_epoch_max(vb) batches the array
-// is refilled with 0xFF by this kernel.  The workgroup that draws the last ticket publishes the
-// new epoch (all workgroups have read the old one by then) and advances the device-resident
-// iteration used by graph replay.
+// start (:151).  Here there is nothing to clear: no per-vertex state exists.  What is left of the op: the batch's counters
+// as the trainer end will read them, and the device-resident iteration used by graph replay.  One wave per lane.
 // ------------------------------------------------------------------------------------------
 __global__ void end_of_batch_kernel(const LanePtrs* __restrict__ lanes, int32_t* __restrict__ iter_state)
 {
     const BracketLane L = bracket_lane(lanes[blockIdx.y]);
-    __shared__ int32_t s_last;
-    const int32_t epoch = L.hop_scratch[HS_EPOCH];
-    const int32_t epoch_max = lg_pos_epoch_max(L.hop_scratch[HS_VALUE_BITS]);
-    if (epoch >= epoch_max) {
-        if (L.pos_table != nullptr) {
-            for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i <= (int64_t)L.pos_mask; i += (int64_t)gridDim.x * blockDim.x)
-                L.pos_table[i] = ~0ull;
-        } else if (L.position_map != nullptr) {
-            LG_G uint32_t* pm = L.position_map;
-            for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < L.total_num_nodes; i += (int64_t)gridDim.x * blockDim.x)
-                pm[i] = 0xFFFFFFFFu;
-        }
-        // the loser marks carry (epoch, hop): epochs are about to repeat
-        for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < L.max_slots; i += (int64_t)gridDim.x * blockDim.x)
-            L.slot_mark[i] = 0;
-    }
     // GPURunner's lanes: the batch's counters in host-visible memory, as the trainer end will read them -- node_counter[2..3]
     // already holding what the last gather op leaves there (counter_update(op%3==1), operator_impl.cu:83-85: the range of the
     // last hop's new nodes), whether or not that gather has run yet.  Visible to the host once the launch group has completed.
-    if (L.counter_mirror != nullptr && blockIdx.x == 0 && threadIdx.x < 32) {
+    if (L.counter_mirror != nullptr && threadIdx.x < 32) {
         const int32_t t = threadIdx.x;
         int32_t v = t < 16 ? L.node_counter[t] : L.edge_counter[t - 16];
         const int32_t hop_num = L.node_counter[INTRABATCH_CON * 3 - 1];
@@ -1649,28 +1231,13 @@ __global__ void end_of_batch_kernel(const LanePtrs* __restrict__ lanes, int32_t*
         if (t == 3 && hop_num >= 0 && hop_num <= 6) v = L.hop_scratch[HS_RANGE + 2 * hop_num + 1];
         L.counter_mirror[t] = v;
     }
-    __syncthreads();
-    if (threadIdx.x == 0)   // no fence needed: the kernel boundary publishes the refill and the new epoch
-        s_last = (__hip_atomic_fetch_add(L.hop_scratch + HS_TICKET, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ==
-                  (int32_t)gridDim.x - 1) ? 1 : 0;
-    __syncthreads();
-    if (s_last && threadIdx.x == 0) {
-        L.hop_scratch[HS_TICKET] = 0;
-        L.hop_scratch[HS_EPOCH] = epoch >= epoch_max ? 1 : epoch + 1;
-        if (iter_state != nullptr && blockIdx.y == 0) iter_state[0] += iter_state[1];
-    }
+    // (every lane's batch_generate read the iteration in an earlier kernel of this stream)
+    if (iter_state != nullptr && blockIdx.y == 0 && threadIdx.x == 0) iter_state[0] += iter_state[1];
 }
 
-void launch_end_of_batch(hipStream_t s, const LanePtrs* d_lanes, int32_t n_lanes, int32_t* iter_state,
-                         int64_t state_bytes)
+void launch_end_of_batch(hipStream_t s, const LanePtrs* d_lanes, int32_t n_lanes, int32_t* iter_state)
 {
-    // enough workgroups to refill the position state (array or table) at HBM speed on the rare epoch wrap,
-    // few enough to cost nothing otherwise
-    int32_t gx = (int32_t)((state_bytes + (1 << 20) - 1) >> 20);   // ~1 MiB per workgroup
-    if (gx < 1) gx = 1;
-    if (gx > 512) gx = 512;
-    while (gx > 16 && gx * n_lanes > 2048) gx /= 2;
-    end_of_batch_kernel<<<dim3(gx, n_lanes), 256, 0, s>>>(d_lanes, iter_state);
+    end_of_batch_kernel<<<dim3(1, n_lanes), 64, 0, s>>>(d_lanes, iter_state);
     hipCheckError();
 }
 

@@ -9,9 +9,9 @@
 //   FeatureStorage                 SS/storage/feature_storage.cuh:6-34
 //   CacheController / UnifiedCache SS/cache/cache.cuh:10-177
 //   IPCEnv                         SS/engine/ipc_service.h:6-35
-// The implementations are new: device-resident counters (no host read-backs), a fused
-// first-touch/position state array instead of bitmap + position map, direct-mapped id->slot
-// tables instead of the vendored cuckoo hash, deterministic slot-ordered compaction.
+// The implementations are new: device-resident counters (no host read-backs), first touches
+// resolved bucket by bucket in LDS instead of bitmap + position map (no per-vertex state at all),
+// direct-mapped id->slot tables instead of the vendored cuckoo hash, deterministic slot-ordered compaction.
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -51,48 +51,21 @@
         }                                                                                     \
     }
 
-// ---- position/first-touch state array (replaces accessed_map + position_map) ---------------
-// One uint32 per vertex, compared UNSIGNED: [ EMAX - epoch : 31-vb | pending : 1 | value : vb ],
-// EMAX = 2^(31-vb) - 1.  vb (hop_scratch[HS_VALUE_BITS]) is fixed per pool: just enough for the pool's
-// worst-case id count (B = 1024, fan-out 25,10 -> 19; B = 8000 -> 22; B = 8000, 25,10,10 -> 25), 16..28, so
-// that the epoch field is as wide as possible: the refill below writes N x 4 B, and at vb = 19 it runs
-// every 4094 batches instead of every 254 (1 MB per batch at N = 2^26 with 8 epoch bits).
-// A lane's epoch e (1..EMAX-1; in hop_scratch[HS_EPOCH]) goes up by one per
-// mini-batch, so whatever an older batch left behind carries a larger top field and reads as
-// "untouched" -- nothing has to be cleared between batches (the reference memsets an N/8-byte bitmap
-// per batch and zeroes the position map entry by entry, operator_impl.cu:151,542-548); every EMAX-1
-// batches the end-of-batch kernel refills the array with 0xFF.  Within the current epoch the low
-// vb+1 bits hold either the final position of the vertex in sampled_ids, or pending | (lowest slot
-// index that sampled it in the hop being compacted); atomicMin keeps the lowest.
-//
-// The array costs N x 4 B per lane (268 MB at N = 2^26; a 128-lane group with two slots pins 69 GB), which is
-// the fastest layout measured (tools/micro/dedup_tables.hip) but does not scale to the
-// billion-vertex graphs of legion_server.py:73-88 or to N = 2^28 with many lanes.  The COMPACT form keeps the
-// same state in a per-lane open-addressing table sized by the pool's worst-case id count, not by N:
-//   uint64 word = [ EMAX - epoch : 32-vb | vertex id : 31 | pending : 1 | value : vb ],  empty = all ones.
-// One atomicMin(u64) per probe (ordered linear probing): a stale or empty word is replaced; a word of the
-// same vertex merges (lowest value stays: a known position beats any pending slot, a lower slot beats a
-// higher one); a LARGER word of another vertex is displaced and carried by the displacing thread to the next
-// position, a smaller one sends the claim itself on.  Words only ever decrease at a position within an
-// epoch, so a vertex has one home however the claims interleave, and every word that is merged away is
-// merged away exactly once -- by the thread that observes it -- which keeps "one writer per loser mark".
-// Same epochs, same refill rule (T x 8 B instead of N x 4 B).  Selected per pool: LEGION_DEDUP=direct|table|lds|auto
-// (auto: the LDS form below for pools whose largest hop has at most 2^25 slots per lane -- every shape of legion_server.py --
-// beyond that direct, or table when the direct arrays of all lanes in flight would take more than a quarter of HBM).
-//
-// The LDS form (round 2) issues no memory-side atomic per claim at all.  A hop's claims (vertex, slot) are written, by
-// the sampling kernel, into hash buckets of their lane (one reservation per partition tile, ranks by LDS atomics); a
-// second kernel gives every (lane, bucket) a workgroup that builds an open-addressing table of the bucket's vertices IN
-// LDS -- the batch's known vertices of that bucket (the seeds from sampled_ids, the nodes earlier hops added from the
-// bucket's list, which list_known_kernel keeps) with their positions, then the claims with atomicMin on
-// (vertex, pending | slot) -- and writes, for every claim that is not the lowest slot of a new vertex, the same loser
-// mark the other forms leave.  No per-vertex state survives the hop, nothing to clear, nothing that scales with N.  A
-// bucket whose vertices do not fit the table is handled in several passes over sub-buckets, so the result never depends
-// on the hash.  Used for hops of up to 2^25 slots per lane (every shape of legion_server.py; beyond: the atomics forms).
-// Buckets per lane and the partition tile follow the pool's largest hop, so that a bucket sees at most ~64 k slots and
-// a bucket's share of a partition tile stays a few sectors long: 8 buckets / 1024-slot tiles up to 2^19 slots per lane
-// (B = 1024-class batches), 64 / 8192 up to 2^22 (B = 8000 with [25,10]), 256 up to 2^25 (B = 8000 with [15,10,5] has 6 M,
-// with [25,10,10] 20 M); at most 1024 partition tiles per hop.  The kernels are instantiated for the three classes.
+// ---- first touches without per-vertex state (replaces accessed_map + position_map) ----------
+// The reference marks first touches with atomicOr on an N-bit map it memsets per batch and keeps positions in an N-entry map it
+// clears node by node (operator_impl.cu:151,244-272,542-548).  Here a hop issues no memory-side atomic per claim and keeps
+// nothing per vertex: a hop's claims (vertex, slot) are written, grouped by hash bucket, into one list per bucket of the lane
+// (ranks by LDS atomics, one reservation per bucket and tile); a second kernel gives every (lane, bucket) a workgroup that builds
+// an open-addressing table of the bucket's vertices IN LDS -- the batch's known vertices of that bucket (the seeds from
+// sampled_ids, the nodes earlier hops added from the bucket's known list, which list_known_kernel keeps) with their positions,
+// then the claims with atomicMin on (vertex, pending | slot) -- and marks every claim that is not the lowest slot of a new
+// vertex.  Nothing survives the hop, nothing to clear, nothing that scales with N.  A bucket whose vertices do not fit the
+// table is handled in several passes over sub-buckets, so the result never depends on the hash.
+// Buckets per lane follow the pool's largest hop, so that a bucket sees a few thousand claims: 8 (or 16, dense graphs) up to 2^19
+// slots per lane (B = 1024-class batches), 64 up to 2^22 (B = 8000 with [25,10]), 256 beyond (B = 8000 with [15,10,5] has 6 M,
+// with [25,10,10] 20 M; larger hops run more passes per bucket).  The kernels are instantiated for the four classes.
+// (Rounds 1-4 also had a uint32[N] array per lane and a per-lane open-addressing table in memory, claimed with one atomicMin per
+// pick: slower by 5-14 % wherever the LDS form applied, removed in round 5 when it applied everywhere -- DESIGN_HISTORY.md.)
 #define LG_LDS_BITS_SMALL 3
 #define LG_LDS_BITS_SMALL16 4                    // the same class with 16 buckets: dense graphs, see lg_set_pool_claims_hint
 #ifndef LG_LDS_BITS_MEDIUM
@@ -101,11 +74,11 @@
 #ifndef LG_LDS_BITS_LARGE
 #define LG_LDS_BITS_LARGE 8
 #endif
-#define LG_LDS_K_MEDIUM 8                       // super tiles (1024 slots) per partition tile
-#define LG_LDS_K_LARGE 32
 #define LG_LDS_SLOTS_SMALL (1 << 19)
 #define LG_LDS_SLOTS_MEDIUM (1 << 22)
-#define LG_LDS_MAX_PARTS 1024
+// fewest super tiles (1024 slots) a partition tile of the 64- / 256-bucket classes may have (the launch picks up to
+// LG_PLACE_MAX_K, kernels_sample.hip); sizes run_off
+static inline int32_t lg_lds_k_min(int32_t bucket_bits) { return bucket_bits == LG_LDS_BITS_LARGE ? 4 : 1; }
 #ifndef LG_LDS_TABLE_BITS
 #define LG_LDS_TABLE_BITS 13
 #endif
@@ -113,33 +86,6 @@
 #ifndef LG_LDS_FILL_16THS
 #define LG_LDS_FILL_16THS 14                    // a pass may fill its table up to this many sixteenths (bound: known + claims of the pass)
 #endif
-#define LG_LDS_MAX_SLOTS (1 << 25)
-#define LG_POS_VALUE_BITS_MIN 16
-#define LG_POS_VALUE_BITS_MAX 28
-struct PosFmt {
-    uint32_t hi;        // (EMAX - epoch) << (vb + 1)
-    uint32_t pending;   // 1 << vb
-    uint32_t vmask;     // pending - 1
-    uint32_t hifield;   // EMAX - epoch (unshifted): the top 32-vb bits of a table word
-    int32_t vb;
-};
-__host__ __device__ inline int32_t lg_pos_epoch_max(int32_t vb) { return (int32_t)((1u << (31 - vb)) - 2u); }
-__host__ __device__ inline PosFmt lg_pos_fmt(int32_t epoch, int32_t vb)
-{
-    PosFmt f;
-    f.hifield = ((1u << (31 - vb)) - 1u) - (uint32_t)epoch;
-    f.hi = f.hifield << (vb + 1);
-    f.pending = 1u << vb;
-    f.vmask = f.pending - 1u;
-    f.vb = vb;
-    return f;
-}
-// table form
-__host__ __device__ inline uint64_t lg_tab_word(const PosFmt& f, int32_t id, uint32_t low)
-{
-    return ((uint64_t)f.hifield << (32 + f.vb)) | ((uint64_t)(uint32_t)id << (f.vb + 1)) | (uint64_t)low;
-}
-__host__ __device__ inline bool lg_tab_current(const PosFmt& f, uint64_t w) { return (uint32_t)(w >> (32 + f.vb)) == f.hifield; }
 __host__ __device__ inline uint32_t lg_tab_hash(int32_t id)
 {
     uint32_t x = (uint32_t)id;
@@ -157,21 +103,17 @@ enum HopScratch {
     HS_N_NEW = 5,
     HS_N_EDGE = 6,
     HS_SLOTS = 7,
-    HS_EPOCH = 8,          // this lane's current epoch of the position-state array
-    HS_TICKET = 9,         // last-workgroup ticket of the end-of-batch kernel
     HS_CTICKET = 24,       // compact_kernel: next super tile to hand out / workgroups that finished (both zero between hops)
     HS_CDONE = 25,
-    HS_VALUE_BITS = 30,    // vb of the position-state format (fixed at pool creation)
-    HS_PAIR_CURSOR = 27,   // lds form: pairs reserved so far in the hop being sampled (reset by the de-duplication kernel)
     HS_ERROR = 29,         // sticky error bits of the lane (LG_ERR_*), also mirrored to the pool's host-visible flag
     HS_RANGE = 10,         // [HS_RANGE + 2h], [+1]: {offset, count} of the new nodes of op 3h, kept for its gather
     HS_WORDS = 32
 };
 
 // error bits a kernel can raise for its lane (MemoryPool::ErrorBits / legion_pool_error)
-#define LG_ERR_TABLE_FULL 1       // compact position table had no free word (cannot happen for a pool-sized table)
+#define LG_ERR_TABLE_FULL 1       // a de-duplication bucket did not fit its LDS table even in 2^14 sub-bucket passes (not a hash problem: cannot happen)
 #define LG_ERR_FEATURE_ROWS 2     // the batch has more rows than the feature buffer: the gather stopped at its end
-#define LG_ERR_CHAIN 4            // localise_kernel ran out of steps following a loser chain
+#define LG_ERR_CHAIN 4            // compact_kernel gave up waiting for an earlier tile's status word / a winner's position (cannot happen)
 
 // Device code: a pointer that was loaded from memory (LanePtrs, pointer tables, LDS) is "generic" to
 // the compiler, which then emits flat_* instructions; those count on lgkmcnt as well as vmcnt, so every
@@ -193,7 +135,9 @@ enum HopScratch {
 // Feature-cache slot of a sampled neighbour, carried from the sampler to the gather (see "column slots", GraphStorage):
 // a value >= 0 or CACHEMISS_FLAG is what node_map[id] holds; LG_FS_UNKNOWN means "not carried: look it up"
 #define LG_FS_UNKNOWN (-3)
-#define LG_LOSER_BIT 0x40000000   // see HopParams::loser_in_dst
+// slot_dst[slot] of a hop: -1 no edge; v >= 0 the sampled neighbour; v < -1 the neighbour -2 - v, marked by the de-duplication as
+// NOT the first touch of a new vertex (an involution: the same expression marks and unmarks; every int32 vertex id fits)
+#define LG_SLOT_LOSER(v) (-2 - (v))
 #ifndef LG_CLAIM_CNT_STRIDE
 #define LG_CLAIM_CNT_STRIDE 32        // ints between the claim-list counts of two buckets: a line each (the 8 / 16 reservations of a super tile go to different lines)
 #endif
@@ -242,22 +186,18 @@ struct LanePtrs {
     int32_t* agg_src_off;
     int32_t* agg_dst_off;
     char* tmp_part_ind;
-    int32_t* position_map;             // direct form: uint32[N]; null in table form
-    unsigned long long* pos_table;     // table form: uint64[pos_table_mask + 1]; null in direct form
-    uint32_t pos_table_mask;
-    // lds form of the first-touch state (no per-vertex state at all, legion_core.h "LDS form"): the hop's claims,
-    // partitioned by hash bucket inside the run of every 1024-slot super tile
-    unsigned long long* claim_pairs;   // (vertex << 32 | slot): [max_slots], or [buckets][claim_cap] in the 8/16-bucket classes
-    int32_t* run_off;                  // [super tiles][buckets + 1] where each bucket's claims of that super tile start in claim_pairs
-    int32_t lds_buckets;               // 8, 16, 64 or 256 (0: not the lds form)
-    // 8/16-bucket classes: one list of claims per bucket (no segment table): the sampling kernel appends a super tile's claims of a
-    // bucket with one reservation on claim_cnt[bucket]; a count beyond claim_cap says the list is incomplete and the bucket's
-    // workgroup reads the hop's slots instead (kernels_sample.hip)
+    // first touches (no per-vertex state, see above): the hop's claims, one list per hash bucket
+    unsigned long long* claim_pairs;   // (vertex << 32 | slot): [buckets][claim_cap], interleaved by chunk (below)
+    int32_t* run_off;                  // 64/256-bucket classes: [partition tiles][buckets] x {first place in the bucket's claim list, count} (sample_kernel -> place_kernel)
+    int32_t lds_buckets;               // 8, 16, 64 or 256
+    // one list of claims per bucket: the sampling kernel reserves places for a super tile's (8/16 buckets) or a partition tile's
+    // (64/256 buckets) claims of a bucket with one atomic on claim_cnt[bucket]; a count beyond claim_cap says the list is incomplete
+    // and the bucket's workgroup reads the hop's slots instead (kernels_sample.hip)
     // The lists are interleaved in chunks of LG_CLAIM_CHUNK entries -- entry k of bucket b sits at lg_claim_at(b, k, buckets) --
     // so that what a hop really uses (a fraction of the capacity) is one dense prefix of the array, as few pages as the segment form
     // touches (measured: with one contiguous region per bucket, 16 x oversized, both kernels lost ~15 us per group to translation misses)
     int32_t* claim_cnt;                // [buckets], zero between hops
-    int32_t claim_cap;                 // 0: segment form
+    int32_t claim_cap;
     int32_t ids_cap;                   // capacity of sampled_ids (what may be read before the live counters are known)
     // ... and the batch's vertices that later hops must recognise (every node but the seeds and the last hop's), one list
     // per bucket: scatter appends (vertex << 32 | position), the next hop's workgroup of that bucket reads only its list
@@ -272,8 +212,7 @@ struct LanePtrs {
     int32_t* node_counter;
     int32_t* edge_counter;
     int32_t* slot_dst;
-    int32_t* slot_pos;
-    int32_t* slot_mark;
+    int32_t* slot_pos;                 // [max_slots] -1, or for a loser: the vertex's position / -2 - (the winning slot); winners publish their position here
     int32_t* slot_fs;                  // [max_slots] feature-cache slot of the slot's sampled neighbour, or LG_FS_UNKNOWN (column slots)
     int32_t* node_slot;                // [num_ids] the same per node of the batch, by position in sampled_ids: what the gather reads
                                        // instead of node_map[id] (one 128-byte line per row for 4 bytes)
@@ -283,7 +222,6 @@ struct LanePtrs {
     int32_t* cache_search_buffer;
     float* float_features;
     int32_t feature_rows;
-    int32_t total_num_nodes;
     int32_t max_slots;
 };
 
@@ -303,7 +241,7 @@ public:
     float* GetFloatFeatures() const { return float_features_[current_pipe_]; }
     int32_t* GetCacheSearchBuffer() const { return cache_search_buffer_; }
     int32_t* GetLabels() const { return labels_[current_pipe_]; }
-    int32_t* GetPositionMap() const { return position_map_; }
+    int32_t* GetPositionMap() const { return nullptr; }      // (the reference's accessor, memorypool.cuh:120-135: no such array here)
     int32_t* GetNodeCounter() const { return node_counter_[current_pipe_]; }
     int32_t* GetEdgeCounter() const { return edge_counter_[current_pipe_]; }
     int32_t* GetSampledIds() const { return sampled_ids_[current_pipe_]; }
@@ -317,7 +255,6 @@ public:
     void SetFloatFeatures(float* p, int32_t pipe) { float_features_[pipe] = p; lanes_dirty_ = true; }
     void SetCacheSearchBuffer(int32_t* p) { cache_search_buffer_ = p; lanes_dirty_ = true; }
     void SetLabels(int32_t* p, int32_t pipe) { labels_[pipe] = p; lanes_dirty_ = true; }
-    void SetPositionMap(int32_t* p) { position_map_ = p; lanes_dirty_ = true; }
     void SetNodeCounter(int32_t* p, int32_t pipe) { node_counter_[pipe] = p; lanes_dirty_ = true; }
     void SetEdgeCounter(int32_t* p, int32_t pipe) { edge_counter_[pipe] = p; lanes_dirty_ = true; }
     void SetSampledIds(int32_t* p, int32_t pipe) { sampled_ids_[pipe] = p; lanes_dirty_ = true; }
@@ -336,14 +273,13 @@ public:
 
     // new in this build: sampler scratch (all device memory, private to the server)
     int32_t* slot_dst = nullptr;       // [max_slots] sampled neighbour per slot
-    int32_t* slot_pos = nullptr;       // [max_slots] what the position state held for that neighbour
-    int32_t* slot_mark = nullptr;      // [max_slots] (epoch, hop) tag of the hop in which the slot lost its first touch
+    int32_t* slot_pos = nullptr;       // [max_slots] see LanePtrs
     int32_t* slot_fs = nullptr;        // [max_slots] / [num_ids]: feature-cache slots carried from the sampler to the gather
     int32_t* node_slot = nullptr;
     unsigned long long* tile_state = nullptr;   // [max_tiles / 4 + 1] (LanePtrs)
     RowHdr* fh_edge = nullptr;         // [num_ids] frontier row headers written by scatter
     int32_t* hop_scratch = nullptr;    // [HS_WORDS]
-    unsigned long long* claim_pairs = nullptr; // lds form: see LanePtrs
+    unsigned long long* claim_pairs = nullptr; // see LanePtrs
     int32_t* run_off = nullptr;
     int32_t* claim_cnt = nullptr;
     int32_t claim_cap = 0;
@@ -351,9 +287,6 @@ public:
     unsigned long long* known_pairs = nullptr;
     int32_t* known_cnt = nullptr;
     int32_t known_cap = 0;
-    bool lds_form = false;
-    unsigned long long* pos_table = nullptr;   // compact position state (table form), else null
-    uint32_t pos_table_mask = 0;
     int32_t* err_host = nullptr;       // host-visible error word (mapped pinned), err_dev = its device address
     int32_t* err_dev = nullptr;
     int32_t ErrorBits() const { return err_host ? *(volatile int32_t*)err_host : 0; }
@@ -388,7 +321,6 @@ private:
     int32_t iter_ = 0;
     int32_t mode_ = 0;
     int32_t* cache_search_buffer_ = nullptr;
-    int32_t* position_map_ = nullptr;
     int32_t* agg_src_ids_ = nullptr;
     int32_t* agg_dst_ids_ = nullptr;
     char* tmp_part_ind_ = nullptr;
@@ -536,7 +468,6 @@ public:
     void SetReplicaMemory(int64_t bytes) { replica_bytes_ = bytes; }
     int32_t ReplicaRows(int32_t dev_id) const { return replica_rows_.empty() ? 0 : replica_rows_[dev_id]; }
     int32_t FloatFeatureLen() const { return float_feature_len_; }
-    int32_t CachePitch() const { return cache_pitch_ > 0 ? cache_pitch_ : float_feature_len_; }   // floats per row of a stripe
     bool gather_stats_on_ = true;        // GatherStats() arms the counters; SetGatherStats pauses them (a device word: graphs follow)
     void SetGatherStats(bool on);
     unsigned long long* GatherStats(int32_t dev_id);   // device {stripe rows, replica rows, peer-stripe rows}, allocated on first use
@@ -587,7 +518,6 @@ private:
     std::vector<float**> d_float_feature_cache_ptr_;
     int32_t float_feature_len_ = 0;
     uint64_t uid_ = 0, fill_generation_ = 0;
-    int32_t cache_pitch_ = 0;             // floats per row of the feature-cache stripes and the replica (0: dense)
     float* cpu_float_features_ = nullptr;
     bool is_presc_ = true;
     std::vector<int32_t> peer_max_ids_;   // MaxIdNum of every clique member when they live in other processes
@@ -703,7 +633,6 @@ void lg_pool_alloc_private(MemoryPool* mp, int32_t dev_id, int32_t total_num_nod
                            const int32_t* fanout, int32_t hop_num, int32_t float_feature_len);
 // how many pools of this shape the caller is about to keep in flight on the device (Pipeline: lanes x slots);
 // feeds the direct-vs-table choice of the position state (LEGION_DEDUP=auto).  Thread-local; 0 = one pool.
-void lg_set_pool_lanes_hint(int32_t lanes);
 // what PreSC saw of the LAST hop, the largest one: its edges (= the claims its de-duplication takes) and the batch's nodes
 // before it (= what that de-duplication must recognise), maxima over the PreSC batches; 0, 0 = unknown.  Pools created
 // afterwards by this thread pick the small class's bucket count from it (8, or 16 where a bucket would need two passes).
@@ -759,17 +688,10 @@ struct HopParams {                  // what every lane of a launch shares
     int32_t max_slots;              // capacity of slot_dst for this hop
     unsigned long long* edge_access_time;  // presample only (single lane), else null
     unsigned long long* topo_transactions; // presample only: 64-byte transactions the hop's topology reads amount to
-    bool loser_in_dst;              // lds form, vertex ids < 2^30: a slot that lost its first touch carries LG_LOSER_BIT in slot_dst (written by
-                                    // the de-duplication kernel) instead of the hop's tag in slot_mark -- the compaction then streams one array less
-    bool compact_hoist;             // compact_kernel loads what depends on the slot index only together with slot_dst (LegionTuning.compact_hoist)
-    int32_t lds_bucket_bits;        // lds form: LG_LDS_BITS_SMALL / SMALL16 / MEDIUM / LARGE (the pool's)
-    int32_t lds_k;                  // lds form: super tiles per partition tile in this hop (set by launch_random_sample)
+    int32_t lds_bucket_bits;        // LG_LDS_BITS_SMALL / SMALL16 / MEDIUM / LARGE (the pool's)
+    int32_t lds_k;                  // super tiles per partition tile in this hop (set by launch_random_sample)
 };
-// which kernels of a hop launch_random_sample / the REST phase really launch (experiments: legion_pipeline_probe_overlap):
-// 1 sample (+ place), 2 de-duplication, 4 compaction (+ known lists), 8 end-of-batch.  15 = all (the only value product code uses).
-extern int g_sample_stages;
-// form: 0 direct array, 1 table, 2 lds
-void launch_random_sample(hipStream_t s, const HopParams& p, const LanePtrs* d_lanes, int32_t n_lanes, int32_t form);
+void launch_random_sample(hipStream_t s, const HopParams& p, const LanePtrs* d_lanes, int32_t n_lanes);
 
 // hand-over of a lane's finished batch to a trainer-visible pipe slot (kernels_gather.hip)
 struct DeliverParams {
@@ -778,9 +700,6 @@ struct DeliverParams {
     int32_t* mirror;          // device address of the slot's host-visible counter mirror [32], or null
     int32_t num_ids;          // capacity of the id / edge arrays
     int32_t batch_cap;        // capacity of labels
-    float* float_features;    // launch_handover_copy only: the slot's feature buffer, its rows and the row width
-    int32_t feature_rows;
-    int32_t D;
 };
 
 struct GatherParams {
@@ -796,7 +715,6 @@ struct GatherParams {
     const int32_t* node_map;
     int32_t node_capacity;
     int32_t D;
-    int32_t cache_pitch;            // floats between consecutive rows of a cache stripe / the replica (>= D; the full table is always dense)
     int32_t total_num_nodes;
     int32_t max_rows;               // grid bound: rows any lane can have for this op
     int32_t hop;                    // >= 0: take the range from hop_scratch[HS_RANGE + 2*hop] (snapshot that later
@@ -821,12 +739,11 @@ struct BulkLists {
 };
 void launch_bulk_bucket(hipStream_t s, const GatherParams& g, const LanePtrs* d_lanes, int32_t n_lanes, const BulkLists& lists,
                         const char* arena_base);
-void launch_bulk_push(hipStream_t s, const float* stripe, int32_t pitch, int32_t D, const int32_t* fidx, const int64_t* dst,
+void launch_bulk_push(hipStream_t s, const float* stripe, int32_t D, const int32_t* fidx, const int64_t* dst,
                       const unsigned long long* cnt, int64_t cap, char* peer_arena);
 void launch_gather(hipStream_t s, const GatherParams& g, const LanePtrs* d_lanes, int32_t n_lanes);
 void launch_deliver(hipStream_t s, const LanePtrs* d_lane, const DeliverParams& d);
 // the whole finished batch of a lane -- ids, feature rows, labels, both edge arrays, counters -- copied into a pipe slot
-void launch_handover_copy(hipStream_t s, const LanePtrs* d_lane, const DeliverParams& d, int32_t max_rows);
 // stand-alone form for tests / probes: explicit arrays, one lane
 void launch_gather_explicit(hipStream_t s, const GatherParams& g, const int32_t* sampled_ids,
                             int32_t* cache_index_out, const int32_t* range, float* dst, int32_t dst_rows);
@@ -842,8 +759,7 @@ struct SeedParams {
 };
 void launch_batch_generate(hipStream_t s, const SeedParams& p, const LanePtrs* d_lanes, int32_t n_lanes);
 
-void launch_end_of_batch(hipStream_t s, const LanePtrs* d_lanes, int32_t n_lanes, int32_t* iter_state,
-                         int64_t state_bytes);
+void launch_end_of_batch(hipStream_t s, const LanePtrs* d_lanes, int32_t n_lanes, int32_t* iter_state);
 void launch_hotness_measure(hipStream_t s, const int32_t* sampled_ids, const int32_t* node_counter,
                             unsigned long long* access_map);
 void init_row_headers(hipStream_t s, RowHdr* hdr, const int64_t* csr_index, int32_t n, int32_t slot);
@@ -881,7 +797,7 @@ void fill_value_i32(hipStream_t s, int32_t* p, int32_t v, int64_t n);
 void build_column_slots(hipStream_t s, const int32_t* col, const int32_t* node_map, int32_t* colx_pairs, int64_t num_edges);
 void fill_value_i8(hipStream_t s, char* p, char v, int64_t n);
 void feat_fill_up(hipStream_t s, int32_t capacity, int32_t D, float* cache, const float* table,
-                  const int32_t* QF, int32_t Kg, int32_t Ki, int32_t n, int32_t pitch = 0);
+                  const int32_t* QF, int32_t Kg, int32_t Ki, int32_t n);
 void topo_neighbor_count(hipStream_t s, const int32_t* QT, int32_t Kg, int32_t Ki, int32_t capacity,
                          int32_t n, const int64_t* csr_index, int64_t* counts);
 void inclusive_scan_i64(hipStream_t s, const int64_t* in, int64_t* out, int32_t n);

@@ -30,24 +30,12 @@ extern "C" void RandomSample(legion_stream_t strm_hdl, LegionGraphStorage* graph
 // UnifiedCache as its first member (cache.hip: LegionCacheBox).
 static inline UnifiedCache* cache_of(LegionUnifiedCache* c) { return reinterpret_cast<UnifiedCache*>(c); }
 
-// weave_early_gathers needs to know, while a HEAD phase is enqueued, whether this group gathers at all (a REST_SAMPLE group --
-// GPURunner serving a slab-only trainer -- must not): pipeline.hip says so around its enqueue / capture calls.  Thread-local.
-static thread_local bool g_weave_head_gathers = true;
-extern "C" void legion_set_weave_head_gathers(int32_t on) { g_weave_head_gathers = on != 0; }
-static inline bool lg_weave_head_gathers() { return g_weave_head_gathers; }
-
 // ---- lane-group bodies: every operator works on n lanes (n = 1 for the reference-shaped calls) ----
 struct LegionLaneGroup {
     std::vector<MemoryPool*> pools;
     LanePtrs* d_lanes = nullptr;      // contiguous device copy of every pool's current lane
     int32_t* iter_state = nullptr;    // device {next iteration of lane 0, stride} for graph replay, or null
 };
-
-static inline int64_t pool_state_bytes(const MemoryPool* mp)     // what an epoch wrap refills
-{
-    if (mp->lds_form) return 4;
-    return mp->pos_table ? ((int64_t)mp->pos_table_mask + 1) * 8 : (int64_t)mp->total_num_nodes * 4;
-}
 
 static bool seed_set(FeatureStorage* feature, int32_t dev_id, int32_t mode, int32_t*& all_ids, int32_t*& all_labels,
                      int32_t& total_cap)
@@ -131,11 +119,9 @@ static void do_random_sample(hipStream_t s, GraphStorage* graph, UnifiedCache* c
     p.max_slots = (int32_t)(hop < pool0->max_new.size() ? pool0->max_new[hop] : pool0->max_slots);
     p.edge_access_time = (is_presc && cache) ? cache->GetEdgeAccessedMap(dev_id) : nullptr;   // :473
     p.topo_transactions = (is_presc && cache) ? cache->Controller(dev_id)->GetTopoTransactions() : nullptr;
-    p.loser_in_dst = pool0->lds_form && (int64_t)pool0->total_num_nodes <= ((int64_t)1 << 30) && lg::tuning().loser_in_dst != 0;
-    p.compact_hoist = lg::tuning().compact_hoist != 0;
     p.lds_bucket_bits = pool0->lds_bucket_bits;
     p.lds_k = 1;                             // (launch_random_sample picks the hop's partition tile)
-    lg::launch_random_sample(s, p, d_lanes, n_lanes, pool0->lds_form ? 2 : (pool0->pos_table != nullptr ? 1 : 0));
+    lg::launch_random_sample(s, p, d_lanes, n_lanes);
 }
 
 static void do_feature_lookup(hipStream_t s, UnifiedCache* cache, const LanePtrs* d_lanes, int32_t n_lanes,
@@ -233,7 +219,7 @@ extern "C" void IOComplete(legion_stream_t strm_hdl, LegionUnifiedCache* cache_,
         cache->CacheProfiling(memorypool->GetSampledIds(), memorypool->GetAggSrcId(), memorypool->GetAggDstId(),
                               memorypool->GetAggSrcOf(), memorypool->GetAggDstOf(), memorypool->GetNodeCounter(),
                               memorypool->GetEdgeCounter(), s, dev_id);
-    lg::launch_end_of_batch(s, memorypool->DeviceLane(), 1, memorypool->iter_state, pool_state_bytes(memorypool));
+    lg::launch_end_of_batch(s, memorypool->DeviceLane(), 1, memorypool->iter_state);
 }
 
 // =============================================================================================
@@ -337,7 +323,6 @@ extern "C" void legion_gather_rows(legion_stream_t stream, const float* full_tab
     g.node_map = node_map;
     g.node_capacity = node_capacity;
     g.D = float_feature_len;
-    g.cache_pitch = float_feature_len;
     g.skip_remote = false;
     g.total_num_nodes = total_num_nodes;
     g.max_rows = max_rows;
@@ -371,32 +356,20 @@ static void enqueue_lanes(hipStream_t s, GraphStorage* graph, FeatureStorage* fe
     const bool seeds_ride = hop_num >= 2;
     if (phase >= LG_PHASE_HEAD) {          // the two pieces of the weave arrangement (serve mode only)
         const int32_t last = hop_num - 1;
-        // weave_early_gathers: the rows of the seeds and of every hop but the last are complete when the HEAD's sampling is done;
-        // their gathers (hot rows: mostly L2 / Infinity-Cache hits) then run on the light stream too, under the PREVIOUS group's
-        // last-hop gather, and only the last hop's gather stays on the heavy stream.  (REST_SAMPLE groups never gather.)
-        const bool early = lg::tuning().weave_early_gathers != 0 && last >= 1;
-        auto early_gathers = [&]() {
-            if (!seeds_ride) do_feature_lookup(s, cache, d_lanes, n_lanes, pool0, 1, dev_id, true);
-            for (int32_t h = 0; h < last; h++)
-                do_feature_lookup(s, cache, d_lanes, n_lanes, pool0, INTRABATCH_CON * (h + 1) + 1, dev_id, true, (h == 0 && seeds_ride) ? 1 : -1);
-        };
+        // (every gather stays on the heavy stream, behind the last hop: the seeds' and earlier hops' gathers on the light stream
+        // under the previous group's last gather were measured in round 4 -- no gain -- and removed)
         if (phase == LG_PHASE_HEAD) {
             do_batch_generate(s, feature, d_lanes, n_lanes, pool0, batch_size, counter, dev_id, mode, hop_num, iter_state);
             for (int32_t h = 0; h < last; h++)
                 do_random_sample(s, graph, cache, d_lanes, n_lanes, pool0, fanout[h], dev_id, INTRABATCH_CON * (h + 1), false);
-            if (early && pool0->GetFloatFeatures() != nullptr && lg_weave_head_gathers()) early_gathers();
         } else {
             if (last >= 0) do_random_sample(s, graph, cache, d_lanes, n_lanes, pool0, fanout[last], dev_id, INTRABATCH_CON * (last + 1), false);
-            if (lg::g_sample_stages & 8) lg::launch_end_of_batch(s, d_lanes, n_lanes, iter_state, pool_state_bytes(pool0));
+            lg::launch_end_of_batch(s, d_lanes, n_lanes, iter_state);
             if (phase == LG_PHASE_REST_SAMPLE) return;
-            if (early && lg_weave_head_gathers()) {
-                do_feature_lookup(s, cache, d_lanes, n_lanes, pool0, INTRABATCH_CON * (last + 1) + 1, dev_id, true, -1);
-            } else {
-                if (!seeds_ride) do_feature_lookup(s, cache, d_lanes, n_lanes, pool0, 1, dev_id, true);
-                for (int32_t h = 0; h <= last; h++)
-                    do_feature_lookup(s, cache, d_lanes, n_lanes, pool0, INTRABATCH_CON * (h + 1) + 1, dev_id, true,
-                                      (h == 0 && seeds_ride) ? 1 : -1);
-            }
+            if (!seeds_ride) do_feature_lookup(s, cache, d_lanes, n_lanes, pool0, 1, dev_id, true);
+            for (int32_t h = 0; h <= last; h++)
+                do_feature_lookup(s, cache, d_lanes, n_lanes, pool0, INTRABATCH_CON * (h + 1) + 1, dev_id, true,
+                                  (h == 0 && seeds_ride) ? 1 : -1);
         }
         return;
     }
@@ -416,7 +389,7 @@ static void enqueue_lanes(hipStream_t s, GraphStorage* graph, FeatureStorage* fe
     if (is_presc && mode == TRAINMODE && cache != nullptr)     // CacheProfiling (one lane only in PreSC)
         cache->CacheProfiling(pool0->GetSampledIds(), pool0->GetAggSrcId(), pool0->GetAggDstId(), pool0->GetAggSrcOf(),
                               pool0->GetAggDstOf(), pool0->GetNodeCounter(), pool0->GetEdgeCounter(), s, dev_id);
-    lg::launch_end_of_batch(s, d_lanes, n_lanes, iter_state, pool_state_bytes(pool0));
+    lg::launch_end_of_batch(s, d_lanes, n_lanes, iter_state);
 }
 
 extern "C" void legion_enqueue_batch(legion_stream_t strm_hdl, LegionGraphStorage* graph, LegionFeatureStorage* feature,

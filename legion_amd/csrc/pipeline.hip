@@ -13,16 +13,16 @@
 //     depends on host-side values: sizes (including the clamped last batch) are computed on the
 //     device and the batch index lives in iter_state on the device, advanced by the last kernel;
 //   * `slots` groups are in flight (default 2): while the consumer reads slot s, slot s+1 runs;
-//   * split mode (use_graph bit 2): the sampler of a group is bound by scattered 4-byte atomics and
-//     loads (~2 TB/s of HBM traffic, waves mostly waiting), its gathers by HBM streaming.  The two
-//     phases are captured as two graphs and run on two streams -- every group's sampler on a
-//     high-priority stream, every group's gathers on another, gathers(k) waiting on sampler(k) -- so
-//     sampler(k+1) runs under gathers(k) and the two kinds of memory traffic share the machine.
+//   * weave (use_graph bit 4, what bench.py and the Runner use): a group is cut where its character changes -- the
+//     HEAD (seeds + every hop but the last) of group k+1 runs on a low-priority stream under the heavy kernels of group k
+//     (see submit).  The plain two-stream split (every sampler on one stream, every gather on another, with CU masks and
+//     priorities) was measured against it in rounds 2-4 and removed in round 5: DESIGN_HISTORY.md 4.5.
 #include "legion_core.h"
 
 #include <algorithm>
 #include <cstring>
 #include <map>
+#include <tuple>
 
 struct LegionLaneGroup;
 extern "C" void* d_alloc_scattered(int64_t num_bytes, int32_t chunk_mb);
@@ -44,16 +44,15 @@ extern "C" void legion_enqueue_group_phase(legion_stream_t strm_hdl, LegionGraph
                                            const int32_t* fanout, int32_t hop_num, int32_t phase);
 extern "C" void legion_pool_profile_begin(LegionMemoryPool* p_, int32_t max_ops);
 extern "C" const void* legion_group_lane_desc(LegionLaneGroup* g, int32_t lane);
-extern "C" void legion_set_weave_head_gathers(int32_t on);
 
 struct Slot {
     std::vector<MemoryPool*> pools;           // G lanes
     LegionLaneGroup* group = nullptr;
     hipStream_t stream = nullptr;
     hipEvent_t done = nullptr;
-    hipEvent_t sampled = nullptr;             // split mode: the group's sampler phase has finished (weave: its head)
+    hipEvent_t sampled = nullptr;             // weave: the group's head has finished
     bool busy = false;
-    std::map<int64_t, hipGraphExec_t> exec;   // key: (mode, active lanes, batch_size, phase)
+    std::map<std::tuple<int32_t, int32_t, int32_t, int32_t>, hipGraphExec_t> exec;   // key: (phase, mode, active lanes, batch_size)
     int32_t* d_iter = nullptr;                // device {next counter0, stride}
     int32_t* h_iter = nullptr;                // pinned staging
     int32_t next_iter = -1;                   // what d_iter[0] will hold once the slot is idle
@@ -84,13 +83,11 @@ struct LegionPipeline {
     std::vector<Slot> slots;
     bool use_graph;
     bool overlap = false;   // let kernels of different slots run concurrently (default: chained)
-    bool split = false;     // sampler and gather phases on two streams (see the header comment)
     bool weave = false;     // head of group k+1 on a second stream under the heavy kernels of group k (see submit)
     bool gathers = true;        // weave: false = the REST phase stops before the gathers (legion_pipeline_set_gathers)
     bool sample_only = false;   // only the sampler phase runs here; the owner gathers each lane itself (GPURunner: straight
                                 // into a trainer-visible pipe slot)
-    hipStream_t sample_stream = nullptr;
-    bool gather_high = false;
+    hipStream_t sample_stream = nullptr;      // weave: the light stream
     int32_t rr = 0;
     int32_t last_slot = -1;
     bool profiling = false;
@@ -121,17 +118,11 @@ extern "C" LegionPipeline* legion_pipeline_create(LegionGraphStorage* graph, Leg
     p->slots_n = slots < 1 ? 1 : slots;
     p->use_graph = (use_graph & 1) != 0;
     p->overlap = (use_graph & 2) != 0;
-    p->split = (use_graph & 4) != 0;
     p->sample_only = (use_graph & 8) != 0;
     p->weave = (use_graph & 16) != 0;
-    if (p->sample_only) p->split = p->weave = false;
-    if (p->weave) p->split = false;
-    if (p->split) p->overlap = false;
+    if (p->sample_only) p->weave = false;
     SetGPUDevice(dev_id);
     lg::tuning_refresh();
-    // split mode with a CU partition (LEGION_SPLIT_SAMPLER_CUS = n): the sampler stream may only use n of the 256 CUs
-    // (every (256/n)-th bit of the mask), the gather stream the others.  The sampler is bound by the latency of scattered
-    // atomics, not by CUs; the gather needs every wave slot it can get to keep ~12 MB of loads in flight.
     if (p->weave) {
         // the light stream (heads of the next group) runs at LOW priority: its dozen small kernels have the whole rest of the
         // current group (1.6 ms for 0.2 ms of work) to finish, and at equal priority their workgroups take slots from the
@@ -141,30 +132,6 @@ extern "C" LegionPipeline* legion_pipeline_create(LegionGraphStorage* graph, Leg
         HIP_CALL(hipDeviceGetStreamPriorityRange(&lo, &hi));
         if (wp == 0) HIP_CALL(hipStreamCreateWithFlags(&p->sample_stream, hipStreamNonBlocking))
         else HIP_CALL(hipStreamCreateWithPriority(&p->sample_stream, hipStreamNonBlocking, wp > 0 ? hi : lo));
-    }
-    std::vector<uint32_t> mask_s, mask_g;
-    if (p->split) {
-        const int n_cu = lg::tuning().split_sampler_cus;
-        if (n_cu > 0 && n_cu < 256) {
-            hipDeviceProp_t prop;
-            HIP_CALL(hipGetDeviceProperties(&prop, GetGPUDevice()));
-            const int total = prop.multiProcessorCount, words = (total + 31) / 32;
-            mask_s.assign(words, 0u);
-            mask_g.assign(words, 0u);
-            const int stride = std::max(1, total / n_cu);
-            for (int c = 0; c < total; c++) {
-                if (c % stride == 0 && (int)(c / stride) < n_cu) mask_s[c / 32] |= 1u << (c % 32);
-                else mask_g[c / 32] |= 1u << (c % 32);
-            }
-        }
-        int lo = 0, hi = 0;                                  // hi is the numerically lowest = highest priority
-        HIP_CALL(hipDeviceGetStreamPriorityRange(&lo, &hi));
-        const int prio = lg::tuning().split_priority;        // 1: sampler first, 0: equal, -1: gathers first
-        if (!mask_s.empty())
-            HIP_CALL(hipExtStreamCreateWithCUMask(&p->sample_stream, (uint32_t)mask_s.size(), mask_s.data()))
-        else
-            HIP_CALL(hipStreamCreateWithPriority(&p->sample_stream, hipStreamNonBlocking, prio > 0 ? hi : lo));
-        if (prio < 0) p->gather_high = true;
     }
     p->slots.resize(p->slots_n);
     p->feature_rows = feature_rows;
@@ -179,7 +146,6 @@ extern "C" LegionPipeline* legion_pipeline_create(LegionGraphStorage* graph, Leg
         p->arena.base = (char*)(((use_graph & 64) == 0 && chunk_mb > 0) ? d_alloc_scattered(p->arena.bytes, chunk_mb) : d_alloc_space(p->arena.bytes));
         lg_set_pool_arena(&p->arena);
     }
-    lg_set_pool_lanes_hint(p->group_size * p->slots_n);   // direct-vs-table choice of the position state sees every lane
     {   // what PreSC saw of the largest hop decides the small class's bucket count (8 or 16, storage.hip)
         int32_t last_hop[2] = {0, 0};
         if (p->cache_handle != nullptr)     // (the handle boxes the UnifiedCache as its first member, cache.hip)
@@ -188,7 +154,7 @@ extern "C" LegionPipeline* legion_pipeline_create(LegionGraphStorage* graph, Leg
     }
     // Arena pipelines (own arena or the caller's -- the server's) also carve their lanes' PRIVATE arrays from one block of shuffled
     // chunks (storage.hip): one lane is created with plain allocations first, only to add up what a lane asks for.
-    if (lg_get_pool_arena() != nullptr && lg::tuning().arena_scatter_mb > 0 && !(getenv("LEGION_PRIVATE_ARENA") && atoi(getenv("LEGION_PRIVATE_ARENA")) == 0)) {
+    if (lg_get_pool_arena() != nullptr && lg::tuning().arena_scatter_mb > 0) {
         PoolArena* trainer_arena = lg_get_pool_arena();
         lg_set_pool_arena(nullptr);
         lg_alloc_count_begin();
@@ -218,20 +184,13 @@ extern "C" LegionPipeline* legion_pipeline_create(LegionGraphStorage* graph, Leg
         HIP_CALL(hipHostMalloc((void**)&sl.h_iter, 2 * sizeof(int32_t), hipHostMallocDefault));
         // chained slots share one in-order stream (back-to-back graph launches, no event round trip);
         // overlapping slots get a stream each
-        if (!mask_g.empty() && &sl == &p->slots[0]) {
-            HIP_CALL(hipExtStreamCreateWithCUMask(&sl.stream, (uint32_t)mask_g.size(), mask_g.data()));
-        } else if (p->gather_high && &sl == &p->slots[0]) {
-            int lo = 0, hi = 0;
-            HIP_CALL(hipDeviceGetStreamPriorityRange(&lo, &hi));
-            HIP_CALL(hipStreamCreateWithPriority(&sl.stream, hipStreamNonBlocking, hi));
-        } else if (p->overlap || &sl == &p->slots[0])
+        if (p->overlap || &sl == &p->slots[0])
             HIP_CALL(hipStreamCreateWithFlags(&sl.stream, hipStreamNonBlocking))
         else
             sl.stream = p->slots[0].stream;
         HIP_CALL(hipEventCreateWithFlags(&sl.done, hipEventDisableTiming));
         HIP_CALL(hipEventCreateWithFlags(&sl.sampled, hipEventDisableTiming));
     }
-    lg_set_pool_lanes_hint(0);
     lg_set_pool_claims_hint(0, 0);
     lg_set_pool_arena(nullptr);
     if (p->priv_arena) lg_private_arena_end();
@@ -260,15 +219,13 @@ static void slot_wait(LegionPipeline* p, Slot& sl)
 static hipGraphExec_t graph_of(LegionPipeline* p, Slot& sl, hipStream_t strm, int32_t phase, int32_t mode, int32_t n_active,
                                int32_t batch_size)
 {
-    // (a HEAD captured for a group that gathers may carry the early gathers: its key differs from the sampler-only HEAD's)
-    const int64_t key = ((int64_t)phase << 48) | ((int64_t)((phase == LG_PHASE_HEAD && !p->gathers) ? 1 : 0) << 56) | ((int64_t)mode << 40) |
-                        ((int64_t)n_active << 32) | (uint32_t)batch_size;
+    // (a tuple, not packed bit fields: groups have up to 512 lanes, and (mode m, 256 + k lanes) must not meet (mode m + 1, k lanes))
+    const auto key = std::make_tuple(phase, mode, n_active, batch_size);
     auto it = sl.exec.find(key);
     if (it == sl.exec.end()) {
         hipGraph_t graph = nullptr;
         hipGraphExec_t exec = nullptr;
         HIP_CALL(hipStreamSynchronize(strm));
-        legion_set_weave_head_gathers(p->gathers ? 1 : 0);
         HIP_CALL(hipStreamBeginCapture(strm, hipStreamCaptureModeThreadLocal));
         legion_enqueue_group_phase(strm, reinterpret_cast<LegionGraphStorage*>(p->graph), reinterpret_cast<LegionFeatureStorage*>(p->feature),
                                    p->cache_handle, sl.group, n_active, batch_size, 0, p->dev_id, mode, p->fanout.data(),
@@ -306,7 +263,7 @@ extern "C" void legion_pipeline_prepare(LegionPipeline* p, int32_t mode, int32_t
     if (n_active < 1 || n_active > p->group_size) n_active = p->group_size;
     batch_size = checked_batch_size(p, batch_size);
     SetGPUDevice(p->dev_id);
-    const int32_t first_phase = (p->split || p->sample_only) ? LG_PHASE_SAMPLE : LG_PHASE_ALL;
+    const int32_t first_phase = p->sample_only ? LG_PHASE_SAMPLE : LG_PHASE_ALL;
     for (Slot& sl : p->slots) {
         slot_wait(p, sl);
         legion_group_set_iter_state(sl.group, sl.d_iter);
@@ -315,8 +272,7 @@ extern "C" void legion_pipeline_prepare(LegionPipeline* p, int32_t mode, int32_t
             (void)graph_of(p, sl, sl.stream, p->gathers ? LG_PHASE_REST : LG_PHASE_REST_SAMPLE, mode, n_active, batch_size);
             continue;
         }
-        (void)graph_of(p, sl, p->split ? p->sample_stream : sl.stream, first_phase, mode, n_active, batch_size);
-        if (p->split) (void)graph_of(p, sl, sl.stream, LG_PHASE_GATHER, mode, n_active, batch_size);
+        (void)graph_of(p, sl, sl.stream, first_phase, mode, n_active, batch_size);
     }
 }
 
@@ -387,7 +343,6 @@ extern "C" int32_t legion_pipeline_submit_ex(LegionPipeline* p, int32_t counter0
             HIP_CALL(hipMemcpyAsync(sl.d_iter, sl.h_iter, 2 * sizeof(int32_t), hipMemcpyHostToDevice, Y));
         }
         auto run = [&](hipStream_t strm, int32_t phase) {
-            legion_set_weave_head_gathers(p->gathers ? 1 : 0);
             if (eager)
                 legion_enqueue_group_phase(strm, gr, f, p->cache_handle, sl.group, n_active, batch_size, counter0, p->dev_id, mode,
                                            p->fanout.data(), p->hop_num, phase);
@@ -408,19 +363,12 @@ extern "C" int32_t legion_pipeline_submit_ex(LegionPipeline* p, int32_t counter0
         sl.busy = true;
         return si;
     }
-    // split mode: phase 1 on the sampler stream, phase 2 on the slot's (gather) stream behind it
-    hipStream_t s1 = p->split ? p->sample_stream : sl.stream;
-    const int32_t first_phase = (p->split || p->sample_only) ? LG_PHASE_SAMPLE : LG_PHASE_ALL;
+    hipStream_t s1 = sl.stream;
+    const int32_t first_phase = p->sample_only ? LG_PHASE_SAMPLE : LG_PHASE_ALL;
     if (!p->use_graph || p->profiling) {            // HIP cannot time events recorded by graph nodes
         legion_group_set_iter_state(sl.group, nullptr);     // eager: iteration by value
         legion_enqueue_group_phase(s1, gr, f, p->cache_handle, sl.group, n_active, batch_size, counter0,
                                    p->dev_id, mode, p->fanout.data(), p->hop_num, first_phase);
-        if (p->split) {
-            HIP_CALL(hipEventRecord(sl.sampled, s1));
-            HIP_CALL(hipStreamWaitEvent(sl.stream, sl.sampled, 0));
-            legion_enqueue_group_phase(sl.stream, gr, f, p->cache_handle, sl.group, n_active, batch_size, counter0,
-                                       p->dev_id, mode, p->fanout.data(), p->hop_num, LG_PHASE_GATHER);
-        }
         sl.next_iter = -1;
         sl.prof_pairs = sl.pools[0]->prof_used;
     } else {
@@ -430,81 +378,13 @@ extern "C" int32_t legion_pipeline_submit_ex(LegionPipeline* p, int32_t counter0
             sl.h_iter[1] = p->group_size * p->slots_n;
             HIP_CALL(hipMemcpyAsync(sl.d_iter, sl.h_iter, 2 * sizeof(int32_t), hipMemcpyHostToDevice, s1));
         }
-        hipGraphExec_t e1 = graph_of(p, sl, s1, first_phase, mode, n_active, batch_size);
-        hipGraphExec_t e2 = p->split ? graph_of(p, sl, sl.stream, LG_PHASE_GATHER, mode, n_active, batch_size) : nullptr;
-        HIP_CALL(hipGraphLaunch(e1, s1));
-        if (p->split) {
-            HIP_CALL(hipEventRecord(sl.sampled, s1));
-            HIP_CALL(hipStreamWaitEvent(sl.stream, sl.sampled, 0));
-            HIP_CALL(hipGraphLaunch(e2, sl.stream));
-        }
+        HIP_CALL(hipGraphLaunch(graph_of(p, sl, s1, first_phase, mode, n_active, batch_size), s1));
         // what the last kernel leaves in d_iter[0] (a partial group breaks the regular stride)
         sl.next_iter = n_active == p->group_size ? counter0 + p->group_size * p->slots_n : -1;
     }
     HIP_CALL(hipEventRecord(sl.done, sl.stream));
     sl.busy = true;
     return si;
-}
-
-// Experiment: can the last hop's de-duplication + compaction of group B run BESIDE the gathers of group A?
-// out_ms: [0] gathers(A) alone, [1] dedup+compact(B) alone, [2] both on one stream, [3] on two streams of equal priority,
-// [4] with the de-duplication's stream at high priority, [5] with it at low priority.  Eager launches, slots 0 and 1.
-extern "C" int32_t legion_pipeline_probe_overlap(LegionPipeline* p, int32_t counter0, int32_t mode, double* out_ms, int32_t prep_stages, int32_t side_stages)
-{
-    if (!p || p->slots_n < 2 || p->hop_num < 2) return 0;
-    SetGPUDevice(p->dev_id);
-    for (auto& sl : p->slots) slot_wait(p, sl);
-    Slot& A = p->slots[0];
-    Slot& B = p->slots[1];
-    LegionGraphStorage* gr = reinterpret_cast<LegionGraphStorage*>(p->graph);
-    LegionFeatureStorage* f = reinterpret_cast<LegionFeatureStorage*>(p->feature);
-    const int32_t G = p->group_size;
-    auto enq = [&](Slot& sl, hipStream_t s, int32_t phase, int stages, int32_t c0) {
-        for (int32_t g = 0; g < G; g++) { sl.pools[g]->SetCurrentMode(mode); sl.pools[g]->SetIter(c0 + g); }
-        legion_group_set_iter_state(sl.group, nullptr);
-        lg::g_sample_stages = stages;
-        legion_enqueue_group_phase(s, gr, f, p->cache_handle, sl.group, G, p->batch_size, c0, p->dev_id, mode, p->fanout.data(), p->hop_num, phase);
-        lg::g_sample_stages = 15;
-    };
-    hipStream_t X = A.stream, Z[3];
-    int lo = 0, hi = 0;
-    HIP_CALL(hipDeviceGetStreamPriorityRange(&lo, &hi));
-    HIP_CALL(hipStreamCreateWithPriority(&Z[0], hipStreamNonBlocking, 0));
-    HIP_CALL(hipStreamCreateWithPriority(&Z[1], hipStreamNonBlocking, hi));
-    HIP_CALL(hipStreamCreateWithPriority(&Z[2], hipStreamNonBlocking, lo));
-    hipEvent_t e0, e1, ez;
-    HIP_CALL(hipEventCreate(&e0)); HIP_CALL(hipEventCreate(&e1)); HIP_CALL(hipEventCreate(&ez));
-    enq(A, X, LG_PHASE_SAMPLE, 15, counter0);                         // A: sampled, ready for its gathers
-    auto prep_b = [&]() {                                              // B: everything up to and including the last hop's sampling kernel
-        enq(B, X, LG_PHASE_HEAD, 15, counter0 + G);
-        enq(B, X, LG_PHASE_REST_SAMPLE, prep_stages, counter0 + G);
-        HIP_CALL(hipStreamSynchronize(X));
-    };
-    auto timed = [&](int which) -> double {
-        prep_b();
-        float ms = 0;
-        HIP_CALL(hipEventRecord(e0, X));
-        if (which == 0) enq(A, X, LG_PHASE_GATHER, 15, counter0);
-        else if (which == 1) enq(B, X, LG_PHASE_REST_SAMPLE, side_stages, counter0 + G);
-        else if (which == 2) { enq(A, X, LG_PHASE_GATHER, 15, counter0); enq(B, X, LG_PHASE_REST_SAMPLE, side_stages, counter0 + G); }
-        else {
-            hipStream_t z = Z[which - 3];
-            HIP_CALL(hipStreamWaitEvent(z, e0, 0));
-            enq(A, X, LG_PHASE_GATHER, 15, counter0);
-            enq(B, z, LG_PHASE_REST_SAMPLE, side_stages, counter0 + G);
-            HIP_CALL(hipEventRecord(ez, z));
-            HIP_CALL(hipStreamWaitEvent(X, ez, 0));
-        }
-        HIP_CALL(hipEventRecord(e1, X));
-        HIP_CALL(hipEventSynchronize(e1));
-        HIP_CALL(hipEventElapsedTime(&ms, e0, e1));
-        return ms;
-    };
-    for (int rep = 0; rep < 2; rep++)                                  // (the first round warms up)
-        for (int w = 0; w < 6; w++) out_ms[w] = timed(w);
-    for (int i = 0; i < 3; i++) HIP_CALL(hipStreamDestroy(Z[i]));
-    HIP_CALL(hipEventDestroy(e0)); HIP_CALL(hipEventDestroy(e1)); HIP_CALL(hipEventDestroy(ez));
-    return 1;
 }
 
 extern "C" void legion_pipeline_wait(LegionPipeline* p, int32_t slot)

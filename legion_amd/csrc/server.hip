@@ -440,9 +440,8 @@ public:
     //           launch gathers the lane's rows straight into the pipe slot's feature buffer and copies its ids / edges /
     //           labels / counters there (deliver_slice in gather_kernel).  Bound by the launch -> completion latency of one
     //           small kernel with two slots in flight.
-    //   copy    (only when asked for) the groups run the whole path; per batch one pure copy launch moves the finished batch
-    //           from its lane into the pipe slot.  Measured slower than `gather` at every batch size (the rows cross HBM
-    //           twice): kept as the measured alternative.
+    //   (a third kind -- whole groups + one pure copy launch per batch into the pipe slot -- was built in round 4, measured slower than
+    //   `gather` at every batch size, the rows crossing HBM twice, and removed in round 5: DESIGN_HISTORY.md)
     // A slot's lanes are reused by a later group only when the trainer has RELEASED every batch of the group that used
     // them (a view is read in place; a copied / gathered batch was posted before it was released): the semaphore token that
     // lets batch k through says batch k-2 was released.  LEGION_RUNNER_GRAPH=0: the operator-by-operator path of the
@@ -499,7 +498,7 @@ public:
         const int32_t lane = k - g.first;
         MemoryPool* lp = reinterpret_cast<MemoryPool*>(legion_pipeline_pool(pipe_, g.slot, lane));
         if (kind_ == KIND_VIEWS) {
-            ReportErrors(lp);
+            ReportErrors(lp, true);
             const LanePtrs h = lp->HostLane(0);
             const int64_t off[5] = {(char*)h.sampled_ids - arena_.base, (char*)h.float_features - arena_.base, (char*)h.labels - arena_.base,
                                     (char*)h.agg_src_off - arena_.base, (char*)h.agg_dst_off - arena_.base};
@@ -509,17 +508,12 @@ public:
             // hand-overs run on their own (high-priority) streams, one per pipe slot: the two in flight overlap on the GPU
             hipStream_t s = ho_streams_[p % 2] != nullptr ? ho_streams_[p % 2] : static_cast<hipStream_t>(legion_pipeline_stream(pipe_));
             const int64_t max_rows = std::min<int64_t>(memorypool_->feature_rows, memorypool_->num_ids);
-            if (kind_ == KIND_COPY) {
-                lg::launch_handover_copy(s, static_cast<const LanePtrs*>(legion_pipeline_lane_desc(pipe_, g.slot, lane)), deliver_[p],
-                                         (int32_t)max_rows);
-            } else {
-                const LanePtrs* desc = d_desc_ + ((size_t)p * slots_ + g.slot) * lanes_ + lane;     // lane -> pipe slot p
-                UnifiedCache* cache = (UnifiedCache*)(params->cache);
-                if (float_feature_len_ > 0 && max_rows > 0)   // one launch: gather of every row of the batch + the hand-over copies
-                    cache->FeatCacheLookup(desc, 1, INTRABATCH_CON * hop_num_ + 1, local_dev_id_, s, (int32_t)max_rows, true, 1);
-                else
-                    lg::launch_deliver(s, desc, deliver_[p]);
-            }
+            const LanePtrs* desc = d_desc_ + ((size_t)p * slots_ + g.slot) * lanes_ + lane;     // lane -> pipe slot p
+            UnifiedCache* cache = (UnifiedCache*)(params->cache);
+            if (float_feature_len_ > 0 && max_rows > 0)   // one launch: gather of every row of the batch + the hand-over copies
+                cache->FeatCacheLookup(desc, 1, INTRABATCH_CON * hop_num_ + 1, local_dev_id_, s, (int32_t)max_rows, true, 1);
+            else
+                lg::launch_deliver(s, desc, deliver_[p]);
             HIP_CALL(hipEventRecord(batch_done_[p], s));
             // single producer (this thread), single consumer (the poster): at most INTERBATCH_CON jobs are outstanding
             // (a slot is only reused after the trainer released it, i.e. after its previous job was posted)
@@ -551,7 +545,6 @@ public:
         // known only when the trainer end attaches): no stream capture while the poster thread polls events
         for (int with_gathers = 0; with_gathers < 2; with_gathers++) {
             if ((handover_ == 1 || !lane_features_) && with_gathers) continue;     // forced `gather` (or no features at all): the groups never gather
-            if (handover_ == 2 && lane_features_ && !with_gathers) continue;       // forced `copy`: they always do
             legion_pipeline_set_gathers(pipe_, with_gathers);
             for (int32_t first = 0; first < max_step_;) {
                 int32_t mode = 0, local0 = 0;
@@ -605,24 +598,27 @@ public:
 
 private:
     struct Pending { hipEvent_t ev; int pipe; MemoryPool* lane; std::chrono::steady_clock::time_point enqueued; };
-    enum { KIND_UNDECIDED = 0, KIND_VIEWS, KIND_GATHER, KIND_COPY };
+    enum { KIND_UNDECIDED = 0, KIND_VIEWS, KIND_GATHER };
 
-    void ReportErrors(MemoryPool* mp)
+    // as_view: the batch is about to be handed over as views of its lane
+    void ReportErrors(MemoryPool* mp, bool as_view = false)
     {
         const int32_t bits = mp->ErrorBits() & ~reported_;
         if (bits == 0) return;
         reported_ |= bits;
         if (bits & LG_ERR_FEATURE_ROWS)
-            std::cout << "WARNING (gpu " << local_dev_id_ << "): a batch has more rows than the feature buffer ("
+            std::cout << (as_view ? "ERROR" : "WARNING") << " (gpu " << local_dev_id_ << "): a batch has more rows than the feature buffer ("
                       << memorypool_->feature_rows << " rows = 1.2 x the PreSC maximum); its tail rows were not gathered\n";
-        if (bits & LG_ERR_TABLE_FULL) std::cout << "ERROR (gpu " << local_dev_id_ << "): position table overflow\n";
+        if (bits & LG_ERR_TABLE_FULL) std::cout << "ERROR (gpu " << local_dev_id_ << "): a de-duplication bucket fits no LDS table\n";
         if (bits & LG_ERR_CHAIN) std::cout << "ERROR (gpu " << local_dev_id_ << "): unresolved first-touch chain\n";
         std::cout << std::flush;
-        // A full table or an unresolved chain means positions in this batch are garbage: it must not reach a trainer.
+        // An unresolved bucket or chain means positions in this batch are garbage: it must not reach a trainer.
         // Same convention as every other device-side failure at this boundary (include/legion_hip.h, the reference's
         // cudaCheckError): say what happened and end the process -- the caller is about to IPCPost.  A truncated feature
-        // buffer (above) stays a warning: ids, edges and the rows that fit are correct.
-        if (bits & (LG_ERR_TABLE_FULL | LG_ERR_CHAIN)) {
+        // buffer stays a warning where the rows were gathered into the pipe slot's own buffer (ids, edges and the rows that fit
+        // are correct; the reference overruns here, SS/engine/server.cu:277) -- but a VIEW of a lane's feature buffer with more
+        // rows than the buffer has would show the trainer the neighbouring lane's arrays as rows: never posted.
+        if ((bits & (LG_ERR_TABLE_FULL | LG_ERR_CHAIN)) || (as_view && (bits & LG_ERR_FEATURE_ROWS))) {
             std::cout << "legion_hip: corrupt batch on gpu " << local_dev_id_ << ", not posted; stopping the server\n" << std::flush;
             // trainers blocked in sem_wait must not wait for ever: mark the mirror object (this build's trainer end checks it
             // after every wake-up and fails), wake every waiter, unlink the names -- then go (no destructors: other runner
@@ -635,14 +631,12 @@ private:
     // what the trainer end of this GPU is, known when the first semaphore token arrives
     void DecideHandover(IPCEnv* env)
     {
-        if (handover_ == 2) kind_ = KIND_COPY;
-        else if (handover_ == 0 && env->TrainerTakesViews(local_dev_id_)) kind_ = KIND_VIEWS;
+        if (handover_ == 0 && env->TrainerTakesViews(local_dev_id_)) kind_ = KIND_VIEWS;
         else kind_ = KIND_GATHER;
         // groups submitted from now on gather their rows only when somebody reads them from the lanes
         legion_pipeline_set_gathers(pipe_, kind_ != KIND_GATHER && lane_features_);
         std::cout << "runner " << local_dev_id_ << ": hand-over by "
-                  << (kind_ == KIND_VIEWS ? "views of the lane arena" : kind_ == KIND_COPY ? "copy into the pipe slots"
-                                                                                         : "one gather launch per batch into the pipe slots")
+                  << (kind_ == KIND_VIEWS ? "views of the lane arena" : "one gather launch per batch into the pipe slots")
                   << ", " << lanes_ << " lanes per group, " << slots_ << " groups in flight\n" << std::flush;
     }
 
@@ -742,9 +736,6 @@ private:
             d.mirror = env->GetCounterMirror(local_dev_id_, p);
             d.num_ids = memorypool_->num_ids;
             d.batch_cap = memorypool_->batch_size;
-            d.float_features = float_feature_len_ > 0 ? env->GetFloatFeatures(local_dev_id_, p) : nullptr;
-            d.feature_rows = (int32_t)feature_rows;
-            d.D = float_feature_len_;
             HIP_CALL(hipEventCreateWithFlags(&batch_done_[p], hipEventDisableTiming));
         }
         d_deliver_ = (lg::DeliverParams*)d_alloc_space(sizeof(deliver_));
@@ -847,7 +838,7 @@ private:
     std::vector<OpParams*> op_params_;
     bool use_groups_ = lg::tuning().runner_graph != 0;
     // launch groups
-    int32_t handover_ = lg::tuning().runner_handover;     // 0 auto (views, else gather), 1 gather, 2 copy
+    int32_t handover_ = lg::tuning().runner_handover;     // 0 auto (views, else gather), 1 gather
     int kind_ = KIND_UNDECIDED;
     bool lane_features_ = false;                           // the lanes have feature buffers (and the groups may gather into them)
     bool bulk_ = false;                                    // peer_gather = bulk is in effect for this runner's groups

@@ -597,9 +597,6 @@ LanePtrs MemoryPool::HostLane(int32_t pipe) const
     h.agg_src_off = agg_src_off_[pipe];
     h.agg_dst_off = agg_dst_off_[pipe];
     h.tmp_part_ind = tmp_part_ind_;
-    h.position_map = position_map_;
-    h.pos_table = pos_table;
-    h.pos_table_mask = pos_table_mask;
     h.err_flag = err_dev;
     h.counter_mirror = counter_mirror_dev;
     h.claim_pairs = claim_pairs;
@@ -607,7 +604,7 @@ LanePtrs MemoryPool::HostLane(int32_t pipe) const
     h.claim_cnt = claim_cnt;
     h.claim_cap = claim_cap;
     h.ids_cap = num_ids;
-    h.lds_buckets = lds_form ? (1 << lds_bucket_bits) : 0;
+    h.lds_buckets = 1 << lds_bucket_bits;
     h.known_pairs = known_pairs;
     h.known_cnt = known_cnt;
     h.known_cap = known_cap;
@@ -615,11 +612,9 @@ LanePtrs MemoryPool::HostLane(int32_t pipe) const
     h.edge_counter = edge_counter_[pipe];
     h.slot_dst = slot_dst;
     h.slot_pos = slot_pos;
-    h.slot_mark = slot_mark;
     h.slot_fs = slot_fs;
     h.node_slot = node_slot;
     h.max_slots = max_slots;
-    h.total_num_nodes = total_num_nodes;
     h.tile_state = tile_state;
     h.hop_scratch = hop_scratch;
     h.fh_edge = fh_edge;
@@ -650,9 +645,6 @@ void MemoryPool::Finalize()
     d_free_space(d_lanes_);
     d_lanes_ = nullptr;
     d_free_space(cache_search_buffer_);
-    d_free_space(position_map_);
-    d_free_space(pos_table);
-    pos_table = nullptr;
     d_free_space(claim_pairs);
     d_free_space(run_off);
     d_free_space(claim_cnt);
@@ -672,8 +664,6 @@ void MemoryPool::Finalize()
     d_free_space(slot_dst);
     d_free_space(slot_pos);
     slot_pos = nullptr;
-    d_free_space(slot_mark);
-    slot_mark = nullptr;
     d_free_space(slot_fs);
     d_free_space(node_slot);
     slot_fs = node_slot = nullptr;
@@ -681,7 +671,7 @@ void MemoryPool::Finalize()
     d_free_space(hop_scratch);
     d_free_space(fh_edge);
     fh_edge = nullptr;
-    cache_search_buffer_ = position_map_ = agg_src_ids_ = agg_dst_ids_ = tmp_part_off_ = nullptr;
+    cache_search_buffer_ = agg_src_ids_ = agg_dst_ids_ = tmp_part_off_ = nullptr;
     tmp_part_ind_ = nullptr;
     slot_dst = hop_scratch = nullptr;
     tile_state = nullptr;
@@ -701,37 +691,11 @@ void MemoryPool::Finalize()
     }
 }
 
-// ---- direct array or compact table for the position state (legion_core.h) ------------------------
-static bool lg_use_pos_table(int64_t total_num_nodes);
-static thread_local int32_t g_pool_lanes_hint = 0;
-void lg_set_pool_lanes_hint(int32_t lanes) { g_pool_lanes_hint = lanes; }
 static thread_local int64_t g_pool_claims_hint[2] = {0, 0};
 void lg_set_pool_claims_hint(int64_t last_hop_edges, int64_t nodes_before_last_hop)
 {
     g_pool_claims_hint[0] = last_hop_edges;
     g_pool_claims_hint[1] = nodes_before_last_hop;
-}
-
-// 0 direct array, 1 table, 2 lds (legion_core.h)
-static int lg_dedup_form(int64_t total_num_nodes, int64_t max_slots)
-{
-    const int32_t want = lg::tuning().dedup_form;
-    if (want == 1) return 1;
-    if (want == 0) return 0;
-    if (want == 2) return max_slots <= LG_LDS_MAX_SLOTS ? 2 : 1;
-    // auto: the LDS form wherever a hop's slots per lane allow it (no per-vertex state; measured against either atomics form:
-    // +14 % edges/s at B = 1024 with 8 buckets per lane, +5.5 % at B = 8000 [25,10] with 64); otherwise the direct array
-    // while it fits a quarter of HBM over all lanes in flight, else the table
-    if (max_slots <= LG_LDS_MAX_SLOTS) return 2;
-    return lg_use_pos_table(total_num_nodes) ? 1 : 0;
-}
-
-static bool lg_use_pos_table(int64_t total_num_nodes)
-{
-    size_t free_b = 0, total_b = 0;
-    HIP_CALL(hipMemGetInfo(&free_b, &total_b));
-    const int64_t lanes = g_pool_lanes_hint > 0 ? g_pool_lanes_hint : 1;
-    return total_num_nodes * 4 * lanes > (int64_t)(total_b / 4);
 }
 
 // server-private scratch of one GPU: SS/engine/server.cu:216-234 plus the compaction scratch
@@ -744,12 +708,9 @@ void lg_pool_alloc_private(MemoryPool* mp, int32_t dev_id, int32_t total_num_nod
     int64_t num_ids = batch_size, per = batch_size;         // server.cu:187-199
     mp->max_new.assign(1, batch_size);
     for (int i = 0; i < hop_num; i++) { per *= fanout[i]; num_ids += per; mp->max_new.push_back(per); }
-    int32_t value_bits = LG_POS_VALUE_BITS_MIN;          // position-state format, see legion_core.h
-    value_bits = std::max(value_bits, tune.pos_value_bits);
-    while (value_bits <= LG_POS_VALUE_BITS_MAX && (num_ids >> value_bits) != 0) value_bits++;
-    if (value_bits > LG_POS_VALUE_BITS_MAX) {
-        printf("legion_hip: batch %d with this fan-out needs %lld slots / %lld ids; limit is 2^%d\n", batch_size,
-               (long long)per, (long long)num_ids, LG_POS_VALUE_BITS_MAX);
+    if (num_ids >= ((int64_t)1 << 31) - 16384) {          // positions and slot indices are int32, as in the reference (operator_impl.cu:208)
+        printf("legion_hip: batch %d with this fan-out needs %lld slots / %lld ids; the limit is 2^31\n", batch_size, (long long)per,
+               (long long)num_ids);
         exit(EXIT_FAILURE);
     }
     mp->dev_id = dev_id;
@@ -759,12 +720,10 @@ void lg_pool_alloc_private(MemoryPool* mp, int32_t dev_id, int32_t total_num_nod
     mp->batch_size = batch_size;
     mp->float_feature_len = float_feature_len;
     mp->SetCacheSearchBuffer((int32_t*)d_alloc_space(num_ids * sizeof(int32_t)));
-    const int form = lg_dedup_form(total_num_nodes, hop_num > 0 ? per : batch_size);
-    if (form == 2) {
-        // lds form: no per-vertex state; the hop's claim pairs + the runs of every super tile
+    {
+        // first touches (legion_core.h): no per-vertex state; one claim list and one known list per hash bucket
         const int64_t slots = hop_num > 0 ? per : batch_size;
         const int64_t n_super = (slots + LG_SUPER - 1) / LG_SUPER + 1;
-        mp->lds_form = true;
         mp->lds_bucket_bits = slots <= LG_LDS_SLOTS_SMALL ? LG_LDS_BITS_SMALL : (slots <= LG_LDS_SLOTS_MEDIUM ? LG_LDS_BITS_MEDIUM : LG_LDS_BITS_LARGE);
         if (mp->lds_bucket_bits == LG_LDS_BITS_SMALL) {
             // The small class has 8 or 16 buckets per lane.  Slots say how large a hop CAN get, not how many of them hold an
@@ -777,20 +736,20 @@ void lg_pool_alloc_private(MemoryPool* mp, int32_t dev_id, int32_t total_num_nod
             if (tune.lds_small_buckets == 16 || (tune.lds_small_buckets != 8 && need / 8 > one_pass)) mp->lds_bucket_bits = LG_LDS_BITS_SMALL16;
         }
         const int64_t n_buckets = (int64_t)1 << mp->lds_bucket_bits;
-        if (mp->lds_bucket_bits == LG_LDS_BITS_SMALL || mp->lds_bucket_bits == LG_LDS_BITS_SMALL16) {
+        {
             // one claim list per bucket, twice an even share each (a bucket that outgrows its list is served from the hop's
             // slots instead, kernels_sample.hip)
             mp->claim_cap = (int32_t)(2 * ((slots + n_buckets - 1) / n_buckets) + 256);
             if (tune.lds_claim_cap > 0) mp->claim_cap = tune.lds_claim_cap;      // tests: force the fallback
             const int64_t chunks = ((int64_t)mp->claim_cap + LG_CLAIM_CHUNK - 1) / LG_CLAIM_CHUNK;      // (interleaved by chunk: LanePtrs)
             mp->claim_pairs = (unsigned long long*)d_alloc_space(n_buckets * chunks * LG_CLAIM_CHUNK * sizeof(unsigned long long));
-            mp->claim_cnt = (int32_t*)d_alloc_space(n_buckets * 32 * sizeof(int32_t));
-            HIP_CALL(hipMemset(mp->claim_cnt, 0, n_buckets * 32 * sizeof(int32_t)));
-        } else {
-            mp->claim_pairs = (unsigned long long*)d_alloc_space(slots * sizeof(unsigned long long));
+            mp->claim_cnt = (int32_t*)d_alloc_space(n_buckets * LG_CLAIM_CNT_STRIDE * sizeof(int32_t));
+            HIP_CALL(hipMemset(mp->claim_cnt, 0, n_buckets * LG_CLAIM_CNT_STRIDE * sizeof(int32_t)));
         }
-        const int64_t n_parts = std::min<int64_t>(n_super, LG_LDS_MAX_PARTS) + 2;    // launch_random_sample keeps every hop within LG_LDS_MAX_PARTS
-        mp->run_off = (int32_t*)d_alloc_space(n_parts * (n_buckets + 1) * sizeof(int32_t));
+        if (n_buckets > 16) {        // 64 / 256 buckets: {first place, count} per partition tile and bucket (sample_kernel -> place_kernel)
+            const int64_t n_parts = (n_super + lg_lds_k_min(mp->lds_bucket_bits) - 1) / lg_lds_k_min(mp->lds_bucket_bits) + 1;
+            mp->run_off = (int32_t*)d_alloc_space(n_parts * n_buckets * 2 * sizeof(int32_t));
+        }
         // per-bucket lists of the nodes hops 1 .. H-1 add (later hops must recognise them): twice an even share each;
         // a bucket that outgrows its list is served by scanning sampled_ids instead (kernels_sample.hip)
         int64_t listed = 0;
@@ -802,20 +761,6 @@ void lg_pool_alloc_private(MemoryPool* mp, int32_t dev_id, int32_t total_num_nod
             mp->known_cnt = (int32_t*)d_alloc_space(n_buckets * sizeof(int32_t));
             HIP_CALL(hipMemset(mp->known_cnt, 0, n_buckets * sizeof(int32_t)));
         }
-        mp->SetPositionMap(nullptr);
-    } else if (form == 1) {
-        // compact form: at least 1.5 x the pool's worst-case id count, so a free word always exists
-        uint32_t bits = 10;
-        while (((int64_t)1 << bits) < num_ids + num_ids / 2) bits++;
-        if (tune.pos_table_bits > 0) bits = (uint32_t)tune.pos_table_bits;   // tests: force a crowded table
-        mp->pos_table_mask = (1u << bits) - 1u;
-        mp->pos_table = (unsigned long long*)d_alloc_space(((int64_t)1 << bits) * sizeof(unsigned long long));
-        HIP_CALL(hipMemset(mp->pos_table, 0xFF, ((size_t)1 << bits) * sizeof(unsigned long long)));
-        mp->SetPositionMap(nullptr);
-    } else {
-        int32_t* position_map = (int32_t*)d_alloc_space((int64_t)total_num_nodes * sizeof(int32_t));
-        HIP_CALL(hipMemset(position_map, 0xFF, (size_t)total_num_nodes * sizeof(int32_t)));   // every entry 'untouched'
-        mp->SetPositionMap(position_map);
     }
     {   // host-visible error word (kernels OR LG_ERR_* into it; reading it costs the host nothing)
         void* h = nullptr;
@@ -833,8 +778,6 @@ void lg_pool_alloc_private(MemoryPool* mp, int32_t dev_id, int32_t total_num_nod
     const int64_t max_tiles = (mp->max_slots + LG_TILE - 1) / LG_TILE + 1;
     mp->slot_dst = (int32_t*)d_alloc_space((int64_t)mp->max_slots * sizeof(int32_t));
     mp->slot_pos = (int32_t*)d_alloc_space((int64_t)mp->max_slots * sizeof(int32_t));
-    mp->slot_mark = (int32_t*)d_alloc_space((int64_t)mp->max_slots * sizeof(int32_t));
-    HIP_CALL(hipMemset(mp->slot_mark, 0, (size_t)mp->max_slots * sizeof(int32_t)));
     if (tune.col_slots != 0) {       // carried feature-cache slots (column slots): per slot of a hop, per node of the batch
         mp->slot_fs = (int32_t*)d_alloc_space((int64_t)mp->max_slots * sizeof(int32_t));
         mp->node_slot = (int32_t*)d_alloc_space(num_ids * sizeof(int32_t));
@@ -847,9 +790,6 @@ void lg_pool_alloc_private(MemoryPool* mp, int32_t dev_id, int32_t total_num_nod
     mp->fh_edge = (RowHdr*)d_alloc_space(num_ids * sizeof(RowHdr));
     mp->hop_scratch = (int32_t*)d_alloc_space(HS_WORDS * sizeof(int32_t));
     HIP_CALL(hipMemset(mp->hop_scratch, 0, HS_WORDS * sizeof(int32_t)));
-    const int32_t first_epoch = 1;
-    HIP_CALL(hipMemcpy(mp->hop_scratch + HS_EPOCH, &first_epoch, sizeof(int32_t), hipMemcpyHostToDevice));
-    HIP_CALL(hipMemcpy(mp->hop_scratch + HS_VALUE_BITS, &value_bits, sizeof(int32_t), hipMemcpyHostToDevice));
 }
 
 // ---- C API ----------------------------------------------------------------------------------
@@ -1019,7 +959,7 @@ extern "C" void* legion_pool_buffer(LegionMemoryPool* p_, int32_t which)
         case 9: return mp->GetCacheSearchBuffer();
         case 10: return mp->GetTmpPartIdx();
         case 11: return mp->GetTmpPartOff();
-        case 12: return mp->GetPositionMap();
+        case 12: return mp->GetPositionMap();      // always null: no per-vertex state in this build
         default: return nullptr;
     }
 }
@@ -1032,34 +972,19 @@ extern "C" int32_t legion_pool_error(const LegionMemoryPool* p_)
     return mp ? mp->ErrorBits() : 0;
 }
 
-// 1 if the pool keeps its position state in the compact table form, 0 for the direct uint32[N] array
-extern "C" int32_t legion_pool_uses_table(const LegionMemoryPool* p_)
-{
-    const MemoryPool* mp = reinterpret_cast<const MemoryPool*>(p_);
-    return (mp && mp->pos_table != nullptr) ? 1 : 0;
-}
-
-// 0 direct uint32[N] array, 1 compact table, 2 lds (no per-vertex state)
+// hash buckets per lane of the first-touch de-duplication: 8, 16, 64 or 256
 extern "C" int32_t legion_pool_lds_buckets(const LegionMemoryPool* p_)
 {
     const MemoryPool* p = reinterpret_cast<const MemoryPool*>(p_);
-    return (p && p->lds_form) ? (1 << p->lds_bucket_bits) : 0;
-}
-
-extern "C" int32_t legion_pool_dedup_form(const LegionMemoryPool* p_)
-{
-    const MemoryPool* mp = reinterpret_cast<const MemoryPool*>(p_);
-    if (!mp) return -1;
-    return mp->lds_form ? 2 : (mp->pos_table != nullptr ? 1 : 0);
+    return p ? (1 << p->lds_bucket_bits) : 0;
 }
 
 extern "C" int64_t legion_pool_state_bytes(const LegionMemoryPool* p_)
 {
     const MemoryPool* mp = reinterpret_cast<const MemoryPool*>(p_);
     if (!mp) return 0;
-    if (mp->lds_form)      // one hop's claim pairs + the known lists
-        return (mp->claim_cap > 0 ? ((((int64_t)mp->claim_cap + LG_CLAIM_CHUNK - 1) / LG_CLAIM_CHUNK * LG_CLAIM_CHUNK) << mp->lds_bucket_bits) : (int64_t)mp->max_slots) * 8 + ((int64_t)mp->known_cap << mp->lds_bucket_bits) * 8;
-    return mp->pos_table ? ((int64_t)mp->pos_table_mask + 1) * 8 : (int64_t)mp->total_num_nodes * 4;
+    // one hop's claim lists + the known lists (nothing that scales with the graph)
+    return ((((int64_t)mp->claim_cap + LG_CLAIM_CHUNK - 1) / LG_CLAIM_CHUNK * LG_CLAIM_CHUNK) << mp->lds_bucket_bits) * 8 + ((int64_t)mp->known_cap << mp->lds_bucket_bits) * 8;
 }
 
 extern "C" void legion_pool_destroy(LegionMemoryPool* p_)

@@ -1,8 +1,9 @@
 // tuning.hip -- the one place where the LEGION_* tuning environment is parsed (include/legion_hip.h section 6).
 //
-// The reference has compile-time constants only (SS/include/system_config.cuh); this build grew run-time switches
-// while its kernels were measured.  They select HOW the path runs (which form of the first-touch state, tile counts,
-// stream layout of the Runner), never WHAT it computes -- every combination is parity-tested against the oracle.
+// The reference has compile-time constants only (SS/include/system_config.cuh); this build has run-time switches for
+// HOW the path runs (bucket and tile counts, stream layout of the Runner, where tables live), never WHAT it computes --
+// every combination is parity-tested against the oracle.  Switches whose measured alternative lost were removed in round 5
+// (DESIGN_HISTORY.md keeps the measurements).
 // The library keeps one process-wide LegionTuning; launch paths read it through lg::tuning() and never call getenv.
 #include "legion_core.h"
 
@@ -27,37 +28,19 @@ int env_int(const char* name, int dflt)
 void parse_env(LegionTuning& t)
 {
     memset(&t, 0, sizeof(t));
-    t.dedup_form = -1;
-    if (const char* e = getenv("LEGION_DEDUP")) {
-        if (strcmp(e, "direct") == 0) t.dedup_form = 0;
-        else if (strcmp(e, "table") == 0) t.dedup_form = 1;
-        else if (strcmp(e, "lds") == 0) t.dedup_form = 2;
-        else if (strcmp(e, "auto") != 0 && *e) {
-            printf("legion_hip: LEGION_DEDUP=%s is not one of auto|direct|table|lds\n", e);
-            exit(EXIT_FAILURE);
-        }
-    }
-    t.pos_value_bits = env_int("LEGION_POS_VALUE_BITS", 0);
-    t.pos_table_bits = env_int("LEGION_POS_TABLE_BITS", 0);
     t.lds_known_cap = env_int("LEGION_LDS_KNOWN_CAP", 0);
     t.lds_claim_cap = env_int("LEGION_LDS_CLAIM_CAP", 0);
-    t.lds_one_wg_lanes = env_int("LEGION_LDS_ONE_WG_LANES", 0);
     t.arena_scatter_mb = env_int("LEGION_ARENA_SCATTER_MB", 2);
     t.lds_part_wg = env_int("LEGION_LDS_PART_WG", 8192);
     t.lds_small_buckets = env_int("LEGION_LDS_SMALL_BUCKETS", 0);
     t.sample_max_wg = env_int("LEGION_SAMPLE_MAX_WG", 4096);
-    t.loser_in_dst = env_int("LEGION_LOSER_IN_DST", 1);
-    t.gather_small_tiles = env_int("LEGION_GATHER_SMALL_TILES", 1);
     t.gather_rows_per_wg = env_int("LEGION_GATHER_ROWS", 0);
-    t.compact_hoist = env_int("LEGION_COMPACT_HOIST", 1);
     t.col_slots = env_int("LEGION_COL_SLOTS", -1);
-    t.split_sampler_cus = env_int("LEGION_SPLIT_SAMPLER_CUS", 0);
-    t.split_priority = env_int("LEGION_SPLIT_PRIORITY", 1);
     t.weave_priority = env_int("LEGION_WEAVE_PRIORITY", -1);
-    t.weave_early_gathers = env_int("LEGION_WEAVE_EARLY_GATHERS", 0);
     t.runner_graph = env_int("LEGION_RUNNER_GRAPH", 1);
     t.runner_lanes = env_int("LEGION_RUNNER_LANES", 0);
     t.runner_ho_stream = env_int("LEGION_RUNNER_HO_STREAM", 2);
+    t.runner_spin_us = env_int("LEGION_RUNNER_SPIN_US", -1);
     t.runner_stats = getenv("LEGION_RUNNER_STATS") != nullptr ? 1 : 0;
     auto word = [](const char* name, std::initializer_list<std::pair<const char*, int>> words, int dflt) {
         const char* e = getenv(name);
@@ -70,10 +53,9 @@ void parse_env(LegionTuning& t)
         printf("legion_hip: %s=%s is not one of %s\n", name, e, all.c_str());
         exit(EXIT_FAILURE);
     };
-    t.runner_handover = word("LEGION_RUNNER_HANDOVER", {{"auto", 0}, {"gather", 1}, {"copy", 2}}, 0);
+    t.runner_handover = word("LEGION_RUNNER_HANDOVER", {{"auto", 0}, {"gather", 1}}, 0);
     t.runner_slots = env_int("LEGION_RUNNER_SLOTS", 3);
     t.peer_gather = word("LEGION_PEER_GATHER", {{"direct", 0}, {"bulk", 1}}, 0);
-    t.feature_pitch = word("LEGION_FEATURE_PITCH", {{"auto", -1}, {"dense", 0}, {"aligned", 1}}, -1);
     t.hotness_reduce = word("LEGION_HOTNESS_REDUCE", {{"auto", -1}, {"p2p", 0}, {"rccl", 1}}, -1);
     t.markers = env_int("LEGION_MARKERS", 1);
     t.table_placement = 0;

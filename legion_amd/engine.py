@@ -82,7 +82,7 @@ def tuning():
 
 
 def set_tuning(**fields):
-    """Installs programmatic tuning values (kept until tuning_from_env() is called): set_tuning(dedup_form=1, ...)."""
+    """Installs programmatic tuning values (kept until tuning_from_env() is called): set_tuning(runner_lanes=4, ...)."""
     t = _libmod.Tuning()
     L = _libmod.load()
     L.legion_tuning_get(ctypes.byref(t))
@@ -274,16 +274,8 @@ class MemoryPool:
             shape = (self.num_ids,)
         return device_view(ptr, shape, dtype, self.device)
 
-    def uses_table(self):
-        """True if the pool's first-touch/position state is the compact table form (LEGION_DEDUP)."""
-        return bool(self._lib.legion_pool_uses_table(self.handle))
-
-    def dedup_form(self):
-        """'direct', 'table' or 'lds' (legion_hip.h: legion_pool_dedup_form)."""
-        return ("direct", "table", "lds")[int(self._lib.legion_pool_dedup_form(self.handle))]
-
     def lds_buckets(self):
-        """Hash buckets per lane of the lds form (8, 16, 64, 256), 0 for the other forms."""
+        """Hash buckets per lane of the first-touch de-duplication (8, 16, 64 or 256 by the pool's largest hop)."""
         return int(self._lib.legion_pool_lds_buckets(self.handle))
 
     def state_bytes(self):
@@ -354,7 +346,7 @@ class Pipeline:
     allocation that other processes / GPUs can map (peer_gather = bulk)."""
 
     def __init__(self, graph, feature, cache, dev_id, batch_size, fanout, group_size, feature_rows, use_graph=True,
-                 slots=2, overlap=False, split=False, weave=False, arena=False):
+                 slots=2, overlap=False, split=False, weave=False, arena=False):      # (split: accepted and ignored -- removed in round 5)
         self._lib = _libmod.load()
         self.group_size, self.slots = int(group_size), int(slots)
         self.fanout = [int(f) for f in fanout]

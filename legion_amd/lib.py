@@ -40,8 +40,6 @@ SIGNATURES = {
     "legion_pool_num_ids": (c_i32, [c_p]),
     "legion_pool_buffer": (c_p, [c_p, c_i32]),
     "legion_pool_destroy": (None, [c_p]),
-    "legion_pool_uses_table": (c_i32, [c_p]),
-    "legion_pool_dedup_form": (c_i32, [c_p]),
     "legion_pool_lds_buckets": (c_i32, [c_p]),
     "legion_pool_state_bytes": (c_i64, [c_p]),
     "legion_pool_error": (c_i32, [c_p]),
@@ -98,7 +96,6 @@ SIGNATURES = {
     "legion_pipeline_submit_n": (c_i32, [c_p, c_i32, c_i32, c_i32]),
     "legion_enqueue_group_n": (None, [c_p, c_p, c_p, c_p, c_p, c_i32, c_i32, c_i32, c_i32, c_i32, P_I32, c_i32]),
     "legion_pipeline_wait": (None, [c_p, c_i32]),
-    "legion_pipeline_probe_overlap": (c_i32, [c_p, c_i32, c_i32, ctypes.POINTER(ctypes.c_double), c_i32, c_i32]),
     "legion_pipeline_pool": (c_p, [c_p, c_i32, c_i32]),
     "legion_pipeline_destroy": (None, [c_p]),
     "legion_pipeline_bulk_enable": (c_i32, [c_p]),
@@ -151,9 +148,9 @@ class LinkCounters(ctypes.Structure):          # LegionLinkCounters
 
 class Tuning(ctypes.Structure):                # LegionTuning (include/legion_hip.h section 6)
     _fields_ = [(n, c_i32) for n in (
-        "dedup_form", "pos_value_bits", "pos_table_bits", "lds_known_cap", "lds_claim_cap", "lds_one_wg_lanes", "arena_scatter_mb", "lds_part_wg", "lds_small_buckets", "sample_max_wg", "loser_in_dst",
-        "gather_small_tiles", "gather_rows_per_wg", "compact_hoist", "col_slots", "split_sampler_cus", "split_priority", "weave_priority", "weave_early_gathers", "runner_graph", "runner_lanes",
-        "runner_ho_stream", "runner_stats", "runner_handover", "runner_slots", "peer_gather", "feature_pitch", "hotness_reduce", "markers", "table_placement", "shm_mirror", "link_counters")] + \
+        "lds_small_buckets", "lds_part_wg", "sample_max_wg", "lds_known_cap", "lds_claim_cap", "col_slots", "gather_rows_per_wg", "peer_gather",
+        "arena_scatter_mb", "weave_priority", "markers", "runner_graph", "runner_lanes", "runner_slots", "runner_handover", "runner_ho_stream",
+        "runner_spin_us", "runner_stats", "shm_mirror", "table_placement", "hotness_reduce", "link_counters")] + \
         [("link_counter_values", c_u64 * 2)]
 
 

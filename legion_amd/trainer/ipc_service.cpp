@@ -78,9 +78,42 @@ typedef struct shmExt_st {
 } shmExt;
 static_assert(sizeof(hipIpcMemHandle_t) == 64, "IPC handle size is part of the wire format");
 
-// The server's lane arena as chunks: connect, receive the descriptors (64 per message), import and map them in order.
-static void* map_arena_chunks(int pid, int dev, int n_chunks, long long chunk_bytes, int hip_dev, std::string* why)
+// What this module reads from the environment, once, in initialize() (it is an extension of its own: LegionTuning lives in the
+// server's library).  Deployment: LEGION_IPC_NAMESPACE (suffix of every shm / semaphore name; must match the server's),
+// LEGION_IPC_DEVICE (attach to this LOGICAL server GPU while staying on the current physical device).  Behaviour:
+// LEGION_NO_SHM_MIRROR=1 (counters copied from the device, as the reference's trainer end does), LEGION_NO_DIRECT_VIEWS=1
+// (batches from the two pipe slots only, as a build of TB/ipc_cuda_kernel.cu gets them).
+struct TrainerOptions {
+    std::string suffix;
+    int ipc_device = -1;
+    bool shm_mirror = true, direct_views = true;
+    static TrainerOptions FromEnv()
+    {
+        TrainerOptions o;
+        if (const char* e = getenv("LEGION_IPC_NAMESPACE")) o.suffix = e;
+        if (const char* e = getenv("LEGION_IPC_DEVICE")) o.ipc_device = atoi(e);
+        o.shm_mirror = getenv("LEGION_NO_SHM_MIRROR") == nullptr;
+        o.direct_views = getenv("LEGION_NO_DIRECT_VIEWS") == nullptr;
+        return o;
+    }
+};
+
+#include "vmm_probe.h"      // vmm_fd_convention(): how THIS process's HIP runtime takes a file-descriptor handle
+
+// The server's lane arena as chunks: connect, receive the descriptors (64 per message), import and map them in order.  An import
+// handle is released as soon as its chunk is mapped (the mapping keeps the memory alive, nothing else has to); on any failure
+// what was mapped is unmapped again and the range given back, and the caller falls back to the pipe slots.
+static void unmap_arena_chunks(void* base, int n_mapped, int n_chunks, long long chunk_bytes)
 {
+    if (base == nullptr) return;
+    for (int i = 0; i < n_mapped; i++)
+        if (hipMemUnmap((char*)base + (size_t)i * (size_t)chunk_bytes, (size_t)chunk_bytes) != hipSuccess) (void)hipGetLastError();
+    if (hipMemAddressFree(base, (size_t)n_chunks * (size_t)chunk_bytes) != hipSuccess) (void)hipGetLastError();
+}
+static void* map_arena_chunks(const std::string& suffix, int pid, int dev, int n_chunks, long long chunk_bytes, int hip_dev, std::string* why)
+{
+    const int conv = vmm_fd_convention();
+    if (conv < 0) { *why = "this HIP runtime imports no file-descriptor handles"; return nullptr; }
     const int c = socket(AF_UNIX, SOCK_STREAM | SOCK_CLOEXEC, 0);
     if (c < 0) { *why = "socket()"; return nullptr; }
     sockaddr_un addr;
@@ -88,11 +121,15 @@ static void* map_arena_chunks(int pid, int dev, int n_chunks, long long chunk_by
     addr.sun_family = AF_UNIX;
     const int len = snprintf(addr.sun_path + 1, sizeof(addr.sun_path) - 1, "legion_arena_%d_%d", pid, dev);
     if (connect(c, (sockaddr*)&addr, (socklen_t)(offsetof(sockaddr_un, sun_path) + 1 + len)) != 0) { close(c); *why = "connect()"; return nullptr; }
+    {   // whoever answers under that name hands out descriptors this process will map: it must be the same user's process
+        ucred cr;
+        socklen_t cl = sizeof(cr);
+        if (getsockopt(c, SOL_SOCKET, SO_PEERCRED, &cr, &cl) != 0 || cr.uid != geteuid()) { close(c); *why = "the arena socket belongs to another user"; return nullptr; }
+    }
+    (void)suffix;
     void* base = nullptr;
     if (hipMemAddressReserve(&base, (size_t)n_chunks * (size_t)chunk_bytes, 0, nullptr, 0) != hipSuccess) { (void)hipGetLastError(); close(c); *why = "hipMemAddressReserve"; return nullptr; }
-    int got = 0, rt_version = 0;
-    (void)hipRuntimeGetVersion(&rt_version);
-    const bool fd_by_value = rt_version >= 70200000;
+    int got = 0;
     bool ok = true;
     while (got < n_chunks && ok) {
         char payload = 0;
@@ -110,16 +147,20 @@ static void* map_arena_chunks(int pid, int dev, int n_chunks, long long chunk_by
         for (int i = 0; i < n; i++) {
             if (ok && got < n_chunks) {
                 hipMemGenericAllocationHandle_t h;
-                // (the HIP runtime bundled with torch 2.10+rocm7.0 -- the one this module runs on inside a trainer -- takes a POINTER to the
-                //  descriptor and crashes on the value; ROCm 7.2's takes the value, as CUDA's does: tools/micro/vmm_torch_probe.py)
-                void* os_handle = fd_by_value ? (void*)(uintptr_t)fds[i] : (void*)&fds[i];
-                if (hipMemImportFromShareableHandle(&h, os_handle, hipMemHandleTypePosixFileDescriptor) != hipSuccess ||
-                    hipMemMap((char*)base + (size_t)got * (size_t)chunk_bytes, (size_t)chunk_bytes, 0, h, 0) != hipSuccess) {
+                void* os_handle = conv == 1 ? (void*)(uintptr_t)fds[i] : (void*)&fds[i];
+                if (hipMemImportFromShareableHandle(&h, os_handle, hipMemHandleTypePosixFileDescriptor) != hipSuccess) {
                     (void)hipGetLastError();
-                    *why = "hipMemImportFromShareableHandle / hipMemMap";
+                    *why = "hipMemImportFromShareableHandle";
                     ok = false;
                 } else {
-                    got++;
+                    if (hipMemMap((char*)base + (size_t)got * (size_t)chunk_bytes, (size_t)chunk_bytes, 0, h, 0) != hipSuccess) {
+                        (void)hipGetLastError();
+                        *why = "hipMemMap";
+                        ok = false;
+                    } else {
+                        got++;
+                    }
+                    if (hipMemRelease(h) != hipSuccess) (void)hipGetLastError();      // (mapped or not: the handle is not needed again)
                 }
             }
             close(fds[i]);
@@ -133,27 +174,26 @@ static void* map_arena_chunks(int pid, int dev, int n_chunks, long long chunk_by
         acc.flags = hipMemAccessFlagsProtReadWrite;
         if (hipMemSetAccess(base, (size_t)n_chunks * (size_t)chunk_bytes, &acc, 1) != hipSuccess) { (void)hipGetLastError(); *why = "hipMemSetAccess"; ok = false; }
     }
-    return ok ? base : nullptr;      // (on failure what was mapped stays mapped: the process falls back to the pipe slots)
-}
-
-static std::string ipc_suffix()
-{
-    const char* ns = getenv("LEGION_IPC_NAMESPACE");
-    return ns ? std::string(ns) : std::string();
+    if (!ok) {
+        unmap_arena_chunks(base, got, n_chunks, chunk_bytes);
+        return nullptr;
+    }
+    return base;
 }
 
 class GPUIPCEnv {
 public:
     int Initialize()
     {
+        opt_ = TrainerOptions::FromEnv();
         int central_device = -1;
         hipGetDevice(&central_device);
         hipCheckError();
         const int physical_device = central_device;
         // LEGION_IPC_DEVICE (testing): attach to the buffers / semaphores of this LOGICAL server GPU while staying on the
         // current physical device (a server with more logical GPUs than the box has, see storage.hip SetGPUDevice)
-        if (const char* e = getenv("LEGION_IPC_DEVICE")) central_device = atoi(e);
-        const std::string shm_name = std::string("simpleIPCshm") + ipc_suffix();
+        if (opt_.ipc_device >= 0) central_device = opt_.ipc_device;
+        const std::string shm_name = std::string("simpleIPCshm") + opt_.suffix;
         int fd = shm_open(shm_name.c_str(), O_RDWR | O_CREAT, 0777);
         if (fd < 0 || ftruncate(fd, sizeof(shmStruct)) != 0) {     // the reference's call; the slab has exactly this size
             printf("Failed to create shared memory slab\n");
@@ -191,8 +231,8 @@ public:
             }
         }
         std::cout << "HIP: " << central_device << " IPC shared memory opened\n";
-        if (!getenv("LEGION_NO_SHM_MIRROR")) {                  // this build's server: counters in host memory (never created here)
-            const std::string ext_name = std::string("legionIPCext") + ipc_suffix();
+        if (opt_.shm_mirror) {                                  // this build's server: counters in host memory (never created here)
+            const std::string ext_name = std::string("legionIPCext") + opt_.suffix;
             const int efd = shm_open(ext_name.c_str(), O_RDWR, 0);
             if (efd >= 0) {
                 void* ea = mmap(0, sizeof(shmExt), PROT_READ | PROT_WRITE, MAP_SHARED, efd, 0);
@@ -204,15 +244,16 @@ public:
         // direct views: open the server's lane arena and say so BEFORE the first sem_post below (the server reads the flag
         // when its first wait returns)
         if (mirror_ != nullptr && mirror_->ext_version >= 3 && mirror_->arena_bytes[central_device] > 0 && mirror_->arena_kind[central_device] == 1 &&
-            !getenv("LEGION_NO_DIRECT_VIEWS")) {
+            opt_.direct_views) {
             int hip_dev = 0;
             (void)hipGetDevice(&hip_dev);
             std::string why;
-            arena_ = map_arena_chunks(mirror_->arena_sock_pid, central_device, mirror_->arena_chunks[central_device],
+            arena_ = map_arena_chunks(opt_.suffix, mirror_->arena_sock_pid, central_device, mirror_->arena_chunks[central_device],
                                       mirror_->arena_chunk_bytes[central_device], hip_dev, &why);
             if (arena_ != nullptr) {
                 arena_bytes_ = mirror_->arena_bytes[central_device];
-                arena_is_chunks_ = true;
+                arena_chunks_ = mirror_->arena_chunks[central_device];
+                arena_chunk_bytes_ = mirror_->arena_chunk_bytes[central_device];
                 mirror_->trainer_direct[central_device] = 1;
                 __sync_synchronize();
                 std::cout << "HIP: " << central_device << " lane arena mapped (" << (arena_bytes_ >> 20) << " MiB in " << mirror_->arena_chunks[central_device]
@@ -220,7 +261,7 @@ public:
             } else {
                 printf("ipc_service: could not map the server's lane arena (%s); batches arrive in the pipe slots\n", why.c_str());
             }
-        } else if (mirror_ != nullptr && mirror_->ext_version >= 2 && mirror_->arena_bytes[central_device] > 0 && !getenv("LEGION_NO_DIRECT_VIEWS")) {
+        } else if (mirror_ != nullptr && mirror_->ext_version >= 2 && mirror_->arena_bytes[central_device] > 0 && opt_.direct_views) {
             hipIpcMemHandle_t h = *(hipIpcMemHandle_t*)&mirror_->arena[central_device];
             hipError_t e = hipIpcOpenMemHandle(&arena_, h, hipIpcMemLazyEnablePeerAccess);
             for (int attempt = 0; e != hipSuccess && attempt < 10; attempt++) {
@@ -241,7 +282,7 @@ public:
         }
         semr_.resize(INTERBATCH_CON);
         semw_.resize(INTERBATCH_CON);
-        const std::string sfx = ipc_suffix();
+        const std::string sfx = opt_.suffix;
         for (int i = 0; i < INTERBATCH_CON; i++) {
             const std::string ssri = "sem_r_" + std::to_string(central_device) + "_" + std::to_string(i) + sfx;
             const std::string sswi = "sem_w_" + std::to_string(central_device) + "_" + std::to_string(i) + sfx;
@@ -302,17 +343,35 @@ public:
     // host-visible counters of the batch in the current pipe slot, or null (then they are copied from the device)
     const volatile int32_t* CounterMirror() const { return mirror_ ? &mirror_->counters[slab_device_][current_pipe_][0] : nullptr; }
 
+    // TB/ipc_cuda_kernel.cu:140-156 closes what it opened; so does this: every IPC handle, the lane arena (a chunked one unmapped
+    // chunk by chunk and its address range given back; a plain one closed), the semaphores, the mirror object -- after which the
+    // object is as new and Initialize() may attach to another server life.  (Round 4 kept the arena mapped "until the process
+    // ends": a trainer that outlived its server kept the server's whole arena alive in HBM.)
     void Finalize()
     {
         std::vector<void*>* slots[MEMORY_USAGE] = {&ids_, &float_features_, &labels_, &agg_src_, &agg_dst_,
                                                    &node_counter_, &edge_counter_};
-        for (int i = 0; i < INTERBATCH_CON; i++) {
-            for (auto* s : slots) hipIpcCloseMemHandle((*s)[i]);
+        (void)hipDeviceSynchronize();                      // nothing of this process still reads a view or a slot buffer
+        for (int i = 0; i < (int)semw_.size(); i++) {
+            for (auto* s : slots)
+                if ((*s)[i] != nullptr && hipIpcCloseMemHandle((*s)[i]) != hipSuccess) (void)hipGetLastError();
             if (sem_close(semw_[i]) == -1) std::cout << "close sem " << i << " failed\n";
             sem_close(semr_[i]);
         }
-        if (arena_ != nullptr && !arena_is_chunks_ && getenv("LEGION_IPC_CLOSE_ARENA")) hipIpcCloseMemHandle(arena_);
+        for (auto* s : slots) s->clear();
+        semw_.clear();
+        semr_.clear();
+        if (arena_ != nullptr) {
+            if (arena_chunks_ > 0) unmap_arena_chunks(arena_, arena_chunks_, arena_chunks_, arena_chunk_bytes_);
+            else if (hipIpcCloseMemHandle(arena_) != hipSuccess) (void)hipGetLastError();
+        }
         arena_ = nullptr;
+        arena_bytes_ = 0;
+        arena_chunks_ = 0;
+        arena_chunk_bytes_ = 0;
+        if (mirror_ != nullptr) munmap((void*)mirror_, sizeof(shmExt));
+        mirror_ = nullptr;
+        current_pipe_ = 0;
     }
 
 private:
@@ -325,7 +384,9 @@ private:
     volatile shmExt* mirror_ = nullptr;
     void* arena_ = nullptr;          // the server's lane arena, opened (direct views), or null
     long long arena_bytes_ = 0;
-    bool arena_is_chunks_ = false;   // mapped from file descriptors (stays mapped until the process ends)
+    int arena_chunks_ = 0;           // > 0: mapped from that many file descriptors of arena_chunk_bytes_ each
+    long long arena_chunk_bytes_ = 0;
+    TrainerOptions opt_;
 };
 
 static GPUIPCEnv* env = nullptr;
@@ -354,6 +415,10 @@ static long long whole_buffer(void* p, size_t elem)
 
 void InitializeIPC()
 {
+    if (env != nullptr) {
+        printf("ipc_service: initialize() while attached; call finalize() first\n");
+        exit(EXIT_FAILURE);
+    }
     env = new GPUIPCEnv();
     env->Initialize();
 }
@@ -367,8 +432,15 @@ void FinalizeIPC()
     arena_i32 = torch::Tensor();
     arena_f32 = torch::Tensor();
     arena_ready = false;
+    if (env == nullptr) return;
     env->Finalize();
+    delete env;
+    env = nullptr;
 }
+
+// 0: hipMemImportFromShareableHandle of this process's HIP runtime takes a pointer to the descriptor, 1: the descriptor's value,
+// -1: neither worked (no chunked arenas: batches arrive in the pipe slots).  Exposed for the tests.
+int VmmFdConvention() { return vmm_fd_convention(); }
 
 // training_backend/ipc_cuda_kernel.cu:177-235 + training_backend/ipc_service.cpp:44-59
 std::vector<torch::Tensor> get_next(int feature_dim)
@@ -461,4 +533,5 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m)
     m.def("initialize", &InitializeIPC, "InitializeIPC (HIP)");
     m.def("finalize", &FinalizeIPC, "FinalizeIPC (HIP)");
     m.def("synchronize", &Synchronize, "synchronize (HIP)");
+    m.def("vmm_fd_convention", &VmmFdConvention, "how this process's HIP runtime takes a file-descriptor handle (this build only)");
 }

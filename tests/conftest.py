@@ -45,17 +45,14 @@ def hip():
     return L
 
 
-@pytest.fixture(params=["direct", "table", "lds", "lds-16-buckets"])
-def dedup(request, monkeypatch):
-    """Runs a GPU test once per form of the first-touch state (legion_core.h): the direct uint32[N] array, the compact
-    open-addressing table, and the LDS form (no per-vertex state) -- the latter with the small class's 8 and with its 16
-    hash buckets per lane (LegionTuning.lds_small_buckets; classes of larger hops have 64 / 256 either way).  All must give
-    bit-identical batches.  Returns the form's name as MemoryPool.dedup_form() reports it."""
-    form = request.param.split("-")[0]
-    monkeypatch.setenv("LEGION_DEDUP", form)
-    if request.param.endswith("16-buckets"):
-        monkeypatch.setenv("LEGION_LDS_SMALL_BUCKETS", "16")
-    return form
+@pytest.fixture(params=["8", "16"], ids=["8-buckets", "16-buckets"])
+def buckets(request, monkeypatch):
+    """Runs a GPU test with the small class's 8 and with its 16 hash buckets per lane (LegionTuning.lds_small_buckets; pools of
+    larger hops have 64 / 256 either way): how many (lane, bucket) workgroups de-duplicate a hop must not change a batch.
+    (Rounds 1-4 ran these tests over three forms of the first-touch state -- a uint32[N] array, an open-addressing table, the LDS
+    form; since round 5 the LDS form is the only one.)"""
+    monkeypatch.setenv("LEGION_LDS_SMALL_BUCKETS", request.param)
+    return int(request.param)
 
 
 @pytest.fixture(params=["0", "1"], ids=["no-column-slots", "column-slots"])

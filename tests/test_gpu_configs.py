@@ -180,13 +180,11 @@ def test_refill_and_second_cache_with_column_slots(hip, monkeypatch):
 
 
 @pytest.mark.parametrize("D", [7, 100, 602])
-@pytest.mark.parametrize("pitch", ["dense", "aligned"])
-def test_feature_cache_row_pitch(hip, monkeypatch, col_slots, D, pitch):
-    """LegionTuning.feature_pitch: rows of the HBM-resident feature cache (stripes and replica) dense, or padded to whole
-    128-byte lines.  Outputs are dense and byte-identical either way (SS/cache/cache_impl.cuh:259-268 fixes the values, not
-    the cache's layout); D = 7 (28-byte rows, scalar path), 100 (products: 400 bytes), 602 (2408 bytes, unaligned 16-byte
-    chunks + tail)."""
-    monkeypatch.setenv("LEGION_FEATURE_PITCH", pitch)
+def test_feature_cache_row_widths_in_a_striped_clique(hip, col_slots, D):
+    """Rows of the HBM-resident feature cache (own stripe, the other member's stripe, a hot-row replica) at widths that are not
+    whole 128-byte lines: D = 7 (28-byte rows, scalar path), 100 (products: 400 bytes), 602 (2408 bytes, unaligned 16-byte chunks
+    + tail); byte-identical with the oracle (SS/cache/cache_impl.cuh:259-268)."""
+    pitch = "dense"
     wl = Workload(scale=11, edge_factor=8, dim=D, partition_count=2, n_seeds=1200)
     fanout, batch = [5, 4], 64
     gpu, cpu = GpuSide(wl, batch, fanout), CpuSide(wl, batch, fanout)

@@ -43,7 +43,7 @@ def _last_json(text):
 def test_scale_command_line_two_ranks_on_one_gpu(hip, stripe):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo",
-           "--force-device", "0"] + SMALL + (["--stripe", "--no-overlap-leg"] if stripe else [])
+           "--force-device", "0"] + SMALL + (["--stripe"] if stripe else [])
     res = subprocess.run(cmd, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
     assert res.returncode == 0, res.stderr[-4000:]
     d = _last_json(res.stdout)
@@ -51,7 +51,6 @@ def test_scale_command_line_two_ranks_on_one_gpu(hip, stripe):
     assert d["roofline"]["frac"] > 0 and d["roofline"]["launches"] == 2
     assert ("striped" in d["config"]["parallelism"]) == stripe
     assert "cpu_baseline" not in d                      # N = 1 only
-    assert (d["overlapped"] is None) == stripe and (stripe or d["overlapped"]["value"] > 0)
     # the line is its own evidence of what ran on how many ranks: the world size as an all-reduce of
     # ones saw it, the one collective of the path timed, and what every rank measured for itself
     col = d["collective"]

@@ -18,10 +18,10 @@ pytestmark = pytest.mark.gpu
     (13, 8, [10, 10], 1024, 256),
     (10, 2, [1, 1, 1, 1], 32, 6),
 ])
-def test_serve_batches_no_cache(hip, dedup, scale, ef, fanout, batch, dim):
+def test_serve_batches_no_cache(hip, buckets, scale, ef, fanout, batch, dim):
     wl = Workload(scale=scale, edge_factor=ef, dim=dim)
     gpu, cpu = GpuSide(wl, batch, fanout), CpuSide(wl, batch, fanout)
-    assert gpu.pools[0].dedup_form() == dedup
+    assert gpu.pools[0].lds_buckets() == buckets
     n_train = wl.sets[(0, 0)][0].size
     for mode, counters in ((0, range(min(3, (n_train - 1) // batch))), (1, range(2)), (2, range(1))):
         bs = batch if mode == 0 else min(batch, 100)
@@ -33,7 +33,7 @@ def test_serve_batches_no_cache(hip, dedup, scale, ef, fanout, batch, dim):
     gpu.close(); cpu.close()
 
 
-def test_partial_last_batch_and_empty(hip, dedup):
+def test_partial_last_batch_and_empty(hip, buckets):
     wl = Workload(scale=9, edge_factor=8, dim=8, n_seeds=100, n_valid=37, n_test=5)
     gpu, cpu = GpuSide(wl, 16, [4, 3]), CpuSide(wl, 16, [4, 3])
     for counter in (1, 2, 3):       # 37 ids, batch 16: full, partial (5, read at the reference's quirky offset), empty
@@ -44,7 +44,7 @@ def test_partial_last_batch_and_empty(hip, dedup):
 
 @pytest.mark.parametrize("P,mode_bits,capacity", [(1, 0, (300, 200)), (2, 1, (150, 90)), (4, 2, (64, 33)),
                                                   (4, 1, (100, 50)), (8, 3, (40, 20)), (3, 0, (77, 10))])
-def test_presc_cache_build_and_serve(hip, dedup, col_slots, P, mode_bits, capacity):
+def test_presc_cache_build_and_serve(hip, buckets, col_slots, P, mode_bits, capacity):
     """PreSC epoch -> hotness -> order -> maps/fills -> serving with hits, on P logical GPUs striped
     over cliques of 2^mode_bits (logical GPUs share the physical one on a 1-GPU box).  Once with the gather looking every
     row's cache slot up in node_map, once with the slots carried from the sampler (column slots): identical."""
@@ -191,39 +191,15 @@ def test_pipeline_lanes_in_a_scattered_arena(hip, monkeypatch, chunk_mb):
     gpu.close(); cpu.close()
 
 
-def test_overlap_probe_leaves_the_pipeline_usable(hip):
-    """`legion_pipeline_probe_overlap` (bench.py --probe-overlap) launches the last hop's kernels of one group stage by
-    stage beside the gathers of another: it must return six positive times, put the stage mask back to "everything" and leave
-    the pipeline producing the oracle's batches."""
-    import ctypes
-    from legion_amd import engine
-    wl = Workload(scale=11, edge_factor=8, dim=32, n_seeds=700)
-    fanout, batch, group = [6, 3], 64, 3
-    gpu, cpu = GpuSide(wl, batch, fanout), CpuSide(wl, batch, fanout)
-    pipe = engine.Pipeline(gpu.graph, gpu.feature, gpu.cache, 0, batch, fanout, group, gpu.pools[0].num_ids, True, 2, weave=True)
-    out = (ctypes.c_double * 6)()
-    for prep, side in ((1, 6), (3, 4), (1, 2)):
-        assert pipe._lib.legion_pipeline_probe_overlap(pipe.handle, 0, 0, out, prep, side) == 1
-        assert all(v > 0 for v in out), list(out)
-    for gi in range(2):
-        sl = pipe.submit(gi * group, 0)
-        pipe.wait(sl)
-        for lane in range(group):
-            compare_batches(engine.read_batch(pipe.pools[sl][lane]), cpu.run(0, gi * group + lane, 0), f"after the probe, batch {gi * group + lane}: ")
-    pipe.close()
-    gpu.close(); cpu.close()
-
-
-@pytest.mark.parametrize("group,slots,use_graph,split", [(1, 1, True, False), (3, 2, True, False), (4, 2, False, False),
-                                                         (2, 3, True, False), (8, 2, True, False), (3, 2, True, True),
-                                                         (4, 2, False, True), (2, 3, True, True), (1, 1, True, True),
-                                                         (3, 2, True, "weave"), (4, 2, False, "weave"), (2, 3, True, "weave"),
-                                                         (1, 1, True, "weave"), (8, 2, True, "weave")])
-def test_pipeline_groups_and_graph_replay(hip, dedup, group, slots, use_graph, split):
+@pytest.mark.parametrize("group,slots,use_graph,weave", [(1, 1, True, False), (3, 2, True, False), (4, 2, False, False),
+                                                         (2, 3, True, False), (8, 2, True, False),
+                                                         (3, 2, True, True), (4, 2, False, True), (2, 3, True, True),
+                                                         (1, 1, True, True), (8, 2, True, True)])
+def test_pipeline_groups_and_graph_replay(hip, buckets, group, slots, use_graph, weave):
     """Grouped launches (grid.y = lanes) + hipGraph replay produce exactly the batches the one-lane
     eager path does: every batch of a short run -- including the clamped last batch and the empty
     batches past the end of the set, whose sizes are computed on the device -- is compared with the
-    oracle.  split = sampler phase and gather phase as two graphs on two streams."""
+    oracle.  weave = the head of a group (seeds + every hop but the last) and its rest as two graphs on two streams."""
     from legion_amd import engine
     wl = Workload(scale=11, edge_factor=8, dim=32, n_seeds=700)
     fanout, batch = [6, 3], 64
@@ -236,7 +212,7 @@ def test_pipeline_groups_and_graph_replay(hip, dedup, group, slots, use_graph, s
     gpu.cache.fill_up(gpu.feature, gpu.graph)
     cpu.build_cache(0, capacity=(150, 80))
     pipe = engine.Pipeline(gpu.graph, gpu.feature, gpu.cache, 0, batch, fanout, group, gpu.pools[0].num_ids, use_graph, slots,
-                           split=split is True, weave=split == "weave")
+                           weave=weave)
     n_batches = (wl.sets[(0, 0)][0].size + batch - 1) // batch     # the last one is partial
     n_groups = (n_batches + group - 1) // group                    # the last group may reach past the set
     for rep in range(2):                                          # the second epoch re-positions the device iteration
@@ -264,7 +240,7 @@ def test_pipeline_groups_and_graph_replay(hip, dedup, group, slots, use_graph, s
 @pytest.mark.parametrize("batch,fanout,group", [(1024, [25, 10], 128), (2000, [15, 10, 5], 16)])
 def test_full_width_groups_against_the_oracle(hip, batch, fanout, group):
     """The headline's own geometry -- B = 1024, [25,10], lane groups wide enough to keep every XCD busy, the weave arrangement
-    under hipGraph replay, the default (LDS) form -- with EVERY lane of two consecutive groups compared with the oracle: the
+    under hipGraph replay -- with EVERY lane of two consecutive groups compared with the oracle: the
     ticketed tiles and the decoupled look-back of compact_kernel, the winners' published positions and the software-pipelined
     gather under the concurrency they run with in the bench (250 super tiles per lane at hop 2, 128 lanes in flight).  The
     second shape has three hops in the 64-bucket class (staged placement, known lists across two hops)."""
@@ -278,7 +254,6 @@ def test_full_width_groups_against_the_oracle(hip, batch, fanout, group):
     gpu.cache.fill_up(gpu.feature, gpu.graph)
     cpu.build_cache(0, capacity=(20_000, 2_000))
     pipe = engine.Pipeline(gpu.graph, gpu.feature, gpu.cache, 0, batch, fanout, group, gpu.pools[0].num_ids, True, 2, weave=True)
-    assert pipe.pools[0][0].dedup_form() == "lds"
     slots = [pipe.submit(0, 0), pipe.submit(group, 0)]
     for gi, sl in enumerate(slots):
         pipe.wait(sl)
@@ -289,7 +264,7 @@ def test_full_width_groups_against_the_oracle(hip, batch, fanout, group):
     gpu.close(); cpu.close()
 
 
-def test_lane_group_eager(hip, dedup):
+def test_lane_group_eager(hip, buckets):
     """legion_enqueue_group on caller-owned pools (no pipeline, no graph)."""
     from legion_amd import engine
     wl = Workload(scale=10, edge_factor=8, dim=16, n_seeds=400)
@@ -308,49 +283,6 @@ def test_lane_group_eager(hip, dedup):
     for p in pools:
         p.close()
     gpu.close(); cpu.close()
-
-
-def test_epoch_wrap_of_position_state(hip, dedup, monkeypatch):
-    """The position state is never cleared between batches (epoch tag); with 8 epoch bits (23 value bits,
-    forced here: a pool this small would get 15 epoch bits) the end-of-batch kernel refills it after 254
-    batches on one lane.  600 consecutive batches (two wraps) stay bit-exact, eager and under graph replay."""
-    from legion_amd import engine
-    monkeypatch.setenv("LEGION_POS_VALUE_BITS", "23")
-    wl = Workload(scale=9, edge_factor=8, dim=4, n_seeds=512)
-    fanout, batch = [3, 2], 8
-    gpu, cpu = GpuSide(wl, batch, fanout), CpuSide(wl, batch, fanout)
-    n_batches = 600
-    for it in range(n_batches):
-        c = it % 60
-        if it % 37 == 0 or it > n_batches - 5 or 250 <= it <= 260 or 505 <= it <= 515:
-            compare_batches(gpu.run(0, c, 0), cpu.run(0, c, 0), f"eager batch {it}: ")
-        else:
-            engine.enqueue_batch(None, gpu.graph, gpu.feature, gpu.cache, gpu.pools[0], batch, c, 0, 0, False, fanout)
-    pipe = engine.Pipeline(gpu.graph, gpu.feature, gpu.cache, 0, batch, fanout, 2, gpu.pools[0].num_ids, True, 1)
-    for gi in range(300):                     # 300 replays per lane: crosses the wrap inside the graph
-        c0 = (gi % 30) * 2
-        sl = pipe.submit(c0, 0)
-        if gi % 41 == 0 or 120 <= gi <= 130 or gi > 295:
-            pipe.wait(sl)
-            for lane in range(2):
-                compare_batches(engine.read_batch(pipe.pools[sl][lane]), cpu.run(0, c0 + lane, 0), f"replay {gi} lane {lane}: ")
-    pipe.close()
-    gpu.close(); cpu.close()
-
-
-def test_wide_position_format(hip, dedup, monkeypatch):
-    """Pools whose worst-case slot count needs more than 23 value bits switch to a wider value field
-    and a shorter epoch field (28 bits -> 6 epochs between refills).  Forced here through
-    LEGION_POS_VALUE_BITS on a small pool: 40 batches cross the refill six times and stay bit-exact."""
-    from legion_amd import engine
-    for bits in ("27", "28"):
-        monkeypatch.setenv("LEGION_POS_VALUE_BITS", bits)
-        wl = Workload(scale=9, edge_factor=8, dim=4, n_seeds=512)
-        fanout, batch = [3, 2, 2], 8
-        gpu, cpu = GpuSide(wl, batch, fanout), CpuSide(wl, batch, fanout)
-        for it in range(40):
-            compare_batches(gpu.run(0, it % 60, 0), cpu.run(0, it % 60, 0), f"vb={bits} batch {it}: ")
-        gpu.close(); cpu.close()
 
 
 @pytest.mark.parametrize("P,mode_bits,capacity,replica_rows", [(4, 2, (64, 33), 40), (8, 3, (40, 20), 100), (2, 1, (150, 90), 10_000)])
@@ -411,7 +343,6 @@ def test_lds_small_class_picks_16_buckets_on_a_dense_graph(hip, monkeypatch):
     buckets take in one pass) gets 16 buckets, the same shape on a sparse graph 8 -- and both serve what the oracle serves."""
     from legion_amd import engine
     from oracle import ffi
-    monkeypatch.setenv("LEGION_DEDUP", "lds")
     monkeypatch.delenv("LEGION_LDS_SMALL_BUCKETS", raising=False)
     fanout, batch = [25, 10], 512                                   # hop 2: up to 128 k slots per lane
     for scale, ef, want in ((14, 64, 16), (16, 2, 8)):              # mean degree 64: nearly every slot valid; 2: few are
@@ -428,7 +359,7 @@ def test_lds_small_class_picks_16_buckets_on_a_dense_graph(hip, monkeypatch):
         gpu.cache.fill_up(gpu.feature, gpu.graph)
         cpu.build_cache(0, capacity=(64, 8))
         pipe = engine.Pipeline(gpu.graph, gpu.feature, gpu.cache, 0, batch, fanout, 2, ffi.num_ids_for(batch, fanout), True, 2)
-        assert pipe.pools[0][0].dedup_form() == "lds" and pipe.pools[0][0].lds_buckets() == want
+        assert pipe.pools[0][0].lds_buckets() == want
         slot = pipe.submit(0)
         pipe.wait(slot)
         for lane in range(2):
@@ -440,11 +371,9 @@ def test_lds_dedup_multi_pass_buckets(hip, monkeypatch):
     """The LDS form when a bucket's vertices do not fit its table: batches of up to ~100 k claims per lane make every
     (lane, bucket) workgroup run 2-4 passes over sub-buckets; still bit-exact, no error raised.  Also a graph with hubs
     sampled thousands of times in one batch (every duplicate lands in the same bucket)."""
-    monkeypatch.setenv("LEGION_DEDUP", "lds")
     wl = Workload(scale=15, edge_factor=16, dim=4, n_seeds=9000)
     fanout, batch = [10, 10], 2000                         # hop 2: up to 200 k slots per lane
     gpu, cpu = GpuSide(wl, batch, fanout), CpuSide(wl, batch, fanout)
-    assert gpu.pools[0].dedup_form() == "lds"
     for it in range(3):
         g, c = gpu.run(0, it, 0), cpu.run(0, it, 0)
         compare_batches(g, c, f"multi-pass lds batch {it}: ")
@@ -471,8 +400,8 @@ def test_lds_dedup_skewed_sub_bucket(hip, monkeypatch):
     same low 10 bits, so the passes the kernel plans from the claim count (sub-buckets by hash bits 3, 4) all land in one
     sub-bucket of ~11 k distinct vertices -- more than the 8192-word table.  The kernel notices the failed insert and redoes
     the bucket with more passes until the sub-buckets fit: bit-exact, no error (this used to raise
-    LG_ERR_TABLE_FULL and leave garbage positions)."""
-    monkeypatch.setenv("LEGION_DEDUP", "lds")
+    LG_ERR_TABLE_FULL and leave garbage positions).  The hops here have <= 61 440 slots: this is the retry path of
+    dedup_lists_kernel (the barrier behind `passes <<= 1`) -- one template for all four bucket classes since round 5."""
     N = 1 << 24
     x = np.arange(N, dtype=np.uint32)
     x ^= x >> np.uint32(16); x *= np.uint32(0x7feb352d); x ^= x >> np.uint32(15); x *= np.uint32(0x846ca68b); x ^= x >> np.uint32(16)
@@ -488,32 +417,10 @@ def test_lds_dedup_skewed_sub_bucket(hip, monkeypatch):
     wl.sets[(0, 0)] = (np.ascontiguousarray(seeds), np.ascontiguousarray(wl.labels_all[seeds]))
     fanout, batch = [20, 3], 1024
     gpu, cpu = GpuSide(wl, batch, fanout), CpuSide(wl, batch, fanout)
-    assert gpu.pools[0].dedup_form() == "lds"
     for it in range(2):
         g, c = gpu.run(0, it, 0), cpu.run(0, it, 0)
         compare_batches(g, c, f"skewed sub-bucket batch {it}: ")
         assert int(g["node_counter"][10] - g["node_counter"][9]) > 8192          # hop 1 alone adds more vertices than a table holds
-    assert gpu.pools[0].error() == 0
-    gpu.close(); cpu.close()
-
-
-@pytest.mark.parametrize("buckets", ["8", "16"])
-@pytest.mark.parametrize("claim_cap", [None, "3"], ids=["lists", "lists-overflow"])
-def test_lds_dedup_one_workgroup_per_lane(hip, monkeypatch, claim_cap, buckets):
-    """LDS form, small hops: one de-duplication workgroup per lane takes the lane's buckets in turn, the next bucket's loads
-    requested before the current one's table work (large launch groups only by default: forced here).  Three hops, so that
-    the known lists and -- with 2 claims per thread in registers -- buckets that are not resident take part."""
-    monkeypatch.setenv("LEGION_DEDUP", "lds")
-    monkeypatch.setenv("LEGION_LDS_ONE_WG_LANES", "1")
-    monkeypatch.setenv("LEGION_LDS_SMALL_BUCKETS", buckets)
-    if claim_cap is not None:
-        monkeypatch.setenv("LEGION_LDS_CLAIM_CAP", claim_cap)
-    wl = Workload(scale=13, edge_factor=8, dim=4, n_seeds=2000)
-    fanout, batch = [6, 5, 4], 200                 # hops of 1200 / 6000 / 24000 slots: all below the one-workgroup limit; hop 3 has
-    gpu, cpu = GpuSide(wl, batch, fanout), CpuSide(wl, batch, fanout)      # ~2.5 k claims per bucket of 8 (> 2 per thread)
-    assert gpu.pools[0].dedup_form() == "lds"
-    for it in range(4):
-        compare_batches(gpu.run(0, it, 0), cpu.run(0, it, 0), f"one workgroup per lane (cap {claim_cap}, {buckets} buckets) batch {it}: ")
     assert gpu.pools[0].error() == 0
     gpu.close(); cpu.close()
 
@@ -523,13 +430,11 @@ def test_lds_dedup_known_lists(hip, monkeypatch, known_cap):
     """LDS form, three hops: hops 2 and 3 recognise the nodes hops 1 and 2 added through the per-bucket lists scatter
     appends to.  A list that outgrows its capacity is not used (that bucket's workgroup scans sampled_ids instead):
     forced for every bucket (capacity 1) and for some of them (capacity 80 against ~75 nodes per bucket)."""
-    monkeypatch.setenv("LEGION_DEDUP", "lds")
     if known_cap is not None:
         monkeypatch.setenv("LEGION_LDS_KNOWN_CAP", known_cap)
     wl = Workload(scale=12, edge_factor=8, dim=4, n_seeds=600)
     fanout, batch = [4, 3, 3], 48
     gpu, cpu = GpuSide(wl, batch, fanout), CpuSide(wl, batch, fanout)
-    assert gpu.pools[0].dedup_form() == "lds"
     for it in range(6):
         compare_batches(gpu.run(0, it, 0), cpu.run(0, it, 0), f"known lists ({known_cap}) batch {it}: ")
     assert gpu.pools[0].error() == 0
@@ -543,7 +448,6 @@ def test_lds_dedup_claim_lists_overflow(hip, monkeypatch, claim_cap, buckets):
     cannot take all of its bucket's claims says so by its count, and that bucket's workgroup reads the hop's slots instead:
     forced for every bucket (capacity 1), for some of them (capacity 40 against ~45 claims per bucket of hop 2), and -- on a
     batch whose buckets need several passes over the table -- with the slots walked once per sweep and pass."""
-    monkeypatch.setenv("LEGION_DEDUP", "lds")
     monkeypatch.setenv("LEGION_LDS_CLAIM_CAP", claim_cap)
     monkeypatch.setenv("LEGION_LDS_SMALL_BUCKETS", buckets)
     if claim_cap == "700":
@@ -553,7 +457,6 @@ def test_lds_dedup_claim_lists_overflow(hip, monkeypatch, claim_cap, buckets):
         wl = Workload(scale=12, edge_factor=8, dim=4, n_seeds=600)
         fanout, batch, n_it = [4, 3, 3], 48, 6
     gpu, cpu = GpuSide(wl, batch, fanout), CpuSide(wl, batch, fanout)
-    assert gpu.pools[0].dedup_form() == "lds"
     for it in range(n_it):
         compare_batches(gpu.run(0, it, 0), cpu.run(0, it, 0), f"claim lists (cap {claim_cap}, {buckets} buckets) batch {it}: ")
     assert gpu.pools[0].error() == 0
@@ -564,45 +467,63 @@ def test_lds_dedup_claim_lists_overflow(hip, monkeypatch, claim_cap, buckets):
 @pytest.mark.parametrize("batch,fanout", [(6000, [10, 10]), (5000, [5, 5, 5]), (6000, [10, 10, 8]), (8000, [13, 13, 13])],
                          ids=["b6000-10x10-64buckets", "b5000-5x5x5-64buckets", "b6000-10x10x8-256buckets", "b8000-13x13x13-17Mslots"])
 def test_lds_dedup_large_batches(hip, monkeypatch, batch, fanout, part_wg):
-    """LDS form for hops of more than 2^19 slots per lane (Legion's default B = 8000 class): 64 buckets per lane and
-    partition tiles of 8 super tiles up to 2^22 slots, 256 buckets and 32 super tiles beyond (here 4.8 M and 17.6 M slots); the
-    sampling kernel places the pairs in a second sweep; bit-exact like the 8-bucket form."""
-    monkeypatch.setenv("LEGION_DEDUP", "lds")
-    if part_wg is not None:                              # partition tiles of 8 / 32 super tiles, or as few as the hop allows
+    """Hops of more than 2^19 slots per lane (Legion's default B = 8000 class): 64 buckets per lane up to 2^22 slots, 256 beyond
+    (here 4.8 M and 17.6 M slots).  The sampling kernel samples partition tiles of 1-8 super tiles and reserves, per bucket, a run
+    of the bucket's claim list; place_kernel stages the tile's pairs in LDS and writes the runs; bit-exact like the 8-bucket class."""
+    if part_wg is not None:                              # partition tiles of 8 super tiles, or as few as the class allows
         monkeypatch.setenv("LEGION_LDS_PART_WG", part_wg)
     wl = Workload(scale=16, edge_factor=16, dim=4, n_seeds=3 * batch + 17)
     gpu, cpu = GpuSide(wl, batch, fanout), CpuSide(wl, batch, fanout)
-    assert gpu.pools[0].dedup_form() == "lds" and gpu.pools[0].state_bytes() > (1 << 19) * 8
+    assert gpu.pools[0].lds_buckets() in (64, 256) and gpu.pools[0].state_bytes() > (1 << 19) * 8
     for it in range(4):                                  # the last batch is the clamped one
         compare_batches(gpu.run(0, it, 0), cpu.run(0, it, 0), f"large lds batch {it}: ")
     assert gpu.pools[0].error() == 0
     gpu.close(); cpu.close()
 
 
-def test_crowded_position_table(hip, monkeypatch):
-    """The compact table under pressure: forced down to 2^10 words for batches of up to ~950 distinct vertices
-    (load up to 0.93), so that claims walk long probe runs and displaced words are carried far.  Still bit-exact,
-    no error raised; with a table smaller than a batch the kernels raise LG_ERR_TABLE_FULL instead of hanging."""
-    monkeypatch.setenv("LEGION_DEDUP", "table")
-    monkeypatch.setenv("LEGION_POS_TABLE_BITS", "10")
-    wl = Workload(scale=14, edge_factor=8, dim=4, n_seeds=3000)
-    fanout, batch = [5, 3], 160
+@pytest.mark.parametrize("batch,fanout,claim_cap,known_cap", [(6000, [10, 10], "1", None), (6000, [10, 10], "2500", None),
+                                                              (5000, [5, 5, 5], "1500", "1"), (6000, [10, 10, 8], "1", None),
+                                                              (6000, [10, 10, 8], "6000", "900")],
+                         ids=["64buckets-no-room", "64buckets-some-overflow", "64buckets-3hops-known-scan", "256buckets-no-room",
+                              "256buckets-some-overflow"])
+def test_lds_dedup_large_batches_list_overflow(hip, monkeypatch, batch, fanout, claim_cap, known_cap):
+    """64- / 256-bucket classes (round 5: one claim list per bucket here too, written by place_kernel into the runs the sampling
+    kernel reserved): a list that cannot take all of its bucket's claims says so by its count and that bucket's workgroup reads
+    the hop's slots instead -- forced for every bucket (capacity 1) and for some (a capacity near the buckets' mean); a known
+    list that outgrew its capacity makes its bucket's workgroup scan sampled_ids."""
+    monkeypatch.setenv("LEGION_LDS_CLAIM_CAP", claim_cap)
+    if known_cap is not None:
+        monkeypatch.setenv("LEGION_LDS_KNOWN_CAP", known_cap)
+    wl = Workload(scale=16, edge_factor=16, dim=4, n_seeds=2 * batch + 17)
     gpu, cpu = GpuSide(wl, batch, fanout), CpuSide(wl, batch, fanout)
-    assert gpu.pools[0].uses_table() and gpu.pools[0].state_bytes() == 1024 * 8
-    most = 0
-    for it in range(12):
-        g, c = gpu.run(0, it, 0), cpu.run(0, it, 0)
-        compare_batches(g, c, f"crowded table batch {it}: ")
-        most = max(most, g["sampled_ids"].size)
-    assert 850 < most < 1024 and gpu.pools[0].error() == 0
+    assert gpu.pools[0].lds_buckets() in (64, 256)
+    for it in range(3):                                  # the last batch is the clamped one
+        compare_batches(gpu.run(0, it, 0), cpu.run(0, it, 0), f"large batch, list caps {claim_cap} / {known_cap}, batch {it}: ")
+    assert gpu.pools[0].error() == 0
     gpu.close(); cpu.close()
-    monkeypatch.setenv("LEGION_POS_TABLE_BITS", "9")             # 512 words < a batch's vertices
-    gpu = GpuSide(wl, batch, fanout)
+
+
+def test_graph_cache_keeps_modes_and_lane_counts_apart(hip):
+    """the hipGraph cache of a pipeline slot used to pack (mode << 40 | active lanes << 32 | batch) into one
+    word -- written when groups had at most 128 lanes.  With up to 512 lanes, (mode 0, 256 + 3 lanes) and (mode 1, 3 lanes) of
+    one batch size met on the same key: the graph captured for the training group was replayed for the validation group (wrong
+    seed set, wrong grid).  Both groups, same slot, same batch size: each must serve what the oracle serves."""
     from legion_amd import engine
-    engine.enqueue_batch(None, gpu.graph, gpu.feature, gpu.cache, gpu.pools[0], batch, 0, 0, 0, False, fanout)
-    torch.cuda.synchronize()
-    assert gpu.pools[0].error() & 1
-    gpu.close()
+    wl = Workload(scale=11, edge_factor=8, dim=4, n_seeds=1700, n_valid=200)
+    fanout, batch, G = [3, 2], 6, 260
+    gpu, cpu = GpuSide(wl, batch, fanout), CpuSide(wl, batch, fanout)
+    pipe = engine.Pipeline(gpu.graph, gpu.feature, gpu.cache, 0, batch, fanout, G, gpu.pools[0].num_ids, True, 1)
+    slot = pipe.submit(0, 0, 259)                        # captures (train, 259 lanes)
+    pipe.wait(slot)
+    for lane in (0, 3, 258):
+        compare_batches(engine.read_batch(pipe.pools[slot][lane]), cpu.run(0, lane, 0), f"train group lane {lane}: ")
+    slot2 = pipe.submit(0, 1, 3)                         # (valid, 3 lanes): a graph of its own
+    assert slot2 == slot
+    pipe.wait(slot2)
+    for lane in range(3):
+        compare_batches(engine.read_batch(pipe.pools[slot][lane]), cpu.run(0, lane, 1), f"validation group lane {lane}: ")
+    pipe.close()
+    gpu.close(); cpu.close()
 
 
 def test_pipeline_partial_group(hip):

@@ -17,23 +17,24 @@ def _restore():
 
 
 def test_defaults_and_environment(monkeypatch):
-    for k in ("LEGION_DEDUP", "LEGION_POS_TABLE_BITS", "LEGION_RUNNER_LANES", "LEGION_LINK_COUNTERS", "LEGION_NO_SHM_MIRROR",
-              "LEGION_TABLE_PLACEMENT", "LEGION_RUNNER_HO_STREAM", "LEGION_GATHER_ROWS"):
+    for k in ("LEGION_LDS_SMALL_BUCKETS", "LEGION_RUNNER_LANES", "LEGION_LINK_COUNTERS", "LEGION_NO_SHM_MIRROR", "LEGION_RUNNER_HANDOVER",
+              "LEGION_TABLE_PLACEMENT", "LEGION_RUNNER_HO_STREAM", "LEGION_GATHER_ROWS", "LEGION_RUNNER_SPIN_US"):
         monkeypatch.delenv(k, raising=False)
     engine.tuning_from_env()
     t = engine.tuning()
-    assert t["dedup_form"] == -1 and t["lds_part_wg"] == 8192 and t["sample_max_wg"] == 4096 and t["runner_graph"] == 1
+    assert t["lds_small_buckets"] == 0 and t["lds_part_wg"] == 8192 and t["sample_max_wg"] == 4096 and t["runner_graph"] == 1
     assert t["runner_ho_stream"] == 2 and t["shm_mirror"] == 1 and t["link_counters"] == 0 and t["table_placement"] == 0
-    assert t["gather_rows_per_wg"] == 0 and t["gather_small_tiles"] == 1 and t["col_slots"] == -1
-    monkeypatch.setenv("LEGION_DEDUP", "table")
-    monkeypatch.setenv("LEGION_POS_TABLE_BITS", "10")
+    assert t["gather_rows_per_wg"] == 0 and t["col_slots"] == -1 and t["runner_spin_us"] == -1 and t["runner_handover"] == 0
+    assert len(t) <= 26                                         # (the struct had grown to 38 switches)
+    monkeypatch.setenv("LEGION_LDS_SMALL_BUCKETS", "16")
+    monkeypatch.setenv("LEGION_RUNNER_HANDOVER", "gather")
     monkeypatch.setenv("LEGION_RUNNER_LANES", "3")
     monkeypatch.setenv("LEGION_LINK_COUNTERS", "123,45")
     monkeypatch.setenv("LEGION_NO_SHM_MIRROR", "1")
     monkeypatch.setenv("LEGION_TABLE_PLACEMENT", "pinned")
     engine.tuning_from_env()
     t = engine.tuning()
-    assert (t["dedup_form"], t["pos_table_bits"], t["runner_lanes"], t["shm_mirror"], t["table_placement"]) == (1, 10, 3, 0, 1)
+    assert (t["lds_small_buckets"], t["runner_handover"], t["runner_lanes"], t["shm_mirror"], t["table_placement"]) == (16, 1, 3, 0, 1)
     assert t["link_counters"] == 3 and t["link_counter_values"] == [123, 45]
     for word, code in (("v2", 0), ("measured", 1), ("smi", 2)):
         monkeypatch.setenv("LEGION_LINK_COUNTERS", word)
@@ -42,15 +43,15 @@ def test_defaults_and_environment(monkeypatch):
 
 
 def test_programmatic_values_survive_until_the_environment_is_asked_again(monkeypatch):
-    monkeypatch.delenv("LEGION_DEDUP", raising=False)
+    monkeypatch.delenv("LEGION_LDS_SMALL_BUCKETS", raising=False)
     engine.tuning_from_env()
-    engine.set_tuning(dedup_form=2, runner_lanes=7)
+    engine.set_tuning(lds_small_buckets=16, runner_lanes=7)
     t = engine.tuning()
-    assert t["dedup_form"] == 2 and t["runner_lanes"] == 7 and t["lds_part_wg"] == 8192     # the rest untouched
-    monkeypatch.setenv("LEGION_DEDUP", "direct")
-    assert engine.tuning()["dedup_form"] == 2                   # installed values are kept ...
+    assert t["lds_small_buckets"] == 16 and t["runner_lanes"] == 7 and t["lds_part_wg"] == 8192     # the rest untouched
+    monkeypatch.setenv("LEGION_LDS_SMALL_BUCKETS", "8")
+    assert engine.tuning()["lds_small_buckets"] == 16           # installed values are kept ...
     engine.tuning_from_env()
-    assert engine.tuning()["dedup_form"] == 0                   # ... until the environment is asked for explicitly
+    assert engine.tuning()["lds_small_buckets"] == 8            # ... until the environment is asked for explicitly
 
 
 def test_struct_mirror_matches_the_header():

@@ -7,7 +7,7 @@ OUT=$R/gpurun_out/prof_$RND
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 # 1. the bench line as the driver runs it, and at its defaults
-timeout -k 5 600 python3 $R/bench.py --gpus 1 --steps 20 --warmup 5 --boundary-modes views,slab,copy 2> $OUT/bench_driver_args.err < /dev/null | tail -1 > $OUT/bench_driver_args.json
+timeout -k 5 600 python3 $R/bench.py --gpus 1 --steps 20 --warmup 5 2> $OUT/bench_driver_args.err < /dev/null | tail -1 > $OUT/bench_driver_args.json
 timeout -k 5 600 python3 $R/bench.py 2> $OUT/bench_default.err < /dev/null | tail -1 > $OUT/bench_default.json
 # 2. rocprofv3 --kernel-trace --stats of the same command (no boundary leg: that is another process)
 rm -rf /tmp/prof_stats

@@ -32,17 +32,16 @@ def main():
                     help="do not write the `features` file: the server then serves a zero-filled table of the same shape (v2 of the "
                          "reference reads no features either, storage_management.cu:162); a 34 GB file is too slow to write for a "
                          "throughput run at RMAT-26, the traffic is the same")
-    ap.add_argument("--handover", type=str, default="", choices=["", "auto", "copy", "gather"],
+    ap.add_argument("--handover", type=str, default="", choices=["", "auto", "gather"],
                     help="LEGION_RUNNER_HANDOVER for the server (default: whatever the environment says, i.e. auto)")
     ap.add_argument("--no-views", action="store_true",
                     help="the consumer does not take batches as views of the server's lane arena (a trainer end that knows only the "
                          "reference's slab): LEGION_NO_DIRECT_VIEWS=1 for the python consumer, no `views` flag for the native one")
     ap.add_argument("--modes", type=str, default="",
-                    help="comma list of views|slab|gather|copy: one server run per (mode, batch size) over the same data set files.  views = "
+                    help="comma list of views|slab|gather: one server run per (mode, batch size) over the same data set files.  views = "
                          "server as it starts by default + a consumer that takes views of the lane arena; slab = the same server + a "
                          "consumer that opens only the reference's slab (the server then gathers each batch into the pipe slot); gather = "
-                         "LEGION_RUNNER_HANDOVER=gather (that hand-over for everybody, no arena); copy = LEGION_RUNNER_HANDOVER=copy (whole "
-                         "groups + one copy launch per batch); overrides --handover / --no-views")
+                         "LEGION_RUNNER_HANDOVER=gather (that hand-over for everybody, no arena); overrides --handover / --no-views")
     ap.add_argument("--min-timed-batches", type=int, default=0,
                     help="run as many epochs as it takes for the timed window to hold at least this many batches (views mode hands "
                          "over 100 k+ batches/s: a single epoch of a few thousand batches is a window of milliseconds)")
@@ -86,7 +85,7 @@ def main():
     try:
         for mode in (a.modes.split(",") if a.modes else [""]):
             if mode:
-                a.handover = mode if mode in ("gather", "copy") else "auto"
+                a.handover = mode if mode == "gather" else "auto"
                 a.no_views = mode != "views"
                 os.environ.pop("LEGION_NO_DIRECT_VIEWS", None)
             for b in batches:

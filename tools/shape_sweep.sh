@@ -7,8 +7,8 @@ import json, sys
 try:
     d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
     print(sys.argv[2], "value %.3f G edges/s" % (d["value"] / 1e9), "ms/step %.4f" % d["ms_per_step"], "batches/step", d["batches_per_step"],
-          "gather frac %.3f" % d["roofline"]["frac"], "overlapped %.3f G" % (d["overlapped"]["value"] / 1e9 if d.get("overlapped") else 0),
-          "sampler-only %.2f G" % (d["sampling_only"]["edges_per_sec"] / 1e9), d["position_state"]["form"], d["position_state"].get("lds_buckets_per_lane"))
+          "gather frac %.3f" % d["roofline"]["frac"],
+          "sampler-only %.2f G" % (d["sampling_only"]["edges_per_sec"] / 1e9), "buckets", d["first_touch_state"].get("lds_buckets_per_lane"))
 except Exception as e:
     print(sys.argv[2], "FAILED", e)
 PY
