@@ -30,6 +30,7 @@ import ctypes
 import json
 import os
 import signal
+import subprocess
 import sys
 import threading
 import time
@@ -214,6 +215,10 @@ def parse_args():
     ap.add_argument("--no-boundary", action="store_true",
                     help="skip the drop-in boundary leg (sampling_server binary -> shm/semaphores/IPC handles -> ipc_service "
                          "consumer on an RMAT-22 data set written in the reference's file formats; N = 1 only, ~15 s)")
+    ap.add_argument("--no-traffic-leg", action="store_true",
+                    help="skip the measurement of roofline.traffic in this run (two fresh child processes of this command under "
+                         "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, N = 1 only; also skipped with --no-boundary)")
+    ap.add_argument("--traffic-deadline", type=int, default=300, help="seconds each of those child processes may take")
     ap.add_argument("--boundary-modes", type=str, default="views,slab",
                     help="boundary leg: hand-overs to measure, one server run per mode and batch size (tools/server_throughput.py --modes: "
                          "views | slab | gather | copy); tools/profile_round.sh adds copy")
@@ -389,6 +394,8 @@ def main():
             if args.cpu_seconds > 0 and world == 1:      # reported at N = 1 only
                 out["cpu_baseline"] = cpu_baseline(indptr, col, c.mine, N, B, c.fanout, c.n_warm, args.cpu_seconds,
                                                    features if args.placement == "hbm" else None)
+            if world == 1 and not args.no_boundary and not args.no_traffic_leg and args.placement == "hbm":
+                measured_traffic(args, out["roofline"], c.G)
         except Exception as e:      # (an armed exit hook must not outlive the interpreter: see above)
             import traceback
             traceback.print_exc()
@@ -797,9 +804,10 @@ def run_leg(c, engine, synth, stripe, replica_memory, headline, bulk=False):
         roof = {"bound": "hbm", "kernel": "lg::gather_kernel<..., LASTOP = true> (hop-%d gather, op %d: the instance launched for a batch's last op)" % (H, last_op),
                 "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_unit": "bytes per launch",
-                "traffic_source": traffic_src,
-                "traffic_is": "the committed PMC figure of this kernel on this configuration rescaled by this run's rows -- a claim about the "
-                              "kernel, not a measurement of this run (counters cannot be read while timing)",
+                "traffic_source": traffic_src, "traffic_committed_source": traffic_src,
+                "traffic_is": "`traffic` = the committed PMC figure of this kernel on this configuration rescaled by this run's rows (a claim "
+                              "about the kernel; counters cannot be read while timing); `traffic_measured` (N = 1, when the traffic leg ran) "
+                              "= the same two counters collected by child processes of THIS run",
                 "rocprofv3_avg_launch_us": rocprof_us, "rocprofv3_source": rocprof_src,
                 "algorithmic_bytes_per_launch": rows_last / max(n_last, 1) * bytes_per_row,
                 "bytes_per_row": bytes_per_row, "rows_per_launch": rows_last / max(n_last, 1),
@@ -921,7 +929,7 @@ def boundary_leg(args, fanout):
     # how a batch reaches the trainer end (LegionTuning.runner_handover, server.hip): `views` -- whole launch groups into the
     # server's lane arena, this build's ipc_service takes every batch as views of its lane: what a user of legion_graphsage.py
     # gets; `slab` -- the same server with a trainer end that opens only the reference's slab: one gather launch per batch
-    # straight into the pipe slot (round 3's path); `copy` -- whole groups + one copy launch per batch (the measured alternative)
+    # straight into the pipe slot (round 3's path; the COMPATIBILITY path, not the fast one)
     cmd = [sys.executable, os.path.join(ROOT, "tools", "server_throughput.py"), "--scale", str(scale), "--edge-factor", str(args.edge_factor),
            "--batch", ",".join(str(b) for b in batches), "--dim", str(args.dim), "--fanout", ",".join(str(f) for f in fanout),
            "--train-batches", str(max(64, min(3072, (3 << 20) // args.batch))), "--no-features-file", "--cache-memory", str(args.cache_memory),
@@ -931,24 +939,119 @@ def boundary_leg(args, fanout):
         lines = [json.loads(ln) for ln in res.stdout.splitlines() if ln.startswith("{")]
         if not lines:
             raise RuntimeError(res.stderr[-300:])
-        legs = [{"mode": r.get("mode"), "batch": r["batch"], "batches_per_sec": r["batches_per_sec"], "edges_per_sec": r["edges_per_sec"],
-                 "handover": r.get("handover"), "path": r["path"], "workload": r["workload"], "ms_per_batch": r["ms_per_batch"],
-                 "timed_batches": r["timed_batches"], "epochs": r.get("epochs")} for r in lines]
+        def leg_of(r):
+            return {"mode": r.get("mode"), "batch": r["batch"], "batches_per_sec": r["batches_per_sec"], "edges_per_sec": r["edges_per_sec"],
+                    "handover": r.get("handover"), "path": r["path"], "workload": r["workload"], "ms_per_batch": r["ms_per_batch"],
+                    "timed_batches": r["timed_batches"], "epochs": r.get("epochs"), "server_cpu_cores": r.get("server_cpu_cores")}
+        legs = [leg_of(r) for r in lines]
+        # ... and once more with a consumer that READS every batch it is handed (one launch per get_next over the rows and the
+        # outermost COO pair, completed before the batch is released): the protocol-only figure above is a rate of hand-overs
+        # nobody looks at; this one shares the HBM with the server's gathers like a training loop's first layer would
+        consuming = None
+        try:
+            i = cmd.index("--modes")
+            cmd2 = cmd[:i] + ["--modes", "views"] + cmd[i + 2:]
+            i = cmd2.index("--min-timed-batches")
+            cmd2[i + 1] = str(max(2000, args.boundary_batches // 4))
+            res2 = subprocess.run(cmd2 + ["--consume"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+            l2 = [json.loads(ln) for ln in res2.stdout.splitlines() if ln.startswith("{")]
+            if not l2:
+                raise RuntimeError(res2.stderr[-300:])
+            consuming = {"by_batch_size": [leg_of(r) for r in l2],
+                         "note": "views hand-over with a trainer end that reads every batch: legion_consume_batch (one launch: every float of "
+                                 "the rows + the outermost COO pair) and a stream synchronise before each synchronize(), as the protocol "
+                                 "demands of a consumer that reads in place; the consumer's reads share the HBM with the server's gathers "
+                                 "(+ rows x D x 4 bytes of traffic per batch), and at B = 1024 its per-batch launch + synchronise "
+                                 "(~10 us of host time) exceeds the 6.3 us the server needs per batch"}
+        except Exception as e:
+            consuming = {"error": repr(e)[:300]}
         first = legs[0]
         out = {"boundary_batches_per_sec": first["batches_per_sec"], "boundary_edges_per_sec": first["edges_per_sec"],
                "boundary": {"path": first["path"], "workload": first["workload"], "ms_per_batch": first["ms_per_batch"],
                             "timed_batches": first["timed_batches"], "handover": first["handover"],
+                            "what_it_measures": "the hand-over protocol with a consumer that never reads a row (zero-filled feature table of the "
+                                                "right shape): the rate at which batches CAN be taken; `consuming_trainer` reads them",
                             "by_batch_size": [l for l in legs if l["mode"] == "views"],
-                            "slab_only_trainer": {"note": "a trainer end that opens only the reference's slab (no views of the lane arena): the batch "
-                                                          "is gathered (`slab`: what the server does by itself for such a trainer end) or copied "
-                                                          "(`copy`: LEGION_RUNNER_HANDOVER=copy) into the pipe slot by one launch per batch, two "
-                                                          "slots in flight",
+                            "consuming_trainer": consuming,
+                            "slab_only_trainer": {"note": "the COMPATIBILITY path: a trainer end that opens only the reference's slab (a build of "
+                                                          "TB/ipc_cuda_kernel.cu; no views of the lane arena) gets every batch gathered into the "
+                                                          "pipe slot by one launch, two slots in flight -- bound by the launch -> completion -> "
+                                                          "semaphore round trip per batch, not by the GPU",
                                                   "by_batch_size": [l for l in legs if l["mode"] != "views"]}}}
         if note:
             out["boundary"]["note"] = note
         return out
     except Exception as e:            # the headline must not depend on this leg
         return {"boundary_batches_per_sec": None, "boundary": {"error": repr(e)[:300]}}
+
+
+def measured_traffic(args, roof, G):
+    """roofline.traffic MEASURED in this run: two fresh child processes of this very command -- started as
+    children, never an exec of this process -- under `rocprofv3 --kernel-trace --pmc FETCH_SIZE` and `... WRITE_SIZE` (separate
+    passes, counters beside the kernel trace only, the interpreter binary directly behind `--`: MI355X_MICROARCH.md, HBM), two
+    timed steps each on the same workload and group size; folded as tools/pmc_summary.py folds the committed profile (both
+    counters KiB; FETCH_SIZE doubled: gfx950 tallies the 128-byte requests of a 16-byte-per-lane stream at 64 B).  Adds
+    traffic_measured / traffic_over_algorithmic / traffic_source to `roof`; the committed figure stays beside it as the
+    cross-check.  A child that fails or hangs costs only these fields."""
+    import csv
+    import glob
+    import shutil
+    import tempfile
+    prof = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
+    if prof is None:
+        roof["traffic_measured"], roof["traffic_measured_note"] = None, "rocprofv3 not found on this box"
+        return
+    t0 = time.time()
+    shape = ["--scale", str(args.scale), "--edge-factor", str(args.edge_factor), "--dim", str(args.dim), "--batch", str(args.batch),
+             "--fanout", args.fanout, "--group", str(G), "--cache-memory", str(args.cache_memory)]
+    if args.nodes > 0:
+        shape += ["--nodes", str(args.nodes), "--edges", str(args.edges)]
+    if args.scramble:
+        shape += ["--scramble"]
+    child = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--presc-steps", "64", "--cpu-seconds", "0",
+             "--no-verify", "--no-boundary", "--min-seconds", "0.01"] + shape
+    got, rows_child, note = {}, None, None
+    tmp = tempfile.mkdtemp(prefix="legion_pmc_", dir="/tmp")
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = os.path.join(tmp, counter)
+            os.makedirs(d)
+            cmd = [prof, "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", d, "--"] + child
+            try:
+                res = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                                     stdin=subprocess.DEVNULL, text=True, timeout=args.traffic_deadline)
+            except subprocess.TimeoutExpired:
+                note = f"the {counter} pass did not finish within {args.traffic_deadline} s"
+                break
+            lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+            files = glob.glob(d + "/*/*counter_collection.csv") + glob.glob(d + "/*counter_collection.csv")
+            if res.returncode != 0 or not lines or not files:
+                note = f"the {counter} pass failed (rc {res.returncode}): {res.stderr[-300:]}"
+                break
+            rows_child = json.loads(lines[-1])["roofline"]["rows_per_launch"]
+            sel = [r for r in csv.DictReader(open(files[0])) if r["Counter_Name"] == counter and "gather_kernel" in r["Kernel_Name"] and
+                   r["Kernel_Name"][:r["Kernel_Name"].rfind("(")].rstrip().endswith("true>")]
+            if not sel:
+                note = f"no launch of the last-hop gather in the {counter} pass"
+                break
+            full = max(int(r["Grid_Size"]) for r in sel)                       # launches over a full group
+            vals = [float(r["Counter_Value"]) for r in sel if int(r["Grid_Size"]) == full]
+            got[counter] = (sum(vals) / len(vals), len(vals))
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    if note is not None or len(got) != 2 or not rows_child:
+        roof["traffic_measured"], roof["traffic_measured_note"] = None, note or "incomplete"
+        return
+    read_b, write_b = 2 * got["FETCH_SIZE"][0] * 1024, got["WRITE_SIZE"][0] * 1024
+    alg = rows_child * roof["bytes_per_row"]
+    roof["traffic_measured"] = read_b + write_b
+    roof["traffic_measured_read_bytes"], roof["traffic_measured_write_bytes"] = read_b, write_b
+    roof["traffic_over_algorithmic"] = (read_b + write_b) / alg
+    roof["traffic_source"] = "this run"
+    roof["traffic_measured_note"] = ("bytes per launch of the last hop's gather over a full group, averaged over %d / %d launches of two child "
+                                     "processes of this command under rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (%d rows per launch there; "
+                                     "FETCH_SIZE doubled per the guide's gfx950 correction, both KiB); %.0f s" %
+                                     (got["FETCH_SIZE"][1], got["WRITE_SIZE"][1], rows_child, time.time() - t0))
 
 
 def cpu_baseline(indptr, col, seeds, N, B, fanout, first_batch, target_s, features=None):

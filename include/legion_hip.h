@@ -355,6 +355,12 @@ void legion_synth_feature_check(legion_stream_t stream, const float* rows, const
                                 int64_t num_rows, int32_t dim, uint64_t seed,
                                 unsigned long long* mismatch_count_devptr);
 
+/* Measurement aid (no reference counterpart): one launch that loads every float of a batch's feature rows and every entry of its
+ * two COO arrays and folds them into *acc_devptr -- a trainer-side consumer that really reads its batches
+ * (tools/server_throughput.py --consume, bench.py's boundary.consuming_trainer). */
+void legion_consume_batch(legion_stream_t stream, const float* feats, int64_t n_floats, const int32_t* src, const int32_t* dst,
+                          int64_t n_edges, double* acc_devptr);
+
 /* Spill-over tier: mapped pinned host memory (what the reference uses for the full CSR / feature table,
  * SS/storage/storage_management.cu:106-107,161).  Returns the pointer the GPU dereferences; *host_ptr_out
  * is the host-side address to fill and to pass to legion_host_free. */

@@ -275,7 +275,12 @@ void UnifiedCache::CandidateSelection(int cache_agg_mode, FeatureStorage* featur
         // ends up with the sum, in place, and the leader sorts its own copy.  Possible when every member lives in this
         // process on a physical GPU of its own (the reference's deployment: one server, a thread per GPU); logical GPUs that
         // share a device (tests on one GPU) cannot form a communicator and keep the reference's leader loop.
+        // (the all-reduce writes the sums into scratch arrays, not over the members' counters -- a second
+        // CandidateSelection over the same counters (another cache_agg_mode, a re-fill after more presampling) then sums the
+        // counters again, not sums of sums -- and an RCCL failure in `auto` falls back to the leader loop instead of ending the
+        // process.)
         bool reduced = world_reduced;
+        unsigned long long* summed[2] = {nullptr, nullptr};       // the leader's copy of the clique sums (RCCL path), else null
         if (!world_reduced) {
             std::vector<int32_t> devs;
             for (int32_t j = 0; j < Kg; j++)
@@ -286,37 +291,59 @@ void UnifiedCache::CandidateSelection(int cache_agg_mode, FeatureStorage* featur
                 printf("legion_hip: LEGION_HOTNESS_REDUCE=rccl, but the %d members of clique %d do not sit on %d distinct GPUs of this process\n", Kg, i, Kg);
                 exit(EXIT_FAILURE);
             }
+            bool rccl_ok = false;
             if (how == 1 || (how == -1 && distinct && Kg > 1)) {
                 double ms = 0;
-                for (int which = 0; which < 2; which++) {
-                    std::vector<unsigned long long*> bufs;
-                    for (int32_t d : devs)
-                        bufs.push_back(which == 0 ? cache_controller_[d]->GetNodeAccessedMap() : cache_controller_[d]->GetEdgeAccessedMap());
-                    ms += lg::allreduce_u64_clique(devs, bufs, N);
+                rccl_ok = true;
+                for (int which = 0; which < 2 && rccl_ok; which++) {
+                    std::vector<unsigned long long*> send, recv;
+                    for (int32_t d : devs) {
+                        SetGPUDevice(d);
+                        send.push_back(which == 0 ? cache_controller_[d]->GetNodeAccessedMap() : cache_controller_[d]->GetEdgeAccessedMap());
+                        recv.push_back((unsigned long long*)d_alloc_space((int64_t)N * sizeof(unsigned long long)));
+                    }
+                    const double t = lg::allreduce_u64_clique(devs, send, recv, N);
+                    rccl_ok = t >= 0;
+                    ms += rccl_ok ? t : 0;
+                    for (size_t j = 0; j < devs.size(); j++) {
+                        SetGPUDevice(devs[j]);
+                        if (rccl_ok && devs[j] == lead) summed[which] = recv[j];
+                        else d_free_space(recv[j]);
+                    }
                 }
-                std::cout << "Hotness reduce on clique " << i << ": RCCL all-reduce (ncclUint64, ncclSum) over " << Kg << " GPU" << (Kg > 1 ? "s" : "")
-                          << ", 2 x " << N << " x 8 bytes per GPU, " << ms << " ms\n";
-                hotness_reduce_path_[i] = 2;
-                hotness_reduce_ms_ += ms;
-                reduced = true;
-            } else if (Kg > 1) {
+                if (!rccl_ok) {
+                    for (int which = 0; which < 2; which++) { if (summed[which]) { SetGPUDevice(lead); d_free_space(summed[which]); summed[which] = nullptr; } }
+                    if (how == 1) { printf("legion_hip: LEGION_HOTNESS_REDUCE=rccl and RCCL failed\n"); exit(EXIT_FAILURE); }
+                    std::cout << "Hotness reduce on clique " << i << ": RCCL refused; falling back to the leader loop over peer pointers\n";
+                } else {
+                    std::cout << "Hotness reduce on clique " << i << ": RCCL all-reduce (ncclUint64, ncclSum) over " << Kg << " GPU" << (Kg > 1 ? "s" : "")
+                              << ", 2 x " << N << " x 8 bytes per GPU, " << ms << " ms\n";
+                    hotness_reduce_path_[i] = 2;
+                    hotness_reduce_ms_ += ms;
+                    reduced = true;
+                }
+            }
+            if (!rccl_ok && Kg > 1) {
                 std::cout << "Hotness reduce on clique " << i << ": leader loop over peer pointers ("
-                          << (all_local ? "its logical GPUs share physical devices" : "members in other processes") << ")\n";
+                          << (all_local ? (distinct ? "RCCL unavailable" : "its logical GPUs share physical devices") : "members in other processes") << ")\n";
                 hotness_reduce_path_[i] = 1;
             }
         }
         SetGPUDevice(lead);
         for (int which = 0; which < 2; which++) {     // 0: node hotness -> QF/AF, 1: edge hotness -> QT/AT
             int32_t* order = (int32_t*)d_alloc_space((int64_t)N * sizeof(int32_t));
-            unsigned long long* agg = (unsigned long long*)d_alloc_space((int64_t)N * sizeof(unsigned long long));
-            HIP_CALL(hipMemset(agg, 0, (size_t)N * sizeof(unsigned long long)));
-            // aggregate_access on the leader reading each member's counters (peer loads over xGMI).
-            // When the counters were already all-reduced across processes (RCCL), every member
-            // holds the clique sum: take the leader's copy once.
-            for (int32_t j = 0; j < Kg; j++) {
-                if (reduced ? (i * Kg + j != lead) : !lg_is_local(i * Kg + j)) continue;
-                CacheController* cc = cache_controller_[i * Kg + j];
-                lg::aggregate_access(nullptr, agg, which == 0 ? cc->GetNodeAccessedMap() : cc->GetEdgeAccessedMap(), N);
+            unsigned long long* agg = summed[which];
+            if (agg == nullptr) {
+                agg = (unsigned long long*)d_alloc_space((int64_t)N * sizeof(unsigned long long));
+                HIP_CALL(hipMemset(agg, 0, (size_t)N * sizeof(unsigned long long)));
+                // aggregate_access on the leader reading each member's counters (peer loads over xGMI).
+                // When the counters were already all-reduced across processes (RCCL), every member
+                // holds the clique sum: take the leader's copy once.
+                for (int32_t j = 0; j < Kg; j++) {
+                    if (reduced ? (i * Kg + j != lead) : !lg_is_local(i * Kg + j)) continue;
+                    CacheController* cc = cache_controller_[i * Kg + j];
+                    lg::aggregate_access(nullptr, agg, which == 0 ? cc->GetNodeAccessedMap() : cc->GetEdgeAccessedMap(), N);
+                }
             }
             lg::sort_hotness_desc(nullptr, agg, order, N);
             if (which == 0) { QF_.push_back(order); AF_.push_back(agg); }

@@ -71,17 +71,30 @@ bool clique_is_physical(const std::vector<int32_t>& devs)
     return true;
 }
 
-// In-place all-reduce (sum) of `count` uint64 over the members of a clique that live in THIS process: bufs[j] is member
-// devs[j]'s array on its own GPU.  Called from one host thread (group call).  Returns the milliseconds it took.
-double allreduce_u64_clique(const std::vector<int32_t>& devs, const std::vector<unsigned long long*>& bufs, int64_t count)
+// All-reduce (sum) of `count` uint64 over the members of a clique that live in THIS process: send[j] is member devs[j]'s array
+// on its own GPU, recv[j] where that member receives the sum (recv[j] == send[j]: in place).  Called from one host thread (group
+// call).  Returns the milliseconds it took, or -1 when RCCL refused (communicator or call): the caller decides whether another
+// way to form the sum exists (UnifiedCache::CandidateSelection falls back to the reference's leader loop in `auto`).
+double allreduce_u64_clique(const std::vector<int32_t>& devs, const std::vector<unsigned long long*>& send,
+                            const std::vector<unsigned long long*>& recv, int64_t count)
 {
+#define RCCL_SOFT(expr)                                                                       \
+    {                                                                                         \
+        ncclResult_t r_ = (expr);                                                             \
+        if (r_ != ncclSuccess) {                                                              \
+            printf("RCCL failure %s:%d: '%s'\n", __FILE__, __LINE__, ncclGetErrorString(r_)); \
+            fflush(stdout);                                                                   \
+            return -1.0;                                                                      \
+        }                                                                                     \
+    }
     std::vector<int> phys;
     for (int32_t d : devs) phys.push_back(lg_physical_device(d));
     std::lock_guard<std::mutex> lk(g_mu);
     CliqueComm& cc = g_cliques[phys];
     if (cc.comms.empty()) {
-        cc.comms.resize(phys.size());
-        RCCL_CALL(ncclCommInitAll(cc.comms.data(), (int)phys.size(), phys.data()));
+        std::vector<ncclComm_t> comms(phys.size());
+        RCCL_SOFT(ncclCommInitAll(comms.data(), (int)phys.size(), phys.data()));
+        cc.comms = comms;
         cc.streams.resize(phys.size());
         for (size_t j = 0; j < phys.size(); j++) {
             SetGPUDevice(devs[j]);
@@ -93,17 +106,18 @@ double allreduce_u64_clique(const std::vector<int32_t>& devs, const std::vector<
         HIP_CALL(hipDeviceSynchronize());
     }
     const auto t0 = std::chrono::steady_clock::now();
-    RCCL_CALL(ncclGroupStart());
+    RCCL_SOFT(ncclGroupStart());
     for (size_t j = 0; j < devs.size(); j++) {
         SetGPUDevice(devs[j]);
-        RCCL_CALL(ncclAllReduce(bufs[j], bufs[j], (size_t)count, ncclUint64, ncclSum, cc.comms[j], cc.streams[j]));
+        RCCL_SOFT(ncclAllReduce(send[j], recv[j], (size_t)count, ncclUint64, ncclSum, cc.comms[j], cc.streams[j]));
     }
-    RCCL_CALL(ncclGroupEnd());
+    RCCL_SOFT(ncclGroupEnd());
     for (size_t j = 0; j < devs.size(); j++) {
         SetGPUDevice(devs[j]);
         HIP_CALL(hipStreamSynchronize(cc.streams[j]));
     }
     return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+#undef RCCL_SOFT
 }
 
 }  // namespace lg

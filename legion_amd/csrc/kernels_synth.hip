@@ -126,3 +126,37 @@ extern "C" void legion_synth_feature_check(legion_stream_t stream, const float* 
                                                                                       mismatch_count_devptr);
     hipCheckError();
 }
+
+// ---- measurement aid: a consumer that READS what it is handed --------------------------------------------------------
+// One launch per mini-batch: every float of the feature rows and every entry of the two COO arrays is loaded and folded into a
+// device accumulator (what the first layer of a GNN does to a batch at the very least).  tools/server_throughput.py --consume
+// launches it per get_next, so that the boundary figure is a rate with the batch actually read on the trainer's side, not a
+// rate of hand-overs nobody looks at.
+namespace lg {
+__global__ __launch_bounds__(256) void consume_batch_kernel(const float* __restrict__ feats, int64_t n_floats, const int32_t* __restrict__ a,
+                                                           const int32_t* __restrict__ b, int64_t n_edges, double* __restrict__ acc)
+{
+    typedef float v4 __attribute__((ext_vector_type(4)));
+    const int64_t stride = (int64_t)gridDim.x * 256, t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    float s = 0.f;
+    long long e = 0;
+    const int64_t q = ((reinterpret_cast<uintptr_t>(feats) & 15) == 0) ? n_floats >> 2 : 0;
+    for (int64_t i = t; i < q; i += stride) { const v4 v = reinterpret_cast<const v4*>(feats)[i]; s += (v.x + v.y) + (v.z + v.w); }
+    for (int64_t i = (q << 2) + t; i < n_floats; i += stride) s += feats[i];
+    for (int64_t i = t; i < n_edges; i += stride) e += (long long)a[i] + b[i];
+    double w = (double)s + (double)e;
+    for (int off = 32; off > 0; off >>= 1) w += __shfl_down(w, off);
+    if ((threadIdx.x & 63) == 0 && w != 0.0) atomicAdd(acc, w);
+}
+}  // namespace lg
+
+extern "C" void legion_consume_batch(legion_stream_t stream, const float* feats, int64_t n_floats, const int32_t* src, const int32_t* dst,
+                                     int64_t n_edges, double* acc_devptr)
+{
+    if (acc_devptr == nullptr || (n_floats <= 0 && n_edges <= 0)) return;
+    int64_t grid = (n_floats / 4 + n_edges + 1023) / 1024;
+    if (grid > 2048) grid = 2048;
+    if (grid < 1) grid = 1;
+    lg::consume_batch_kernel<<<(int32_t)grid, 256, 0, static_cast<hipStream_t>(stream)>>>(feats, n_floats, src, dst, n_edges, acc_devptr);
+    hipCheckError();
+}

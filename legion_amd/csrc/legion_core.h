@@ -781,7 +781,8 @@ private:
 
 // the hotness all-reduce (collective.hip): RCCL over the members of a clique that live in this process
 bool clique_is_physical(const std::vector<int32_t>& devs);
-double allreduce_u64_clique(const std::vector<int32_t>& devs, const std::vector<unsigned long long*>& bufs, int64_t count);
+double allreduce_u64_clique(const std::vector<int32_t>& devs, const std::vector<unsigned long long*>& send,
+                            const std::vector<unsigned long long*>& recv, int64_t count);
 
 // set-up kernels (kernels_cache.hip)
 void aggregate_access(hipStream_t s, unsigned long long* agg, const unsigned long long* add, int32_t n);

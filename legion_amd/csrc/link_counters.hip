@@ -47,7 +47,7 @@ bool rsmi_ready()
     // RTLD_DEEPBIND: the library must resolve its OWN symbols first.  This process also holds libamd_smi (a dependency of RCCL),
     // which carries the same rocm_smi C++ classes under the same names; bound to those, rsmi_* calls corrupted the heap
     // ("corrupted size vs. prev_size" at exit, tools/smi_probe.py)
-    const int flags = RTLD_NOW | RTLD_LOCAL | (getenv("LEGION_SMI_NO_DEEPBIND") ? 0 : RTLD_DEEPBIND);
+    const int flags = RTLD_NOW | RTLD_LOCAL | RTLD_DEEPBIND;
     g_rsmi.h = dlopen("librocm_smi64.so.1", flags);
     if (!g_rsmi.h) g_rsmi.h = dlopen("librocm_smi64.so", flags);
     if (!g_rsmi.h) return false;
@@ -140,8 +140,6 @@ extern "C" int32_t legion_link_counters_from(int32_t dev_id, int32_t source, Leg
 {
     if (!out) return 0;
     memset(out, 0, sizeof(*out));
-    if (source == 0)
-        if (const char* e = getenv("LEGION_LINK_SOURCE")) source = atoi(e);      // deployment override: 1 library only, 2 byte offsets only
     int count = 0;
     if (hipGetDeviceCount(&count) != hipSuccess || count < 1) return 0;
     char bdf[64] = {0};

@@ -20,6 +20,7 @@
 #include "legion_core.h"
 
 #include <algorithm>
+#include <chrono>
 #include <cstring>
 #include <map>
 #include <tuple>
@@ -50,6 +51,7 @@ struct Slot {
     LegionLaneGroup* group = nullptr;
     hipStream_t stream = nullptr;
     hipEvent_t done = nullptr;
+    hipEvent_t done_blocking = nullptr;       // recorded with `done`; created with hipEventBlockingSync: a host thread that waits for it sleeps
     hipEvent_t sampled = nullptr;             // weave: the group's head has finished
     bool busy = false;
     std::map<std::tuple<int32_t, int32_t, int32_t, int32_t>, hipGraphExec_t> exec;   // key: (phase, mode, active lanes, batch_size)
@@ -189,6 +191,7 @@ extern "C" LegionPipeline* legion_pipeline_create(LegionGraphStorage* graph, Leg
         else
             sl.stream = p->slots[0].stream;
         HIP_CALL(hipEventCreateWithFlags(&sl.done, hipEventDisableTiming));
+        HIP_CALL(hipEventCreateWithFlags(&sl.done_blocking, hipEventDisableTiming | hipEventBlockingSync));
         HIP_CALL(hipEventCreateWithFlags(&sl.sampled, hipEventDisableTiming));
     }
     lg_set_pool_claims_hint(0, 0);
@@ -360,6 +363,7 @@ extern "C" int32_t legion_pipeline_submit_ex(LegionPipeline* p, int32_t counter0
             sl.next_iter = n_active == p->group_size ? counter0 + p->group_size * p->slots_n : -1;
         }
         HIP_CALL(hipEventRecord(sl.done, X));
+        HIP_CALL(hipEventRecord(sl.done_blocking, X));
         sl.busy = true;
         return si;
     }
@@ -383,6 +387,7 @@ extern "C" int32_t legion_pipeline_submit_ex(LegionPipeline* p, int32_t counter0
         sl.next_iter = n_active == p->group_size ? counter0 + p->group_size * p->slots_n : -1;
     }
     HIP_CALL(hipEventRecord(sl.done, sl.stream));
+    HIP_CALL(hipEventRecord(sl.done_blocking, sl.stream));
     sl.busy = true;
     return si;
 }
@@ -395,6 +400,28 @@ extern "C" void legion_pipeline_wait(LegionPipeline* p, int32_t slot)
     for (Slot& sl : p->slots) slot_wait(p, sl);
 }
 
+// The same for a host thread that has nothing else to do until the group is complete (GPURunner handing batches over as views: a
+// group completes every few ms): poll for at most spin_us microseconds, then SLEEP until the completion interrupt
+// (hipEventSynchronize on an event created with hipEventBlockingSync) instead of burning a core in the runtime's own spin.
+extern "C" void legion_pipeline_wait_sleeping(LegionPipeline* p, int32_t slot, int32_t spin_us)
+{
+    if (!p) return;
+    SetGPUDevice(p->dev_id);
+    Slot& sl = p->slots[slot % p->slots_n];
+    if (sl.busy) {
+        const auto t0 = std::chrono::steady_clock::now();
+        hipError_t q = hipEventQuery(sl.done);
+        while (q == hipErrorNotReady && std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() < spin_us) q = hipEventQuery(sl.done);
+        if (q == hipErrorNotReady) {
+            (void)hipGetLastError();
+            HIP_CALL(hipEventSynchronize(sl.done_blocking));
+        } else if (q != hipSuccess) {
+            HIP_CALL(q);
+        }
+    }
+    slot_wait(p, sl);       // (complete by now: returns at once, collects the profile)
+}
+
 extern "C" LegionMemoryPool* legion_pipeline_pool(LegionPipeline* p, int32_t slot, int32_t lane)
 {
     if (!p) return nullptr;
@@ -404,13 +431,6 @@ extern "C" LegionMemoryPool* legion_pipeline_pool(LegionPipeline* p, int32_t slo
 // weave arrangement: whether the groups submitted (and the graphs prepared) from now on include their gathers.  GPURunner
 // switches them off when the trainer end it serves gets its rows gathered batch by batch straight into a pipe slot.
 extern "C" void legion_pipeline_set_gathers(LegionPipeline* p, int32_t on) { if (p) p->gathers = on != 0; }
-
-// device address of the LanePtrs of (slot, lane)
-extern "C" const void* legion_pipeline_lane_desc(LegionPipeline* p, int32_t slot, int32_t lane)
-{
-    if (!p) return nullptr;
-    return legion_group_lane_desc(p->slots[slot % p->slots_n].group, lane);
-}
 
 extern "C" void legion_pipeline_destroy(LegionPipeline* p)
 {
@@ -426,6 +446,7 @@ extern "C" void legion_pipeline_destroy(LegionPipeline* p)
         HIP_CALL(hipHostFree(sl.h_iter));
         for (MemoryPool* mp : sl.pools) legion_pool_destroy(reinterpret_cast<LegionMemoryPool*>(mp));
         HIP_CALL(hipEventDestroy(sl.done));
+        HIP_CALL(hipEventDestroy(sl.done_blocking));
         HIP_CALL(hipEventDestroy(sl.sampled));
         if (p->overlap || &sl == &p->slots[0]) HIP_CALL(hipStreamDestroy(sl.stream));
     }
@@ -657,6 +678,7 @@ extern "C" int32_t legion_pipeline_submit_bulk_inproc(LegionPipeline* p, int32_t
     SetGPUDevice(p->dev_id);
     Slot& sl = p->slots[si];
     HIP_CALL(hipEventRecord(sl.done, sl.stream));
+    HIP_CALL(hipEventRecord(sl.done_blocking, sl.stream));
     sl.busy = true;
     return si;
 }

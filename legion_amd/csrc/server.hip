@@ -307,7 +307,7 @@ extern "C" void* legion_pipeline_slot_done_event(LegionPipeline* p, int32_t slot
 extern "C" LegionMemoryPool* legion_pipeline_pool(LegionPipeline* p, int32_t slot, int32_t lane);
 extern "C" void legion_pipeline_destroy(LegionPipeline* p);
 extern "C" void legion_pipeline_wait(LegionPipeline* p, int32_t slot);
-extern "C" const void* legion_pipeline_lane_desc(LegionPipeline* p, int32_t slot, int32_t lane);
+extern "C" void legion_pipeline_wait_sleeping(LegionPipeline* p, int32_t slot, int32_t spin_us);
 extern "C" void legion_pipeline_set_gathers(LegionPipeline* p, int32_t on);
 extern "C" int32_t legion_pipeline_bulk_enable_shared(LegionPipeline* p, const PoolArena* arena);
 extern "C" int32_t legion_pipeline_submit_bulk_inproc(LegionPipeline* p, int32_t counter0, int32_t mode, int32_t n_active, int32_t batch_size);
@@ -473,9 +473,17 @@ public:
         const int p = current_pipe_;
         const auto t_a = std::chrono::steady_clock::now();
         {   // the trainer has released this slot?  Poll for a short while (a futex wake costs more than a small batch's
-            // GPU time) before blocking
-            bool got = false;
-            for (int spin = 0; spin < 20000 && !got; spin++) got = env->IPCTryWait(local_dev_id_, p);
+            // GPU time) before blocking: ~20000 polls with the gather hand-over, where the per-batch round trip IS the rate;
+            // LegionTuning.runner_spin_us (20 us by default) once batches go out as views -- the trainer then sets the pace and a
+            // group completes every few ms, so the thread sleeps instead of holding a core
+            bool got = env->IPCTryWait(local_dev_id_, p);
+            if (!got && kind_ == KIND_VIEWS && spin_us_ >= 0) {
+                const auto t0 = std::chrono::steady_clock::now();
+                while (!got && std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() < spin_us_)
+                    got = env->IPCTryWait(local_dev_id_, p);
+            } else {
+                for (int spin = 0; spin < 20000 && !got; spin++) got = env->IPCTryWait(local_dev_id_, p);
+            }
             if (!got) env->IPCWait(local_dev_id_, p);
         }
         const auto t_b = std::chrono::steady_clock::now();
@@ -490,6 +498,8 @@ public:
                 for (int i = 0; i < 2; i++)
                     if (ho_streams_[i] != nullptr)
                         HIP_CALL(hipStreamWaitEvent(ho_streams_[i], (hipEvent_t)legion_pipeline_slot_done_event(pipe_, g.slot), 0));
+            } else if (kind_ == KIND_VIEWS && spin_us_ >= 0) {
+                legion_pipeline_wait_sleeping(pipe_, g.slot, spin_us_);    // the group has completed on the GPU (the thread slept meanwhile)
             } else {
                 legion_pipeline_wait(pipe_, g.slot);             // the group has completed on the GPU
             }
@@ -838,6 +848,7 @@ private:
     std::vector<OpParams*> op_params_;
     bool use_groups_ = lg::tuning().runner_graph != 0;
     // launch groups
+    int32_t spin_us_ = lg::tuning().runner_spin_us < 0 ? 20 : lg::tuning().runner_spin_us;      // views hand-over: poll this long, then sleep (< 0 in the struct: the default)
     int32_t handover_ = lg::tuning().runner_handover;     // 0 auto (views, else gather), 1 gather
     int kind_ = KIND_UNDECIDED;
     bool lane_features_ = false;                           // the lanes have feature buffers (and the groups may gather into them)

@@ -119,6 +119,7 @@ SIGNATURES = {
     "legion_synth_rmat_edges_scrambled": (None, [c_p, c_i32, c_i64, c_u64, c_p, c_p, c_u64]),
     "legion_synth_features": (None, [c_p, c_p, c_i64, c_i64, c_i32, c_u64]),
     "legion_synth_feature_check": (None, [c_p, c_p, c_p, c_i64, c_i32, c_u64, c_p]),
+    "legion_consume_batch": (None, [c_p, c_p, c_i64, c_p, c_p, c_i64, c_p]),
     "legion_link_counters": (c_i32, [c_i32, P_U64, P_U64]),
     "legion_link_counters_ex": (c_i32, [c_i32, c_p]),
     "legion_link_counters_from": (c_i32, [c_i32, c_i32, c_p]),

@@ -15,6 +15,28 @@ sys.path.insert(0, os.path.join(ROOT, "legion_amd", "trainer"))
 from tests.server_proc import start_server  # noqa: E402
 
 
+def vram_held_mib():
+    """What THIS process holds in VRAM according to the driver (amdgpu fdinfo of its drm / kfd descriptors, one entry per drm
+    client).  hipMemGetInfo answers from the runtime's own book-keeping, which does not follow another process's chunks being
+    mapped and unmapped here (tools/micro/vmm_release_probe.cpp)."""
+    seen, total = set(), 0
+    for name in os.listdir("/proc/self/fdinfo"):
+        try:
+            text = open(f"/proc/self/fdinfo/{name}").read()
+        except OSError:
+            continue
+        cid, vram = None, None
+        for ln in text.splitlines():
+            if ln.startswith("drm-client-id:"):
+                cid = ln.split()[1]
+            elif ln.startswith("drm-memory-vram:"):
+                vram = int(ln.split()[1])
+        if vram is not None and cid not in seen:
+            seen.add(cid)
+            total += vram >> 10
+    return total
+
+
 def main():
     import hashlib
     lives, dim, epoch, work = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), sys.argv[4]
@@ -43,7 +65,7 @@ def main():
                 del t
                 torch.cuda.synchronize()
                 ipc_service.synchronize()
-            mid_free = torch.cuda.mem_get_info(0)[0]
+            mid_free, mid_held = torch.cuda.mem_get_info(0)[0], vram_held_mib()
             ipc_service.finalize()
             server.wait(timeout=120)
             assert server.returncode == 0, open(os.path.join(work, f"server{life}.log")).read()[-2000:]
@@ -54,12 +76,14 @@ def main():
         np.savez(os.path.join(work, f"life{life}.npz"), steps=np.array([train, valid, test], dtype=np.int32),
                  digests=np.array(digests, dtype=np.uint64), sizes=np.array(sizes, dtype=np.int32))
         torch.cuda.empty_cache()
-        free = torch.cuda.mem_get_info(0)[0]
-        print(f"life {life}: {total} batches, free MiB while attached {mid_free >> 20}, after finalize + server exit {free >> 20}", flush=True)
+        free, held = torch.cuda.mem_get_info(0)[0], vram_held_mib()
+        print(f"life {life}: {total} batches; VRAM held by this process (driver's fdinfo) while attached {mid_held} MiB, after finalize + server "
+              f"exit {held} MiB; hipMemGetInfo free {mid_free >> 20} -> {free >> 20} MiB", flush=True)
         if level is None:
-            level = free
-        # the dead server's arena (tens of MB per life) must not survive in this process's mappings
-        assert free >= level - (16 << 20), f"life {life}: {(level - free) >> 20} MiB of HBM did not come back"
+            level = held
+        # the dead server's arena (hundreds of MB per life) must not survive in this process's mappings
+        assert mid_held >= held + 200, f"life {life}: the lane arena does not show in what this process holds ({mid_held} vs {held} MiB): nothing is measured"
+        assert held <= level + 16, f"life {life}: this process still holds {held - level} MiB more VRAM than after the first life"
     print("all lives clean", flush=True)
 
 

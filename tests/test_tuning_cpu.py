@@ -68,6 +68,29 @@ def test_struct_mirror_matches_the_header():
     assert ctypes.sizeof(lib.LinkCounters) == 8 * 3 + 8 * 16 + 8 + 32 + 8
 
 
+def test_integration_table_is_generated_from_the_header():
+    """INTEGRATION.md's LegionTuning table is tools/tuning_table.py's rendering of include/legion_hip.h."""
+    import subprocess
+    import sys
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "tuning_table.py"), "--check"], stdout=subprocess.PIPE, text=True)
+    assert res.returncode == 0, res.stdout
+
+
+def test_no_stray_environment_reads_in_the_library():
+    """Every LEGION_* variable the library reads is parsed in tuning.hip (LegionTuning), except the deployment names (which shm /
+    semaphore namespace, whether this process owns the names): VERDICT r04 counted 12 stray getenv calls."""
+    import glob
+    import re
+    stray = []
+    for f in glob.glob(os.path.join(ROOT, "legion_amd", "csrc", "*")):
+        if f.endswith("tuning.hip"):
+            continue
+        for m in re.finditer(r'getenv\("([A-Z_0-9]+)"\)', open(f).read()):
+            if m.group(1) not in ("LEGION_IPC_NAMESPACE", "LEGION_IPC_LOCAL", "HSA_ENABLE_IPC_MODE_LEGACY"):
+                stray.append((os.path.basename(f), m.group(1)))
+    assert not stray, stray
+
+
 def test_link_counters_without_a_gpu_report_unsupported():
     c = engine.link_counters_ex(0)
     assert set(c) >= {"supported", "pcie_bytes", "xgmi_read_bytes", "xgmi_read_bytes_link", "gpu_metrics_revision", "pci_bus_id"}

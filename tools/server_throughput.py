@@ -28,6 +28,10 @@ def main():
     ap.add_argument("--consumer", type=str, default="python", choices=["python", "native"],
                     help="python: the ipc_service extension as a trainer would use it (get_next -> synchronize); "
                          "native: tools/boundary_consumer.c, the wire protocol with nothing else (what the server can hand over)")
+    ap.add_argument("--consume", action="store_true",
+                    help="python consumer: READ every batch -- one launch per get_next that loads every float of the rows and every entry of "
+                         "the outermost COO pair (legion_consume_batch), completed before the batch is released -- instead of only walking "
+                         "the protocol")
     ap.add_argument("--no-features-file", action="store_true",
                     help="do not write the `features` file: the server then serves a zero-filled table of the same shape (v2 of the "
                          "reference reads no features either, storage_management.cu:162); a 34 GB file is too slow to write for a "
@@ -108,6 +112,15 @@ def consume(spec):
     import ipc_service
     torch.cuda.set_device(0)
     ipc_service.initialize()
+    consume_lib, acc, c_p = None, None, None
+    if a.consume:       # a consumer that READS every batch: one launch per get_next over the rows and the two outermost COO arrays
+        import ctypes
+        from legion_amd import lib as _lib
+        consume_lib, c_p = _lib.load(), ctypes.c_void_p
+        acc = torch.zeros(1, dtype=torch.float64, device="cuda:0")
+        torch.cuda.synchronize()
+        hp = torch.cuda.Stream(priority=-1)           # the consumer's one kernel per batch must not queue behind the server's saturating gathers
+        stream = c_p(hp.cuda_stream)
     tr, va, te = ipc_service.get_steps()
     edges, t0, t1, n_timed, verified = 0, None, None, 0, 0
     t_start = time.time()
@@ -122,6 +135,10 @@ def consume(spec):
                 torch.cuda.synchronize(); t0 = time.perf_counter(); edges = 0; n_timed = 0
             edges += int(out[3].numel())          # outermost block = every edge of the batch
             n_timed += 1
+        if consume_lib is not None:
+            f, s_, d_ = out[1], out[3], out[4]
+            consume_lib.legion_consume_batch(stream, c_p(f.data_ptr()), f.numel(), c_p(s_.data_ptr()), c_p(d_.data_ptr()), s_.numel(), c_p(acc.data_ptr()))
+            hp.synchronize()      # a batch is released (synchronize() below) only when its reads have completed
         if a.verify_every and i % a.verify_every == 0:
             ids, fts = out[0], out[1]
             n = int(ids.numel())
@@ -142,7 +159,18 @@ def consume(spec):
     ipc_service.finalize()
     dt = t1 - t0
     print(json.dumps({"batches_per_sec": n_timed / dt, "edges_per_sec": edges / dt, "timed_batches": n_timed,
-                      "ms_per_batch": dt / n_timed * 1e3, "verified_batches": verified}), flush=True)
+                      "ms_per_batch": dt / n_timed * 1e3, "verified_batches": verified,
+                      "consumed_checksum": None if acc is None else float(acc.item())}), flush=True)
+
+
+def proc_cpu_seconds(pid):
+    """user + system CPU time of a live process, all threads (None when it is gone)"""
+    try:
+        f = open(f"/proc/{pid}/stat").read()
+        rest = f[f.rindex(")") + 2:].split()
+        return (int(rest[11]) + int(rest[12])) / os.sysconf("SC_CLK_TCK")
+    except (OSError, ValueError, IndexError):
+        return None
 
 
 def run_one(a, ds, tmp, batch, n_train, train, fanout, N, E, mode=""):
@@ -190,10 +218,12 @@ def run_one(a, ds, tmp, batch, n_train, train, fanout, N, E, mode=""):
                         "workload": workload, "batch": batch, "handover": handover_of(), "mode": mode, "epochs": a.epochs})
             print(json.dumps(res), flush=True)
             return
-        spec = {"args": {k: getattr(a, k) for k in ("dim", "epochs", "watchdog", "verify_every", "no_features_file")},
+        spec = {"args": {k: getattr(a, k) for k in ("dim", "epochs", "watchdog", "verify_every", "no_features_file", "consume")},
                 "batch": batch, "fanout": fanout, "train_file": ds + "trainingset"}
+        cpu0, w0 = proc_cpu_seconds(server.pid), time.time()
         child = subprocess.run([sys.executable, os.path.abspath(__file__), "--child-consumer", json.dumps(spec)], env=dict(os.environ),
                                stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=(a.watchdog or 3000) + 120)
+        cpu1, w1 = proc_cpu_seconds(server.pid), time.time()
         cl = [ln for ln in child.stdout.splitlines() if ln.startswith("{")]
         if child.returncode != 0 or not cl:
             raise RuntimeError(f"consumer failed (rc {child.returncode}): {child.stdout[-800:]} {child.stderr[-2500:]}")
@@ -202,7 +232,11 @@ def run_one(a, ds, tmp, batch, n_train, train, fanout, N, E, mode=""):
         print(json.dumps({"path": "sampling_server binary -> shm/semaphores/IPC handles -> ipc_service consumer",
                           "workload": workload, "batch": batch, "handover": handover_of(), "mode": mode, "epochs": a.epochs,
                           "batches_per_sec": r["batches_per_sec"], "edges_per_sec": r["edges_per_sec"], "timed_batches": r["timed_batches"],
-                          "ms_per_batch": r["ms_per_batch"], "verified_batches": r["verified_batches"]}), flush=True)
+                          "ms_per_batch": r["ms_per_batch"], "verified_batches": r["verified_batches"],
+                          "consumer_reads_every_batch": bool(a.consume), "consumed_checksum": r.get("consumed_checksum"),
+                          "server_cpu_cores": None if cpu0 is None or cpu1 is None else (cpu1 - cpu0) / max(w1 - w0, 1e-9),
+                          "server_cpu_cores_note": "user + system CPU seconds of the server process over the consumer's lifetime (incl. its "
+                                                   "start-up, during which the server waits) / wall seconds"}), flush=True)
     finally:
         if server.poll() is None:
             server.kill()
