@@ -21,6 +21,7 @@
 
 #include <algorithm>
 #include <chrono>
+#include <thread>
 #include <cstring>
 #include <map>
 #include <tuple>
@@ -51,7 +52,6 @@ struct Slot {
     LegionLaneGroup* group = nullptr;
     hipStream_t stream = nullptr;
     hipEvent_t done = nullptr;
-    hipEvent_t done_blocking = nullptr;       // recorded with `done`; created with hipEventBlockingSync: a host thread that waits for it sleeps
     hipEvent_t sampled = nullptr;             // weave: the group's head has finished
     bool busy = false;
     std::map<std::tuple<int32_t, int32_t, int32_t, int32_t>, hipGraphExec_t> exec;   // key: (phase, mode, active lanes, batch_size)
@@ -191,7 +191,6 @@ extern "C" LegionPipeline* legion_pipeline_create(LegionGraphStorage* graph, Leg
         else
             sl.stream = p->slots[0].stream;
         HIP_CALL(hipEventCreateWithFlags(&sl.done, hipEventDisableTiming));
-        HIP_CALL(hipEventCreateWithFlags(&sl.done_blocking, hipEventDisableTiming | hipEventBlockingSync));
         HIP_CALL(hipEventCreateWithFlags(&sl.sampled, hipEventDisableTiming));
     }
     lg_set_pool_claims_hint(0, 0);
@@ -363,7 +362,6 @@ extern "C" int32_t legion_pipeline_submit_ex(LegionPipeline* p, int32_t counter0
             sl.next_iter = n_active == p->group_size ? counter0 + p->group_size * p->slots_n : -1;
         }
         HIP_CALL(hipEventRecord(sl.done, X));
-        HIP_CALL(hipEventRecord(sl.done_blocking, X));
         sl.busy = true;
         return si;
     }
@@ -387,7 +385,6 @@ extern "C" int32_t legion_pipeline_submit_ex(LegionPipeline* p, int32_t counter0
         sl.next_iter = n_active == p->group_size ? counter0 + p->group_size * p->slots_n : -1;
     }
     HIP_CALL(hipEventRecord(sl.done, sl.stream));
-    HIP_CALL(hipEventRecord(sl.done_blocking, sl.stream));
     sl.busy = true;
     return si;
 }
@@ -401,8 +398,11 @@ extern "C" void legion_pipeline_wait(LegionPipeline* p, int32_t slot)
 }
 
 // The same for a host thread that has nothing else to do until the group is complete (GPURunner handing batches over as views: a
-// group completes every few ms): poll for at most spin_us microseconds, then SLEEP until the completion interrupt
-// (hipEventSynchronize on an event created with hipEventBlockingSync) instead of burning a core in the runtime's own spin.
+// group completes every few ms): poll for at most spin_us microseconds, then SLEEP between polls (200 us naps: a completion is
+// noticed at most that late, which delays a hand-over that has two more groups queued behind it, not the GPU).
+// (hipEventSynchronize on an event created with hipEventBlockingSync was tried first: on this runtime the waiting thread and
+// one of the runtime's own threads then burn 0.6 of a core each -- 1.25 cores per GPU at B = 8000 against 0.27 at B = 1024, where
+// the thread mostly sleeps on the trainer's semaphore instead.)
 extern "C" void legion_pipeline_wait_sleeping(LegionPipeline* p, int32_t slot, int32_t spin_us)
 {
     if (!p) return;
@@ -412,12 +412,12 @@ extern "C" void legion_pipeline_wait_sleeping(LegionPipeline* p, int32_t slot, i
         const auto t0 = std::chrono::steady_clock::now();
         hipError_t q = hipEventQuery(sl.done);
         while (q == hipErrorNotReady && std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() < spin_us) q = hipEventQuery(sl.done);
-        if (q == hipErrorNotReady) {
-            (void)hipGetLastError();
-            HIP_CALL(hipEventSynchronize(sl.done_blocking));
-        } else if (q != hipSuccess) {
-            HIP_CALL(q);
+        while (q == hipErrorNotReady) {
+            std::this_thread::sleep_for(std::chrono::microseconds(200));
+            q = hipEventQuery(sl.done);
         }
+        (void)hipGetLastError();
+        if (q != hipSuccess) HIP_CALL(q);
     }
     slot_wait(p, sl);       // (complete by now: returns at once, collects the profile)
 }
@@ -446,7 +446,6 @@ extern "C" void legion_pipeline_destroy(LegionPipeline* p)
         HIP_CALL(hipHostFree(sl.h_iter));
         for (MemoryPool* mp : sl.pools) legion_pool_destroy(reinterpret_cast<LegionMemoryPool*>(mp));
         HIP_CALL(hipEventDestroy(sl.done));
-        HIP_CALL(hipEventDestroy(sl.done_blocking));
         HIP_CALL(hipEventDestroy(sl.sampled));
         if (p->overlap || &sl == &p->slots[0]) HIP_CALL(hipStreamDestroy(sl.stream));
     }
@@ -678,7 +677,6 @@ extern "C" int32_t legion_pipeline_submit_bulk_inproc(LegionPipeline* p, int32_t
     SetGPUDevice(p->dev_id);
     Slot& sl = p->slots[si];
     HIP_CALL(hipEventRecord(sl.done, sl.stream));
-    HIP_CALL(hipEventRecord(sl.done_blocking, sl.stream));
     sl.busy = true;
     return si;
 }

@@ -13,6 +13,8 @@
 // only stream 0's last event).  Full CSR / feature table go to HBM when they fit
 // (288 GB per MI355X), to mapped pinned host memory otherwise.
 #include "legion_core.h"
+
+#include <pthread.h>
 extern "C" void* d_alloc_scattered_exportable(int64_t num_bytes, int32_t chunk_mb);
 #include "runner_schedule.h"
 
@@ -773,6 +775,11 @@ private:
             // behind hipStreamWaitValue32 and signalling completion with hipStreamWriteValue32 -- 36 k batches/s against
             // 44 k with events at B = 1024.)  With the `views` hand-over it has nothing to do and sleeps.
             SetGPUDevice(local_dev_id_);
+            {
+                char name[16];
+                snprintf(name, sizeof(name), "lg-poster%d", local_dev_id_);
+                pthread_setname_np(pthread_self(), name);
+            }
             uint32_t head = 0;
             for (uint32_t idle = 0;;) {
                 if (q_tail_.load(std::memory_order_acquire) == head) {
@@ -887,6 +894,11 @@ static void PreSCLoop(int train_step, Runner* runner, RunnerParams* params)
 
 static void RunnerLoop(int max_step, Runner* runner, RunnerParams* params)
 {
+    {   // (thread names show in /proc/<pid>/task/*/comm: tools/server_throughput.py reports the server's CPU time by thread)
+        char name[16];
+        snprintf(name, sizeof(name), "lg-runner%d", params->device_id);
+        pthread_setname_np(pthread_self(), name);
+    }
     for (int i = 0; i < max_step; i++) {
         params->global_batch_id = i;
         runner->RunOnce(params);

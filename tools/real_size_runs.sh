@@ -4,13 +4,16 @@
 #   papers100M N = 111 059 956, E = 1 615 685 872, D = 128, B = 8000, [15,10,5], CSR + features in pinned host memory (configs[2])
 RND=${1:-r03}
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.."; pwd)}; OUT=$R/gpurun_out/real_$RND; mkdir -p $OUT
-COMMON="--cpu-seconds 0 --no-boundary --no-overlap-leg --presc-steps 64 --steps 8 --warmup 2 --group 8"
+# GROUP: lanes per launch group.  Rounds 3-4 ran these shapes with 8 (a cautious guess at what fits beside 160-200 GB of tables); since round 5
+# the default is bench.py's own rule -- 524288 / B lanes, halved while the lanes of the groups in flight would take more than 0.7 of the
+# HBM the tables left free: 64 lanes at every one of these shapes -- and GROUP=8 reproduces the old lines.
+COMMON="--cpu-seconds 0 --no-boundary --presc-steps 64 --steps 8 --warmup 2 ${GROUP:+--group $GROUP}"
 run() { name=$1; shift; ( time timeout -k 5 1200 python3 $R/bench.py $COMMON "$@" > $OUT/$name.json 2> $OUT/$name.err < /dev/null ) 2>&1 | grep real
   python3 - $OUT/$name.json $name <<'PY'
 import json, sys
 try:
     d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
-    print(sys.argv[2], "value %.3f G edges/s" % (d["value"] / 1e9), "ms/step %.3f" % d["ms_per_step"], "gather frac %.3f" % d["roofline"]["frac"],
+    print(sys.argv[2], "value %.3f G edges/s" % (d["value"] / 1e9), "ms/step %.3f" % d["ms_per_step"], "batches/step", d["batches_per_step"], "gather frac %.3f" % d["roofline"]["frac"],
           "rows/launch %.0f" % d["roofline"]["rows_per_launch"], "sampler-only %.2f G" % (d["sampling_only"]["edges_per_sec"] / 1e9),
           "cache rows", d["config"]["feature_cache_rows"], "hit rate %.3f" % d["feature_cache_hit_rate"], d.get("miss_path", {}).get("pcie_feature_GBps"))
 except Exception as e:

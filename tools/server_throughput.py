@@ -173,6 +173,22 @@ def proc_cpu_seconds(pid):
         return None
 
 
+def thread_cpu_seconds(pid):
+    """{thread name: user + system CPU seconds} of a live process (threads of one name summed)"""
+    out = {}
+    try:
+        for tid in os.listdir(f"/proc/{pid}/task"):
+            f = open(f"/proc/{pid}/task/{tid}/stat").read()
+            name = f[f.index("(") + 1:f.rindex(")")]
+            rest = f[f.rindex(")") + 2:].split()
+            if not name.startswith("lg-"):         # (the runtime's helper threads carry the process's name: tell them apart)
+                name = f"{name}:{'main' if int(tid) == int(pid) else int(tid) - int(pid)}"
+            out[name] = out.get(name, 0.0) + (int(rest[11]) + int(rest[12])) / os.sysconf("SC_CLK_TCK")
+    except (OSError, ValueError, IndexError):
+        pass
+    return out
+
+
 def run_one(a, ds, tmp, batch, n_train, train, fanout, N, E, mode=""):
     work = os.path.join(tmp, f"run_b{batch}{mode}")
     os.makedirs(work)
@@ -221,9 +237,33 @@ def run_one(a, ds, tmp, batch, n_train, train, fanout, N, E, mode=""):
         spec = {"args": {k: getattr(a, k) for k in ("dim", "epochs", "watchdog", "verify_every", "no_features_file", "consume")},
                 "batch": batch, "fanout": fanout, "train_file": ds + "trainingset"}
         cpu0, w0 = proc_cpu_seconds(server.pid), time.time()
-        child = subprocess.run([sys.executable, os.path.abspath(__file__), "--child-consumer", json.dumps(spec)], env=dict(os.environ),
-                               stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=(a.watchdog or 3000) + 120)
+        child_p = subprocess.Popen([sys.executable, os.path.abspath(__file__), "--child-consumer", json.dumps(spec)], env=dict(os.environ),
+                                   stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+        # the server's CPU time by thread WHILE it serves (its runner threads end with the schedule): snapshots every 0.2 s, the
+        # window = first to last snapshot that shows a runner thread
+        snaps = []
+
+        def watch():
+            while child_p.poll() is None:
+                t = thread_cpu_seconds(server.pid)
+                if any(n.startswith("lg-runner") for n in t):
+                    snaps.append((time.time(), t))
+                time.sleep(0.2)
+        import threading
+        wt = threading.Thread(target=watch, daemon=True)
+        wt.start()
+        try:
+            c_out, c_err = child_p.communicate(timeout=(a.watchdog or 3000) + 120)
+        except subprocess.TimeoutExpired:
+            child_p.kill()
+            c_out, c_err = child_p.communicate()
+        wt.join(timeout=2)
+        child = argparse.Namespace(returncode=child_p.returncode, stdout=c_out, stderr=c_err)
         cpu1, w1 = proc_cpu_seconds(server.pid), time.time()
+        by_thread = []
+        if len(snaps) >= 2:
+            (ta, tha), (tb, thb) = snaps[0], snaps[-1]
+            by_thread = sorted(((n, (thb.get(n, 0.0) - tha.get(n, 0.0)) / max(tb - ta, 1e-9)) for n in thb), key=lambda kv: -kv[1])[:6]
         cl = [ln for ln in child.stdout.splitlines() if ln.startswith("{")]
         if child.returncode != 0 or not cl:
             raise RuntimeError(f"consumer failed (rc {child.returncode}): {child.stdout[-800:]} {child.stderr[-2500:]}")
@@ -235,6 +275,7 @@ def run_one(a, ds, tmp, batch, n_train, train, fanout, N, E, mode=""):
                           "ms_per_batch": r["ms_per_batch"], "verified_batches": r["verified_batches"],
                           "consumer_reads_every_batch": bool(a.consume), "consumed_checksum": r.get("consumed_checksum"),
                           "server_cpu_cores": None if cpu0 is None or cpu1 is None else (cpu1 - cpu0) / max(w1 - w0, 1e-9),
+                          "server_cpu_cores_by_thread": {n: round(v, 3) for n, v in by_thread if v > 0.005},
                           "server_cpu_cores_note": "user + system CPU seconds of the server process over the consumer's lifetime (incl. its "
                                                    "start-up, during which the server waits) / wall seconds"}), flush=True)
     finally:
