@@ -289,10 +289,10 @@ __device__ __forceinline__ HopGeom hop_geometry(const SampleArgs& a)
 #ifndef LG_SAMPLE_SGPRS
 #define LG_SAMPLE_SGPRS 80           // 8 workgroups of 256 threads per CU need <= 80 SGPRs (MI355X_MICROARCH.md, residency); 90-106 give 6-7
 #endif
-// !SINGLE (64- and 256-bucket classes): the kernel samples K super tiles (a partition tile), counts their claims per bucket and
+// !SINGLE (256-bucket class): the kernel samples K super tiles (a partition tile), counts their claims per bucket and
 // reserves, with one atomic per bucket, that many places of each bucket's claim list (run_off: {first place, count} per
-// partition tile and bucket); place_kernel writes the pairs (see there)
-template <int BB, bool SINGLE>      // 2^BB hash buckets per lane; SINGLE: partition tile = super tile
+// partition tile and bucket); place_kernel writes the pairs (see there).  SINGLE + STAGED (64-bucket class): below.
+template <int BB, bool SINGLE, bool STAGED = false>      // 2^BB hash buckets per lane; SINGLE: partition tile = super tile; STAGED: see below
 __global__ __launch_bounds__(LG_TILE) __attribute__((amdgpu_num_sgpr(LG_SAMPLE_SGPRS))) void sample_kernel(HopParams hp, const LanePtrs* __restrict__ lanes)
 {
     constexpr int NB = 1 << BB;
@@ -300,7 +300,8 @@ __global__ __launch_bounds__(LG_TILE) __attribute__((amdgpu_num_sgpr(LG_SAMPLE_S
     static_assert(NB <= LG_TILE, "one thread per bucket in the prefix");
     const SampleArgs a = lane_args(hp, lanes);
     __shared__ RowHdr s_hdr[LG_SUPER];
-    __shared__ int32_t s_bcnt[NB], s_boff[SINGLE ? NB : 1];
+    __shared__ int32_t s_bcnt[NB], s_boff[SINGLE ? NB : 1], s_list[STAGED ? NB : 1];
+    static_assert(!STAGED || (SINGLE && NB <= 64), "the staged form scans its buckets with one wave");
 
     const HopGeom g = hop_geometry(a);
     const int32_t tid = threadIdx.x;
@@ -308,9 +309,9 @@ __global__ __launch_bounds__(LG_TILE) __attribute__((amdgpu_num_sgpr(LG_SAMPLE_S
     const bool seeds = (a.op_id == INTRABATCH_CON);
     const LG_G RowHdr* fh = a.fh_edge + g.frontier_off;
 
-    // lds form: a hop's claims go, grouped by hash bucket, to ONE LIST PER BUCKET of the lane.  SINGLE (8 / 16 buckets): ranks are
-    // taken while the super tile is sampled and the pairs are written here.  Otherwise (many buckets: a bucket's share of a super
-    // tile is a few pairs) the kernel only samples and counts; place_kernel re-reads slot_dst and writes the pairs.
+    // a hop's claims go, grouped by hash bucket, to ONE LIST PER BUCKET of the lane.  SINGLE (8 / 16 / 64 buckets): ranks are
+    // taken while the super tile is sampled and the pairs are written here.  Otherwise (256 buckets: a bucket's share of a super
+    // tile is a pair or two) the kernel only samples and counts; place_kernel re-reads slot_dst and writes the pairs.
     const int32_t nparts = (g.nsuper + K - 1) / K;
     for (int32_t m = blockIdx.x; m < nparts; m += gridDim.x) {
         if (!SINGLE && tid < NB) s_bcnt[tid] = 0;      // (visible after the first barrier of the first super tile)
@@ -411,7 +412,50 @@ __global__ __launch_bounds__(LG_TILE) __attribute__((amdgpu_num_sgpr(LG_SAMPLE_S
                     if (a.slot_fs != nullptr && dst[u] >= 0) __builtin_nontemporal_store(fs[u], &a.slot_fs[idx]);     // (read for first-touch slots only)
                 }
             }
-            if (SINGLE) {
+            if (SINGLE && STAGED) {
+                // 64 buckets: a super tile's ~450 claims are ~7 per bucket.  Written straight from the registers (as below) a wave's 64
+                // claims would go to ~40 different lists: 8-byte stores all over the lane's pair array, +60 % memory requests in a
+                // kernel that is bound by them.  So the claims are ranked and STAGED in LDS grouped by bucket -- in the row-header
+                // stage, which nobody reads any more once every pick has been loaded: no LDS added, the kernel keeps its 8 workgroups
+                // per CU -- and written out entry by entry: consecutive entries of a bucket go to consecutive places of its list, a
+                // wave's store covers ~9 runs instead of ~40.  One reservation per non-empty bucket and super tile.  (Round 4 did this
+                // with a second kernel over partition tiles of 8 super tiles, place_kernel: 93-107 us per 64-lane group of B = 8000
+                // for 250 MB of traffic; the 256-bucket class, where a bucket's share of a super tile is 1-2 claims, still does.)
+                int32_t rank[LG_SLOTS_PER_LANE], bkt[LG_SLOTS_PER_LANE];
+                unsigned long long* s_stage = reinterpret_cast<unsigned long long*>(s_hdr);      // LG_SUPER pairs = 8 KB of the 16 KB
+                __syncthreads();                                   // every thread has read its headers; s_bcnt zeroed
+#pragma unroll
+                for (int u = 0; u < LG_SLOTS_PER_LANE; u++) {
+                    bkt[u] = -1;
+                    if (dst[u] >= 0) {
+                        bkt[u] = (int32_t)(lg_tab_hash(dst[u]) & (NB - 1));
+                        rank[u] = atomicAdd(&s_bcnt[bkt[u]], 1);
+                    }
+                }
+                __syncthreads();
+                if (tid < 64) {                                    // wave 0: exclusive prefix of the bucket counts + the reservations
+                    const int32_t c = tid < NB ? s_bcnt[tid] : 0;
+                    int32_t inc = c;
+                    for (int d = 1; d < 64; d <<= 1) { const int32_t o = __shfl_up(inc, d); if (tid >= d) inc += o; }
+                    if (tid < NB) {
+                        s_boff[tid] = inc - c;
+                        s_list[tid] = c > 0 ? __hip_atomic_fetch_add(a.claim_cnt + tid * LG_CLAIM_CNT_STRIDE, c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+                    }
+                }
+                __syncthreads();
+#pragma unroll
+                for (int u = 0; u < LG_SLOTS_PER_LANE; u++)
+                    if (bkt[u] >= 0)
+                        s_stage[s_boff[bkt[u]] + rank[u]] = ((unsigned long long)(uint32_t)dst[u] << 32) | (uint32_t)(idx0 + u * LG_TILE + tid);
+                __syncthreads();
+                const int32_t tot = s_boff[NB - 1] + s_bcnt[NB - 1];
+                for (int32_t i = tid; i < tot; i += LG_TILE) {
+                    const unsigned long long pr = s_stage[i];
+                    const int32_t bk = (int32_t)(lg_tab_hash((int32_t)(pr >> 32)) & (NB - 1));
+                    const int32_t at = s_list[bk] + (i - s_boff[bk]);
+                    if (at < a.claim_cap) a.claim_pairs[lg_claim_at<NB>(bk, at)] = pr;
+                }
+            } else if (SINGLE) {
                 // the super tile's claims, grouped by hash bucket, into one run of the lane's pair array: ranks by LDS atomics
                 // (the order inside a bucket does not matter), ONE global reservation per super tile
                 int32_t rank[LG_SLOTS_PER_LANE], bkt[LG_SLOTS_PER_LANE];
@@ -466,8 +510,8 @@ __global__ __launch_bounds__(LG_TILE) __attribute__((amdgpu_num_sgpr(LG_SAMPLE_S
 }
 
 // ------------------------------------------------------------------------------------------
-// K1a (lds form, 64- and 256-bucket classes, partition tiles of at most LG_PLACE_MAX_K super tiles): the pairs of a partition
-// tile, written to the buckets' claim lists.  With 64-256 buckets a wave's 64 pairs go to ~50 different lists: written straight
+// K1a (256-bucket class, partition tiles of at most LG_PLACE_MAX_K super tiles): the pairs of a partition
+// tile, written to the buckets' claim lists.  With 256 buckets a wave's 64 pairs go to ~60 different lists: written straight
 // from the sampling kernel they are 8-byte stores all over the lane's pair array (that sweep cost the hop-3 launch of [15,10,5]
 // at B = 8000 as much again as its scattered column loads).  Here the partition tile's pairs are ranked and staged in LDS grouped
 // by bucket (8 KB per super tile), and the staged block is then written out entry by entry: consecutive entries of a bucket go
@@ -548,7 +592,7 @@ __global__ __launch_bounds__(LG_PLACE_THREADS) void place_kernel(HopParams hp, c
 // A bucket whose vertices cannot fit the table is processed in P passes over sub-buckets (further hash bits), so the
 // result never depends on how the hash spreads the batch.  Nothing survives the hop: nothing to clear, no state that
 // scales with the graph.
-// The claims arrive as ONE LIST PER BUCKET in every class (8 / 16 buckets: written by sample_kernel; 64 / 256: by place_kernel).
+// The claims arrive as ONE LIST PER BUCKET in every class (8 / 16 / 64 buckets: written by sample_kernel; 256: by place_kernel).
 // A workgroup's life used to be a chain of dependent round trips to memory (lane pointers -> live counters -> segment table ->
 // claims); with one list per bucket, what a thread reads first -- its claims of the list, its seed, its entry of the known list --
 // sits at addresses that do not depend on the live counters, so these loads leave TOGETHER with the loads of the counters and
@@ -1099,15 +1143,15 @@ void launch_random_sample(hipStream_t s, const HopParams& p, const LanePtrs* d_l
     while (gx > 1 && (int64_t)gx * n_lanes > max_wg && max_wg < 4096) gx /= 2;   // (experiments with fewer workgroups)
     const dim3 grid(gx, n_lanes);
     {
-        // buckets per lane follow the pool's largest hop (legion_core.h).  8 / 16 buckets: the sampling kernel writes the claim
-        // lists itself.  64 / 256 buckets: it samples partition tiles of K super tiles and place_kernel writes the lists; K follows
-        // THIS hop: as large as the staging allows (LG_PLACE_MAX_K) unless that leaves the launch with fewer than ~8 k workgroups
-        // by the hop's capacity (a hop typically fills a quarter of it: ~2 k active ones; measured at B = 8000: 2 k -> 8 k
-        // +1...2 %, beyond: the same), and never below the class's minimum (run_off is sized by it, storage.hip)
+        // buckets per lane follow the pool's largest hop (legion_core.h).  8 / 16 / 64 buckets: the sampling kernel writes the claim
+        // lists itself (64: staged per super tile in LDS).  256 buckets: it samples partition tiles of K super tiles and place_kernel
+        // writes the lists; K follows THIS hop: as large as the staging allows (LG_PLACE_MAX_K) unless that leaves the launch with
+        // fewer than ~8 k workgroups by the hop's capacity (a hop typically fills a quarter of it: ~2 k active ones; measured at
+        // B = 8000: 2 k -> 8 k +1...2 %, beyond: the same), and never below the class's minimum (run_off is sized by it, storage.hip)
         HopParams q = p;
         const bool small = p.lds_bucket_bits == LG_LDS_BITS_SMALL || p.lds_bucket_bits == LG_LDS_BITS_SMALL16;
         const int32_t k_lo = lg_lds_k_min(p.lds_bucket_bits);
-        int32_t k = small ? 1 : LG_PLACE_MAX_K;
+        int32_t k = (small || p.lds_bucket_bits == LG_LDS_BITS_MEDIUM) ? 1 : LG_PLACE_MAX_K;
         const int want_wg = tuning().lds_part_wg;
         while (k > k_lo && (int64_t)(max_super / k) * n_lanes < want_wg) k /= 2;
         q.lds_k = k;
@@ -1127,9 +1171,7 @@ void launch_random_sample(hipStream_t s, const HopParams& p, const LanePtrs* d_l
             dedup_lists_kernel<LG_LDS_BITS_SMALL16, LG_DEDUP_CLAIMS><<<dim3(1 << LG_LDS_BITS_SMALL16, n_lanes), LG_DEDUP_THREADS, 0, s>>>(q, d_lanes);
             break;
         case LG_LDS_BITS_MEDIUM:
-            sample_kernel<LG_LDS_BITS_MEDIUM, false><<<pgrid, LG_TILE, 0, s>>>(q, d_lanes);
-            hipCheckError();
-            place_kernel<LG_LDS_BITS_MEDIUM><<<pgrid, LG_PLACE_THREADS, stage, s>>>(q, d_lanes);
+            sample_kernel<LG_LDS_BITS_MEDIUM, true, true><<<grid, LG_TILE, 0, s>>>(q, d_lanes);
             hipCheckError();
             dedup_lists_kernel<LG_LDS_BITS_MEDIUM, LG_DEDUP_CLAIMS><<<dim3(1 << LG_LDS_BITS_MEDIUM, n_lanes), LG_DEDUP_THREADS, 0, s>>>(q, d_lanes);
             break;

@@ -188,7 +188,7 @@ struct LanePtrs {
     char* tmp_part_ind;
     // first touches (no per-vertex state, see above): the hop's claims, one list per hash bucket
     unsigned long long* claim_pairs;   // (vertex << 32 | slot): [buckets][claim_cap], interleaved by chunk (below)
-    int32_t* run_off;                  // 64/256-bucket classes: [partition tiles][buckets] x {first place in the bucket's claim list, count} (sample_kernel -> place_kernel)
+    int32_t* run_off;                  // 256-bucket class: [partition tiles][buckets] x {first place in the bucket's claim list, count} (sample_kernel -> place_kernel)
     int32_t lds_buckets;               // 8, 16, 64 or 256
     // one list of claims per bucket: the sampling kernel reserves places for a super tile's (8/16 buckets) or a partition tile's
     // (64/256 buckets) claims of a bucket with one atomic on claim_cnt[bucket]; a count beyond claim_cap says the list is incomplete

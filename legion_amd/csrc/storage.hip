@@ -746,7 +746,7 @@ void lg_pool_alloc_private(MemoryPool* mp, int32_t dev_id, int32_t total_num_nod
             mp->claim_cnt = (int32_t*)d_alloc_space(n_buckets * LG_CLAIM_CNT_STRIDE * sizeof(int32_t));
             HIP_CALL(hipMemset(mp->claim_cnt, 0, n_buckets * LG_CLAIM_CNT_STRIDE * sizeof(int32_t)));
         }
-        if (n_buckets > 16) {        // 64 / 256 buckets: {first place, count} per partition tile and bucket (sample_kernel -> place_kernel)
+        if (n_buckets > 64) {        // 256 buckets: {first place, count} per partition tile and bucket (sample_kernel -> place_kernel)
             const int64_t n_parts = (n_super + lg_lds_k_min(mp->lds_bucket_bits) - 1) / lg_lds_k_min(mp->lds_bucket_bits) + 1;
             mp->run_off = (int32_t*)d_alloc_space(n_parts * n_buckets * 2 * sizeof(int32_t));
         }

@@ -468,8 +468,9 @@ def test_lds_dedup_claim_lists_overflow(hip, monkeypatch, claim_cap, buckets):
                          ids=["b6000-10x10-64buckets", "b5000-5x5x5-64buckets", "b6000-10x10x8-256buckets", "b8000-13x13x13-17Mslots"])
 def test_lds_dedup_large_batches(hip, monkeypatch, batch, fanout, part_wg):
     """Hops of more than 2^19 slots per lane (Legion's default B = 8000 class): 64 buckets per lane up to 2^22 slots, 256 beyond
-    (here 4.8 M and 17.6 M slots).  The sampling kernel samples partition tiles of 1-8 super tiles and reserves, per bucket, a run
-    of the bucket's claim list; place_kernel stages the tile's pairs in LDS and writes the runs; bit-exact like the 8-bucket class."""
+    (here 4.8 M and 17.6 M slots).  64 buckets: the sampling kernel stages a super tile's claims in LDS grouped by bucket and
+    writes them to the buckets' lists itself.  256 buckets: it samples partition tiles of 4-8 super tiles and reserves, per bucket, a
+    run of the bucket's claim list; place_kernel stages the tile's pairs in LDS and writes the runs.  Bit-exact like the 8-bucket class."""
     if part_wg is not None:                              # partition tiles of 8 super tiles, or as few as the class allows
         monkeypatch.setenv("LEGION_LDS_PART_WG", part_wg)
     wl = Workload(scale=16, edge_factor=16, dim=4, n_seeds=3 * batch + 17)
@@ -487,8 +488,8 @@ def test_lds_dedup_large_batches(hip, monkeypatch, batch, fanout, part_wg):
                          ids=["64buckets-no-room", "64buckets-some-overflow", "64buckets-3hops-known-scan", "256buckets-no-room",
                               "256buckets-some-overflow"])
 def test_lds_dedup_large_batches_list_overflow(hip, monkeypatch, batch, fanout, claim_cap, known_cap):
-    """64- / 256-bucket classes (round 5: one claim list per bucket here too, written by place_kernel into the runs the sampling
-    kernel reserved): a list that cannot take all of its bucket's claims says so by its count and that bucket's workgroup reads
+    """64- / 256-bucket classes (round 5: one claim list per bucket here too, written by the sampling kernel -- 64 buckets -- or by
+    place_kernel into the runs the sampling kernel reserved -- 256): a list that cannot take all of its bucket's claims says so by its count and that bucket's workgroup reads
     the hop's slots instead -- forced for every bucket (capacity 1) and for some (a capacity near the buckets' mean); a known
     list that outgrew its capacity makes its bucket's workgroup scan sampled_ids."""
     monkeypatch.setenv("LEGION_LDS_CLAIM_CAP", claim_cap)
