@@ -604,13 +604,9 @@ __global__ __launch_bounds__(LG_PLACE_THREADS) void place_kernel(HopParams hp, c
 // workgroups take every slot a long-lived workgroup cannot ask for again (DESIGN_HISTORY 4.2: two buckets per workgroup, a
 // persistent launch, one workgroup per lane for small hops -- all rejected and removed).
 // ------------------------------------------------------------------------------------------
-#ifndef LG_DEDUP_CLAIMS
-#define LG_DEDUP_CLAIMS 5           // claims a thread keeps in registers (a bucket of at most LG_DEDUP_CLAIMS * LG_DEDUP_THREADS is "resident")
-#endif
 #ifndef LG_DEDUP_THREADS
 #define LG_DEDUP_THREADS 1024
 #endif
-__device__ __forceinline__ uint32_t lds_slot_of(uint32_t h) { return (h * 0x9E3779B1u) >> (32 - LG_LDS_TABLE_BITS); }
 
 // (SGPR cap: two of these 16-wave workgroups share a CU only while the kernel stays within 80 SGPRs -- 82..96 admit 28 waves
 // per CU, i.e. ONE workgroup, and the kernel takes 150 us instead of 94 at hop 2 of a 256-lane group; measured, round 3)
@@ -625,13 +621,17 @@ __device__ __forceinline__ void lds_barrier()
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
 }
 
-template <int BB, int CL>      // CL: claims a thread keeps in registers (a bucket of at most CL * LG_DEDUP_THREADS claims is "resident")
+template <int BB, int CL, int TB = LG_LDS_TABLE_BITS>      // CL: claims a thread keeps in registers (a bucket of at most CL * LG_DEDUP_THREADS claims is "resident");
+                                                            // TB: log2 words of the LDS table (13: 64 KB, two workgroups per CU; 14: 128 KB, one -- the CL = 16 form, whose 85 VGPRs
+                                                            // admit one 16-wave workgroup per CU anyway)
 __global__ __launch_bounds__(LG_DEDUP_THREADS) __attribute__((amdgpu_num_sgpr(80)))
 void dedup_lists_kernel(HopParams hp, const LanePtrs* __restrict__ lanes)
 {
     constexpr int NB = 1 << BB;
     constexpr uint32_t PENDING = 0x80000000u;
-    __shared__ unsigned long long s_tab[LG_LDS_TABLE];
+    constexpr int TABLE = 1 << TB;
+    auto slot_of = [](uint32_t h) { return (h * 0x9E3779B1u) >> (32 - TB); };
+    __shared__ unsigned long long s_tab[TABLE];
     __shared__ int32_t s_full;
     const int32_t tid = threadIdx.x, b = (int32_t)blockIdx.x;
     const SampleArgs a = lane_args(hp, lanes);
@@ -652,12 +652,12 @@ void dedup_lists_kernel(HopParams hp, const LanePtrs* __restrict__ lanes)
     const int32_t n_seed = min(max(a.node_counter[INTRABATCH_CON * 3], 0), n_known);
 
     auto insert = [&](unsigned long long w, uint32_t h) {
-        uint32_t p = lds_slot_of(h);
-        for (int it = 0; it < LG_LDS_TABLE; it++) {
+        uint32_t p = slot_of(h);
+        for (int it = 0; it < TABLE; it++) {
             const unsigned long long old = __hip_atomic_fetch_min(&s_tab[p], w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             if (old == ~0ull || (uint32_t)(old >> 32) == (uint32_t)(w >> 32)) return;    // placed, or merged with the same vertex
             if (old > w) w = old;                                                          // displaced a larger word: carry it on
-            p = (p + 1) & (LG_LDS_TABLE - 1);
+            p = (p + 1) & (TABLE - 1);
         }
         s_full = 1;
     };
@@ -678,7 +678,7 @@ void dedup_lists_kernel(HopParams hp, const LanePtrs* __restrict__ lanes)
     // outcome is the same under any partition, so what finished passes already wrote is simply written again.
     const int32_t known_est = (listed ? n_listed : 0) + n_scan / NB + n_scan / (4 * NB) + 32;
     int32_t passes = 1;
-    while ((int64_t)known_est + total > (int64_t)passes * (LG_LDS_TABLE / 16 * LG_LDS_FILL_16THS)) passes <<= 1;
+    while ((int64_t)known_est + total > (int64_t)passes * (TABLE / 16 * LG_LDS_FILL_16THS)) passes <<= 1;
     // A bucket of at most CL claims per thread (the usual case) works from the registers.  A larger one is read
     // again, sweep by sweep; and a bucket whose list could not take all its claims (its count says so) reads the hop's slots
     // instead and keeps what hashes into this bucket.
@@ -706,7 +706,7 @@ void dedup_lists_kernel(HopParams hp, const LanePtrs* __restrict__ lanes)
         const uint32_t pmask = (uint32_t)passes - 1u;
         bool overflow = false;
         for (uint32_t pass = 0; pass <= pmask; pass++) {
-            for (int32_t i = tid; i < LG_LDS_TABLE; i += LG_DEDUP_THREADS) s_tab[i] = ~0ull;
+            for (int32_t i = tid; i < TABLE; i += LG_DEDUP_THREADS) s_tab[i] = ~0ull;
             if (tid == 0) s_full = 0;
             lds_barrier();
             for (int32_t i0 = 0; i0 < n_scan; i0 += LG_DEDUP_THREADS) {
@@ -758,12 +758,12 @@ void dedup_lists_kernel(HopParams hp, const LanePtrs* __restrict__ lanes)
                     const uint32_t id = (uint32_t)(pr[u] >> 32), slot = (uint32_t)pr[u];
                     const uint32_t h = lg_tab_hash((int32_t)id);
                     if (((h >> BB) & pmask) != pass) continue;
-                    uint32_t p = lds_slot_of(h);
+                    uint32_t p = slot_of(h);
                     uint32_t v = 0xFFFFFFFFu;
-                    for (int it = 0; it < LG_LDS_TABLE; it++) {
+                    for (int it = 0; it < TABLE; it++) {
                         const unsigned long long w = s_tab[p];
                         if ((uint32_t)(w >> 32) == id) { v = (uint32_t)w; break; }
-                        p = (p + 1) & (LG_LDS_TABLE - 1);
+                        p = (p + 1) & (TABLE - 1);
                     }
                     if (v != (PENDING | slot)) {          // not the lowest slot of a new vertex
                         a.slot_dst[slot] = LG_SLOT_LOSER((int32_t)id);
@@ -1173,7 +1173,9 @@ void launch_random_sample(hipStream_t s, const HopParams& p, const LanePtrs* d_l
         case LG_LDS_BITS_MEDIUM:
             sample_kernel<LG_LDS_BITS_MEDIUM, true, true><<<grid, LG_TILE, 0, s>>>(q, d_lanes);
             hipCheckError();
-            dedup_lists_kernel<LG_LDS_BITS_MEDIUM, LG_DEDUP_CLAIMS><<<dim3(1 << LG_LDS_BITS_MEDIUM, n_lanes), LG_DEDUP_THREADS, 0, s>>>(q, d_lanes);
+            // (a bucket of up to CL x 1024 claims is worked on from registers, whatever the number of passes over its sub-buckets)
+            if (p.big_buckets) dedup_lists_kernel<LG_LDS_BITS_MEDIUM, LG_DEDUP_CLAIMS_BIG, LG_LDS_TABLE_BITS + 1><<<dim3(1 << LG_LDS_BITS_MEDIUM, n_lanes), LG_DEDUP_THREADS, 0, s>>>(q, d_lanes);
+            else dedup_lists_kernel<LG_LDS_BITS_MEDIUM, LG_DEDUP_CLAIMS><<<dim3(1 << LG_LDS_BITS_MEDIUM, n_lanes), LG_DEDUP_THREADS, 0, s>>>(q, d_lanes);
             break;
         default:
             sample_kernel<LG_LDS_BITS_LARGE, false><<<pgrid, LG_TILE, 0, s>>>(q, d_lanes);

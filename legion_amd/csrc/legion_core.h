@@ -74,6 +74,10 @@
 #ifndef LG_LDS_BITS_LARGE
 #define LG_LDS_BITS_LARGE 8
 #endif
+#ifndef LG_DEDUP_CLAIMS
+#define LG_DEDUP_CLAIMS 5                       // claims a thread of a de-duplication workgroup keeps in registers (a bucket of at most LG_DEDUP_CLAIMS x 1024 is "resident")
+#endif
+#define LG_DEDUP_CLAIMS_BIG 20                  // claims a thread of a 64-bucket de-duplication workgroup keeps in registers when PreSC saw large buckets
 #define LG_LDS_SLOTS_SMALL (1 << 19)
 #define LG_LDS_SLOTS_MEDIUM (1 << 22)
 // fewest super tiles (1024 slots) a partition tile of the 64- / 256-bucket classes may have (the launch picks up to
@@ -284,6 +288,7 @@ public:
     int32_t* claim_cnt = nullptr;
     int32_t claim_cap = 0;
     int32_t lds_bucket_bits = 0;
+    int64_t last_hop_claims_hint = 0;  // PreSC's maximum of the last hop's edges (0: unknown), see lg_pool_alloc_private
     unsigned long long* known_pairs = nullptr;
     int32_t* known_cnt = nullptr;
     int32_t known_cap = 0;
@@ -690,6 +695,7 @@ struct HopParams {                  // what every lane of a launch shares
     unsigned long long* topo_transactions; // presample only: 64-byte transactions the hop's topology reads amount to
     int32_t lds_bucket_bits;        // LG_LDS_BITS_SMALL / SMALL16 / MEDIUM / LARGE (the pool's)
     int32_t lds_k;                  // super tiles per partition tile in this hop (set by launch_random_sample)
+    bool big_buckets;               // 64-bucket class: PreSC saw more claims per bucket in this (the last) hop than 5 per thread: keep 16 in registers
 };
 void launch_random_sample(hipStream_t s, const HopParams& p, const LanePtrs* d_lanes, int32_t n_lanes);
 

@@ -121,6 +121,8 @@ static void do_random_sample(hipStream_t s, GraphStorage* graph, UnifiedCache* c
     p.topo_transactions = (is_presc && cache) ? cache->Controller(dev_id)->GetTopoTransactions() : nullptr;
     p.lds_bucket_bits = pool0->lds_bucket_bits;
     p.lds_k = 1;                             // (launch_random_sample picks the hop's partition tile)
+    p.big_buckets = p.last_hop && pool0->lds_bucket_bits == LG_LDS_BITS_MEDIUM &&
+                    pool0->last_hop_claims_hint * 11 / 10 / 64 > (int64_t)LG_DEDUP_CLAIMS * 1024;
     lg::launch_random_sample(s, p, d_lanes, n_lanes);
 }
 

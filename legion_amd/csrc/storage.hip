@@ -724,7 +724,16 @@ void lg_pool_alloc_private(MemoryPool* mp, int32_t dev_id, int32_t total_num_nod
         // first touches (legion_core.h): no per-vertex state; one claim list and one known list per hash bucket
         const int64_t slots = hop_num > 0 ? per : batch_size;
         const int64_t n_super = (slots + LG_SUPER - 1) / LG_SUPER + 1;
-        mp->lds_bucket_bits = slots <= LG_LDS_SLOTS_SMALL ? LG_LDS_BITS_SMALL : (slots <= LG_LDS_SLOTS_MEDIUM ? LG_LDS_BITS_MEDIUM : LG_LDS_BITS_LARGE);
+        // Buckets per lane.  Slots say how large a hop CAN get; PreSC (when this thread's creator passed its maxima on,
+        // lg_set_pool_claims_hint) says how many claims the largest hop really has.  64 buckets serve a hop as long as a bucket's
+        // claims fit the registers of its workgroup (LG_DEDUP_CLAIMS_BIG x 1024; it then runs its passes over sub-buckets from the
+        // registers) -- e.g. B = 8000 with [15,10,5]: 6 M slots but ~0.9 M claims in hop 3 -- and the sampling kernel writes 64
+        // lists itself; beyond that 256 buckets, whose lists a second kernel writes (place_kernel).  Without PreSC's numbers: by slots.
+        const int64_t hint_claims = g_pool_claims_hint[0] * 11 / 10;      // (+10 %: buckets are not even; one that still outgrows the registers re-reads its list)
+        const bool medium = hint_claims > 0 ? hint_claims <= (int64_t)64 * LG_DEDUP_CLAIMS_BIG * 1024 && slots <= ((int64_t)1 << 24)
+                                            : slots <= LG_LDS_SLOTS_MEDIUM;
+        mp->lds_bucket_bits = slots <= LG_LDS_SLOTS_SMALL ? LG_LDS_BITS_SMALL : (medium ? LG_LDS_BITS_MEDIUM : LG_LDS_BITS_LARGE);
+        mp->last_hop_claims_hint = g_pool_claims_hint[0];
         if (mp->lds_bucket_bits == LG_LDS_BITS_SMALL) {
             // The small class has 8 or 16 buckets per lane.  Slots say how large a hop CAN get, not how many of them hold an
             // edge: on a dense graph (ogbn-products: 60 k edges per batch of 1024 where RMAT-26 has 35 k) a bucket of 8 holds
