@@ -7,7 +7,7 @@ R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.."; pwd)}; OUT=$R/gpurun_out/real_$R
 # GROUP: lanes per launch group.  Rounds 3-4 ran these shapes with 8 (a cautious guess at what fits beside 160-200 GB of tables); since round 5
 # the default is bench.py's own rule -- 524288 / B lanes, halved while the lanes of the groups in flight would take more than 0.7 of the
 # HBM the tables left free: 64 lanes at every one of these shapes -- and GROUP=8 reproduces the old lines.
-COMMON="--cpu-seconds 0 --no-boundary --presc-steps 64 --steps 8 --warmup 2 ${GROUP:+--group $GROUP}"
+COMMON="--cpu-seconds 0 --no-boundary --presc-steps 704 --steps 8 --warmup 2 ${GROUP:+--group $GROUP}"
 run() { name=$1; shift; ( time timeout -k 5 1200 python3 $R/bench.py $COMMON "$@" > $OUT/$name.json 2> $OUT/$name.err < /dev/null ) 2>&1 | grep real
   python3 - $OUT/$name.json $name <<'PY'
 import json, sys
