@@ -504,6 +504,36 @@ def test_lds_dedup_large_batches_list_overflow(hip, monkeypatch, batch, fanout, 
     gpu.close(); cpu.close()
 
 
+def test_lds_dedup_big_buckets_after_presc(hip):
+    """A pipeline created AFTER PreSC knows how many claims the largest hop really has: here ~1 M in a hop of 1.4 M slots -- more
+    than 5 x 1024 per bucket of 64, fewer than 20 x 1024 -- so its lanes get 64 buckets (by slots alone: 64 as well; a hop of 6 M
+    slots with as many claims would get 256) and the last hop's de-duplication is the form with 20 claims per thread in registers,
+    a 128 KB table and passes over sub-buckets from the registers (dedup_lists_kernel<6,20,14>).  Every lane of a group against
+    the oracle."""
+    from legion_amd import engine
+    batch, fanout, group = 6000, [10, 6, 4], 3
+    wl = Workload(scale=16, edge_factor=16, dim=4, n_seeds=(group + 1) * batch + 17)
+    gpu, cpu = GpuSide(wl, batch, fanout), CpuSide(wl, batch, fanout)
+    for it in range(2):
+        g, c = gpu.run(0, it, 0, is_presc=True), cpu.run(0, it, 0, is_presc=True)
+        compare_batches(g, c, f"presc {it}: ")
+    last_edges = int(g["edge_counter"][12] - g["edge_counter"][11])
+    assert 64 * 5 * 1024 * 10 // 11 < last_edges < 64 * 20 * 1024 * 10 // 11, last_edges        # (operators.hip / storage.hip's rules)
+    gpu.cache.candidate_selection(0, gpu.graph)
+    gpu.cache.set_capacity(2000, 200)
+    gpu.cache.fill_up(gpu.feature, gpu.graph)
+    cpu.build_cache(0, capacity=(2000, 200))
+    pipe = engine.Pipeline(gpu.graph, gpu.feature, gpu.cache, 0, batch, fanout, group, gpu.pools[0].num_ids, True, 1, weave=True)
+    assert pipe.pools[0][0].lds_buckets() == 64
+    slot = pipe.submit(0, 0)
+    pipe.wait(slot)
+    for lane in range(group):
+        compare_batches(engine.read_batch(pipe.pools[slot][lane]), cpu.run(0, lane, 0), f"big buckets lane {lane}: ")
+        assert pipe.pools[slot][lane].error() == 0
+    pipe.close()
+    gpu.close(); cpu.close()
+
+
 def test_graph_cache_keeps_modes_and_lane_counts_apart(hip):
     """the hipGraph cache of a pipeline slot used to pack (mode << 40 | active lanes << 32 | batch) into one
     word -- written when groups had at most 128 lanes.  With up to 512 lanes, (mode 0, 256 + 3 lanes) and (mode 1, 3 lanes) of
