@@ -1174,7 +1174,7 @@ void launch_random_sample(hipStream_t s, const HopParams& p, const LanePtrs* d_l
             sample_kernel<LG_LDS_BITS_MEDIUM, true, true><<<grid, LG_TILE, 0, s>>>(q, d_lanes);
             hipCheckError();
             // (a bucket of up to CL x 1024 claims is worked on from registers, whatever the number of passes over its sub-buckets)
-            if (p.big_buckets) dedup_lists_kernel<LG_LDS_BITS_MEDIUM, LG_DEDUP_CLAIMS_BIG, LG_LDS_TABLE_BITS + 1><<<dim3(1 << LG_LDS_BITS_MEDIUM, n_lanes), LG_DEDUP_THREADS, 0, s>>>(q, d_lanes);
+            if (p.big_buckets) dedup_lists_kernel<LG_LDS_BITS_MEDIUM, LG_DEDUP_CLAIMS_BIG, LG_DEDUP_BIG_TABLE_BITS><<<dim3(1 << LG_LDS_BITS_MEDIUM, n_lanes), LG_DEDUP_THREADS, 0, s>>>(q, d_lanes);
             else dedup_lists_kernel<LG_LDS_BITS_MEDIUM, LG_DEDUP_CLAIMS><<<dim3(1 << LG_LDS_BITS_MEDIUM, n_lanes), LG_DEDUP_THREADS, 0, s>>>(q, d_lanes);
             break;
         default:

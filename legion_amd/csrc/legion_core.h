@@ -77,7 +77,12 @@
 #ifndef LG_DEDUP_CLAIMS
 #define LG_DEDUP_CLAIMS 5                       // claims a thread of a de-duplication workgroup keeps in registers (a bucket of at most LG_DEDUP_CLAIMS x 1024 is "resident")
 #endif
+#ifndef LG_DEDUP_CLAIMS_BIG
 #define LG_DEDUP_CLAIMS_BIG 20                  // claims a thread of a 64-bucket de-duplication workgroup keeps in registers when PreSC saw large buckets
+#endif
+#ifndef LG_DEDUP_BIG_TABLE_BITS
+#define LG_DEDUP_BIG_TABLE_BITS 14               // ... and the log2 words of its LDS table (14: 128 KB)
+#endif
 #define LG_LDS_SLOTS_SMALL (1 << 19)
 #define LG_LDS_SLOTS_MEDIUM (1 << 22)
 // fewest super tiles (1024 slots) a partition tile of the 64- / 256-bucket classes may have (the launch picks up to
