@@ -566,7 +566,7 @@ def run_leg(c, engine, synth, stripe, replica_memory, headline, bulk=False):
         # peer_gather = bulk (pipeline.hip): the rows of other members' stripes are pushed by their OWNERS; a group runs as
         # phase A (own sampler + lists + local gather) -> barrier -> phase B (push for the others) -> barrier, eager launches
         weave = False
-        pipe = BulkPipe(engine.Pipeline(graph, feature, cache, d, B, fanout, G, feature_rows, False, args.slots, arena="plain"), use_dist)
+        pipe = BulkPipe(engine.Pipeline(graph, feature, cache, d, B, fanout, G, feature_rows, False, args.slots, arena="shared"), use_dist)
         hs = [None] * world
         dist.all_gather_object(hs, pipe.p.bulk_export())
         for r, h in enumerate(hs):

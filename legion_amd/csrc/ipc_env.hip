@@ -50,6 +50,7 @@ static_assert(offsetof(shmStruct, memHandle) == 12 && sizeof(shmStruct) == 12 + 
 // the reference-sized slab above stays valid for a trainer that knows nothing of this (it gets copies in the slot buffers).
 extern "C" int64_t lg_scattered_info(void* ptr, int32_t* n_chunks);
 extern "C" int lg_scattered_export_fd(void* ptr, int32_t index);
+extern "C" int32_t lg_scattered_serve(void* ptr, const char* name);
 typedef struct shmExt_st {
     int32_t ext_magic;                                         // LEGION_SHM_EXT_MAGIC once the mirror below is live
     int32_t ext_version;                                       // >= 2: the fields behind `counters` exist; 3: those behind `view` too
@@ -321,54 +322,9 @@ public:
         int32_t n_chunks = 0;
         const int64_t chunk_bytes = lg_scattered_info(base, &n_chunks);
         if (chunk_bytes > 0) {          // an arena of shuffled chunks: handed over as file descriptors (shmExt, version 3)
-            const int ls = socket(AF_UNIX, SOCK_STREAM | SOCK_CLOEXEC, 0);
-            if (ls < 0) return false;
-            sockaddr_un addr;
-            memset(&addr, 0, sizeof(addr));
-            addr.sun_family = AF_UNIX;
-            const int len = snprintf(addr.sun_path + 1, sizeof(addr.sun_path) - 1, "legion_arena_%d_%d", (int)getpid(), dev_id);
-            if (bind(ls, (sockaddr*)&addr, (socklen_t)(offsetof(sockaddr_un, sun_path) + 1 + len)) != 0 || listen(ls, 8) != 0) { close(ls); return false; }
-            int hip_dev = 0;
-            (void)hipGetDevice(&hip_dev);                      // (the Runner thread's device: the arena's)
-            std::thread([ls, base, n_chunks, hip_dev]() {
-                (void)hipSetDevice(hip_dev);
-                for (;;) {
-                    const int c = accept(ls, nullptr, nullptr);
-                    if (c < 0) { if (errno == EINTR) continue; return; }
-                    {   // a descriptor to device memory is a capability: only a process of the server's own user gets one (the name lives
-                        // in the abstract namespace, which has no file permissions)
-                        ucred cr;
-                        socklen_t cl = sizeof(cr);
-                        if (getsockopt(c, SOL_SOCKET, SO_PEERCRED, &cr, &cl) != 0 || cr.uid != geteuid()) {
-                            printf("legion_hip: refused a lane-arena request from uid %d (pid %d)\n", (int)cr.uid, (int)cr.pid);
-                            fflush(stdout);
-                            close(c);
-                            continue;
-                        }
-                    }
-                    bool ok = true;
-                    for (int32_t i0 = 0; i0 < n_chunks && ok; i0 += 64) {           // 64 descriptors per message
-                        const int32_t n = std::min(64, n_chunks - i0);
-                        int fds[64];
-                        for (int32_t i = 0; i < n; i++) { fds[i] = lg_scattered_export_fd(base, i0 + i); ok = ok && fds[i] >= 0; }
-                        if (ok) {
-                            char payload = 'f';
-                            iovec io = {&payload, 1};
-                            alignas(cmsghdr) char ctl[CMSG_SPACE(sizeof(int) * 64)];
-                            memset(ctl, 0, sizeof(ctl));
-                            msghdr msg;
-                            memset(&msg, 0, sizeof(msg));
-                            msg.msg_iov = &io; msg.msg_iovlen = 1; msg.msg_control = ctl; msg.msg_controllen = CMSG_SPACE(sizeof(int) * n);
-                            cmsghdr* cm = CMSG_FIRSTHDR(&msg);
-                            cm->cmsg_level = SOL_SOCKET; cm->cmsg_type = SCM_RIGHTS; cm->cmsg_len = CMSG_LEN(sizeof(int) * n);
-                            memcpy(CMSG_DATA(cm), fds, sizeof(int) * n);
-                            ok = sendmsg(c, &msg, MSG_NOSIGNAL) == 1;
-                        }
-                        for (int32_t i = 0; i < n; i++) if (fds[i] >= 0) close(fds[i]);
-                    }
-                    close(c);
-                }
-            }).detach();
+            char name[64];
+            snprintf(name, sizeof(name), "legion_arena_%d_%d", (int)getpid(), dev_id);
+            if (!lg_scattered_serve(base, name)) return false;      // (storage.hip: a thread hands the chunks' descriptors to a same-user peer)
             ext_->arena_kind[dev_id] = 1;
             ext_->arena_chunks[dev_id] = n_chunks;
             ext_->arena_chunk_bytes[dev_id] = chunk_bytes;

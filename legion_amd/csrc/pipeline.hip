@@ -19,7 +19,9 @@
 //     priorities) was measured against it in rounds 2-4 and removed in round 5: DESIGN_HISTORY.md 4.5.
 #include "legion_core.h"
 
+#include <unistd.h>
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <thread>
 #include <cstring>
@@ -28,6 +30,12 @@
 
 struct LegionLaneGroup;
 extern "C" void* d_alloc_scattered(int64_t num_bytes, int32_t chunk_mb);
+extern "C" void* d_alloc_scattered_exportable(int64_t num_bytes, int32_t chunk_mb);
+extern "C" int64_t lg_scattered_info(void* ptr, int32_t* n_chunks);
+extern "C" int32_t lg_scattered_grant(void* ptr, const int32_t* logical_devs, int32_t n);
+extern "C" int32_t lg_scattered_serve(void* ptr, const char* name);
+extern "C" void* lg_scattered_map_remote(const char* name, int32_t n_chunks, int64_t chunk_bytes);
+extern "C" void lg_scattered_unmap_remote(void* base);
 extern "C" void* lg_private_arena_begin(int64_t bytes, int32_t scatter_mb);
 extern "C" void lg_private_arena_end();
 extern "C" void lg_private_arena_free(void* handle);
@@ -65,6 +73,7 @@ struct Slot {
 // the other members of its clique -- their lane arenas and their lists, as pointers this process can dereference
 struct BulkPeer {
     char* arena = nullptr;
+    bool mapped_chunks = false;                  // arena mapped from another process's file descriptors (unmapped at destroy)
     std::vector<lg::BulkLists> lists;            // [slot], pointers into the peer's memory
 };
 struct BulkState {
@@ -74,6 +83,7 @@ struct BulkState {
     std::vector<lg::BulkLists> mine;             // [slot]
     std::vector<BulkPeer> peers;                 // [Kg]
     std::vector<hipStream_t> owner_streams;      // [Kg] in-process pull: a stream on each owner's device for THIS requester's pushes
+    int32_t served_tag = -1;                     // >= 0: this arena's chunks are served on "legion_bulk_<pid>_<tag>"
 };
 
 struct LegionPipeline {
@@ -142,10 +152,15 @@ extern "C" LegionPipeline* legion_pipeline_create(LegionGraphStorage* graph, Leg
         int64_t num_ids = batch_size, per = batch_size;
         for (int32_t h = 0; h < hop_num; h++) { per *= fanout[h]; num_ids += per; }
         p->arena.bytes = lg_pool_arena_bytes(batch_size, num_ids, feature_rows, D) * p->group_size * p->slots_n;
-        // (use_graph bit 6: the arena must be reachable from another process or GPU -- peer_gather = bulk -- and is a plain allocation;
-        //  otherwise it is built from shuffled physical chunks, storage.hip d_alloc_scattered)
+        // The arena is built from shuffled physical chunks (storage.hip d_alloc_scattered; LegionTuning.arena_scatter_mb = 0: one plain
+        // allocation).  use_graph bit 6: it must be reachable from another process or GPU (peer_gather = bulk: owners push rows into
+        // it) -- then its chunks are created exportable, other GPUs of this process are granted access when they are linked
+        // (legion_pipeline_bulk_link) and other processes map them from file descriptors (legion_pipeline_bulk_export / _import).
+        // (Round 4 kept such arenas plain: hipIpcGetMemHandle cannot export chunked memory.)
         const int32_t chunk_mb = lg::tuning().arena_scatter_mb;
-        p->arena.base = (char*)(((use_graph & 64) == 0 && chunk_mb > 0) ? d_alloc_scattered(p->arena.bytes, chunk_mb) : d_alloc_space(p->arena.bytes));
+        p->arena.base = (char*)(chunk_mb <= 0 ? d_alloc_space(p->arena.bytes)
+                                              : ((use_graph & 64) != 0 ? d_alloc_scattered_exportable(p->arena.bytes, std::max(chunk_mb, 16))
+                                                                       : d_alloc_scattered(p->arena.bytes, chunk_mb)));
         lg_set_pool_arena(&p->arena);
     }
     {   // what PreSC saw of the largest hop decides the small class's bucket count (8 or 16, storage.hip)
@@ -457,6 +472,8 @@ extern "C" void legion_pipeline_destroy(LegionPipeline* p)
                 HIP_CALL(hipStreamDestroy(p->bulk->owner_streams[o]));
             }
         SetGPUDevice(p->dev_id);
+        for (BulkPeer& peer : p->bulk->peers)
+            if (peer.mapped_chunks && peer.arena != nullptr) lg_scattered_unmap_remote(peer.arena);
         for (void* a : p->bulk->alloc) d_free_space(a);
         delete p->bulk;
     }
@@ -476,11 +493,16 @@ extern "C" void legion_pipeline_destroy(LegionPipeline* p)
 //   --- barrier --- : every lane of the slot holds its complete batch.
 // Lookup results (cache_search_buffer, hit mask) and rows are those of the direct arrangement, bit for bit.
 struct LegionBulkHandles {
-    hipIpcMemHandle_t arena;
+    hipIpcMemHandle_t arena;          // arena_kind 0: a plain allocation
     hipIpcMemHandle_t lists[4];
     int64_t cap;
     int32_t slots, member;
+    // arena_kind 1: the arena consists of arena_chunks chunks of arena_chunk_bytes, served as file descriptors on the abstract unix
+    // socket "legion_bulk_<arena_pid>_<arena_tag>"
+    int32_t arena_kind, arena_chunks, arena_pid, arena_tag;
+    int64_t arena_chunk_bytes;
 };
+static_assert(sizeof(LegionBulkHandles) <= 512, "bulk handles travel in a 512-byte buffer");
 
 extern "C" int32_t legion_pipeline_bulk_enable(LegionPipeline* p)
 {
@@ -505,6 +527,19 @@ extern "C" int32_t legion_pipeline_bulk_enable(LegionPipeline* p)
         l.fidx = (int32_t*)(a + 256 + b->Kg * b->cap * 8);
         b->alloc.push_back(a);
         b->mine.push_back(l);
+    }
+    // the other members of the clique, as owners, write rows into THIS arena: a chunked arena must grant their devices access
+    // (members that live in other processes map the chunks themselves: legion_pipeline_bulk_import)
+    if (lg_scattered_info(p->arena.base, nullptr) > 0) {
+        std::vector<int32_t> devs;
+        const int32_t base = p->dev_id / b->Kg * b->Kg;
+        for (int32_t o = 0; o < b->Kg; o++)
+            if (lg_is_local(base + o)) devs.push_back(base + o);
+        if (!lg_scattered_grant(p->arena.base, devs.data(), (int32_t)devs.size())) {
+            for (void* a : b->alloc) d_free_space(a);
+            delete b;
+            return 0;
+        }
     }
     p->bulk = b;
     return 1;
@@ -538,7 +573,24 @@ extern "C" int32_t legion_pipeline_bulk_export(LegionPipeline* p, void* out_hand
     SetGPUDevice(p->dev_id);
     LegionBulkHandles h;
     memset(&h, 0, sizeof(h));
-    lg_ipc_export(&h.arena, p->arena.base, __FILE__, __LINE__);
+    int32_t n_chunks = 0;
+    const int64_t chunk_bytes = lg_scattered_info(p->arena.base, &n_chunks);
+    if (chunk_bytes > 0) {              // an arena of shuffled chunks: other processes map it from file descriptors
+        static std::atomic<int32_t> next_tag{0};
+        if (p->bulk->served_tag < 0) {
+            p->bulk->served_tag = next_tag.fetch_add(1);
+            char name[64];
+            snprintf(name, sizeof(name), "legion_bulk_%d_%d", (int)getpid(), p->bulk->served_tag);
+            if (!lg_scattered_serve(p->arena.base, name)) { printf("legion_hip: could not serve the lane arena's chunks on %s\n", name); return 0; }
+        }
+        h.arena_kind = 1;
+        h.arena_chunks = n_chunks;
+        h.arena_chunk_bytes = chunk_bytes;
+        h.arena_pid = (int32_t)getpid();
+        h.arena_tag = p->bulk->served_tag;
+    } else {
+        lg_ipc_export(&h.arena, p->arena.base, __FILE__, __LINE__);
+    }
     for (int32_t s = 0; s < p->slots_n; s++) lg_ipc_export(&h.lists[s], p->bulk->alloc[s], __FILE__, __LINE__);
     h.cap = p->bulk->cap;
     h.slots = p->slots_n;
@@ -562,7 +614,15 @@ extern "C" int32_t legion_pipeline_bulk_import(LegionPipeline* p, const void* ha
     SetGPUDevice(p->dev_id);
     BulkPeer& peer = p->bulk->peers[h.member];
     void* a = nullptr;
-    HIP_CALL(hipIpcOpenMemHandle(&a, h.arena, hipIpcMemLazyEnablePeerAccess));
+    if (h.arena_kind == 1) {
+        char name[64];
+        snprintf(name, sizeof(name), "legion_bulk_%d_%d", h.arena_pid, h.arena_tag);
+        a = lg_scattered_map_remote(name, h.arena_chunks, h.arena_chunk_bytes);
+        if (a == nullptr) return 0;
+        peer.mapped_chunks = true;
+    } else {
+        HIP_CALL(hipIpcOpenMemHandle(&a, h.arena, hipIpcMemLazyEnablePeerAccess));
+    }
     peer.arena = (char*)a;
     peer.lists.clear();
     for (int32_t s = 0; s < h.slots; s++) {
@@ -580,6 +640,10 @@ extern "C" int32_t legion_pipeline_bulk_link(LegionPipeline* p, LegionPipeline* 
     BulkPeer& peer = p->bulk->peers[other->bulk->member];
     peer.arena = other->arena.base;
     peer.lists = other->bulk->mine;
+    // this GPU, as an owner, writes rows into the other member's arena: a chunked arena must say so (a plain one is reached through
+    // the peer access SetGPUDevice enabled)
+    const int32_t me = p->dev_id;
+    if (lg_scattered_info(other->arena.base, nullptr) > 0 && !lg_scattered_grant(other->arena.base, &me, 1)) return 0;
     return 1;
 }
 

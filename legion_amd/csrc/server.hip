@@ -700,7 +700,7 @@ private:
         // nobody else maps; LegionTuning.arena_scatter_mb = 0: one plain allocation, handed over as a hipIpcMemHandle.
         {
             const int32_t mb = tune.arena_scatter_mb;
-            const bool plain = mb <= 0 || tune.peer_gather != 0;
+            const bool plain = mb <= 0;      // (peer_gather = bulk: the other GPUs of the clique are granted access below, bulk_enable_shared)
             arena_.base = (char*)(plain ? d_alloc_space(arena_.bytes) : d_alloc_scattered_exportable(arena_.bytes, std::max(mb, 128)));
         }
         arena_.used = 0;

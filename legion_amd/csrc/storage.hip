@@ -16,6 +16,14 @@
 #include <vector>
 
 #include <cstring>
+#include <cerrno>
+#include <cstddef>
+#include <string>
+#include <thread>
+#include <sys/socket.h>
+#include <sys/un.h>
+
+#include "../trainer/vmm_probe.h"      // vmm_fd_convention(): how THIS process's HIP runtime takes a file-descriptor handle
 
 // ---- device helpers: logical device ids beyond the physical count map round-robin onto the
 //      physical GPUs, so that clique striping (Kg > 1) can be exercised on a 1-GPU box ----------
@@ -129,6 +137,188 @@ extern "C" int lg_scattered_export_fd(void* ptr, int32_t index)
     if (hipMemExportToShareableHandle(&fd, h, hipMemHandleTypePosixFileDescriptor, 0) != hipSuccess) { (void)hipGetLastError(); return -1; }
     return fd;
 }
+// ---- a scattered allocation reached from OTHER GPUs / processes -------------------------------------------------------------------
+// (the server's lane arena handed to a trainer; since round 5 also the lane arenas owners push rows into, peer_gather = bulk: round 4
+// kept those plain because hipIpcGetMemHandle cannot export memory made with hipMemCreate, and the bulk leg started 7 % behind what
+// the shuffled placement is worth to the gathers.)
+// Same process, other GPUs: the range is made accessible to those devices as well.
+extern "C" int32_t lg_scattered_grant(void* ptr, const int32_t* logical_devs, int32_t n)
+{
+    size_t bytes = 0;
+    {
+        std::lock_guard<std::mutex> lk(g_scatter_mu);
+        auto it = g_scatter_live.find(ptr);
+        if (it == g_scatter_live.end()) return 0;
+        bytes = it->second.bytes;
+    }
+    std::vector<hipMemAccessDesc> acc;
+    for (int32_t i = 0; i < n; i++) {
+        const int phys = lg_physical_device(logical_devs[i]);
+        bool seen = false;
+        for (const auto& a : acc) seen = seen || a.location.id == phys;
+        if (seen) continue;
+        hipMemAccessDesc d = {};
+        d.location.type = hipMemLocationTypeDevice;
+        d.location.id = phys;
+        d.flags = hipMemAccessFlagsProtReadWrite;
+        acc.push_back(d);
+    }
+    if (acc.empty()) return 1;
+    const hipError_t e = hipMemSetAccess(ptr, bytes, acc.data(), acc.size());
+    if (e != hipSuccess) {          // (the caller decides: a bulk leg without peer access to the arenas cannot run, everything else can)
+        (void)hipGetLastError();
+        printf("legion_hip: hipMemSetAccess for %d device(s) failed: '%s'\n", (int)acc.size(), hipGetErrorString(e));
+        return 0;
+    }
+    return 1;
+}
+
+// Other processes: a detached thread hands the chunks' file descriptors (64 per SCM_RIGHTS message, in mapping order) to whoever
+// connects to the abstract unix socket `name` -- if it is a process of the same user (SO_PEERCRED: a descriptor to device memory is a
+// capability, and the abstract namespace has no file permissions).  `ptr` must be an EXPORTABLE scattered allocation.
+extern "C" int32_t lg_scattered_serve(void* ptr, const char* name)
+{
+    int32_t n_chunks = 0;
+    if (lg_scattered_info(ptr, &n_chunks) <= 0) return 0;
+    const int ls = socket(AF_UNIX, SOCK_STREAM | SOCK_CLOEXEC, 0);
+    if (ls < 0) return 0;
+    sockaddr_un addr;
+    memset(&addr, 0, sizeof(addr));
+    addr.sun_family = AF_UNIX;
+    const int len = snprintf(addr.sun_path + 1, sizeof(addr.sun_path) - 1, "%s", name);
+    if (bind(ls, (sockaddr*)&addr, (socklen_t)(offsetof(sockaddr_un, sun_path) + 1 + len)) != 0 || listen(ls, 16) != 0) { close(ls); return 0; }
+    int hip_dev = 0;
+    (void)hipGetDevice(&hip_dev);                      // (the caller's device: the allocation's)
+    std::thread([ls, ptr, n_chunks, hip_dev]() {
+        (void)hipSetDevice(hip_dev);
+        for (;;) {
+            const int c = accept(ls, nullptr, nullptr);
+            if (c < 0) { if (errno == EINTR) continue; return; }
+            {
+                ucred cr;
+                socklen_t cl = sizeof(cr);
+                if (getsockopt(c, SOL_SOCKET, SO_PEERCRED, &cr, &cl) != 0 || cr.uid != geteuid()) {
+                    printf("legion_hip: refused a request for device-memory descriptors from uid %d (pid %d)\n", (int)cr.uid, (int)cr.pid);
+                    fflush(stdout);
+                    close(c);
+                    continue;
+                }
+            }
+            bool ok = true;
+            for (int32_t i0 = 0; i0 < n_chunks && ok; i0 += 64) {
+                const int32_t n = std::min(64, n_chunks - i0);
+                int fds[64];
+                for (int32_t i = 0; i < n; i++) { fds[i] = lg_scattered_export_fd(ptr, i0 + i); ok = ok && fds[i] >= 0; }
+                if (ok) {
+                    char payload = 'f';
+                    iovec io = {&payload, 1};
+                    alignas(cmsghdr) char ctl[CMSG_SPACE(sizeof(int) * 64)];
+                    memset(ctl, 0, sizeof(ctl));
+                    msghdr msg;
+                    memset(&msg, 0, sizeof(msg));
+                    msg.msg_iov = &io; msg.msg_iovlen = 1; msg.msg_control = ctl; msg.msg_controllen = CMSG_SPACE(sizeof(int) * n);
+                    cmsghdr* cm = CMSG_FIRSTHDR(&msg);
+                    cm->cmsg_level = SOL_SOCKET; cm->cmsg_type = SCM_RIGHTS; cm->cmsg_len = CMSG_LEN(sizeof(int) * n);
+                    memcpy(CMSG_DATA(cm), fds, sizeof(int) * n);
+                    ok = sendmsg(c, &msg, MSG_NOSIGNAL) == 1;
+                }
+                for (int32_t i = 0; i < n; i++) if (fds[i] >= 0) close(fds[i]);
+            }
+            close(c);
+        }
+    }).detach();
+    return 1;
+}
+
+// ... and the other side: connect to `name`, receive n_chunks descriptors, import and map them back to back, accessible to THIS
+// process's current device.  Returns the base address or null (why: printed).  lg_scattered_unmap_remote gives everything back.
+struct RemoteMap { size_t chunk_bytes; int32_t n_chunks; };
+static std::map<void*, RemoteMap> g_remote_maps;
+extern "C" void* lg_scattered_map_remote(const char* name, int32_t n_chunks, int64_t chunk_bytes)
+{
+    const int conv = vmm_fd_convention();
+    if (conv < 0 || n_chunks <= 0 || chunk_bytes <= 0) { printf("legion_hip: cannot import file-descriptor handles here\n"); return nullptr; }
+    const int c = socket(AF_UNIX, SOCK_STREAM | SOCK_CLOEXEC, 0);
+    if (c < 0) return nullptr;
+    sockaddr_un addr;
+    memset(&addr, 0, sizeof(addr));
+    addr.sun_family = AF_UNIX;
+    const int len = snprintf(addr.sun_path + 1, sizeof(addr.sun_path) - 1, "%s", name);
+    if (connect(c, (sockaddr*)&addr, (socklen_t)(offsetof(sockaddr_un, sun_path) + 1 + len)) != 0) { close(c); printf("legion_hip: connect(%s) failed\n", name); return nullptr; }
+    {
+        ucred cr;
+        socklen_t cl = sizeof(cr);
+        if (getsockopt(c, SOL_SOCKET, SO_PEERCRED, &cr, &cl) != 0 || cr.uid != geteuid()) { close(c); printf("legion_hip: %s belongs to another user\n", name); return nullptr; }
+    }
+    int dev = 0;
+    HIP_CALL(hipGetDevice(&dev));
+    void* base = nullptr;
+    HIP_CALL(hipMemAddressReserve(&base, (size_t)n_chunks * (size_t)chunk_bytes, 0, nullptr, 0));
+    int got = 0;
+    bool ok = true;
+    while (got < n_chunks && ok) {
+        char payload = 0;
+        iovec io = {&payload, 1};
+        alignas(cmsghdr) char ctl[CMSG_SPACE(sizeof(int) * 64)];
+        msghdr msg;
+        memset(&msg, 0, sizeof(msg));
+        msg.msg_iov = &io; msg.msg_iovlen = 1; msg.msg_control = ctl; msg.msg_controllen = sizeof(ctl);
+        if (recvmsg(c, &msg, MSG_CMSG_CLOEXEC) != 1) { ok = false; break; }
+        cmsghdr* cm = CMSG_FIRSTHDR(&msg);
+        if (cm == nullptr || cm->cmsg_level != SOL_SOCKET || cm->cmsg_type != SCM_RIGHTS) { ok = false; break; }
+        const int n = (int)((cm->cmsg_len - CMSG_LEN(0)) / sizeof(int));
+        int fds[64];
+        memcpy(fds, CMSG_DATA(cm), sizeof(int) * (size_t)n);
+        for (int i = 0; i < n; i++) {
+            if (ok && got < n_chunks) {
+                hipMemGenericAllocationHandle_t h;
+                void* os_handle = conv == 1 ? (void*)(uintptr_t)fds[i] : (void*)&fds[i];
+                if (hipMemImportFromShareableHandle(&h, os_handle, hipMemHandleTypePosixFileDescriptor) != hipSuccess) {
+                    (void)hipGetLastError();
+                    ok = false;
+                } else {
+                    if (hipMemMap((char*)base + (size_t)got * (size_t)chunk_bytes, (size_t)chunk_bytes, 0, h, 0) != hipSuccess) { (void)hipGetLastError(); ok = false; }
+                    else got++;
+                    if (hipMemRelease(h) != hipSuccess) (void)hipGetLastError();
+                }
+            }
+            close(fds[i]);
+        }
+    }
+    close(c);
+    if (ok) {
+        hipMemAccessDesc acc = {};
+        acc.location.type = hipMemLocationTypeDevice;
+        acc.location.id = dev;
+        acc.flags = hipMemAccessFlagsProtReadWrite;
+        if (hipMemSetAccess(base, (size_t)n_chunks * (size_t)chunk_bytes, &acc, 1) != hipSuccess) { (void)hipGetLastError(); ok = false; }
+    }
+    if (!ok) {
+        for (int i = 0; i < got; i++) (void)hipMemUnmap((char*)base + (size_t)i * (size_t)chunk_bytes, (size_t)chunk_bytes);
+        (void)hipMemAddressFree(base, (size_t)n_chunks * (size_t)chunk_bytes);
+        (void)hipGetLastError();
+        printf("legion_hip: mapping %d chunks of %s failed\n", n_chunks, name);
+        return nullptr;
+    }
+    std::lock_guard<std::mutex> lk(g_scatter_mu);
+    g_remote_maps[base] = RemoteMap{(size_t)chunk_bytes, n_chunks};
+    return base;
+}
+extern "C" void lg_scattered_unmap_remote(void* base)
+{
+    RemoteMap m;
+    {
+        std::lock_guard<std::mutex> lk(g_scatter_mu);
+        auto it = g_remote_maps.find(base);
+        if (it == g_remote_maps.end()) return;
+        m = it->second;
+        g_remote_maps.erase(it);
+    }
+    for (int32_t i = 0; i < m.n_chunks; i++)
+        if (hipMemUnmap((char*)base + (size_t)i * m.chunk_bytes, m.chunk_bytes) != hipSuccess) (void)hipGetLastError();
+    if (hipMemAddressFree(base, (size_t)m.n_chunks * m.chunk_bytes) != hipSuccess) (void)hipGetLastError();
+}
+
 static bool d_free_scattered(void* ptr)
 {
     ScatterLive live;

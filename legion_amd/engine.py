@@ -342,8 +342,9 @@ class Pipeline:
     """`slots` groups of `group_size` mini-batches in flight on one GPU, each group replayed as one
     hipGraph (pipeline.hip).  submit(counter0) enqueues batches counter0 .. counter0+group_size-1.
     arena: False = every lane's arrays are allocations of their own; True = all lanes' trainer-visible arrays in ONE arena built from
-    shuffled physical chunks (LegionTuning.arena_scatter_mb: the gathers' rows land all over the HBM); "plain" = the arena is one plain
-    allocation that other processes / GPUs can map (peer_gather = bulk)."""
+    shuffled physical chunks (LegionTuning.arena_scatter_mb: the gathers' rows land all over the HBM); "shared" = an arena that other GPUs and
+    processes can reach (peer_gather = bulk: owners push rows into it) -- the same shuffled chunks, created exportable; other GPUs of this
+    process are granted access at bulk_link, other processes map them from file descriptors at bulk_import ("plain": the old name)."""
 
     def __init__(self, graph, feature, cache, dev_id, batch_size, fanout, group_size, feature_rows, use_graph=True,
                  slots=2, overlap=False, split=False, weave=False, arena=False):      # (split: accepted and ignored -- removed in round 5)
@@ -354,7 +355,7 @@ class Pipeline:
                                                        int(batch_size), _i32_array(self.fanout), len(self.fanout),
                                                        self.group_size, self.slots, int(feature_rows),
                                                        (1 if use_graph else 0) | (2 if overlap else 0) | (4 if split else 0) |
-                                                       (16 if weave else 0) | (32 if arena else 0) | (64 if arena == "plain" else 0))
+                                                       (16 if weave else 0) | (32 if arena else 0) | (64 if arena in ("shared", "plain") else 0))
         self.pools = [[MemoryPool._borrowed(self._lib.legion_pipeline_pool(self.handle, s, g), dev_id,
                                             feature.total_num_nodes, batch_size, fanout, feature.float_feature_len,
                                             feature_rows) for g in range(self.group_size)]
@@ -383,7 +384,7 @@ class Pipeline:
 
     # ---- peer_gather = bulk (pipeline.hip): owner-bucketed transfer of the rows a striped gather needs from other members ----
     def bulk_enable(self):
-        """Needs arena="plain".  Allocates this GPU's per-owner request lists (one set per slot)."""
+        """Needs arena="shared".  Allocates this GPU's per-owner request lists (one set per slot)."""
         if not self._lib.legion_pipeline_bulk_enable(self.handle):
             raise RuntimeError("legion_pipeline_bulk_enable failed (pipeline not created with arena='plain'?)")
 

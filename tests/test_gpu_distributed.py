@@ -93,9 +93,13 @@ def _worker(rank, world, port, q):
         # ---- the same batches with the remote rows moved by the OWNERS (peer_gather = bulk): lists and lane arenas exchanged as
         #      IPC handles, two host barriers per launch group ------------------------------------------------------------
         G = 3
-        pipe = engine.Pipeline(graph, feature, cache, rank, batch, fanout, G, pool.num_ids, use_graph=False, slots=2, arena="plain")
+        pipe = engine.Pipeline(graph, feature, cache, rank, batch, fanout, G, pool.num_ids, use_graph=False, slots=2, arena="shared")
         pipe.bulk_enable()
-        for r, h in enumerate(all_gather_bytes(pipe.bulk_export())):
+        mine = pipe.bulk_export()
+        # (LegionBulkHandles: five 64-byte IPC handles, cap, slots, member, then arena_kind: 1 = chunks served as file descriptors)
+        kind = int(np.frombuffer(mine[336:340], dtype=np.int32)[0])
+        assert kind == (0 if os.environ.get("LEGION_ARENA_SCATTER_MB") == "0" else 1), kind
+        for r, h in enumerate(all_gather_bytes(mine)):
             if r != rank:
                 pipe.bulk_import(h)
         bulk_rows = 0
@@ -119,8 +123,12 @@ def _worker(rank, world, port, q):
         q.put((rank, "fail: " + repr(e) + "\n" + traceback.format_exc(), 0))
 
 
-@pytest.mark.parametrize("world", [2, 4])
-def test_clique_across_processes(hip, world):
+@pytest.mark.parametrize("world,arena_mb", [(2, None), (4, None), (2, "0")], ids=["2-ranks", "4-ranks", "2-ranks-plain-arenas"])
+def test_clique_across_processes(hip, world, arena_mb, monkeypatch):
+    """(the bulk leg's lane arenas: shuffled chunks that the other ranks map from file descriptors -- round 5 -- or, with
+    LEGION_ARENA_SCATTER_MB=0, one plain allocation opened through an IPC handle)"""
+    if arena_mb is not None:
+        monkeypatch.setenv("LEGION_ARENA_SCATTER_MB", arena_mb)
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()

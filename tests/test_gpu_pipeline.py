@@ -580,7 +580,7 @@ def test_pipeline_partial_group(hip):
 
 @pytest.mark.parametrize("P,mode_bits,capacity,replica_rows,D", [(2, 1, (150, 90), 0, 32), (4, 2, (64, 33), 0, 100), (8, 3, (40, 20), 0, 24),
                                                                  (4, 2, (64, 33), 40, 32), (4, 1, (100, 50), 0, 7)])
-def test_owner_bucketed_bulk_transfer_matches_direct_peer_loads(hip, col_slots, P, mode_bits, capacity, replica_rows, D):
+def test_owner_bucketed_bulk_transfer_matches_direct_peer_loads(hip, monkeypatch, col_slots, P, mode_bits, capacity, replica_rows, D):
     """LegionTuning.peer_gather = bulk (pipeline.hip, kernels_gather.hip): every member lists, per owner, the rows of that owner's
     stripe its launch group needs; the owners read their own HBM and push whole rows into the requesters' lane arenas.  Batches,
     hit masks, global slots and rows are those of the oracle's striped clique (= what direct peer loads give), on cliques of
@@ -602,7 +602,9 @@ def test_owner_bucketed_bulk_transfer_matches_direct_peer_loads(hip, col_slots, 
     Kg = cpu.Kg
     from oracle import ffi
     rows = ffi.num_ids_for(batch, fanout)
-    pipes = [engine.Pipeline(gpu.graph, gpu.feature, gpu.cache, p, batch, fanout, G, rows, use_graph=False, slots=2, arena="plain")
+    if D == 100:                                         # (one case with plain arenas; the others: shuffled chunks every member is granted access to)
+        monkeypatch.setenv("LEGION_ARENA_SCATTER_MB", "0")
+    pipes = [engine.Pipeline(gpu.graph, gpu.feature, gpu.cache, p, batch, fanout, G, rows, use_graph=False, slots=2, arena="shared")
              for p in range(P)]
     for pl in pipes:
         pl.bulk_enable()
