@@ -272,13 +272,15 @@ void legion_pipeline_wait(LegionPipeline* p, int32_t slot);                     
 LegionMemoryPool* legion_pipeline_pool(LegionPipeline* p, int32_t slot, int32_t lane);
 void legion_pipeline_destroy(LegionPipeline* p);
 /* Owner-bucketed bulk transfer for a striped feature cache (LegionTuning.peer_gather = bulk; SURVEY section 7 "hard parts"; the
- * alternative to the 512-1024-byte direct peer loads of SS/cache/cache_impl.cuh:268).  A pipeline created with use_graph bit 5 keeps
- * its lanes' trainer-visible arrays in ONE exportable allocation (the lane arena).  Per group, phase A on every member of the clique
+ * alternative to the 512-1024-byte direct peer loads of SS/cache/cache_impl.cuh:268).  A pipeline created with use_graph bits 5 + 6 keeps
+ * its lanes' trainer-visible arrays in ONE arena other GPUs and processes can reach (shuffled physical chunks created exportable; a
+ * plain allocation with LegionTuning.arena_scatter_mb = 0).  Per group, phase A on every member of the clique
  * (sampler, bucket pass that lists per owner {row inside its stripe, destination inside the requester's arena}, gather of everything
  * that is not another member's stripe) -> the caller's barrier -> phase B on every member as an OWNER (its rows, read from its own
  * HBM, pushed to the requesters with coalesced posted stores) -> barrier.  Lookup results and rows are those of the direct
- * arrangement, bit for bit.  _export / _import carry a member's IPC handles (<= 512 bytes) between processes, _link takes a member
- * that lives in the same process. */
+ * arrangement, bit for bit.  _export / _import carry what a member in another process needs (<= 512 bytes: IPC handles of the lists and
+ * of a plain arena, or the name of the abstract unix socket that serves a chunked arena's file descriptors to a same-user peer), _link
+ * takes a member that lives in the same process (and grants its GPU access to a chunked arena). */
 int32_t legion_pipeline_bulk_enable(LegionPipeline* p);
 int32_t legion_pipeline_bulk_export(LegionPipeline* p, void* out_handles, int32_t out_bytes);
 int32_t legion_pipeline_bulk_import(LegionPipeline* p, const void* handles);

@@ -406,7 +406,7 @@ __global__ __launch_bounds__(LG_TILE) __attribute__((amdgpu_num_sgpr(LG_SAMPLE_S
                                                __HIP_MEMORY_SCOPE_AGENT);
                     if (dst[u] < 0) dst[u] = -1;                               // :244
                     // slot_dst / slot_fs are read once, by the compaction two kernels later: non-temporal stores (+0.5 % on the whole job,
-                    // tools/lds_tuning/value_rounds.sh: they do not push the column arrays' lines out of the caches)
+                    // round 4, five alternating runs per build: they do not push the column arrays' lines out of the caches)
                     __builtin_nontemporal_store(dst[u], &a.slot_dst[idx]);
                     a.slot_pos[idx] = -1;      // "no position yet": compact_kernel publishes a first touch's position here (plain store: no difference)
                     if (a.slot_fs != nullptr && dst[u] >= 0) __builtin_nontemporal_store(fs[u], &a.slot_fs[idx]);     // (read for first-touch slots only)

@@ -69,7 +69,7 @@ extern "C" int32_t GetGPUDevice()
 // the lanes in one hipMalloc'ed block -- one contiguous physical range -- it runs at 0.80 of the HBM peak, with the same block built from
 // shuffled 2 MB ... 128 MB chunks at 0.87 (whole job 5.19 -> 5.57 G edges/s), better than what separate allocations get on a machine
 // whose free memory happens to be fragmented (0.84-0.85) and independent of that luck.  Not exportable with hipIpcGetMemHandle and
-// mapped for THIS device only: lanes that another process or another GPU must reach stay in plain allocations.
+// mapped for THIS device only; what another process or another GPU must reach is created exportable (below) and granted / served.
 namespace {
 struct ScatterLive { size_t bytes; std::vector<hipMemGenericAllocationHandle_t> chunks; };
 std::mutex g_scatter_mu;

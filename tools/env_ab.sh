@@ -1,6 +1,6 @@
 #!/bin/bash
 # Whole-job A/B of ONE environment variable on one box, alternating runs (no profiler):
-#   tools/env_ab.sh LEGION_WEAVE_EARLY_GATHERS 0 1 [rounds=3] [extra bench.py args]   -> gpurun_out/env_ab_<var>.txt
+#   tools/env_ab.sh LEGION_WEAVE_PRIORITY -1 0 [rounds=3] [extra bench.py args]   -> gpurun_out/env_ab_<var>.txt
 VAR=$1; A=$2; B=$3; N=${4:-3}; shift 4
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.."; pwd)}
 OUT=$R/gpurun_out/env_ab_$VAR.txt; mkdir -p $R/gpurun_out; : > $OUT

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Per-kernel timeline of a launch group (tools/trace_group.py) under two settings of ONE environment variable, same box:
-#   tools/timeline_ab.sh LEGION_LOSER_IN_DST 0 1 [extra bench.py args]   -> gpurun_out/timeline_ab_<var>.md
+#   tools/timeline_ab.sh LEGION_LDS_SMALL_BUCKETS 8 16 [extra bench.py args]   -> gpurun_out/timeline_ab_<var>.md
 VAR=$1; A=$2; B=$3; shift 3
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.."; pwd)}
 OUT=$R/gpurun_out/timeline_ab_$VAR.md; mkdir -p $R/gpurun_out; : > $OUT
