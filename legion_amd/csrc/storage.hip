@@ -71,7 +71,7 @@ extern "C" int32_t GetGPUDevice()
 // whose free memory happens to be fragmented (0.84-0.85) and independent of that luck.  Not exportable with hipIpcGetMemHandle and
 // mapped for THIS device only; what another process or another GPU must reach is created exportable (below) and granted / served.
 namespace {
-struct ScatterLive { size_t bytes; std::vector<hipMemGenericAllocationHandle_t> chunks; };
+struct ScatterLive { size_t bytes; std::vector<hipMemGenericAllocationHandle_t> chunks; std::vector<int> listeners; };      // listeners: sockets of lg_scattered_serve threads
 std::mutex g_scatter_mu;
 std::map<void*, ScatterLive> g_scatter_live;
 }
@@ -175,7 +175,8 @@ extern "C" int32_t lg_scattered_grant(void* ptr, const int32_t* logical_devs, in
 
 // Other processes: a detached thread hands the chunks' file descriptors (64 per SCM_RIGHTS message, in mapping order) to whoever
 // connects to the abstract unix socket `name` -- if it is a process of the same user (SO_PEERCRED: a descriptor to device memory is a
-// capability, and the abstract namespace has no file permissions).  `ptr` must be an EXPORTABLE scattered allocation.
+// capability, and the abstract namespace has no file permissions).  `ptr` must be an EXPORTABLE scattered allocation.  The thread and
+// its socket go when the allocation is freed (d_free_scattered shuts the socket down; the thread, woken by that, closes it).
 extern "C" int32_t lg_scattered_serve(void* ptr, const char* name)
 {
     int32_t n_chunks = 0;
@@ -187,13 +188,19 @@ extern "C" int32_t lg_scattered_serve(void* ptr, const char* name)
     addr.sun_family = AF_UNIX;
     const int len = snprintf(addr.sun_path + 1, sizeof(addr.sun_path) - 1, "%s", name);
     if (bind(ls, (sockaddr*)&addr, (socklen_t)(offsetof(sockaddr_un, sun_path) + 1 + len)) != 0 || listen(ls, 16) != 0) { close(ls); return 0; }
+    {
+        std::lock_guard<std::mutex> lk(g_scatter_mu);
+        auto it = g_scatter_live.find(ptr);
+        if (it == g_scatter_live.end()) { close(ls); return 0; }
+        it->second.listeners.push_back(ls);
+    }
     int hip_dev = 0;
     (void)hipGetDevice(&hip_dev);                      // (the caller's device: the allocation's)
     std::thread([ls, ptr, n_chunks, hip_dev]() {
         (void)hipSetDevice(hip_dev);
         for (;;) {
             const int c = accept(ls, nullptr, nullptr);
-            if (c < 0) { if (errno == EINTR) continue; return; }
+            if (c < 0) { if (errno == EINTR) continue; close(ls); return; }      // (shut down: the allocation has been freed)
             {
                 ucred cr;
                 socklen_t cl = sizeof(cr);
@@ -329,6 +336,7 @@ static bool d_free_scattered(void* ptr)
         live = std::move(it->second);
         g_scatter_live.erase(it);
     }
+    for (int ls : live.listeners) shutdown(ls, SHUT_RDWR);      // wakes the serving thread out of accept(); it closes the socket itself
     HIP_CALL(hipMemUnmap(ptr, live.bytes));
     HIP_CALL(hipMemAddressFree(ptr, live.bytes));
     for (auto h : live.chunks) HIP_CALL(hipMemRelease(h));

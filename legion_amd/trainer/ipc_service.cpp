@@ -445,6 +445,7 @@ int VmmFdConvention() { return vmm_fd_convention(); }
 // training_backend/ipc_cuda_kernel.cu:177-235 + training_backend/ipc_service.cpp:44-59
 std::vector<torch::Tensor> get_next(int feature_dim)
 {
+    TORCH_CHECK(env != nullptr, "ipc_service.get_next(): not attached -- call initialize() first (and not after finalize())");
     env->Wait();
     if (const volatile int32_t* m = env->CounterMirror()) {
         for (int i = 0; i < 16; i++) {
@@ -456,7 +457,8 @@ std::vector<torch::Tensor> get_next(int feature_dim)
         hipMemcpy(h_edge_counter, env->GetEdgeCounter(), 16 * sizeof(int32_t), hipMemcpyDeviceToHost);
         hipCheckError();
     }
-    const int hop_num = h_node_counter[INTRABATCH_CON * 3 - 1];
+    // (the counters hold INTRABATCH_CON * 3 + hop + 1 <= 16 words: six hops at most, whatever the word says)
+    const int hop_num = std::min(std::max(h_node_counter[INTRABATCH_CON * 3 - 1], 0), 16 - INTRABATCH_CON * 3 - 1);
     const int pipe = env->CurrentPipe();
     if (const volatile int64_t* vw = env->View()) {
         // the batch is where the server's launch group left it: views of its lane inside the arena
@@ -510,7 +512,7 @@ std::vector<torch::Tensor> get_next(int feature_dim)
 std::vector<int> get_block_size()
 {
     std::vector<int> ret;
-    const int hop_num = h_node_counter[INTRABATCH_CON * 3 - 1];
+    const int hop_num = std::min(std::max(h_node_counter[INTRABATCH_CON * 3 - 1], 0), 16 - INTRABATCH_CON * 3 - 1);
     for (int i = hop_num; i > 0; i--) {
         ret.push_back(h_node_counter[INTRABATCH_CON * 3 + i]);
         ret.push_back(h_node_counter[INTRABATCH_CON * 3 + i - 1]);
@@ -520,10 +522,15 @@ std::vector<int> get_block_size()
 
 std::vector<int32_t> get_steps()
 {
+    TORCH_CHECK(env != nullptr, "ipc_service.get_steps(): not attached");
     return {env->GetTrainStep(), env->GetValidStep(), env->GetTestStep()};
 }
 
-void Synchronize() { env->Post(); }
+void Synchronize()
+{
+    TORCH_CHECK(env != nullptr, "ipc_service.synchronize(): not attached");
+    env->Post();
+}
 
 PYBIND11_MODULE(TORCH_EXTENSION_NAME, m)
 {

@@ -32,14 +32,23 @@ static int vmm_fd_convention()
     if (hipMemCreate(&own, gran, &prop, 0) != hipSuccess) { (void)hipGetLastError(); return -1; }
     int fd = -1;
     if (hipMemExportToShareableHandle(&fd, own, hipMemHandleTypePosixFileDescriptor, 0) == hipSuccess && fd >= 0) {
-        // where the descriptor's copy sits: an address whose low 32 bits are no descriptor of this process (>= 2^24 or negative)
+        // where the descriptor's copy sits: an address whose low 32 bits are no descriptor of this process (>= 2^24 or negative).
+        // A static array, then the stack, then the heap: one of them lies outside the 0.4 % of the address space that fails the test.
         static int cells[4096];
+        int on_stack[2] = {-1, -1};
+        int* on_heap = new int[1 << 23];          // (32 MB of address space, untouched: wider than the 16 MB window that fails the test)
+        auto usable = [](const int* p) {
+            const int32_t low = (int32_t)(uint32_t)(uintptr_t)p;
+            return low < 0 || low >= (1 << 24);
+        };
         int* cell = nullptr;
-        for (int i = 0; i < 4096 && cell == nullptr; i++) {
-            const int32_t low = (int32_t)(uint32_t)(uintptr_t)&cells[i];
-            if (low < 0 || low >= (1 << 24)) cell = &cells[i];
-        }
+        for (int i = 0; i < 4096 && cell == nullptr; i++)
+            if (usable(&cells[i])) cell = &cells[i];
+        if (cell == nullptr && usable(&on_stack[0])) cell = &on_stack[0];
+        for (int i = 0; i < (1 << 23) && cell == nullptr; i += 1 << 20)
+            if (usable(&on_heap[i])) cell = &on_heap[i];
         hipMemGenericAllocationHandle_t h;
+        bool pointer_refused = false;
         if (cell != nullptr) {
             *cell = fd;
             if (hipMemImportFromShareableHandle(&h, (void*)cell, hipMemHandleTypePosixFileDescriptor) == hipSuccess) {
@@ -47,9 +56,12 @@ static int vmm_fd_convention()
                 g_fd_convention = 0;
             } else {
                 (void)hipGetLastError();
+                pointer_refused = true;
             }
         }
-        if (g_fd_convention < 0) {        // the pointer to a good descriptor was refused: this runtime reads osHandle as the value
+        delete[] on_heap;
+        if (pointer_refused) {            // the pointer to a good descriptor was refused: this runtime reads osHandle as the value
+                                          // (never tried blind: on a runtime that wants the pointer the value is a segmentation fault)
             if (hipMemImportFromShareableHandle(&h, (void*)(uintptr_t)fd, hipMemHandleTypePosixFileDescriptor) == hipSuccess) {
                 (void)hipMemRelease(h);
                 g_fd_convention = 1;
