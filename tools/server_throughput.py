@@ -173,8 +173,9 @@ def proc_cpu_seconds(pid):
         return None
 
 
-def thread_cpu_seconds(pid):
-    """{thread name: user + system CPU seconds} of a live process (threads of one name summed)"""
+def thread_cpu_seconds(pid, detail=None):
+    """{thread name: user + system CPU seconds} of a live process (threads of one name summed); `detail`, when given, gets
+    {name: [user seconds, system seconds, voluntary context switches]}"""
     out = {}
     try:
         for tid in os.listdir(f"/proc/{pid}/task"):
@@ -183,7 +184,22 @@ def thread_cpu_seconds(pid):
             rest = f[f.rindex(")") + 2:].split()
             if not name.startswith("lg-"):         # (the runtime's helper threads carry the process's name: tell them apart)
                 name = f"{name}:{'main' if int(tid) == int(pid) else int(tid) - int(pid)}"
-            out[name] = out.get(name, 0.0) + (int(rest[11]) + int(rest[12])) / os.sysconf("SC_CLK_TCK")
+            tck = os.sysconf("SC_CLK_TCK")
+            out[name] = out.get(name, 0.0) + (int(rest[11]) + int(rest[12])) / tck
+            if detail is not None:
+                vol = 0
+                for ln in open(f"/proc/{pid}/task/{tid}/status"):
+                    if ln.startswith("voluntary_ctxt_switches"):
+                        vol = int(ln.split()[1])
+                d = detail.setdefault(name, [0.0, 0.0, 0, ""])
+                d[0] += int(rest[11]) / tck
+                d[1] += int(rest[12]) / tck
+                d[2] += vol
+                try:        # what the thread is doing right now: "running" or the number of the system call it is in (+ wchan)
+                    sc = open(f"/proc/{pid}/task/{tid}/syscall").read().split()
+                    d[3] = (sc[0] if sc else "?") + "/" + open(f"/proc/{pid}/task/{tid}/wchan").read().strip()
+                except OSError:
+                    d[3] = "?"
     except (OSError, ValueError, IndexError):
         pass
     return out
@@ -242,12 +258,17 @@ def run_one(a, ds, tmp, batch, n_train, train, fanout, N, E, mode=""):
         # the server's CPU time by thread WHILE it serves (its runner threads end with the schedule): snapshots every 0.2 s, the
         # window = first to last snapshot that shows a runner thread
         snaps = []
+        seen = {}
 
         def watch():
             while child_p.poll() is None:
-                t = thread_cpu_seconds(server.pid)
+                det = {}
+                t = thread_cpu_seconds(server.pid, det)
                 if any(n.startswith("lg-runner") for n in t):
-                    snaps.append((time.time(), t))
+                    snaps.append((time.time(), t, det))
+                    for n, d in det.items():
+                        seen.setdefault(n, {})
+                        seen[n][d[3]] = seen[n].get(d[3], 0) + 1
                 time.sleep(0.2)
         import threading
         wt = threading.Thread(target=watch, daemon=True)
@@ -260,10 +281,16 @@ def run_one(a, ds, tmp, batch, n_train, train, fanout, N, E, mode=""):
         wt.join(timeout=2)
         child = argparse.Namespace(returncode=child_p.returncode, stdout=c_out, stderr=c_err)
         cpu1, w1 = proc_cpu_seconds(server.pid), time.time()
-        by_thread = []
+        by_thread, thread_detail = [], {}
         if len(snaps) >= 2:
-            (ta, tha), (tb, thb) = snaps[0], snaps[-1]
+            (ta, tha, da), (tb, thb, db) = snaps[0], snaps[-1]
             by_thread = sorted(((n, (thb.get(n, 0.0) - tha.get(n, 0.0)) / max(tb - ta, 1e-9)) for n in thb), key=lambda kv: -kv[1])[:6]
+            zero = [0.0, 0.0, 0, ""]
+            thread_detail = {n: {"user": round((db[n][0] - da.get(n, zero)[0]) / max(tb - ta, 1e-9), 3),
+                                 "system": round((db[n][1] - da.get(n, zero)[1]) / max(tb - ta, 1e-9), 3),
+                                 "voluntary_switches_per_s": round((db[n][2] - da.get(n, zero)[2]) / max(tb - ta, 1e-9)),
+                                 "seen_in": dict(sorted(seen.get(n, {}).items(), key=lambda kv: -kv[1])[:4])}
+                             for n, _ in by_thread if n in db}
         cl = [ln for ln in child.stdout.splitlines() if ln.startswith("{")]
         if child.returncode != 0 or not cl:
             raise RuntimeError(f"consumer failed (rc {child.returncode}): {child.stdout[-800:]} {child.stderr[-2500:]}")
@@ -276,6 +303,7 @@ def run_one(a, ds, tmp, batch, n_train, train, fanout, N, E, mode=""):
                           "consumer_reads_every_batch": bool(a.consume), "consumed_checksum": r.get("consumed_checksum"),
                           "server_cpu_cores": None if cpu0 is None or cpu1 is None else (cpu1 - cpu0) / max(w1 - w0, 1e-9),
                           "server_cpu_cores_by_thread": {n: round(v, 3) for n, v in by_thread if v > 0.005},
+                          "server_threads": thread_detail,
                           "server_cpu_cores_note": "user + system CPU seconds of the server process over the consumer's lifetime (incl. its "
                                                    "start-up, during which the server waits) / wall seconds"}), flush=True)
     finally:
