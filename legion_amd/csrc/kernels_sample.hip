@@ -376,12 +376,15 @@ __global__ __launch_bounds__(LG_TILE) __attribute__((amdgpu_num_sgpr(LG_SAMPLE_S
                         // with the launch; only a cached row's pick loads its column array's address from the table first
                         const int64_t at = h.start + (int64_t)pick;
                         if (h.slot == a.partition_count) {
+                            // (non-temporal: a pick brings a whole 128-byte line in for 4-8 bytes, and most lines are not picked from
+                            // again before they are evicted -- tools/micro/random_load_policy.hip: 48.9 -> 53.5 G random loads/s, every
+                            // allocation kind and cache-policy bit fetches the full line; whole job +1.2 % at B = 1024 and 8000)
                             if (a.colx_full != nullptr) {
-                                const lg_v2i e = a.colx_full[at];
+                                const lg_v2i e = __builtin_nontemporal_load(&a.colx_full[at]);
                                 dst[u] = e.x;
                                 fs[u] = e.y;
                             } else {
-                                dst[u] = a.col_full[at];                        // :239-243
+                                dst[u] = __builtin_nontemporal_load(&a.col_full[at]);                        // :239-243
                             }
                         } else {
                             const LG_G lg_v2i* cx = a.csr_dst_x != nullptr ? LG_GPTR(const lg_v2i, a.csr_dst_x[h.slot]) : nullptr;

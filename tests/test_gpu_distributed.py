@@ -116,6 +116,25 @@ def _worker(rank, world, port, q):
         assert bulk_rows > 0, f"rank {rank}: no row travelled by the bulk path"
         dist.barrier()                      # peers keep their stripes alive until everyone is done
         pipe.close()
+        if kind == 1:
+            # the thread that handed this arena's chunks out went with the arena: nobody answers under its name any more
+            import socket as _s
+            import time as _t
+            pid_, tag_ = (int(v) for v in np.frombuffer(mine[344:352], dtype=np.int32))
+            assert pid_ == os.getpid()
+            gone = False
+            for _ in range(100):
+                c = _s.socket(_s.AF_UNIX, _s.SOCK_STREAM)
+                try:
+                    c.connect(f"\0legion_bulk_{pid_}_{tag_}")
+                except ConnectionRefusedError:
+                    gone = True
+                finally:
+                    c.close()
+                if gone:
+                    break
+                _t.sleep(0.02)
+            assert gone, "the arena's descriptor socket outlived the arena"
         q.put((rank, "ok", remote_hits))
         dist.destroy_process_group()
     except Exception as e:                  # pragma: no cover
