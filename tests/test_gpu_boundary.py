@@ -52,14 +52,16 @@ def write_dataset(path, wl_indptr, wl_col, feats, labels, train, valid, test):
     {"LEGION_HOTNESS_REDUCE": "rccl"},                         # the clique sum of the access counters as the library's RCCL all-reduce (a 1-rank communicator here)
     {"LEGION_ARENA_SCATTER_MB": "0"},                          # the lane arena as ONE plain allocation, handed over as a hipIpcMemHandle (default: shuffled chunks, as file descriptors)
     {"LEGION_ARENA_SCATTER_MB": "0", "LEGION_RUNNER_LANES": "3"},
+    {"_FANOUT": "4,3,2", "LEGION_RUNNER_LANES": "3"},          # three hops: the groups' REST graph forks (de-duplication beside the earlier hops' gathers)
 ], ids=["default-views", "views-lanes3", "views-lanes1", "views-lanes2-two-groups", "views-lanes2-four-groups", "trainer-without-views",
         "trainer-without-views-lanes3", "gather", "gather-lanes4-16-buckets", "gather-lanes1", "operators",
-        "no-mirror", "gather-lanes5-one-stream", "gather-lanes6-shared-ho-stream", "rccl-hotness-reduce", "views-plain-arena", "views-plain-arena-lanes3"])
+        "no-mirror", "gather-lanes5-one-stream", "gather-lanes6-shared-ho-stream", "rccl-hotness-reduce", "views-plain-arena", "views-plain-arena-lanes3", "views-three-hops"])
 def test_server_binary_serves_fake_trainer(hip, tmp_path, server_env, monkeypatch):
     for k, v in server_env.items():
-        monkeypatch.setenv(k, v)
+        if not k.startswith("_"):
+            monkeypatch.setenv(k, v)
 
-    scale, D, B, fanout, epoch, cache_memory = 11, 24, 48, [5, 3], 2, 60_000
+    scale, D, B, fanout, epoch, cache_memory = 11, 24, 48, [int(f) for f in server_env.get("_FANOUT", "5,3").split(",")], 2, 60_000
     indptr, col = synth.rmat_csr_numpy(scale, 8, 20231)
     N = indptr.size - 1
     feats = synth.features_numpy(0, N, D, 7)
