@@ -1010,7 +1010,6 @@ void compact_kernel(HopParams hp, const LanePtrs* __restrict__ lanes)
         if (tid == 0) next_st = __hip_atomic_fetch_add(hs + HS_CTICKET, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #pragma unroll
         for (int u = 0; u < LG_SLOTS_PER_LANE; u++) {
-            const int32_t idx = idx0 + u * CT + tid;
             if (v[u] < 0) continue;
             const int32_t dst = v[u];
             const int32_t e = edge_base + xe + s_pre[0][u * (CT / 64) + wave] + __popcll(mv[u] & lt);
