@@ -38,25 +38,39 @@ def main():
     heavy_q = collections.Counter(k[3] for k in last).most_common(1)[0][0]
     last = [k for k in last if k[3] == heavy_q]
     last = last[len(last) // 2:]
+    # the light stream = the queue the groups' heads run on (it starts with batch_generate_kernel); every other queue belongs to the REST
+    # phase: the heavy stream and, with three hops and more, the branch of its graph that runs the last hop's de-duplication beside the
+    # earlier hops' gathers
+    heads = collections.Counter(k[3] for k in ks if "batch_generate_kernel" in k[2])
+    light_q = heads.most_common(1)[0][0] if heads else None
+    if light_q == heavy_q:
+        light_q = None
     groups = []
     for a, b in zip(last, last[1:]):
         t0, t1 = a[1], b[1]
-        heavy = [k for k in ks if k[3] == heavy_q and t0 <= k[0] < t1]
-        light = [k for k in ks if k[3] != heavy_q and k[0] < t1 and k[1] > t0]
-        # time of the interval in which at least one heavy kernel runs
-        busy = sum(min(k[1], t1) - k[0] for k in heavy)
+        heavy = [k for k in ks if k[3] != light_q and t0 <= k[0] < t1]
+        light = [k for k in ks if k[3] == light_q and k[0] < t1 and k[1] > t0]
+        # time of the interval in which at least one kernel of the REST phase runs (union: its branches overlap)
+        busy, reach = 0, t0
+        for k in heavy:
+            lo, hi = max(k[0], reach), min(k[1], t1)
+            if hi > lo:
+                busy += hi - lo
+            reach = max(reach, hi)
         light_busy = sum(min(k[1], t1) - max(k[0], t0) for k in light)
         hidden = 0
         for l in light:
+            reach = t0
             for h in heavy:
-                lo, hi = max(l[0], h[0], t0), min(l[1], h[1], t1)
+                lo, hi = max(l[0], h[0], t0, reach), min(l[1], h[1], t1)
                 if hi > lo:
                     hidden += hi - lo
+                reach = max(reach, min(h[1], t1))
         seq = []
-        prev = t0
+        reach = t0
         for k in heavy:
-            seq.append((k[2], (k[1] - k[0]) / 1e3, (k[0] - prev) / 1e3))
-            prev = k[1]
+            seq.append((k[2] + ("" if k[3] == heavy_q else " (side branch)"), (k[1] - k[0]) / 1e3, (k[0] - reach) / 1e3))
+            reach = max(reach, k[1])
         groups.append({"step": (t1 - t0) / 1e3, "busy": busy / 1e3, "light": light_busy / 1e3, "hidden": hidden / 1e3, "seq": seq,
                        "light_names": [k[2] for k in light]})
     if not groups:
@@ -66,7 +80,7 @@ def main():
     groups = [g for g in groups if len(g["seq"]) == n_seq]
     med = lambda xs: statistics.median(xs)
     lines = [f"Launch group of {lanes} lanes, heavy stream = queue {heavy_q}; medians over {len(groups)} replayed groups.", "",
-             "| # | kernel on the heavy stream | µs | idle before it, µs |", "|---|---|---|---|"]
+             "| # | kernel of the REST phase, by start | µs | idle before it, µs (negative: it starts while an earlier one still runs) |", "|---|---|---|---|"]
     for i in range(n_seq):
         lines.append("| {} | `{}` | {:.1f} | {:.1f} |".format(i, groups[0]["seq"][i][0], med([g["seq"][i][1] for g in groups]),
                                                               med([g["seq"][i][2] for g in groups])))
@@ -74,7 +88,8 @@ def main():
     light, hidden = med([g["light"] for g in groups]), med([g["hidden"] for g in groups])
     gathers = med([sum(s[1] for s in g["seq"] if "gather_kernel" in s[0]) for g in groups])
     sampler = med([sum(s[1] for s in g["seq"] if "gather_kernel" not in s[0]) for g in groups])
-    lines += ["", f"step {step:.1f} µs = heavy stream busy {busy:.1f} (gathers {gathers:.1f} + unhidden sampler chain {sampler:.1f}) + idle {step - busy:.1f}; "
+    lines += ["", f"step {step:.1f} µs = REST phase busy {busy:.1f} (its kernels add up to: gathers {gathers:.1f} + sampler chain {sampler:.1f}"
+                  f"{'' if abs(gathers + sampler - busy) < 1 else ', overlapping by %.1f' % (gathers + sampler - busy)}) + idle {step - busy:.1f}; "
                   f"light stream (the next group's head: {len(set(groups[0]['light_names']))} kernel kinds) busy {light:.1f} µs, "
                   f"{hidden:.1f} of them under a heavy kernel."]
     marks = []
