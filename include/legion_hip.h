@@ -242,8 +242,6 @@ void legion_ipc_finalize(LegionIPCEnv* e);
 typedef struct LegionLaneGroup LegionLaneGroup;
 LegionLaneGroup* legion_group_create(LegionMemoryPool** pools, int32_t n);
 void legion_group_set_iter_state(LegionLaneGroup* g, int32_t* iter_state_devptr);
-/* (weave) a second stream and two events: LG_PHASE_REST then runs the last hop's de-duplication on `side` beside the earlier hops' gathers */
-void legion_group_set_side(LegionLaneGroup* g, legion_stream_t side, void* ev_fork, void* ev_join);
 void legion_group_destroy(LegionLaneGroup* g);
 void legion_enqueue_group(legion_stream_t strm_hdl, LegionGraphStorage* graph, LegionFeatureStorage* feature,
                           LegionUnifiedCache* cache, LegionLaneGroup* group, int32_t batch_size,

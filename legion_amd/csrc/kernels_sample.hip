@@ -1134,9 +1134,7 @@ __global__ __launch_bounds__(LG_TILE) void list_known_kernel(HopParams hp, const
     }
 }
 
-// parts: 1 = the sampling kernel (+ place_kernel), 2 = the de-duplication, 4 = compaction (+ the known lists); callers that cut a hop
-// (operators.hip: the last hop's de-duplication runs beside the earlier hops' gathers) launch them in this order, on any streams
-void launch_random_sample(hipStream_t s, const HopParams& p, const LanePtrs* d_lanes, int32_t n_lanes, int32_t parts)
+void launch_random_sample(hipStream_t s, const HopParams& p, const LanePtrs* d_lanes, int32_t n_lanes)
 {
     // Fixed grids that stride over super tiles; grid.y = lanes (independent mini-batches of a group).
     int32_t max_super = (p.max_slots + LG_SUPER - 1) / LG_SUPER;
@@ -1146,7 +1144,7 @@ void launch_random_sample(hipStream_t s, const HopParams& p, const LanePtrs* d_l
     while (gx > 64 && (int64_t)gx * n_lanes > max_wg) gx /= 2;  // keep the whole launch near 2 x resident capacity
     while (gx > 1 && (int64_t)gx * n_lanes > max_wg && max_wg < 4096) gx /= 2;   // (experiments with fewer workgroups)
     const dim3 grid(gx, n_lanes);
-    if (parts & 3) {
+    {
         // buckets per lane follow the pool's largest hop (legion_core.h).  8 / 16 / 64 buckets: the sampling kernel writes the claim
         // lists itself (64: staged per super tile in LDS).  256 buckets: it samples partition tiles of K super tiles and place_kernel
         // writes the lists; K follows THIS hop: as large as the staging allows (LG_PLACE_MAX_K) unless that leaves the launch with
@@ -1163,38 +1161,34 @@ void launch_random_sample(hipStream_t s, const HopParams& p, const LanePtrs* d_l
         while (gp > 16 && (int64_t)gp * n_lanes > 16384) gp = (gp + 1) / 2;  // ... within reason
         const dim3 pgrid(gp, n_lanes);
         const size_t stage = (size_t)k * LG_SUPER * sizeof(unsigned long long);
-        const bool do_sample = (parts & 1) != 0, do_dedup = (parts & 2) != 0;
         switch (p.lds_bucket_bits) {
         case LG_LDS_BITS_SMALL:
-            if (do_sample) sample_kernel<LG_LDS_BITS_SMALL, true><<<grid, LG_TILE, 0, s>>>(q, d_lanes);
+            sample_kernel<LG_LDS_BITS_SMALL, true><<<grid, LG_TILE, 0, s>>>(q, d_lanes);
             hipCheckError();
-            if (do_dedup) dedup_lists_kernel<LG_LDS_BITS_SMALL, LG_DEDUP_CLAIMS><<<dim3(1 << LG_LDS_BITS_SMALL, n_lanes), LG_DEDUP_THREADS, 0, s>>>(q, d_lanes);
+            dedup_lists_kernel<LG_LDS_BITS_SMALL, LG_DEDUP_CLAIMS><<<dim3(1 << LG_LDS_BITS_SMALL, n_lanes), LG_DEDUP_THREADS, 0, s>>>(q, d_lanes);
             break;
         case LG_LDS_BITS_SMALL16:
-            if (do_sample) sample_kernel<LG_LDS_BITS_SMALL16, true><<<grid, LG_TILE, 0, s>>>(q, d_lanes);
+            sample_kernel<LG_LDS_BITS_SMALL16, true><<<grid, LG_TILE, 0, s>>>(q, d_lanes);
             hipCheckError();
-            if (do_dedup) dedup_lists_kernel<LG_LDS_BITS_SMALL16, LG_DEDUP_CLAIMS><<<dim3(1 << LG_LDS_BITS_SMALL16, n_lanes), LG_DEDUP_THREADS, 0, s>>>(q, d_lanes);
+            dedup_lists_kernel<LG_LDS_BITS_SMALL16, LG_DEDUP_CLAIMS><<<dim3(1 << LG_LDS_BITS_SMALL16, n_lanes), LG_DEDUP_THREADS, 0, s>>>(q, d_lanes);
             break;
         case LG_LDS_BITS_MEDIUM:
-            if (do_sample) sample_kernel<LG_LDS_BITS_MEDIUM, true, true><<<grid, LG_TILE, 0, s>>>(q, d_lanes);
+            sample_kernel<LG_LDS_BITS_MEDIUM, true, true><<<grid, LG_TILE, 0, s>>>(q, d_lanes);
             hipCheckError();
             // (a bucket of up to CL x 1024 claims is worked on from registers, whatever the number of passes over its sub-buckets)
-            if (do_dedup && p.big_buckets) dedup_lists_kernel<LG_LDS_BITS_MEDIUM, LG_DEDUP_CLAIMS_BIG, LG_DEDUP_BIG_TABLE_BITS><<<dim3(1 << LG_LDS_BITS_MEDIUM, n_lanes), LG_DEDUP_THREADS, 0, s>>>(q, d_lanes);
-            else if (do_dedup) dedup_lists_kernel<LG_LDS_BITS_MEDIUM, LG_DEDUP_CLAIMS><<<dim3(1 << LG_LDS_BITS_MEDIUM, n_lanes), LG_DEDUP_THREADS, 0, s>>>(q, d_lanes);
+            if (p.big_buckets) dedup_lists_kernel<LG_LDS_BITS_MEDIUM, LG_DEDUP_CLAIMS_BIG, LG_DEDUP_BIG_TABLE_BITS><<<dim3(1 << LG_LDS_BITS_MEDIUM, n_lanes), LG_DEDUP_THREADS, 0, s>>>(q, d_lanes);
+            else dedup_lists_kernel<LG_LDS_BITS_MEDIUM, LG_DEDUP_CLAIMS><<<dim3(1 << LG_LDS_BITS_MEDIUM, n_lanes), LG_DEDUP_THREADS, 0, s>>>(q, d_lanes);
             break;
         default:
-            if (do_sample) {
-                sample_kernel<LG_LDS_BITS_LARGE, false><<<pgrid, LG_TILE, 0, s>>>(q, d_lanes);
-                hipCheckError();
-                place_kernel<LG_LDS_BITS_LARGE><<<pgrid, LG_PLACE_THREADS, stage, s>>>(q, d_lanes);
-                hipCheckError();
-            }
-            if (do_dedup) dedup_lists_kernel<LG_LDS_BITS_LARGE, LG_DEDUP_CLAIMS><<<dim3(1 << LG_LDS_BITS_LARGE, n_lanes), LG_DEDUP_THREADS, 0, s>>>(q, d_lanes);
+            sample_kernel<LG_LDS_BITS_LARGE, false><<<pgrid, LG_TILE, 0, s>>>(q, d_lanes);
+            hipCheckError();
+            place_kernel<LG_LDS_BITS_LARGE><<<pgrid, LG_PLACE_THREADS, stage, s>>>(q, d_lanes);
+            hipCheckError();
+            dedup_lists_kernel<LG_LDS_BITS_LARGE, LG_DEDUP_CLAIMS><<<dim3(1 << LG_LDS_BITS_LARGE, n_lanes), LG_DEDUP_THREADS, 0, s>>>(q, d_lanes);
             break;
         }
     }
     hipCheckError();
-    if (!(parts & 4)) return;
     // compaction: LG_COMPACT_THREADS per workgroup (a workgroup iteration takes 4 x that many consecutive slots), as many workgroups per
     // lane as the sampling launch has per 1024 slots' worth
     {

@@ -702,7 +702,7 @@ struct HopParams {                  // what every lane of a launch shares
     int32_t lds_k;                  // super tiles per partition tile in this hop (set by launch_random_sample)
     bool big_buckets;               // 64-bucket class: PreSC saw more claims per bucket in this (the last) hop than 5 per thread: keep 16 in registers
 };
-void launch_random_sample(hipStream_t s, const HopParams& p, const LanePtrs* d_lanes, int32_t n_lanes, int32_t parts = 7);
+void launch_random_sample(hipStream_t s, const HopParams& p, const LanePtrs* d_lanes, int32_t n_lanes);
 
 // hand-over of a lane's finished batch to a trainer-visible pipe slot (kernels_gather.hip)
 struct DeliverParams {

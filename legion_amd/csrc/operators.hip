@@ -31,13 +31,10 @@ extern "C" void RandomSample(legion_stream_t strm_hdl, LegionGraphStorage* graph
 static inline UnifiedCache* cache_of(LegionUnifiedCache* c) { return reinterpret_cast<UnifiedCache*>(c); }
 
 // ---- lane-group bodies: every operator works on n lanes (n = 1 for the reference-shaped calls) ----
-// (weave) what LG_PHASE_REST needs to run the last hop's de-duplication beside the earlier hops' gathers: a second stream and two events
-struct SideLane { hipStream_t stream = nullptr; hipEvent_t fork = nullptr, join = nullptr; };
 struct LegionLaneGroup {
     std::vector<MemoryPool*> pools;
     LanePtrs* d_lanes = nullptr;      // contiguous device copy of every pool's current lane
     int32_t* iter_state = nullptr;    // device {next iteration of lane 0, stride} for graph replay, or null
-    SideLane side;
 };
 
 static bool seed_set(FeatureStorage* feature, int32_t dev_id, int32_t mode, int32_t*& all_ids, int32_t*& all_labels,
@@ -97,7 +94,7 @@ static void do_batch_generate(hipStream_t s, FeatureStorage* feature, const Lane
 
 static void do_random_sample(hipStream_t s, GraphStorage* graph, UnifiedCache* cache, const LanePtrs* d_lanes,
                              int32_t n_lanes, MemoryPool* pool0, int32_t count, int32_t dev_id, int32_t op_id,
-                             bool is_presc, int32_t parts = 7)
+                             bool is_presc)
 {
     if (op_id < INTRABATCH_CON || op_id % INTRABATCH_CON != 0 || count < 1) {
         printf("Sampling Parameters Error\n");   // counter_update's complaint, operator_impl.cu:86-88
@@ -126,7 +123,7 @@ static void do_random_sample(hipStream_t s, GraphStorage* graph, UnifiedCache* c
     p.lds_k = 1;                             // (launch_random_sample picks the hop's partition tile)
     p.big_buckets = p.last_hop && pool0->lds_bucket_bits == LG_LDS_BITS_MEDIUM &&
                     pool0->last_hop_claims_hint * 11 / 10 / 64 > (int64_t)LG_DEDUP_CLAIMS * 1024;
-    lg::launch_random_sample(s, p, d_lanes, n_lanes, parts);
+    lg::launch_random_sample(s, p, d_lanes, n_lanes);
 }
 
 static void do_feature_lookup(hipStream_t s, UnifiedCache* cache, const LanePtrs* d_lanes, int32_t n_lanes,
@@ -347,7 +344,7 @@ extern "C" void legion_draw_batch(legion_stream_t stream, const int32_t* idx, co
 static void enqueue_lanes(hipStream_t s, GraphStorage* graph, FeatureStorage* feature, UnifiedCache* cache,
                           const LanePtrs* d_lanes, int32_t n_lanes, MemoryPool* pool0, int32_t* iter_state,
                           int32_t batch_size, int32_t counter, int32_t dev_id, int32_t mode, bool is_presc,
-                          const int32_t* fanout, int32_t hop_num, int32_t phase = LG_PHASE_ALL, const SideLane* side = nullptr)
+                          const int32_t* fanout, int32_t hop_num, int32_t phase = LG_PHASE_ALL)
 {
     if (cache == nullptr && !is_presc) {
         std::cout << "invalid cache ptr\n";     // serving needs the cache object (it owns the feature tiers)
@@ -367,23 +364,6 @@ static void enqueue_lanes(hipStream_t s, GraphStorage* graph, FeatureStorage* fe
             do_batch_generate(s, feature, d_lanes, n_lanes, pool0, batch_size, counter, dev_id, mode, hop_num, iter_state);
             for (int32_t h = 0; h < last; h++)
                 do_random_sample(s, graph, cache, d_lanes, n_lanes, pool0, fanout[h], dev_id, INTRABATCH_CON * (h + 1), false);
-        } else if (phase == LG_PHASE_REST && last >= 1 && side != nullptr && side->stream != nullptr) {
-            // The last hop's de-duplication is LDS work behind one round trip to memory; the earlier hops' gathers (a seventh of the
-            // group's rows at [25,10], more with three hops) are HBM traffic and depend on nothing the last hop does: they run
-            // BESIDE each other -- the de-duplication on the side stream, the gathers here -- between the last hop's sampling
-            // kernel and its compaction.  (The gathers read the range snapshots their own hops left in hop_scratch.)
-            const int32_t op = INTRABATCH_CON * (last + 1);
-            do_random_sample(s, graph, cache, d_lanes, n_lanes, pool0, fanout[last], dev_id, op, false, 1);
-            HIP_CALL(hipEventRecord(side->fork, s));
-            HIP_CALL(hipStreamWaitEvent(side->stream, side->fork, 0));
-            do_random_sample(side->stream, graph, cache, d_lanes, n_lanes, pool0, fanout[last], dev_id, op, false, 2);
-            HIP_CALL(hipEventRecord(side->join, side->stream));
-            for (int32_t h = 0; h < last; h++)
-                do_feature_lookup(s, cache, d_lanes, n_lanes, pool0, INTRABATCH_CON * (h + 1) + 1, dev_id, true, (h == 0 && seeds_ride) ? 1 : -1);
-            HIP_CALL(hipStreamWaitEvent(s, side->join, 0));
-            do_random_sample(s, graph, cache, d_lanes, n_lanes, pool0, fanout[last], dev_id, op, false, 4);
-            lg::launch_end_of_batch(s, d_lanes, n_lanes, iter_state);
-            do_feature_lookup(s, cache, d_lanes, n_lanes, pool0, op + 1, dev_id, true, -1);
         } else {
             if (last >= 0) do_random_sample(s, graph, cache, d_lanes, n_lanes, pool0, fanout[last], dev_id, INTRABATCH_CON * (last + 1), false);
             lg::launch_end_of_batch(s, d_lanes, n_lanes, iter_state);
@@ -443,14 +423,6 @@ extern "C" LegionLaneGroup* legion_group_create(LegionMemoryPool** pools, int32_
 }
 
 extern "C" void legion_group_set_iter_state(LegionLaneGroup* g, int32_t* iter_state_devptr) { if (g) g->iter_state = iter_state_devptr; }
-// (pipeline.hip, weave) the stream and the two events LG_PHASE_REST forks with; a null stream = everything on the launch stream
-extern "C" void legion_group_set_side(LegionLaneGroup* g, legion_stream_t side, void* ev_fork, void* ev_join)
-{
-    if (!g) return;
-    g->side.stream = static_cast<hipStream_t>(side);
-    g->side.fork = static_cast<hipEvent_t>(ev_fork);
-    g->side.join = static_cast<hipEvent_t>(ev_join);
-}
 // device address of lane `lane`'s descriptor (GPURunner: the source of a hand-over copy)
 extern "C" const void* legion_group_lane_desc(LegionLaneGroup* g, int32_t lane)
 {
@@ -475,7 +447,7 @@ extern "C" void legion_enqueue_group_phase(legion_stream_t strm_hdl, LegionGraph
     if (n_active < 1 || n_active > (int32_t)group->pools.size()) n_active = (int32_t)group->pools.size();
     enqueue_lanes(static_cast<hipStream_t>(strm_hdl), reinterpret_cast<GraphStorage*>(graph),
                   reinterpret_cast<FeatureStorage*>(feature), cache_of(cache), group->d_lanes, n_active, group->pools[0],
-                  group->iter_state, batch_size, counter0, dev_id, mode, false, fanout, hop_num, phase, &group->side);
+                  group->iter_state, batch_size, counter0, dev_id, mode, false, fanout, hop_num, phase);
 }
 
 extern "C" void legion_enqueue_group_n(legion_stream_t strm_hdl, LegionGraphStorage* graph, LegionFeatureStorage* feature,

@@ -43,7 +43,6 @@ extern "C" void lg_alloc_count_begin();
 extern "C" int64_t lg_alloc_count_end();
 extern "C" LegionLaneGroup* legion_group_create(LegionMemoryPool** pools, int32_t n);
 extern "C" void legion_group_set_iter_state(LegionLaneGroup* g, int32_t* iter_state_devptr);
-extern "C" void legion_group_set_side(LegionLaneGroup* g, legion_stream_t side, void* ev_fork, void* ev_join);
 extern "C" void legion_group_destroy(LegionLaneGroup* g);
 extern "C" void legion_enqueue_group_n(legion_stream_t strm_hdl, LegionGraphStorage* graph, LegionFeatureStorage* feature,
                                        LegionUnifiedCache* cache, LegionLaneGroup* group, int32_t n_active,
@@ -62,7 +61,6 @@ struct Slot {
     hipStream_t stream = nullptr;
     hipEvent_t done = nullptr;
     hipEvent_t sampled = nullptr;             // weave: the group's head has finished
-    hipEvent_t fork = nullptr, join = nullptr;    // weave: around the last hop's de-duplication on the side stream (operators.hip, LG_PHASE_REST)
     bool busy = false;
     std::map<std::tuple<int32_t, int32_t, int32_t, int32_t>, hipGraphExec_t> exec;   // key: (phase, mode, active lanes, batch_size)
     int32_t* d_iter = nullptr;                // device {next counter0, stride}
@@ -102,7 +100,6 @@ struct LegionPipeline {
     bool sample_only = false;   // only the sampler phase runs here; the owner gathers each lane itself (GPURunner: straight
                                 // into a trainer-visible pipe slot)
     hipStream_t sample_stream = nullptr;      // weave: the light stream
-    hipStream_t side_stream = nullptr;        // weave: the last hop's de-duplication beside the earlier hops' gathers (operators.hip)
     int32_t rr = 0;
     int32_t last_slot = -1;
     bool profiling = false;
@@ -147,10 +144,6 @@ extern "C" LegionPipeline* legion_pipeline_create(LegionGraphStorage* graph, Leg
         HIP_CALL(hipDeviceGetStreamPriorityRange(&lo, &hi));
         if (wp == 0) HIP_CALL(hipStreamCreateWithFlags(&p->sample_stream, hipStreamNonBlocking))
         else HIP_CALL(hipStreamCreateWithPriority(&p->sample_stream, hipStreamNonBlocking, wp > 0 ? hi : lo));
-        // three hops and more: the last hop's de-duplication on a side stream beside the earlier hops' gathers (operators.hip).  Measured
-        // (alternating runs, one box): B = 8000 [15,10,5] 6.70-6.72 -> 6.76-6.81 G edges/s; with two hops the earlier gathers are a seventh
-        // of the rows and the graph's extra branch costs more than it hides (headline 5.60 -> 5.52, B = 8000 [25,10] 5.99 -> 5.80): not there
-        if (hop_num >= 3) HIP_CALL(hipStreamCreateWithFlags(&p->side_stream, hipStreamNonBlocking));
     }
     p->slots.resize(p->slots_n);
     p->feature_rows = feature_rows;
@@ -214,11 +207,6 @@ extern "C" LegionPipeline* legion_pipeline_create(LegionGraphStorage* graph, Leg
             sl.stream = p->slots[0].stream;
         HIP_CALL(hipEventCreateWithFlags(&sl.done, hipEventDisableTiming));
         HIP_CALL(hipEventCreateWithFlags(&sl.sampled, hipEventDisableTiming));
-        if (p->side_stream != nullptr) {
-            HIP_CALL(hipEventCreateWithFlags(&sl.fork, hipEventDisableTiming));
-            HIP_CALL(hipEventCreateWithFlags(&sl.join, hipEventDisableTiming));
-            legion_group_set_side(sl.group, (legion_stream_t)p->side_stream, (void*)sl.fork, (void*)sl.join);
-        }
     }
     lg_set_pool_claims_hint(0, 0);
     lg_set_pool_arena(nullptr);
@@ -464,7 +452,6 @@ extern "C" void legion_pipeline_destroy(LegionPipeline* p)
     if (!p) return;
     SetGPUDevice(p->dev_id);
     if (p->sample_stream) HIP_CALL(hipStreamSynchronize(p->sample_stream));
-    if (p->side_stream) HIP_CALL(hipStreamSynchronize(p->side_stream));
     for (Slot& sl : p->slots) {
         slot_wait(p, sl);
         HIP_CALL(hipStreamSynchronize(sl.stream));
@@ -475,12 +462,9 @@ extern "C" void legion_pipeline_destroy(LegionPipeline* p)
         for (MemoryPool* mp : sl.pools) legion_pool_destroy(reinterpret_cast<LegionMemoryPool*>(mp));
         HIP_CALL(hipEventDestroy(sl.done));
         HIP_CALL(hipEventDestroy(sl.sampled));
-        if (sl.fork) HIP_CALL(hipEventDestroy(sl.fork));
-        if (sl.join) HIP_CALL(hipEventDestroy(sl.join));
         if (p->overlap || &sl == &p->slots[0]) HIP_CALL(hipStreamDestroy(sl.stream));
     }
     if (p->sample_stream) HIP_CALL(hipStreamDestroy(p->sample_stream));
-    if (p->side_stream) HIP_CALL(hipStreamDestroy(p->side_stream));
     if (p->bulk) {
         for (size_t o = 0; o < p->bulk->owner_streams.size(); o++)
             if (p->bulk->owner_streams[o] != nullptr) {

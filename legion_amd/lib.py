@@ -89,7 +89,6 @@ SIGNATURES = {
     "legion_ipc_finalize": (None, [c_p]),
     "legion_group_create": (c_p, [ctypes.POINTER(c_p), c_i32]),
     "legion_group_set_iter_state": (None, [c_p, c_p]),
-    "legion_group_set_side": (None, [c_p, c_p, c_p, c_p]),
     "legion_group_destroy": (None, [c_p]),
     "legion_enqueue_group": (None, [c_p, c_p, c_p, c_p, c_p, c_i32, c_i32, c_i32, c_i32, P_I32, c_i32]),
     "legion_pipeline_create": (c_p, [c_p, c_p, c_p, c_i32, c_i32, P_I32, c_i32, c_i32, c_i32, c_i64, c_i32]),

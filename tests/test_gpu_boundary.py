@@ -52,7 +52,7 @@ def write_dataset(path, wl_indptr, wl_col, feats, labels, train, valid, test):
     {"LEGION_HOTNESS_REDUCE": "rccl"},                         # the clique sum of the access counters as the library's RCCL all-reduce (a 1-rank communicator here)
     {"LEGION_ARENA_SCATTER_MB": "0"},                          # the lane arena as ONE plain allocation, handed over as a hipIpcMemHandle (default: shuffled chunks, as file descriptors)
     {"LEGION_ARENA_SCATTER_MB": "0", "LEGION_RUNNER_LANES": "3"},
-    {"_FANOUT": "4,3,2", "LEGION_RUNNER_LANES": "3"},          # three hops: the groups' REST graph forks (de-duplication beside the earlier hops' gathers)
+    {"_FANOUT": "4,3,2", "LEGION_RUNNER_LANES": "3"},          # three hops through the server (known lists across two hops, three gathers per group)
 ], ids=["default-views", "views-lanes3", "views-lanes1", "views-lanes2-two-groups", "views-lanes2-four-groups", "trainer-without-views",
         "trainer-without-views-lanes3", "gather", "gather-lanes4-16-buckets", "gather-lanes1", "operators",
         "no-mirror", "gather-lanes5-one-stream", "gather-lanes6-shared-ho-stream", "rccl-hotness-reduce", "views-plain-arena", "views-plain-arena-lanes3", "views-three-hops"])

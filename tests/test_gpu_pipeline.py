@@ -243,8 +243,7 @@ def test_full_width_groups_against_the_oracle(hip, batch, fanout, group):
     under hipGraph replay -- with EVERY lane of two consecutive groups compared with the oracle: the
     ticketed tiles and the decoupled look-back of compact_kernel, the winners' published positions and the software-pipelined
     gather under the concurrency they run with in the bench (250 super tiles per lane at hop 2, 128 lanes in flight).  The
-    second shape has three hops in the 64-bucket class (staged placement, known lists across two hops); with three and four hops
-    the REST graph forks (the last hop's de-duplication on a side stream beside the earlier hops' gathers, operators.hip)."""
+    second shape has three hops in the 64-bucket class (staged placement, known lists across two hops), the third four hops."""
     from legion_amd import engine
     wl = Workload(scale=19, edge_factor=16, dim=16, n_seeds=2 * group * batch + batch)
     gpu, cpu = GpuSide(wl, batch, fanout), CpuSide(wl, batch, fanout)
