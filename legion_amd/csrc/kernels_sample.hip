@@ -627,7 +627,7 @@ __device__ __forceinline__ void lds_barrier()
 template <int BB, int CL, int TB = LG_LDS_TABLE_BITS>      // CL: claims a thread keeps in registers (a bucket of at most CL * LG_DEDUP_THREADS claims is "resident");
                                                             // TB: log2 words of the LDS table (13: 64 KB, two workgroups per CU; 14: 128 KB, one -- the CL = 16 form, whose 85 VGPRs
                                                             // admit one 16-wave workgroup per CU anyway)
-__global__ __launch_bounds__(LG_DEDUP_THREADS) __attribute__((amdgpu_num_sgpr(80)))
+__global__ __launch_bounds__(LG_DEDUP_THREADS, (CL <= LG_DEDUP_CLAIMS_MID ? 8 : 4)) __attribute__((amdgpu_num_sgpr(80)))      // (8 waves per SIMD = two workgroups per CU: at most 64 VGPRs)
 void dedup_lists_kernel(HopParams hp, const LanePtrs* __restrict__ lanes)
 {
     constexpr int NB = 1 << BB;
@@ -1176,7 +1176,8 @@ void launch_random_sample(hipStream_t s, const HopParams& p, const LanePtrs* d_l
             sample_kernel<LG_LDS_BITS_MEDIUM, true, true><<<grid, LG_TILE, 0, s>>>(q, d_lanes);
             hipCheckError();
             // (a bucket of up to CL x 1024 claims is worked on from registers, whatever the number of passes over its sub-buckets)
-            if (p.big_buckets) dedup_lists_kernel<LG_LDS_BITS_MEDIUM, LG_DEDUP_CLAIMS_BIG, LG_DEDUP_BIG_TABLE_BITS><<<dim3(1 << LG_LDS_BITS_MEDIUM, n_lanes), LG_DEDUP_THREADS, 0, s>>>(q, d_lanes);
+            if (p.dedup_claims == LG_DEDUP_CLAIMS_BIG) dedup_lists_kernel<LG_LDS_BITS_MEDIUM, LG_DEDUP_CLAIMS_BIG, LG_DEDUP_BIG_TABLE_BITS><<<dim3(1 << LG_LDS_BITS_MEDIUM, n_lanes), LG_DEDUP_THREADS, 0, s>>>(q, d_lanes);
+            else if (p.dedup_claims == LG_DEDUP_CLAIMS_MID) dedup_lists_kernel<LG_LDS_BITS_MEDIUM, LG_DEDUP_CLAIMS_MID><<<dim3(1 << LG_LDS_BITS_MEDIUM, n_lanes), LG_DEDUP_THREADS, 0, s>>>(q, d_lanes);
             else dedup_lists_kernel<LG_LDS_BITS_MEDIUM, LG_DEDUP_CLAIMS><<<dim3(1 << LG_LDS_BITS_MEDIUM, n_lanes), LG_DEDUP_THREADS, 0, s>>>(q, d_lanes);
             break;
         default:

@@ -77,8 +77,11 @@
 #ifndef LG_DEDUP_CLAIMS
 #define LG_DEDUP_CLAIMS 5                       // claims a thread of a de-duplication workgroup keeps in registers (a bucket of at most LG_DEDUP_CLAIMS x 1024 is "resident")
 #endif
+#ifndef LG_DEDUP_CLAIMS_MID
+#define LG_DEDUP_CLAIMS_MID 10                  // ... 10 where PreSC saw buckets of 5-10 k claims (B = 8000 on the less repetitive graphs: uk-union size, RMAT-28): 64 KB
+#endif                                          // table, two workgroups per CU as with 5
 #ifndef LG_DEDUP_CLAIMS_BIG
-#define LG_DEDUP_CLAIMS_BIG 20                  // claims a thread of a 64-bucket de-duplication workgroup keeps in registers when PreSC saw large buckets
+#define LG_DEDUP_CLAIMS_BIG 20                  // ... 20 beyond (B = 8000 [15,10,5] on RMAT-26: 15 k per bucket)
 #endif
 #ifndef LG_DEDUP_BIG_TABLE_BITS
 #define LG_DEDUP_BIG_TABLE_BITS 14               // ... and the log2 words of its LDS table (14: 128 KB)
@@ -700,7 +703,7 @@ struct HopParams {                  // what every lane of a launch shares
     unsigned long long* topo_transactions; // presample only: 64-byte transactions the hop's topology reads amount to
     int32_t lds_bucket_bits;        // LG_LDS_BITS_SMALL / SMALL16 / MEDIUM / LARGE (the pool's)
     int32_t lds_k;                  // super tiles per partition tile in this hop (set by launch_random_sample)
-    bool big_buckets;               // 64-bucket class: PreSC saw more claims per bucket in this (the last) hop than 5 per thread: keep 16 in registers
+    int32_t dedup_claims;           // 64-bucket class: claims per thread the (last) hop's de-duplication keeps in registers: LG_DEDUP_CLAIMS, _MID or _BIG by what PreSC saw
 };
 void launch_random_sample(hipStream_t s, const HopParams& p, const LanePtrs* d_lanes, int32_t n_lanes);
 
