@@ -1185,7 +1185,8 @@ void launch_random_sample(hipStream_t s, const HopParams& p, const LanePtrs* d_l
             hipCheckError();
             place_kernel<LG_LDS_BITS_LARGE><<<pgrid, LG_PLACE_THREADS, stage, s>>>(q, d_lanes);
             hipCheckError();
-            dedup_lists_kernel<LG_LDS_BITS_LARGE, LG_DEDUP_CLAIMS><<<dim3(1 << LG_LDS_BITS_LARGE, n_lanes), LG_DEDUP_THREADS, 0, s>>>(q, d_lanes);
+            if (p.dedup_claims == LG_DEDUP_CLAIMS_MID) dedup_lists_kernel<LG_LDS_BITS_LARGE, LG_DEDUP_CLAIMS_MID><<<dim3(1 << LG_LDS_BITS_LARGE, n_lanes), LG_DEDUP_THREADS, 0, s>>>(q, d_lanes);
+            else dedup_lists_kernel<LG_LDS_BITS_LARGE, LG_DEDUP_CLAIMS><<<dim3(1 << LG_LDS_BITS_LARGE, n_lanes), LG_DEDUP_THREADS, 0, s>>>(q, d_lanes);
             break;
         }
     }

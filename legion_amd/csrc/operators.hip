@@ -121,12 +121,12 @@ static void do_random_sample(hipStream_t s, GraphStorage* graph, UnifiedCache* c
     p.topo_transactions = (is_presc && cache) ? cache->Controller(dev_id)->GetTopoTransactions() : nullptr;
     p.lds_bucket_bits = pool0->lds_bucket_bits;
     p.lds_k = 1;                             // (launch_random_sample picks the hop's partition tile)
-    // 64-bucket class, last hop: how many claims a de-duplication thread keeps in registers follows what PreSC saw in that hop (+10 %:
-    // buckets are not even; a bucket that still outgrows its workgroup's registers re-reads its list)
+    // 64- and 256-bucket classes, last hop: how many claims a de-duplication thread keeps in registers follows what PreSC saw in that hop
+    // (+10 %: buckets are not even; a bucket that still outgrows its workgroup's registers re-reads its list, sweep by sweep)
     p.dedup_claims = LG_DEDUP_CLAIMS;
-    if (p.last_hop && pool0->lds_bucket_bits == LG_LDS_BITS_MEDIUM) {
-        const int64_t per_bucket = pool0->last_hop_claims_hint * 11 / 10 / 64;
-        if (per_bucket > (int64_t)LG_DEDUP_CLAIMS_MID * 1024) p.dedup_claims = LG_DEDUP_CLAIMS_BIG;
+    if (p.last_hop && (pool0->lds_bucket_bits == LG_LDS_BITS_MEDIUM || pool0->lds_bucket_bits == LG_LDS_BITS_LARGE)) {
+        const int64_t per_bucket = (pool0->last_hop_claims_hint * 11 / 10) >> pool0->lds_bucket_bits;
+        if (per_bucket > (int64_t)LG_DEDUP_CLAIMS_MID * 1024 && pool0->lds_bucket_bits == LG_LDS_BITS_MEDIUM) p.dedup_claims = LG_DEDUP_CLAIMS_BIG;
         else if (per_bucket > (int64_t)LG_DEDUP_CLAIMS * 1024) p.dedup_claims = LG_DEDUP_CLAIMS_MID;
     }
     lg::launch_random_sample(s, p, d_lanes, n_lanes);
