@@ -504,30 +504,31 @@ def test_lds_dedup_large_batches_list_overflow(hip, monkeypatch, batch, fanout, 
     gpu.close(); cpu.close()
 
 
-@pytest.mark.parametrize("batch,per_thread", [(6000, 10), (9000, 20)])
-def test_lds_dedup_big_buckets_after_presc(hip, batch, per_thread):
+@pytest.mark.parametrize("batch,scale,per_thread,buckets", [(6000, 16, 10, 64), (9000, 16, 20, 64), (18000, 17, 10, 256)])
+def test_lds_dedup_big_buckets_after_presc(hip, batch, scale, per_thread, buckets):
     """A pipeline created AFTER PreSC knows how many claims the largest hop really has: 0.45 M (0.67 M) in a hop of 1.4 M (2.2 M)
     slots -- more than 5 x 1024 per bucket of 64 -- so its lanes get 64 buckets and the last hop's de-duplication keeps 10 (20)
     claims per thread in registers: dedup_lists_kernel<6,10,13> (64 KB table, two workgroups per CU) for buckets of up to 10 k
-    claims, dedup_lists_kernel<6,20,14> (128 KB table, passes over sub-buckets from the registers) beyond.  Every lane of a group
-    against the oracle."""
+    claims, dedup_lists_kernel<6,20,14> (128 KB table, passes over sub-buckets from the registers) beyond.  Third case: more than
+    64 x 20 x 1024 claims -- 256 buckets (place_kernel) and, their buckets holding more than 5 k claims, dedup_lists_kernel<8,10,13>.
+    Every lane of a group against the oracle."""
     from legion_amd import engine
-    fanout, group = [10, 6, 4], 3
-    wl = Workload(scale=16, edge_factor=16, dim=4, n_seeds=(group + 1) * batch + 17)
+    fanout, group = [10, 6, 4], 3 if batch < 10000 else 2
+    wl = Workload(scale=scale, edge_factor=16, dim=4, n_seeds=(group + 1) * batch + 17)
     gpu, cpu = GpuSide(wl, batch, fanout), CpuSide(wl, batch, fanout)
     last_edges = 0
     for it in range(2):
         g, c = gpu.run(0, it, 0, is_presc=True), cpu.run(0, it, 0, is_presc=True)
         compare_batches(g, c, f"presc {it}: ")
         last_edges = max(last_edges, int(g["edge_counter"][12] - g["edge_counter"][11]))
-    lo, hi = {10: (5, 10), 20: (10, 20)}[per_thread]
+    lo, hi = {(10, 64): (5, 10), (20, 64): (10, 20), (10, 256): (20, 160)}[(per_thread, buckets)]
     assert 64 * lo * 1024 * 10 // 11 < last_edges <= 64 * hi * 1024 * 10 // 11, last_edges        # (operators.hip / storage.hip's rules)
     gpu.cache.candidate_selection(0, gpu.graph)
     gpu.cache.set_capacity(2000, 200)
     gpu.cache.fill_up(gpu.feature, gpu.graph)
     cpu.build_cache(0, capacity=(2000, 200))
     pipe = engine.Pipeline(gpu.graph, gpu.feature, gpu.cache, 0, batch, fanout, group, gpu.pools[0].num_ids, True, 1, weave=True)
-    assert pipe.pools[0][0].lds_buckets() == 64
+    assert pipe.pools[0][0].lds_buckets() == buckets
     slot = pipe.submit(0, 0)
     pipe.wait(slot)
     for lane in range(group):
