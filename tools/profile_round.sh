@@ -6,6 +6,11 @@ R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.."; pwd)}
 OUT=$R/gpurun_out/prof_$RND
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
+# 0. a minute of load first (the driver's bench also follows its GPU test run): about every second fresh box of this pool runs its first
+#    50-70 s of GPU work 2-10 % slow -- sampler and gathers alike -- and then settles (profiles/r05/README.md); WARM=0 skips this
+if [ "${WARM:-1}" != "0" ]; then
+  for i in 1 2 3; do timeout -k 5 300 python3 $R/bench.py --cpu-seconds 0 --no-boundary --no-verify --steps 20 --warmup 5 2> /dev/null < /dev/null | tail -1 | cut -c1-120; done > $OUT/warm_up_runs.txt
+fi
 # 1. the bench line as the driver runs it, and at its defaults
 timeout -k 5 600 python3 $R/bench.py --gpus 1 --steps 20 --warmup 5 2> $OUT/bench_driver_args.err < /dev/null | tail -1 > $OUT/bench_driver_args.json
 timeout -k 5 600 python3 $R/bench.py 2> $OUT/bench_default.err < /dev/null | tail -1 > $OUT/bench_default.json
