@@ -1143,6 +1143,14 @@ void launch_random_sample(hipStream_t s, const HopParams& p, const LanePtrs* d_l
     const int max_wg = tuning().sample_max_wg;
     while (gx > 64 && (int64_t)gx * n_lanes > max_wg) gx /= 2;  // keep the whole launch near 2 x resident capacity
     while (gx > 1 && (int64_t)gx * n_lanes > max_wg && max_wg < 4096) gx /= 2;   // (experiments with fewer workgroups)
+    {
+        // Equal workgroups that fill the machine about twice leave its second round half empty: between one and six rounds' worth
+        // (8 workgroups of this kernel per CU x 256 CUs), take ONE round of longer-lived workgroups instead.  Measured (one_round_ab.txt):
+        // 64 lanes at B = 8000 (3 904 -> 2 048 workgroups) +1 %, 128 lanes at B = 4096 +1.4 %, 256 lanes and D = 256 the same within
+        // the noise; 512 lanes at B = 1024 (15 rounds) are not touched.
+        const int64_t resident = 8 * 256, total = (int64_t)gx * n_lanes;
+        if (total > resident && total < 6 * resident) gx = (int32_t)std::max<int64_t>(1, resident / n_lanes);
+    }
     const dim3 grid(gx, n_lanes);
     {
         // buckets per lane follow the pool's largest hop (legion_core.h).  8 / 16 / 64 buckets: the sampling kernel writes the claim
