@@ -1,7 +1,7 @@
 """Builds the in-tree native artefacts for gfx950 with hipcc.
 
-    python -m legion_amd.build            # liblegion_hip.so + bin/sampling_server
-    python -m legion_amd.build --trainer  # also the `ipc_service` torch extension
+    python -m legion_amd.build            # liblegion_hip.so + bin/sampling_server + the `ipc_service` torch extension, each when its
+                                          # sources are newer (--no-trainer: skip the extension; --force: everything)
 
 hipcc cross-compiles without a GPU.  Outputs stay inside the package directory (git-ignored,
 shipped to the GPU box by gpurun).
@@ -126,5 +126,5 @@ if __name__ == "__main__":
         build_variant(sys.argv[i + 1], sys.argv[i + 2:])
         sys.exit(0)
     build_lib(force="--force" in sys.argv)
-    if "--trainer" in sys.argv:
-        build_trainer()
+    if "--no-trainer" not in sys.argv:      # (by its time stamps, like the library: a stale trainer end once rode along for half a day of GPU runs)
+        build_trainer(force="--force" in sys.argv)

@@ -23,7 +23,7 @@
 #include <sys/socket.h>
 #include <sys/un.h>
 
-#include "../trainer/vmm_probe.h"      // vmm_fd_convention(): how THIS process's HIP runtime takes a file-descriptor handle
+#include "../trainer/vmm_probe.h"      // vmm_import_fd(): imports a received descriptor whichever way THIS process's HIP runtime takes one
 
 // ---- device helpers: logical device ids beyond the physical count map round-robin onto the
 //      physical GPUs, so that clique striping (Kg > 1) can be exercised on a 1-GPU box ----------
@@ -243,8 +243,7 @@ struct RemoteMap { size_t chunk_bytes; int32_t n_chunks; };
 static std::map<void*, RemoteMap> g_remote_maps;
 extern "C" void* lg_scattered_map_remote(const char* name, int32_t n_chunks, int64_t chunk_bytes)
 {
-    const int conv = vmm_fd_convention();
-    if (conv < 0 || n_chunks <= 0 || chunk_bytes <= 0) { printf("legion_hip: cannot import file-descriptor handles here\n"); return nullptr; }
+    if (n_chunks <= 0 || chunk_bytes <= 0) return nullptr;
     const int c = socket(AF_UNIX, SOCK_STREAM | SOCK_CLOEXEC, 0);
     if (c < 0) return nullptr;
     sockaddr_un addr;
@@ -279,8 +278,7 @@ extern "C" void* lg_scattered_map_remote(const char* name, int32_t n_chunks, int
         for (int i = 0; i < n; i++) {
             if (ok && got < n_chunks) {
                 hipMemGenericAllocationHandle_t h;
-                void* os_handle = conv == 1 ? (void*)(uintptr_t)fds[i] : (void*)&fds[i];
-                if (hipMemImportFromShareableHandle(&h, os_handle, hipMemHandleTypePosixFileDescriptor) != hipSuccess) {
+                if (vmm_import_fd(&h, fds[i]) != hipSuccess) {
                     (void)hipGetLastError();
                     ok = false;
                 } else {

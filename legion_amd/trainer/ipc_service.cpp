@@ -98,7 +98,7 @@ struct TrainerOptions {
     }
 };
 
-#include "vmm_probe.h"      // vmm_fd_convention(): how THIS process's HIP runtime takes a file-descriptor handle
+#include "vmm_probe.h"      // vmm_import_fd(): imports a received descriptor whichever way THIS process's HIP runtime takes one
 
 // The server's lane arena as chunks: connect, receive the descriptors (64 per message), import and map them in order.  An import
 // handle is released as soon as its chunk is mapped (the mapping keeps the memory alive, nothing else has to); on any failure
@@ -112,8 +112,6 @@ static void unmap_arena_chunks(void* base, int n_mapped, int n_chunks, long long
 }
 static void* map_arena_chunks(const std::string& suffix, int pid, int dev, int n_chunks, long long chunk_bytes, int hip_dev, std::string* why)
 {
-    const int conv = vmm_fd_convention();
-    if (conv < 0) { *why = "this HIP runtime imports no file-descriptor handles"; return nullptr; }
     const int c = socket(AF_UNIX, SOCK_STREAM | SOCK_CLOEXEC, 0);
     if (c < 0) { *why = "socket()"; return nullptr; }
     sockaddr_un addr;
@@ -147,8 +145,7 @@ static void* map_arena_chunks(const std::string& suffix, int pid, int dev, int n
         for (int i = 0; i < n; i++) {
             if (ok && got < n_chunks) {
                 hipMemGenericAllocationHandle_t h;
-                void* os_handle = conv == 1 ? (void*)(uintptr_t)fds[i] : (void*)&fds[i];
-                if (hipMemImportFromShareableHandle(&h, os_handle, hipMemHandleTypePosixFileDescriptor) != hipSuccess) {
+                if (vmm_import_fd(&h, fds[i]) != hipSuccess) {
                     (void)hipGetLastError();
                     *why = "hipMemImportFromShareableHandle";
                     ok = false;

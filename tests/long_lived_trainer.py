@@ -46,7 +46,8 @@ def main():
     torch.cuda.set_device(0)
     torch.zeros(1, device="cuda:0")
     torch.cuda.synchronize()
-    print("vmm_fd_convention", ipc_service.vmm_fd_convention(), flush=True)
+    # (no ipc_service.vmm_fd_convention() here: that explicit probe imports a chunk this process exported itself; the product path learns
+    # the convention from the first descriptor the server sends, and this process should do nothing a trainer would not)
     dig = lambda t: int.from_bytes(hashlib.blake2b(t.contiguous().cpu().numpy().tobytes(), digest_size=8).digest(), "little")
     level = None                                # free memory after the first life (everything of this process is warm by then)
     for life in range(lives):
