@@ -13,10 +13,11 @@
 //   * sample_kernel: a workgroup owns 1024 consecutive slots, four per lane; the tile's frontier row
 //     headers (row start, degree, CSR slot) are staged once in LDS; the minstd draw is a table-driven
 //     modular power + one IEEE double divide; the picks (claims: vertex, slot) are written grouped by hash bucket into one
-//     list per bucket of the lane (8 / 16 buckets: here; 64 / 256 buckets: by place_kernel);
+//     list per bucket of the lane (8 / 16 buckets: from the registers; 64: staged per super tile in LDS; 256: by place_kernel);
 //   * dedup_lists_kernel: a (lane, bucket)'s claims de-duplicated in an LDS table against the batch's known vertices: the LOWEST
 //     slot owns a first touch (deterministic, unlike atomicOr on a bitmap); every other claim's slot is marked a loser.  No
-//     per-vertex state in memory at all: nothing to clear, nothing that scales with the graph;
+//     per-vertex state in memory at all: nothing to clear, nothing that scales with the graph.  5, 10 or 20 claims per thread in
+//     registers, by how many claims PreSC saw per bucket in the last hop (operators.hip);
 //   * compact_kernel: ONE pass -- tiles handed out by ticket, counts of valid edges / first touches by wave ballots, the
 //     prefix over a lane's tiles by decoupled look-back, then the slot-ordered compaction of edges (global ids + both local
 //     positions) and of new nodes, + the next hop's row headers; its last workgroup does the counter_update state machine,
