@@ -169,6 +169,21 @@ void legion_cache_cost_model(LegionUnifiedCache* c, LegionFeatureStorage* featur
 void legion_cache_set_capacity(LegionUnifiedCache* c, int32_t node_capacity, int32_t edge_capacity);
 /* SS/cache/cache.cu:553-611 */
 void legion_cache_fill_up(LegionUnifiedCache* c, LegionFeatureStorage* feature, LegionGraphStorage* graph);
+/* The hybrid CPU-cache / GPU-cache tier: UnifiedCache::HybridInit (SS/cache/cache.cu:614-670) with
+ * PreSCCacheController::HybridInsert (:138-153, HybridInitPair SS/cache/cache_impl.cuh:113-123) INSTEAD OF candidate_selection +
+ * cost_model + fill_up -- the call the reference keeps commented out at SS/engine/server.cu:112.  Every GPU orders the vertices by
+ * its OWN PreSC counters (no clique sum); the gpu_cache_capacity hottest rows live in an HBM cache (slots cpu_cap + rank), the next
+ * cpu_cache_capacity in a mapped pinned host cache (slots rank - gpu_cap), everything else is a miss; the topology maps stay empty.
+ * The gather then resolves a slot as feat_cache_lookup does (cache_impl.cuh:202-235).  The capacities are the disk-mode
+ * meta_config fields 14 and 15 (SS/storage/storage_management.cu:91-94).  The reference fills neither cache (cache.cu:616,656);
+ * here both are filled from the feature table.  miss_from_table != 0: a miss row is read from the FeatureStorage table (the stand-in
+ * for the unreleased SSD reader, IOSubmit SS/engine/operator_impl.cu:522-539); 0: as that kernel, a miss row is left unwritten. */
+void legion_cache_hybrid_init(LegionUnifiedCache* c, LegionFeatureStorage* feature, LegionGraphStorage* graph,
+                              int32_t cpu_cache_capacity, int32_t gpu_cache_capacity, int32_t miss_from_table);
+/* device address of GPU dev_id's CPU cache (mapped pinned host memory, float[cpu_cache_capacity x D]) / of its HBM cache
+ * (float[capacity x D]: this member's stripe after fill_up, the GPU cache after hybrid_init); null before either */
+const float* legion_cache_hybrid_cpu_cache(const LegionUnifiedCache* c, int32_t dev_id);
+const float* legion_cache_feature_cache(const LegionUnifiedCache* c, int32_t dev_id);
 void legion_cache_destroy(LegionUnifiedCache* c);
 /* A clique spread over PROCESSES (one process per GPU, Kg = world size): every rank owns member
  * `dev` = its rank (legion_set_local_device), builds its own stripe, publishes three IPC handles

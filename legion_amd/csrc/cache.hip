@@ -126,10 +126,12 @@ public:
         HIP_CALL(hipDeviceSynchronize());
     }
 
-    void HybridInsert(int32_t*, int32_t, int32_t) override
+    // SS/cache/cache.cu:138-153 (HybridInitPair + insert; features only, the two topology maps stay empty)
+    void HybridInsert(int32_t* QF, int32_t cpu_cache_capacity, int32_t gpu_cache_capacity) override
     {
-        // Legion-SSD hybrid CPU/GPU cache: unreleased upstream (README.md:100-101), out of scope
-        printf("HybridInsert: SSD tier is not part of this build\n");
+        SetGPUDevice(device_idx_);
+        lg::init_node_map_hybrid(nullptr, node_map_, QF, cpu_cache_capacity, gpu_cache_capacity, total_num_nodes_);
+        HIP_CALL(hipDeviceSynchronize());
     }
 
     void AccessCount(int32_t*, int32_t, void*) override {}
@@ -219,6 +221,10 @@ void UnifiedCache::Finalize(int32_t dev_id)
 {
     SetGPUDevice(dev_id);
     cache_controller_[dev_id]->Finalize();
+    if (dev_id < (int32_t)cpu_cache_host_.size() && cpu_cache_host_[dev_id] != nullptr) {     // the hybrid tier's CPU cache
+        legion_host_free(cpu_cache_host_[dev_id]);
+        cpu_cache_host_[dev_id] = cpu_cache_dev_[dev_id] = nullptr;
+    }
 }
 
 void UnifiedCache::FindFeat(int32_t* sampled_ids, int32_t* cache_offset, int32_t* node_counter,
@@ -453,6 +459,12 @@ int32_t UnifiedCache::EdgeCapacity(int32_t dev_id) const
     return edge_capacity_[dev_id / Kg_];
 }
 
+static uint64_t next_cache_uid()
+{
+    static std::atomic<uint64_t> next_uid{1};
+    return next_uid.fetch_add(1);
+}
+
 // SS/cache/cache.cu:553-611, in two steps so that a clique spread over processes can exchange its
 // stripes in between (in one process FillUp = FillUpLocal + FillUpLink).
 void UnifiedCache::FillUp(int cache_agg_mode, FeatureStorage* feature, GraphStorage* graph)
@@ -465,12 +477,12 @@ void UnifiedCache::FillUp(int cache_agg_mode, FeatureStorage* feature, GraphStor
 void UnifiedCache::FillUpLocal(FeatureStorage* feature, GraphStorage* graph)
 {
     {   // a new fill: pairs built from the previous node_map (of this or any other cache) are stale from here on
-        static std::atomic<uint64_t> next_uid{1};
-        if (uid_ == 0) uid_ = next_uid.fetch_add(1);
+        if (uid_ == 0) uid_ = next_cache_uid();
         fill_generation_++;
         for (int32_t d = 0; d < device_count_; d++)
             if (lg_is_local(d)) graph->DropColumnSlots(d);
     }
+    hybrid_ = false;                  // (a clique fill after HybridInit: the gather decodes (owner, row) slots again)
     const int32_t N = feature->TotalNodeNum();
     float* cpu_float_feature = feature->GetAllFloatFeature();
     cpu_float_features_ = cpu_float_feature;
@@ -538,6 +550,82 @@ void UnifiedCache::FillUpLink(FeatureStorage* feature, GraphStorage* graph)
         // column slots: with the id -> slot map of this GPU final, pair the column array with it (legion_core.h, GraphStorage)
         if (QF_[i / Kg_] != nullptr && float_feature_len_ > 0) graph->BuildColumnSlots(i, cache_controller_[i]->NodeMap(), FillStamp());
     }
+}
+
+// SS/cache/cache.cu:614-670.  Differences, all forced: the reference sorts each GPU's counters in place (here a copy: the
+// counters survive), allocates ONE CPU cache on device 0 for every GPU although each GPU has its own order (here one per GPU),
+// and fills neither cache (:616 allocates and nothing writes; :656 FeatFillUp is commented out) -- here both are filled from
+// the table the way FillUp fills its stripes.  Ranks at or beyond N are skipped.
+void UnifiedCache::HybridInit(FeatureStorage* feature, GraphStorage* graph, bool miss_from_table)
+{
+    const int32_t N = feature->TotalNodeNum();
+    total_num_nodes_ = N;
+    float* table = feature->GetAllFloatFeature();
+    const int32_t cpu_cap = cpu_cache_capacity_ < 0 ? 0 : cpu_cache_capacity_;
+    const int32_t gpu_cap = gpu_cache_capacity_ < 0 ? 0 : gpu_cache_capacity_;
+    {   // a new fill (as in FillUpLocal): column slots built from an earlier node_map are stale
+        if (uid_ == 0) uid_ = next_cache_uid();
+        fill_generation_++;
+        for (int32_t d = 0; d < device_count_; d++)
+            if (lg_is_local(d)) graph->DropColumnSlots(d);
+    }
+    for (void* p : QF_) d_free_space(p);
+    for (void* p : QT_) d_free_space(p);
+    for (void* p : AF_) d_free_space(p);
+    for (void* p : AT_) d_free_space(p);
+    QF_.assign(device_count_, nullptr); AF_.assign(device_count_, nullptr);
+    QT_.assign(device_count_, nullptr); AT_.assign(device_count_, nullptr);
+    Kc_ = device_count_;              // every GPU on its own: "clique" i is GPU i
+    Kg_ = 1;
+    cache_agg_mode_ = 0;
+    node_capacity_.assign(device_count_, gpu_cap + cpu_cap);
+    edge_capacity_.assign(device_count_, 0);
+    cpu_cache_dev_.resize(device_count_, nullptr);
+    cpu_cache_host_.resize(device_count_, nullptr);
+    for (int32_t i = 0; i < device_count_; i++) {
+        if (!lg_is_local(i)) continue;
+        SetGPUDevice(i);
+        // :626-636 this GPU's counters alone, iota, sort_by_key(greater): ties keep ascending id
+        unsigned long long* keys = (unsigned long long*)d_alloc_space((int64_t)N * sizeof(unsigned long long));
+        HIP_CALL(hipMemcpy(keys, cache_controller_[i]->GetNodeAccessedMap(), (size_t)N * sizeof(unsigned long long), hipMemcpyDeviceToDevice));
+        int32_t* order = (int32_t*)d_alloc_space((int64_t)N * sizeof(int32_t));
+        lg::sort_hotness_desc(nullptr, keys, order, N);
+        QF_[i] = order;
+        AF_[i] = keys;
+        cache_controller_[i]->InitializeMap(gpu_cap + cpu_cap, 100);     // :642 "edge cache disabled now"
+        cache_controller_[i]->HybridInsert(order, cpu_cap, gpu_cap);     // :643
+        graph->GraphCacheBuildLocal(order, i, 1, 0);                     // no cached topology: every row header back on the full CSR
+        d_free_space(d_float_feature_cache_ptr_[i]);
+        d_float_feature_cache_ptr_[i] = (float**)d_alloc_space(device_count_ * sizeof(float*));     // :647-652
+        if (float_feature_len_ > 0) {
+            d_free_space(float_feature_cache_[i]);
+            float_feature_cache_[i] = (float*)d_alloc_space((int64_t)gpu_cap * float_feature_len_ * sizeof(float));   // :657
+            if (cpu_cache_host_[i] != nullptr) legion_host_free(cpu_cache_host_[i]);
+            void* host = nullptr;
+            cpu_cache_dev_[i] = (float*)legion_host_alloc((int64_t)cpu_cap * float_feature_len_ * sizeof(float), &host);   // :616
+            cpu_cache_host_[i] = (float*)host;
+            lg::feat_fill_up(nullptr, std::min(gpu_cap, N), float_feature_len_, float_feature_cache_[i], table, order, 1, 0, N);
+            if (N > gpu_cap)
+                lg::feat_fill_up(nullptr, std::min(cpu_cap, N - gpu_cap), float_feature_len_, cpu_cache_dev_[i], table, order + gpu_cap, 1, 0,
+                                 N - gpu_cap);
+            HIP_CALL(hipDeviceSynchronize());
+            std::vector<float*> tab(device_count_, nullptr);
+            tab[0] = float_feature_cache_[i];
+            HIP_CALL(hipMemcpy(d_float_feature_cache_ptr_[i], tab.data(), device_count_ * sizeof(float*), hipMemcpyHostToDevice));
+        }
+        if ((int32_t)replica_.size() > i && replica_[i] != nullptr) { d_free_space(replica_[i]); replica_[i] = nullptr; replica_rows_[i] = 0; }
+    }
+    hybrid_ = true;
+    hybrid_miss_from_table_ = miss_from_table;
+    hybrid_table_ = table;
+    cpu_float_features_ = table;      // what the operators check to know the cache is bound (the reference points it at the CPU cache, :616)
+    for (int32_t i = 0; i < device_count_; i++) {
+        if (!lg_is_local(i)) continue;
+        SetGPUDevice(i);
+        if (float_feature_len_ > 0) graph->BuildColumnSlots(i, cache_controller_[i]->NodeMap(), FillStamp());
+    }
+    is_presc_ = false;
+    std::cout << "Finish initializing cache\n";        // :669
 }
 
 int32_t UnifiedCache::MaxIdNum(int32_t dev_id) { return cache_controller_[dev_id]->MaxIdNum(); }
@@ -625,6 +713,18 @@ lg::GatherParams UnifiedCache::GatherParamsOf(int32_t dev_id, int32_t op_id, int
     g.first_hop = (use_snapshot && first_op_id >= 0 && first_op_id < op_id) ? first_op_id / INTRABATCH_CON : g.hop;
     g.last_op = last_op;
     g.skip_remote = false;
+    g.hybrid = hybrid_ && filled;
+    g.hybrid_cpu_cap = g.hybrid_gpu_cap = 0;
+    g.hybrid_cpu_cache = nullptr;
+    if (g.hybrid) {
+        g.hybrid_cpu_cap = cpu_cache_capacity_ < 0 ? 0 : cpu_cache_capacity_;
+        g.hybrid_gpu_cap = gpu_cache_capacity_ < 0 ? 0 : gpu_cache_capacity_;
+        g.hybrid_cpu_cache = cpu_cache_dev_[dev_id];
+        g.full_table = hybrid_miss_from_table_ ? hybrid_table_ : nullptr;
+        g.striped = false;
+        g.replica = nullptr;
+        g.replica_rows = 0;
+    }
     return g;
 }
 
@@ -763,6 +863,29 @@ extern "C" void legion_cache_fill_up(LegionUnifiedCache* c, LegionFeatureStorage
     UnifiedCache* u = as_cache(c);
     if (!u || !feature || !graph) { printf("invalid cache/feature/graph ptr\n"); return; }
     u->FillUp(u->cache_agg_mode_, reinterpret_cast<FeatureStorage*>(feature), reinterpret_cast<GraphStorage*>(graph));
+}
+
+// The hybrid CPU-cache / GPU-cache tier instead of candidate_selection + cost_model + fill_up (UnifiedCache::HybridInit)
+extern "C" void legion_cache_hybrid_init(LegionUnifiedCache* c, LegionFeatureStorage* feature, LegionGraphStorage* graph,
+                                         int32_t cpu_cache_capacity, int32_t gpu_cache_capacity, int32_t miss_from_table)
+{
+    UnifiedCache* u = as_cache(c);
+    if (!u || !feature || !graph) { printf("invalid cache/feature/graph ptr\n"); return; }
+    u->SetHybridCapacity(cpu_cache_capacity, gpu_cache_capacity);
+    u->HybridInit(reinterpret_cast<FeatureStorage*>(feature), reinterpret_cast<GraphStorage*>(graph), miss_from_table != 0);
+}
+
+// device address of GPU dev_id's CPU cache (mapped pinned host memory, cpu_cache_capacity x D floats), or null
+extern "C" const float* legion_cache_hybrid_cpu_cache(const LegionUnifiedCache* c, int32_t dev_id)
+{
+    const UnifiedCache* u = as_cache(c);
+    return u ? u->HybridCPUCache(dev_id) : nullptr;
+}
+
+extern "C" const float* legion_cache_feature_cache(const LegionUnifiedCache* c, int32_t dev_id)
+{
+    const UnifiedCache* u = as_cache(c);
+    return u ? u->FeatureCachePtr(dev_id) : nullptr;
 }
 
 extern "C" void legion_cache_destroy(LegionUnifiedCache* c)

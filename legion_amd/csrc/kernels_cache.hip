@@ -166,6 +166,24 @@ void init_node_map(hipStream_t s, int32_t* node_map, const int32_t* QF, int32_t 
     hipCheckError();
 }
 
+// HybridInitPair, cache_impl.cuh:113-123: the gpu_cap hottest ids -> slots cpu_cap + t (the GPU cache), the next cpu_cap ids ->
+// slots t - gpu_cap (the CPU cache); QF has n entries
+__global__ void init_node_map_hybrid_kernel(int32_t* __restrict__ node_map, const int32_t* __restrict__ QF,
+                                            int32_t cpu_cap, int32_t gpu_cap, int32_t n)
+{
+    const int64_t total = min((int64_t)cpu_cap + gpu_cap, (int64_t)n);
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x)
+        node_map[QF[t]] = (int32_t)(t < gpu_cap ? cpu_cap + t : t - gpu_cap);
+}
+
+void init_node_map_hybrid(hipStream_t s, int32_t* node_map, const int32_t* QF, int32_t cpu_cache_capacity,
+                          int32_t gpu_cache_capacity, int32_t n)
+{
+    init_node_map_hybrid_kernel<<<grid_for((int64_t)cpu_cache_capacity + gpu_cache_capacity), 256, 0, s>>>(
+        node_map, QF, cpu_cache_capacity, gpu_cache_capacity, n);
+    hipCheckError();
+}
+
 // InitIndexPair / InitOffsetPair, cache_impl.cuh:89-101
 __global__ void init_edge_maps_kernel(char* __restrict__ index_map, int32_t* __restrict__ offset_map,
                                       const int32_t* __restrict__ QT, int32_t capacity, int32_t Kg,

@@ -6,6 +6,10 @@
 //     id = sampled_ids[off + r];  g = node_map[id] (or -2)          -> cache_index[r] = g
 //     g <  0 : dst[off + r] = full_table[id % N]                    (miss: full table tier)
 //     g >= 0 : dst[off + r] = cache_tables[g / cap][g % cap]        (hit: local or peer HBM)
+// and, with GatherParams.hybrid, what feat_cache_lookup does (SS/cache/cache_impl.cuh:202-235):
+//     0 <= g < cpu_cap : dst[off + r] = cpu_cache[g]                (hit in the mapped pinned CPU cache)
+//     g >= cpu_cap     : dst[off + r] = gpu_cache[(g - cpu_cap) % gpu_cap]
+//     g <  0           : left to the storage tier (the full table when one is bound, else the row is not written)
 // Rows are copied verbatim (byte-identical, no arithmetic).
 //
 // The reference runs one thread per float on a fixed 32x1024 grid with a 64-bit div/mod per
@@ -155,8 +159,13 @@ __global__ __launch_bounds__(LG_GATHER_THREADS, LG_GATHER_MIN_WAVES) void gather
     auto source_of = [&](int32_t id, int32_t g) -> const LG_G float* {
         const LG_G float* p = nullptr;
         if (g < 0) {
-            if (id >= 0)     // :262-266 (the modulo only where it does anything)
+            if (id >= 0 && gp.full_table != nullptr)     // :262-266 (the modulo only where it does anything)
                 p = LG_GPTR(const float, gp.full_table) + (int64_t)(id < gp.total_num_nodes ? id : id % gp.total_num_nodes) * D;
+        } else if (gp.hybrid) {      // feat_cache_lookup, cache_impl.cuh:224-231: CPU cache below cpu_cap, this GPU's cache above
+            if (g < gp.hybrid_cpu_cap)
+                p = LG_GPTR(const float, gp.hybrid_cpu_cache) + (int64_t)g * D;       // (g % cpu_cap == g)
+            else
+                p = LG_GPTR(const float, gp.local_table) + (int64_t)((g - gp.hybrid_cpu_cap) % gp.hybrid_gpu_cap) * D;
         } else {
             int32_t didx = 0, fidx = g;                                                      // :259-260 (one division, and
             if (gp.striped) { didx = g / gp.node_capacity; fidx = g - didx * gp.node_capacity; }  // none without striping)

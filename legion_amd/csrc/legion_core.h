@@ -471,6 +471,21 @@ public:
     void FillUp(int cache_agg_mode, FeatureStorage* feature, GraphStorage* graph);
     void FillUpLocal(FeatureStorage* feature, GraphStorage* graph);   // maps + the local members' stripes
     void FillUpLink(FeatureStorage* feature, GraphStorage* graph);    // pointer tables over every known member
+    // The hybrid CPU-cache / GPU-cache tier (SS/cache/cache.cu:614-670; the reference's server.cu:112 keeps the call commented
+    // out): per GPU, its OWN hotness order; the gpu_cache_capacity hottest rows in an HBM cache, the next cpu_cache_capacity
+    // in a mapped pinned host cache, the rest misses.  Replaces CandidateSelection + CostModel + FillUp.  miss_from_table:
+    // a miss row is read from the FeatureStorage table (this build's stand-in for the unreleased SSD reader); false = the
+    // reference's kernel to the letter: the gather leaves a miss row unwritten.
+    void HybridInit(FeatureStorage* feature, GraphStorage* graph, bool miss_from_table = true);
+    void SetHybridCapacity(int32_t cpu_cache_capacity, int32_t gpu_cache_capacity)
+    {
+        cpu_cache_capacity_ = cpu_cache_capacity;
+        gpu_cache_capacity_ = gpu_cache_capacity;
+    }
+    int32_t CPUCapacity() const { return cpu_cache_capacity_; }     // cache.cu:676-682
+    int32_t GPUCapacity() const { return gpu_cache_capacity_; }
+    bool IsHybrid() const { return hybrid_; }
+    const float* HybridCPUCache(int32_t dev_id) const { return dev_id < (int32_t)cpu_cache_dev_.size() ? cpu_cache_dev_[dev_id] : nullptr; }
     void SetPeerFeatureCache(int32_t dev, float* ptr) { float_feature_cache_[dev] = ptr; }
     float* FeatureCachePtr(int32_t dev) const { return float_feature_cache_[dev]; }
     void SetPeerMaxIds(const int32_t* v, int32_t n) { peer_max_ids_.assign(v, v + n); }
@@ -538,6 +553,11 @@ private:
     std::vector<float*> replica_;         // [device] hottest rows of its clique in rank order, or null
     std::vector<int32_t> replica_rows_;
     std::vector<unsigned long long*> gather_stats_;
+    // hybrid tier: one CPU cache per GPU (the reference allocates a single one on device 0 although every GPU orders its rows
+    // by its own counters, cache.cu:616,630-641 -- "single gpu version", :681)
+    bool hybrid_ = false, hybrid_miss_from_table_ = true;
+    std::vector<float*> cpu_cache_dev_, cpu_cache_host_;   // device-side / host-side address of each GPU's mapped pinned cache
+    float* hybrid_table_ = nullptr;                        // the FeatureStorage table misses are served from
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -737,6 +757,12 @@ struct GatherParams {
                                     // sampled_ids); == hop for a plain single-op gather
     bool last_op;                   // the gather of the batch's last op (kernel instance of its own: hand-over, traces)
     bool skip_remote;               // peer_gather = bulk: rows of OTHER members' stripes are not fetched here (their owners push them)
+    // hybrid CPU-cache / GPU-cache tier (feat_cache_lookup, SS/cache/cache_impl.cuh:202-235): slots [0, cpu_cap) are rows of
+    // hybrid_cpu_cache (mapped pinned host memory), slots >= cpu_cap rows (g - cpu_cap) % gpu_cap of local_table; a miss reads
+    // full_table when that is bound and is left unwritten otherwise
+    bool hybrid;
+    int32_t hybrid_cpu_cap, hybrid_gpu_cap;
+    const float* hybrid_cpu_cache;
 };
 
 // Owner-bucketed bulk transfer of a striped gather (LegionTuning.peer_gather = bulk; SURVEY section 7 "hard parts", the
@@ -806,6 +832,8 @@ void edge_mem_in_order(hipStream_t s, const int32_t* order, unsigned long long* 
                        const int64_t* csr_index);
 void init_node_map(hipStream_t s, int32_t* node_map, const int32_t* QF, int32_t capacity, int32_t Kg,
                    int32_t n);
+void init_node_map_hybrid(hipStream_t s, int32_t* node_map, const int32_t* QF, int32_t cpu_cache_capacity,
+                          int32_t gpu_cache_capacity, int32_t n);
 void init_edge_maps(hipStream_t s, char* index_map, int32_t* offset_map, const int32_t* QT,
                     int32_t capacity, int32_t Kg, int32_t Ki, int32_t n);
 void fill_value_i32(hipStream_t s, int32_t* p, int32_t v, int64_t n);

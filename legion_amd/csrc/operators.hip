@@ -332,6 +332,9 @@ extern "C" void legion_gather_rows(legion_stream_t stream, const float* full_tab
     g.node_capacity = node_capacity;
     g.D = float_feature_len;
     g.skip_remote = false;
+    g.hybrid = false;
+    g.hybrid_cpu_cap = g.hybrid_gpu_cap = 0;
+    g.hybrid_cpu_cache = nullptr;
     g.total_num_nodes = total_num_nodes;
     g.max_rows = max_rows;
     lg::launch_gather_explicit(static_cast<hipStream_t>(stream), g, sampled_ids, cache_index_out, range_devptr, dst,

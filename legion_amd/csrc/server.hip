@@ -134,9 +134,10 @@ public:
         }
     }
 
-    // SS/storage/storage_management.cu:29-98 (in-memory fields; the disk-mode extras are the
-    // unreleased SSD tier)
-    bool ReadMetaFIle(BuildInfo* info)
+    // SS/storage/storage_management.cu:29-98: ten fields in memory mode; disk mode (in_memory_mode == 0) appends partition, the
+    // two SSD parameters (read and logged; the SSD reader is unreleased upstream) and the two capacities of the hybrid
+    // CPU-cache / GPU-cache tier (:85-94)
+    bool ReadMetaFIle(BuildInfo* info, int32_t in_memory_mode)
     {
         std::ifstream Metafile("./meta_config");
         if (!Metafile.is_open()) {
@@ -168,6 +169,23 @@ public:
         iss >> epoch_;
         std::cout << "Train epoch:        " << epoch_ << "\n";
         info->epoch = epoch_;
+        if (!in_memory_mode) {
+            iss >> partition_;
+            std::cout << "Partition?:         " << partition_ << "\n";
+            iss >> num_ssd_;
+            std::cout << "SSD Num?:           " << num_ssd_ << "\n";
+            iss >> num_queues_per_ssd_;
+            std::cout << "Q/SSD    ?:         " << num_queues_per_ssd_ << "\n";
+            iss >> cpu_cache_capacity_;
+            std::cout << "CPU Cache Capacity: " << cpu_cache_capacity_ << "\n";
+            iss >> gpu_cache_capacity_;
+            std::cout << "GPU Cache Capacity: " << gpu_cache_capacity_ << "\n";
+            if (iss.fail() || cpu_cache_capacity_ < 0 || gpu_cache_capacity_ < 0) {
+                std::cout << "meta_config: disk mode needs fifteen fields (... partition ssd_num queues_per_ssd cpu_cache_capacity "
+                             "gpu_cache_capacity)\n" << std::flush;
+                return false;
+            }
+        }
         return true;
     }
 
@@ -254,11 +272,10 @@ public:
     // SS/storage/storage_management.cu:234-269
     bool Initialze(int32_t partition_count, int32_t in_memory_mode)
     {
-        (void)in_memory_mode;
         BuildInfo* info = new BuildInfo();
         EnableP2PAccess();
         info->partition_count = partition_count;
-        if (!ReadMetaFIle(info)) return false;
+        if (!ReadMetaFIle(info, in_memory_mode)) return false;
         SetGPUDevice(0);
         LoadGraph(info);
         LoadFeature(info);
@@ -272,7 +289,7 @@ public:
         cache_ = new UnifiedCache();
         const int32_t train_step = env_->GetTrainStep();
         SetGPUDevice(0);
-        cache_->Initialize(cache_memory_, float_feature_len_, train_step, partition_count, 0, 0);
+        cache_->Initialize(cache_memory_, float_feature_len_, train_step, partition_count, cpu_cache_capacity_, gpu_cache_capacity_);   // :266
         std::cout << "Storage Initialized\n";
         info_ = info;
         return true;
@@ -289,6 +306,7 @@ private:
     int32_t raw_batch_size_ = 0, node_num_ = 0, float_feature_len_ = 0;
     int64_t edge_num_ = 0, cache_memory_ = 0;
     int32_t training_set_num_ = 0, validation_set_num_ = 0, testing_set_num_ = 0, epoch_ = 0;
+    int32_t partition_ = 0, num_ssd_ = 0, num_queues_per_ssd_ = 0, cpu_cache_capacity_ = 0, gpu_cache_capacity_ = 0;   // disk mode
     GraphStorage* graph_ = nullptr;
     FeatureStorage* feature_ = nullptr;
     UnifiedCache* cache_ = nullptr;
@@ -910,6 +928,7 @@ public:
     void Initialize(int global_shard_count, std::vector<int> fanout, int in_memory_mode) override
     {
         shard_count_ = global_shard_count;
+        in_memory_mode_ = in_memory_mode;
         lg::tuning_refresh();           // the environment as it is when the server starts (or what the host program installed)
         if (in_memory_mode) std::cout << "In Memory Mode\n";
         else std::cout << "In Disk Mode\n";
@@ -994,9 +1013,15 @@ public:
             counters[1] = tune.link_counter_values[1];
         }
         double t = std::chrono::duration_cast<std::chrono::duration<double>>(std::chrono::steady_clock::now() - t1).count();
-        cache_->CandidateSelection(cache_agg_mode, feature_, graph_);
-        cache_->CostModel(cache_agg_mode, feature_, graph_, counters, train_step_);
-        cache_->FillUp(cache_agg_mode, feature_, graph_);
+        if (!in_memory_mode_ && cache_->CPUCapacity() + cache_->GPUCapacity() > 0) {
+            // disk mode with the two capacities given: the hybrid CPU-cache / GPU-cache tier -- the call the reference keeps
+            // commented out (server.cu:112) beside the three above it
+            cache_->HybridInit(feature_, graph_);
+        } else {
+            cache_->CandidateSelection(cache_agg_mode, feature_, graph_);
+            cache_->CostModel(cache_agg_mode, feature_, graph_, counters, train_step_);
+            cache_->FillUp(cache_agg_mode, feature_, graph_);
+        }
         for (int i = 0; i < shard_count_; i++) {
             params_[i]->global_batch_id = 0;
             runners_[i]->PrepareServing(params_[i]);
@@ -1045,7 +1070,7 @@ private:
     FeatureStorage* feature_ = nullptr;
     UnifiedCache* cache_ = nullptr;
     IPCEnv* ipc_env_ = nullptr;
-    int shard_count_ = 0, train_step_ = 0, max_step_ = 0;
+    int shard_count_ = 0, train_step_ = 0, max_step_ = 0, in_memory_mode_ = 1;
     std::vector<Runner*> runners_;
     std::vector<RunnerParams*> params_;
 };

@@ -505,6 +505,21 @@ class UnifiedCache:
     def fill_up(self, feature, graph):
         self._lib.legion_cache_fill_up(self.handle, feature.handle, graph.handle)
 
+    def hybrid_init(self, feature, graph, cpu_cache_capacity, gpu_cache_capacity, miss_from_table=True):
+        """The hybrid CPU-cache / GPU-cache tier instead of candidate_selection + cost_model + fill_up
+        (UnifiedCache::HybridInit, SS/cache/cache.cu:614-670)."""
+        self._hybrid = (int(cpu_cache_capacity), int(gpu_cache_capacity), int(feature.float_feature_len))
+        self._lib.legion_cache_hybrid_init(self.handle, feature.handle, graph.handle, int(cpu_cache_capacity),
+                                           int(gpu_cache_capacity), 1 if miss_from_table else 0)
+
+    def hybrid_caches(self, dev_id=0):
+        """(CPU cache, GPU cache) of dev_id after hybrid_init as float32 tensors [capacity, D] (device views)."""
+        cpu_cap, gpu_cap, dim = self._hybrid
+        dev = _torch_device(dev_id)
+        cpu = device_view(self._lib.legion_cache_hybrid_cpu_cache(self.handle, int(dev_id)), (cpu_cap, dim), torch.float32, dev)
+        gpu = device_view(self._lib.legion_cache_feature_cache(self.handle, int(dev_id)), (gpu_cap, dim), torch.float32, dev)
+        return cpu, gpu
+
     def fill_up_distributed(self, feature, graph, rank, world, max_ids_all, all_gather_bytes):
         """FillUp of a clique spread over `world` processes (this process owns member `rank`):
         local stripe -> export 3 IPC handles -> all-gather -> open the peers' -> link.

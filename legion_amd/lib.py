@@ -52,6 +52,9 @@ SIGNATURES = {
     "legion_cache_cost_model": (None, [c_p, c_p, c_p, P_U64, c_i32]),
     "legion_cache_set_capacity": (None, [c_p, c_i32, c_i32]),
     "legion_cache_fill_up": (None, [c_p, c_p, c_p]),
+    "legion_cache_hybrid_init": (None, [c_p, c_p, c_p, c_i32, c_i32, c_i32]),
+    "legion_cache_hybrid_cpu_cache": (c_p, [c_p, c_i32]),
+    "legion_cache_feature_cache": (c_p, [c_p, c_i32]),
     "legion_cache_destroy": (None, [c_p]),
     "legion_set_local_device": (None, [c_i32]),
     "legion_cache_set_peer_max_ids": (None, [c_p, P_I32, c_i32]),

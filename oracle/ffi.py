@@ -44,7 +44,8 @@ class Cache(ctypes.Structure):
                 ("QF", P_I32), ("QT", P_I32), ("AF", P_U64), ("AT", P_U64),
                 ("node_map", P_I32), ("edge_index_map", P_I8), ("edge_offset_map", P_I32),
                 ("feat_cache", P_F32 * MAX_DEVICE), ("topo_indptr", P_I64 * MAX_DEVICE),
-                ("topo_col", P_I32 * MAX_DEVICE)]
+                ("topo_col", P_I32 * MAX_DEVICE),
+                ("hybrid", c_i32), ("cpu_cache_capacity", c_i32), ("gpu_cache_capacity", c_i32), ("cpu_cache", P_F32)]
 
 
 class Steps(ctypes.Structure):
@@ -86,6 +87,7 @@ def load():
         "lgo_candidate_selection": (None, [PC, ctypes.POINTER(P_U64), ctypes.POINTER(P_U64)]),
         "lgo_cost_model": (c_i32, [PC, c_i64, P_I64, P_U64, P_I32, c_i32, P_F32]),
         "lgo_fill_up": (None, [PC, P_F32, P_I64, P_I32]),
+        "lgo_hybrid_init": (None, [PC, P_U64, P_F32, c_i32, c_i32]),
         "lgo_find_topo": (None, [PC, P_I32, P_I8, P_I32, c_i32]),
         "lgo_find_feat": (None, [PC, PP, c_i32]),
         "lgo_feature_cache_lookup": (None, [PC, PP, P_F32, c_i32]),
@@ -168,6 +170,12 @@ class OracleCache:
 
     def fill_up(self, features, indptr, col):
         self.L.lgo_fill_up(self.c, _p(features, P_F32), _p(indptr, P_I64), _p(col, P_I32))
+
+    def hybrid_init(self, node_access, features, cpu_cache_capacity, gpu_cache_capacity):
+        """The hybrid CPU-cache / GPU-cache tier of one GPU from its own hotness counters (cache.cu:614-670)."""
+        self._na = [np.ascontiguousarray(node_access, dtype=np.uint64)]
+        self.L.lgo_hybrid_init(self.c, _p(self._na[0], P_U64), _p(features, P_F32), int(cpu_cache_capacity),
+                               int(gpu_cache_capacity))
 
     def arr(self, name, dtype):
         return np.ctypeslib.as_array(getattr(self.c.contents, name), shape=(self.N,)).astype(dtype, copy=True)

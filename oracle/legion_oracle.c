@@ -249,6 +249,7 @@ void lgo_cache_destroy(lgo_cache* c)
     for (int i = 0; i < LGO_MAX_DEVICE; i++) {
         free(c->feat_cache[i]); free(c->topo_indptr[i]); free(c->topo_col[i]);
     }
+    free(c->cpu_cache);
     free(c);
 }
 
@@ -416,6 +417,38 @@ void lgo_fill_up(lgo_cache* c, const float* host_features, const int64_t* csr_in
     }
 }
 
+/* SS/cache/cache.cu:614-670 (HybridInit) + :138-153 (HybridInsert) + cache_impl.cuh:113-123 (HybridInitPair) */
+void lgo_hybrid_init(lgo_cache* c, const uint64_t* node_access, const float* host_features,
+                     int32_t cpu_cache_capacity, int32_t gpu_cache_capacity)
+{
+    const int32_t N = c->total_num_nodes, D = c->feature_dim;
+    const int64_t cpu_cap = cpu_cache_capacity, gpu_cap = gpu_cache_capacity;
+    const uint64_t* one[1] = {node_access};
+    c->Kg = 1;
+    c->hybrid = 1;
+    c->cpu_cache_capacity = cpu_cache_capacity;
+    c->gpu_cache_capacity = gpu_cache_capacity;
+    lgo_sorted_order(one, 1, N, c->QF, c->AF);             /* :630-635: this GPU's counters alone, iota, sort_by_key greater */
+    c->node_capacity = (int32_t)(gpu_cap + cpu_cap);       /* :642 InitializeMap(gpu + cpu, 100) */
+    c->edge_capacity = 0;                                  /* nothing is inserted into the two topology maps */
+    for (int32_t i = 0; i < N; i++) {
+        c->node_map[i] = LGO_CACHEMISS_FLAG;
+        c->edge_index_map[i] = (int8_t)LGO_CACHEMISS_FLAG;
+        c->edge_offset_map[i] = LGO_CACHEMISS_FLAG;
+    }
+    for (int64_t t = 0; t < cpu_cap + gpu_cap && t < N; t++)          /* HybridInitPair cache_impl.cuh:113-123 */
+        c->node_map[c->QF[t]] = (int32_t)(t < gpu_cap ? cpu_cap + t : t - gpu_cap);
+    free(c->feat_cache[0]); free(c->cpu_cache);
+    c->feat_cache[0] = (float*)xcalloc((size_t)(gpu_cap > 0 ? gpu_cap : 1) * (size_t)(D > 0 ? D : 1), 4);   /* :653-657 */
+    c->cpu_cache = (float*)xcalloc((size_t)(cpu_cap > 0 ? cpu_cap : 1) * (size_t)(D > 0 ? D : 1), 4);        /* :616 */
+    if (host_features) {
+        for (int64_t r = 0; r < gpu_cap && r < N; r++)
+            memcpy(c->feat_cache[0] + r * D, host_features + (int64_t)c->QF[r] * D, (size_t)D * 4);
+        for (int64_t r = 0; r < cpu_cap && gpu_cap + r < N; r++)
+            memcpy(c->cpu_cache + r * D, host_features + (int64_t)c->QF[gpu_cap + r] * D, (size_t)D * 4);
+    }
+}
+
 /* SS/cache/cache.cu:217-225: two bcht::find calls, sentinel -2 (as char for the index map) */
 void lgo_find_topo(const lgo_cache* c, const int32_t* input_ids, int8_t* part_ind,
                    int32_t* part_off, int32_t batch_size)
@@ -449,6 +482,25 @@ void lgo_feature_cache_lookup(const lgo_cache* c, lgo_pool* p, const float* host
     const int32_t N = p->total_num_nodes;
     int32_t node_off = p->node_counter[(op_id % LGO_INTRABATCH_CON) * 2];
     int32_t batch_size = p->node_counter[(op_id % LGO_INTRABATCH_CON) * 2 + 1];
+    if (c && c->hybrid) {                                                       /* feat_cache_lookup, cache_impl.cuh:202-235 */
+        const int32_t cpu_cap = c->cpu_cache_capacity, gpu_cap = c->gpu_cache_capacity;
+        if (D <= 0) return;                                                     /* :216 */
+        for (int32_t r = 0; r < batch_size; r++) {
+            int32_t gidx = p->cache_search_buffer[r];
+            float* dst = p->float_features + ((int64_t)node_off + r) * D;
+            if (gidx < cpu_cap && gidx >= 0) {                                  /* :224-226 cache in cpu */
+                int32_t fidx = gidx % cpu_cap;
+                memcpy(dst, c->cpu_cache + (int64_t)fidx * D, (size_t)D * 4);
+            } else if (gidx >= cpu_cap) {                                       /* :227-231 cache in gpu */
+                int32_t fidx = (gidx - cpu_cap) % gpu_cap;
+                memcpy(dst, c->feat_cache[0] + (int64_t)fidx * D, (size_t)D * 4);
+            } else if (host_features != NULL) {                                 /* the kernel writes nothing; the storage tier's reader */
+                int32_t fidx = p->sampled_ids[node_off + r];
+                if (fidx >= 0) memcpy(dst, host_features + (int64_t)(fidx % N) * D, (size_t)D * 4);
+            }
+        }
+        return;
+    }
     if (D <= 0 || host_features == NULL) return;                                /* :256 */
     for (int32_t r = 0; r < batch_size; r++) {
         int32_t gidx = p->cache_search_buffer[r];

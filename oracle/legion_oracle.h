@@ -123,6 +123,11 @@ typedef struct lgo_cache {
     float*    feat_cache[LGO_MAX_DEVICE];      /* [node_capacity*D] per in-clique GPU */
     int64_t*  topo_indptr[LGO_MAX_DEVICE];     /* [edge_capacity+1] */
     int32_t*  topo_col[LGO_MAX_DEVICE];
+    /* hybrid CPU-cache / GPU-cache tier of ONE GPU (lgo_hybrid_init; SS/cache/cache.cu:614-670): the GPU cache is
+     * feat_cache[0] with gpu_cache_capacity rows */
+    int32_t   hybrid;                          /* 0: the clique cache above, 1: the hybrid tier */
+    int32_t   cpu_cache_capacity, gpu_cache_capacity;
+    float*    cpu_cache;                       /* [cpu_cache_capacity*D] (the reference's mapped pinned cpu_float_features_) */
 } lgo_cache;
 
 lgo_cache* lgo_cache_create(int32_t total_num_nodes, int32_t feature_dim, int32_t Kg, int32_t Ki);
@@ -138,12 +143,22 @@ int32_t lgo_cost_model(lgo_cache* c, int64_t cache_memory, const int64_t* csr_in
 /* SS/cache/cache.cu:553-611 + :71-136 + cache_impl.cuh:89-109,183-188 + graph_storage.cu:76-111 */
 void lgo_fill_up(lgo_cache* c, const float* host_features, const int64_t* csr_index,
                  const int32_t* csr_dst);
+/* The hybrid CPU-cache / GPU-cache tier (Legion-SSD / Helios, unreleased: SS/engine/server.cu:112 is commented out).
+ * SS/cache/cache.cu:614-670 (HybridInit: THIS GPU's own hotness order, no clique sum), :138-153 (HybridInsert) with
+ * SS/cache/cache_impl.cuh:113-123 (HybridInitPair): rank t < gpu_cap -> value cpu_cap + t, gpu_cap <= t < gpu_cap + cpu_cap ->
+ * value t - gpu_cap; the topology maps stay empty (:642 "edge cache disabled now").  The reference allocates both caches and
+ * fills neither (:616 allocates, nothing writes; :656 FeatFillUp commented out); here, as FillUp does for its stripes, GPU-cache
+ * row r holds the features of QF[r] and CPU-cache row r those of QF[gpu_cap + r].  Ranks at or beyond N are skipped. */
+void lgo_hybrid_init(lgo_cache* c, const uint64_t* node_access, const float* host_features,
+                     int32_t cpu_cache_capacity, int32_t gpu_cache_capacity);
 /* SS/cache/cache.cu:217-225 */
 void lgo_find_topo(const lgo_cache* c, const int32_t* input_ids, int8_t* part_ind,
                    int32_t* part_off, int32_t batch_size);
 /* SS/cache/cache.cu:180-215 (node_counter[(op%3)*2], [(op%3)*2+1]) */
 void lgo_find_feat(const lgo_cache* c, lgo_pool* p, int32_t op_id);
-/* SS/cache/cache_impl.cuh:239-272 driven by SS/engine/operator_impl.cu:502-519 */
+/* SS/cache/cache_impl.cuh:239-272 driven by SS/engine/operator_impl.cu:502-519; with c->hybrid the single-GPU kernel
+ * feat_cache_lookup (SS/cache/cache_impl.cuh:202-235): a miss row is NOT written by that kernel (the unreleased SSD reader's job,
+ * SS/engine/operator_impl.cu:522-539); host_features != NULL stands in for that reader: the row comes from the full table */
 void lgo_feature_cache_lookup(const lgo_cache* c, lgo_pool* p, const float* host_features,
                               int32_t op_id);
 
