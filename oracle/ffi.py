@@ -10,7 +10,8 @@ import subprocess
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "_build", "liblegion_oracle.so")
+# LEGION_ORACLE_LIB=<path>: another build of the same library (oracle/_build/san/: the sanitizer leg, tests/test_sanitizers_cpu.py)
+LIB_PATH = os.environ.get("LEGION_ORACLE_LIB") or os.path.join(HERE, "_build", "liblegion_oracle.so")
 MAX_DEVICE = 8
 INTRABATCH_CON = 3
 
@@ -67,7 +68,7 @@ def load():
     if _lib is not None:
         return _lib
     srcs = [os.path.join(HERE, f) for f in ("legion_oracle.c", "dgl_semantics.c", "legion_oracle.h")]
-    if not os.path.exists(LIB_PATH) or any(os.path.getmtime(f) > os.path.getmtime(LIB_PATH) for f in srcs):
+    if "LEGION_ORACLE_LIB" not in os.environ and (not os.path.exists(LIB_PATH) or any(os.path.getmtime(f) > os.path.getmtime(LIB_PATH) for f in srcs)):
         build()
     L = ctypes.CDLL(LIB_PATH)
     PP, PG, PC = ctypes.POINTER(Pool), ctypes.POINTER(Graph), ctypes.POINTER(Cache)

@@ -10,9 +10,9 @@
 //   SS/cache/cache.cu:415                sort_by_key(keys, keys+N, order, greater<unsigned long long>())
 // and prints the known answers the oracle (oracle/legion_oracle.c) and the HIP path are pinned to.
 //
-// Build + run (oracle/Makefile target `golden`):
-//   g++ -O1 -std=c++17 -I/opt/rocm/include -DTHRUST_DEVICE_SYSTEM=THRUST_DEVICE_SYSTEM_CPP \
-//       oracle/thrust_pin.cpp -o oracle/_build/thrust_pin && oracle/_build/thrust_pin > tests/golden/rng_thrust.json
+// Build + run: oracle/Makefile target `golden` (hipcc: this rocThrust's host paths include rocPRIM headers that need it);
+// target `san` builds the same program with ASan + UBSan on the host half (tests/test_sanitizers_cpu.py compares its output
+// with the committed golden file).
 #include <thrust/random/linear_congruential_engine.h>
 #include <thrust/random/uniform_int_distribution.h>
 #include <thrust/sort.h>
