@@ -22,8 +22,14 @@ every rank runs K batches of B seeds; value = total sampled edges of all ranks /
 
 Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel, the hop-2 gather:
 achieved = rows * (8*D + 8) bytes / HIP-event time around that launch, summed over the timed steps.
+`roofline.unique_row_frac` says how many of that launch's rows are distinct (a repeat may be served by the
+256 MiB Infinity Cache); `roofline.cold` is the same launch over rows that never repeat (the HBM-only figure),
+`roofline.traffic` the FETCH_SIZE + WRITE_SIZE bytes per launch collected by child processes of this run.
+`other_shapes[0]` (N = 1, default command) is Legion's default batch size, B = 8000, on the same tables.
 `cpu_baseline` is the oracle's C restatement (oracle/, test infrastructure) timed on the host cores
 on a bounded sample of the same batches -- a reported baseline, not a target.
+The legs around the timed region (argument parsing, the boundary leg, the PMC children, the pieces run_leg strings
+together) live in tools/bench_legs.py; this file is the entry point, the leg itself and the CPU baseline.
 """
 import argparse
 import ctypes
@@ -43,227 +49,16 @@ import torch.distributed as dist
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBPS = 8000.0   # MI355X_MICROARCH.md: 8 TB/s spec
-
-
-class OneLine:
-    """The ONE JSON line of rank 0, written exactly once.  At N > 1 the extra legs (striped caches over peer pointers) run after
-    the headline leg and have never met more than one physical GPU before the driver's SCALE run: whatever ends this process
-    while they run -- a Python error (caught by the caller), a native exit() of the library (libc atexit hook), SIGTERM from
-    the launcher after another rank died (wake-up fd + watcher thread: works while the main thread is blocked inside a HIP or
-    RCCL call), or nothing at all for `deadline_s` seconds (a hang) -- the headline leg's line, already measured, still goes
-    out, with a note on what happened."""
-
-    def __init__(self, fd):
-        self.fd, self.line, self.done, self.lock = fd, None, False, threading.Lock()
-        self._hook = None
-
-    def emit(self, obj):
-        with self.lock:
-            if self.done:
-                return
-            self.done = True
-        text = None
-        for _ in range(5):          # (the fallback may serialise the object while the main thread adds a leg to it)
-            try:
-                text = json.dumps(obj)
-                break
-            except RuntimeError:
-                time.sleep(0.01)
-        if text is None:
-            text = json.dumps({k: v for k, v in list(obj.items()) if k not in ("striped", "striped_replica", "striped_bulk")})
-        os.write(self.fd, (text + "\n").encode())
-
-    def arm(self, headline_obj, deadline_s=900):
-        """From here on a dying -- or, after `deadline_s`, a hung -- process still prints `headline_obj` -- the object itself, not a
-        copy: whatever extra legs have been added to it by then go out with it."""
-        self.line = headline_obj
-
-        def fallback(why):
-            if self.line is not None and not self.done:
-                self.line["extra_legs_error"] = why
-                self.emit(self.line)
-
-        # (glibc exports __cxa_atexit; plain atexit lives in its static part)
-        self._hook = ctypes.CFUNCTYPE(None, ctypes.c_void_p)(lambda _: fallback("the process exited inside an extra leg (native exit)"))
-        getattr(ctypes.CDLL(None), "__cxa_atexit")(self._hook, None, None)
-        rfd, wfd = os.pipe()
-        os.set_blocking(wfd, False)
-        signal.set_wakeup_fd(wfd, warn_on_full_buffer=False)
-        signal.signal(signal.SIGTERM, lambda *_: None)       # (the C-level handler writes the signal number to wfd)
-
-        def watch():
-            import select
-            got, _, _ = select.select([rfd], [], [], deadline_s)
-            fallback("SIGTERM while an extra leg was running (another rank failed?)" if got else
-                     "the extra legs did not finish within %d s (hung peer load or collective?)" % deadline_s)
-            os._exit(1)
-
-        threading.Thread(target=watch, daemon=True).start()
-        return fallback
-
-
-class BulkPipe:
-    """engine.Pipeline's submit / wait / run_range interface over the two-phase bulk protocol (pipeline.hip): phase A on every
-    rank -> barrier -> phase B on every rank -> barrier.  No hipGraphs, no per-gather HIP events."""
-
-    def __init__(self, pipe, use_dist):
-        self.p, self.pools, self.use_dist = pipe, pipe.pools, use_dist
-        self.group_size = pipe.group_size
-        pipe.bulk_enable()
-        self.count_rows, self.rows_listed = False, 0
-        self.reset_clocks()
-
-    def reset_clocks(self):
-        self.t_a = self.t_b = self.t_bar = 0.0
-        self.groups = 0
-
-    def submit(self, counter0, mode=0, n_active=None):
-        t0 = time.perf_counter()
-        slot = self.p.bulk_phase_a(counter0, mode, n_active)
-        t1 = time.perf_counter()
-        if self.use_dist:
-            dist.barrier()
-        t2 = time.perf_counter()
-        if self.count_rows:
-            self.rows_listed += self.p.bulk_listed(slot)
-            t2 = time.perf_counter()
-        self.p.bulk_phase_b(slot)
-        t3 = time.perf_counter()
-        if self.use_dist:
-            dist.barrier()
-        t4 = time.perf_counter()
-        self.t_a += t1 - t0
-        self.t_b += t3 - t2
-        self.t_bar += (t2 - t1) + (t4 - t3)
-        self.groups += 1
-        return slot
-
-    def run_range(self, first, count, mode=0, wrap=None):
-        k, last = 0, None
-        while k < count:
-            b = (first + k) % wrap if wrap else first + k
-            n = min(self.group_size, count - k, (wrap - b) if wrap else count)
-            last = (self.submit(b, mode, n), b, n)
-            k += n
-        return last
-
-    def wait(self, slot=-1):
-        pass                                        # both phases synchronise their stream
-
-    def profile_begin(self):
-        pass
-
-    def profile_end(self):
-        pass
-
-    def profile_read(self):
-        return {}
-
-    def close(self):
-        self.p.close()
-
-
-def parse_args():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=32, help="timed steps; a step = one launch group of --group mini-batches")
-    ap.add_argument("--warmup", type=int, default=8, help="untimed warm-up steps (launch groups)")
-    ap.add_argument("--min-seconds", type=float, default=1.5,
-                    help="repeat the K-step timed region until this much time has been measured (median reported)")
-    ap.add_argument("--max-repeats", type=int, default=400)
-    ap.add_argument("--placement", type=str, default="hbm", choices=["hbm", "pinned"],
-                    help="pinned: full CSR and full feature table in mapped pinned host memory (the reference's only tier; "
-                         "BASELINE configs[2]): cache hits come from HBM, misses are read in place over PCIe")
-    ap.add_argument("--scramble", action="store_true",
-                    help="Graph500-style label scrambling of the RMAT vertices (hubs no longer sit at the low ids)")
-    ap.add_argument("--scale", type=int, default=26)
-    ap.add_argument("--nodes", type=int, default=0,
-                    help="with --edges: a skewed synthetic graph of exactly this many vertices and edges instead of RMAT-<scale> "
-                         "(synth.csr_device_large: any vertex count, more than 2^32 edges; the reference's real data-set sizes, "
-                         "legion_server.py:41-88, e.g. uk-union --nodes 133633040 --edges 5507679822)")
-    ap.add_argument("--edges", type=int, default=0)
-    ap.add_argument("--edge-factor", type=int, default=16)
-    ap.add_argument("--dim", type=int, default=128)
-    ap.add_argument("--batch", type=int, default=1024)
-    ap.add_argument("--fanout", type=str, default="25,10")
-    ap.add_argument("--cache-memory", type=int, default=8 << 30, help="bytes per GPU fed to the cost model")
-    ap.add_argument("--presc-steps", type=int, default=512, help="PreSC batches per GPU (bounded epoch)")
-    ap.add_argument("--cpu-seconds", type=float, default=16.0,
-                    help="target time of EACH CPU-baseline leg (Legion-semantics port, DGL-semantics port); 0 disables")
-    ap.add_argument("--group", type=int, default=0,
-                    help="mini-batches served by every launch (lanes of a group); 0 = 524288 // batch rounded down to a power of "
-                         "two, at most 512, halved while the lanes in flight would not fit 0.7 of the free HBM")
-    ap.add_argument("--slots", type=int, default=2, help="groups in flight per GPU")
-    ap.add_argument("--lanes", dest="lane_arena", default=True, type=lambda v: {"arena": True, "plain-arena": "plain", "separate": False}[v],
-                    help="where the lanes' trainer-visible arrays live: arena (default: one arena of shuffled physical chunks), plain-arena (one plain "
-                         "allocation: what the server's hand-over needs), separate (an allocation per array and lane)")
-    ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
-    ap.add_argument("--overlap", action="store_true", help="let kernels of different slots share the GPU")
-    ap.add_argument("--no-weave", action="store_true",
-                    help="everything of a group on ONE stream (default: the next group's head -- seeds + every hop but the last, small "
-                         "latency-bound kernels -- runs on a second stream under the current group's heavy kernels, pipeline.hip)")
-    ap.add_argument("--capacity", type=str, default="",
-                    help="NODE,EDGE: cache capacities per GPU set by hand after the cost model has run (its choice is logged): e.g. a "
-                         "topology cache of the EDGE hottest vertices' adjacency beside a pinned-host CSR (SURVEY section 8 N1)")
-    ap.add_argument("--no-cache", action="store_true",
-                    help="experiment: no feature/topology cache at all (no FillUp): every row comes from the full table and the "
-                         "gather makes no node_map lookup -- what the lookup's 128-byte line per row costs the gather")
-    ap.add_argument("--gather-rows", type=int, default=0, help="experiment: rows per gather workgroup (LegionTuning.gather_rows_per_wg)")
-    ap.add_argument("--no-verify", action="store_true")
-    ap.add_argument("--no-overlap-leg", action="store_true", help=argparse.SUPPRESS)      # (accepted, ignored: the leg it skipped was removed in round 5)
-    ap.add_argument("--no-boundary", action="store_true",
-                    help="skip the drop-in boundary leg (sampling_server binary -> shm/semaphores/IPC handles -> ipc_service "
-                         "consumer on an RMAT-22 data set written in the reference's file formats; N = 1 only, ~15 s)")
-    ap.add_argument("--no-traffic-leg", action="store_true",
-                    help="skip the measurement of roofline.traffic in this run (two fresh child processes of this command under "
-                         "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, N = 1 only; also skipped with --no-boundary)")
-    ap.add_argument("--traffic-deadline", type=int, default=300, help="seconds each of those child processes may take")
-    ap.add_argument("--boundary-modes", type=str, default="views,slab",
-                    help="boundary leg: hand-overs to measure, one server run per mode and batch size (tools/server_throughput.py --modes: "
-                         "views | slab | gather | copy); tools/profile_round.sh adds copy")
-    ap.add_argument("--boundary-batches", type=int, default=40000,
-                    help="boundary leg: timed batches per server run at least (the server runs as many epochs as that takes)")
-    ap.add_argument("--measured-counters", action="store_true", help="same as --link-counters computed")
-    ap.add_argument("--link-counters", type=str, default="v2", choices=["v2", "computed", "smi"],
-                    help="what feeds CostModel's PCIe transaction counters: v2 = {0,0} as the reference's v2 does; computed = the "
-                         "64-byte topology transactions the sampler counted during PreSC; smi = what the PCIe link really carried "
-                         "during PreSC, from the driver's cumulative gpu_metrics counter (the paper's Intel-PCM reading)")
-    ap.add_argument("--stripe", action="store_true",
-                    help="N > 1: one clique of N GPUs, feature/topology caches striped over the ranks and read "
-                         "through peer pointers over xGMI (default: every GPU caches for itself, no peer traffic)")
-    ap.add_argument("--replica-memory", type=int, default=0,
-                    help="with --stripe: bytes per GPU for a private copy of the clique's hottest rows (hits below that hotness "
-                         "rank are read from local HBM instead of a peer over xGMI; lookup results unchanged)")
-    ap.add_argument("--no-striped-leg", action="store_true",
-                    help="N > 1 without --stripe: skip the two extra timed legs with the caches striped over one clique of N "
-                         "(plain, and with a hot-row replica of --striped-replica-memory bytes)")
-    ap.add_argument("--no-bulk-leg", action="store_true",
-                    help="N > 1: skip the `striped_bulk` leg (striped caches, remote rows pushed by their owners: peer_gather = bulk)")
-    ap.add_argument("--striped-replica-memory", type=int, default=4 << 30,
-                    help="bytes per GPU of the hot-row replica in the `striped_replica` leg")
-    ap.add_argument("--backend", type=str, default="nccl", help="torch.distributed backend (nccl = RCCL)")
-    ap.add_argument("--no-product-collective", action="store_true",
-                    help="hotness all-reduce through torch.distributed instead of the library's own RCCL call")
-    ap.add_argument("--collective-deadline", type=int, default=120,
-                    help="seconds the library's communicator may take to form before the run falls back to torch.distributed")
-    ap.add_argument("--force-dist", action="store_true",
-                    help="initialise torch.distributed and run the collectives even at N = 1 (exercises the RCCL calls on a 1-GPU box)")
-    ap.add_argument("--extra-legs-deadline", type=int, default=600,
-                    help="N > 1: seconds the extra (striped) legs may take together before rank 0 prints the headline line alone and exits")
-    ap.add_argument("--fail-extra-leg", type=str, default="", choices=["", "raise", "exit", "sigterm", "hang"],
-                    help="testing: make rank 0 fail this way when the first extra leg starts (the headline line must still go out)")
-    ap.add_argument("--force-device", type=int, default=-1,
-                    help="put every rank on this GPU (testing the N > 1 code path on a 1-GPU box, with --backend gloo)")
-    return ap.parse_args()
+from tools import bench_legs as legs  # noqa: E402
+from tools.bench_legs import HBM_PEAK_GBPS  # noqa: E402
 
 
 def main():
-    args = parse_args()
+    args = legs.parse_args()
     # the library logs the reference's lines ("Alpha: ...", "Feat capacity: ...") on stdout from every
     # rank; keep the real stdout for the one JSON line and send everything else to stderr
     sys.stdout.flush()
-    one_line = OneLine(os.dup(1))
+    one_line = legs.OneLine(os.dup(1))
     os.dup2(2, 1)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -387,15 +182,27 @@ def main():
             sys.stderr.flush()
             os._exit(1)
 
+    # ---- N = 1, the default shape: Legion's default batch size on the same tables, driver-timed in the same run ----------------
+    # (like the boundary and traffic legs, part of the FULL default run only: --no-boundary, which every measurement script passes, skips it)
+    if world == 1 and not args.no_other_shapes and not args.no_boundary and args.placement == "hbm" and B == 1024 and args.nodes == 0 and not args.no_cache:
+        try:
+            c2 = shape_context(c, synth, 8000, args.other_shapes_steps, 2)
+            if c2 is not None:
+                out["other_shapes"] = [run_leg(c2, engine, synth, False, 0, headline=False, shape_leg=True)["json"]]
+        except Exception as e:      # the headline stands
+            import traceback
+            traceback.print_exc()
+            out["other_shapes"] = [{"error": f"{type(e).__name__}: {e}"[:400]}]
+
     if rank == 0:
         try:
             if world == 1 and not args.no_boundary and args.placement == "hbm":
-                out.update(boundary_leg(args, c.fanout))
+                out.update(legs.boundary_leg(args, c.fanout))
             if args.cpu_seconds > 0 and world == 1:      # reported at N = 1 only
                 out["cpu_baseline"] = cpu_baseline(indptr, col, c.mine, N, B, c.fanout, c.n_warm, args.cpu_seconds,
                                                    features if args.placement == "hbm" else None)
             if world == 1 and not args.no_boundary and not args.no_traffic_leg and args.placement == "hbm":
-                measured_traffic(args, out["roofline"], c.G)
+                legs.measured_traffic(args, out["roofline"], c.G)
         except Exception as e:      # (an armed exit hook must not outlive the interpreter: see above)
             import traceback
             traceback.print_exc()
@@ -412,12 +219,13 @@ def main():
         os._exit(0)
 
 
-def run_leg(c, engine, synth, stripe, replica_memory, headline, bulk=False):
+def run_leg(c, engine, synth, stripe, replica_memory, headline, bulk=False, shape_leg=False):
     """One cache layout over the resident workload: objects -> PreSC -> hotness all-reduce -> cost model -> fills -> pipeline ->
-    counting pass -> warm-up -> timed regions -> eager pass with HIP events around the gathers.  Returns {"json": rank 0's
-    report of the leg}.  The headline leg also verifies; the extra legs are shorter."""
+    counting pass -> warm-up -> timed regions -> eager pass with HIP events around the gathers (-> headline: the cold-row regather).
+    Returns {"json": rank 0's report of the leg}.  The headline leg also verifies; the extra legs are shorter.  shape_leg: another
+    batch shape of the same workload on one GPU (`other_shapes`), reported in the extra legs' short form."""
     args, world, rank, dev, use_dist = c.args, c.world, c.rank, c.dev, c.use_dist
-    if not headline and args.fail_extra_leg and rank == 0:        # (tests of OneLine)
+    if not headline and not shape_leg and args.fail_extra_leg and rank == 0:        # (tests of OneLine)
         if args.fail_extra_leg == "raise":
             raise RuntimeError("requested by --fail-extra-leg")
         if args.fail_extra_leg == "exit":
@@ -427,7 +235,7 @@ def run_leg(c, engine, synth, stripe, replica_memory, headline, bulk=False):
         while True:
             ctypes.CDLL(None).sleep(5)      # (a main thread that never comes back from a C call)
     fanout, H, N, D, B, G = c.fanout, c.H, c.N, c.D, c.B, c.G
-    n_warm, n_timed, wrap, mine = c.n_warm, c.n_timed, c.wrap, c.mine
+    n_timed, mine = c.n_timed, c.mine
     t_leg = time.time()
     P = world if stripe else 1              # logical GPUs the objects know about
     d = rank if stripe else 0               # the one this process owns
@@ -460,67 +268,7 @@ def run_leg(c, engine, synth, stripe, replica_memory, headline, bulk=False):
     lc1 = engine.link_counters(d)
     pcie_tx = (lc1[0] - lc0[0]) // 64 if (lc0 is not None and lc1 is not None) else None
     xgmi_tx = (lc1[1] - lc0[1]) // 64 if (lc0 is not None and lc1 is not None) else None
-    collective = None
-    if use_dist:    # the only collective of the path: RCCL all-reduce of the uint64 hotness counters
-        ones = torch.ones(1, dtype=torch.int64, device=red_dev)
-        dist.all_reduce(ones)                                   # the world size as torch.distributed sees it
-        torch.cuda.synchronize()
-        # The PRODUCT issues the collective (legion_amd/csrc/collective.hip: ncclAllReduce(ncclUint64, ncclSum) over its own
-        # communicator); torch.distributed only carries rank 0's 128-byte unique id to the other ranks.  A join or a call that
-        # fails or does not return within --collective-deadline seconds falls back to dist.all_reduce on the same arrays and
-        # the line says so -- a SCALE run must not be lost to the first meeting of this code with a second physical GPU.
-        issued_by, product_err, world_seen, ar_ms = None, None, 0, 0.0
-        if args.backend == "nccl" and not args.no_product_collective and not getattr(c, "product_collective_broken", False):
-            ids = [engine.collective_unique_id() if rank == 0 else None]
-            dist.broadcast_object_list(ids, src=0)
-            box = {}
-
-            def product_call():
-                try:
-                    if not engine.collective_init_rank(ids[0], world, rank, d):
-                        box["err"] = "legion_collective_init_rank failed"
-                        return
-                    box["joined"] = True
-                except Exception as e:      # noqa: BLE001
-                    box["err"] = repr(e)[:200]
-
-            th = threading.Thread(target=product_call, daemon=True)
-            th.start()
-            th.join(args.collective_deadline)
-            ok_t = torch.tensor([1 if box.get("joined") else 0], dtype=torch.int64, device=red_dev)
-            dist.all_reduce(ok_t, op=dist.ReduceOp.MIN)         # every rank takes the same path
-            if int(ok_t.item()) == 1:
-                dist.barrier()
-                t0 = time.perf_counter()
-                world_seen, ar_ms_lib = cache.allreduce_hotness(d)
-                torch.cuda.synchronize()
-                ar_ms = (time.perf_counter() - t0) * 1e3
-                ok_t = torch.tensor([1 if world_seen == world else 0], dtype=torch.int64, device=red_dev)
-                dist.all_reduce(ok_t, op=dist.ReduceOp.MIN)
-                if int(ok_t.item()) == 1:
-                    issued_by = "liblegion_hip.so (collective.hip: ncclAllReduce, ncclUint64, ncclSum, in place, the library's own communicator)"
-                else:
-                    raise RuntimeError("the product's hotness all-reduce ran on some ranks only: the counters are inconsistent")
-            else:
-                product_err = box.get("err", f"no join within {args.collective_deadline} s")
-                c.product_collective_broken = True      # (a join that is still stuck holds the library's lock: later legs do not try again)
-        if issued_by is None:
-            dist.barrier()
-            t0 = time.perf_counter()
-            dist.all_reduce(cache.array("node_access_time", d))
-            dist.all_reduce(cache.array("edge_access_time", d))
-            torch.cuda.synchronize()
-            ar_ms = (time.perf_counter() - t0) * 1e3
-            world_seen = int(ones.item())
-            issued_by = f"torch.distributed ({dist.get_backend()})" + (" -- the product's own call was not used: " + product_err if product_err else "")
-        ar_t = torch.tensor([ar_ms], dtype=torch.float64, device=red_dev)
-        dist.all_reduce(ar_t, op=dist.ReduceOp.MAX)
-        collective = {"backend": "rccl" if "liblegion" in issued_by else dist.get_backend(), "issued_by": issued_by,
-                      "world_size_seen_by_all_reduce": int(world_seen),
-                      "hotness_all_reduce_ms": float(ar_t.item()), "hotness_all_reduce_bytes": 2 * N * 8,
-                      "hotness_all_reduce_GBps_algorithmic": 2 * N * 8 / max(float(ar_t.item()), 1e-6) / 1e6,
-                      "note": "two uint64[N] arrays (node and edge access counts), all-reduced in place once before CandidateSelection; "
-                              "time = max over ranks, wall clock around both calls incl. synchronize"}
+    collective = legs.hotness_collective(c, engine, cache, d, red_dev) if use_dist else None
     max_ids = cache.max_id_num(d)
     topo_tx = cache.topo_transactions(d)
     if use_dist:
@@ -566,7 +314,7 @@ def run_leg(c, engine, synth, stripe, replica_memory, headline, bulk=False):
         # peer_gather = bulk (pipeline.hip): the rows of other members' stripes are pushed by their OWNERS; a group runs as
         # phase A (own sampler + lists + local gather) -> barrier -> phase B (push for the others) -> barrier, eager launches
         weave = False
-        pipe = BulkPipe(engine.Pipeline(graph, feature, cache, d, B, fanout, G, feature_rows, False, args.slots, arena="shared"), use_dist)
+        pipe = legs.BulkPipe(engine.Pipeline(graph, feature, cache, d, B, fanout, G, feature_rows, False, args.slots, arena="shared"), use_dist)
         hs = [None] * world
         dist.all_gather_object(hs, pipe.p.bulk_export())
         for r, h in enumerate(hs):
@@ -579,144 +327,17 @@ def run_leg(c, engine, synth, stripe, replica_memory, headline, bulk=False):
     torch.cuda.synchronize()
     setup_s = time.time() - (c.t_setup if headline else t_leg)
 
-    # ---- untimed counting pass over exactly the timed batches (deterministic) --------------------
-    first = n_warm
-    edges = np.zeros(n_timed, dtype=np.int64)
-    rows = np.zeros((n_timed, H + 1), dtype=np.int64)
-    hop_edges = np.zeros((n_timed, H), dtype=np.int64)
-    hop_slots = np.zeros((n_timed, H), dtype=np.int64)
-    hits = 0
+    # ---- counting pass, timed regions, the verification of what the last replay left, the profiled pass ---------------------------
     have_map = cache.node_capacity(d) > 0 and not args.no_cache
     node_map = cache.array("node_map", d) if have_map else torch.empty(0, dtype=torch.int32, device=dev)
-    feat_hit_rows = feat_miss_rows = 0           # over every timed batch (all hops)
-    if stripe:
-        cache.gather_stats3(d)                   # arms the row-source counters for this (untimed) pass only
-    if bulk:
-        pipe.count_rows = True
-    for k in range(n_timed):
-        if k % G == 0:
-            slot = pipe.submit((first + k) % wrap if wrap else first + k)
-            pipe.wait(slot)
-        pl = pipe.pools[slot][k % G]
-        nc = pl.buffer("node_counter").cpu().numpy()
-        ec = pl.buffer("edge_counter").cpu().numpy()
-        edges[k] = ec[9 + H]
-        rows[k, 0] = nc[9]
-        if node_map.numel() > 0 and (args.placement == "pinned" or k < G):
-            hm = node_map[pl.buffer("sampled_ids")[:int(nc[9 + H])].long()] >= 0
-            feat_hit_rows += int(hm.sum())
-            feat_miss_rows += int(hm.numel() - int(hm.sum()))
-        for h in range(H):
-            rows[k, h + 1] = nc[9 + h + 1] - nc[9 + h]
-            hop_edges[k, h] = ec[9 + h + 1] - ec[9 + h]
-            hop_slots[k, h] = (nc[9] if h == 0 else ec[9 + h] - ec[9 + h - 1]) * fanout[h]
-        if k == 0 and headline and not args.no_verify:
-            # size-independent parity properties at full size: every gathered row is byte-identical to
-            # the generator's value for its id; ids are unique; positions localise the edge endpoints
-            n = int(nc[9 + H])
-            assert n <= feature_rows
-            ids = pl.buffer("sampled_ids")[:n]
-            bad_words = synth.feature_check_device(pl.buffer("float_features")[:n].contiguous(), ids.contiguous(), D, 7)
-            assert bad_words == 0, f"{bad_words} gathered words differ from the source rows"
-            assert int(torch.unique(ids).numel()) == n, "duplicate node ids in the batch"
-            e = int(ec[9 + H])
-            src_g = pl.buffer("agg_src_ids")[:e].long()
-            assert bool((ids.long()[pl.buffer("agg_src_off")[:e].long()] == src_g).all())
-            hits = int((pl.buffer("cache_search_buffer")[:int(nc[1])] >= 0).sum())
-    if bulk:
-        pipe.count_rows = False
-        pipe.reset_clocks()
-    source_rows = None
-    if stripe:                                   # where this rank's gathers read the timed batches' hit rows from
-        source_rows = cache.gather_stats3(d)
-        cache.gather_stats_enable(False)         # counting costs an atomic per hit row: off before anything is timed
-
-    # ---- warm-up, then the timed region: exactly K steps (K hipGraph replays of G batches each) between
-    #      barrier + synchronize brackets.  The region is repeated (same batches: an epoch over the same
-    #      seeds, replays are deterministic) until --min-seconds have been timed; every rank runs the same
-    #      number of repeats, per repeat the MAX over ranks counts, and the median repeat is reported. -------
-    pipe.run_range(0, n_warm, wrap=wrap)
-    pipe.wait()
-
-    def timed_region(p=None):
-        p = p or pipe
-        if use_dist:
-            dist.barrier()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        last = p.run_range(first, n_timed, wrap=wrap)
-        p.wait()
-        torch.cuda.synchronize()
-        if use_dist:
-            dist.barrier()
-        torch.cuda.synchronize()
-        return time.perf_counter() - t0, last
-
-    min_seconds = args.min_seconds if headline else 0.5 * args.min_seconds
-    time.sleep(0.005)
-    lk0, t_lk0 = engine.link_counters_ex(d), time.perf_counter()
-    el0, last_group = timed_region()
-    reps_t = torch.tensor([max(1, min(args.max_repeats, int(np.ceil(min_seconds / max(el0, 1e-6)))))],
-                          dtype=torch.int64, device=dev)
-    if use_dist:
-        dist.all_reduce(reps_t, op=dist.ReduceOp.MAX)
-    repeats = int(reps_t.item())
-    region_s = [el0]
-    for _ in range(repeats - 1):
-        el, last_group = timed_region()
-        region_s.append(el)
-    time.sleep(0.005)
-    lk1, t_lk1 = engine.link_counters_ex(d), time.perf_counter()
-    own_region = float(np.median(np.asarray(region_s)))                     # this rank's own clock (brackets include the barriers)
-    region_t = torch.tensor(region_s, dtype=torch.float64, device=dev)
-    if use_dist:
-        dist.all_reduce(region_t, op=dist.ReduceOp.MAX)              # per repeat: the slowest rank
-    region_s = region_t.cpu().numpy()
-    elapsed_max = float(np.median(region_s))
-    elapsed = elapsed_max                                            # used for the rank-0 sampler/gather split below
-    if headline and not args.no_verify and last_group is not None:
-        # the last group of the timed region is still in its slot: its batches must be the ones the counting
-        # pass saw (replays are deterministic), and its last lane passes the full-size property checks
-        slot, k0, n_lanes = last_group
-        for lane in range(n_lanes):
-            pl = pipe.pools[slot][lane]
-            nc = pl.buffer("node_counter").cpu().numpy()
-            ec = pl.buffer("edge_counter").cpu().numpy()
-            k = n_timed - n_lanes + lane          # the last group submitted holds the last n_lanes batches of the region
-            assert ec[9 + H] == edges[k] and nc[9 + H] - nc[9] == rows[k, 1:].sum(), f"replayed batch {k0 + lane} differs"
-        n = int(nc[9 + H])
-        ids = pl.buffer("sampled_ids")[:n]
-        assert synth.feature_check_device(pl.buffer("float_features")[:n].contiguous(), ids.contiguous(), D, 7) == 0
-        assert int(torch.unique(ids).numel()) == n
-
-    # ---- the same K batches once more with HIP events around every gather launch (recorded on the
-    #      lane's own stream).  Eager launches: HIP cannot time events recorded by graph nodes. ------
-    pipe.profile_begin()
-    pipe.run_range(0, n_warm, wrap=wrap)
-    pipe.wait()
-    warm = pipe.profile_read()
-    t1 = time.perf_counter()
-    pipe.run_range(first, n_timed, wrap=wrap)
-    pipe.wait()
-    elapsed_profiled = time.perf_counter() - t1
-    prof = pipe.profile_read()
-    pipe.profile_end()
-    prof = {op: (ms - warm.get(op, (0.0, 0))[0], cnt - warm.get(op, (0.0, 0))[1]) for op, (ms, cnt) in prof.items()}
-    err_bits = 0                              # LG_ERR_* bits a kernel raised for any lane (table full, feature rows, chain)
-    for row in pipe.pools:
-        for pl in row:
-            err_bits |= pl.error()
-    if err_bits:
-        raise RuntimeError(f"a kernel raised error bits {err_bits:#x} during the run (legion_core.h LG_ERR_*)")
+    counted = legs.counting_pass(c, synth, pipe, cache, d, node_map, feature_rows, headline or shape_leg, stripe, bulk)
+    edges, rows, hop_edges, hop_slots = counted.edges, counted.rows, counted.hop_edges, counted.hop_slots
+    timed = legs.timed_regions(c, engine, pipe, d, headline)
+    elapsed_max = elapsed = timed.elapsed_max                        # (`elapsed`: the rank-0 sampler / gather split below)
+    if headline and not args.no_verify and timed.last_group is not None:
+        legs.verify_last_group(c, synth, pipe, counted, timed.last_group)
+    prof, elapsed_profiled = legs.profiled_pass(c, pipe)
     state_bytes, lds_buckets = pipe.pools[0][0].state_bytes(), pipe.pools[0][0].lds_buckets()
-
-    pipe.close()
-
-    tot_edges = torch.tensor([float(edges.sum())], dtype=torch.float64, device=dev)
-    gather_bytes_t = torch.tensor([float(rows.sum() * D * 4)], dtype=torch.float64, device=dev)
-    if use_dist:
-        dist.all_reduce(tot_edges)
-        dist.all_reduce(gather_bytes_t)
 
     # ---- roofline of the dominant kernel: the last hop's gather (op 3H+1) -------------------------
     last_op = 3 * H + 1
@@ -727,74 +348,26 @@ def run_leg(c, engine, synth, stripe, replica_memory, headline, bulk=False):
     achieved = rows_last * bytes_per_row / t_last / 1e9 if t_last > 0 else 0.0
     t_all_gathers = sum(v[0] for v in prof.values()) * 1e-3
     payload_gbps = float(rows.sum() * D * 4) / t_all_gathers / 1e9 if t_all_gathers > 0 else 0.0
+    # the same launch alone and over rows that never repeat (rank 0 of a one-GPU run: the figure is about the kernel, not the job)
+    cold = None
+    if (headline or shape_leg) and world == 1 and not bulk and not args.no_cold_leg and (not args.no_boundary or args.cold_leg):
+        try:
+            cold = legs.cold_regather(c, pipe, node_map, bytes_per_row)
+        except Exception as e:      # a diagnostic: never the reason a headline is lost
+            cold = {"error": repr(e)[:300]}
+    pipe.close()
+
+    tot_edges = torch.tensor([float(edges.sum())], dtype=torch.float64, device=dev)
+    gather_bytes_t = torch.tensor([float(rows.sum() * D * 4)], dtype=torch.float64, device=dev)
+    if use_dist:
+        dist.all_reduce(tot_edges)
+        dist.all_reduce(gather_bytes_t)
     # sampler side: bytes = sum_h [S_h*25/f_h + E_h*44 + U_h*8]; time = step time minus the gathers
     samp_bytes = sum(float(hop_slots[:, h].sum()) * 25.0 / fanout[h] + float(hop_edges[:, h].sum()) * 44.0 +
                      float(rows[:, h + 1].sum()) * 8.0 for h in range(H))
     t_sampling = max(elapsed - t_all_gathers, 1e-9)
-
-    # ---- N > 1: what every rank saw, so that one SCALE invocation is its own evidence ------------------------------
-    per_rank = None
-    if use_dist:
-        window_s = t_lk1 - t_lk0
-        mine_info = {"rank": rank, "pci_bus_id": lk1["pci_bus_id"], "gpu_metrics_revision": lk1["gpu_metrics_revision"],
-                     "edges_per_sec": float(edges.sum()) / max(own_region, 1e-9),
-                     "gather_roofline_frac": achieved / HBM_PEAK_GBPS, "gather_avg_launch_us": t_last / max(n_last, 1) * 1e6}
-        if lk0["supported"] and lk1["supported"]:
-            xr = lk1["xgmi_read_bytes"] - lk0["xgmi_read_bytes"]
-            mine_info.update({"xgmi_read_bytes": xr, "xgmi_write_bytes": lk1["xgmi_write_bytes"] - lk0["xgmi_write_bytes"],
-                              "xgmi_read_GBps": xr / max(window_s, 1e-9) / 1e9,
-                              "xgmi_read_bytes_link": [b - a for a, b in zip(lk0["xgmi_read_bytes_link"], lk1["xgmi_read_bytes_link"])],
-                              "pcie_bytes": lk1["pcie_bytes"] - lk0["pcie_bytes"], "window_s": window_s,
-                              "window": f"{repeats} timed regions incl. their barriers"})
-        if source_rows is not None:
-            # rows of ONE timed region by where the gather read them: computed by the kernel in the untimed counting pass
-            stripe_rows, replica_rows_read, peer_rows = source_rows
-            mine_info.update({"rows_from_own_stripe": stripe_rows - peer_rows, "rows_from_peer_stripes": peer_rows,
-                              "rows_from_local_replica": replica_rows_read, "rows_gathered": int(rows.sum()),
-                              "peer_bytes_per_region_computed": peer_rows * D * 4,
-                              "peer_read_GBps_computed": peer_rows * D * 4 / max(own_region, 1e-9) / 1e9})
-            if "xgmi_read_bytes" in mine_info:
-                mine_info["xgmi_read_bytes_per_region_measured"] = mine_info["xgmi_read_bytes"] / repeats
-        if bulk:
-            pushed = pipe.rows_listed                              # rows the other members pushed into this GPU per counted region
-            mine_info["bulk"] = {"rows_pushed_into_me_per_region": pushed, "bytes_pushed_into_me_per_region": pushed * D * 4,
-                                 "phase_a_s_per_group": pipe.t_a / max(pipe.groups, 1), "phase_b_s_per_group": pipe.t_b / max(pipe.groups, 1),
-                                 "barriers_s_per_group": pipe.t_bar / max(pipe.groups, 1), "groups_clocked": pipe.groups,
-                                 "push_GBps_out_of_me": (pushed * D * 4 / max(args.steps, 1)) / max(pipe.t_b / max(pipe.groups, 1), 1e-9) / 1e9,
-                                 "note": "phase A = own sampler + per-owner lists + gather of local rows; phase B = this GPU as an owner pushing "
-                                         "the rows the others listed (about as many as were pushed into it); wall clock incl. stream synchronise"}
-        per_rank = [None] * world
-        dist.all_gather_object(per_rank, mine_info)
-
-    # HBM traffic of that kernel cannot be read live: it comes from the committed PMC summary
-    # (profiles/rNN/pmc_gather_kernel.json: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of
-    # this same command, gfx950 corrections applied), used only when it was taken on this configuration
-    traffic, traffic_src = None, None
-    import glob
-    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "pmc_gather_kernel.json")), reverse=True):
-        try:
-            pmc = json.load(open(f))
-        except (OSError, ValueError):
-            continue
-        if pmc.get("batches_per_launch_group") == G and f"batch {B}," in pmc.get("config", "") and f"N x {D}]" in pmc.get("config", "") \
-                and f"RMAT-{args.scale} " in pmc.get("config", "") and ("scrambled" in pmc.get("config", "")) == bool(args.scramble):
-            traffic = pmc["traffic_bytes_per_launch"] / pmc["rows_per_launch"] * (rows_last / max(n_last, 1))
-            traffic_src = os.path.relpath(f, ROOT)
-            break
-
-    # the same kernel's average duration in the committed rocprofv3 kernel trace of this command (profiles/rNN/, tools/profile_round.sh)
-    rocprof_us, rocprof_src = None, None
-    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "bench_default_kernel_trace_by_grid.csv")), reverse=True):
-        try:
-            for ln in open(f).read().splitlines()[1:]:
-                cols = ln.rsplit(",", 10)       # kernel (its template arguments contain commas), then ten numeric columns
-                if len(cols) == 11 and "gather_kernel" in cols[0] and cols[0].rstrip().endswith("true>") and int(cols[2]) == G:
-                    rocprof_us, rocprof_src = float(cols[7]), os.path.relpath(f, ROOT)
-                    break
-        except (OSError, ValueError, KeyError):
-            continue
-        if rocprof_us is not None:
-            break
+    per_rank = legs.per_rank_info(c, timed, counted, achieved, t_last, n_last, pipe, bulk) if use_dist else None
+    traffic_committed, traffic_committed_src, rocprof_us, rocprof_src = legs.committed_profiles(c, rows_last, n_last)
 
     out = None
     if rank == 0:
@@ -803,11 +376,12 @@ def run_leg(c, engine, synth, stripe, replica_memory, headline, bulk=False):
                   if stripe else f"seed-sharded x{world}, replicated graph+features, cache_agg_mode 0")
         roof = {"bound": "hbm", "kernel": "lg::gather_kernel<..., LASTOP = true> (hop-%d gather, op %d: the instance launched for a batch's last op)" % (H, last_op),
                 "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_unit": "bytes per launch",
-                "traffic_source": traffic_src, "traffic_committed_source": traffic_src,
-                "traffic_is": "`traffic` = the committed PMC figure of this kernel on this configuration rescaled by this run's rows (a claim "
-                              "about the kernel; counters cannot be read while timing); `traffic_measured` (N = 1, when the traffic leg ran) "
-                              "= the same two counters collected by child processes of THIS run",
+                "frac": achieved / HBM_PEAK_GBPS,
+                "traffic": None, "traffic_unit": "bytes per launch", "traffic_source": None,
+                "traffic_committed": traffic_committed, "traffic_committed_source": traffic_committed_src,
+                "traffic_is": "`traffic` = HBM bytes per launch from FETCH_SIZE + WRITE_SIZE collected by child processes of THIS run (N = 1, "
+                              "the default command; null where that leg did not run); `traffic_committed` = the committed profile's figure for "
+                              "this configuration rescaled by this run's rows",
                 "rocprofv3_avg_launch_us": rocprof_us, "rocprofv3_source": rocprof_src,
                 "algorithmic_bytes_per_launch": rows_last / max(n_last, 1) * bytes_per_row,
                 "bytes_per_row": bytes_per_row, "rows_per_launch": rows_last / max(n_last, 1),
@@ -816,13 +390,27 @@ def run_leg(c, engine, synth, stripe, replica_memory, headline, bulk=False):
                             "steps, %d batches per launch, eager launches (wall clock of that pass: ms_per_step %.4f; "
                             "hipGraph replay, timed region: %.4f)"
                             % (H, args.steps, G, elapsed_profiled / args.steps * 1e3, elapsed_max / args.steps * 1e3)}
-        timed = {"steps": args.steps, "repeats": repeats, "median_s": elapsed_max,
-                 "min_s": float(region_s.min()), "max_s": float(region_s.max()), "total_timed_s": float(region_s.sum()),
-                 "note": "exactly K steps per region between barrier+synchronize brackets; region repeated over the "
-                         "same batches until --min-seconds; per repeat the max over ranks; value uses the median"}
+        if counted.unique is not None:
+            u = counted.unique
+            roof["unique_row_frac"] = u["unique_rows"] / max(u["rows"], 1)
+            roof["row_reuse"] = {"rows": u["rows"], "unique_rows": u["unique_rows"], "rows_gathered_once": u["rows_gathered_once"],
+                                 "repeat_rows": u["repeat_rows"], "unique_rows_bytes": u["unique_rows"] * D * 4,
+                                 "infinity_cache_bytes": legs.INFINITY_CACHE_BYTES,
+                                 "note": "the last hop's rows of ONE launch group (%d mini-batches): a vertex new to several batches of the "
+                                         "group is gathered once per batch; FETCH_SIZE counts a repeat the memory-side cache serves as a "
+                                         "fabric read all the same (MI355X_MICROARCH.md), so `frac` is a fabric-side figure and "
+                                         "`cold.frac` the HBM-only one" % G}
+        if cold is not None:
+            roof["cold"] = cold.get("cold") if "error" not in cold else None
+            roof["alone"] = cold.get("alone")
+            roof["cold_note"] = cold.get("note") or cold.get("error")
+        timed_j = {"steps": args.steps, "repeats": timed.repeats, "median_s": elapsed_max,
+                   "min_s": float(timed.region_s.min()), "max_s": float(timed.region_s.max()), "total_timed_s": float(timed.region_s.sum()),
+                   "note": "exactly K steps per region between barrier+synchronize brackets; region repeated over the "
+                           "same batches until --min-seconds; per repeat the max over ranks; value uses the median"}
         if not headline:
             out = {"value": float(tot_edges.item()) / elapsed_max, "unit": "edges/s", "ms_per_step": elapsed_max / args.steps * 1e3,
-                   "parallelism": layout, "timed_region": timed, "roofline": roof,
+                   "parallelism": layout, "timed_region": timed_j, "roofline": roof,
                    "feature_gather_GBps": payload_gbps, "feature_cache_rows": cache.node_capacity(d),
                    "topology_cache_vertices": cache.edge_capacity(d), "hot_row_replica_rows": cache.replica_rows(d),
                    "collective": collective, "per_rank": per_rank, "setup_seconds": setup_s,
@@ -837,6 +425,15 @@ def run_leg(c, engine, synth, stripe, replica_memory, headline, bulk=False):
                                "owners (LegionTuning.peer_gather = bulk: whole rows as coalesced posted stores over xGMI instead of scattered "
                                "512-1024-byte load round trips); eager launches, two host barriers per launch group (per_rank[].bulk has the "
                                "phase clocks): compare its xGMI GB/s and ms_per_step with `striped`, minus the barrier time")
+            if shape_leg:
+                for k in ("collective", "per_rank", "xgmi_ingest_peak_GBps_per_gpu", "hot_row_replica_rows"):
+                    out.pop(k, None)
+                out.update({"steps": args.steps, "warmup": c.n_warm // G, "batches_per_step": G,
+                            "workload": f"{c.graph_name}, float32[N x {D}] features, batch {B}, fanout {fanout}, all tables resident in HBM",
+                            "sampling_only_edges_per_sec": float(edges.sum()) / t_sampling,
+                            "edges_per_batch": float(edges.mean()), "rows_per_batch": float(rows.sum(axis=1).mean()),
+                            "note": "another batch shape of the headline's graph and feature table, same code path, same brackets (K steps per "
+                                    "region, median region), in the same process right after the headline leg; not `value`"})
         else:
             out = {
                 "metric": "sampled_edges_per_sec",
@@ -845,7 +442,7 @@ def run_leg(c, engine, synth, stripe, replica_memory, headline, bulk=False):
                 "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                 "ms_per_step": elapsed_max / args.steps * 1e3,
                 "batches_per_step": G, "ms_per_batch": elapsed_max / n_timed * 1e3,
-                "timed_region": timed,
+                "timed_region": timed_j,
                 "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                 "dtype": "int32+f32(copy)", "data": "synthetic",
                 "config": {"workload": f"{c.graph_name}, "
@@ -858,7 +455,7 @@ def run_leg(c, engine, synth, stripe, replica_memory, headline, bulk=False):
                            "batches_per_launch_group": G, "groups_in_flight": args.slots,
                            "lane_arrays": {True: "one arena of shuffled 2 MB physical chunks (LegionTuning.arena_scatter_mb)", "plain": "one plain arena", False: "separate allocations"}[args.lane_arena], "epoch_batches": c.epoch_batches,
                            "streams": "weave: head of group k+1 on a second stream under the heavy kernels of group k" if weave else "one",
-                           "epochs_wrap": bool(wrap), "hipgraph": not args.no_graph,
+                           "epochs_wrap": bool(c.wrap), "hipgraph": not args.no_graph,
                            "cache_memory_bytes": args.cache_memory,
                            "feature_cache_rows": cache.node_capacity(d), "topology_cache_vertices": cache.edge_capacity(d),
                            "presc_batches": train_step, "presc_topology_transactions": topo_tx,
@@ -876,19 +473,19 @@ def run_leg(c, engine, synth, stripe, replica_memory, headline, bulk=False):
                                           "the de-duplication and compaction by their dependent chains: DESIGN.md section 4.2"},
                 "edges_per_step": float(edges.sum()) / args.steps, "rows_per_step": float(rows.sum()) / args.steps,
                 "edges_per_batch": float(edges.mean()), "rows_per_batch": float(rows.sum(axis=1).mean()),
-                "seed_feature_cache_hits_step0": hits,
+                "seed_feature_cache_hits_step0": counted.hits,
                 "roofline": roof,
                 "setup_seconds": setup_s,
                 "first_touch_state": {"form": "none per vertex: a hop's claims are de-duplicated bucket by bucket in LDS", "bytes_per_lane": state_bytes,
                                       "lanes": G * args.slots, "lds_buckets_per_lane": lds_buckets},
-                "feature_cache_hit_rate": feat_hit_rows / max(feat_hit_rows + feat_miss_rows, 1),
+                "feature_cache_hit_rate": counted.feat_hit_rows / max(counted.feat_hit_rows + counted.feat_miss_rows, 1),
                 "feature_cache_hit_rate_over": "every timed batch" if args.placement == "pinned" else "the first timed step",
             }
             if collective is not None:
                 out["collective"] = collective
                 out["per_rank"] = per_rank
             if args.placement == "pinned":
-                miss_frac = feat_miss_rows / max(feat_hit_rows + feat_miss_rows, 1)
+                miss_frac = counted.feat_miss_rows / max(counted.feat_hit_rows + counted.feat_miss_rows, 1)
                 miss_gbps = float(rows.sum() * D * 4) * miss_frac / t_all_gathers / 1e9 if t_all_gathers > 0 else 0.0
                 out["miss_path"] = {"feature_rows_missed_frac": miss_frac, "pcie_feature_GBps": miss_gbps,
                                     "pcie_peak_GBps": 64.0, "frac_of_pcie_peak": miss_gbps / 64.0,
@@ -905,153 +502,25 @@ def run_leg(c, engine, synth, stripe, replica_memory, headline, bulk=False):
     return {"json": out}
 
 
-def boundary_leg(args, fanout):
-    """The same kernels behind the reference's own server <-> trainer protocol (tools/server_throughput.py): the
-    `sampling_server` binary serving a Python `ipc_service` consumer one mini-batch per semaphore hand-off into one of two
-    pipe slots -- on the bench's own graph (RMAT-26) at the bench's batch size AND at Legion's default B = 8000, where the
-    per-batch hand-over latency no longer hides the GPU.  Reported beside the headline, never as `value`.  The data set is
-    written to /tmp in the reference's file formats (CSR 4.8 GB at RMAT-26; no `features` file: the server serves a zero-filled
-    table of the same shape, as v2 of the reference does, storage_management.cu:162); without room there the leg falls back
-    to RMAT-22 and says so."""
-    import shutil
-    import subprocess
-    scale = args.scale
-    need = (1 << scale) * (8 + 4 * args.edge_factor + 4) + (2 << 30)
-    note = None
-    try:
-        free = shutil.disk_usage("/tmp").free
-    except OSError:
-        free = 0
-    if free < need:
-        note = f"/tmp has {free >> 20} MiB free, the RMAT-{scale} data set needs {need >> 20}: boundary leg run at RMAT-22 instead"
-        scale = min(scale, 22)
-    batches = [args.batch] + ([8000] if args.batch != 8000 else [])
-    # how a batch reaches the trainer end (LegionTuning.runner_handover, server.hip): `views` -- whole launch groups into the
-    # server's lane arena, this build's ipc_service takes every batch as views of its lane: what a user of legion_graphsage.py
-    # gets; `slab` -- the same server with a trainer end that opens only the reference's slab: one gather launch per batch
-    # straight into the pipe slot (round 3's path; the COMPATIBILITY path, not the fast one)
-    cmd = [sys.executable, os.path.join(ROOT, "tools", "server_throughput.py"), "--scale", str(scale), "--edge-factor", str(args.edge_factor),
-           "--batch", ",".join(str(b) for b in batches), "--dim", str(args.dim), "--fanout", ",".join(str(f) for f in fanout),
-           "--train-batches", str(max(64, min(3072, (3 << 20) // args.batch))), "--no-features-file", "--cache-memory", str(args.cache_memory),
-           "--modes", args.boundary_modes, "--min-timed-batches", str(args.boundary_batches), "--watchdog", "800"]
-    try:
-        res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=1200)
-        lines = [json.loads(ln) for ln in res.stdout.splitlines() if ln.startswith("{")]
-        if not lines:
-            raise RuntimeError(res.stderr[-300:])
-        def leg_of(r):
-            return {"mode": r.get("mode"), "batch": r["batch"], "batches_per_sec": r["batches_per_sec"], "edges_per_sec": r["edges_per_sec"],
-                    "handover": r.get("handover"), "path": r["path"], "workload": r["workload"], "ms_per_batch": r["ms_per_batch"],
-                    "timed_batches": r["timed_batches"], "epochs": r.get("epochs"), "server_cpu_cores": r.get("server_cpu_cores")}
-        legs = [leg_of(r) for r in lines]
-        # ... and once more with a consumer that READS every batch it is handed (one launch per get_next over the rows and the
-        # outermost COO pair, completed before the batch is released): the protocol-only figure above is a rate of hand-overs
-        # nobody looks at; this one shares the HBM with the server's gathers like a training loop's first layer would
-        consuming = None
-        try:
-            i = cmd.index("--modes")
-            cmd2 = cmd[:i] + ["--modes", "views"] + cmd[i + 2:]
-            i = cmd2.index("--min-timed-batches")
-            cmd2[i + 1] = str(max(2000, args.boundary_batches // 4))
-            res2 = subprocess.run(cmd2 + ["--consume"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
-            l2 = [json.loads(ln) for ln in res2.stdout.splitlines() if ln.startswith("{")]
-            if not l2:
-                raise RuntimeError(res2.stderr[-300:])
-            consuming = {"by_batch_size": [leg_of(r) for r in l2],
-                         "note": "views hand-over with a trainer end that reads every batch: legion_consume_batch (one launch: every float of "
-                                 "the rows + the outermost COO pair) and a stream synchronise before each synchronize(), as the protocol "
-                                 "demands of a consumer that reads in place; the consumer's reads share the HBM with the server's gathers "
-                                 "(+ rows x D x 4 bytes of traffic per batch), and at B = 1024 its per-batch launch + synchronise "
-                                 "(~10 us of host time) exceeds the 6.3 us the server needs per batch"}
-        except Exception as e:
-            consuming = {"error": repr(e)[:300]}
-        first = legs[0]
-        out = {"boundary_batches_per_sec": first["batches_per_sec"], "boundary_edges_per_sec": first["edges_per_sec"],
-               "boundary": {"path": first["path"], "workload": first["workload"], "ms_per_batch": first["ms_per_batch"],
-                            "timed_batches": first["timed_batches"], "handover": first["handover"],
-                            "what_it_measures": "the hand-over protocol with a consumer that never reads a row (zero-filled feature table of the "
-                                                "right shape): the rate at which batches CAN be taken; `consuming_trainer` reads them",
-                            "by_batch_size": [l for l in legs if l["mode"] == "views"],
-                            "consuming_trainer": consuming,
-                            "slab_only_trainer": {"note": "the COMPATIBILITY path: a trainer end that opens only the reference's slab (a build of "
-                                                          "TB/ipc_cuda_kernel.cu; no views of the lane arena) gets every batch gathered into the "
-                                                          "pipe slot by one launch, two slots in flight -- bound by the launch -> completion -> "
-                                                          "semaphore round trip per batch, not by the GPU",
-                                                  "by_batch_size": [l for l in legs if l["mode"] != "views"]}}}
-        if note:
-            out["boundary"]["note"] = note
-        return out
-    except Exception as e:            # the headline must not depend on this leg
-        return {"boundary_batches_per_sec": None, "boundary": {"error": repr(e)[:300]}}
-
-
-def measured_traffic(args, roof, G):
-    """roofline.traffic MEASURED in this run: two fresh child processes of this very command -- started as
-    children, never an exec of this process -- under `rocprofv3 --kernel-trace --pmc FETCH_SIZE` and `... WRITE_SIZE` (separate
-    passes, counters beside the kernel trace only, the interpreter binary directly behind `--`: MI355X_MICROARCH.md, HBM), two
-    timed steps each on the same workload and group size; folded as tools/pmc_summary.py folds the committed profile (both
-    counters KiB; FETCH_SIZE doubled: gfx950 tallies the 128-byte requests of a 16-byte-per-lane stream at 64 B).  Adds
-    traffic_measured / traffic_over_algorithmic / traffic_source to `roof`; the committed figure stays beside it as the
-    cross-check.  A child that fails or hangs costs only these fields."""
-    import csv
-    import glob
-    import shutil
-    import tempfile
-    prof = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
-    if prof is None:
-        roof["traffic_measured"], roof["traffic_measured_note"] = None, "rocprofv3 not found on this box"
-        return
-    t0 = time.time()
-    shape = ["--scale", str(args.scale), "--edge-factor", str(args.edge_factor), "--dim", str(args.dim), "--batch", str(args.batch),
-             "--fanout", args.fanout, "--group", str(G), "--cache-memory", str(args.cache_memory)]
-    if args.nodes > 0:
-        shape += ["--nodes", str(args.nodes), "--edges", str(args.edges)]
-    if args.scramble:
-        shape += ["--scramble"]
-    child = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--presc-steps", "64", "--cpu-seconds", "0",
-             "--no-verify", "--no-boundary", "--min-seconds", "0.01"] + shape
-    got, rows_child, note = {}, None, None
-    tmp = tempfile.mkdtemp(prefix="legion_pmc_", dir="/tmp")
-    try:
-        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
-            d = os.path.join(tmp, counter)
-            os.makedirs(d)
-            cmd = [prof, "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", d, "--"] + child
-            try:
-                res = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.PIPE, stderr=subprocess.PIPE,
-                                     stdin=subprocess.DEVNULL, text=True, timeout=args.traffic_deadline)
-            except subprocess.TimeoutExpired:
-                note = f"the {counter} pass did not finish within {args.traffic_deadline} s"
-                break
-            lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
-            files = glob.glob(d + "/*/*counter_collection.csv") + glob.glob(d + "/*counter_collection.csv")
-            if res.returncode != 0 or not lines or not files:
-                note = f"the {counter} pass failed (rc {res.returncode}): {res.stderr[-300:]}"
-                break
-            rows_child = json.loads(lines[-1])["roofline"]["rows_per_launch"]
-            sel = [r for r in csv.DictReader(open(files[0])) if r["Counter_Name"] == counter and "gather_kernel" in r["Kernel_Name"] and
-                   r["Kernel_Name"][:r["Kernel_Name"].rfind("(")].rstrip().endswith("true>")]
-            if not sel:
-                note = f"no launch of the last-hop gather in the {counter} pass"
-                break
-            full = max(int(r["Grid_Size"]) for r in sel)                       # launches over a full group
-            vals = [float(r["Counter_Value"]) for r in sel if int(r["Grid_Size"]) == full]
-            got[counter] = (sum(vals) / len(vals), len(vals))
-    finally:
-        shutil.rmtree(tmp, ignore_errors=True)
-    if note is not None or len(got) != 2 or not rows_child:
-        roof["traffic_measured"], roof["traffic_measured_note"] = None, note or "incomplete"
-        return
-    read_b, write_b = 2 * got["FETCH_SIZE"][0] * 1024, got["WRITE_SIZE"][0] * 1024
-    alg = rows_child * roof["bytes_per_row"]
-    roof["traffic_measured"] = read_b + write_b
-    roof["traffic_measured_read_bytes"], roof["traffic_measured_write_bytes"] = read_b, write_b
-    roof["traffic_over_algorithmic"] = (read_b + write_b) / alg
-    roof["traffic_source"] = "this run"
-    roof["traffic_measured_note"] = ("bytes per launch of the last hop's gather over a full group, averaged over %d / %d launches of two child "
-                                     "processes of this command under rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (%d rows per launch there; "
-                                     "FETCH_SIZE doubled per the guide's gfx950 correction, both KiB); %.0f s" %
-                                     (got["FETCH_SIZE"][1], got["WRITE_SIZE"][1], rows_child, time.time() - t0))
+def shape_context(c, synth, batch, steps, warmup):
+    """The headline's context with another batch size: group size by the same rule, K = steps, seeds for exactly that run."""
+    c2 = types.SimpleNamespace(**vars(c))
+    c2.args = types.SimpleNamespace(**vars(c.args))
+    c2.args.steps, c2.args.warmup, c2.args.batch = steps, warmup, batch
+    c2.B = batch
+    G = 1
+    while G * 2 <= 512 and G * 2 * batch <= 524288:
+        G *= 2
+    c2.G = G
+    c2.n_warm, c2.n_timed = warmup * G, steps * G
+    need = max((c2.n_warm + c2.n_timed + 2) * batch + batch, (c.args.presc_steps + 2) * batch)
+    all_seeds = synth.seed_ids(c.N, min(max(need * 2, c.N // 10), c.N), 11)
+    c2.mine = np.ascontiguousarray(all_seeds)
+    c2.epoch_batches = ((c2.mine.size - 1) // batch) // G * G
+    if c2.epoch_batches < G:
+        return None
+    c2.wrap = c2.epoch_batches if c2.n_warm + c2.n_timed > c2.epoch_batches else None
+    return c2
 
 
 def cpu_baseline(indptr, col, seeds, N, B, fanout, first_batch, target_s, features=None):

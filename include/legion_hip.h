@@ -111,7 +111,8 @@ int32_t legion_pool_num_ids(const LegionMemoryPool* p);
 /* which: 0 sampled_ids 1 float_features 2 labels 3 agg_src_off 4 agg_dst_off 5 node_counter
  *        6 edge_counter (the IPC slot order, SS/engine/ipc_service.cu:163-169,203);
  *        7 agg_src_ids 8 agg_dst_ids 9 cache_search_buffer 10 tmp_part_ind 11 tmp_part_off
- *        12 position_map.  Returns the device pointer of the CURRENT pipe slot. */
+ *        12 position_map (always null here); 13 node_slot (new: int32[num_ids], the feature-cache slot the sampler carried for
+ *        each node of the batch, -3 = not carried: the gather looks node_map up).  Returns the device pointer of the CURRENT pipe slot. */
 void* legion_pool_buffer(LegionMemoryPool* p, int32_t which);
 /* New in this build.  The reference keeps first touches in accessed_map (N bits, memset per batch) + position_map (N entries,
  * SS/engine/memorypool.cuh:120-135); a pool here keeps NOTHING per vertex: a hop's claims are de-duplicated bucket by bucket in
@@ -311,6 +312,12 @@ void legion_pipeline_profile_begin(LegionPipeline* p);
 void legion_pipeline_profile_end(LegionPipeline* p);
 int32_t legion_pipeline_profile_read(LegionPipeline* p, int32_t* op_ids, double* ms_sums, int64_t* counts,
                                      int32_t cap);
+/* Measurement aid: the gather of the LAST op of the group sitting in `slot`, launched `repeats` more times over the lanes as they
+ * stand -- the kernel instance, grid and ranges of the group's own op list (multiGPU_feat_cache_lookup for op 3H+1,
+ * SS/cache/cache_impl.cuh:239-272) -- each launch between two HIP events on the slot's stream; ms_each[i] = its duration.  A caller
+ * may rewrite the lanes' ids (legion_pool_buffer 0 / 13) in between: bench.py's roofline.cold gathers rows of which none repeats
+ * inside the launch.  Returns the launches timed. */
+int32_t legion_pipeline_regather_last(LegionPipeline* p, int32_t slot, int32_t n_active, int32_t repeats, double* ms_each);
 
 /* =====================================================================================
  * 4. Kernel-level launchers (what the operators call), exported so the hot kernels can be
@@ -435,6 +442,8 @@ typedef struct LegionTuning {
     int32_t runner_spin_us;      /* LEGION_RUNNER_SPIN_US  (-1 auto): how long the Runner polls (a trainer's semaphore, a group's completion) before it
                                     blocks.  auto: 20 us when batches are handed over as views (a group completes every few ms: the host
                                     sleeps in between), polling only with the gather hand-over (per-batch latency is the rate there) */
+    int32_t runner_overflow;     /* LEGION_RUNNER_OVERFLOW (1): views hand-over: a batch with more rows than its lane's feature buffer (1.2 x the PreSC
+                                    maximum) is handed over whole from one of two num_ids-row overflow buffers; 0 = no such buffers: the server stops there */
     int32_t runner_stats;        /* LEGION_RUNNER_STATS    (0): print where a hand-over's time went at Finalize */
     int32_t shm_mirror;          /* LEGION_NO_SHM_MIRROR unset -> 1: counters also go to a host-visible mirror (no D2H copy per batch) */
     /* -- set-up -------------------------------------------------------------------------------------------------------------- */

@@ -476,6 +476,17 @@ extern "C" void legion_enqueue_group(legion_stream_t strm_hdl, LegionGraphStorag
     legion_enqueue_group_n(strm_hdl, graph, feature, cache, group, 0, batch_size, counter0, dev_id, mode, fanout, hop_num);
 }
 
+// Diagnostics (bench.py's roofline.cold / roofline.warm_again, tools/): the gather of the group's LAST op once more, over the lanes as
+// they stand -- same kernel instance, same grid, same ranges (the hop snapshot in hop_scratch) as inside a group's op list.
+extern "C" void legion_enqueue_group_last_gather(legion_stream_t strm_hdl, LegionUnifiedCache* cache, LegionLaneGroup* group,
+                                                 int32_t n_active, int32_t dev_id, int32_t hop_num)
+{
+    if (!cache || !group || group->pools.empty() || hop_num < 1) { std::cout << "invalid cache/group ptr\n"; return; }
+    if (n_active < 1 || n_active > (int32_t)group->pools.size()) n_active = (int32_t)group->pools.size();
+    do_feature_lookup(static_cast<hipStream_t>(strm_hdl), cache_of(cache), group->d_lanes, n_active, group->pools[0],
+                      INTRABATCH_CON * hop_num + 1, dev_id, true, -1);
+}
+
 // ---- gather-op timing (HIP events recorded on the op's stream around the gather launch) -------
 extern "C" void legion_pool_profile_begin(LegionMemoryPool* p_, int32_t max_ops)
 {

@@ -404,6 +404,38 @@ extern "C" int32_t legion_pipeline_submit_ex(LegionPipeline* p, int32_t counter0
     return si;
 }
 
+// Diagnostics: the last op's gather of the group sitting in `slot`, launched `repeats` more times over the lanes as they stand
+// (a caller may have rewritten the lanes' ids in between: bench.py's cold-row figure), each launch between two HIP events on the
+// slot's stream; ms_each[i] = its duration.  Returns the launches timed.
+extern "C" void legion_enqueue_group_last_gather(legion_stream_t strm_hdl, LegionUnifiedCache* cache, LegionLaneGroup* group,
+                                                 int32_t n_active, int32_t dev_id, int32_t hop_num);
+extern "C" int32_t legion_pipeline_regather_last(LegionPipeline* p, int32_t slot, int32_t n_active, int32_t repeats, double* ms_each)
+{
+    if (!p || slot < 0 || slot >= p->slots_n || repeats < 1 || !ms_each) return 0;
+    SetGPUDevice(p->dev_id);
+    Slot& sl = p->slots[slot];
+    slot_wait(p, sl);
+    HIP_CALL(hipDeviceSynchronize());
+    const bool was_on = sl.pools[0]->prof_on;
+    sl.pools[0]->prof_on = false;                 // (this launch is timed here, not by the pool's op profile)
+    hipEvent_t a, b;
+    HIP_CALL(hipEventCreate(&a));
+    HIP_CALL(hipEventCreate(&b));
+    for (int32_t i = 0; i < repeats; i++) {
+        HIP_CALL(hipEventRecord(a, sl.stream));
+        legion_enqueue_group_last_gather(sl.stream, p->cache_handle, sl.group, n_active, p->dev_id, p->hop_num);
+        HIP_CALL(hipEventRecord(b, sl.stream));
+        HIP_CALL(hipEventSynchronize(b));
+        float ms = 0.f;
+        HIP_CALL(hipEventElapsedTime(&ms, a, b));
+        ms_each[i] = ms;
+    }
+    HIP_CALL(hipEventDestroy(a));
+    HIP_CALL(hipEventDestroy(b));
+    sl.pools[0]->prof_on = was_on;
+    return repeats;
+}
+
 extern "C" void legion_pipeline_wait(LegionPipeline* p, int32_t slot)
 {
     if (!p) return;

@@ -528,10 +528,29 @@ public:
         const int32_t lane = k - g.first;
         MemoryPool* lp = reinterpret_cast<MemoryPool*>(legion_pipeline_pool(pipe_, g.slot, lane));
         if (kind_ == KIND_VIEWS) {
-            ReportErrors(lp, true);
             const LanePtrs h = lp->HostLane(0);
-            const int64_t off[5] = {(char*)h.sampled_ids - arena_.base, (char*)h.float_features - arena_.base, (char*)h.labels - arena_.base,
-                                    (char*)h.agg_src_off - arena_.base, (char*)h.agg_dst_off - arena_.base};
+            int64_t off[5] = {(char*)h.sampled_ids - arena_.base, (char*)h.float_features - arena_.base, (char*)h.labels - arena_.base,
+                              (char*)h.agg_src_off - arena_.base, (char*)h.agg_dst_off - arena_.base};
+            // A batch with more rows than its lane's feature buffer (sized 1.2 x the largest TRAINING batch PreSC saw, server.cu:277:
+            // validation / test seeds with heavier neighbourhoods exceed it) is not a reason to stop serving: its rows are
+            // gathered once more, ALL of them, into the pipe slot's overflow buffer -- num_ids rows, inside the arena -- and the view of
+            // its rows points there.  The slot's previous batch has been released (the token this call consumed), so the buffer is free.
+            const int32_t batch_rows = lp->counter_mirror_host != nullptr ? lp->counter_mirror_host[INTRABATCH_CON * 3 + hop_num_] : 0;
+            bool overflowed = false;
+            if (float_feature_len_ > 0 && batch_rows > lane_feature_rows_ && overflow_[p] != nullptr) {
+                UnifiedCache* cache = (UnifiedCache*)(params->cache);
+                const LanePtrs* desc = d_overflow_desc_ + ((size_t)p * slots_ + g.slot) * lanes_ + lane;
+                cache->FeatCacheLookup(desc, 1, INTRABATCH_CON * hop_num_ + 1, local_dev_id_, overflow_stream_, memorypool_->num_ids, true, 1);
+                HIP_CALL(hipStreamSynchronize(overflow_stream_));
+                off[1] = (char*)overflow_[p] - arena_.base;
+                *(volatile int32_t*)lp->err_host &= ~LG_ERR_FEATURE_ROWS;      // this batch is whole again; the lane's next batch starts clean
+                overflowed = true;
+                overflow_batches_++;
+                if (overflow_batches_ == 1)
+                    std::cout << "WARNING (gpu " << local_dev_id_ << "): batch " << k << " has " << batch_rows << " rows, its lane's feature buffer "
+                              << lane_feature_rows_ << " (1.2 x the PreSC maximum): its rows are handed over from the pipe slot's overflow buffer\n" << std::flush;
+            }
+            ReportErrors(lp, !overflowed);
             env->SetView(local_dev_id_, p, off, lp->counter_mirror_host);
             env->IPCPost(local_dev_id_, p);
         } else {
@@ -620,6 +639,10 @@ public:
             arena_ = PoolArena();
             d_free_space(d_desc_);
             d_desc_ = nullptr;
+            d_free_space(d_overflow_desc_);
+            d_overflow_desc_ = nullptr;
+            if (overflow_stream_ != nullptr) { HIP_CALL(hipStreamDestroy(overflow_stream_)); overflow_stream_ = nullptr; }
+            if (overflow_batches_ > 0) std::cout << "runner " << local_dev_id_ << ": " << overflow_batches_ << " batches handed over from an overflow buffer\n";
             d_free_space(d_deliver_);
             d_deliver_ = nullptr;
         }
@@ -713,6 +736,17 @@ private:
         HIP_CALL(hipMemGetInfo(&free_b, &total_b));
         while (lanes_ > 1 && (int64_t)lanes_ * slots_ * lane_bytes > (int64_t)(free_b / 10 * 6)) lanes_ /= 2;
         arena_.bytes = arena_lane * lanes_ * slots_;
+        lane_feature_rows_ = lane_features ? (int32_t)feature_rows : 0;
+        // one overflow buffer per pipe slot behind the lanes, inside the arena (a trainer end that takes views maps the whole arena): the
+        // worst case of a batch, num_ids rows -- unless two of them would not leave the lanes their memory (then an oversized batch
+        // stops the server as before)
+        int64_t overflow_bytes = 0;
+        if (lane_features && handover_ == 0 && feature_rows < memorypool_->num_ids && tune.runner_overflow != 0) {
+            overflow_bytes = (((int64_t)memorypool_->num_ids * float_feature_len_ * (int64_t)sizeof(float)) + 4095) & ~(int64_t)4095;
+            if (interbatch_concurrency_ * overflow_bytes > (int64_t)(free_b / 10) || (int64_t)lanes_ * slots_ * lane_bytes + interbatch_concurrency_ * overflow_bytes > (int64_t)(free_b / 10 * 7))
+                overflow_bytes = 0;
+        }
+        arena_.bytes += interbatch_concurrency_ * overflow_bytes;
         // The arena is built from physical chunks mapped in shuffled order unless another GPU must reach it (peer_gather = bulk):
         // 128 MB chunks -- a trainer end receives them as file descriptors (IPCEnv::PublishArena) -- against the 2 MB of an arena
         // nobody else maps; LegionTuning.arena_scatter_mb = 0: one plain allocation, handed over as a hipIpcMemHandle.
@@ -733,6 +767,12 @@ private:
                                        (LegionUnifiedCache*)params->cache, local_dev_id_, memorypool_->batch_size,
                                        fanout.data(), hop_num_, lanes_, slots_, lane_features ? feature_rows : 0, 1 | 16);
         lg_set_pool_arena(nullptr);
+        for (int pp = 0; pp < interbatch_concurrency_ && pp < INTERBATCH_CON; pp++)
+            overflow_[pp] = overflow_bytes > 0 ? (float*)(arena_.base + arena_.bytes - (int64_t)(interbatch_concurrency_ - pp) * overflow_bytes) : nullptr;
+        if (overflow_bytes > 0) {
+            if (arena_.used > arena_.bytes - interbatch_concurrency_ * overflow_bytes) { printf("legion_hip: the lanes overran their share of the arena\n"); exit(EXIT_FAILURE); }
+            HIP_CALL(hipStreamCreateWithFlags(&overflow_stream_, hipStreamNonBlocking));
+        }
         {   // LegionTuning.peer_gather = bulk: only where it means something (a clique of several GPUs, rows landing in lanes)
             UnifiedCache* uc = (UnifiedCache*)(params->cache);
             bulk_ = tune.peer_gather == 1 && uc->Kg_ > 1 && lane_features && legion_pipeline_bulk_enable_shared(pipe_, &arena_) != 0;
@@ -786,6 +826,17 @@ private:
                 }
         d_desc_ = (LanePtrs*)d_alloc_space((int64_t)h.size() * sizeof(LanePtrs));
         HIP_CALL(hipMemcpy(d_desc_, h.data(), h.size() * sizeof(LanePtrs), hipMemcpyHostToDevice));
+        if (overflow_[0] != nullptr) {      // the same lanes with the pipe slot's overflow buffer as the gather's destination, nothing delivered
+            for (int p = 0; p < interbatch_concurrency_; p++)
+                for (size_t i = 0; i < (size_t)slots_ * lanes_; i++) {
+                    LanePtrs& d = h[(size_t)p * slots_ * lanes_ + i];
+                    d.float_features = overflow_[p];
+                    d.feature_rows = memorypool_->num_ids;
+                    d.deliver = nullptr;
+                }
+            d_overflow_desc_ = (LanePtrs*)d_alloc_space((int64_t)h.size() * sizeof(LanePtrs));
+            HIP_CALL(hipMemcpy(d_overflow_desc_, h.data(), h.size() * sizeof(LanePtrs), hipMemcpyHostToDevice));
+        }
         poster_ = std::thread([this, env] {
             // The poster polls (the reference's runner thread polls cudaEventQuery the same way, server.cu:319-324): one core
             // per GPU buys a hand-over latency of about a microsecond instead of a condition-variable wake-up.
@@ -883,6 +934,11 @@ private:
     int32_t lanes_ = 1, slots_ = 3, hop_num_ = 0, max_step_ = 0;
     RunnerSchedule sched_;                                 // which group sits in which slot, and when a slot may be overwritten
     LanePtrs* d_desc_ = nullptr;
+    LanePtrs* d_overflow_desc_ = nullptr;                  // views: [pipe slot][group slot][lane] with the slot's overflow buffer as the rows' destination
+    float* overflow_[INTERBATCH_CON] = {};                 // per pipe slot: num_ids rows inside the arena, for a batch that outgrew its lane's buffer
+    hipStream_t overflow_stream_ = nullptr;
+    int32_t lane_feature_rows_ = 0;
+    int64_t overflow_batches_ = 0;
     lg::DeliverParams deliver_[INTERBATCH_CON] = {};
     lg::DeliverParams* d_deliver_ = nullptr;
     hipEvent_t batch_done_[INTERBATCH_CON] = {};

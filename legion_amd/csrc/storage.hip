@@ -1165,6 +1165,7 @@ extern "C" void* legion_pool_buffer(LegionMemoryPool* p_, int32_t which)
         case 10: return mp->GetTmpPartIdx();
         case 11: return mp->GetTmpPartOff();
         case 12: return mp->GetPositionMap();      // always null: no per-vertex state in this build
+        case 13: return mp->node_slot;             // [num_ids] feature-cache slot carried per node (LG_FS_UNKNOWN = -3: look it up), or null
         default: return nullptr;
     }
 }

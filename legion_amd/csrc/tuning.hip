@@ -41,6 +41,7 @@ void parse_env(LegionTuning& t)
     t.runner_lanes = env_int("LEGION_RUNNER_LANES", 0);
     t.runner_ho_stream = env_int("LEGION_RUNNER_HO_STREAM", 2);
     t.runner_spin_us = env_int("LEGION_RUNNER_SPIN_US", -1);
+    t.runner_overflow = env_int("LEGION_RUNNER_OVERFLOW", 1);
     t.runner_stats = getenv("LEGION_RUNNER_STATS") != nullptr ? 1 : 0;
     auto word = [](const char* name, std::initializer_list<std::pair<const char*, int>> words, int dflt) {
         const char* e = getenv(name);

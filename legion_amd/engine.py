@@ -221,7 +221,7 @@ class MemoryPool:
             "node_counter": (5, torch.int32), "edge_counter": (6, torch.int32),
             "agg_src_ids": (7, torch.int32), "agg_dst_ids": (8, torch.int32),
             "cache_search_buffer": (9, torch.int32), "tmp_part_ind": (10, torch.int8),
-            "tmp_part_off": (11, torch.int32), "position_map": (12, torch.int32)}
+            "tmp_part_off": (11, torch.int32), "position_map": (12, torch.int32), "node_slot": (13, torch.int32)}
 
     def __init__(self, dev_id, total_num_nodes, batch_size, fanout, float_feature_len, pipeline_depth=1):
         self._lib = _libmod.load()
@@ -424,6 +424,13 @@ class Pipeline:
 
     def profile_end(self):
         self._lib.legion_pipeline_profile_end(self.handle)
+
+    def regather_last(self, slot, repeats=5, n_active=0):
+        """The last op's gather of the group sitting in `slot`, `repeats` more times over the lanes as they stand: ms per launch
+        (HIP events on the slot's stream).  legion_hip.h: legion_pipeline_regather_last."""
+        ms = (ctypes.c_double * int(repeats))()
+        n = self._lib.legion_pipeline_regather_last(self.handle, int(slot), int(n_active), int(repeats), ms)
+        return [float(ms[i]) for i in range(n)]
 
     def profile_read(self):
         """{gather op id: (summed ms, launches)} for every batch waited for since profile_begin()."""

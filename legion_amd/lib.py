@@ -112,6 +112,7 @@ SIGNATURES = {
     "legion_pipeline_profile_end": (None, [c_p]),
     "legion_pipeline_profile_read": (c_i32, [c_p, P_I32, ctypes.POINTER(ctypes.c_double),
                                              ctypes.POINTER(ctypes.c_int64), c_i32]),
+    "legion_pipeline_regather_last": (c_i32, [c_p, c_i32, c_i32, c_i32, ctypes.POINTER(ctypes.c_double)]),
     # 4. kernel-level
     "legion_gather_rows": (None, [c_p, c_p, c_p, c_p, c_i32, c_i32, c_i32, c_p, c_p, c_p, c_p, c_i32]),
     "legion_draw_batch": (None, [c_p, c_p, c_p, c_p, c_i32]),
@@ -154,7 +155,7 @@ class Tuning(ctypes.Structure):                # LegionTuning (include/legion_hi
     _fields_ = [(n, c_i32) for n in (
         "lds_small_buckets", "lds_part_wg", "sample_max_wg", "lds_known_cap", "lds_claim_cap", "col_slots", "gather_rows_per_wg", "peer_gather",
         "arena_scatter_mb", "weave_priority", "markers", "runner_graph", "runner_lanes", "runner_slots", "runner_handover", "runner_ho_stream",
-        "runner_spin_us", "runner_stats", "shm_mirror", "table_placement", "hotness_reduce", "link_counters")] + \
+        "runner_spin_us", "runner_overflow", "runner_stats", "shm_mirror", "table_placement", "hotness_reduce", "link_counters")] + \
         [("link_counter_values", c_u64 * 2)]
 
 

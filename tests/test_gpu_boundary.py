@@ -34,6 +34,42 @@ def write_dataset(path, wl_indptr, wl_col, feats, labels, train, valid, test):
     test.astype(np.int32).tofile(os.path.join(path, "testingset"))
 
 
+def check_trainer_batches(got, st, pool, g, cache, feats, sets, labels, fanout, D, epoch):
+    """Every batch the trainer process dumped against the oracle's replay of the server's schedule."""
+    import ctypes
+    L = ffi.load()
+    total = L.lgo_max_step(ctypes.byref(st))
+    assert total == (st.train_step + st.valid_step) * epoch + st.test_step
+    H = len(fanout)
+    for gb in range(total):
+        mode = L.lgo_current_mode(ctypes.byref(st), gb)
+        it = L.lgo_local_batch_id(ctypes.byref(st), gb)
+        bs = L.lgo_current_batchsize(ctypes.byref(st), 0, mode)
+        pool.run_batch(g, cache, feats, sets[mode], labels[sets[mode]], bs, it, mode, False)
+        want = pool.read_batch()
+        nc, ec = want["node_counter"], want["edge_counter"]
+        assert got[f"b{gb}_ntensors"] == 3 + 2 * H
+        assert np.array_equal(got[f"b{gb}_ids"], want["sampled_ids"]), f"batch {gb}"
+        assert np.array_equal(got[f"b{gb}_labels"], want["labels"])
+        got_f = got[f"b{gb}_feats"]
+        assert got_f.shape == (int(nc[9 + H]), D)
+        if not np.array_equal(got_f, want["float_features"].view(np.uint32)):
+            bad = np.nonzero((got_f != want["float_features"].view(np.uint32)).any(axis=1))[0]
+            src_rows = [int(np.nonzero((feats.view(np.uint32) == got_f[r]).all(axis=1))[0][:1].sum()) for r in bad[:8]]
+            raise AssertionError(f"batch {gb} mode {mode}: rows {bad[:20]} of {got_f.shape[0]} differ; ids there "
+                                 f"{want['sampled_ids'][bad[:8]]}, rows actually hold features of {src_rows}; "
+                                 f"node_map of those ids {cache.arr('node_map', np.int32)[want['sampled_ids'][bad[:8]]]}; "
+                                 f"cap {cache.node_capacity} nc {nc[:12]}")
+        for k, h in enumerate(range(H, 0, -1)):      # cumulative prefixes, outermost block first
+            n_e = int(ec[9 + h])
+            assert np.array_equal(got[f"b{gb}_src{k}"], want["agg_src_off"][:n_e])
+            assert np.array_equal(got[f"b{gb}_dst{k}"], want["agg_dst_off"][:n_e])
+        exp_sizes = []
+        for h in range(H, 0, -1):
+            exp_sizes += [int(nc[9 + h]), int(nc[9 + h - 1])]
+        assert got[f"b{gb}_sizes"].tolist() == exp_sizes
+
+
 @pytest.mark.parametrize("server_env", [
     {},                                                        # defaults: whole launch groups into the lane arena, batches handed over as VIEWS of their lane
     {"LEGION_RUNNER_LANES": "3"},                              # many small groups: three in flight, partial groups, mode changes mid-run, lane reuse
@@ -53,9 +89,10 @@ def write_dataset(path, wl_indptr, wl_col, feats, labels, train, valid, test):
     {"LEGION_ARENA_SCATTER_MB": "0"},                          # the lane arena as ONE plain allocation, handed over as a hipIpcMemHandle (default: shuffled chunks, as file descriptors)
     {"LEGION_ARENA_SCATTER_MB": "0", "LEGION_RUNNER_LANES": "3"},
     {"_FANOUT": "4,3,2", "LEGION_RUNNER_LANES": "3"},          # three hops through the server (known lists across two hops, three gathers per group)
+    {"_FANOUT": "2,2,2,2,2,2", "LEGION_RUNNER_LANES": "3"},    # six hops, the most the counter block holds: 15 tensors per batch at the trainer
 ], ids=["default-views", "views-lanes3", "views-lanes1", "views-lanes2-two-groups", "views-lanes2-four-groups", "trainer-without-views",
         "trainer-without-views-lanes3", "gather", "gather-lanes4-16-buckets", "gather-lanes1", "operators",
-        "no-mirror", "gather-lanes5-one-stream", "gather-lanes6-shared-ho-stream", "rccl-hotness-reduce", "views-plain-arena", "views-plain-arena-lanes3", "views-three-hops"])
+        "no-mirror", "gather-lanes5-one-stream", "gather-lanes6-shared-ho-stream", "rccl-hotness-reduce", "views-plain-arena", "views-plain-arena-lanes3", "views-three-hops", "views-six-hops"])
 def test_server_binary_serves_fake_trainer(hip, tmp_path, server_env, monkeypatch):
     for k, v in server_env.items():
         if not k.startswith("_"):
@@ -109,36 +146,7 @@ def test_server_binary_serves_fake_trainer(hip, tmp_path, server_env, monkeypatc
         assert tr.returncode == 0, tr.stdout[-3000:] + "\n---- server ----\n" + open(work / "server.log").read()[-2000:]
         got = np.load(out_npz)
         assert got["steps"].tolist() == [st.train_step, st.valid_step, st.test_step]
-        total = L.lgo_max_step(ctypes.byref(st))
-        assert total == (st.train_step + st.valid_step) * epoch + st.test_step
-        H = len(fanout)
-        for gb in range(total):
-            mode = L.lgo_current_mode(ctypes.byref(st), gb)
-            it = L.lgo_local_batch_id(ctypes.byref(st), gb)
-            bs = L.lgo_current_batchsize(ctypes.byref(st), 0, mode)
-            pool.run_batch(g, cache, feats, sets[mode], labels[sets[mode]], bs, it, mode, False)
-            want = pool.read_batch()
-            nc, ec = want["node_counter"], want["edge_counter"]
-            assert got[f"b{gb}_ntensors"] == 3 + 2 * H
-            assert np.array_equal(got[f"b{gb}_ids"], want["sampled_ids"]), f"batch {gb}"
-            assert np.array_equal(got[f"b{gb}_labels"], want["labels"])
-            got_f = got[f"b{gb}_feats"]
-            assert got_f.shape == (int(nc[9 + H]), D)
-            if not np.array_equal(got_f, want["float_features"].view(np.uint32)):
-                bad = np.nonzero((got_f != want["float_features"].view(np.uint32)).any(axis=1))[0]
-                src_rows = [int(np.nonzero((feats.view(np.uint32) == got_f[r]).all(axis=1))[0][:1].sum()) for r in bad[:8]]
-                raise AssertionError(f"batch {gb} mode {mode}: rows {bad[:20]} of {got_f.shape[0]} differ; ids there "
-                                     f"{want['sampled_ids'][bad[:8]]}, rows actually hold features of {src_rows}; "
-                                     f"node_map of those ids {cache.arr('node_map', np.int32)[want['sampled_ids'][bad[:8]]]}; "
-                                     f"cap {cache.node_capacity} nc {nc[:12]}")
-            for k, h in enumerate(range(H, 0, -1)):      # cumulative prefixes, outermost block first
-                n_e = int(ec[9 + h])
-                assert np.array_equal(got[f"b{gb}_src{k}"], want["agg_src_off"][:n_e])
-                assert np.array_equal(got[f"b{gb}_dst{k}"], want["agg_dst_off"][:n_e])
-            exp_sizes = []
-            for h in range(H, 0, -1):
-                exp_sizes += [int(nc[9 + h]), int(nc[9 + h - 1])]
-            assert got[f"b{gb}_sizes"].tolist() == exp_sizes
+        check_trainer_batches(got, st, pool, g, cache, feats, sets, labels, fanout, D, epoch)
         server.wait(timeout=60)
         assert server.returncode == 0
         text = open(work / "server.log").read()
@@ -158,6 +166,94 @@ def test_server_binary_serves_fake_trainer(hip, tmp_path, server_env, monkeypatc
         for name in os.listdir("/dev/shm"):
             if name.endswith(ns):
                 os.unlink(os.path.join("/dev/shm", name))
+
+
+@pytest.mark.parametrize("server_env", [{}, {"LEGION_RUNNER_HANDOVER": "gather", "LEGION_RUNNER_LANES": "3"}, {"LEGION_RUNNER_GRAPH": "0"},
+                                        {"LEGION_COL_SLOTS": "0", "LEGION_RUNNER_LANES": "2"}],
+                         ids=["views", "gather-lanes3", "operators", "views-no-column-slots"])
+def test_server_binary_in_disk_mode_serves_the_hybrid_tier(hip, tmp_path, server_env, monkeypatch):
+    """`sampling_server ... --disk` = Run(fanout, gpu_number, in_memory_mode = 0, cache_mode) (sampling_server/sampling_server.cpp:7):
+    a fifteen-field meta_config (SS/storage/storage_management.cu:60-94) whose last two fields size the hybrid CPU-cache /
+    GPU-cache tier, built by UnifiedCache::HybridInit instead of CandidateSelection + CostModel + FillUp (the call the reference
+    keeps commented out at SS/engine/server.cu:112).  Every batch a trainer process receives against the oracle's replay:
+    rows from the GPU cache, from the mapped pinned CPU cache and (misses) from the feature table."""
+    for k, v in server_env.items():
+        monkeypatch.setenv(k, v)
+    scale, D, B, fanout, epoch, cpu_cap, gpu_cap = 11, 24, 48, [5, 3], 2, 260, 170
+    indptr, col = synth.rmat_csr_numpy(scale, 8, 20231)
+    N = indptr.size - 1
+    feats = synth.features_numpy(0, N, D, 7)
+    labels = (np.arange(N) % 47).astype(np.int32)
+    perm = np.random.RandomState(3).permutation(N).astype(np.int32)
+    train, valid, test = perm[:500], perm[500:590], perm[590:640]
+    ds = str(tmp_path / "ds") + "/"
+    write_dataset(ds, indptr, col, feats, labels, train, valid, test)
+    work = tmp_path / "run"
+    work.mkdir()
+    (work / "meta_config").write_text("{} {} {} {} {} {} {} {} {} {} {} {} {} {} {}".format(
+        ds, B, N, col.size, D, train.size, valid.size, test.size, 60_000, epoch, 0, 0, 0, cpu_cap, gpu_cap))
+    ns = f"_d{os.getpid()}"
+    monkeypatch.setenv("LEGION_IPC_NAMESPACE", ns)
+    env = dict(os.environ)
+    server, log = start_server([os.path.join(ROOT, "legion_amd", "bin", "sampling_server"), "1", "0", "5", "3", "--disk"],
+                               work, env, work / "server.log")
+    try:
+        import ctypes
+        g = ffi.OracleGraph(1, indptr, col)
+        st = ffi.Steps()
+        L = ffi.load()
+        one = lambda v: (ctypes.c_int32 * 1)(v)
+        L.lgo_coordinate(ctypes.byref(st), 1, one(train.size), one(valid.size), one(test.size), B, epoch)
+        node_acc, edge_acc = np.zeros(N, dtype=np.uint64), np.zeros(N, dtype=np.uint64)
+        max_bs = max(B, st.valid_bs[0], st.test_bs[0])
+        pool = ffi.OraclePool(N, max_bs, fanout, ffi.num_ids_for(max_bs, fanout), D)
+        for it in range(st.train_step):
+            pool.run_batch(g, None, None, train, labels[train], B, it, 0, True, node_acc, edge_acc)
+        cache = ffi.OracleCache(N, D, 1, 0)
+        cache.hybrid_init(node_acc, feats, cpu_cap, gpu_cap)
+        out_npz = tmp_path / "trainer.npz"
+        tr = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "fake_trainer.py"), "0", str(D), str(epoch), str(out_npz)],
+                            env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, stdin=subprocess.DEVNULL, text=True, timeout=300)
+        assert tr.returncode == 0, tr.stdout[-3000:] + "\n---- server ----\n" + open(work / "server.log").read()[-2000:]
+        got = np.load(out_npz)
+        check_trainer_batches(got, st, pool, g, cache, feats, {0: train, 1: valid, 2: test}, labels, fanout, D, epoch)
+        # all three row sources were in play
+        node_map = cache.arr("node_map", np.int32)
+        slots = np.concatenate([node_map[got[f"b{gb}_ids"]] for gb in range(4)])
+        assert ((slots >= 0) & (slots < cpu_cap)).any() and (slots >= cpu_cap).any() and (slots < 0).any()
+        server.wait(timeout=60)
+        assert server.returncode == 0
+        text = open(work / "server.log").read()
+        for needle in ("In Disk Mode", "CPU Cache Capacity: %d" % cpu_cap, "GPU Cache Capacity: %d" % gpu_cap, "Finish initializing cache",
+                       "System is ready for serving", "Server Stopped"):
+            assert needle in text, needle
+        assert "Alpha:" not in text                     # the cost model did not run
+    finally:
+        if server.poll() is None:
+            server.kill()
+        log.close()
+        for name in os.listdir("/dev/shm"):
+            if name.endswith(ns):
+                os.unlink(os.path.join("/dev/shm", name))
+
+
+def test_server_in_disk_mode_rejects_a_ten_field_meta_config(hip, tmp_path):
+    indptr, col = synth.rmat_csr_numpy(9, 4, 20231)
+    N = indptr.size - 1
+    ds = str(tmp_path / "ds") + "/"
+    perm = np.arange(N, dtype=np.int32)
+    write_dataset(ds, indptr, col, synth.features_numpy(0, N, 4, 7), np.zeros(N, dtype=np.int32), perm[:100], perm[100:120], perm[120:130])
+    work = tmp_path / "run"
+    work.mkdir()
+    (work / "meta_config").write_text("{} {} {} {} {} {} {} {} {} {}".format(ds, 16, N, col.size, 4, 100, 20, 10, 50_000, 1))
+    ns = f"_e{os.getpid()}"
+    res = subprocess.run([os.path.join(ROOT, "legion_amd", "bin", "sampling_server"), "1", "0", "5", "3", "--disk"], cwd=work,
+                         env=dict(os.environ, LEGION_IPC_NAMESPACE=ns), stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+                         stdin=subprocess.DEVNULL, text=True, timeout=300)
+    for name in os.listdir("/dev/shm"):
+        if name.endswith(ns):
+            os.unlink(os.path.join("/dev/shm", name))
+    assert res.returncode != 0 and "disk mode needs fifteen fields" in res.stdout, res.stdout[-2000:]
 
 
 @pytest.mark.parametrize("damage,needle", [("short_edge_dst", "file too short"), ("edge_count", "data set mismatch"),
@@ -294,21 +390,14 @@ def test_one_trainer_process_outlives_eight_server_lives(hip, tmp_path):
                 os.unlink(os.path.join("/dev/shm", name))
 
 
-def test_server_stops_instead_of_posting_a_corrupt_batch(hip, tmp_path):
-    """Device-side corruption ends the server before IPCPost (include/legion_hip.h error convention; the reference's
-    cudaCheckError).  Forced here: the lanes' feature buffers hold 1.2 x the largest PreSC (= training) batch, scaled by the ratio
-    of the largest batch of any mode to the training batch -- and the training seeds are the graph's lowest-degree vertices (a
-    few dozen ids per batch of 16) while the one validation batch has the 400 highest-degree ones (thousands of ids): its rows do
-    not fit its lane's buffer (LG_ERR_FEATURE_ROWS), and a VIEW with more rows than the buffer behind it would show the trainer
-    the next lane's arrays as rows.  The PreSC epoch and the training batches are served; the validation batch is not posted and the server
-    exits non-zero.  (A trainer end that gets its rows gathered into the pipe slot's own buffer is served the rows that fit, with
-    a warning: the reference overruns there, SS/engine/server.cu:277.)"""
-    scale, D, B, fanout = 14, 8, 16, [5, 3]
+def _hub_validation_dataset(tmp_path, B):
+    """Training seeds: the graph's lowest-degree vertices (a batch of 16 has a few dozen ids); the validation seeds: its 400 hubs
+    (thousands of ids per batch): validation batches outgrow lane feature buffers sized 1.2 x the largest TRAINING batch."""
+    scale, D = 14, 8
     indptr, col = synth.rmat_csr_numpy(scale, 8, 20231)
     N = indptr.size - 1
     feats = synth.features_numpy(0, N, D, 7)
     labels = (np.arange(N) % 47).astype(np.int32)
-    # training seeds: the vertices of lowest degree (a batch of 16 has a few dozen ids); validation seeds: the 400 hubs (thousands)
     by_deg = np.argsort(np.diff(indptr), kind="stable").astype(np.int32)
     train, valid, test = by_deg[:100], by_deg[-400:], by_deg[2000:2020]
     ds = str(tmp_path / "ds") + "/"
@@ -317,8 +406,74 @@ def test_server_stops_instead_of_posting_a_corrupt_batch(hip, tmp_path):
     work.mkdir()
     (work / "meta_config").write_text("{} {} {} {} {} {} {} {} {} {}".format(
         ds, B, N, col.size, D, train.size, valid.size, test.size, 50_000, 1))
+    return work, (indptr, col, feats, labels, train, valid, test, N, D)
+
+
+@pytest.mark.parametrize("lanes", ["4", "1"])
+def test_oversized_validation_batch_is_served_whole_from_the_overflow_buffer(hip, tmp_path, lanes):
+    """with the views hand-over a batch with more rows than its lane's feature buffer used to stop the server --
+    and validation / test seeds with heavier neighbourhoods than the training batches PreSC saw do that on real data sets.  Now the
+    batch's rows are gathered once more, all of them, into the pipe slot's overflow buffer inside the arena and the view of its rows
+    points there: every batch of the schedule reaches the trainer and equals the oracle's, rows included."""
+    B, fanout, epoch = 16, [5, 3], 1
+    work, (indptr, col, feats, labels, train, valid, test, N, D) = _hub_validation_dataset(tmp_path, B)
+    ns = f"_o{os.getpid()}"
+    env = dict(os.environ, LEGION_IPC_NAMESPACE=ns, LEGION_RUNNER_LANES=lanes)
+    server, log = start_server([os.path.join(ROOT, "legion_amd", "bin", "sampling_server"), "1", "0"] + [str(f) for f in fanout],
+                               work, env, work / "server.log")
+    try:
+        import ctypes
+        g = ffi.OracleGraph(1, indptr, col)
+        st = ffi.Steps()
+        L = ffi.load()
+        one = lambda v: (ctypes.c_int32 * 1)(v)
+        L.lgo_coordinate(ctypes.byref(st), 1, one(train.size), one(valid.size), one(test.size), B, epoch)
+        node_acc, edge_acc = np.zeros(N, dtype=np.uint64), np.zeros(N, dtype=np.uint64)
+        max_bs = max(B, st.valid_bs[0], st.test_bs[0])
+        pool = ffi.OraclePool(N, max_bs, fanout, ffi.num_ids_for(max_bs, fanout), D)
+        max_ids = 0
+        for it in range(st.train_step):
+            pool.run_batch(g, None, None, train, labels[train], B, it, 0, True, node_acc, edge_acc)
+            max_ids = max(max_ids, int(pool.read_batch()["node_counter"][7]))
+        cache = ffi.OracleCache(N, D, 1, 0)
+        cache.candidate_selection([node_acc], [edge_acc])
+        cache.cost_model(50_000, indptr, (0, 0), [max_ids], st.train_step)
+        cache.fill_up(feats, indptr, col)
+        g.attach_cache(cache)
+        out_npz = tmp_path / "trainer.npz"
+        tr = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "fake_trainer.py"), "0", str(D), str(epoch), str(out_npz)],
+                            env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, stdin=subprocess.DEVNULL, text=True, timeout=300)
+        assert tr.returncode == 0, tr.stdout[-3000:] + "\n---- server ----\n" + open(work / "server.log").read()[-2000:]
+        got = np.load(out_npz)
+        check_trainer_batches(got, st, pool, g, cache, feats, {0: train, 1: valid, 2: test}, labels, fanout, D, epoch)
+        server.wait(timeout=60)
+        text = open(work / "server.log").read()
+        assert server.returncode == 0 and "Server Stopped" in text, text[-2000:]
+        # the validation batches really were larger than what a lane holds, and they went out through the overflow buffers
+        lane_rows = int(max_ids * 1.2) * ((max_bs + B - 1) // B)
+        n_over = sum(int(got[f"b{gb}_ids"].size) > lane_rows for gb in range(st.train_step + st.valid_step + st.test_step))
+        assert n_over >= 1 and "handed over from the pipe slot's overflow buffer" in text
+        assert f"{n_over} batches handed over from an overflow buffer" in text, text[-1500:]
+    finally:
+        if server.poll() is None:
+            server.kill()
+        log.close()
+        for name in os.listdir("/dev/shm"):
+            if name.endswith(ns):
+                os.unlink(os.path.join("/dev/shm", name))
+
+
+def test_server_stops_instead_of_posting_a_corrupt_batch(hip, tmp_path):
+    """Device-side corruption ends the server before IPCPost (include/legion_hip.h error convention; the reference's
+    cudaCheckError).  Forced here with LEGION_RUNNER_OVERFLOW=0 (no overflow buffers): a validation batch whose rows do not fit its
+    lane's buffer (LG_ERR_FEATURE_ROWS) cannot go out as a VIEW -- a view with more rows than the buffer behind it would show the
+    trainer the next lane's arrays as rows.  The PreSC epoch and the training batches are served; the validation batch is
+    not posted, the server exits non-zero and wakes the trainer blocked on its semaphore.  (A trainer end that gets its rows gathered
+    into the pipe slot's own buffer is served the rows that fit, with a warning: the reference overruns there, SS/engine/server.cu:277.)"""
+    B, fanout = 16, [5, 3]
+    work, (indptr, col, feats, labels, train, valid, test, N, D) = _hub_validation_dataset(tmp_path, B)
     ns = f"_c{os.getpid()}"
-    env = dict(os.environ, LEGION_IPC_NAMESPACE=ns, LEGION_RUNNER_LANES="4")
+    env = dict(os.environ, LEGION_IPC_NAMESPACE=ns, LEGION_RUNNER_LANES="4", LEGION_RUNNER_OVERFLOW="0")
     server, log = start_server([os.path.join(ROOT, "legion_amd", "bin", "sampling_server"), "1", "0"] + [str(f) for f in fanout],
                                work, env, work / "server.log")
     trainer = subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "fake_trainer.py"), "0", str(D), "1", str(work / "out.npz")],

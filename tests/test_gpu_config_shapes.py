@@ -223,6 +223,71 @@ def test_config4_shape_2pow28_vertices(hip):
     cache.close(); feature.close(); graph.close()
 
 
+def test_config4_shape_d256_rows_pinned_spill_and_hbm_cache(hip):
+    """What ONE GPU of configs[4] sees of the 256-wide table: its rows are 1024 bytes, the full table sits in MAPPED PINNED HOST memory
+    (it exists nowhere in one GPU's HBM: 2^28 rows x 1 KB = 275 GB) and the hot rows in an HBM cache -- stripe + spill.  On this pool a
+    1-GPU box's control group holds 300 GiB of host memory (profiles/r06/box_probe.txt), so the pinned table of the full 2^28 rows
+    (256 GiB) does not fit beside the process; this runs the largest power of two that does with room to spare: 2^27 vertices, edge
+    factor 8 (the same 2^30 edges), [15,10,5], B = 8000 -- a 128 GiB pinned table, 1 KB rows over PCIe on a miss, and every id-width
+    property of the 2^28-vertex D = 128 case above (test_config4_shape_2pow28_vertices keeps the vertex count itself).  A box whose
+    control group is smaller drops one more power of two rather than risking the box."""
+    limit = None
+    try:
+        txt = open("/sys/fs/cgroup/memory.max").read().strip()
+        limit = None if txt == "max" else int(txt)
+    except OSError:
+        pass
+    scale = 27 if (limit is None or limit >= (220 << 30)) else 26
+    D, fanout, batch, group, ef = 256, [15, 10, 5], 8000, 4, 8 if scale == 27 else 16
+    N = 1 << scale
+    dev = torch.device("cuda:0")
+    indptr, col = synth.rmat_csr_device(scale, ef, 20231, dev, scramble=True)
+    torch.cuda.empty_cache()
+    assert int(indptr[-1]) == N * ef and int(col.max()) >= N // 2
+    p_feat = engine.PinnedArray.empty((N, D), np.float32)                 # 128 GiB at scale 27
+    feats = p_feat.tensor(dev)
+    chunk = 1 << 21
+    for r0 in range(0, N, chunk):                                         # generated on the device, parked in pinned host memory
+        feats[r0:r0 + chunk].copy_(synth.features_device_rows(r0, chunk, D, 7, dev))
+    torch.cuda.synchronize()
+    seeds = synth.seed_ids(N, 400_000, 11)
+    graph, feature = engine.GraphStorage(1, indptr, col), engine.FeatureStorage(1, feats)
+    feature.set_ids(0, 0, seeds, None)
+    presc = 4
+    cache = engine.UnifiedCache(24 << 30, D, presc, 1, N)                 # 24 GB: about what an eighth of a 288 GB part leaves a stripe
+    cache.init_controller(0)
+    pool = engine.MemoryPool(0, N, batch, fanout, D)
+    for it in range(presc):
+        engine.enqueue_batch(None, graph, feature, cache, pool, batch, it, 0, 0, True, fanout)
+    torch.cuda.synchronize()
+    cache.candidate_selection(0, graph)
+    cache.cost_model(feature, graph, (cache.topo_transactions(0), 0), presc)
+    cache.fill_up(feature, graph)
+    ncap = cache.node_capacity(0)
+    assert ncap > 1_000_000 and ncap * D * 4 <= (24 << 30)
+    rows = int(cache.max_id_num(0) * 1.2)
+    pool.close()
+    pipe = engine.Pipeline(graph, feature, cache, 0, batch, fanout, group, rows, True, 2)
+    deg = indptr[1:] - indptr[:-1]
+    hit = miss = 0
+    seen = {}
+    for rep in range(2):                                                  # replayed: the same batches both times
+        for c0 in (presc, presc + group):
+            slot = pipe.submit(c0)
+            pipe.wait(slot)
+            for lane in (0, group - 1):
+                pl = pipe.pools[slot][lane]
+                n, e, nc, ec = _check_lane(pl, seeds[(c0 + lane) * batch:(c0 + lane + 1) * batch], indptr, col, deg, fanout, D, rows)
+                sig = (n, e, int(pl.buffer("sampled_ids")[:n].long().sum()), int(pl.buffer("agg_src_off")[:e].long().sum()))
+                assert seen.setdefault((c0, lane), sig) == sig
+                assert int(pl.buffer("sampled_ids")[:n].max()) > N // 2
+                csb = pl.buffer("cache_search_buffer")[:int(nc[1])]
+                hit += int((csb >= 0).sum()); miss += int((csb < 0).sum())
+    assert hit > 0 and miss > 0                                           # rows came from the HBM cache AND over PCIe from the pinned table
+    pipe.close(); cache.close(); feature.close(); graph.close()
+    p_feat.close()
+
+
 def test_config2_shape_full_size_pinned_spill(hip):
     """configs[2] at size (papers100M-like): 2^26 vertices, 3 hops [15,10,5], full CSR and the full 128-wide
     feature table (34 GB) in MAPPED PINNED HOST memory, hotness-ranked feature cache + topology cache in HBM

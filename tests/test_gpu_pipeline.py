@@ -17,6 +17,8 @@ pytestmark = pytest.mark.gpu
     (11, 8, [3], 500, 7),
     (13, 8, [10, 10], 1024, 256),
     (10, 2, [1, 1, 1, 1], 32, 6),
+    (10, 2, [2, 2, 2, 2, 2], 32, 6),            # five and six hops: counter words 14 and 15 are the block's last
+    (11, 4, [3, 2, 2, 2, 2, 2], 24, 8),         # (SS/engine/operator_impl.cu:67,81-82; hop_num <= 6)
 ])
 def test_serve_batches_no_cache(hip, buckets, scale, ef, fanout, batch, dim):
     wl = Workload(scale=scale, edge_factor=ef, dim=dim)
@@ -233,6 +235,47 @@ def test_pipeline_groups_and_graph_replay(hip, buckets, group, slots, use_graph,
     pipe.wait(sl)
     for lane in range(min(group, 2)):
         compare_batches(engine.read_batch(pipe.pools[sl][lane]), cpu.run(0, lane, 1), f"valid batch {lane}: ")
+    pipe.close()
+    gpu.close(); cpu.close()
+
+
+@pytest.mark.parametrize("fanout,group,slots,use_graph,weave", [([2, 2, 2, 2, 2], 3, 2, True, True), ([3, 2, 2, 2, 2, 2], 4, 2, True, True),
+                                                                ([3, 2, 2, 2, 2, 2], 2, 3, True, False), ([2, 2, 2, 2, 2, 2], 3, 2, False, True)])
+def test_five_and_six_hops_through_groups_graph_replay_and_weave(hip, buckets, fanout, group, slots, use_graph, weave):
+    """hop_num = 5 and 6 (the counter block allows no more: words 9 + hop_num = 14, 15 are its last, SS/engine/operator_impl.cu:67,81-82)
+    through PreSC, the cost model, a cache with cached topology, lane groups, hipGraph replay and the weave -- five / six known-list
+    generations, six gathers per group -- every batch of two epochs against the oracle."""
+    from legion_amd import engine
+    wl = Workload(scale=11, edge_factor=8, dim=20, n_seeds=500)
+    batch = 48
+    gpu, cpu = GpuSide(wl, batch, fanout, cache_memory=120_000), CpuSide(wl, batch, fanout)
+    steps = (wl.sets[(0, 0)][0].size - 1) // batch
+    for it in range(steps):
+        compare_batches(gpu.run(0, it, 0, is_presc=True), cpu.run(0, it, 0, is_presc=True), f"presc {it}: ")
+    gpu.cache.candidate_selection(0, gpu.graph)
+    gpu.cache.cost_model(gpu.feature, gpu.graph, (0, 0), steps)
+    oc = cpu.build_cache(0, cache_memory=120_000, train_step=steps)[0]
+    assert (gpu.cache.node_capacity(0), gpu.cache.edge_capacity(0)) == (oc.node_capacity, oc.edge_capacity)
+    gpu.cache.fill_up(gpu.feature, gpu.graph)
+    g, c = gpu.run(0, 0, 0), cpu.run(0, 0, 0)
+    compare_batches(g, c, "eager serve: ")
+    H = len(fanout)
+    assert int(g["node_counter"][8]) == H and g["node_counter"][9 + H] == g["sampled_ids"].size and g["edge_counter"][9 + H] == g["agg_src_off"].size
+    pipe = engine.Pipeline(gpu.graph, gpu.feature, gpu.cache, 0, batch, fanout, group, gpu.pools[0].num_ids, use_graph, slots, weave=weave)
+    n_batches = (wl.sets[(0, 0)][0].size + batch - 1) // batch
+    n_groups = (n_batches + group - 1) // group
+    for rep in range(2):
+        pending = []
+        for gi in range(n_groups):
+            pending.append((gi, pipe.submit(gi * group, 0)))
+            if len(pending) == slots or gi == n_groups - 1:
+                for gj, sl in pending:
+                    pipe.wait(sl)
+                    for lane in range(group):
+                        compare_batches(engine.read_batch(pipe.pools[sl][lane]), cpu.run(0, gj * group + lane, 0),
+                                        f"{H} hops rep {rep} batch {gj * group + lane}: ")
+                        assert pipe.pools[sl][lane].error() == 0
+                pending = []
     pipe.close()
     gpu.close(); cpu.close()
 
