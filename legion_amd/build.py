@@ -80,7 +80,8 @@ def build_trainer(verbose=True, force=False):
     if built and not force and not _newer(built[0], srcs):
         return built[0]
     env = dict(os.environ, PYTORCH_ROCM_ARCH=ARCH)
-    cmd = [sys.executable, "setup.py", "build_ext", "--inplace"]
+    # --force: setuptools compares only the .cpp with its object; a changed header (vmm_probe.h) must rebuild too
+    cmd = [sys.executable, "setup.py", "build_ext", "--inplace", "--force"]
     if verbose:
         print("(cd trainer &&", " ".join(cmd) + ")", flush=True)
     subprocess.check_call(cmd, cwd=tdir, env=env)

@@ -34,6 +34,7 @@ extern "C" void* d_alloc_scattered_exportable(int64_t num_bytes, int32_t chunk_m
 extern "C" int64_t lg_scattered_info(void* ptr, int32_t* n_chunks);
 extern "C" int32_t lg_scattered_grant(void* ptr, const int32_t* logical_devs, int32_t n);
 extern "C" int32_t lg_scattered_serve(void* ptr, const char* name);
+extern "C" int32_t lg_scattered_exportable(void* ptr);
 extern "C" void* lg_scattered_map_remote(const char* name, int32_t n_chunks, int64_t chunk_bytes);
 extern "C" void lg_scattered_unmap_remote(void* base);
 extern "C" void* lg_private_arena_begin(int64_t bytes, int32_t scatter_mb);
@@ -608,6 +609,11 @@ extern "C" int32_t legion_pipeline_bulk_export(LegionPipeline* p, void* out_hand
     int32_t n_chunks = 0;
     const int64_t chunk_bytes = lg_scattered_info(p->arena.base, &n_chunks);
     if (chunk_bytes > 0) {              // an arena of shuffled chunks: other processes map it from file descriptors
+        if (!lg_scattered_exportable(p->arena.base)) {      // (a pipeline created with arena = True, bit 5 without bit 6)
+            printf("legion_hip: legion_pipeline_bulk_export: this pipeline's lane arena was not created exportable (use_graph bit 6 / arena = \"shared\"); "
+                   "another process cannot map it\n");
+            return 0;
+        }
         static std::atomic<int32_t> next_tag{0};
         if (p->bulk->served_tag < 0) {
             p->bulk->served_tag = next_tag.fetch_add(1);

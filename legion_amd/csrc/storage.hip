@@ -21,6 +21,7 @@
 #include <string>
 #include <thread>
 #include <sys/socket.h>
+#include <sys/time.h>
 #include <sys/un.h>
 
 #include "../trainer/vmm_probe.h"      // vmm_import_fd(): imports a received descriptor whichever way THIS process's HIP runtime takes one
@@ -71,7 +72,12 @@ extern "C" int32_t GetGPUDevice()
 // whose free memory happens to be fragmented (0.84-0.85) and independent of that luck.  Not exportable with hipIpcGetMemHandle and
 // mapped for THIS device only; what another process or another GPU must reach is created exportable (below) and granted / served.
 namespace {
-struct ScatterLive { size_t bytes; std::vector<hipMemGenericAllocationHandle_t> chunks; std::vector<int> listeners; };      // listeners: sockets of lg_scattered_serve threads
+struct ScatterLive {
+    size_t bytes;
+    std::vector<hipMemGenericAllocationHandle_t> chunks;
+    std::vector<int> listeners;       // sockets of lg_scattered_serve threads (each thread takes its own out again when it ends)
+    bool exportable = false;          // chunks created with a POSIX-file-descriptor handle type: only these can be exported / served
+};
 std::mutex g_scatter_mu;
 std::map<void*, ScatterLive> g_scatter_live;
 }
@@ -95,6 +101,7 @@ static void* alloc_scattered(int64_t num_bytes, int32_t chunk_mb, bool exportabl
     const size_t n = ((size_t)(num_bytes > 0 ? num_bytes : 16) + g - 1) / g;
     ScatterLive live;
     live.bytes = n * g;
+    live.exportable = exportable;
     live.chunks.resize(n);
     for (size_t i = 0; i < n; i++) HIP_CALL(hipMemCreate(&live.chunks[i], g, &prop, 0));
     uint64_t r = 0x9E3779B97F4A7C15ull;
@@ -123,19 +130,24 @@ extern "C" int64_t lg_scattered_info(void* ptr, int32_t* n_chunks)
     if (n_chunks) *n_chunks = (int32_t)it->second.chunks.size();
     return (int64_t)(it->second.bytes / it->second.chunks.size());
 }
-// a new file descriptor for chunk `index` of an exportable scattered allocation (the caller closes it), or -1
+// a new file descriptor for chunk `index` of an exportable scattered allocation (the caller closes it), or -1.  The export runs
+// under the registry's lock: d_free_scattered takes the allocation out of the registry under the same lock before it releases the
+// chunks, so a handle is never exported while it is being released.
 extern "C" int lg_scattered_export_fd(void* ptr, int32_t index)
 {
-    hipMemGenericAllocationHandle_t h;
-    {
-        std::lock_guard<std::mutex> lk(g_scatter_mu);
-        auto it = g_scatter_live.find(ptr);
-        if (it == g_scatter_live.end() || index < 0 || (size_t)index >= it->second.chunks.size()) return -1;
-        h = it->second.chunks[(size_t)index];
-    }
+    std::lock_guard<std::mutex> lk(g_scatter_mu);
+    auto it = g_scatter_live.find(ptr);
+    if (it == g_scatter_live.end() || !it->second.exportable || index < 0 || (size_t)index >= it->second.chunks.size()) return -1;
     int fd = -1;
-    if (hipMemExportToShareableHandle(&fd, h, hipMemHandleTypePosixFileDescriptor, 0) != hipSuccess) { (void)hipGetLastError(); return -1; }
+    if (hipMemExportToShareableHandle(&fd, it->second.chunks[(size_t)index], hipMemHandleTypePosixFileDescriptor, 0) != hipSuccess) { (void)hipGetLastError(); return -1; }
     return fd;
+}
+// 1 when `ptr` is a scattered allocation whose chunks can be exported (d_alloc_scattered_exportable)
+extern "C" int32_t lg_scattered_exportable(void* ptr)
+{
+    std::lock_guard<std::mutex> lk(g_scatter_mu);
+    auto it = g_scatter_live.find(ptr);
+    return (it != g_scatter_live.end() && it->second.exportable) ? 1 : 0;
 }
 // ---- a scattered allocation reached from OTHER GPUs / processes -------------------------------------------------------------------
 // (the server's lane arena handed to a trainer; since round 5 also the lane arenas owners push rows into, peer_gather = bulk: round 4
@@ -181,6 +193,10 @@ extern "C" int32_t lg_scattered_serve(void* ptr, const char* name)
 {
     int32_t n_chunks = 0;
     if (lg_scattered_info(ptr, &n_chunks) <= 0) return 0;
+    if (!lg_scattered_exportable(ptr)) {
+        printf("legion_hip: %s: the allocation was not created exportable (d_alloc_scattered_exportable): its chunks cannot be served\n", name);
+        return 0;
+    }
     const int ls = socket(AF_UNIX, SOCK_STREAM | SOCK_CLOEXEC, 0);
     if (ls < 0) return 0;
     sockaddr_un addr;
@@ -199,8 +215,24 @@ extern "C" int32_t lg_scattered_serve(void* ptr, const char* name)
     std::thread([ls, ptr, n_chunks, hip_dev]() {
         (void)hipSetDevice(hip_dev);
         for (;;) {
-            const int c = accept(ls, nullptr, nullptr);
-            if (c < 0) { if (errno == EINTR) continue; close(ls); return; }      // (shut down: the allocation has been freed)
+            const int c = accept4(ls, nullptr, nullptr, SOCK_CLOEXEC);
+            if (c < 0) {
+                // the allocation has been freed (d_free_scattered took it out of the registry, then shut the socket down): close and go.
+                // Anything else -- EINTR, ECONNABORTED, EMFILE / ENFILE, ENOMEM ... -- is transient: a later peer must still be served.
+                bool freed;
+                {
+                    std::lock_guard<std::mutex> lk(g_scatter_mu);
+                    auto it = g_scatter_live.find(ptr);
+                    freed = it == g_scatter_live.end() || std::find(it->second.listeners.begin(), it->second.listeners.end(), ls) == it->second.listeners.end();
+                }
+                if (freed) { close(ls); return; }
+                if (errno != EINTR) usleep(2000);
+                continue;
+            }
+            {   // a peer that connects and never reads must not block the only serving thread for ever
+                timeval tv = {2, 0};
+                (void)setsockopt(c, SOL_SOCKET, SO_SNDTIMEO, &tv, sizeof(tv));
+            }
             {
                 ucred cr;
                 socklen_t cl = sizeof(cr);
@@ -334,7 +366,7 @@ static bool d_free_scattered(void* ptr)
         live = std::move(it->second);
         g_scatter_live.erase(it);
     }
-    for (int ls : live.listeners) shutdown(ls, SHUT_RDWR);      // wakes the serving thread out of accept(); it closes the socket itself
+    for (int ls : live.listeners) shutdown(ls, SHUT_RDWR);      // wakes the serving thread out of accept(); it finds the allocation gone and closes the socket itself
     HIP_CALL(hipMemUnmap(ptr, live.bytes));
     HIP_CALL(hipMemAddressFree(ptr, live.bytes));
     for (auto h : live.chunks) HIP_CALL(hipMemRelease(h));

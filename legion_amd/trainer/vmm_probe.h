@@ -3,7 +3,9 @@
 // (storage.hip: a clique member mapping another process's lane arena) and by tools/micro/vmm_convention_probe.cpp (built against
 // /opt/rocm): tests/test_gpu_boundary.py runs both runtimes.
 #pragma once
+#include <atomic>
 #include <cstdint>
+#include <mutex>
 #include <fcntl.h>
 #include <unistd.h>
 
@@ -17,9 +19,18 @@
 // vmm_import_fd() finds out on the first descriptor it is given -- one that came from the exporting process, so that nothing is
 // ever imported into the process that exported it -- and cannot crash: it passes a POINTER first, and the descriptor's copy sits at
 // an address whose low 32 bits are no descriptor of this process.  A runtime that wants the value reads those bits as a descriptor
-// number, finds none and returns an error; only then, and only for a descriptor that fcntl() says is open, the value is tried.
-// g_fd_convention: -2 not known yet, 0 pointer, 1 value.
-static int g_fd_convention = -2;
+// number, finds none and returns an error.  The value is tried afterwards only when ALL of this holds (a pointer attempt
+// also fails for honest reasons -- out of memory, no access to the exporter's GPU, a chunk the server already released -- and on a
+// pointer runtime the value convention is a segmentation fault, not an error code):
+//   * the convention is still unknown,
+//   * the runtime reports a version from which the value convention is known (hipRuntimeGetVersion() >= 7.2: an independent prior;
+//     the runtime bundled with torch reports 7.0 and is never handed a value),
+//   * the pointer attempt did not fail for lack of memory,
+//   * fcntl() says the descriptor is open.
+// Otherwise the error goes back to the caller, which falls back to the pipe slots / the direct arrangement.
+// One import at a time (the cell is shared): a mutex; g_fd_convention: -2 not known yet, 0 pointer, 1 value.
+static std::atomic<int> g_fd_convention{-2};
+static std::mutex g_fd_import_mu;
 
 static int* vmm_safe_cell()
 {
@@ -42,19 +53,29 @@ static int* vmm_safe_cell()
     return chosen;
 }
 
+static bool vmm_runtime_known_to_take_the_value()
+{
+    int v = 0;
+    if (hipRuntimeGetVersion(&v) != hipSuccess) { (void)hipGetLastError(); return false; }
+    return v >= 70200000;
+}
+
 static hipError_t vmm_import_fd(hipMemGenericAllocationHandle_t* h, int fd)
 {
-    if (g_fd_convention == 1) return hipMemImportFromShareableHandle(h, (void*)(uintptr_t)fd, hipMemHandleTypePosixFileDescriptor);
+    std::lock_guard<std::mutex> lock(g_fd_import_mu);
+    if (g_fd_convention.load() == 1) return hipMemImportFromShareableHandle(h, (void*)(uintptr_t)fd, hipMemHandleTypePosixFileDescriptor);
     int* cell = vmm_safe_cell();
     if (cell == nullptr) return hipErrorNotSupported;          // (cannot happen: see vmm_safe_cell)
     *cell = fd;
     hipError_t e = hipMemImportFromShareableHandle(h, (void*)cell, hipMemHandleTypePosixFileDescriptor);
-    if (e == hipSuccess) { g_fd_convention = 0; return e; }
-    if (g_fd_convention == 0) return e;                        // a runtime known to take the pointer refused this descriptor
+    if (e == hipSuccess) { g_fd_convention.store(0); return e; }
+    if (g_fd_convention.load() == 0) return e;                 // a runtime known to take the pointer refused this descriptor
     (void)hipGetLastError();
-    if (fcntl(fd, F_GETFD) == -1) return e;                    // not an open descriptor: nothing learned, and the value is never tried blind
+    if (e == hipErrorOutOfMemory || e == hipErrorMemoryAllocation) return e;      // an honest failure says nothing about the convention
+    if (!vmm_runtime_known_to_take_the_value()) return e;      // never a value blind: the caller falls back
+    if (fcntl(fd, F_GETFD) == -1) return e;                    // not an open descriptor: nothing learned
     e = hipMemImportFromShareableHandle(h, (void*)(uintptr_t)fd, hipMemHandleTypePosixFileDescriptor);
-    if (e == hipSuccess) g_fd_convention = 1;
+    if (e == hipSuccess) g_fd_convention.store(1);
     return e;
 }
 
@@ -63,7 +84,7 @@ static hipError_t vmm_import_fd(hipMemGenericAllocationHandle_t* h, int fd)
 // learn the convention from the first descriptor they receive (above) and import nothing of their own.
 static int vmm_fd_convention()
 {
-    if (g_fd_convention >= 0) return g_fd_convention;
+    if (g_fd_convention.load() >= 0) return g_fd_convention.load();
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return -1; }
     hipMemAllocationProp prop = {};
@@ -85,5 +106,5 @@ static int vmm_fd_convention()
         (void)hipGetLastError();
     }
     (void)hipMemRelease(own);
-    return g_fd_convention >= 0 ? g_fd_convention : -1;
+    return g_fd_convention.load() >= 0 ? g_fd_convention.load() : -1;
 }
