@@ -360,8 +360,11 @@ void UnifiedCache::CandidateSelection(int cache_agg_mode, FeatureStorage* featur
     is_presc_ = false;
 }
 
-// SS/cache/cache.cu:445-551.  Same statement-by-statement arithmetic as oracle/legion_oracle.c
-// lgo_cost_model (float tables, double intermediates); prefix[-1] reads as 0.
+// SS/cache/cache.cu:445-551: the split of a clique's cache memory between feature rows and adjacency.  The budget is walked in granules of
+// 1 % (MIN_INTERVAL); at every granule count k the transactions a topology cache of k granules and a feature cache of the remaining
+// steps - 1 - k granules would save are added up, and the k with the largest sum wins.  The arithmetic TYPES are the reference's (float
+// tables filled from double expressions, integer capacities stored through float: oracle/legion_oracle.c lgo_cost_model restates the
+// same) because they decide which k wins on ties; prefix[-1] reads as 0; the two log lines are part of the launcher's contract.
 void UnifiedCache::CostModel(int, FeatureStorage* feature, GraphStorage* graph,
                              std::vector<uint64_t>& counters, int32_t train_step)
 {
@@ -374,70 +377,70 @@ void UnifiedCache::CostModel(int, FeatureStorage* feature, GraphStorage* graph,
         if (QF_[i] == nullptr) { node_capacity_.push_back(0); edge_capacity_.push_back(0); continue; }
         for (int32_t j = 0; j < Kg_; j++)
             if (lg_is_local(i * Kg_ + j)) { SetGPUDevice(i * Kg_ + j); break; }
-        const int max_payload_size = CLS;
-        const int64_t memory_step = (int64_t)((double)(cache_memory_ * Kg_) * MIN_INTERVAL);
-        const uint64_t total_trans_of_topo = counters[0] + counters[1];
-        uint64_t total_trans_of_feat = 0;
+        const int transaction_bytes = CLS;
+        const int64_t granule = (int64_t)((double)(cache_memory_ * Kg_) * MIN_INTERVAL);
+        const uint64_t topo_tx_total = counters[0] + counters[1];
+        uint64_t feat_tx_total = 0;
         for (int j = 0; j < Kg_; j++)     // the reference indexes controller j, not i*Kg+j (:462)
-            total_trans_of_feat += (uint64_t)((int64_t)(((int64_t)(j < (int32_t)peer_max_ids_.size() ? peer_max_ids_[j]
+            feat_tx_total += (uint64_t)((int64_t)(((int64_t)(j < (int32_t)peer_max_ids_.size() ? peer_max_ids_[j]
                                                                    : cache_controller_[j]->MaxIdNum()) * train_step) * D) * sizeof(float)) /
-                                   (uint64_t)max_payload_size;
+                                   (uint64_t)transaction_bytes;
 
         unsigned long long* d_prefix = (unsigned long long*)d_alloc_space((int64_t)N * 8);
         unsigned long long* d_edge_mem = (unsigned long long*)d_alloc_space((int64_t)N * 8);
-        std::vector<uint64_t> h_node_prefix(N), h_edge_prefix(N), h_edge_mem_prefix(N);
+        std::vector<uint64_t> node_hot_prefix(N), edge_hot_prefix(N), adjacency_bytes_prefix(N);
         lg::inclusive_scan_u64(nullptr, AF_[i], d_prefix, N);
-        HIP_CALL(hipMemcpy(h_node_prefix.data(), d_prefix, (size_t)N * 8, hipMemcpyDeviceToHost));
+        HIP_CALL(hipMemcpy(node_hot_prefix.data(), d_prefix, (size_t)N * 8, hipMemcpyDeviceToHost));
         lg::inclusive_scan_u64(nullptr, AT_[i], d_prefix, N);
-        HIP_CALL(hipMemcpy(h_edge_prefix.data(), d_prefix, (size_t)N * 8, hipMemcpyDeviceToHost));
+        HIP_CALL(hipMemcpy(edge_hot_prefix.data(), d_prefix, (size_t)N * 8, hipMemcpyDeviceToHost));
         lg::edge_mem_in_order(nullptr, QT_[i], d_edge_mem, N, csr_index);
         lg::inclusive_scan_u64(nullptr, d_edge_mem, d_prefix, N);
-        HIP_CALL(hipMemcpy(h_edge_mem_prefix.data(), d_prefix, (size_t)N * 8, hipMemcpyDeviceToHost));
+        HIP_CALL(hipMemcpy(adjacency_bytes_prefix.data(), d_prefix, (size_t)N * 8, hipMemcpyDeviceToHost));
         d_free_space(d_prefix);
         d_free_space(d_edge_mem);
 
-        const int64_t total_mem = cache_memory_ * Kg_;
-        if (memory_step <= 0) {
+        const int64_t clique_bytes = cache_memory_ * Kg_;
+        if (granule <= 0) {
             printf("cache_memory %lld is too small for the cost model\n", (long long)cache_memory_);
             exit(EXIT_FAILURE);
         }
-        const int64_t steps = (total_mem - 1) / memory_step + 1;
-        int64_t current_steps = 0;
-        int32_t node_num_topo = 0, node_num_feat = 0;
-        std::vector<float> trans_of_topo(steps + 1, 0), trans_of_feat(steps + 1, 0);
-        std::vector<float> cap_of_topo(steps + 1, 0), cap_of_feat(steps + 1, 0), trans_of_total(steps + 1, 0);
+        const int64_t steps = (clique_bytes - 1) / granule + 1;
+        int64_t step = 0;
+        int32_t topo_vertices = 0, feat_rows = 0;
+        std::vector<float> topo_tx_at(steps + 1, 0), feat_tx_at(steps + 1, 0);
+        std::vector<float> topo_rows_at(steps + 1, 0), feat_rows_at(steps + 1, 0), saved_tx_at(steps + 1, 0);
         auto at = [](const std::vector<uint64_t>& v, int64_t k) -> uint64_t { return k < 0 ? 0 : v[k]; };
-        for (int64_t current_mem = 0; current_mem < total_mem; current_mem += memory_step) {
-            if ((uint64_t)current_mem > (uint64_t)N * D * sizeof(float))
-                node_num_feat = N;
+        for (int64_t budget = 0; budget < clique_bytes; budget += granule) {
+            if ((uint64_t)budget > (uint64_t)N * D * sizeof(float))
+                feat_rows = N;
             else
-                node_num_feat = (int32_t)((uint64_t)(current_steps + 1) * ((uint64_t)memory_step / (D * sizeof(float))));
-            if ((uint64_t)current_mem > h_edge_mem_prefix[N - 1])
-                node_num_topo = N;
+                feat_rows = (int32_t)((uint64_t)(step + 1) * ((uint64_t)granule / (D * sizeof(float))));
+            if ((uint64_t)budget > adjacency_bytes_prefix[N - 1])
+                topo_vertices = N;
             else
-                node_num_topo = (int32_t)(std::lower_bound(h_edge_mem_prefix.begin(), h_edge_mem_prefix.end(),
-                                                           (uint64_t)current_mem) - h_edge_mem_prefix.begin());
-            if (node_num_topo < N) {
-                trans_of_topo[current_steps] = (float)((double)total_trans_of_topo * 1.0 / (double)h_edge_prefix[N - 1] *
-                                                       (double)at(h_edge_prefix, (int64_t)node_num_topo - 1));
-                cap_of_topo[current_steps] = (float)(node_num_topo / Kg_);
+                topo_vertices = (int32_t)(std::lower_bound(adjacency_bytes_prefix.begin(), adjacency_bytes_prefix.end(),
+                                                           (uint64_t)budget) - adjacency_bytes_prefix.begin());
+            if (topo_vertices < N) {
+                topo_tx_at[step] = (float)((double)topo_tx_total * 1.0 / (double)edge_hot_prefix[N - 1] *
+                                                       (double)at(edge_hot_prefix, (int64_t)topo_vertices - 1));
+                topo_rows_at[step] = (float)(topo_vertices / Kg_);
             }
-            if (node_num_feat < N) {
-                trans_of_feat[current_steps] = (float)((double)total_trans_of_feat * 1.0 / (double)h_node_prefix[N - 1] *
-                                                       (double)at(h_node_prefix, (int64_t)node_num_feat - 1));
-                cap_of_feat[current_steps] = (float)(node_num_feat / Kg_);
+            if (feat_rows < N) {
+                feat_tx_at[step] = (float)((double)feat_tx_total * 1.0 / (double)node_hot_prefix[N - 1] *
+                                                       (double)at(node_hot_prefix, (int64_t)feat_rows - 1));
+                feat_rows_at[step] = (float)(feat_rows / Kg_);
             }
-            current_steps++;
+            step++;
         }
-        for (int64_t sidx = 1; sidx < steps; sidx++)
-            trans_of_total[sidx] = trans_of_topo[sidx] + trans_of_feat[steps - 1 - sidx];
-        const int64_t max_sidx = std::max_element(trans_of_total.begin(), trans_of_total.end()) - trans_of_total.begin();
-        std::cout << "Alpha: " << (max_sidx * MIN_INTERVAL) << " Transactions: " << trans_of_total[max_sidx]
+        for (int64_t k = 1; k < steps; k++)
+            saved_tx_at[k] = topo_tx_at[k] + feat_tx_at[steps - 1 - k];
+        const int64_t best = std::max_element(saved_tx_at.begin(), saved_tx_at.end()) - saved_tx_at.begin();
+        std::cout << "Alpha: " << (best * MIN_INTERVAL) << " Transactions: " << saved_tx_at[best]
                   << " on Clique: " << i << std::endl;
-        node_capacity_.push_back((int32_t)(cap_of_feat[steps - 1 - max_sidx] + 1));
-        edge_capacity_.push_back((int32_t)(cap_of_topo[max_sidx] + 1));
-        std::cout << "Feat capacity: " << cap_of_feat[steps - 1 - max_sidx] << " Topo capacity: "
-                  << cap_of_topo[max_sidx] << " on Clique: " << i << std::endl;
+        node_capacity_.push_back((int32_t)(feat_rows_at[steps - 1 - best] + 1));
+        edge_capacity_.push_back((int32_t)(topo_rows_at[best] + 1));
+        std::cout << "Feat capacity: " << feat_rows_at[steps - 1 - best] << " Topo capacity: "
+                  << topo_rows_at[best] << " on Clique: " << i << std::endl;
     }
 }
 

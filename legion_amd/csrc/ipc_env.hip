@@ -157,35 +157,31 @@ public:
         semw_.resize(device_count);
     }
 
-    // ipc_service.cu:60-128
+    // ipc_service.cu:60-128: the schedule every GPU follows.  Training: as many steps as the SMALLEST partition fills with raw batches (the
+    // last, partial batch of every partition is dropped: (n - 1) / B).  Validation / testing: the LARGEST partition is cut into batches of
+    // at most 512 seeds, and every partition spreads its seeds over that many steps (ceil division): all GPUs post the same number of
+    // batches, of per-GPU sizes.  The three log lines and steps[0..2] of the slab are the contract with the trainer end.
     void Coordinate(BuildInfo* info) override
     {
-        const int32_t partition_count = info->partition_count;
+        const int32_t gpus = info->partition_count;
         epoch_ = info->epoch;
         raw_batch_size_ = info->raw_batch_size;
-        int32_t min_train_size = 1000000000;
-        for (int32_t i = 0; i < partition_count; i++)
-            if (info->training_set_num[i] < min_train_size) min_train_size = info->training_set_num[i];
-        train_step_ = (min_train_size - 1) / raw_batch_size_;
-        train_batch_size_.assign(partition_count, raw_batch_size_);
-
-        int32_t max_valid_size = 0;
-        const int32_t raw_valid_batch_size = 512;
-        for (int32_t i = 0; i < partition_count; i++)
-            if (info->validation_set_num[i] > max_valid_size) max_valid_size = info->validation_set_num[i];
-        valid_step_ = (max_valid_size - 1) / raw_valid_batch_size + 1;
-        valid_batch_size_.clear();
-        for (int32_t i = 0; i < partition_count; i++)
-            valid_batch_size_.push_back((info->validation_set_num[i] - 1) / valid_step_ + 1);
-
-        int32_t max_test_size = 0;
-        const int32_t raw_test_batch_size = 512;
-        for (int32_t i = 0; i < partition_count; i++)
-            if (info->testing_set_num[i] > max_test_size) max_test_size = info->testing_set_num[i];
-        test_step_ = (max_test_size - 1) / raw_test_batch_size + 1;
-        test_batch_size_.clear();
-        for (int32_t i = 0; i < partition_count; i++)
-            test_batch_size_.push_back((info->testing_set_num[i] - 1) / test_step_ + 1);
+        const int32_t eval_unit = 512;
+        // (steps, per-GPU batch size) of an evaluation set: steps from its largest partition, sizes by ceil(n_i / steps)
+        auto spread = [gpus, eval_unit](const std::vector<int32_t>& count, std::vector<int32_t>& per_gpu) {
+            int32_t largest = 0;
+            for (int32_t g = 0; g < gpus; g++) largest = std::max(largest, count[g]);
+            const int32_t steps = (largest - 1) / eval_unit + 1;
+            per_gpu.clear();
+            for (int32_t g = 0; g < gpus; g++) per_gpu.push_back((count[g] - 1) / steps + 1);
+            return steps;
+        };
+        int32_t smallest_train = 1000000000;
+        for (int32_t g = 0; g < gpus; g++) smallest_train = std::min(smallest_train, info->training_set_num[g]);
+        train_step_ = (smallest_train - 1) / raw_batch_size_;
+        train_batch_size_.assign(gpus, raw_batch_size_);
+        valid_step_ = spread(info->validation_set_num, valid_batch_size_);
+        test_step_ = spread(info->testing_set_num, test_batch_size_);
 
         std::cout << "Train Steps: " << train_step_ << "\n";
         std::cout << "Valid Steps: " << valid_step_ << "\n";

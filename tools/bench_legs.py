@@ -226,12 +226,14 @@ def parse_args():
     ap.add_argument("--backend", type=str, default="nccl", help="torch.distributed backend (nccl = RCCL)")
     ap.add_argument("--no-product-collective", action="store_true",
                     help="hotness all-reduce through torch.distributed instead of the library's own RCCL call")
-    ap.add_argument("--collective-deadline", type=int, default=120,
+    ap.add_argument("--collective-deadline", type=int, default=90,
                     help="seconds the library's communicator may take to form before the run falls back to torch.distributed")
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise torch.distributed and run the collectives even at N = 1 (exercises the RCCL calls on a 1-GPU box)")
-    ap.add_argument("--extra-legs-deadline", type=int, default=600,
-                    help="N > 1: seconds the extra (striped) legs may take together before rank 0 prints the headline line alone and exits")
+    ap.add_argument("--extra-legs-deadline", type=int, default=330,
+                    help="N > 1: seconds the extra (striped) legs may take together before rank 0 prints the headline line alone and exits "
+                         "(budget of an N = 8 run against a 600 s limit: headline leg <= ~150 s even when the library's communicator never forms "
+                         "-- set-up ~60 s + --collective-deadline 90 s -- plus these 330 s)")
     ap.add_argument("--fail-extra-leg", type=str, default="", choices=["", "raise", "exit", "sigterm", "hang"],
                     help="testing: make rank 0 fail this way when the first extra leg starts (the headline line must still go out)")
     ap.add_argument("--force-device", type=int, default=-1,
