@@ -19,6 +19,7 @@ import torch.distributed as dist
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 HBM_PEAK_GBPS = 8000.0   # MI355X_MICROARCH.md: 8 TB/s spec
 INFINITY_CACHE_BYTES = 256 << 20   # MI355X_MICROARCH.md: 256 MiB memory-side cache in front of the HBM
+HBM_ACHIEVABLE_GBPS = 6290.0       # MI355X_MICROARCH.md: what a float4 streaming copy measures (79 % of the spec peak)
 
 
 class OneLine:
@@ -650,6 +651,8 @@ def cold_regather(c, pipe, node_map, bytes_per_row, repeats=7):
     med = ms_cold[len(ms_cold) // 2]
     out["cold"] = {"avg_launch_us": med * 1e3, "achieved": total * bytes_per_row / (med * 1e-3) / 1e9,
                    "frac": total * bytes_per_row / (med * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                   "frac_of_achievable": total * bytes_per_row / (med * 1e-3) / 1e9 / HBM_ACHIEVABLE_GBPS,
+                   "achievable_peak": HBM_ACHIEVABLE_GBPS,
                    "min_launch_us": ms_cold[0] * 1e3, "max_launch_us": ms_cold[-1] * 1e3, "launches": len(ms_cold)}
     out["note"] = ("`alone`: the group's last-hop gather launched again with nothing beside it (inside a group the next group's head shares "
                    "the machine); `cold`: the same launch after every lane's last-hop ids were replaced by ids that do not repeat anywhere in "
