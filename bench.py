@@ -300,6 +300,9 @@ def run_leg(c, engine, synth, stripe, replica_memory, headline, bulk=False, shap
             cache.set_replica_memory(replica_memory)
         cache.fill_up_distributed(feature, graph, d, world, mids, all_gather_bytes)
         dist.barrier()
+    elif args.hybrid:
+        hy_cpu, hy_gpu = (int(x) for x in args.hybrid.split(","))
+        cache.hybrid_init(feature, graph, hy_cpu, hy_gpu)                   # every GPU from its own counters: no collective result is used
     else:
         cache.candidate_selection(0, graph, world_reduced=use_dist)
         cache.cost_model(feature, graph, counters, train_step)
@@ -481,6 +484,17 @@ def run_leg(c, engine, synth, stripe, replica_memory, headline, bulk=False, shap
                 "feature_cache_hit_rate": counted.feat_hit_rows / max(counted.feat_hit_rows + counted.feat_miss_rows, 1),
                 "feature_cache_hit_rate_over": "every timed batch" if args.placement == "pinned" else "the first timed step",
             }
+            if args.hybrid and counted.tiers is not None:
+                t_cpu, t_gpu, t_miss = counted.tiers
+                pcie_gbps = t_cpu / max(t_cpu + t_gpu + t_miss, 1) * float(rows.sum() * D * 4) / t_all_gathers / 1e9 if t_all_gathers > 0 else 0.0
+                out["hybrid_tier"] = {"cpu_cache_rows": hy_cpu, "gpu_cache_rows": hy_gpu,
+                                      "rows_from_cpu_cache": t_cpu, "rows_from_gpu_cache": t_gpu, "rows_from_table": t_miss,
+                                      "rows_counted_over": "the first timed step",
+                                      "cpu_cache_GBps_over_pcie": pcie_gbps, "pcie_peak_GBps": 64.0,
+                                      "note": "UnifiedCache::HybridInit (SS/cache/cache.cu:614-670) instead of the cost model: the hottest "
+                                              "gpu_cache_rows of this GPU's own order in HBM, the next cpu_cache_rows in mapped pinned host memory "
+                                              "(read in place over PCIe inside the same gather launches), misses from the full table in HBM; "
+                                              "cpu_cache_GBps = CPU-cache rows x D x 4 / HIP-event time of all gather launches"}
             if collective is not None:
                 out["collective"] = collective
                 out["per_rank"] = per_rank

@@ -128,15 +128,18 @@ def test_rccl_calls_execute_at_n1(hip):
     assert d["n_gpus"] == 1 and d["value"] > 0
 
 
-@pytest.mark.parametrize("partition_file,peer_gather", [(False, "direct"), (True, "direct"), (False, "bulk")],
-                         ids=["modulo", "partition-file", "modulo-bulk-peer-gather"])
-def test_one_server_process_two_gpus_thread_per_gpu(hip, tmp_path, partition_file, peer_gather):
+@pytest.mark.parametrize("partition_file,peer_gather,disk", [(False, "direct", False), (True, "direct", False), (False, "bulk", False),
+                                                             (False, "direct", True)],
+                         ids=["modulo", "partition-file", "modulo-bulk-peer-gather", "disk-mode-hybrid-tier"])
+def test_one_server_process_two_gpus_thread_per_gpu(hip, tmp_path, partition_file, peer_gather, disk):
     """`sampling_server 2 1 5 3`: GPUServer with two runners (a host thread each), PreSC on both, hotness summed over the
     clique, caches striped Kg = 2, two pipe-slot sets, two trainer processes.  Logical GPU 1 shares the box's one GPU.
     With a `partition` file in the dataset directory (the reference's xtrapulp output, storage_management.cu:165-183)
     training seeds go to the GPU the file names -- an uneven split, entries >= 2 dropped -- while validation and testing
     seeds stay on id % 2.  peer_gather = bulk: the rows a runner needs from the OTHER member's stripe are listed per owner and pushed
-    by kernels on the owner's device (LegionTuning.peer_gather, pipeline.hip) instead of being loaded through peer pointers."""
+    by kernels on the owner's device (LegionTuning.peer_gather, pipeline.hip) instead of being loaded through peer pointers.
+    disk: `sampling_server 2 1 5 3 --disk` with the fifteen-field meta_config: no clique at all -- every GPU builds the hybrid
+    CPU-cache / GPU-cache tier from its OWN counters (UnifiedCache::HybridInit, SS/cache/cache.cu:626-643), one CPU cache per GPU."""
     scale, D, B, fanout, epoch, cache_memory = 11, 24, 40, [5, 3], 2, 40_000
     part = None
     if partition_file:
@@ -154,12 +157,14 @@ def test_one_server_process_two_gpus_thread_per_gpu(hip, tmp_path, partition_fil
     train.tofile(ds + "trainingset"); valid.tofile(ds + "validationset"); test.tofile(ds + "testingset")
     work = tmp_path / "run"
     work.mkdir()
+    cpu_cap, gpu_cap = 140, 110
     (work / "meta_config").write_text("{} {} {} {} {} {} {} {} {} {}".format(
-        ds, B, N, wl.col.size, D, train.size, valid.size, test.size, cache_memory, epoch))
+        ds, B, N, wl.col.size, D, train.size, valid.size, test.size, cache_memory, epoch) +
+        (" 0 0 0 {} {}".format(cpu_cap, gpu_cap) if disk else ""))
     ns = f"_m{os.getpid()}"
     env = dict(os.environ, LEGION_IPC_NAMESPACE=ns, LEGION_PEER_GATHER=peer_gather)
-    server, log = start_server([os.path.join(ROOT, "legion_amd", "bin", "sampling_server"), "2", "1"] + [str(f) for f in fanout],
-                               work, env, work / "server.log")
+    server, log = start_server([os.path.join(ROOT, "legion_amd", "bin", "sampling_server"), "2", "1"] + [str(f) for f in fanout] +
+                               (["--disk"] if disk else []), work, env, work / "server.log")
     trainers = []
     try:
         for dev in range(2):
@@ -174,7 +179,10 @@ def test_one_server_process_two_gpus_thread_per_gpu(hip, tmp_path, partition_fil
         assert server.returncode == 0, open(work / "server.log").read()[-3000:]
         text = open(work / "server.log").read()
         assert ("pushed by their owners (peer_gather = bulk)" in text) == (peer_gather == "bulk"), text[-2000:]
-        assert "leader loop over peer pointers (its logical GPUs share physical devices)" in text      # one GPU in the box: no RCCL communicator
+        if disk:
+            assert "Finish initializing cache" in text and "Alpha:" not in text and "GPU Cache Capacity: %d" % gpu_cap in text
+        else:
+            assert "leader loop over peer pointers (its logical GPUs share physical devices)" in text      # one GPU in the box: no RCCL communicator
 
         # ---- the oracle: the same two-GPU server in one address space --------------------------------
         from oracle import ffi
@@ -189,7 +197,15 @@ def test_one_server_process_two_gpus_thread_per_gpu(hip, tmp_path, partition_fil
         for p in range(2):
             for it in range(st.train_step):
                 cpu.run(p, it, 0, is_presc=True, batch_size=B)
-        cpu.build_cache(1, cache_memory=cache_memory, train_step=st.train_step)
+        if disk:
+            cpu.Kg, cpu.caches = 1, []
+            for p in range(2):
+                c = ffi.OracleCache(wl.N, wl.D, 1, p)
+                c.hybrid_init(cpu.node_access[p], wl.features, cpu_cap, gpu_cap)
+                cpu.caches.append(c)
+            assert not np.array_equal(cpu.caches[0].arr("QF", np.int32)[:50], cpu.caches[1].arr("QF", np.int32)[:50])    # two orders
+        else:
+            cpu.build_cache(1, cache_memory=cache_memory, train_step=st.train_step)
         total = L.lgo_max_step(ctypes.byref(st))
         H = len(fanout)
         hits = 0

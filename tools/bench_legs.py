@@ -182,6 +182,10 @@ def parse_args():
     ap.add_argument("--capacity", type=str, default="",
                     help="NODE,EDGE: cache capacities per GPU set by hand after the cost model has run (its choice is logged): e.g. a "
                          "topology cache of the EDGE hottest vertices' adjacency beside a pinned-host CSR (SURVEY section 8 N1)")
+    ap.add_argument("--hybrid", type=str, default="",
+                    help="CPU_ROWS,GPU_ROWS: the hybrid CPU-cache / GPU-cache tier (UnifiedCache::HybridInit, SS/cache/cache.cu:614-670; what the "
+                         "server builds in disk mode) instead of CandidateSelection + CostModel + FillUp: the GPU_ROWS hottest rows of this GPU's own "
+                         "order in an HBM cache, the next CPU_ROWS in a mapped pinned host cache (read over PCIe), the rest from the full table")
     ap.add_argument("--no-cache", action="store_true",
                     help="experiment: no feature/topology cache at all (no FillUp): every row comes from the full table and the "
                          "gather makes no node_map lookup -- what the lookup's 128-byte line per row costs the gather")
@@ -471,6 +475,8 @@ def counting_pass(c, synth, pipe, cache, d, node_map, feature_rows, headline, st
     r.hop_edges = np.zeros((n_timed, H), dtype=np.int64)
     r.hop_slots = np.zeros((n_timed, H), dtype=np.int64)
     r.hits = r.feat_hit_rows = r.feat_miss_rows = 0
+    hybrid_cpu_cap = int(args.hybrid.split(",")[0]) if args.hybrid else None
+    tiers = [0, 0, 0]
     last_hop_ids = []
     if stripe:
         cache.gather_stats3(d)                   # arms the row-source counters for this (untimed) pass only
@@ -486,9 +492,15 @@ def counting_pass(c, synth, pipe, cache, d, node_map, feature_rows, headline, st
         r.edges[k] = ec[9 + H]
         r.rows[k, 0] = nc[9]
         if node_map.numel() > 0 and (args.placement == "pinned" or k < G):
-            hm = node_map[pl.buffer("sampled_ids")[:int(nc[9 + H])].long()] >= 0
+            slots = node_map[pl.buffer("sampled_ids")[:int(nc[9 + H])].long()]
+            hm = slots >= 0
             r.feat_hit_rows += int(hm.sum())
             r.feat_miss_rows += int(hm.numel() - int(hm.sum()))
+            if hybrid_cpu_cap is not None:       # hybrid tier: slots below cpu_cap are CPU-cache rows (cache_impl.cuh:224-231)
+                in_cpu = int(((slots >= 0) & (slots < hybrid_cpu_cap)).sum())
+                tiers[0] += in_cpu
+                tiers[1] += int(hm.sum()) - in_cpu
+                tiers[2] += int(hm.numel() - int(hm.sum()))
         if k < G and headline:
             last_hop_ids.append(pl.buffer("sampled_ids")[int(nc[9 + H - 1]):int(nc[9 + H])].clone())
         for h in range(H):
@@ -508,6 +520,7 @@ def counting_pass(c, synth, pipe, cache, d, node_map, feature_rows, headline, st
             src_g = pl.buffer("agg_src_ids")[:e].long()
             assert bool((ids.long()[pl.buffer("agg_src_off")[:e].long()] == src_g).all())
             r.hits = int((pl.buffer("cache_search_buffer")[:int(nc[1])] >= 0).sum())
+    r.tiers = tuple(tiers) if hybrid_cpu_cap is not None else None
     r.unique = None
     if last_hop_ids:
         allids = torch.cat(last_hop_ids)
