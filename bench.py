@@ -185,14 +185,16 @@ def main():
     # ---- N = 1, the default shape: Legion's default batch size on the same tables, driver-timed in the same run ----------------
     # (like the boundary and traffic legs, part of the FULL default run only: --no-boundary, which every measurement script passes, skips it)
     if world == 1 and not args.no_other_shapes and not args.no_boundary and args.placement == "hbm" and B == 1024 and args.nodes == 0 and not args.no_cache:
-        try:
-            c2 = shape_context(c, synth, 8000, args.other_shapes_steps, 2)
-            if c2 is not None:
-                out["other_shapes"] = [run_leg(c2, engine, synth, False, 0, headline=False, shape_leg=True)["json"]]
-        except Exception as e:      # the headline stands
-            import traceback
-            traceback.print_exc()
-            out["other_shapes"] = [{"error": f"{type(e).__name__}: {e}"[:400]}]
+        out["other_shapes"] = []
+        for sb, sf in ((8000, [25, 10]), (8000, [15, 10, 5])):      # Legion's default batch size at BASELINE's two fan-outs
+            try:
+                c2 = shape_context(c, synth, sb, sf, args.other_shapes_steps, 2)
+                if c2 is not None:
+                    out["other_shapes"].append(run_leg(c2, engine, synth, False, 0, headline=False, shape_leg=True)["json"])
+            except Exception as e:      # the headline stands
+                import traceback
+                traceback.print_exc()
+                out["other_shapes"].append({"error": f"{type(e).__name__}: {e}"[:400], "batch": sb, "fanout": sf})
 
     if rank == 0:
         try:
@@ -516,15 +518,23 @@ def run_leg(c, engine, synth, stripe, replica_memory, headline, bulk=False, shap
     return {"json": out}
 
 
-def shape_context(c, synth, batch, steps, warmup):
-    """The headline's context with another batch size: group size by the same rule, K = steps, seeds for exactly that run."""
+def shape_context(c, synth, batch, fanout, steps, warmup):
+    """The headline's context with another batch size / fan-out: group size by the same rule (halved while the lanes in flight would not
+    fit 0.7 of the free HBM), K = steps, seeds for exactly that run."""
     c2 = types.SimpleNamespace(**vars(c))
     c2.args = types.SimpleNamespace(**vars(c.args))
-    c2.args.steps, c2.args.warmup, c2.args.batch = steps, warmup, batch
-    c2.B = batch
+    c2.args.steps, c2.args.warmup, c2.args.batch, c2.args.fanout = steps, warmup, batch, ",".join(str(f) for f in fanout)
+    c2.B, c2.fanout, c2.H = batch, list(fanout), len(fanout)
     G = 1
     while G * 2 <= 512 and G * 2 * batch <= 524288:
         G *= 2
+    num_ids, per = batch, batch
+    for f in fanout:
+        per *= f
+        num_ids += per
+    lane_bytes = num_ids * 56 + per * 28 + (num_ids // (8 if len(fanout) <= 2 else 16)) * c.D * 4
+    while G > 1 and G * c.args.slots * lane_bytes > torch.cuda.mem_get_info(c.dev)[0] * 7 // 10:
+        G //= 2
     c2.G = G
     c2.n_warm, c2.n_timed = warmup * G, steps * G
     need = max((c2.n_warm + c2.n_timed + 2) * batch + batch, (c.args.presc_steps + 2) * batch)

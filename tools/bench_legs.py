@@ -200,7 +200,8 @@ def parse_args():
                          "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, N = 1 only; also skipped with --no-boundary)")
     ap.add_argument("--traffic-deadline", type=int, default=300, help="seconds each of those child processes may take")
     ap.add_argument("--no-other-shapes", action="store_true",
-                    help="skip the `other_shapes` leg (N = 1, B = 1024 only: B = 8000 [25,10] on the same tables, --other-shapes-steps timed steps, ~20 s)")
+                    help="skip the `other_shapes` legs (N = 1, the default shape only: B = 8000 at [25,10] and at [15,10,5] on the same tables, "
+                         "--other-shapes-steps timed steps each, ~25 s each)")
     ap.add_argument("--other-shapes-steps", type=int, default=5)
     ap.add_argument("--cold-leg", action="store_true", help="run roofline.cold / roofline.alone even with --no-boundary (they belong to the full default run)")
     ap.add_argument("--no-cold-leg", action="store_true",
