@@ -168,7 +168,7 @@ public:
         raw_batch_size_ = info->raw_batch_size;
         const int32_t eval_unit = 512;
         // (steps, per-GPU batch size) of an evaluation set: steps from its largest partition, sizes by ceil(n_i / steps)
-        auto spread = [gpus, eval_unit](const std::vector<int32_t>& count, std::vector<int32_t>& per_gpu) {
+        auto spread = [gpus](const std::vector<int32_t>& count, std::vector<int32_t>& per_gpu) {
             int32_t largest = 0;
             for (int32_t g = 0; g < gpus; g++) largest = std::max(largest, count[g]);
             const int32_t steps = (largest - 1) / eval_unit + 1;

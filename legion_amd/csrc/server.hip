@@ -543,7 +543,7 @@ public:
                 cache->FeatCacheLookup(desc, 1, INTRABATCH_CON * hop_num_ + 1, local_dev_id_, overflow_stream_, memorypool_->num_ids, true, 1);
                 HIP_CALL(hipStreamSynchronize(overflow_stream_));
                 off[1] = (char*)overflow_[p] - arena_.base;
-                *(volatile int32_t*)lp->err_host &= ~LG_ERR_FEATURE_ROWS;      // this batch is whole again; the lane's next batch starts clean
+                if (lp->err_host != nullptr) *(volatile int32_t*)lp->err_host &= ~LG_ERR_FEATURE_ROWS;      // this batch is whole again; the lane's next batch starts clean
                 overflowed = true;
                 overflow_batches_++;
                 if (overflow_batches_ == 1)
