@@ -87,6 +87,10 @@ void legion_graph_destroy(LegionGraphStorage* g);
  * the one sector it fetches anyway, and the gather no longer looks the row's cache slot up (a 128-byte line per row for four
  * bytes: SS/cache/cache.cu:180-215 does it with a hash find per row).  Results are unchanged.  Returns 1 when GPU dev has it. */
 int32_t legion_graph_column_slots(const LegionGraphStorage* g, int32_t dev);
+/* The cached CSR logical GPU dev holds after a fill (GraphStorage::GraphCache, SS/storage/graph_storage.cu:76-111; kernels
+ * SS/storage/graph_storage_impl.cuh:33-53): device pointers to int64 index[capacity + 1] and int32 dst[index[capacity]]; nulls before a
+ * fill.  Introspection: tests/test_gpu_ref_graph_cache.py compares them with what the reference's own kernels produce (oracle/_ref). */
+void legion_graph_cached_csr(const LegionGraphStorage* g, int32_t dev, const int64_t** index_out, const int32_t** dst_out);
 
 /* FeatureStorage: SS/storage/feature_storage.cu:18-90.  ids/labels are HOST arrays copied to
  * device `dev_id`; mode selects the training / validation / testing set. */

@@ -1052,6 +1052,16 @@ extern "C" int32_t legion_graph_column_slots(const LegionGraphStorage* g_, int32
     return (g && dev >= 0 && dev < g->GetPartitionCount() && g->GetCSRXMatrix(dev) != nullptr) ? 1 : 0;
 }
 
+// the cached CSR GPU dev holds after a fill (GraphStorage::GraphCache, SS/storage/graph_storage.cu:76-111): device pointers to
+// int64 index[capacity + 1] and int32 dst[index[capacity]], or nulls before any fill (introspection for the parity tests)
+extern "C" void legion_graph_cached_csr(const LegionGraphStorage* g_, int32_t dev, const int64_t** index_out, const int32_t** dst_out)
+{
+    const GraphStorage* g = reinterpret_cast<const GraphStorage*>(g_);
+    const bool ok = g && dev >= 0 && dev < g->GetPartitionCount();
+    if (index_out) *index_out = ok ? g->CachedCSRIndex(dev) : nullptr;
+    if (dst_out) *dst_out = ok ? g->CachedCSRDst(dev) : nullptr;
+}
+
 extern "C" void legion_graph_destroy(LegionGraphStorage* g_)
 {
     GraphStorage* g = reinterpret_cast<GraphStorage*>(g_);

@@ -177,6 +177,15 @@ class GraphStorage:
         """True when logical GPU dev_id samples from the {neighbour id, feature-cache slot} copy of the column array."""
         return bool(self._lib.legion_graph_column_slots(self.handle, int(dev_id)))
 
+    def cached_csr(self, dev_id, capacity):
+        """(index int64[capacity + 1], dst int32[index[capacity]]) of the CSR GPU dev_id caches after a fill, as device views."""
+        a, b = ctypes.c_void_p(), ctypes.c_void_p()
+        self._lib.legion_graph_cached_csr(self.handle, int(dev_id), ctypes.byref(a), ctypes.byref(b))
+        dev = _torch_device(dev_id)
+        index = device_view(a.value, (int(capacity) + 1,), torch.int64, dev)
+        n = int(index[-1].item()) if capacity >= 0 and a.value else 0
+        return index, device_view(b.value, (n,), torch.int32, dev)
+
     def close(self):
         if self.handle:
             self._lib.legion_graph_destroy(self.handle)

@@ -30,6 +30,7 @@ SIGNATURES = {
     "legion_graph_create": (c_p, [c_i32, c_i32, c_i64, c_p, c_p]),
     "legion_graph_destroy": (None, [c_p]),
     "legion_graph_column_slots": (c_i32, [c_p, c_i32]),
+    "legion_graph_cached_csr": (None, [c_p, c_i32, ctypes.POINTER(c_p), ctypes.POINTER(c_p)]),
     "legion_feature_create": (c_p, [c_i32, c_i32, c_i32, c_p]),
     "legion_feature_set_ids": (None, [c_p, c_i32, c_i32, c_p, c_p, c_i32]),
     "legion_feature_destroy": (None, [c_p]),

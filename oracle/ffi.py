@@ -58,8 +58,12 @@ class Steps(ctypes.Structure):
 _lib = None
 
 
+REF_GRAPH_CACHE = os.path.join(HERE, "_ref", "ref_graph_cache")     # the reference's own GraphCache kernels behind this repo's driver (Makefile target `ref`)
+
+
 def build():
     subprocess.check_call(["make", "-s", "-C", HERE])
+    subprocess.check_call(["make", "-s", "-C", HERE, "ref"])       # (a no-op where /root/reference does not exist: the GPU box uses the prebuilt binary)
     return LIB_PATH
 
 
