@@ -10,6 +10,10 @@
  * path and its CUDA sources cannot be built in this image (nvcc, libcu++
  * and a GPU are required), so the restatement as a whole is "parity unpinned" against the
  * reference.  What IS pinned:
+ *   - the topology cache's fill (lgo_fill_up's cached CSR) against the REFERENCE'S OWN KERNELS: the one file of the reference that
+ *     compiles here, sampling_server/src/storage/graph_storage_impl.cuh (GetNeighborCount, TopoFillUp), is built by hipcc from where
+ *     it lies into oracle/_ref/ref_graph_cache (oracle/Makefile target `ref`, oracle/ref_graph_cache_driver.hip) and run on the GPU by
+ *     tests/test_gpu_ref_graph_cache.py;
  *   - the random draw (thrust::minstd_rand + discard + uniform_int_distribution) against
  *     rocThrust's own host implementation (oracle/thrust_pin.cpp -> tests/golden/rng_thrust.json);
  *   - the stable descending hotness order against rocThrust's host sort_by_key semantics
