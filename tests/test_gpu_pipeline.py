@@ -307,6 +307,58 @@ def test_full_width_groups_against_the_oracle(hip, batch, fanout, group):
     gpu.close(); cpu.close()
 
 
+def test_regather_last_is_the_groups_own_last_gather(hip, col_slots):
+    """legion_pipeline_regather_last (bench.py's roofline.alone / roofline.cold): launching a group's last gather again leaves every
+    lane exactly as it was; after the last hop's ids of the lanes were replaced (and the carried cache slots rewritten to match) it
+    gathers the NEW ids' rows into the same positions -- hits from the cache, misses from the table -- and nothing else changes."""
+    from legion_amd import engine, synth
+    wl = Workload(scale=12, edge_factor=8, dim=24, n_seeds=900)
+    fanout, batch, group = [6, 3], 64, 5
+    gpu, cpu = GpuSide(wl, batch, fanout), CpuSide(wl, batch, fanout)
+    steps = (wl.sets[(0, 0)][0].size - 1) // batch
+    for it in range(steps):
+        gpu.run(0, it, 0, is_presc=True); cpu.run(0, it, 0, is_presc=True)
+    gpu.cache.candidate_selection(0, gpu.graph)
+    gpu.cache.set_capacity(400, 100)
+    gpu.cache.fill_up(gpu.feature, gpu.graph)
+    cpu.build_cache(0, capacity=(400, 100))
+    assert gpu.graph.column_slots(0) == col_slots
+    pipe = engine.Pipeline(gpu.graph, gpu.feature, gpu.cache, 0, batch, fanout, group, gpu.pools[0].num_ids, True, 2, weave=True)
+    sl = pipe.submit(0, 0)
+    pipe.wait(sl)
+    before = [engine.read_batch(pipe.pools[sl][lane]) for lane in range(group)]
+    ms = pipe.regather_last(sl, 3)
+    assert len(ms) == 3 and all(m > 0 for m in ms)
+    node_map = gpu.cache.array("node_map", 0)
+    H = len(fanout)
+    new_ids = []
+    for lane in range(group):
+        compare_batches(engine.read_batch(pipe.pools[sl][lane]), before[lane], f"regather, lane {lane}: ")
+        compare_batches(before[lane], cpu.run(0, lane, 0), f"lane {lane}: ")
+        pl = pipe.pools[sl][lane]
+        nc = before[lane]["node_counter"]
+        a, n = int(nc[9 + H - 1]), int(nc[9 + H] - nc[9 + H - 1])
+        ids = torch.from_numpy(np.random.RandomState(lane).permutation(wl.N)[:n].astype(np.int32)).cuda()
+        pl.buffer("sampled_ids")[a:a + n] = ids
+        if col_slots:
+            pl.buffer("node_slot")[a:a + n] = node_map[ids.long()]
+        new_ids.append((a, n, ids.cpu().numpy()))
+    pipe.regather_last(sl, 1)
+    hits = misses = 0
+    for lane in range(group):
+        a, n, ids = new_ids[lane]
+        got = engine.read_batch(pipe.pools[sl][lane])
+        assert np.array_equal(got["float_features"][a:a + n].view(np.uint32), wl.features[ids].view(np.uint32))      # the new ids' rows
+        assert np.array_equal(got["float_features"][:a].view(np.uint32), before[lane]["float_features"][:a].view(np.uint32))   # earlier hops' rows untouched
+        assert np.array_equal(got["agg_src_off"], before[lane]["agg_src_off"]) and np.array_equal(got["node_counter"], before[lane]["node_counter"])
+        slots = node_map[torch.from_numpy(ids).long().cuda()].cpu().numpy()
+        assert np.array_equal(pipe.pools[sl][lane].buffer("cache_search_buffer")[:n].cpu().numpy(), slots)
+        hits += int((slots >= 0).sum()); misses += int((slots < 0).sum())
+    assert hits > 0 and misses > 0
+    pipe.close()
+    gpu.close(); cpu.close()
+
+
 def test_lane_group_eager(hip, buckets):
     """legion_enqueue_group on caller-owned pools (no pipeline, no graph)."""
     from legion_amd import engine
