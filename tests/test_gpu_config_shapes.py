@@ -230,15 +230,23 @@ def test_config4_shape_d256_rows_pinned_spill_and_hbm_cache(hip):
     (256 GiB) does not fit beside the process; this runs the largest power of two that does with room to spare: 2^27 vertices, edge
     factor 8 (the same 2^30 edges), [15,10,5], B = 8000 -- a 128 GiB pinned table, 1 KB rows over PCIe on a miss, and every id-width
     property of the 2^28-vertex D = 128 case above (test_config4_shape_2pow28_vertices keeps the vertex count itself).  A box whose
-    control group is smaller drops one more power of two rather than risking the box."""
+    control group (or available memory) is smaller drops a power of two or two rather than risking the box."""
     limit = None
     try:
         txt = open("/sys/fs/cgroup/memory.max").read().strip()
         limit = None if txt == "max" else int(txt)
     except OSError:
         pass
-    scale = 27 if (limit is None or limit >= (220 << 30)) else 26
-    D, fanout, batch, group, ef = 256, [15, 10, 5], 8000, 4, 8 if scale == 27 else 16
+    avail = None
+    try:
+        for ln in open("/proc/meminfo"):
+            if ln.startswith("MemAvailable:"):
+                avail = int(ln.split()[1]) << 10
+    except OSError:
+        pass
+    room = min(x for x in (limit, avail, 1 << 62) if x is not None)      # what this process may pin without endangering the box
+    scale = 27 if room >= (220 << 30) else (26 if room >= (120 << 30) else 25)
+    D, fanout, batch, group, ef = 256, [15, 10, 5], 8000, 4, {27: 8, 26: 16, 25: 16}[scale]
     N = 1 << scale
     dev = torch.device("cuda:0")
     indptr, col = synth.rmat_csr_device(scale, ef, 20231, dev, scramble=True)
