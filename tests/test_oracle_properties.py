@@ -17,7 +17,9 @@ def graphs(draw):
             col.append(draw(st.integers(0, n - 1)))
         indptr.append(len(col))
     seeds = draw(st.lists(st.integers(0, n - 1), min_size=1, max_size=min(n, 10), unique=True))
-    fanout = draw(st.lists(st.integers(1, 6), min_size=1, max_size=3))
+    # one to SIX hops (the counter block holds no more, operator_impl.cu:67,81-82); deep lists get small fan-outs to bound the slots
+    hops = draw(st.integers(1, 6))
+    fanout = draw(st.lists(st.integers(1, 6 if hops <= 3 else 3), min_size=hops, max_size=hops))
     return np.array(indptr, dtype=np.int64), np.array(col, dtype=np.int32), seeds, fanout
 
 
