@@ -1,5 +1,5 @@
 """Seeded random shapes through the HIP path and the oracle side by side: odd vertex counts, rows of degree 0, hubs,
-duplicate-heavy adjacency, 1-4 hops, fan-outs 1..12 (also above every degree), batch sizes that do not divide the seed
+duplicate-heavy adjacency, 1-4 hops (1-6 in the hybrid-tier cases), fan-outs 1..12 (also above every degree), batch sizes that do not divide the seed
 set (clamped and empty last batches), feature widths that are not multiples of four, every mode -- once per form of the
 first-touch state.  Bit-exact or the test names the seed that failed."""
 import numpy as np
@@ -11,7 +11,7 @@ from tests.helpers import Workload, compare_batches
 pytestmark = pytest.mark.gpu
 
 
-def random_case(seed):
+def random_case(seed, max_hops=4):
     rng = np.random.RandomState(1000 + seed)
     N = int(rng.choice([37, 64, 257, 1000, 4099]))
     kind = seed % 4
@@ -31,7 +31,7 @@ def random_case(seed):
     if kind == 2 and col.size:                     # duplicate-heavy adjacency: half of all entries name ten vertices
         m = rng.rand(col.size) < 0.5
         col[m] = rng.randint(0, 10, int(m.sum()))
-    hops = int(rng.randint(1, 5))
+    hops = int(rng.randint(1, max_hops + 1))
     fanout = [int(rng.randint(1, 13)) for _ in range(hops)]
     while np.prod(fanout) > 600:                   # keep the oracle's run short
         fanout[int(np.argmax(fanout))] //= 2
@@ -93,6 +93,52 @@ def test_random_shapes_through_cache_and_pipeline(hip, buckets, seed):
             for lane in range(group):
                 got, want = engine.read_batch(pipe.pools[sl][lane]), cpu.run(0, g0 + lane, mode)
                 compare_batches(got, want, ctx + f"{arrangement} group {group} mode {mode} batch {g0 + lane}: ")
+    assert all(p.error() == 0 for row in pipe.pools for p in row)
+    pipe.close()
+    gpu.close(); cpu.close()
+
+
+@pytest.mark.parametrize("seed", range(14))
+def test_random_shapes_hybrid_tier_and_up_to_six_hops(hip, buckets, seed):
+    """Random shapes with one to SIX hops through the hybrid CPU-cache / GPU-cache tier (UnifiedCache::HybridInit, random capacities
+    incl. 0 and beyond N) -- or, every third seed, the clique cache -- and lane groups under hipGraph replay: the order, the map and
+    every batch against the oracle."""
+    from legion_amd import engine
+    from oracle import ffi
+    c = random_case(300 + seed, max_hops=6)
+    rng = np.random.RandomState(9000 + seed)
+    dim = max(c["dim"], 3)
+    wl = Workload(dim=dim, n_seeds=c["n_seeds"], n_valid=c["n_valid"], n_test=c["n_test"], indptr=c["indptr"], col=c["col"])
+    batch, fanout = c["batch"], c["fanout"]
+    gpu, cpu = GpuSide(wl, batch, fanout, cache_memory=200_000), CpuSide(wl, batch, fanout)
+    ctx = f"seed {seed} (N {wl.N}, E {wl.E}, fan-out {fanout}, batch {batch}, D {dim}, {buckets} buckets): "
+    steps = max((wl.sets[(0, 0)][0].size - 1) // batch, 1)
+    for it in range(steps):
+        compare_batches(gpu.run(0, it, 0, is_presc=True), cpu.run(0, it, 0, is_presc=True), ctx + f"presc {it}: ")
+    if seed % 3 == 2:
+        gpu.cache.candidate_selection(0, gpu.graph)
+        gpu.cache.cost_model(gpu.feature, gpu.graph, (0, 0), steps)
+        gpu.cache.fill_up(gpu.feature, gpu.graph)
+        oc = cpu.build_cache(0, cache_memory=200_000, train_step=steps)[0]
+    else:
+        cpu_cap = int(rng.choice([0, 5, wl.N // 7, wl.N // 2, 2 * wl.N]))
+        gpu_cap = int(rng.choice([0, 3, wl.N // 5, wl.N // 2, 2 * wl.N]))
+        gpu.cache.hybrid_init(gpu.feature, gpu.graph, cpu_cap, gpu_cap)
+        oc = ffi.OracleCache(wl.N, wl.D, 1, 0)
+        oc.hybrid_init(cpu.node_access[0], wl.features, cpu_cap, gpu_cap)
+        cpu.Kg, cpu.caches = 1, [oc]
+        ctx += f"hybrid cpu {cpu_cap} gpu {gpu_cap}: "
+    assert np.array_equal(gpu.cache.array("QF", 0).cpu().numpy(), oc.arr("QF", np.int32)), ctx
+    assert np.array_equal(gpu.cache.array("node_map", 0).cpu().numpy(), oc.arr("node_map", np.int32)), ctx
+    group, slots = int(rng.randint(1, 5)), int(rng.randint(1, 4))
+    pipe = engine.Pipeline(gpu.graph, gpu.feature, gpu.cache, 0, batch, fanout, group, gpu.pools[0].num_ids, True, slots, weave=bool(seed % 2))
+    for mode in (0, 1, 2):
+        n_batches = (wl.sets[(0, mode)][0].size + batch - 1) // batch + 1
+        for g0 in range(0, n_batches, group):
+            sl = pipe.submit(g0, mode)
+            pipe.wait(sl)
+            for lane in range(group):
+                compare_batches(engine.read_batch(pipe.pools[sl][lane]), cpu.run(0, g0 + lane, mode), ctx + f"mode {mode} batch {g0 + lane}: ")
     assert all(p.error() == 0 for row in pipe.pools for p in row)
     pipe.close()
     gpu.close(); cpu.close()
