@@ -91,6 +91,7 @@ def main():
     c.D = D = args.dim
     c.B = B = args.batch
     c.t_setup = time.time()
+    c.one_line = one_line
 
     # ---- workload, resident in HBM --------------------------------------------------------------
     if args.gather_rows > 0:
@@ -221,6 +222,18 @@ def main():
         os._exit(0)
 
 
+def fail_as_requested(how):
+    """--fail-extra-leg: end (or stall) this process the way a leg behind the headline might."""
+    if how == "raise":
+        raise RuntimeError("requested by --fail-extra-leg")
+    if how == "exit":
+        ctypes.CDLL(None).exit(3)
+    if how == "sigterm":
+        os.kill(os.getpid(), signal.SIGTERM)
+    while True:
+        ctypes.CDLL(None).sleep(5)      # (a main thread that never comes back from a C call)
+
+
 def run_leg(c, engine, synth, stripe, replica_memory, headline, bulk=False, shape_leg=False):
     """One cache layout over the resident workload: objects -> PreSC -> hotness all-reduce -> cost model -> fills -> pipeline ->
     counting pass -> warm-up -> timed regions -> eager pass with HIP events around the gathers (-> headline: the cold-row regather).
@@ -228,14 +241,7 @@ def run_leg(c, engine, synth, stripe, replica_memory, headline, bulk=False, shap
     batch shape of the same workload on one GPU (`other_shapes`), reported in the extra legs' short form."""
     args, world, rank, dev, use_dist = c.args, c.world, c.rank, c.dev, c.use_dist
     if not headline and not shape_leg and args.fail_extra_leg and rank == 0:        # (tests of OneLine)
-        if args.fail_extra_leg == "raise":
-            raise RuntimeError("requested by --fail-extra-leg")
-        if args.fail_extra_leg == "exit":
-            ctypes.CDLL(None).exit(3)
-        if args.fail_extra_leg == "sigterm":
-            os.kill(os.getpid(), signal.SIGTERM)
-        while True:
-            ctypes.CDLL(None).sleep(5)      # (a main thread that never comes back from a C call)
+        fail_as_requested(args.fail_extra_leg)
     fanout, H, N, D, B, G = c.fanout, c.H, c.N, c.D, c.B, c.G
     n_timed, mine = c.n_timed, c.mine
     t_leg = time.time()
@@ -353,15 +359,6 @@ def run_leg(c, engine, synth, stripe, replica_memory, headline, bulk=False, shap
     achieved = rows_last * bytes_per_row / t_last / 1e9 if t_last > 0 else 0.0
     t_all_gathers = sum(v[0] for v in prof.values()) * 1e-3
     payload_gbps = float(rows.sum() * D * 4) / t_all_gathers / 1e9 if t_all_gathers > 0 else 0.0
-    # the same launch alone and over rows that never repeat (rank 0 of a one-GPU run: the figure is about the kernel, not the job)
-    cold = None
-    if (headline or shape_leg) and world == 1 and not bulk and not args.no_cold_leg and (not args.no_boundary or args.cold_leg):
-        try:
-            cold = legs.cold_regather(c, pipe, node_map, bytes_per_row)
-        except Exception as e:      # a diagnostic: never the reason a headline is lost
-            cold = {"error": repr(e)[:300]}
-    pipe.close()
-
     tot_edges = torch.tensor([float(edges.sum())], dtype=torch.float64, device=dev)
     gather_bytes_t = torch.tensor([float(rows.sum() * D * 4)], dtype=torch.float64, device=dev)
     if use_dist:
@@ -405,10 +402,6 @@ def run_leg(c, engine, synth, stripe, replica_memory, headline, bulk=False, shap
                                          "group is gathered once per batch; FETCH_SIZE counts a repeat the memory-side cache serves as a "
                                          "fabric read all the same (MI355X_MICROARCH.md), so `frac` is a fabric-side figure and "
                                          "`cold.frac` the HBM-only one" % G}
-        if cold is not None:
-            roof["cold"] = cold.get("cold") if "error" not in cold else None
-            roof["alone"] = cold.get("alone")
-            roof["cold_note"] = cold.get("note") or cold.get("error")
         timed_j = {"steps": args.steps, "repeats": timed.repeats, "median_s": elapsed_max,
                    "min_s": float(timed.region_s.min()), "max_s": float(timed.region_s.max()), "total_timed_s": float(timed.region_s.sum()),
                    "note": "exactly K steps per region between barrier+synchronize brackets; region repeated over the "
@@ -508,6 +501,20 @@ def run_leg(c, engine, synth, stripe, replica_memory, headline, bulk=False, shap
                                     "note": "missed rows x D x 4 bytes / HIP-event time of all gather launches (hits are served from "
                                             "HBM inside the same launches); PCIe Gen5 x16 = 64 GB/s per direction; topology misses "
                                             "(4-byte column reads) cross the same link during the sampler kernels"}
+    # ---- the same launch alone and over rows that never repeat (a one-GPU run: the figure is about the kernel, not the job).  The
+    #      headline's line exists by now: from here on it goes out even if an optional leg ends the process (a native exit() of the
+    #      library, SIGTERM, a hang) -- this leg, the other shapes, the boundary, the CPU baseline and the traffic children follow. ----
+    if headline and world == 1 and rank == 0 and getattr(c, "one_line", None) is not None:
+        c.one_line.arm(out, args.post_legs_deadline)
+    if (headline or shape_leg) and world == 1 and not bulk and not args.no_cold_leg and (not args.no_boundary or args.cold_leg):
+        try:
+            if headline and args.fail_extra_leg:             # (tests of the guard at N = 1: the first leg behind the headline fails this way)
+                fail_as_requested(args.fail_extra_leg)
+            cold = legs.cold_regather(c, pipe, node_map, bytes_per_row)
+            out["roofline"].update({"cold": cold.get("cold"), "alone": cold.get("alone"), "cold_note": cold.get("note")})
+        except Exception as e:      # a diagnostic: never the reason a headline is lost
+            out["roofline"].update({"cold": None, "alone": None, "cold_note": repr(e)[:300]})
+    pipe.close()
     # this leg's objects go before the next leg builds its own (other logical-GPU numbering, other cache layout)
     cache.close()
     feature.close()

@@ -117,6 +117,23 @@ def test_headline_line_survives_a_failing_extra_leg(hip, how):
     assert "extra_legs_error" in d and "striped" not in d
 
 
+@pytest.mark.parametrize("how", ["exit", "sigterm", "hang", "raise"])
+def test_headline_line_survives_a_failing_leg_at_n1(hip, how):
+    """N = 1 (round 6): the legs behind the headline leg -- cold regather, other shapes, boundary, CPU baseline, traffic children -- run
+    with the guard armed: a native exit(), SIGTERM, a hang still print the headline's line (with a note); a Python error inside the
+    cold leg is caught where it happens and costs only that leg's fields."""
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--cold-leg", "--fail-extra-leg", how, "--post-legs-deadline", "8"] + SMALL
+    res = subprocess.run(cmd, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, (res.stdout[-2000:], res.stderr[-2000:])
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 1 and d["value"] > 0 and d["roofline"]["frac"] > 0 and d["roofline"]["unique_row_frac"] > 0
+    if how == "raise":
+        assert d["roofline"]["cold"] is None and "requested by --fail-extra-leg" in d["roofline"]["cold_note"] and "extra_legs_error" not in d
+    else:
+        assert "extra_legs_error" in d and "cold" not in d["roofline"]
+
+
 def test_rccl_calls_execute_at_n1(hip):
     """bench.py --force-dist: torch.distributed over the nccl backend (= RCCL) with world size 1; the hotness all-reduce,
     the MIN/MAX reductions and the barriers all go through RCCL once."""

@@ -240,6 +240,9 @@ def parse_args():
                     help="N > 1: seconds the extra (striped) legs may take together before rank 0 prints the headline line alone and exits "
                          "(budget of an N = 8 run against a 600 s limit: headline leg <= ~150 s even when the library's communicator never forms "
                          "-- set-up ~60 s + --collective-deadline 90 s -- plus these 330 s)")
+    ap.add_argument("--post-legs-deadline", type=int, default=420,
+                    help="N = 1: seconds the legs behind the headline leg (cold regather, other shapes, boundary, CPU baseline, traffic children; "
+                         "~170 s when nothing hangs) may take together before the headline line goes out alone")
     ap.add_argument("--fail-extra-leg", type=str, default="", choices=["", "raise", "exit", "sigterm", "hang"],
                     help="testing: make rank 0 fail this way when the first extra leg starts (the headline line must still go out)")
     ap.add_argument("--force-device", type=int, default=-1,
