@@ -163,10 +163,12 @@ def main():
             out_striped = run_leg(c, engine, synth, True, 0, headline=False)
             if rank == 0:
                 out["striped"] = out_striped["json"]
+                one_line.refresh()
             if args.striped_replica_memory > 0:
                 out_rep = run_leg(c, engine, synth, True, args.striped_replica_memory, headline=False)
                 if rank == 0:
                     out["striped_replica"] = out_rep["json"]
+                    one_line.refresh()
             if not args.no_bulk_leg:
                 out_bulk = run_leg(c, engine, synth, True, 0, headline=False, bulk=True)
                 if rank == 0:
@@ -192,6 +194,7 @@ def main():
                 c2 = shape_context(c, synth, sb, sf, args.other_shapes_steps, 2)
                 if c2 is not None:
                     out["other_shapes"].append(run_leg(c2, engine, synth, False, 0, headline=False, shape_leg=True)["json"])
+                    one_line.refresh()
             except Exception as e:      # the headline stands
                 import traceback
                 traceback.print_exc()
@@ -201,9 +204,11 @@ def main():
         try:
             if world == 1 and not args.no_boundary and args.placement == "hbm":
                 out.update(legs.boundary_leg(args, c.fanout))
+                one_line.refresh()
             if args.cpu_seconds > 0 and world == 1:      # reported at N = 1 only
                 out["cpu_baseline"] = cpu_baseline(indptr, col, c.mine, N, B, c.fanout, c.n_warm, args.cpu_seconds,
                                                    features if args.placement == "hbm" else None)
+                one_line.refresh()
             if world == 1 and not args.no_boundary and not args.no_traffic_leg and args.placement == "hbm":
                 legs.measured_traffic(args, out["roofline"], c.G)
         except Exception as e:      # (an armed exit hook must not outlive the interpreter: see above)
@@ -217,8 +222,8 @@ def main():
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
-    if one_line.line is not None:     # armed: the libc exit hook is a Python callable and must not outlive the interpreter
-        sys.stderr.flush()
+    if one_line.needs_hard_exit:      # armed with the ctypes stand-in (no C compiler for tools/exit_line.c): a Python callable
+        sys.stderr.flush()            # registered with libc must not be called after the interpreter is gone
         os._exit(0)
 
 
@@ -514,6 +519,8 @@ def run_leg(c, engine, synth, stripe, replica_memory, headline, bulk=False, shap
             out["roofline"].update({"cold": cold.get("cold"), "alone": cold.get("alone"), "cold_note": cold.get("note")})
         except Exception as e:      # a diagnostic: never the reason a headline is lost
             out["roofline"].update({"cold": None, "alone": None, "cold_note": repr(e)[:300]})
+        if headline and getattr(c, "one_line", None) is not None:
+            c.one_line.refresh()
     pipe.close()
     # this leg's objects go before the next leg builds its own (other logical-GPU numbering, other cache layout)
     cache.close()

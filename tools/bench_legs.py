@@ -23,22 +23,20 @@ HBM_ACHIEVABLE_GBPS = 6290.0       # MI355X_MICROARCH.md: what a float4 streamin
 
 
 class OneLine:
-    """The ONE JSON line of rank 0, written exactly once.  At N > 1 the extra legs (striped caches over peer pointers) run after
-    the headline leg and have never met more than one physical GPU before the driver's SCALE run: whatever ends this process
-    while they run -- a Python error (caught by the caller), a native exit() of the library (libc atexit hook), SIGTERM from
-    the launcher after another rank died (wake-up fd + watcher thread: works while the main thread is blocked inside a HIP or
-    RCCL call), or nothing at all for `deadline_s` seconds (a hang) -- the headline leg's line, already measured, still goes
-    out, with a note on what happened."""
+    """The ONE JSON line of rank 0, written exactly once.  The legs behind the headline leg (N > 1: striped caches over peer pointers,
+    never run on more than one physical GPU before the driver's SCALE run; N = 1: cold regather, other shapes, boundary, CPU baseline,
+    traffic children) run with the guard ARMED: whatever ends this process while they run -- a Python error (caught by the caller), a
+    native exit() of the library (a C atexit handler in tools/exit_line.c holding the serialised line), SIGTERM from the launcher
+    (wake-up fd + watcher thread: works while the main thread is blocked inside a HIP or RCCL call), or nothing at all for
+    `deadline_s` seconds (a hang) -- the headline leg's line, already measured, still goes out, with a note on what happened."""
 
     def __init__(self, fd):
         self.fd, self.line, self.done, self.lock = fd, None, False, threading.Lock()
-        self._hook = None
+        self._hook = None                   # the ctypes fallback (no C compiler at hand): then the process must leave through os._exit
+        self._native = None                 # tools/_build/libexit_line.so
+        self.needs_hard_exit = False
 
-    def emit(self, obj):
-        with self.lock:
-            if self.done:
-                return
-            self.done = True
+    def _serialise(self, obj):
         text = None
         for _ in range(5):          # (the fallback may serialise the object while the main thread adds a leg to it)
             try:
@@ -47,12 +45,46 @@ class OneLine:
             except RuntimeError:
                 time.sleep(0.01)
         if text is None:
-            text = json.dumps({k: v for k, v in list(obj.items()) if k not in ("striped", "striped_replica", "striped_bulk")})
-        os.write(self.fd, (text + "\n").encode())
+            text = json.dumps({k: v for k, v in list(obj.items()) if k not in ("striped", "striped_replica", "striped_bulk", "other_shapes")})
+        return text
+
+    def emit(self, obj):
+        with self.lock:
+            if self.done:
+                return
+            self.done = True
+        if self._native is not None:
+            self._native.exit_line_clear()
+        os.write(self.fd, (self._serialise(obj) + "\n").encode())
+
+    def refresh(self):
+        """After a leg added its fields to the armed object: the line the C exit handler holds follows."""
+        if self._native is not None and self.line is not None and not self.done:
+            note = dict(self.line)
+            note["extra_legs_error"] = "the process exited inside a leg behind the headline leg (native exit)"
+            text = (self._serialise(note) + "\n").encode()
+            self._native.exit_line_set(self.fd, text, len(text))
+
+    def _load_native(self):
+        src = os.path.join(ROOT, "tools", "exit_line.c")
+        lib = os.path.join(ROOT, "tools", "_build", "libexit_line.so")
+        try:
+            if not os.path.exists(lib) or os.path.getmtime(lib) < os.path.getmtime(src):
+                os.makedirs(os.path.dirname(lib), exist_ok=True)
+                tmp = lib + ".%d" % os.getpid()
+                subprocess.check_call(["gcc", "-O2", "-shared", "-fPIC", src, "-o", tmp], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+                os.replace(tmp, lib)
+            L = ctypes.CDLL(lib)
+            L.exit_line_set.argtypes = [ctypes.c_int, ctypes.c_char_p, ctypes.c_size_t]
+            L.exit_line_set.restype = None
+            L.exit_line_clear.restype = None
+            return L
+        except Exception:       # noqa: BLE001 -- no compiler, read-only tree ...: the ctypes hook below stands in
+            return None
 
     def arm(self, headline_obj, deadline_s=900):
         """From here on a dying -- or, after `deadline_s`, a hung -- process still prints `headline_obj` -- the object itself, not a
-        copy: whatever extra legs have been added to it by then go out with it."""
+        copy: whatever extra legs have been added to it by then go out with it (call refresh() after each)."""
         self.line = headline_obj
 
         def fallback(why):
@@ -60,9 +92,15 @@ class OneLine:
                 self.line["extra_legs_error"] = why
                 self.emit(self.line)
 
-        # (glibc exports __cxa_atexit; plain atexit lives in its static part)
-        self._hook = ctypes.CFUNCTYPE(None, ctypes.c_void_p)(lambda _: fallback("the process exited inside an extra leg (native exit)"))
-        getattr(ctypes.CDLL(None), "__cxa_atexit")(self._hook, None, None)
+        self._native = self._load_native()
+        if self._native is not None:
+            self.refresh()
+        else:
+            # a Python callable registered with libc (glibc exports __cxa_atexit): it would also be called after the interpreter is
+            # gone on a normal exit, so the caller must leave through os._exit() once it has printed the line
+            self._hook = ctypes.CFUNCTYPE(None, ctypes.c_void_p)(lambda _: fallback("the process exited inside an extra leg (native exit)"))
+            getattr(ctypes.CDLL(None), "__cxa_atexit")(self._hook, None, None)
+            self.needs_hard_exit = True
         rfd, wfd = os.pipe()
         os.set_blocking(wfd, False)
         signal.set_wakeup_fd(wfd, warn_on_full_buffer=False)
@@ -71,8 +109,8 @@ class OneLine:
         def watch():
             import select
             got, _, _ = select.select([rfd], [], [], deadline_s)
-            fallback("SIGTERM while an extra leg was running (another rank failed?)" if got else
-                     "the extra legs did not finish within %d s (hung peer load or collective?)" % deadline_s)
+            fallback("SIGTERM while a leg behind the headline leg was running (another rank failed? a time limit?)" if got else
+                     "the legs behind the headline leg did not finish within %d s (hung peer load, collective or child process?)" % deadline_s)
             os._exit(1)
 
         threading.Thread(target=watch, daemon=True).start()
