@@ -446,8 +446,9 @@ typedef struct LegionTuning {
     int32_t runner_spin_us;      /* LEGION_RUNNER_SPIN_US  (-1 auto): how long the Runner polls (a trainer's semaphore, a group's completion) before it
                                     blocks.  auto: 20 us when batches are handed over as views (a group completes every few ms: the host
                                     sleeps in between), polling only with the gather hand-over (per-batch latency is the rate there) */
-    int32_t runner_overflow;     /* LEGION_RUNNER_OVERFLOW (1): views hand-over: a batch with more rows than its lane's feature buffer (1.2 x the PreSC
-                                    maximum) is handed over whole from one of two num_ids-row overflow buffers; 0 = no such buffers: the server stops there */
+    int32_t runner_overflow;     /* LEGION_RUNNER_OVERFLOW (1): a batch with more rows than 1.2 x the PreSC maximum (the lanes' feature buffers) still goes
+                                    out whole: views from one of two num_ids-row overflow buffers inside the arena, the other hand-overs into pipe-slot
+                                    buffers of num_ids rows; 0 = the rule everywhere: a views server stops there, the slab path truncates with a warning */
     int32_t runner_stats;        /* LEGION_RUNNER_STATS    (0): print where a hand-over's time went at Finalize */
     int32_t shm_mirror;          /* LEGION_NO_SHM_MIRROR unset -> 1: counters also go to a host-visible mirror (no D2H copy per batch) */
     /* -- set-up -------------------------------------------------------------------------------------------------------------- */

@@ -426,10 +426,22 @@ public:
         num_ids = (int32_t)scaled;
         if (num_ids < 1) num_ids = 1;
         IPCEnv* env = (IPCEnv*)(params->env);
-        env->InitializeFeaturesBuffer(0, num_ids, float_feature_len_, local_dev_id_, interbatch_concurrency_);
+        // The 1.2 x rule sizes the LANES (hundreds of them).  The two pipe-slot buffers -- what a trainer end that does not take views
+        // reads its rows from, and what the operator-by-operator Runner gathers into -- take the worst case of a batch, num_ids rows,
+        // whenever the pair costs less than a tenth of the free HBM: no batch is ever truncated there (the reference sizes them by the
+        // rule and overruns, server.cu:277).  LegionTuning.runner_overflow = 0 keeps the rule for them too.
+        lane_rule_rows_ = num_ids;
+        int64_t slot_rows = num_ids;
+        {
+            size_t free_b = 0, total_b = 0;
+            HIP_CALL(hipMemGetInfo(&free_b, &total_b));
+            const int64_t worst_bytes = (int64_t)memorypool_->num_ids * float_feature_len_ * (int64_t)sizeof(float);
+            if (lg::tuning().runner_overflow != 0 && (int64_t)interbatch_concurrency_ * worst_bytes <= (int64_t)(free_b / 10)) slot_rows = memorypool_->num_ids;
+        }
+        env->InitializeFeaturesBuffer(0, (int32_t)slot_rows, float_feature_len_, local_dev_id_, interbatch_concurrency_);
         for (int i = 0; i < interbatch_concurrency_; i++)
             memorypool_->SetFloatFeatures(env->GetFloatFeatures(local_dev_id_, i), i);
-        memorypool_->feature_rows = num_ids;
+        memorypool_->feature_rows = slot_rows;
         // from here on every batch's counters are also written to the slab's host-visible mirror (lane-group path)
         if (use_groups_ && env->GetCounterMirror(local_dev_id_, 0) != nullptr) env->PublishMirror();
     }
@@ -656,12 +668,16 @@ private:
     // as_view: the batch is about to be handed over as views of its lane
     void ReportErrors(MemoryPool* mp, bool as_view = false)
     {
-        const int32_t bits = mp->ErrorBits() & ~reported_;
+        int32_t bits = mp->ErrorBits() & ~reported_;
+        // a lane's own gather may have stopped at the end of the lane's (1.2 x rule) buffer although the batch then went out whole
+        // through a pipe slot that holds the worst case: not an event for that hand-over
+        if (!as_view && mp != memorypool_ && memorypool_->feature_rows >= memorypool_->num_ids) bits &= ~LG_ERR_FEATURE_ROWS;
         if (bits == 0) return;
         reported_ |= bits;
         if (bits & LG_ERR_FEATURE_ROWS)
             std::cout << (as_view ? "ERROR" : "WARNING") << " (gpu " << local_dev_id_ << "): a batch has more rows than the feature buffer ("
-                      << memorypool_->feature_rows << " rows = 1.2 x the PreSC maximum); its tail rows were not gathered\n";
+                      << (as_view ? (int64_t)lane_feature_rows_ : memorypool_->feature_rows) << " rows"
+                      << (as_view || memorypool_->feature_rows < memorypool_->num_ids ? " = 1.2 x the PreSC maximum" : "") << "); its tail rows were not gathered\n";
         if (bits & LG_ERR_TABLE_FULL) std::cout << "ERROR (gpu " << local_dev_id_ << "): a de-duplication bucket fits no LDS table\n";
         if (bits & LG_ERR_CHAIN) std::cout << "ERROR (gpu " << local_dev_id_ << "): unresolved first-touch chain\n";
         std::cout << std::flush;
@@ -716,7 +732,7 @@ private:
         max_step_ = env->GetMaxStep();
         std::vector<int32_t> fanout(params->fanout.begin(), params->fanout.end());
         const LegionTuning tune = lg::tuning();
-        const int64_t feature_rows = std::max<int64_t>(1, std::min<int64_t>(memorypool_->feature_rows, memorypool_->num_ids));
+        const int64_t feature_rows = std::max<int64_t>(1, std::min<int64_t>(lane_rule_rows_, memorypool_->num_ids));     // the lanes: 1.2 x the PreSC maximum
         // groups as large as bench.py's (524288 / B rounded down to a power of two, at most 512: the launch tails and the
         // per-kernel floors are paid once per group), never larger than the schedule can fill, halved while the lanes of
         // the groups in flight would take more than 0.6 of the HBM that is free now (tables and caches are in place).
@@ -938,6 +954,7 @@ private:
     float* overflow_[INTERBATCH_CON] = {};                 // per pipe slot: num_ids rows inside the arena, for a batch that outgrew its lane's buffer
     hipStream_t overflow_stream_ = nullptr;
     int32_t lane_feature_rows_ = 0;
+    int32_t lane_rule_rows_ = 1;                           // 1.2 x the PreSC maximum (scaled by the largest batch of any mode): what a lane's feature buffer holds
     int64_t overflow_batches_ = 0;
     lg::DeliverParams deliver_[INTERBATCH_CON] = {};
     lg::DeliverParams* d_deliver_ = nullptr;
