@@ -248,6 +248,7 @@ def run_leg(c, engine, synth, stripe, replica_memory, headline, bulk=False, shap
     if not headline and not shape_leg and args.fail_extra_leg and rank == 0:        # (tests of OneLine)
         fail_as_requested(args.fail_extra_leg)
     fanout, H, N, D, B, G = c.fanout, c.H, c.N, c.D, c.B, c.G
+    hy_cpu = hy_gpu = 0
     n_timed, mine = c.n_timed, c.mine
     t_leg = time.time()
     P = world if stripe else 1              # logical GPUs the objects know about
@@ -378,134 +379,8 @@ def run_leg(c, engine, synth, stripe, replica_memory, headline, bulk=False, shap
 
     out = None
     if rank == 0:
-        layout = (f"seed-sharded x{world}, replicated graph+features, one clique of {world}: caches striped over the ranks, peer reads "
-                  f"over xGMI (cache_agg_mode {int(np.log2(world))})" + (f", hot-row replica of {replica_memory} bytes per GPU" if replica_memory else "")
-                  if stripe else f"seed-sharded x{world}, replicated graph+features, cache_agg_mode 0")
-        roof = {"bound": "hbm", "kernel": "lg::gather_kernel<..., LASTOP = true> (hop-%d gather, op %d: the instance launched for a batch's last op)" % (H, last_op),
-                "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBPS,
-                "traffic": None, "traffic_unit": "bytes per launch", "traffic_source": None,
-                "traffic_committed": traffic_committed, "traffic_committed_source": traffic_committed_src,
-                "traffic_is": "`traffic` = HBM bytes per launch from FETCH_SIZE + WRITE_SIZE collected by child processes of THIS run (N = 1, "
-                              "the default command; null where that leg did not run); `traffic_committed` = the committed profile's figure for "
-                              "this configuration rescaled by this run's rows",
-                "rocprofv3_avg_launch_us": rocprof_us, "rocprofv3_source": rocprof_src,
-                "algorithmic_bytes_per_launch": rows_last / max(n_last, 1) * bytes_per_row,
-                "bytes_per_row": bytes_per_row, "rows_per_launch": rows_last / max(n_last, 1),
-                "launches": n_last, "avg_launch_us": t_last / max(n_last, 1) * 1e6,
-                "measured": "HIP events on the launch stream around each hop-%d gather launch over the same %d "
-                            "steps, %d batches per launch, eager launches (wall clock of that pass: ms_per_step %.4f; "
-                            "hipGraph replay, timed region: %.4f)"
-                            % (H, args.steps, G, elapsed_profiled / args.steps * 1e3, elapsed_max / args.steps * 1e3)}
-        if counted.unique is not None:
-            u = counted.unique
-            roof["unique_row_frac"] = u["unique_rows"] / max(u["rows"], 1)
-            roof["row_reuse"] = {"rows": u["rows"], "unique_rows": u["unique_rows"], "rows_gathered_once": u["rows_gathered_once"],
-                                 "repeat_rows": u["repeat_rows"], "unique_rows_bytes": u["unique_rows"] * D * 4,
-                                 "infinity_cache_bytes": legs.INFINITY_CACHE_BYTES,
-                                 "note": "the last hop's rows of ONE launch group (%d mini-batches): a vertex new to several batches of the "
-                                         "group is gathered once per batch; FETCH_SIZE counts a repeat the memory-side cache serves as a "
-                                         "fabric read all the same (MI355X_MICROARCH.md), so `frac` is a fabric-side figure and "
-                                         "`cold.frac` the HBM-only one" % G}
-        timed_j = {"steps": args.steps, "repeats": timed.repeats, "median_s": elapsed_max,
-                   "min_s": float(timed.region_s.min()), "max_s": float(timed.region_s.max()), "total_timed_s": float(timed.region_s.sum()),
-                   "note": "exactly K steps per region between barrier+synchronize brackets; region repeated over the "
-                           "same batches until --min-seconds; per repeat the max over ranks; value uses the median"}
-        if not headline:
-            out = {"value": float(tot_edges.item()) / elapsed_max, "unit": "edges/s", "ms_per_step": elapsed_max / args.steps * 1e3,
-                   "parallelism": layout, "timed_region": timed_j, "roofline": roof,
-                   "feature_gather_GBps": payload_gbps, "feature_cache_rows": cache.node_capacity(d),
-                   "topology_cache_vertices": cache.edge_capacity(d), "hot_row_replica_rows": cache.replica_rows(d),
-                   "collective": collective, "per_rank": per_rank, "setup_seconds": setup_s,
-                   "xgmi_ingest_peak_GBps_per_gpu": 7 * 153.0 / 2,
-                   "note": "same workload, same seed batches, same K steps as the headline; the feature and topology caches striped over "
-                           "one clique of all ranks (hotness rank t on GPU t % N), remote rows and adjacency read with direct peer loads "
-                           "over xGMI; per_rank[].rows_from_* were counted by the gather itself in an untimed pass over the timed batches, "
-                           "xgmi_* are deltas of the driver's cumulative gpu_metrics counters over the timed regions"}
-            if bulk:
-                out["peer_gather"] = "bulk"
-                out["note"] = ("same striped clique as `striped`, but the rows of other members' stripes are listed per owner and PUSHED by the "
-                               "owners (LegionTuning.peer_gather = bulk: whole rows as coalesced posted stores over xGMI instead of scattered "
-                               "512-1024-byte load round trips); eager launches, two host barriers per launch group (per_rank[].bulk has the "
-                               "phase clocks): compare its xGMI GB/s and ms_per_step with `striped`, minus the barrier time")
-            if shape_leg:
-                for k in ("collective", "per_rank", "xgmi_ingest_peak_GBps_per_gpu", "hot_row_replica_rows"):
-                    out.pop(k, None)
-                out.update({"steps": args.steps, "warmup": c.n_warm // G, "batches_per_step": G,
-                            "workload": f"{c.graph_name}, float32[N x {D}] features, batch {B}, fanout {fanout}, all tables resident in HBM",
-                            "sampling_only_edges_per_sec": float(edges.sum()) / t_sampling,
-                            "edges_per_batch": float(edges.mean()), "rows_per_batch": float(rows.sum(axis=1).mean()),
-                            "note": "another batch shape of the headline's graph and feature table, same code path, same brackets (K steps per "
-                                    "region, median region), in the same process right after the headline leg; not `value`"})
-        else:
-            out = {
-                "metric": "sampled_edges_per_sec",
-                "value": float(tot_edges.item()) / elapsed_max,
-                "unit": "edges/s",
-                "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-                "ms_per_step": elapsed_max / args.steps * 1e3,
-                "batches_per_step": G, "ms_per_batch": elapsed_max / n_timed * 1e3,
-                "timed_region": timed_j,
-                "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-                "dtype": "int32+f32(copy)", "data": "synthetic",
-                "config": {"workload": f"{c.graph_name}, "
-                                       f"float32[N x {D}] features, batch {B}, fanout {fanout}, " +
-                                       ("all tables resident in HBM" if args.placement == "hbm" else
-                                        "full CSR + full feature table in mapped pinned host memory (read over PCIe on a miss), "
-                                        "hotness-ranked feature/topology caches in HBM")
-                                       + (", vertex labels scrambled" if args.scramble else ""),
-                           "parallelism": layout,
-                           "batches_per_launch_group": G, "groups_in_flight": args.slots,
-                           "lane_arrays": {True: "one arena of shuffled 2 MB physical chunks (LegionTuning.arena_scatter_mb)", "plain": "one plain arena", False: "separate allocations"}[args.lane_arena], "epoch_batches": c.epoch_batches,
-                           "streams": "weave: head of group k+1 on a second stream under the heavy kernels of group k" if weave else "one",
-                           "epochs_wrap": bool(c.wrap), "hipgraph": not args.no_graph,
-                           "cache_memory_bytes": args.cache_memory,
-                           "feature_cache_rows": cache.node_capacity(d), "topology_cache_vertices": cache.edge_capacity(d),
-                           "presc_batches": train_step, "presc_topology_transactions": topo_tx,
-                           "presc_pcie_transactions_gpu_metrics": pcie_tx, "presc_xgmi_transactions_gpu_metrics": xgmi_tx,
-                           "link_counters": args.link_counters,
-                           "cost_model_counters": list(counters),
-                           "hot_row_replica_rows": cache.replica_rows(d)},
-                "feature_gather_GBps": payload_gbps * 1.0,
-                "feature_gather_GBps_note": "payload bytes read (rows*D*4) / HIP-event time of all gather launches, rank 0",
-                "sampling_only": {"edges_per_sec": float(edges.sum()) / t_sampling, "algorithmic_GBps": samp_bytes / t_sampling / 1e9,
-                                  "frac_of_hbm_peak": samp_bytes / t_sampling / 1e9 / HBM_PEAK_GBPS,
-                                  "note": "rank 0; time = timed region minus the HIP-event time of all gather launches (with the weave "
-                                          "arrangement the head of the next group runs hidden under this group's heavy kernels, so this is the "
-                                          "sampler time that is NOT hidden); the sampling kernel is bound by the part's rate of random 128-byte requests, "
-                                          "the de-duplication and compaction by their dependent chains: DESIGN.md section 4.2"},
-                "edges_per_step": float(edges.sum()) / args.steps, "rows_per_step": float(rows.sum()) / args.steps,
-                "edges_per_batch": float(edges.mean()), "rows_per_batch": float(rows.sum(axis=1).mean()),
-                "seed_feature_cache_hits_step0": counted.hits,
-                "roofline": roof,
-                "setup_seconds": setup_s,
-                "first_touch_state": {"form": "none per vertex: a hop's claims are de-duplicated bucket by bucket in LDS", "bytes_per_lane": state_bytes,
-                                      "lanes": G * args.slots, "lds_buckets_per_lane": lds_buckets},
-                "feature_cache_hit_rate": counted.feat_hit_rows / max(counted.feat_hit_rows + counted.feat_miss_rows, 1),
-                "feature_cache_hit_rate_over": "every timed batch" if args.placement == "pinned" else "the first timed step",
-            }
-            if args.hybrid and counted.tiers is not None:
-                t_cpu, t_gpu, t_miss = counted.tiers
-                pcie_gbps = t_cpu / max(t_cpu + t_gpu + t_miss, 1) * float(rows.sum() * D * 4) / t_all_gathers / 1e9 if t_all_gathers > 0 else 0.0
-                out["hybrid_tier"] = {"cpu_cache_rows": hy_cpu, "gpu_cache_rows": hy_gpu,
-                                      "rows_from_cpu_cache": t_cpu, "rows_from_gpu_cache": t_gpu, "rows_from_table": t_miss,
-                                      "rows_counted_over": "the first timed step",
-                                      "cpu_cache_GBps_over_pcie": pcie_gbps, "pcie_peak_GBps": 64.0,
-                                      "note": "UnifiedCache::HybridInit (SS/cache/cache.cu:614-670) instead of the cost model: the hottest "
-                                              "gpu_cache_rows of this GPU's own order in HBM, the next cpu_cache_rows in mapped pinned host memory "
-                                              "(read in place over PCIe inside the same gather launches), misses from the full table in HBM; "
-                                              "cpu_cache_GBps = CPU-cache rows x D x 4 / HIP-event time of all gather launches"}
-            if collective is not None:
-                out["collective"] = collective
-                out["per_rank"] = per_rank
-            if args.placement == "pinned":
-                miss_frac = counted.feat_miss_rows / max(counted.feat_hit_rows + counted.feat_miss_rows, 1)
-                miss_gbps = float(rows.sum() * D * 4) * miss_frac / t_all_gathers / 1e9 if t_all_gathers > 0 else 0.0
-                out["miss_path"] = {"feature_rows_missed_frac": miss_frac, "pcie_feature_GBps": miss_gbps,
-                                    "pcie_peak_GBps": 64.0, "frac_of_pcie_peak": miss_gbps / 64.0,
-                                    "note": "missed rows x D x 4 bytes / HIP-event time of all gather launches (hits are served from "
-                                            "HBM inside the same launches); PCIe Gen5 x16 = 64 GB/s per direction; topology misses "
-                                            "(4-byte column reads) cross the same link during the sampler kernels"}
+        here = locals()                      # (the report is assembled in tools/bench_legs.py from exactly the values it names)
+        out = legs.leg_report(types.SimpleNamespace(**{k: here[k] for k in legs.REPORT_NAMES}))
     # ---- the same launch alone and over rows that never repeat (a one-GPU run: the figure is about the kernel, not the job).  The
     #      headline's line exists by now: from here on it goes out even if an optional leg ends the process (a native exit() of the
     #      library, SIGTERM, a hang) -- this leg, the other shapes, the boundary, the CPU baseline and the traffic children follow. ----

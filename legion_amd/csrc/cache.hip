@@ -671,10 +671,11 @@ unsigned long long int* UnifiedCache::GetEdgeAccessedMap(int32_t dev_id)
 // SS/cache/cache.cu:726-748 -- lookup (FindFeat) fused into the gather
 void UnifiedCache::FeatCacheLookup(const LanePtrs* d_lanes, int32_t n_lanes, int32_t op_id, int32_t dev_id,
                                    hipStream_t strm_hdl, int32_t max_rows, bool use_snapshot, int32_t first_op_id, bool last_op,
-                                   bool skip_remote)
+                                   bool skip_remote, int32_t grid_rows)
 {
     lg::GatherParams g = GatherParamsOf(dev_id, op_id, max_rows, use_snapshot, first_op_id, last_op);
     g.skip_remote = skip_remote;
+    g.grid_rows = grid_rows;
     lg::launch_gather(strm_hdl, g, d_lanes, n_lanes);
 }
 
@@ -712,6 +713,7 @@ lg::GatherParams UnifiedCache::GatherParamsOf(int32_t dev_id, int32_t op_id, int
     g.D = float_feature_len_;
     g.total_num_nodes = total_num_nodes_;
     g.max_rows = max_rows;
+    g.grid_rows = 0;
     g.hop = use_snapshot ? op_id / INTRABATCH_CON : -1;
     g.first_hop = (use_snapshot && first_op_id >= 0 && first_op_id < op_id) ? first_op_id / INTRABATCH_CON : g.hop;
     g.last_op = last_op;

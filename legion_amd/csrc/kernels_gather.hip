@@ -388,18 +388,21 @@ static inline int32_t gather_grid_x(int32_t max_rows, int32_t rows_per_tile, int
 }
 
 template <int ROWS>
-static void launch_gather_v4(hipStream_t s, const GatherParams& g, const LanePtrs* d_lanes, int32_t n_lanes, bool copy_range)
+static void launch_gather_v4(hipStream_t s, const GatherParams& g, int32_t grid_rows, const LanePtrs* d_lanes, int32_t n_lanes, bool copy_range)
 {
     typedef float v4 __attribute__((ext_vector_type(4)));
-    const dim3 grid(gather_grid_x(g.max_rows, ROWS, n_lanes), n_lanes);
+    const dim3 grid(gather_grid_x(grid_rows, ROWS, n_lanes), n_lanes);
     if (g.last_op) gather_kernel<v4, ROWS, LG_GATHER_UNROLL, false, true><<<grid, LG_GATHER_THREADS, 0, s>>>(g, d_lanes, copy_range);
     else gather_kernel<v4, ROWS, LG_GATHER_UNROLL, false, false><<<grid, LG_GATHER_THREADS, 0, s>>>(g, d_lanes, copy_range);
 }
 
-static void launch_gather_impl(hipStream_t s, GatherParams g, const LanePtrs* d_lanes, int32_t n_lanes, bool copy_range)
+static void launch_gather_impl(hipStream_t s, GatherParams g_in, const LanePtrs* d_lanes, int32_t n_lanes, bool copy_range)
 {
-    if (g.D <= 0 || g.max_rows <= 0) return;            // :256 float_feature_len > 0
-    if (g.node_capacity < 1) g.node_capacity = 1;
+    if (g_in.D <= 0 || g_in.max_rows <= 0) return;      // :256 float_feature_len > 0
+    if (g_in.node_capacity < 1) g_in.node_capacity = 1;
+    const GatherParams& gk = g_in;                      // what the kernel gets: max_rows = the clamp
+    GatherParams g = g_in;                              // what sizes the launch: the rows a lane typically has (GatherParams.grid_rows)
+    if (g.grid_rows > 0 && g.grid_rows < g.max_rows) g.max_rows = g.grid_rows;
     const dim3 grid(gather_grid_x(g.max_rows, LG_GATHER_ROWS, n_lanes), n_lanes);     // (the 4-byte vector path, and 64-row tiles at dword alignment)
     const LegionTuning& tune = tuning();
     if (g.D % 4 == 0) {
@@ -420,11 +423,11 @@ static void launch_gather_impl(hipStream_t s, GatherParams g, const LanePtrs* d_
             if ((int64_t)((g.max_rows + rows - 1) / rows) * n_lanes < 4096) rows = 16;      // (a launch of few tiles: 4 x the workgroups)
         }
         switch (rows) {
-            case 16: launch_gather_v4<16>(s, g, d_lanes, n_lanes, copy_range); break;
-            case 32: launch_gather_v4<32>(s, g, d_lanes, n_lanes, copy_range); break;
-            case 128: launch_gather_v4<128>(s, g, d_lanes, n_lanes, copy_range); break;
-            case 256: launch_gather_v4<256>(s, g, d_lanes, n_lanes, copy_range); break;
-            default: launch_gather_v4<64>(s, g, d_lanes, n_lanes, copy_range); break;
+            case 16: launch_gather_v4<16>(s, gk, g.max_rows, d_lanes, n_lanes, copy_range); break;
+            case 32: launch_gather_v4<32>(s, gk, g.max_rows, d_lanes, n_lanes, copy_range); break;
+            case 128: launch_gather_v4<128>(s, gk, g.max_rows, d_lanes, n_lanes, copy_range); break;
+            case 256: launch_gather_v4<256>(s, gk, g.max_rows, d_lanes, n_lanes, copy_range); break;
+            default: launch_gather_v4<64>(s, gk, g.max_rows, d_lanes, n_lanes, copy_range); break;
         }
     } else if (g.D > 4) {
         // rows that are not multiples of 16 bytes (D = 602: 2408-byte rows): 16-byte chunks at dword alignment + a scalar
@@ -433,14 +436,14 @@ static void launch_gather_impl(hipStream_t s, GatherParams g, const LanePtrs* d_
         const bool small = (int64_t)((g.max_rows + LG_GATHER_ROWS - 1) / LG_GATHER_ROWS) * n_lanes < 4096;
         const bool r16 = small || (int64_t)g.D * 4 * 64 > 65536;
         const dim3 gr = r16 ? dim3(gather_grid_x(g.max_rows, 16, n_lanes), n_lanes) : grid;
-        if (r16 && g.last_op) gather_kernel<v4u, 16, LG_GATHER_UNROLL, true, true><<<gr, LG_GATHER_THREADS, 0, s>>>(g, d_lanes, copy_range);
-        else if (r16) gather_kernel<v4u, 16, LG_GATHER_UNROLL, true, false><<<gr, LG_GATHER_THREADS, 0, s>>>(g, d_lanes, copy_range);
-        else if (g.last_op) gather_kernel<v4u, LG_GATHER_ROWS, LG_GATHER_UNROLL, true, true><<<gr, LG_GATHER_THREADS, 0, s>>>(g, d_lanes, copy_range);
-        else gather_kernel<v4u, LG_GATHER_ROWS, LG_GATHER_UNROLL, true, false><<<gr, LG_GATHER_THREADS, 0, s>>>(g, d_lanes, copy_range);
+        if (r16 && g.last_op) gather_kernel<v4u, 16, LG_GATHER_UNROLL, true, true><<<gr, LG_GATHER_THREADS, 0, s>>>(gk, d_lanes, copy_range);
+        else if (r16) gather_kernel<v4u, 16, LG_GATHER_UNROLL, true, false><<<gr, LG_GATHER_THREADS, 0, s>>>(gk, d_lanes, copy_range);
+        else if (g.last_op) gather_kernel<v4u, LG_GATHER_ROWS, LG_GATHER_UNROLL, true, true><<<gr, LG_GATHER_THREADS, 0, s>>>(gk, d_lanes, copy_range);
+        else gather_kernel<v4u, LG_GATHER_ROWS, LG_GATHER_UNROLL, true, false><<<gr, LG_GATHER_THREADS, 0, s>>>(gk, d_lanes, copy_range);
     } else if (g.last_op)
-        gather_kernel<float><<<grid, LG_GATHER_THREADS, 0, s>>>(g, d_lanes, copy_range);
+        gather_kernel<float><<<grid, LG_GATHER_THREADS, 0, s>>>(gk, d_lanes, copy_range);
     else
-        gather_kernel<float, LG_GATHER_ROWS, LG_GATHER_UNROLL, false, false><<<grid, LG_GATHER_THREADS, 0, s>>>(g, d_lanes, copy_range);
+        gather_kernel<float, LG_GATHER_ROWS, LG_GATHER_UNROLL, false, false><<<grid, LG_GATHER_THREADS, 0, s>>>(gk, d_lanes, copy_range);
     hipCheckError();
 }
 

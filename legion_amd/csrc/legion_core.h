@@ -315,6 +315,7 @@ public:
     int32_t batch_size = 0;
     int32_t float_feature_len = 0;
     int64_t feature_rows = 0;
+    int64_t grid_rows_hint = 0;        // > 0: rows a batch typically has (the Runner's pipe-slot pool holds the worst case: launches are sized for the usual one)
     int32_t dev_id = 0;
     bool owns_buffers = false;
 
@@ -506,7 +507,7 @@ public:
     // first_op_id < op_id: one launch also covers the new-node ranges of the earlier ops first_op_id, +3, ...
     void FeatCacheLookup(const LanePtrs* d_lanes, int32_t n_lanes, int32_t op_id, int32_t dev_id,
                          hipStream_t strm_hdl, int32_t max_rows, bool use_snapshot, int32_t first_op_id = -1, bool last_op = true,
-                         bool skip_remote = false);
+                         bool skip_remote = false, int32_t grid_rows = 0);
     // peer_gather = bulk (lg::BulkLists): the requester's bucket pass over every row of its group's batches, and the owner's push
     void BulkBucket(const LanePtrs* d_lanes, int32_t n_lanes, int32_t op_id, int32_t dev_id, hipStream_t s, int32_t max_rows,
                     const lg::BulkLists& lists, const char* arena_base);
@@ -750,7 +751,9 @@ struct GatherParams {
     int32_t node_capacity;
     int32_t D;
     int32_t total_num_nodes;
-    int32_t max_rows;               // grid bound: rows any lane can have for this op
+    int32_t max_rows;               // rows any lane can have for this op: the kernel never gathers more (and the grid covers them, unless ...)
+    int32_t grid_rows;              // ... > 0: the rows a lane TYPICALLY has: the grid is sized for these (the workgroups walk a lane's tiles, so a
+                                    // lane with more rows -- up to max_rows -- is still gathered whole); 0: size the grid for max_rows
     int32_t hop;                    // >= 0: take the range from hop_scratch[HS_RANGE + 2*hop] (snapshot that later
                                     // hops do not overwrite, so the gather may run beside the next hop); < 0: node_counter[0..1]
     int32_t first_hop;              // with hop >= 0: also gather the ranges of hops first_hop .. hop-1 (they are adjacent in

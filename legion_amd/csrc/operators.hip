@@ -156,7 +156,7 @@ static void do_feature_lookup(hipStream_t s, UnifiedCache* cache, const LanePtrs
     const bool prof = pp->prof_on && (size_t)(2 * pp->prof_used + 1) < pp->prof_events.size();
     if (prof) HIP_CALL(hipEventRecord(pp->prof_events[2 * pp->prof_used], s));
     cache->FeatCacheLookup(d_lanes, n_lanes, op_id, dev_id, s, (int32_t)max_rows, use_snapshot, first_op_id,
-                           hop + 1 >= pool0->max_new.size());
+                           hop + 1 >= pool0->max_new.size(), false, (int32_t)std::min<int64_t>(pool0->grid_rows_hint, max_rows));
     if (prof) {
         HIP_CALL(hipEventRecord(pp->prof_events[2 * pp->prof_used + 1], s));
         pp->prof_op[pp->prof_used] = op_id;
@@ -332,6 +332,7 @@ extern "C" void legion_gather_rows(legion_stream_t stream, const float* full_tab
     g.node_capacity = node_capacity;
     g.D = float_feature_len;
     g.skip_remote = false;
+    g.grid_rows = 0;
     g.hybrid = false;
     g.hybrid_cpu_cap = g.hybrid_gpu_cap = 0;
     g.hybrid_cpu_cache = nullptr;

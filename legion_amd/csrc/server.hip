@@ -442,6 +442,7 @@ public:
         for (int i = 0; i < interbatch_concurrency_; i++)
             memorypool_->SetFloatFeatures(env->GetFloatFeatures(local_dev_id_, i), i);
         memorypool_->feature_rows = slot_rows;
+        memorypool_->grid_rows_hint = num_ids;      // launches into the pipe slots are sized for the usual batch, not for the buffers' worst case
         // from here on every batch's counters are also written to the slab's host-visible mirror (lane-group path)
         if (use_groups_ && env->GetCounterMirror(local_dev_id_, 0) != nullptr) env->PublishMirror();
     }
@@ -572,7 +573,7 @@ public:
             const LanePtrs* desc = d_desc_ + ((size_t)p * slots_ + g.slot) * lanes_ + lane;     // lane -> pipe slot p
             UnifiedCache* cache = (UnifiedCache*)(params->cache);
             if (float_feature_len_ > 0 && max_rows > 0)   // one launch: gather of every row of the batch + the hand-over copies
-                cache->FeatCacheLookup(desc, 1, INTRABATCH_CON * hop_num_ + 1, local_dev_id_, s, (int32_t)max_rows, true, 1);
+                cache->FeatCacheLookup(desc, 1, INTRABATCH_CON * hop_num_ + 1, local_dev_id_, s, (int32_t)max_rows, true, 1, true, false, lane_rule_rows_);
             else
                 lg::launch_deliver(s, desc, deliver_[p]);
             HIP_CALL(hipEventRecord(batch_done_[p], s));
