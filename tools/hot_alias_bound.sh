@@ -1,4 +1,5 @@
 #!/bin/bash
+# Upper bound of reading every hot row once: variant builds from tools/experiments/hot_alias.patch (tools/experiments/README.md) against the product library.
 R=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$R/gpurun_out/r06/hot_alias_bound.txt
 mkdir -p $R/gpurun_out/r06

@@ -1,6 +1,7 @@
 #!/bin/bash
 # A/B of variant builds in which the gather loads rows that are unlikely to repeat inside a launch (hotness rank >= K, or table misses)
 # with the non-temporal hint (they then bypass the Infinity Cache and leave it to the rows that do repeat), against the product library.
+# Variant builds: tools/experiments/nt_cold.patch (tools/experiments/README.md).
 R=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$R/gpurun_out/r06/nt_cold_ab.txt
 mkdir -p $R/gpurun_out/r06; : > $OUT
