@@ -102,6 +102,27 @@ def test_scale_command_line_two_ranks_on_one_gpu(hip, stripe):
     assert 0.7 < d["edges_per_step"] / d1["edges_per_step"] < 1.4
 
 
+def test_scale_command_line_four_ranks_on_one_gpu(hip):
+    """The same command line at N = 4 (a GPU box admits six processes on its card): the caches striped over a clique of FOUR ranks
+    (cache_agg_mode 2), stripes exchanged as IPC handles between four processes, the bulk leg's arenas mapped from file descriptors
+    across four processes -- every leg completes and agrees with the others on what was gathered."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "4", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "4", "--backend", "gloo", "--force-device", "0"] + SMALL
+    res = subprocess.run(cmd, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+    assert res.returncode == 0, res.stderr[-4000:]
+    d = _last_json(res.stdout)
+    assert d["n_gpus"] == 4 and d["value"] > 0 and "extra_legs_error" not in d
+    assert d["collective"]["world_size_seen_by_all_reduce"] == 4 and [r["rank"] for r in d["per_rank"]] == [0, 1, 2, 3]
+    for k in ("striped", "striped_replica", "striped_bulk"):
+        assert d[k]["value"] > 0 and "cache_agg_mode 2" in d[k]["parallelism"] and len(d[k]["per_rank"]) == 4, k
+    for a, b, r in zip(d["striped"]["per_rank"], d["striped_bulk"]["per_rank"], d["striped_replica"]["per_rank"]):
+        assert a["rows_from_peer_stripes"] > 0 and b["bulk"]["rows_pushed_into_me_per_region"] == a["rows_from_peer_stripes"]
+        assert r["rows_from_peer_stripes"] < a["rows_from_peer_stripes"]
+    # three quarters of the hit rows of a 4-way striped clique live on the other members
+    for a in d["striped"]["per_rank"]:
+        assert a["rows_from_peer_stripes"] > 2 * a["rows_from_own_stripe"] * 0.8
+
+
 @pytest.mark.parametrize("how", ["raise", "exit", "sigterm", "hang"])
 def test_headline_line_survives_a_failing_extra_leg(hip, how):
     """N > 1: the striped legs run after the headline leg; if one of them ends rank 0 -- a Python error, a native exit() of the
